@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tokens/sec + achieved-HBM-bandwidth fraction on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one decoded token: one pass of the hot path (Forward, go/model.go:490-620
+restated as HIP kernels) plus the greedy argmax, chained on the device.
+
+  N = 1 : BASELINE.json configs[1] -- nano (89M) Q8_0, single-stream greedy decode.
+  N > 1 : BASELINE.json configs[4] -- big (7.9B) Q4_0, tensor-parallel over N GPUs
+          (one process per GPU, RCCL all-reduce after WO and down), strong scaling.
+
+Weights are a deterministic random-weight GGUF written on the box in the
+reference exporter's layout (nanollama_amd.synth); inputs are resident in HBM
+before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from nanollama_amd import gguf, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROMPT_LEN = 8
+SEGMENT = 128  # greedy 128-token decode (BASELINE.json configs)
+
+
+def kernel_bytes(shape: synth.ModelShape, wtype: str, pos: int, tp: int = 1):
+    """Algorithmic HBM bytes per LAUNCH of each kernel kind:
+    every weight byte once + the vectors the kernel must read/write."""
+    t = synth.WTYPES[wtype]
+    bpe = gguf.ggml_block_size(t) / gguf.ggml_block_elements(t)
+    d, i, v, kv, hd = shape.dim, shape.ffn // tp, shape.vocab // tp, shape.kv_dim // tp, shape.head_dim
+    hq = shape.n_head // tp * hd
+    return {
+        "embed": d * bpe + d * 4,
+        "qkv_rope": (hq + 2 * kv) * d * bpe + 2 * d * 4 + (hq + 2 * kv) * 4,
+        "attention": (pos + 1) * kv * 2 * 4 + hq * 4 * 2,
+        "wo_resid": d * hq * bpe + hq * 4 + 2 * d * 4,
+        "gate_up_swiglu": 2 * i * d * bpe + 2 * d * 4 + i * 4,
+        "down_resid": d * i * bpe + i * 4 + 2 * d * 4,
+        "lm_head": v * d * bpe + 2 * d * 4 + v * 4,
+        "argmax": shape.vocab * 4,
+    }
+
+
+def ensure_gguf(shape, wtype, mode, rank=0):
+    path = os.path.join(os.environ.get("NL_BENCH_DIR", "/tmp"), f"nl_bench_{shape.name}_{wtype}_{mode}.gguf")
+    if rank == 0 and not os.path.exists(path):
+        t0 = time.time()
+        tmp = path + ".tmp"
+        synth.generate_gguf(tmp, shape, wtype, mode=mode)
+        os.replace(tmp, path)
+        print(f"[bench] wrote {path} ({os.path.getsize(path) / 1e6:.1f} MB) in {time.time() - t0:.1f}s", file=sys.stderr)
+    return path
+
+
+def cpu_baseline(path, prompt, budget_s=20.0):
+    """The Go engine's algorithm (C restatement, oracle/) timed on this box's
+    host cores on a bounded sample of the same workload.  Reported, not optimised against."""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    oracle.set_threads(cores)
+    m = oracle.OracleModel(gguf.load_gguf(path))
+    pos = 0
+    for t in prompt:
+        m.forward(t, pos)
+        pos += 1
+    nxt = oracle.argmax(m.logits())
+    n, t0 = 0, time.perf_counter()
+    while n < SEGMENT and (time.perf_counter() - t0) < budget_s:   # timer after prefill, go/main.go:171
+        m.forward(nxt, pos)
+        nxt = oracle.argmax(m.logits())
+        pos += 1
+        n += 1
+    dt = time.perf_counter() - t0
+    m.close()
+    return {"value": round(n / dt, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{n} greedy decode tokens after an {len(prompt)}-token prefill, same GGUF, "
+                      f"C restatement of go/quant.go+go/model.go with the Go row partition on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--workload", default=None, help="tier:wtype override, e.g. big:q4_0 (default by --gpus)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-pos", type=int, default=PROMPT_LEN + SEGMENT // 2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = args.gpus
+    if world != n and world != 1:
+        raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}")
+
+    if args.workload:
+        tier, wtype = args.workload.split(":")
+    else:
+        tier, wtype = ("nano", "q8_0") if n == 1 else ("big", "q4_0")
+    shape = synth.TIERS[tier]
+    mode = "qrand" if tier in ("big", "goldie") else "float"
+
+    # the product library is loaded before torch so it binds /opt/rocm's HIP runtime
+    from nanollama_amd import _lib, model
+    _lib.lib()
+
+    dist = None
+    comm_id = None
+    if world > 1:
+        import torch.distributed as dist  # gloo: host-side rendezvous only; the data path is RCCL inside the library
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        box = [model.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm_id = box[0]
+
+    path = ensure_gguf(shape, wtype, mode, rank)
+    if dist:
+        dist.barrier()
+    g = gguf.load_gguf(path)
+    dev = model.load_llama_model(g, device=local_rank, tp_rank=rank if world > 1 else 0, tp_size=world,
+                                 comm_id=comm_id)
+    prompt = synth.prompt_ids(PROMPT_LEN, shape.vocab)
+
+    def prefill():
+        pos = 0
+        for t in prompt:
+            dev.forward(t, pos)
+            pos += 1
+        return int(np.argmax(dev.state.logits)), pos
+
+    def run_steps(k, first, pos0):
+        """k chained decode steps in segments of SEGMENT tokens; every segment restarts at pos0 on
+        the still-valid prompt prefix of the KV cache, so no prefill is inside the loop."""
+        done, ids = 0, []
+        while done < k:
+            seg = min(SEGMENT, k - done)
+            ids = dev.decode_greedy(first, pos0, seg)
+            done += seg
+        return ids
+
+    first, pos0 = prefill()
+    run_steps(args.warmup, first, pos0)
+    dev.synchronize()
+    if dist:
+        dist.barrier()
+    dev.timer_start()
+    t0 = time.perf_counter()
+    ids = run_steps(args.steps, first, pos0)
+    dev.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    ev_ms = dev.timer_stop()
+    if dist:
+        dist.barrier()
+        import torch
+        tmax = torch.tensor([wall_ms], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall_ms = float(tmax.item())
+
+    ms_per_step = wall_ms / args.steps
+    tok_s = args.steps / (wall_ms / 1e3)
+
+    # per-kernel device time (HIP events on the engine's stream, eager launches) at a mid-run position
+    ppos = min(args.profile_pos, shape.seq_len - 1)
+    prof = dev.profile_forward(first, ppos, iters=20)
+    kb = kernel_bytes(shape, wtype, ppos, tp=world)
+    kernels = {}
+    for kind, (ms, calls) in prof.items():
+        if calls:
+            per = ms / calls
+            kernels[kind] = {"launches": calls, "us_per_launch": round(per * 1e3, 3),
+                             "GBps": round(kb[kind] / (per * 1e-3) / 1e9, 1)}
+    dom = max((k for k in kernels if k != "argmax"), key=lambda k: prof[k][0])
+    dom_gbs = kernels[dom]["GBps"]
+    mean_pos = pos0 + (min(SEGMENT, args.steps) - 1) / 2.0
+    step_bytes = (synth.weight_bytes_per_token(shape, wtype) + synth.kv_bytes_per_token(shape, int(mean_pos)))
+    step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
+
+    out = {
+        "metric": f"decode tokens/sec, {tier} {wtype.upper()} single-stream greedy"
+                  + (f", tensor-parallel over {world} GPUs" if world > 1 else ""),
+        "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (random-weight GGUF, reference exporter layout, nanollama_amd.synth)",
+        "config": {"workload": f"{tier} ({shape.matrix_params() / 1e6:.0f}M matrix params) {wtype.upper()} GGUF, "
+                               f"{PROMPT_LEN}-token prompt + {SEGMENT}-token greedy decode segments, 1 stream",
+                   "parallelism": f"tp{world}" if world > 1 else "single-gpu",
+                   "weights": f"{wtype} blocks dequantised in-register, f32 activations and KV cache"},
+        "device_ms_per_step": round(ev_ms / args.steps, 5),
+        "hbm_frac_whole_step": round(step_gbs / (HBM_PEAK_GBS * max(world, 1)), 4),
+        "algorithmic_bytes_per_step": int(step_bytes),
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                     "bytes_per_launch": int(kb[dom]), "us_per_launch": kernels[dom]["us_per_launch"]},
+        "kernels": kernels,
+        "last_ids": ids[-4:],
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(path, prompt)
+    dev.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+/*
+ * nanollama_hip.h -- C ABI of libnanollama_hip.so, the MI355X (gfx950) engine
+ * behind the nanollama Go inference surface.
+ *
+ * The reference (ariannamethod/nanollama, go/) is single-package pure Go with
+ * no FFI; the seams this ABI replaces are the three methods the Go host calls
+ * on its model object:
+ *
+ *   LoadLlamaModel(gguf)            go/model.go:121   -> nl_create + nl_upload_tensor* + nl_finalize
+ *   (*LlamaModel).Forward(tok,pos)  go/model.go:490   -> nl_forward   (fills the caller's Logits slice)
+ *   (*LlamaModel).Reset()           go/model.go:623   -> nl_reset
+ *   argmax(State.Logits)            go/main.go:400    -> nl_forward_argmax / nl_decode_greedy (greedy fast path)
+ *
+ * Conventions: every function returns 0 on success or a negative nl_status;
+ * nl_last_error(h) gives the message.  No exceptions cross the boundary, no
+ * caller pointer is retained after a call returns (cgo pointer rule), all
+ * sizes are explicit.  A handle is single-caller / non-reentrant, like the Go
+ * engine (one Engine per process, HTTP handler under a mutex, go/serve.go:56).
+ * One process drives one GPU; tensor-parallel runs are one process per GPU
+ * (tp_rank / tp_size) joined by an RCCL communicator (nl_comm_*).
+ */
+#ifndef NANOLLAMA_HIP_H
+#define NANOLLAMA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NL_API __attribute__((visibility("default")))
+
+typedef struct nl_engine *nl_handle;
+
+typedef enum {
+    NL_OK = 0,
+    NL_ERR_INVALID = -1,      /* bad argument / shape */
+    NL_ERR_UNSUPPORTED = -2,  /* tensor type or feature not implemented on device */
+    NL_ERR_HIP = -3,          /* HIP runtime error (message has the hipError string) */
+    NL_ERR_STATE = -4,        /* call order violated (e.g. forward before finalize) */
+    NL_ERR_MISSING = -5,      /* a required tensor was never uploaded */
+    NL_ERR_COMM = -6          /* RCCL failure */
+} nl_status;
+
+/* ggml tensor types accepted by nl_upload_tensor (go/gguf.go:43-57). */
+enum { NL_GGML_F32 = 0, NL_GGML_F16 = 1, NL_GGML_Q4_0 = 2, NL_GGML_Q8_0 = 8 };
+
+/* Mirrors LlamaConfig (go/model.go:27-42) + placement.  head_dim == 0 means
+ * dim / n_heads (go/model.go:140-142); seq_len is capped to 2048 exactly as
+ * go/model.go:145-148 does. */
+typedef struct {
+    int32_t n_layers, dim, n_heads, n_kv_heads, head_dim, interm, vocab, seq_len;
+    float rms_eps, rope_theta;
+    int32_t qk_norm, rope_conjugate;
+    int32_t max_streams; /* independent KV caches (decode streams); 0 -> 1 */
+    int32_t device;      /* HIP device ordinal of this process */
+    int32_t tp_rank, tp_size; /* tensor-parallel shard; tp_size 0/1 -> single GPU */
+    int32_t flags;       /* NL_FLAG_* */
+} nl_config;
+
+#define NL_FLAG_NO_GRAPH 1 /* launch kernels eagerly instead of replaying a hipGraph */
+
+/* Library / device probes (no handle, no device work for nl_abi_version). */
+NL_API int nl_abi_version(void);
+NL_API int nl_device_count(void);
+
+/* == LoadLlamaModel (go/model.go:121-174) ================================== */
+NL_API int nl_create(const nl_config *cfg, nl_handle *out);
+/* loadWeights (go/model.go:177-265): one call per GGUF tensor, by its GGUF
+ * name, with the FULL tensor as stored in the file (raw block bytes, rows x
+ * cols in row-major [out,in] order; 1-D tensors: rows = 1).  The bytes are
+ * copied during the call; the library re-packs them for the device and keeps
+ * only this rank's tensor-parallel shard.  Unknown names -> NL_ERR_INVALID,
+ * unsupported types -> NL_ERR_UNSUPPORTED (the Go engine would print a WARNING
+ * and compute garbage, go/model.go:383-385; we refuse instead). */
+NL_API int nl_upload_tensor(nl_handle h, const char *gguf_name, uint32_t ggml_type, const void *data,
+                            uint64_t nbytes, uint64_t rows, uint64_t cols);
+/* allocState + precomputeRoPE (go/model.go:324-358), tied-embedding fallback
+ * (:195-201), graph capture.  NL_ERR_MISSING if a required tensor is absent. */
+NL_API int nl_finalize(nl_handle h);
+NL_API int nl_destroy(nl_handle h);
+NL_API const char *nl_last_error(nl_handle h); /* h may be NULL: last create error */
+
+/* == Reset (go/model.go:623-631) ========================================== */
+/* O(1): positions >= the next pos are never read, so no memset is needed. */
+NL_API int nl_reset(nl_handle h, int stream);
+
+/* == Forward (go/model.go:490-620) ======================================== */
+/* One token through all layers at position pos of KV stream `stream`;
+ * logits_out receives `vocab` floats (caller-owned, e.g. the Go State.Logits
+ * slice).  Synchronous on return. */
+NL_API int nl_forward(nl_handle h, int stream, int token, int pos, float *logits_out);
+/* Forward + argmax (strict '>' => lowest index wins ties, go/main.go:400-408)
+ * without moving the logits to the host. */
+NL_API int nl_forward_argmax(nl_handle h, int stream, int token, int pos, int *next_id);
+/* The greedy decode loop of Engine.Generate (go/main.go:173-219 with temp 0,
+ * rep-penalty 1.0) chained on the device: feeds `token` at `pos`, then each
+ * sampled id back in, n_steps times, with no host round trip in between.
+ * ids_out[i] is the id sampled after step i.  Stops early (returning the
+ * count in *n_done) when pos reaches seq_len, as go/main.go:216 does. */
+NL_API int nl_decode_greedy(nl_handle h, int stream, int token, int pos, int n_steps, int *ids_out, int *n_done);
+
+/* == introspection / measurement ========================================== */
+NL_API int nl_get_config(nl_handle h, nl_config *out); /* effective config (after seq_len cap etc.) */
+NL_API int nl_synchronize(nl_handle h);
+/* HIP events recorded on the engine's own stream (torch.cuda.Event would not
+ * see it): start/stop bracket any sequence of calls; elapsed in milliseconds. */
+NL_API int nl_timer_start(nl_handle h);
+NL_API int nl_timer_stop(nl_handle h, float *ms);
+/* Per-kernel-kind device time of one eager Forward (events around every
+ * launch).  kinds: see nl_kernel_kind_name.  ms_out/calls_out have NL_NUM_KINDS
+ * entries. */
+#define NL_NUM_KINDS 8
+NL_API const char *nl_kernel_kind_name(int kind);
+NL_API int nl_profile_forward(nl_handle h, int stream, int token, int pos, int iters, float *ms_out, int *calls_out);
+/* Device bytes held by the handle (weights, KV, state). */
+NL_API int nl_memory_usage(nl_handle h, uint64_t *weights, uint64_t *kv_cache, uint64_t *state);
+/* Read back a device state buffer for tests ("x","q","xb2","hb","logits",
+ * "k_cache","v_cache"); returns floats copied (<= max_floats). */
+NL_API int64_t nl_debug_read(nl_handle h, const char *which, int stream, float *out, int64_t max_floats);
+
+/* == op-level entry points (parity tests of single kernels) =============== */
+/* matmulDispatch (go/model.go:361-386): out[rows] = W[rows,cols] @ x[cols],
+ * W given as raw GGUF block bytes; x/out are host pointers.  Uses the same
+ * re-pack + GEMV kernel as Forward. */
+NL_API int nl_op_matmul(int device, uint32_t ggml_type, const void *w, uint64_t nbytes, const float *x, float *out,
+                        int rows, int cols);
+/* RMSNormInto (go/quant.go:597-607). */
+NL_API int nl_op_rmsnorm(int device, const float *x, const float *w, float eps, float *out, int n);
+
+/* == tensor-parallel communicator (RCCL over xGMI) ========================= */
+#define NL_COMM_ID_BYTES 128
+/* Rank 0 obtains an id, the host distributes it (any side channel), every
+ * rank passes it to nl_comm_init before nl_finalize. */
+NL_API int nl_comm_get_unique_id(void *id_out /* NL_COMM_ID_BYTES */);
+NL_API int nl_comm_init(nl_handle h, const void *id /* NL_COMM_ID_BYTES */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NANOLLAMA_HIP_H */

@@ -1,0 +1,98 @@
+"""ctypes binding of libnanollama_hip.so (include/nanollama_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no GPU is
+visible, loading / creating a model raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnanollama_hip.so")
+NL_NUM_KINDS = 8
+NL_COMM_ID_BYTES = 128
+NL_FLAG_NO_GRAPH = 1
+
+STATUS = {0: "NL_OK", -1: "NL_ERR_INVALID", -2: "NL_ERR_UNSUPPORTED", -3: "NL_ERR_HIP", -4: "NL_ERR_STATE",
+          -5: "NL_ERR_MISSING", -6: "NL_ERR_COMM"}
+
+
+class NlConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_layers", "dim", "n_heads", "n_kv_heads", "head_dim", "interm", "vocab",
+                                         "seq_len")] + \
+               [("rms_eps", C.c_float), ("rope_theta", C.c_float)] + \
+               [(n, C.c_int32) for n in ("qk_norm", "rope_conjugate", "max_streams", "device", "tp_rank", "tp_size",
+                                         "flags")]
+
+
+class NlError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in ("nl_engine.hip", "nl_kernels.h")] + \
+           [os.path.join(os.path.dirname(_HERE), "include", "nanollama_hip.h")]
+    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", src_dir] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+EXPORTS = ["nl_abi_version", "nl_device_count", "nl_create", "nl_upload_tensor", "nl_finalize", "nl_destroy",
+           "nl_last_error", "nl_reset", "nl_forward", "nl_forward_argmax", "nl_decode_greedy", "nl_get_config",
+           "nl_synchronize", "nl_timer_start", "nl_timer_stop", "nl_kernel_kind_name", "nl_profile_forward",
+           "nl_memory_usage", "nl_debug_read", "nl_op_matmul", "nl_op_rmsnorm", "nl_comm_get_unique_id",
+           "nl_comm_init"]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the engine has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, fp, ip = C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)
+    L.nl_abi_version.restype = i32
+    L.nl_device_count.restype = i32
+    L.nl_create.argtypes = [C.POINTER(NlConfig), C.POINTER(vp)]
+    L.nl_upload_tensor.argtypes = [vp, C.c_char_p, C.c_uint32, vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.nl_finalize.argtypes = [vp]
+    L.nl_destroy.argtypes = [vp]
+    L.nl_last_error.restype = C.c_char_p
+    L.nl_last_error.argtypes = [vp]
+    L.nl_reset.argtypes = [vp, i32]
+    L.nl_forward.argtypes = [vp, i32, i32, i32, fp]
+    L.nl_forward_argmax.argtypes = [vp, i32, i32, i32, ip]
+    L.nl_decode_greedy.argtypes = [vp, i32, i32, i32, i32, ip, ip]
+    L.nl_get_config.argtypes = [vp, C.POINTER(NlConfig)]
+    L.nl_synchronize.argtypes = [vp]
+    L.nl_timer_start.argtypes = [vp]
+    L.nl_timer_stop.argtypes = [vp, fp]
+    L.nl_kernel_kind_name.restype = C.c_char_p
+    L.nl_kernel_kind_name.argtypes = [i32]
+    L.nl_profile_forward.argtypes = [vp, i32, i32, i32, i32, fp, ip]
+    L.nl_memory_usage.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 3
+    L.nl_debug_read.restype = C.c_int64
+    L.nl_debug_read.argtypes = [vp, C.c_char_p, i32, fp, C.c_int64]
+    L.nl_op_matmul.argtypes = [i32, C.c_uint32, vp, C.c_uint64, fp, fp, i32, i32]
+    L.nl_op_rmsnorm.argtypes = [i32, fp, fp, C.c_float, fp, i32]
+    L.nl_comm_get_unique_id.argtypes = [vp]
+    L.nl_comm_init.argtypes = [vp, vp]
+    _lib = L
+    return L
+
+
+def check(handle, rc: int):
+    if rc != 0:
+        msg = lib().nl_last_error(handle)
+        raise NlError(rc, msg.decode() if msg else "")

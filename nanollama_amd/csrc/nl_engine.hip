@@ -1,0 +1,964 @@
+// nl_engine.hip -- host side of libnanollama_hip.so: weight upload / re-pack,
+// state + KV-cache allocation, the per-token launch plan (hipGraph), and the
+// extern "C" entry points declared in include/nanollama_hip.h.
+//
+// Reference being replaced (ariannamethod/nanollama): LoadLlamaModel
+// go/model.go:121-174, loadWeights :177-265, allocState :324-343,
+// precomputeRoPE :346-358, Forward :490-620, Reset :623-631, argmax
+// go/main.go:400-408.  There is no CPU fallback in this library: without a
+// HIP device every entry point that computes returns NL_ERR_HIP.
+#include "../../include/nanollama_hip.h"
+#include "nl_kernels.h"
+
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+using namespace nl;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum Kind { K_EMBED = 0, K_QKV, K_ATTN, K_WO, K_GATEUP, K_DOWN, K_LMHEAD, K_ARGMAX };
+const char *kKindNames[NL_NUM_KINDS] = {"embed", "qkv_rope", "attention", "wo_resid", "gate_up_swiglu",
+                                        "down_resid", "lm_head", "argmax"};
+
+struct PackedMat {
+    uint8_t *q = nullptr;
+    uint32_t *s = nullptr;
+    int wtype = -1, rows = 0, cols = 0, ntiles = 0, npairs = 0;
+    size_t q_bytes = 0, s_bytes = 0;
+    bool ready = false;
+};
+
+int chunks_per_pair(int wt) { return wt == WT_Q8_0 ? 4 : wt == WT_Q4_0 ? 2 : wt == WT_F16 ? 8 : 16; }
+bool is_scaled(int wt) { return wt == WT_Q8_0 || wt == WT_Q4_0; }
+bool type_supported(uint32_t t) { return t == WT_F32 || t == WT_F16 || t == WT_Q4_0 || t == WT_Q8_0; }
+size_t raw_bytes(uint32_t t, uint64_t nel) {
+    switch (t) {
+    case WT_F32: return nel * 4;
+    case WT_F16: return nel * 2;
+    case WT_Q4_0: return nel / 32 * 18;
+    case WT_Q8_0: return nel / 32 * 34;
+    default: return 0;
+    }
+}
+
+// --- RCCL, bound lazily so single-GPU use never loads it ---------------------
+struct NcclId { char internal[128]; };
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(NcclId *) = nullptr;
+    int (*CommInitRank)(void **, int, NcclId, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load(std::string &err) {
+        if (lib) return true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("dlopen librccl failed: ") + dlerror(); return false; }
+        GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+        AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+        AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !AllReduce || !AllGather || !CommDestroy) {
+            err = "librccl is missing required symbols";
+            return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;
+constexpr int kNcclFloat = 7, kNcclSum = 0;
+
+struct Op {
+    int kind;
+    int coll;  // 0 none, 1 all-reduce(sum) of buf[count], 2 all-gather into buf (count per rank)
+    float *buf;
+    size_t count;
+    std::function<hipError_t(hipStream_t)> fn;
+};
+
+}  // namespace
+
+struct nl_engine {
+    nl_config cfg{};
+    std::string err;
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool finalized = false;
+
+    // shard dimensions (== full dimensions when tp_size == 1)
+    int G = 1, rank = 0;
+    int Hs = 0, KVs = 0, Is = 0, Vs = 0, hd = 0, gqa = 1;
+    int nsplit_max = 1;
+
+    struct Layer {
+        PackedMat qkv, wo, gate, up, down;
+        float *attn_norm = nullptr, *ffn_norm = nullptr;
+        bool have_q = false, have_k = false, have_v = false;
+    };
+    std::vector<Layer> layers;
+    PackedMat lm_head;
+    uint8_t *embd_raw = nullptr;
+    int embd_type = -1;
+    size_t embd_bytes = 0;
+    bool have_output = false;
+    float *output_norm = nullptr;
+    // kept so a tied LM head can be packed at finalize
+    std::vector<uint8_t> embd_host;
+
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    float *x[2] = {nullptr, nullptr};
+    float *qbuf = nullptr, *part_o = nullptr, *part_ml = nullptr, *hb = nullptr, *ar = nullptr, *logits = nullptr;
+    float *kcache = nullptr, *vcache = nullptr;
+    long long kv_layer_stride = 0, kv_stream_stride = 0;
+    int *ctl = nullptr, *ids = nullptr, *result = nullptr;
+    int *h_ctl = nullptr;  // pinned staging
+    int ids_cap = 0;
+    size_t bytes_weights = 0, bytes_kv = 0, bytes_state = 0;
+
+    std::vector<Op> plan;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool use_graph = true;
+    void *comm = nullptr;
+    int tw_override = 0, kw_override = 0;
+
+    int fail(int code, const char *fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIPCK(e, expr)                                                                               \
+    do {                                                                                             \
+        hipError_t _s = (expr);                                                                      \
+        if (_s != hipSuccess) return (e)->fail(NL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_s)); \
+    } while (0)
+
+namespace {
+
+template <typename T>
+hipError_t dalloc(T **p, size_t n, size_t *acct = nullptr) {
+    hipError_t s = hipMalloc((void **)p, n * sizeof(T) ? n * sizeof(T) : sizeof(T));
+    if (s == hipSuccess && acct) *acct += n * sizeof(T);
+    return s;
+}
+
+// Re-pack a slice of a raw GGUF tensor (already on the device) into tiles
+// [tile0, tile0 + ntiles) of a PackedMat.
+hipError_t repack(nl_engine *e, PackedMat &m, const uint8_t *d_src, int wtype, int src_cols, int row0, int nrows,
+                  int col0, int ncols, int tile0, int ntiles, int rowmap) {
+    const int cpp = chunks_per_pair(wtype);
+    RepackParams P{};
+    P.src = d_src;
+    P.q = m.q + (size_t)tile0 * m.npairs * cpp * TR * 16;
+    P.s = m.s ? m.s + (size_t)tile0 * m.npairs * TR : nullptr;
+    P.wtype = wtype;
+    P.src_cols = src_cols;
+    P.row0 = row0; P.nrows = nrows; P.col0 = col0; P.ncols = ncols;
+    P.ntiles = ntiles; P.npairs = m.npairs;
+    P.rowmap = rowmap; P.head_dim = e->hd;
+    long long nchunks = (long long)ntiles * m.npairs * cpp * TR;
+    int blocks = (int)std::min<long long>((nchunks + 255) / 256, 8192);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(repack_kernel, dim3(blocks), dim3(256), 0, e->stream, P);
+    return hipGetLastError();
+}
+
+hipError_t alloc_packed(nl_engine *e, PackedMat &m, int wtype, int rows_padded_tiles, int rows, int cols) {
+    m.wtype = wtype;
+    m.rows = rows;
+    m.cols = cols;
+    m.ntiles = rows_padded_tiles;
+    m.npairs = (cols + PAIR - 1) / PAIR;
+    m.q_bytes = (size_t)m.ntiles * m.npairs * chunks_per_pair(wtype) * TR * 16;
+    m.s_bytes = is_scaled(wtype) ? (size_t)m.ntiles * m.npairs * TR * 4 : 0;
+    hipError_t s = hipMalloc((void **)&m.q, m.q_bytes);
+    if (s != hipSuccess) return s;
+    if (m.s_bytes) {
+        s = hipMalloc((void **)&m.s, m.s_bytes);
+        if (s != hipSuccess) return s;
+    }
+    e->bytes_weights += m.q_bytes + m.s_bytes;
+    return hipSuccess;
+}
+
+void choose_geometry(const nl_engine *e, const PackedMat &m, int &tw, int &kw) {
+    int steps = (m.npairs + KL - 1) / KL;  // wave-steps per tile when kw == 1
+    kw = 1;
+    while (m.ntiles * kw < 1024 && kw * 2 <= steps && kw < 8) kw *= 2;
+    tw = std::max(1, 4 / kw);
+    if (e->kw_override > 0) kw = e->kw_override;
+    if (e->tw_override > 0) tw = e->tw_override;
+    if (tw * kw > 16) tw = std::max(1, 16 / kw);
+    if (tw > m.ntiles) tw = m.ntiles;
+}
+
+template <int PRO, int EPI>
+hipError_t launch_gemv_t(int wtype, GemvParams P, hipStream_t st) {
+    const int nm = EPI == EPI_SWIGLU ? 2 : 1;
+    const int nwaves = P.tw * P.kw;
+    const size_t lds = (size_t)P.npairs * PAIR * 4 + (size_t)nm * nwaves * TR * 4 + (size_t)nwaves * 8;
+    const dim3 grid((P.ntiles + P.tw - 1) / P.tw), block(nwaves * 64);
+    switch (wtype) {
+    case WT_Q8_0: hipLaunchKernelGGL((gemv_kernel<WT_Q8_0, PRO, EPI>), grid, block, lds, st, P); break;
+    case WT_Q4_0: hipLaunchKernelGGL((gemv_kernel<WT_Q4_0, PRO, EPI>), grid, block, lds, st, P); break;
+    case WT_F16: hipLaunchKernelGGL((gemv_kernel<WT_F16, PRO, EPI>), grid, block, lds, st, P); break;
+    case WT_F32: hipLaunchKernelGGL((gemv_kernel<WT_F32, PRO, EPI>), grid, block, lds, st, P); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+GemvParams base_params(const nl_engine *e, const PackedMat &m) {
+    GemvParams P{};
+    P.q0 = m.q; P.s0 = m.s;
+    P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
+    choose_geometry(e, m, P.tw, P.kw);
+    P.eps = e->cfg.rms_eps;
+    P.ctl = e->ctl;
+    P.head_dim = e->hd;
+    P.nsplit_max = e->nsplit_max;
+    return P;
+}
+
+template <int HD>
+hipError_t launch_attn_hd(int gqa, AttnParams P, dim3 grid, hipStream_t st) {
+    switch (gqa) {
+    case 1: hipLaunchKernelGGL((attn_kernel<HD, 1>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    case 2: hipLaunchKernelGGL((attn_kernel<HD, 2>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    case 3: hipLaunchKernelGGL((attn_kernel<HD, 3>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    case 4: hipLaunchKernelGGL((attn_kernel<HD, 4>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    case 8: hipLaunchKernelGGL((attn_kernel<HD, 8>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_attn(int hd, int gqa, AttnParams P, dim3 grid, hipStream_t st) {
+    if (hd == 64) return launch_attn_hd<64>(gqa, P, grid, st);
+    if (hd == 32) return launch_attn_hd<32>(gqa, P, grid, st);
+    return hipErrorInvalidValue;
+}
+
+// Build the per-token launch plan: the device-side restatement of Forward
+// (go/model.go:490-620).  token / pos / stream are read from e->ctl by the
+// kernels, so one captured graph serves every step.
+void build_plan(nl_engine *e) {
+    e->plan.clear();
+    const nl_config &c = e->cfg;
+    const bool tp = e->G > 1;
+    int cur = 0;
+    const float *pending = nullptr;  // all-reduced partial still to be added to the residual stream
+
+    {
+        EmbedParams P{e->embd_raw, e->embd_type, c.dim, e->ctl, e->x[0]};
+        e->plan.push_back({K_EMBED, 0, nullptr, 0, [P](hipStream_t st) {
+                               hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, P);
+                               return hipGetLastError();
+                           }});
+    }
+    for (int l = 0; l < c.n_layers; l++) {
+        nl_engine::Layer &L = e->layers[l];
+        float *kc = e->kcache + (long long)l * e->kv_layer_stride;
+        float *vc = e->vcache + (long long)l * e->kv_layer_stride;
+        {   // RMSNorm + Q,K,V GEMV + RoPE + KV store   (go/model.go:517-554)
+            GemvParams P = base_params(e, L.qkv);
+            P.x = e->x[cur]; P.normw = L.attn_norm;
+            if (pending) { P.add = pending; P.x_out = e->x[cur ^ 1]; }
+            P.rope_cos = e->rope_cos; P.rope_sin = e->rope_sin;
+            P.qbuf = e->qbuf; P.kcache = kc; P.vcache = vc; P.kv_stream_stride = e->kv_stream_stride;
+            P.n_q_heads = e->Hs; P.n_kv_heads = e->KVs; P.seq_len = c.seq_len; P.rope_conj = c.rope_conjugate;
+            int wt = L.qkv.wtype;
+            e->plan.push_back({K_QKV, 0, nullptr, 0,
+                               [wt, P](hipStream_t st) { return launch_gemv_t<PRO_NORM, EPI_QKV>(wt, P, st); }});
+            if (pending) { cur ^= 1; pending = nullptr; }
+        }
+        if (c.qk_norm) {
+            QkNormParams P{e->qbuf, kc, e->kv_stream_stride, e->ctl, e->Hs, e->KVs, e->hd, c.seq_len, c.rms_eps};
+            int nh = e->Hs + e->KVs;
+            e->plan.push_back({K_QKV, 0, nullptr, 0, [P, nh](hipStream_t st) {
+                                   hipLaunchKernelGGL(qknorm_kernel, dim3(nh), dim3(64), 0, st, P);
+                                   return hipGetLastError();
+                               }});
+        }
+        {   // GQA attention over the cache (go/model.go:557-587)
+            AttnParams P{e->qbuf, kc, vc, e->kv_stream_stride, e->part_o, e->part_ml, e->ctl,
+                         e->KVs, c.seq_len, e->nsplit_max, (float)(1.0 / std::sqrt((double)e->hd))};
+            dim3 grid(e->KVs, e->nsplit_max);
+            int hd = e->hd, gqa = e->gqa;
+            e->plan.push_back({K_ATTN, 0, nullptr, 0,
+                               [hd, gqa, P, grid](hipStream_t st) { return launch_attn(hd, gqa, P, grid, st); }});
+        }
+        {   // WO + residual (go/model.go:590-594); the prologue merges the attention splits
+            GemvParams P = base_params(e, L.wo);
+            P.part_o = e->part_o; P.part_ml = e->part_ml;
+            int wt = L.wo.wtype;
+            if (!tp) {
+                P.out = e->x[cur]; P.resid = e->x[cur];
+                e->plan.push_back({K_WO, 0, nullptr, 0,
+                                   [wt, P](hipStream_t st) { return launch_gemv_t<PRO_ATTN, EPI_RESID>(wt, P, st); }});
+            } else {
+                P.out = e->ar;
+                e->plan.push_back({K_WO, 1, e->ar, (size_t)c.dim,
+                                   [wt, P](hipStream_t st) { return launch_gemv_t<PRO_ATTN, EPI_STORE>(wt, P, st); }});
+                pending = e->ar;
+            }
+        }
+        {   // RMSNorm + gate/up GEMV + SiLU*up (go/model.go:597-606)
+            GemvParams P = base_params(e, L.gate);
+            P.q1 = L.up.q; P.s1 = L.up.s;
+            P.x = e->x[cur]; P.normw = L.ffn_norm; P.out = e->hb;
+            if (pending) { P.add = pending; P.x_out = e->x[cur ^ 1]; }
+            int wt = L.gate.wtype;
+            e->plan.push_back({K_GATEUP, 0, nullptr, 0,
+                               [wt, P](hipStream_t st) { return launch_gemv_t<PRO_NORM, EPI_SWIGLU>(wt, P, st); }});
+            if (pending) { cur ^= 1; pending = nullptr; }
+        }
+        {   // down + residual (go/model.go:609-612)
+            GemvParams P = base_params(e, L.down);
+            P.x = e->hb;
+            int wt = L.down.wtype;
+            if (!tp) {
+                P.out = e->x[cur]; P.resid = e->x[cur];
+                e->plan.push_back({K_DOWN, 0, nullptr, 0,
+                                   [wt, P](hipStream_t st) { return launch_gemv_t<PRO_PLAIN, EPI_RESID>(wt, P, st); }});
+            } else {
+                P.out = e->ar;
+                e->plan.push_back({K_DOWN, 1, e->ar, (size_t)c.dim,
+                                   [wt, P](hipStream_t st) { return launch_gemv_t<PRO_PLAIN, EPI_STORE>(wt, P, st); }});
+                pending = e->ar;
+            }
+        }
+    }
+    {   // final RMSNorm + LM head (go/model.go:616-619)
+        GemvParams P = base_params(e, e->lm_head);
+        P.x = e->x[cur]; P.normw = e->output_norm;
+        if (pending) { P.add = pending; P.x_out = e->x[cur ^ 1]; }
+        P.out = e->logits + (size_t)e->rank * e->Vs;
+        int wt = e->lm_head.wtype;
+        e->plan.push_back({K_LMHEAD, tp ? 2 : 0, e->logits, (size_t)e->Vs,
+                           [wt, P](hipStream_t st) { return launch_gemv_t<PRO_NORM, EPI_STORE>(wt, P, st); }});
+    }
+    {
+        ArgmaxParams P{e->logits, c.vocab, e->ctl, e->ids, e->result};
+        e->plan.push_back({K_ARGMAX, 0, nullptr, 0, [P](hipStream_t st) {
+                               hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, P);
+                               return hipGetLastError();
+                           }});
+    }
+}
+
+int run_collective(nl_engine *e, const Op &op) {
+    if (!op.coll) return NL_OK;
+    if (!e->comm) return e->fail(NL_ERR_COMM, "tensor-parallel forward without nl_comm_init");
+    int rc;
+    if (op.coll == 1) rc = g_rccl.AllReduce(op.buf, op.buf, op.count, kNcclFloat, kNcclSum, e->comm, e->stream);
+    else rc = g_rccl.AllGather(op.buf + (size_t)e->rank * op.count, op.buf, op.count, kNcclFloat, e->comm, e->stream);
+    if (rc != 0) return e->fail(NL_ERR_COMM, "rccl collective failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return NL_OK;
+}
+
+int run_plan_eager(nl_engine *e) {
+    for (const Op &op : e->plan) {
+        hipError_t s = op.fn(e->stream);
+        if (s != hipSuccess) return e->fail(NL_ERR_HIP, "launch %s: %s", kKindNames[op.kind], hipGetErrorString(s));
+        int rc = run_collective(e, op);
+        if (rc) return rc;
+    }
+    return NL_OK;
+}
+
+int capture_graph(nl_engine *e) {
+    HIPCK(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    int rc = run_plan_eager(e);
+    hipGraph_t g = nullptr;
+    hipError_t s = hipStreamEndCapture(e->stream, &g);
+    if (rc) { if (g) hipGraphDestroy(g); return rc; }
+    if (s != hipSuccess) return e->fail(NL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(s));
+    e->graph = g;
+    HIPCK(e, hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+    return NL_OK;
+}
+
+int launch_step(nl_engine *e) {
+    if (e->graph_exec) {
+        HIPCK(e, hipGraphLaunch(e->graph_exec, e->stream));
+        return NL_OK;
+    }
+    return run_plan_eager(e);
+}
+
+int set_ctl(nl_engine *e, int token, int pos, int chain, int stream) {
+    e->h_ctl[CTL_TOKEN] = token; e->h_ctl[CTL_POS] = pos; e->h_ctl[CTL_CHAIN] = chain;
+    e->h_ctl[CTL_STEP] = 0; e->h_ctl[CTL_STREAM] = stream;
+    HIPCK(e, hipMemcpyAsync(e->ctl, e->h_ctl, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    return NL_OK;
+}
+
+int check_step_args(nl_engine *e, int stream, int token, int pos) {
+    if (!e->finalized) return e->fail(NL_ERR_STATE, "forward before nl_finalize");
+    if (stream < 0 || stream >= e->cfg.max_streams) return e->fail(NL_ERR_INVALID, "stream %d out of range", stream);
+    if (token < 0 || token >= e->cfg.vocab) return e->fail(NL_ERR_INVALID, "token %d out of range [0,%d)", token, e->cfg.vocab);
+    if (pos < 0 || pos >= e->cfg.seq_len) return e->fail(NL_ERR_INVALID, "pos %d out of range [0,%d)", pos, e->cfg.seq_len);
+    return NL_OK;
+}
+
+struct Slot { int layer; std::string field; };
+
+bool parse_name(const char *name, Slot &s) {
+    int li = -1, off = 0;
+    if (sscanf(name, "blk.%d.%n", &li, &off) >= 1 && off > 0) { s.layer = li; s.field = name + off; return true; }
+    s.layer = -1; s.field = name;
+    return true;
+}
+
+}  // namespace
+
+// ============================================================== C ABI =====
+
+extern "C" {
+
+int nl_abi_version(void) { return 1; }
+
+int nl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *nl_last_error(nl_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int nl_create(const nl_config *cfg, nl_handle *out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return NL_ERR_INVALID; }
+    *out = nullptr;
+    nl_config c = *cfg;
+    if (c.head_dim == 0 && c.n_heads > 0) c.head_dim = c.dim / c.n_heads;  // go/model.go:140-142
+    if (c.seq_len > 2048) c.seq_len = 2048;                                // go/model.go:145-148
+    if (c.max_streams <= 0) c.max_streams = 1;
+    if (c.tp_size <= 0) c.tp_size = 1;
+    auto bad = [&](const char *m) { g_create_error = m; return NL_ERR_INVALID; };
+    if (c.n_layers <= 0 || c.dim <= 0 || c.n_heads <= 0 || c.n_kv_heads <= 0 || c.interm <= 0 || c.vocab <= 0 ||
+        c.seq_len <= 0)
+        return bad("config: non-positive dimension");
+    if (c.n_heads % c.n_kv_heads) return bad("config: n_heads not a multiple of n_kv_heads");
+    if (c.dim % 32 || c.interm % 32) return bad("config: dim and interm must be multiples of 32 (whole quant blocks)");
+    if (c.head_dim != 32 && c.head_dim != 64) { g_create_error = "head_dim must be 32 or 64 on this build"; return NL_ERR_UNSUPPORTED; }
+    int gq = c.n_heads / c.n_kv_heads;
+    if (gq != 1 && gq != 2 && gq != 3 && gq != 4 && gq != 8) { g_create_error = "GQA group size must be 1,2,3,4 or 8"; return NL_ERR_UNSUPPORTED; }
+    if (c.tp_rank < 0 || c.tp_rank >= c.tp_size) return bad("config: tp_rank out of range");
+    if (c.n_heads % c.tp_size || c.n_kv_heads % c.tp_size || c.vocab % c.tp_size || c.interm % (32 * c.tp_size))
+        return bad("config: heads / kv heads / vocab / interm(32-blocks) must divide by tp_size");
+    int ndev = 0;
+    hipError_t s = hipGetDeviceCount(&ndev);
+    if (s != hipSuccess || ndev == 0) {
+        g_create_error = std::string("no HIP device: ") + hipGetErrorString(s);
+        return NL_ERR_HIP;
+    }
+    if (c.device < 0 || c.device >= ndev) return bad("config: device ordinal out of range");
+    nl_engine *e = new nl_engine();
+    e->cfg = c;
+    e->dev = c.device;
+    e->G = c.tp_size; e->rank = c.tp_rank;
+    e->hd = c.head_dim; e->gqa = gq;
+    e->Hs = c.n_heads / e->G; e->KVs = c.n_kv_heads / e->G; e->Is = c.interm / e->G; e->Vs = c.vocab / e->G;
+    e->nsplit_max = (c.seq_len + ATT_CH - 1) / ATT_CH;
+    e->layers.resize(c.n_layers);
+    e->use_graph = !(c.flags & NL_FLAG_NO_GRAPH) && !getenv("NL_NO_GRAPH");
+    if (const char *v = getenv("NL_TW")) e->tw_override = atoi(v);
+    if (const char *v = getenv("NL_KW")) e->kw_override = atoi(v);
+    if ((s = hipSetDevice(e->dev)) != hipSuccess || (s = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (s = hipEventCreate(&e->ev0)) != hipSuccess || (s = hipEventCreate(&e->ev1)) != hipSuccess) {
+        g_create_error = std::string("device init: ") + hipGetErrorString(s);
+        delete e;
+        return NL_ERR_HIP;
+    }
+    *out = e;
+    return NL_OK;
+}
+
+int nl_get_config(nl_handle h, nl_config *out) {
+    if (!h || !out) return NL_ERR_INVALID;
+    *out = h->cfg;
+    return NL_OK;
+}
+
+int nl_upload_tensor(nl_handle e, const char *name, uint32_t type, const void *data, uint64_t nbytes, uint64_t rows,
+                     uint64_t cols) {
+    if (!e || !name || !data) return NL_ERR_INVALID;
+    if (e->finalized) return e->fail(NL_ERR_STATE, "upload after nl_finalize");
+    const nl_config &c = e->cfg;
+    Slot sl;
+    parse_name(name, sl);
+    if (sl.layer >= c.n_layers) return e->fail(NL_ERR_INVALID, "tensor %s: layer out of range", name);
+    if (!type_supported(type)) return e->fail(NL_ERR_UNSUPPORTED, "tensor %s: ggml type %u is not supported on device", name, type);
+    if (raw_bytes(type, rows * cols) != nbytes)
+        return e->fail(NL_ERR_INVALID, "tensor %s: %llu bytes given, %zu expected for %llux%llu type %u", name,
+                       (unsigned long long)nbytes, raw_bytes(type, rows * cols), (unsigned long long)rows,
+                       (unsigned long long)cols, type);
+    HIPCK(e, hipSetDevice(e->dev));
+    const std::string &f = sl.field;
+
+    auto norm_upload = [&](float **dst) -> int {
+        if ((int)(rows * cols) != c.dim) return e->fail(NL_ERR_INVALID, "tensor %s: expected %d elements", name, c.dim);
+        std::vector<float> tmp(c.dim);
+        if (type == WT_F32) memcpy(tmp.data(), data, (size_t)c.dim * 4);
+        else if (type == WT_F16) {
+            const uint16_t *hp = (const uint16_t *)data;
+            for (int i = 0; i < c.dim; i++) tmp[i] = __half2float(__ushort_as_half(hp[i]));
+        } else return e->fail(NL_ERR_UNSUPPORTED, "tensor %s: norm weights must be F32 or F16", name);
+        if (!*dst) HIPCK(e, dalloc(dst, (size_t)c.dim, &e->bytes_weights));
+        HIPCK(e, hipMemcpy(*dst, tmp.data(), (size_t)c.dim * 4, hipMemcpyHostToDevice));
+        return NL_OK;
+    };
+    // matrix slot: copy raw bytes to the device, re-pack this rank's slice
+    auto matrix_upload = [&](PackedMat &m, int exp_rows, int exp_cols, int row0, int nrows, int col0, int ncols,
+                             int tile0, int tiles_total, int rowmap, bool first) -> int {
+        if ((int)rows != exp_rows || (int)cols != exp_cols)
+            return e->fail(NL_ERR_INVALID, "tensor %s: shape %llux%llu, expected %dx%d", name, (unsigned long long)rows,
+                           (unsigned long long)cols, exp_rows, exp_cols);
+        if (first) {
+            HIPCK(e, alloc_packed(e, m, (int)type, tiles_total, rowmap == ROWMAP_HEADPERM ? tiles_total * TR : nrows, ncols));
+        } else if (m.wtype != (int)type) {
+            return e->fail(NL_ERR_UNSUPPORTED, "tensor %s: q/k/v (or gate/up) of one layer must share a type", name);
+        }
+        uint8_t *d_raw = nullptr;
+        HIPCK(e, hipMalloc((void **)&d_raw, nbytes));
+        hipError_t s = hipMemcpyAsync(d_raw, data, nbytes, hipMemcpyHostToDevice, e->stream);
+        if (s == hipSuccess) s = repack(e, m, d_raw, (int)type, exp_cols, row0, nrows, col0, ncols, tile0,
+                                        rowmap == ROWMAP_HEADPERM ? nrows / TR : (nrows + TR - 1) / TR, rowmap);
+        if (s == hipSuccess) s = hipStreamSynchronize(e->stream);
+        hipFree(d_raw);
+        if (s != hipSuccess) return e->fail(NL_ERR_HIP, "upload %s: %s", name, hipGetErrorString(s));
+        return NL_OK;
+    };
+
+    const int hd = e->hd, D = c.dim;
+    if (sl.layer < 0) {
+        if (f == "token_embd.weight") {
+            if ((int)rows != c.vocab || (int)cols != D) return e->fail(NL_ERR_INVALID, "token_embd.weight: bad shape");
+            if (e->embd_raw) hipFree(e->embd_raw);
+            HIPCK(e, hipMalloc((void **)&e->embd_raw, nbytes));
+            HIPCK(e, hipMemcpy(e->embd_raw, data, nbytes, hipMemcpyHostToDevice));
+            e->embd_type = (int)type; e->embd_bytes = nbytes; e->bytes_weights += nbytes;
+            if (!e->have_output) e->embd_host.assign((const uint8_t *)data, (const uint8_t *)data + nbytes);
+            return NL_OK;
+        }
+        if (f == "output_norm.weight") return norm_upload(&e->output_norm);
+        if (f == "output.weight") {
+            int rc = matrix_upload(e->lm_head, c.vocab, D, e->rank * e->Vs, e->Vs, 0, D, 0, (e->Vs + TR - 1) / TR,
+                                   ROWMAP_IDENT, true);
+            if (rc) return rc;
+            e->lm_head.ready = true; e->have_output = true;
+            e->embd_host.clear(); e->embd_host.shrink_to_fit();
+            return NL_OK;
+        }
+        return e->fail(NL_ERR_INVALID, "unknown tensor %s", name);
+    }
+    nl_engine::Layer &L = e->layers[sl.layer];
+    if (f == "attn_norm.weight") return norm_upload(&L.attn_norm);
+    if (f == "ffn_norm.weight") return norm_upload(&L.ffn_norm);
+    const int tph = hd / TR;  // tiles per head
+    const int qkv_tiles = (e->Hs + 2 * e->KVs) * tph;
+    const bool qkv_first = !L.have_q && !L.have_k && !L.have_v;
+    if (f == "attn_q.weight") {
+        int rc = matrix_upload(L.qkv, c.n_heads * hd, D, e->rank * e->Hs * hd, e->Hs * hd, 0, D, 0, qkv_tiles,
+                               ROWMAP_HEADPERM, qkv_first);
+        if (!rc) L.have_q = true;
+        return rc;
+    }
+    if (f == "attn_k.weight") {
+        int rc = matrix_upload(L.qkv, c.n_kv_heads * hd, D, e->rank * e->KVs * hd, e->KVs * hd, 0, D, e->Hs * tph,
+                               qkv_tiles, ROWMAP_HEADPERM, qkv_first);
+        if (!rc) L.have_k = true;
+        return rc;
+    }
+    if (f == "attn_v.weight") {
+        int rc = matrix_upload(L.qkv, c.n_kv_heads * hd, D, e->rank * e->KVs * hd, e->KVs * hd, 0, D,
+                               (e->Hs + e->KVs) * tph, qkv_tiles, ROWMAP_HEADPERM, qkv_first);
+        if (!rc) L.have_v = true;
+        return rc;
+    }
+    if (f == "attn_output.weight") {
+        int rc = matrix_upload(L.wo, D, c.n_heads * hd, 0, D, e->rank * e->Hs * hd, e->Hs * hd, 0, (D + TR - 1) / TR,
+                               ROWMAP_IDENT, true);
+        if (!rc) L.wo.ready = true;
+        return rc;
+    }
+    if (f == "ffn_gate.weight" || f == "ffn_up.weight") {
+        PackedMat &m = f == "ffn_gate.weight" ? L.gate : L.up;
+        int rc = matrix_upload(m, c.interm, D, e->rank * e->Is, e->Is, 0, D, 0, (e->Is + TR - 1) / TR, ROWMAP_IDENT, true);
+        if (!rc) m.ready = true;
+        return rc;
+    }
+    if (f == "ffn_down.weight") {
+        int rc = matrix_upload(L.down, D, c.interm, 0, D, e->rank * e->Is, e->Is, 0, (D + TR - 1) / TR, ROWMAP_IDENT, true);
+        if (!rc) L.down.ready = true;
+        return rc;
+    }
+    if (f.size() > 5 && f.compare(f.size() - 5, 5, ".bias") == 0)
+        return e->fail(NL_ERR_UNSUPPORTED, "tensor %s: attention biases are not implemented on device", name);
+    return e->fail(NL_ERR_INVALID, "unknown tensor %s", name);
+}
+
+int nl_finalize(nl_handle e) {
+    if (!e) return NL_ERR_INVALID;
+    if (e->finalized) return e->fail(NL_ERR_STATE, "nl_finalize called twice");
+    const nl_config &c = e->cfg;
+    HIPCK(e, hipSetDevice(e->dev));
+    if (!e->embd_raw) return e->fail(NL_ERR_MISSING, "token_embd.weight: tensor not found");
+    if (!e->output_norm) return e->fail(NL_ERR_MISSING, "output_norm.weight: tensor not found");
+    for (int l = 0; l < c.n_layers; l++) {
+        nl_engine::Layer &L = e->layers[l];
+        const char *miss = !L.attn_norm ? "attn_norm" : !L.ffn_norm ? "ffn_norm" : !L.have_q ? "attn_q" : !L.have_k ? "attn_k"
+                         : !L.have_v ? "attn_v" : !L.wo.ready ? "attn_output" : !L.gate.ready ? "ffn_gate"
+                         : !L.up.ready ? "ffn_up" : !L.down.ready ? "ffn_down" : nullptr;
+        if (miss) return e->fail(NL_ERR_MISSING, "layer %d %s: tensor not found", l, miss);
+        if (L.gate.wtype != L.up.wtype) return e->fail(NL_ERR_UNSUPPORTED, "layer %d: ffn_gate and ffn_up types differ", l);
+    }
+    if (!e->have_output) {
+        // tied embeddings: output.weight missing -> LM head reads token_embd (go/model.go:195-201)
+        PackedMat &m = e->lm_head;
+        HIPCK(e, alloc_packed(e, m, e->embd_type, (e->Vs + TR - 1) / TR, e->Vs, c.dim));
+        HIPCK(e, repack(e, m, e->embd_raw, e->embd_type, c.dim, e->rank * e->Vs, e->Vs, 0, c.dim, 0, m.ntiles, ROWMAP_IDENT));
+        HIPCK(e, hipStreamSynchronize(e->stream));
+        m.ready = true;
+        e->embd_host.clear(); e->embd_host.shrink_to_fit();
+    }
+    // precomputeRoPE go/model.go:346-358 (float64 math, cast to float32)
+    const int half = e->hd / 2;
+    std::vector<float> hc((size_t)c.seq_len * half), hs((size_t)c.seq_len * half);
+    const double theta = (double)c.rope_theta;
+    for (int pos = 0; pos < c.seq_len; pos++)
+        for (int i = 0; i < half; i++) {
+            double freq = 1.0 / std::pow(theta, (double)(2 * i) / (double)e->hd);
+            double angle = (double)pos * freq;
+            hc[(size_t)pos * half + i] = (float)std::cos(angle);
+            hs[(size_t)pos * half + i] = (float)std::sin(angle);
+        }
+    HIPCK(e, dalloc(&e->rope_cos, hc.size(), &e->bytes_state));
+    HIPCK(e, dalloc(&e->rope_sin, hs.size(), &e->bytes_state));
+    HIPCK(e, hipMemcpy(e->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+    HIPCK(e, hipMemcpy(e->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    // allocState go/model.go:324-343
+    HIPCK(e, dalloc(&e->x[0], (size_t)c.dim, &e->bytes_state));
+    HIPCK(e, dalloc(&e->x[1], (size_t)c.dim, &e->bytes_state));
+    HIPCK(e, dalloc(&e->qbuf, (size_t)e->Hs * e->hd, &e->bytes_state));
+    HIPCK(e, dalloc(&e->part_o, (size_t)e->Hs * e->nsplit_max * e->hd, &e->bytes_state));
+    HIPCK(e, dalloc(&e->part_ml, (size_t)e->Hs * e->nsplit_max * 2, &e->bytes_state));
+    HIPCK(e, dalloc(&e->hb, (size_t)e->Is, &e->bytes_state));
+    HIPCK(e, dalloc(&e->ar, (size_t)c.dim, &e->bytes_state));
+    HIPCK(e, dalloc(&e->logits, (size_t)c.vocab, &e->bytes_state));
+    e->kv_layer_stride = (long long)e->KVs * c.seq_len * e->hd;
+    e->kv_stream_stride = e->kv_layer_stride * c.n_layers;
+    const size_t kvn = (size_t)e->kv_stream_stride * c.max_streams;
+    HIPCK(e, dalloc(&e->kcache, kvn, &e->bytes_kv));
+    HIPCK(e, dalloc(&e->vcache, kvn, &e->bytes_kv));
+    HIPCK(e, hipMemsetAsync(e->kcache, 0, kvn * 4, e->stream));
+    HIPCK(e, hipMemsetAsync(e->vcache, 0, kvn * 4, e->stream));
+    e->ids_cap = c.seq_len + 1;
+    HIPCK(e, dalloc(&e->ctl, (size_t)CTL_WORDS, &e->bytes_state));
+    HIPCK(e, dalloc(&e->ids, (size_t)e->ids_cap, &e->bytes_state));
+    HIPCK(e, dalloc(&e->result, (size_t)1, &e->bytes_state));
+    HIPCK(e, hipHostMalloc((void **)&e->h_ctl, CTL_WORDS * sizeof(int), hipHostMallocDefault));
+    memset(e->h_ctl, 0, CTL_WORDS * sizeof(int));
+    HIPCK(e, hipMemcpy(e->ctl, e->h_ctl, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice));
+    if (e->G > 1 && !e->comm) return e->fail(NL_ERR_STATE, "tp_size %d needs nl_comm_init before nl_finalize", e->G);
+    build_plan(e);
+    HIPCK(e, hipStreamSynchronize(e->stream));
+    if (e->use_graph && e->G == 1) {
+        int rc = capture_graph(e);
+        if (rc) return rc;
+    }
+    e->finalized = true;
+    return NL_OK;
+}
+
+int nl_destroy(nl_handle e) {
+    if (!e) return NL_OK;
+    hipSetDevice(e->dev);
+    hipDeviceSynchronize();
+    if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
+    if (e->graph) hipGraphDestroy(e->graph);
+    auto fm = [](PackedMat &m) { if (m.q) hipFree(m.q); if (m.s) hipFree(m.s); };
+    for (auto &L : e->layers) {
+        fm(L.qkv); fm(L.wo); fm(L.gate); fm(L.up); fm(L.down);
+        if (L.attn_norm) hipFree(L.attn_norm);
+        if (L.ffn_norm) hipFree(L.ffn_norm);
+    }
+    fm(e->lm_head);
+    void *bufs[] = {e->embd_raw, e->output_norm, e->rope_cos, e->rope_sin, e->x[0], e->x[1], e->qbuf, e->part_o,
+                    e->part_ml, e->hb, e->ar, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result};
+    for (void *b : bufs) if (b) hipFree(b);
+    if (e->h_ctl) hipHostFree(e->h_ctl);
+    if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+    if (e->ev0) hipEventDestroy(e->ev0);
+    if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+    return NL_OK;
+}
+
+int nl_reset(nl_handle e, int stream) {
+    if (!e) return NL_ERR_INVALID;
+    if (!e->finalized) return e->fail(NL_ERR_STATE, "reset before nl_finalize");
+    if (stream < 0 || stream >= e->cfg.max_streams) return e->fail(NL_ERR_INVALID, "stream %d out of range", stream);
+    // Forward at position p only ever reads cache positions <= p, all of which
+    // the caller has rewritten since the reset, so the reference's memset
+    // (go/model.go:623-631) has no observable effect and is skipped.
+    return NL_OK;
+}
+
+int nl_forward(nl_handle e, int stream, int token, int pos, float *logits_out) {
+    if (!e) return NL_ERR_INVALID;
+    int rc = check_step_args(e, stream, token, pos);
+    if (rc) return rc;
+    HIPCK(e, hipSetDevice(e->dev));
+    if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
+    if ((rc = launch_step(e))) return rc;
+    if (logits_out)
+        HIPCK(e, hipMemcpyAsync(logits_out, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCK(e, hipStreamSynchronize(e->stream));
+    return NL_OK;
+}
+
+int nl_forward_argmax(nl_handle e, int stream, int token, int pos, int *next_id) {
+    if (!e || !next_id) return NL_ERR_INVALID;
+    int rc = check_step_args(e, stream, token, pos);
+    if (rc) return rc;
+    HIPCK(e, hipSetDevice(e->dev));
+    if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
+    if ((rc = launch_step(e))) return rc;
+    HIPCK(e, hipMemcpyAsync(next_id, e->result, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCK(e, hipStreamSynchronize(e->stream));
+    return NL_OK;
+}
+
+int nl_decode_greedy(nl_handle e, int stream, int token, int pos, int n_steps, int *ids_out, int *n_done) {
+    if (!e || !ids_out || n_steps < 0) return NL_ERR_INVALID;
+    int rc = check_step_args(e, stream, token, pos);
+    if (rc) return rc;
+    HIPCK(e, hipSetDevice(e->dev));
+    int n = std::min(n_steps, e->cfg.seq_len - pos);
+    n = std::min(n, e->ids_cap);
+    if ((rc = set_ctl(e, token, pos, 1, stream))) return rc;
+    for (int i = 0; i < n; i++)
+        if ((rc = launch_step(e))) return rc;
+    if (n > 0) HIPCK(e, hipMemcpyAsync(ids_out, e->ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCK(e, hipStreamSynchronize(e->stream));
+    if (n_done) *n_done = n;
+    return NL_OK;
+}
+
+int nl_synchronize(nl_handle e) {
+    if (!e) return NL_ERR_INVALID;
+    HIPCK(e, hipSetDevice(e->dev));
+    HIPCK(e, hipStreamSynchronize(e->stream));
+    return NL_OK;
+}
+
+int nl_timer_start(nl_handle e) {
+    if (!e) return NL_ERR_INVALID;
+    HIPCK(e, hipEventRecord(e->ev0, e->stream));
+    return NL_OK;
+}
+
+int nl_timer_stop(nl_handle e, float *ms) {
+    if (!e || !ms) return NL_ERR_INVALID;
+    HIPCK(e, hipEventRecord(e->ev1, e->stream));
+    HIPCK(e, hipEventSynchronize(e->ev1));
+    HIPCK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
+    return NL_OK;
+}
+
+const char *nl_kernel_kind_name(int k) { return (k >= 0 && k < NL_NUM_KINDS) ? kKindNames[k] : ""; }
+
+int nl_profile_forward(nl_handle e, int stream, int token, int pos, int iters, float *ms_out, int *calls_out) {
+    if (!e || !ms_out || !calls_out || iters <= 0) return NL_ERR_INVALID;
+    int rc = check_step_args(e, stream, token, pos);
+    if (rc) return rc;
+    HIPCK(e, hipSetDevice(e->dev));
+    const size_t nops = e->plan.size();
+    std::vector<hipEvent_t> ev(nops + 1);
+    for (auto &v : ev) HIPCK(e, hipEventCreate(&v));
+    for (int k = 0; k < NL_NUM_KINDS; k++) { ms_out[k] = 0.f; calls_out[k] = 0; }
+    for (int it = 0; it < iters; it++) {
+        if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
+        HIPCK(e, hipEventRecord(ev[0], e->stream));
+        for (size_t i = 0; i < nops; i++) {
+            const Op &op = e->plan[i];
+            hipError_t s = op.fn(e->stream);
+            if (s != hipSuccess) return e->fail(NL_ERR_HIP, "launch %s: %s", kKindNames[op.kind], hipGetErrorString(s));
+            if ((rc = run_collective(e, op))) return rc;
+            HIPCK(e, hipEventRecord(ev[i + 1], e->stream));
+        }
+        HIPCK(e, hipStreamSynchronize(e->stream));
+        for (size_t i = 0; i < nops; i++) {
+            float ms = 0.f;
+            HIPCK(e, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            ms_out[e->plan[i].kind] += ms;
+            if (it == 0) calls_out[e->plan[i].kind]++;
+        }
+    }
+    for (int k = 0; k < NL_NUM_KINDS; k++) ms_out[k] /= (float)iters;
+    for (auto &v : ev) hipEventDestroy(v);
+    return NL_OK;
+}
+
+int nl_memory_usage(nl_handle e, uint64_t *w, uint64_t *kv, uint64_t *st) {
+    if (!e) return NL_ERR_INVALID;
+    if (w) *w = e->bytes_weights;
+    if (kv) *kv = e->bytes_kv;
+    if (st) *st = e->bytes_state;
+    return NL_OK;
+}
+
+int64_t nl_debug_read(nl_handle e, const char *which, int stream, float *out, int64_t max_floats) {
+    if (!e || !which || !out || !e->finalized) return NL_ERR_INVALID;
+    const float *src = nullptr;
+    int64_t n = 0;
+    std::string w = which;
+    if (w == "x") { src = e->x[0]; n = e->cfg.dim; }
+    else if (w == "x1") { src = e->x[1]; n = e->cfg.dim; }
+    else if (w == "q") { src = e->qbuf; n = (int64_t)e->Hs * e->hd; }
+    else if (w == "hb") { src = e->hb; n = e->Is; }
+    else if (w == "logits") { src = e->logits; n = e->cfg.vocab; }
+    else if (w == "k_cache") { src = e->kcache + (long long)stream * e->kv_stream_stride; n = e->kv_stream_stride; }
+    else if (w == "v_cache") { src = e->vcache + (long long)stream * e->kv_stream_stride; n = e->kv_stream_stride; }
+    else return e->fail(NL_ERR_INVALID, "unknown debug buffer %s", which);
+    n = std::min(n, max_floats);
+    if (hipSetDevice(e->dev) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess ||
+        hipMemcpy(out, src, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return e->fail(NL_ERR_HIP, "debug read failed");
+    return n;
+}
+
+// ---- op-level entry points ---------------------------------------------------
+
+int nl_op_matmul(int device, uint32_t type, const void *w, uint64_t nbytes, const float *x, float *out, int rows,
+                 int cols) {
+    if (!w || !x || !out || rows <= 0 || cols <= 0 || cols % 32) return NL_ERR_INVALID;
+    if (!type_supported(type)) return NL_ERR_UNSUPPORTED;  // matmulDispatch default arm, go/model.go:383-385
+    if (raw_bytes(type, (uint64_t)rows * cols) != nbytes) return NL_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return NL_ERR_HIP;
+    nl_engine tmp;
+    tmp.hd = 64;
+    hipStream_t st;
+    if (hipStreamCreate(&st) != hipSuccess) return NL_ERR_HIP;
+    tmp.stream = st;
+    PackedMat m;
+    uint8_t *d_raw = nullptr;
+    float *d_x = nullptr, *d_out = nullptr;
+    int rc = NL_ERR_HIP;
+    do {
+        if (alloc_packed(&tmp, m, (int)type, (rows + TR - 1) / TR, rows, cols) != hipSuccess) break;
+        if (hipMalloc((void **)&d_raw, nbytes) != hipSuccess) break;
+        if (hipMalloc((void **)&d_x, (size_t)cols * 4) != hipSuccess) break;
+        if (hipMalloc((void **)&d_out, (size_t)rows * 4) != hipSuccess) break;
+        if (hipMemcpyAsync(d_raw, w, nbytes, hipMemcpyHostToDevice, st) != hipSuccess) break;
+        if (hipMemcpyAsync(d_x, x, (size_t)cols * 4, hipMemcpyHostToDevice, st) != hipSuccess) break;
+        if (repack(&tmp, m, d_raw, (int)type, cols, 0, rows, 0, cols, 0, m.ntiles, ROWMAP_IDENT) != hipSuccess) break;
+        GemvParams P{};
+        P.q0 = m.q; P.s0 = m.s; P.rows = rows; P.cols = cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
+        if (const char *v = getenv("NL_TW")) tmp.tw_override = atoi(v);
+        if (const char *v = getenv("NL_KW")) tmp.kw_override = atoi(v);
+        choose_geometry(&tmp, m, P.tw, P.kw);
+        P.x = d_x; P.out = d_out;
+        if (launch_gemv_t<PRO_PLAIN, EPI_STORE>((int)type, P, st) != hipSuccess) break;
+        if (hipMemcpyAsync(out, d_out, (size_t)rows * 4, hipMemcpyDeviceToHost, st) != hipSuccess) break;
+        if (hipStreamSynchronize(st) != hipSuccess) break;
+        rc = NL_OK;
+    } while (0);
+    if (m.q) hipFree(m.q);
+    if (m.s) hipFree(m.s);
+    if (d_raw) hipFree(d_raw);
+    if (d_x) hipFree(d_x);
+    if (d_out) hipFree(d_out);
+    hipStreamDestroy(st);
+    tmp.stream = nullptr;
+    return rc;
+}
+
+namespace {
+__global__ void rmsnorm_op_kernel(const float *x, const float *w, float eps, float *out, int n) {
+    __shared__ double dred[16];
+    double ss = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) ss += (double)x[i] * (double)x[i];
+    ss = wave_sum_f64(ss);
+    if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    double tot = 0.0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); k++) tot += dred[k];
+    float inv = (float)(1.0 / sqrt(tot / (double)n + (double)eps));
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = (x[i] * inv) * w[i];
+}
+}  // namespace
+
+int nl_op_rmsnorm(int device, const float *x, const float *w, float eps, float *out, int n) {
+    if (!x || !w || !out || n <= 0) return NL_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return NL_ERR_HIP;
+    float *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)n * 12) != hipSuccess) return NL_ERR_HIP;
+    int rc = NL_ERR_HIP;
+    do {
+        if (hipMemcpy(d, x, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(d + n, w, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) break;
+        hipLaunchKernelGGL(rmsnorm_op_kernel, dim3(1), dim3(256), 0, 0, d, d + n, eps, d + 2 * n, n);
+        if (hipGetLastError() != hipSuccess) break;
+        if (hipMemcpy(out, d + 2 * n, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = NL_OK;
+    } while (0);
+    hipFree(d);
+    return rc;
+}
+
+// ---- tensor-parallel communicator -------------------------------------------
+
+int nl_comm_get_unique_id(void *id_out) {
+    if (!id_out) return NL_ERR_INVALID;
+    std::string err;
+    if (!g_rccl.load(err)) { g_create_error = err; return NL_ERR_COMM; }
+    NcclId id;
+    if (g_rccl.GetUniqueId(&id) != 0) { g_create_error = "ncclGetUniqueId failed"; return NL_ERR_COMM; }
+    memcpy(id_out, &id, NL_COMM_ID_BYTES);
+    return NL_OK;
+}
+
+int nl_comm_init(nl_handle e, const void *id) {
+    if (!e || !id) return NL_ERR_INVALID;
+    if (e->finalized) return e->fail(NL_ERR_STATE, "nl_comm_init after nl_finalize");
+    if (e->G <= 1) return NL_OK;
+    std::string err;
+    if (!g_rccl.load(err)) return e->fail(NL_ERR_COMM, "%s", err.c_str());
+    HIPCK(e, hipSetDevice(e->dev));
+    NcclId nid;
+    memcpy(&nid, id, NL_COMM_ID_BYTES);
+    int rc = g_rccl.CommInitRank(&e->comm, e->G, nid, e->rank);
+    if (rc != 0) return e->fail(NL_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return NL_OK;
+}
+
+}  // extern "C"

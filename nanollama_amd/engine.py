@@ -1,0 +1,134 @@
+"""Generation loop -- mirror of Engine.Generate / GenerateQuiet (go/main.go:143-408).
+
+Prefill is token-at-a-time through model.forward exactly like the reference
+(go/main.go:160-166); decode applies the in-place repetition penalty
+(:177-187), then top-p / top-k / argmax (:191-195, :294-408).  Sampling stays
+on the host over the logits the device returns; the pure-greedy configuration
+(temp <= 0, rep_penalty <= 1) takes the chained on-device loop instead.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+
+from .model import LlamaModel
+
+
+@dataclass
+class GenParams:
+    """go/main.go:135-140 with the CLI defaults of :29-34."""
+    max_tokens: int = 256
+    temperature: float = 0.8
+    top_p: float = 0.9
+    top_k: int = 50
+
+
+def argmax(logits: np.ndarray, n: int) -> int:
+    """go/main.go:400-408 (strict '>': lowest index wins ties; numpy argmax has the same rule)."""
+    return int(np.argmax(logits[:n]))
+
+
+class Engine:
+    def __init__(self, model: LlamaModel, eos_id: int = 2, rep_penalty: float = 1.15, rep_window: int = 64,
+                 seed: Optional[int] = None):
+        self.model = model
+        self.eos_id = eos_id
+        self.rep_penalty = np.float32(rep_penalty)
+        self.rep_window = rep_window
+        self.rng = np.random.default_rng(seed)
+        self.last_tok_per_s = 0.0
+        self.last_tokens = 0
+
+    # sampleTopK go/main.go:294-343
+    def sample_top_k(self, temp: float, top_k: int) -> int:
+        logits, vocab = self.model.state.logits, self.model.config.vocab_size
+        if temp <= 0:
+            return argmax(logits, vocab)
+        top_k = min(top_k, vocab)
+        order = np.argsort(-logits[:vocab], kind="stable")[:top_k]
+        vals = logits[order]
+        probs = np.exp(((vals - vals[0]) / np.float32(temp)).astype(np.float64)).astype(np.float32)
+        r = np.float32(self.rng.random(dtype=np.float32)) * probs.sum(dtype=np.float32)
+        cdf = np.cumsum(probs, dtype=np.float32)
+        hit = np.nonzero(r <= cdf)[0]
+        return int(order[hit[0]]) if len(hit) else int(order[0])
+
+    # sampleTopP go/main.go:346-398
+    def sample_top_p(self, temp: float, top_p: float) -> int:
+        logits, vocab = self.model.state.logits, self.model.config.vocab_size
+        if temp <= 0:
+            return argmax(logits, vocab)
+        lg = logits[:vocab]
+        p = np.exp(((lg - lg.max()) / np.float32(temp)).astype(np.float64)).astype(np.float32)
+        p = p * (np.float32(1.0) / p.sum(dtype=np.float32))
+        order = np.argsort(-p, kind="stable")
+        cs = np.cumsum(p[order], dtype=np.float32)
+        cut = int(np.searchsorted(cs, np.float32(top_p), side="left"))
+        if cut >= vocab:
+            return int(order[0])
+        r = np.float32(self.rng.random(dtype=np.float32)) * cs[cut]
+        hit = np.nonzero(r <= cs[: cut + 1])[0]
+        return int(order[hit[0]]) if len(hit) else int(order[0])
+
+    def generate_ids(self, tokens: List[int], p: GenParams, on_token=None) -> List[int]:
+        """Engine.Generate go/main.go:152-230 on token ids (Encode/Decode stay with the tokenizer)."""
+        m, cfg = self.model, self.model.config
+        m.reset()
+        pos = 0
+        for tok in tokens:                       # prefill, go/main.go:160-166
+            m.forward(tok, pos)
+            pos += 1
+            if pos >= cfg.seq_len - 1:
+                break
+        out: List[int] = []
+        recent: List[int] = []
+        start = time.perf_counter()              # timer starts after prefill, go/main.go:171
+        greedy_fast = p.temperature <= 0 and self.rep_penalty <= 1.0
+        if greedy_fast and p.max_tokens > 0:
+            # sample_0 comes from the prefill logits; sample_k (k >= 1) exists iff k < max_tokens, the
+            # k-th Forward left pos + k < SeqLen (go/main.go:216) and sample_{k-1} was not EOS (:203).
+            nxt = argmax(m.state.logits, cfg.vocab_size)
+            out.append(nxt)
+            n = min(p.max_tokens - 1, cfg.seq_len - 1 - pos)
+            if nxt != self.eos_id and n > 0:
+                for t in m.decode_greedy(nxt, pos, n):
+                    out.append(t)
+                    if t == self.eos_id:
+                        break
+            if on_token:
+                for t in out:
+                    if t != self.eos_id:
+                        on_token(t)
+            recent = out[-self.rep_window:] if self.rep_window > 0 else []
+        else:
+            for _ in range(p.max_tokens):
+                logits = m.state.logits
+                if self.rep_penalty > 1.0 and recent:     # go/main.go:177-187, in place
+                    for tok in recent:
+                        if 0 <= tok < cfg.vocab_size:
+                            if logits[tok] > 0:
+                                logits[tok] /= self.rep_penalty
+                            else:
+                                logits[tok] *= self.rep_penalty
+                nxt = self.sample_top_p(p.temperature, p.top_p) if p.top_p < 1.0 else \
+                    self.sample_top_k(p.temperature, p.top_k)
+                recent.append(nxt)
+                if len(recent) > self.rep_window:
+                    recent = recent[1:]
+                out.append(nxt)
+                if nxt == self.eos_id:
+                    break
+                if on_token:
+                    on_token(nxt)
+                m.forward(nxt, pos)
+                pos += 1
+                if pos >= cfg.seq_len:
+                    break
+        elapsed = time.perf_counter() - start
+        # the reference counts len(recentTokens), capped by --rep-window (go/main.go:198-200,223)
+        self.last_tokens = len(recent)
+        self.last_tok_per_s = (len(recent) / elapsed) if elapsed > 0 and recent else 0.0
+        return out

@@ -1,0 +1,200 @@
+"""Host-side mirror of go/model.go's LlamaModel over the HIP C ABI.
+
+Same names and call pattern as the reference so call sites read alike:
+
+    gguf  = load_gguf(path)                 # go/main.go:51
+    model = load_llama_model(gguf)          # go/main.go:63  LoadLlamaModel
+    model.reset()                           # go/main.go:156 Reset
+    model.forward(tok, pos)                 # go/main.go:161 Forward
+    model.state.logits                      # go/main.go:174 State.Logits (host float32, mutable)
+
+All arithmetic happens in libnanollama_hip.so; this file only moves bytes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from .gguf import GGUFFile
+
+
+@dataclass
+class LlamaConfig:
+    """go/model.go:27-42"""
+    num_layers: int
+    embed_dim: int
+    num_heads: int
+    num_kv_heads: int
+    head_dim: int
+    vocab_size: int
+    seq_len: int
+    interm_size: int
+    rms_norm_eps: float
+    rope_theta: float
+    qk_norm: bool = False
+    rope_conjugate: bool = False
+
+
+class LlamaState:
+    """The slice of go/model.go:93-118 the host touches: Logits (and Pos)."""
+
+    def __init__(self, vocab: int):
+        self.logits = np.zeros(vocab, dtype=np.float32)
+        self.pos = 0
+
+
+class LlamaModel:
+    def __init__(self, config: LlamaConfig, handle, max_streams: int):
+        self.config = config
+        self.state = LlamaState(config.vocab_size)
+        self.gamma = None  # go/model.go:23 (gamma injection is out of scope)
+        self._h = handle
+        self.max_streams = max_streams
+
+    # --- Forward go/model.go:490 ---
+    def forward(self, token: int, pos: int, stream: int = 0) -> None:
+        L = _lib.lib()
+        _lib.check(self._h, L.nl_forward(self._h, stream, int(token), int(pos),
+                                         self.state.logits.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def forward_argmax(self, token: int, pos: int, stream: int = 0) -> int:
+        out = C.c_int(0)
+        _lib.check(self._h, _lib.lib().nl_forward_argmax(self._h, stream, int(token), int(pos), C.byref(out)))
+        return out.value
+
+    def decode_greedy(self, token: int, pos: int, n_steps: int, stream: int = 0) -> List[int]:
+        ids = (C.c_int * max(n_steps, 1))()
+        done = C.c_int(0)
+        _lib.check(self._h, _lib.lib().nl_decode_greedy(self._h, stream, int(token), int(pos), int(n_steps), ids,
+                                                        C.byref(done)))
+        return [int(ids[i]) for i in range(done.value)]
+
+    # --- Reset go/model.go:623 ---
+    def reset(self, stream: int = 0) -> None:
+        _lib.check(self._h, _lib.lib().nl_reset(self._h, stream))
+        self.state.pos = 0
+
+    # --- measurement / introspection ---
+    def synchronize(self):
+        _lib.check(self._h, _lib.lib().nl_synchronize(self._h))
+
+    def timer_start(self):
+        _lib.check(self._h, _lib.lib().nl_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float(0)
+        _lib.check(self._h, _lib.lib().nl_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def profile_forward(self, token: int, pos: int, iters: int = 10, stream: int = 0):
+        L = _lib.lib()
+        ms = (C.c_float * _lib.NL_NUM_KINDS)()
+        calls = (C.c_int * _lib.NL_NUM_KINDS)()
+        _lib.check(self._h, L.nl_profile_forward(self._h, stream, token, pos, iters, ms, calls))
+        return {L.nl_kernel_kind_name(k).decode(): (ms[k], calls[k]) for k in range(_lib.NL_NUM_KINDS)}
+
+    def memory_usage(self):
+        w, kv, st = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self._h, _lib.lib().nl_memory_usage(self._h, C.byref(w), C.byref(kv), C.byref(st)))
+        return {"weights": w.value, "kv_cache": kv.value, "state": st.value}
+
+    def debug_read(self, which: str, n: int, stream: int = 0) -> np.ndarray:
+        out = np.zeros(n, dtype=np.float32)
+        got = _lib.lib().nl_debug_read(self._h, which.encode(), stream, out.ctypes.data_as(C.POINTER(C.c_float)), n)
+        if got < 0:
+            _lib.check(self._h, int(got))
+        return out[:got]
+
+    def close(self):
+        if self._h:
+            _lib.lib().nl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load_llama_model(gguf: GGUFFile, device: int = 0, max_streams: int = 1, tp_rank: int = 0, tp_size: int = 1,
+                     comm_id: Optional[bytes] = None, flags: int = 0, verbose: bool = False) -> LlamaModel:
+    """LoadLlamaModel go/model.go:121-174: config from GGUF metadata, every
+    tensor handed to the device library, state allocated there."""
+    L = _lib.lib()
+    m = gguf.meta
+    head_dim = m.head_dim
+    if head_dim == 0 and m.num_heads > 0:
+        head_dim = m.embed_dim // m.num_heads
+    seq_len = m.seq_len
+    if seq_len > 2048:  # go/model.go:145-148
+        if verbose:
+            print(f"[model] capping seq_len from {seq_len} to 2048")
+        seq_len = 2048
+    cfg = _lib.NlConfig(m.num_layers, m.embed_dim, m.num_heads, m.num_kv_heads, head_dim, m.interm_size, m.vocab_size,
+                        seq_len, m.rms_norm_eps, m.rope_theta, int(m.qk_norm), int(m.rope_conjugate), max_streams,
+                        device, tp_rank, tp_size, flags)
+    h = C.c_void_p()
+    rc = L.nl_create(C.byref(cfg), C.byref(h))
+    if rc != 0:
+        raise _lib.NlError(rc, (L.nl_last_error(None) or b"").decode())
+    try:
+        if tp_size > 1:
+            if comm_id is None or len(comm_id) != _lib.NL_COMM_ID_BYTES:
+                raise ValueError("tp_size > 1 needs the communicator id from nl_comm_get_unique_id")
+            _lib.check(h, L.nl_comm_init(h, C.c_char_p(comm_id)))
+        for name in gguf.tensor_order:
+            data, info = gguf.get_tensor(name)
+            if info.ndims == 1:
+                rows, cols = 1, info.dims[0]
+            else:
+                cols, rows = info.dims[0], info.dims[1]
+            data = np.ascontiguousarray(data)
+            _lib.check(h, L.nl_upload_tensor(h, name.encode(), info.type, data.ctypes.data, data.nbytes, rows, cols))
+        _lib.check(h, L.nl_finalize(h))
+    except Exception:
+        L.nl_destroy(h)
+        raise
+    config = LlamaConfig(m.num_layers, m.embed_dim, m.num_heads, m.num_kv_heads, head_dim, m.vocab_size, seq_len,
+                         m.interm_size, m.rms_norm_eps, m.rope_theta, m.qk_norm, m.rope_conjugate)
+    if verbose:
+        print(f"[model] loaded: {config.num_layers} layers, {config.embed_dim} dim, {config.num_heads} heads, "
+              f"{config.num_kv_heads} kv_heads, {config.vocab_size} vocab, bias=False")
+    return LlamaModel(config, h, max_streams)
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(_lib.NL_COMM_ID_BYTES)
+    rc = _lib.lib().nl_comm_get_unique_id(buf)
+    if rc != 0:
+        raise _lib.NlError(rc, (_lib.lib().nl_last_error(None) or b"").decode())
+    return buf.raw
+
+
+def op_matmul(w_raw: np.ndarray, ggml_type: int, x: np.ndarray, rows: int, cols: int, device: int = 0) -> np.ndarray:
+    """matmulDispatch go/model.go:361-386 on the device (single GEMV, host in/out)."""
+    w_raw = np.ascontiguousarray(w_raw)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(rows, dtype=np.float32)
+    rc = _lib.lib().nl_op_matmul(device, ggml_type, w_raw.ctypes.data, w_raw.nbytes,
+                                 x.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)),
+                                 rows, cols)
+    if rc != 0:
+        raise _lib.NlError(rc, "nl_op_matmul")
+    return out
+
+
+def op_rmsnorm(x: np.ndarray, w: np.ndarray, eps: float, device: int = 0) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    out = np.zeros_like(x)
+    fp = C.POINTER(C.c_float)
+    rc = _lib.lib().nl_op_rmsnorm(device, x.ctypes.data_as(fp), w.ctypes.data_as(fp), C.c_float(eps),
+                                  out.ctypes.data_as(fp), len(x))
+    if rc != 0:
+        raise _lib.NlError(rc, "nl_op_rmsnorm")
+    return out
