@@ -120,6 +120,9 @@ NL_API int nl_memory_usage(nl_handle h, uint64_t *weights, uint64_t *kv_cache, u
  * "k_cache","v_cache"); returns floats copied (<= max_floats). */
 NL_API int64_t nl_debug_read(nl_handle h, const char *which, int stream, float *out, int64_t max_floats);
 
+/* Shader-clock phase stamps of one GEMV launch (developer tool, tools/phase_probe.py). */
+NL_API int nl_debug_stamps(nl_handle h, int kind, long long *out /* 128 */);
+
 /* == op-level entry points (parity tests of single kernels) =============== */
 /* matmulDispatch (go/model.go:361-386): out[rows] = W[rows,cols] @ x[cols],
  * W given as raw GGUF block bytes; x/out are host pointers.  Uses the same

@@ -121,8 +121,6 @@ struct nl_engine {
     size_t embd_bytes = 0;
     bool have_output = false;
     float *output_norm = nullptr;
-    // kept so a tied LM head can be packed at finalize
-    std::vector<uint8_t> embd_host;
 
     float *rope_cos = nullptr, *rope_sin = nullptr;
     float *x[2] = {nullptr, nullptr};
@@ -130,9 +128,19 @@ struct nl_engine {
     float *kcache = nullptr, *vcache = nullptr;
     long long kv_layer_stride = 0, kv_stream_stride = 0;
     int *ctl = nullptr, *ids = nullptr, *result = nullptr;
+    float *amax_val = nullptr;
+    int *amax_idx = nullptr;
+    int amax_slots = 0;
     int *h_ctl = nullptr;  // pinned staging
     int ids_cap = 0;
     size_t bytes_weights = 0, bytes_kv = 0, bytes_state = 0;
+
+    // weights live in a few large allocations (2 MiB-friendly) instead of one hipMalloc per tensor
+    std::vector<void *> arena_chunks;
+    char *arena_cur = nullptr;
+    size_t arena_left = 0;
+    uint8_t *stage = nullptr;  // grow-only device staging buffer for raw GGUF bytes
+    size_t stage_cap = 0;
 
     std::vector<Op> plan;
     hipGraph_t graph = nullptr;
@@ -167,6 +175,35 @@ hipError_t dalloc(T **p, size_t n, size_t *acct = nullptr) {
     return s;
 }
 
+hipError_t arena_alloc(nl_engine *e, void **out, size_t bytes) {
+    const size_t kChunk = (size_t)256 << 20;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes > e->arena_left) {
+        size_t sz = std::max(bytes, kChunk);
+        void *c = nullptr;
+        hipError_t s = hipMalloc(&c, sz);
+        if (s != hipSuccess) return s;
+        e->arena_chunks.push_back(c);
+        e->arena_cur = (char *)c;
+        e->arena_left = sz;
+    }
+    *out = e->arena_cur;
+    e->arena_cur += bytes;
+    e->arena_left -= bytes;
+    return hipSuccess;
+}
+
+hipError_t stage_reserve(nl_engine *e, size_t bytes) {
+    if (bytes <= e->stage_cap) return hipSuccess;
+    if (e->stage) hipFree(e->stage);
+    e->stage = nullptr;
+    e->stage_cap = 0;
+    size_t cap = std::max(bytes, (size_t)64 << 20);
+    hipError_t s = hipMalloc((void **)&e->stage, cap);
+    if (s == hipSuccess) e->stage_cap = cap;
+    return s;
+}
+
 // Re-pack a slice of a raw GGUF tensor (already on the device) into tiles
 // [tile0, tile0 + ntiles) of a PackedMat.
 hipError_t repack(nl_engine *e, PackedMat &m, const uint8_t *d_src, int wtype, int src_cols, int row0, int nrows,
@@ -196,10 +233,10 @@ hipError_t alloc_packed(nl_engine *e, PackedMat &m, int wtype, int rows_padded_t
     m.npairs = (cols + PAIR - 1) / PAIR;
     m.q_bytes = (size_t)m.ntiles * m.npairs * chunks_per_pair(wtype) * TR * 16;
     m.s_bytes = is_scaled(wtype) ? (size_t)m.ntiles * m.npairs * TR * 4 : 0;
-    hipError_t s = hipMalloc((void **)&m.q, m.q_bytes);
+    hipError_t s = arena_alloc(e, (void **)&m.q, m.q_bytes);
     if (s != hipSuccess) return s;
     if (m.s_bytes) {
-        s = hipMalloc((void **)&m.s, m.s_bytes);
+        s = arena_alloc(e, (void **)&m.s, m.s_bytes);
         if (s != hipSuccess) return s;
     }
     e->bytes_weights += m.q_bytes + m.s_bytes;
@@ -207,13 +244,16 @@ hipError_t alloc_packed(nl_engine *e, PackedMat &m, int wtype, int rows_padded_t
 }
 
 void choose_geometry(const nl_engine *e, const PackedMat &m, int &tw, int &kw) {
-    int steps = (m.npairs + KL - 1) / KL;  // wave-steps per tile when kw == 1
-    kw = 1;
-    while (m.ntiles * kw < 1024 && kw * 2 <= steps && kw < 8) kw *= 2;
+    // kw wavefronts share a tile's 256-column groups, tw tiles share a workgroup.  Aim for >= ~2048
+    // wavefronts in flight (8 per CU); small matrices go all the way to one group per wavefront,
+    // which is what minimises the in-launch latency of small models.
+    const int ngroups = (m.npairs + KL - 1) / KL;
+    kw = (2048 + m.ntiles - 1) / std::max(1, m.ntiles);
+    kw = std::max(1, std::min(kw, std::min(ngroups, 8)));  // workgroups are capped at 8 wavefronts (256 VGPRs each)
     tw = std::max(1, 4 / kw);
-    if (e->kw_override > 0) kw = e->kw_override;
+    if (e->kw_override > 0) kw = std::min(e->kw_override, 8);
     if (e->tw_override > 0) tw = e->tw_override;
-    if (tw * kw > 16) tw = std::max(1, 16 / kw);
+    if (tw * kw > 8) tw = std::max(1, 8 / kw);
     if (tw > m.ntiles) tw = m.ntiles;
 }
 
@@ -221,7 +261,7 @@ template <int PRO, int EPI>
 hipError_t launch_gemv_t(int wtype, GemvParams P, hipStream_t st) {
     const int nm = EPI == EPI_SWIGLU ? 2 : 1;
     const int nwaves = P.tw * P.kw;
-    const size_t lds = (size_t)P.npairs * PAIR * 4 + (size_t)nm * nwaves * TR * 4 + (size_t)nwaves * 8;
+    const size_t lds = (size_t)nwaves * XS_WAVE * 4 + (size_t)nm * nwaves * TR * 4 + (size_t)nwaves * 8;
     const dim3 grid((P.ntiles + P.tw - 1) / P.tw), block(nwaves * 64);
     switch (wtype) {
     case WT_Q8_0: hipLaunchKernelGGL((gemv_kernel<WT_Q8_0, PRO, EPI>), grid, block, lds, st, P); break;
@@ -272,6 +312,7 @@ void build_plan(nl_engine *e) {
     const nl_config &c = e->cfg;
     const bool tp = e->G > 1;
     int cur = 0;
+    int lm_blocks = 0, lm_spb = 1;
     const float *pending = nullptr;  // all-reduced partial still to be added to the residual stream
 
     {
@@ -307,7 +348,7 @@ void build_plan(nl_engine *e) {
         }
         {   // GQA attention over the cache (go/model.go:557-587)
             AttnParams P{e->qbuf, kc, vc, e->kv_stream_stride, e->part_o, e->part_ml, e->ctl,
-                         e->KVs, c.seq_len, e->nsplit_max, (float)(1.0 / std::sqrt((double)e->hd))};
+                         e->KVs, c.seq_len, e->nsplit_max, (float)(1.0 / std::sqrt((double)e->hd)), c.max_streams == 1 ? 1 : 0};
             dim3 grid(e->KVs, e->nsplit_max);
             int hd = e->hd, gqa = e->gqa;
             e->plan.push_back({K_ATTN, 0, nullptr, 0,
@@ -359,12 +400,16 @@ void build_plan(nl_engine *e) {
         P.x = e->x[cur]; P.normw = e->output_norm;
         if (pending) { P.add = pending; P.x_out = e->x[cur ^ 1]; }
         P.out = e->logits + (size_t)e->rank * e->Vs;
+        if (!tp) { P.amax_val = e->amax_val; P.amax_idx = e->amax_idx; }
         int wt = e->lm_head.wtype;
+        lm_blocks = (P.ntiles + P.tw - 1) / P.tw;
+        lm_spb = (P.tw * TR + 63) / 64;
         e->plan.push_back({K_LMHEAD, tp ? 2 : 0, e->logits, (size_t)e->Vs,
                            [wt, P](hipStream_t st) { return launch_gemv_t<PRO_NORM, EPI_STORE>(wt, P, st); }});
     }
     {
-        ArgmaxParams P{e->logits, c.vocab, e->ctl, e->ids, e->result};
+        ArgmaxParams P{e->logits, c.vocab, tp ? nullptr : e->amax_val, e->amax_idx, lm_blocks * lm_spb, e->ctl, e->ids,
+                       e->result};
         e->plan.push_back({K_ARGMAX, 0, nullptr, 0, [P](hipStream_t st) {
                                hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, P);
                                return hipGetLastError();
@@ -545,13 +590,15 @@ int nl_upload_tensor(nl_handle e, const char *name, uint32_t type, const void *d
         } else if (m.wtype != (int)type) {
             return e->fail(NL_ERR_UNSUPPORTED, "tensor %s: q/k/v (or gate/up) of one layer must share a type", name);
         }
-        uint8_t *d_raw = nullptr;
-        HIPCK(e, hipMalloc((void **)&d_raw, nbytes));
-        hipError_t s = hipMemcpyAsync(d_raw, data, nbytes, hipMemcpyHostToDevice, e->stream);
-        if (s == hipSuccess) s = repack(e, m, d_raw, (int)type, exp_cols, row0, nrows, col0, ncols, tile0,
+        // row-sliced tensors (tensor-parallel shards) only move their own rows to the device
+        const size_t row_bytes = raw_bytes(type, (uint64_t)exp_cols);
+        const uint8_t *src = (const uint8_t *)data + (size_t)row0 * row_bytes;
+        const size_t copy_bytes = (size_t)nrows * row_bytes;
+        HIPCK(e, stage_reserve(e, copy_bytes));
+        hipError_t s = hipMemcpyAsync(e->stage, src, copy_bytes, hipMemcpyHostToDevice, e->stream);
+        if (s == hipSuccess) s = repack(e, m, e->stage, (int)type, exp_cols, 0, nrows, col0, ncols, tile0,
                                         rowmap == ROWMAP_HEADPERM ? nrows / TR : (nrows + TR - 1) / TR, rowmap);
         if (s == hipSuccess) s = hipStreamSynchronize(e->stream);
-        hipFree(d_raw);
         if (s != hipSuccess) return e->fail(NL_ERR_HIP, "upload %s: %s", name, hipGetErrorString(s));
         return NL_OK;
     };
@@ -564,7 +611,6 @@ int nl_upload_tensor(nl_handle e, const char *name, uint32_t type, const void *d
             HIPCK(e, hipMalloc((void **)&e->embd_raw, nbytes));
             HIPCK(e, hipMemcpy(e->embd_raw, data, nbytes, hipMemcpyHostToDevice));
             e->embd_type = (int)type; e->embd_bytes = nbytes; e->bytes_weights += nbytes;
-            if (!e->have_output) e->embd_host.assign((const uint8_t *)data, (const uint8_t *)data + nbytes);
             return NL_OK;
         }
         if (f == "output_norm.weight") return norm_upload(&e->output_norm);
@@ -573,7 +619,6 @@ int nl_upload_tensor(nl_handle e, const char *name, uint32_t type, const void *d
                                    ROWMAP_IDENT, true);
             if (rc) return rc;
             e->lm_head.ready = true; e->have_output = true;
-            e->embd_host.clear(); e->embd_host.shrink_to_fit();
             return NL_OK;
         }
         return e->fail(NL_ERR_INVALID, "unknown tensor %s", name);
@@ -646,7 +691,6 @@ int nl_finalize(nl_handle e) {
         HIPCK(e, repack(e, m, e->embd_raw, e->embd_type, c.dim, e->rank * e->Vs, e->Vs, 0, c.dim, 0, m.ntiles, ROWMAP_IDENT));
         HIPCK(e, hipStreamSynchronize(e->stream));
         m.ready = true;
-        e->embd_host.clear(); e->embd_host.shrink_to_fit();
     }
     // precomputeRoPE go/model.go:346-358 (float64 math, cast to float32)
     const int half = e->hd / 2;
@@ -683,10 +727,14 @@ int nl_finalize(nl_handle e) {
     HIPCK(e, dalloc(&e->ctl, (size_t)CTL_WORDS, &e->bytes_state));
     HIPCK(e, dalloc(&e->ids, (size_t)e->ids_cap, &e->bytes_state));
     HIPCK(e, dalloc(&e->result, (size_t)1, &e->bytes_state));
+    e->amax_slots = ((e->Vs + TR - 1) / TR) + 64;  // >= one slot per wave of LM-head rows for any tw
+    HIPCK(e, dalloc(&e->amax_val, (size_t)e->amax_slots, &e->bytes_state));
+    HIPCK(e, dalloc(&e->amax_idx, (size_t)e->amax_slots, &e->bytes_state));
     HIPCK(e, hipHostMalloc((void **)&e->h_ctl, CTL_WORDS * sizeof(int), hipHostMallocDefault));
     memset(e->h_ctl, 0, CTL_WORDS * sizeof(int));
     HIPCK(e, hipMemcpy(e->ctl, e->h_ctl, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice));
     if (e->G > 1 && !e->comm) return e->fail(NL_ERR_STATE, "tp_size %d needs nl_comm_init before nl_finalize", e->G);
+    if (e->stage) { hipFree(e->stage); e->stage = nullptr; e->stage_cap = 0; }
     build_plan(e);
     HIPCK(e, hipStreamSynchronize(e->stream));
     if (e->use_graph && e->G == 1) {
@@ -703,15 +751,15 @@ int nl_destroy(nl_handle e) {
     hipDeviceSynchronize();
     if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
     if (e->graph) hipGraphDestroy(e->graph);
-    auto fm = [](PackedMat &m) { if (m.q) hipFree(m.q); if (m.s) hipFree(m.s); };
     for (auto &L : e->layers) {
-        fm(L.qkv); fm(L.wo); fm(L.gate); fm(L.up); fm(L.down);
         if (L.attn_norm) hipFree(L.attn_norm);
         if (L.ffn_norm) hipFree(L.ffn_norm);
     }
-    fm(e->lm_head);
+    for (void *c : e->arena_chunks) hipFree(c);
+    if (e->stage) hipFree(e->stage);
     void *bufs[] = {e->embd_raw, e->output_norm, e->rope_cos, e->rope_sin, e->x[0], e->x[1], e->qbuf, e->part_o,
-                    e->part_ml, e->hb, e->ar, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result};
+                    e->part_ml, e->hb, e->ar, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result, e->amax_val,
+                    e->amax_idx};
     for (void *b : bufs) if (b) hipFree(b);
     if (e->h_ctl) hipHostFree(e->h_ctl);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
@@ -797,34 +845,32 @@ int nl_timer_stop(nl_handle e, float *ms) {
 const char *nl_kernel_kind_name(int k) { return (k >= 0 && k < NL_NUM_KINDS) ? kKindNames[k] : ""; }
 
 int nl_profile_forward(nl_handle e, int stream, int token, int pos, int iters, float *ms_out, int *calls_out) {
+    // One eager Forward to put valid data in every buffer, then every launch of the plan is replayed
+    // `iters` times back to back between two HIP events on the engine's stream: per-launch time =
+    // elapsed / iters (this includes the dependent-launch boundary, ~1-2 us, which a single short kernel
+    // cannot be timed without; profiles/ holds the rocprofv3 pure-kernel durations).
     if (!e || !ms_out || !calls_out || iters <= 0) return NL_ERR_INVALID;
     int rc = check_step_args(e, stream, token, pos);
     if (rc) return rc;
     HIPCK(e, hipSetDevice(e->dev));
-    const size_t nops = e->plan.size();
-    std::vector<hipEvent_t> ev(nops + 1);
-    for (auto &v : ev) HIPCK(e, hipEventCreate(&v));
     for (int k = 0; k < NL_NUM_KINDS; k++) { ms_out[k] = 0.f; calls_out[k] = 0; }
-    for (int it = 0; it < iters; it++) {
-        if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
-        HIPCK(e, hipEventRecord(ev[0], e->stream));
-        for (size_t i = 0; i < nops; i++) {
-            const Op &op = e->plan[i];
+    if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
+    if ((rc = run_plan_eager(e))) return rc;
+    HIPCK(e, hipStreamSynchronize(e->stream));
+    for (const Op &op : e->plan) {
+        HIPCK(e, hipEventRecord(e->ev0, e->stream));
+        for (int it = 0; it < iters; it++) {
             hipError_t s = op.fn(e->stream);
             if (s != hipSuccess) return e->fail(NL_ERR_HIP, "launch %s: %s", kKindNames[op.kind], hipGetErrorString(s));
             if ((rc = run_collective(e, op))) return rc;
-            HIPCK(e, hipEventRecord(ev[i + 1], e->stream));
         }
-        HIPCK(e, hipStreamSynchronize(e->stream));
-        for (size_t i = 0; i < nops; i++) {
-            float ms = 0.f;
-            HIPCK(e, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
-            ms_out[e->plan[i].kind] += ms;
-            if (it == 0) calls_out[e->plan[i].kind]++;
-        }
+        HIPCK(e, hipEventRecord(e->ev1, e->stream));
+        HIPCK(e, hipEventSynchronize(e->ev1));
+        float ms = 0.f;
+        HIPCK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        ms_out[op.kind] += ms / (float)iters;
+        calls_out[op.kind]++;
     }
-    for (int k = 0; k < NL_NUM_KINDS; k++) ms_out[k] /= (float)iters;
-    for (auto &v : ev) hipEventDestroy(v);
     return NL_OK;
 }
 
@@ -854,6 +900,33 @@ int64_t nl_debug_read(nl_handle e, const char *which, int stream, float *out, in
         hipMemcpy(out, src, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
         return e->fail(NL_ERR_HIP, "debug read failed");
     return n;
+}
+
+// Phase timestamps (shader clock) of workgroup 0 for GEMV kind `kind` of layer 0; tools/ only.
+int nl_debug_stamps(nl_handle e, int kind, long long *out /* 16 waves x 8 */) {
+    if (!e || !e->finalized || !out) return NL_ERR_INVALID;
+    HIPCK(e, hipSetDevice(e->dev));
+    long long *d = nullptr;
+    HIPCK(e, hipMalloc((void **)&d, 128 * sizeof(long long)));
+    HIPCK(e, hipMemset(d, 0, 128 * sizeof(long long)));
+    const nl_config &c = e->cfg;
+    nl_engine::Layer &L = e->layers[0];
+    hipError_t s = hipErrorInvalidValue;
+    if (kind == K_GATEUP) {
+        GemvParams P = base_params(e, L.gate);
+        P.q1 = L.up.q; P.s1 = L.up.s; P.x = e->x[0]; P.normw = L.ffn_norm; P.out = e->hb; P.dbg = d;
+        s = launch_gemv_t<PRO_NORM, EPI_SWIGLU>(L.gate.wtype, P, e->stream);
+    } else if (kind == K_DOWN) {
+        GemvParams P = base_params(e, L.down);
+        P.x = e->hb; P.out = e->x[1]; P.resid = e->x[1]; P.dbg = d;
+        s = launch_gemv_t<PRO_PLAIN, EPI_RESID>(L.down.wtype, P, e->stream);
+    }
+    (void)c;
+    if (s != hipSuccess) { hipFree(d); return e->fail(NL_ERR_HIP, "debug launch: %s", hipGetErrorString(s)); }
+    HIPCK(e, hipStreamSynchronize(e->stream));
+    HIPCK(e, hipMemcpy(out, d, 128 * sizeof(long long), hipMemcpyDeviceToHost));
+    hipFree(d);
+    return NL_OK;
 }
 
 // ---- op-level entry points ---------------------------------------------------
@@ -892,8 +965,7 @@ int nl_op_matmul(int device, uint32_t type, const void *w, uint64_t nbytes, cons
         if (hipStreamSynchronize(st) != hipSuccess) break;
         rc = NL_OK;
     } while (0);
-    if (m.q) hipFree(m.q);
-    if (m.s) hipFree(m.s);
+    for (void *c : tmp.arena_chunks) hipFree(c);
     if (d_raw) hipFree(d_raw);
     if (d_x) hipFree(d_x);
     if (d_out) hipFree(d_out);

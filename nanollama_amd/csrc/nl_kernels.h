@@ -4,17 +4,18 @@
 // weights, single-token GQA attention); there is deliberately no MFMA.
 //
 // Weight layout ("row-interleaved tiles", built once at upload by repack_kernel):
-//   a tile = TR(16) consecutive output rows; a pair = two 32-element quant
-//   blocks (64 columns).  For tile t, pair p, 16-byte chunk c, row-in-tile r:
-//       quants : ((t*npairs + p)*CPP + c)*TR + r   (x 16 bytes)
-//       scales : (t*npairs + p)*TR + r             (x 4 bytes: two fp16 d)
+//   a tile  = TR(16) consecutive output rows;
+//   a pair  = two 32-element quant blocks (64 columns);
+//   a group = KL(4) consecutive pairs (256 columns); the last group of a row may hold 1-3 pairs.
+//   For tile t, group g (gsz pairs), 16-byte chunk c of the pair, row-in-tile r, pair-in-group k:
+//       quants : t*npairs*CPP*TR + g*KL*CPP*TR + (c*TR + r)*gsz + k     (x 16 bytes)
+//       scales : t*npairs*TR     + g*KL*TR     +  r*gsz + k             (x 4 bytes: two fp16 d)
 //   CPP = chunks per pair = 4 (Q8_0), 2 (Q4_0), 8 (F16), 16 (F32).
-//   A wavefront owns one tile; lane = (kl, r) with r = lane & 15 the row and
-//   kl = lane >> 4 one of 4 "k-lanes" walking the pairs.  Every global load
-//   instruction therefore reads four 256-byte runs, each lane accumulates whole
-//   blocks of its own row (dot over 32 in-register, then * d, as
-//   go/quant.go:149-165 / :74-94 do per block), and the only cross-lane work
-//   is two shuffles per tile.  The fp16 scale bits are kept verbatim.
+//   A wavefront owns one tile and walks groups; lane = r*4 + k.  Every global load instruction of
+//   a wavefront is therefore ONE contiguous 1 KiB run, each lane accumulates whole blocks of its
+//   own row (dot over 32 in-register, then * d, as go/quant.go:149-165 / :74-94 do per block), the
+//   four partial sums of a row sit in one quad (two DPP adds), and no padding bytes are stored.
+//   The fp16 scale bits are kept verbatim.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -71,15 +72,19 @@ __device__ __forceinline__ int map_row(int rowmap, int head_dim, int tile, int r
 
 __global__ void repack_kernel(RepackParams P) {
     const int cpp = P.wtype == WT_Q8_0 ? 4 : P.wtype == WT_Q4_0 ? 2 : P.wtype == WT_F16 ? 8 : 16;
-    const long long nchunks = (long long)P.ntiles * P.npairs * cpp * TR;
+    const int per_tile = P.npairs * cpp * TR;
+    const long long nchunks = (long long)P.ntiles * per_tile;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < nchunks;
          idx += (long long)gridDim.x * blockDim.x) {
-        int r = (int)(idx % TR);
-        long long t1 = idx / TR;
-        int c = (int)(t1 % cpp);
-        long long t2 = t1 / cpp;
-        int p = (int)(t2 % P.npairs);
-        int tile = (int)(t2 / P.npairs);
+        const int tile = (int)(idx / per_tile);
+        int rem = (int)(idx - (long long)tile * per_tile);
+        const int g = rem / (KL * cpp * TR);
+        rem -= g * (KL * cpp * TR);
+        const int gsz = min(KL, P.npairs - g * KL);
+        const int k = rem % gsz;
+        rem /= gsz;
+        const int r = rem % TR, c = rem / TR;
+        const int p = g * KL + k;
         int row = map_row(P.rowmap, P.head_dim, tile, r);
         uint4 v = make_uint4(0, 0, 0, 0);
         uint8_t *vb = reinterpret_cast<uint8_t *>(&v);
@@ -89,22 +94,22 @@ __global__ void repack_kernel(RepackParams P) {
                 int b = 2 * p + (c >> 1);
                 if (b * 32 < P.ncols) {
                     const uint8_t *blk = P.src + (srow * (P.src_cols / 32) + (P.col0 / 32 + b)) * 34;
-                    for (int k = 0; k < 16; k++) vb[k] = blk[2 + (c & 1) * 16 + k];
+                    for (int j = 0; j < 16; j++) vb[j] = blk[2 + (c & 1) * 16 + j];
                 }
             } else if (P.wtype == WT_Q4_0) {
                 int b = 2 * p + c;
                 if (b * 32 < P.ncols) {
                     const uint8_t *blk = P.src + (srow * (P.src_cols / 32) + (P.col0 / 32 + b)) * 18;
-                    for (int k = 0; k < 16; k++) vb[k] = blk[2 + k];
+                    for (int j = 0; j < 16; j++) vb[j] = blk[2 + j];
                 }
             } else {
                 int esz = P.wtype == WT_F16 ? 2 : 4;
                 int per = 16 / esz;
                 int e0 = p * PAIR + c * per;
                 const uint8_t *sp = P.src + (srow * P.src_cols + P.col0 + e0) * esz;
-                for (int k = 0; k < per; k++)
-                    if (e0 + k < P.ncols)
-                        for (int bb = 0; bb < esz; bb++) vb[k * esz + bb] = sp[k * esz + bb];
+                for (int j = 0; j < per; j++)
+                    if (e0 + j < P.ncols)
+                        for (int bb = 0; bb < esz; bb++) vb[j * esz + bb] = sp[j * esz + bb];
             }
         }
         reinterpret_cast<uint4 *>(P.q)[idx] = v;
@@ -121,19 +126,22 @@ __global__ void repack_kernel(RepackParams P) {
                     }
                 }
             }
-            P.s[((long long)tile * P.npairs + p) * TR + r] = sc;
+            P.s[(long long)tile * P.npairs * TR + g * KL * TR + r * gsz + k] = sc;
         }
     }
 }
 
 // ------------------------------------------------------------- pair dots ---
 
-__device__ __forceinline__ float dot4_i8(uint32_t w, float4 x, float acc) {
-    acc = fmaf((float)(int)(int8_t)(w & 0xff), x.x, acc);
-    acc = fmaf((float)(int)(int8_t)((w >> 8) & 0xff), x.y, acc);
-    acc = fmaf((float)(int)(int8_t)((w >> 16) & 0xff), x.z, acc);
-    acc = fmaf((float)(int)(int8_t)(w >> 24), x.w, acc);
-    return acc;
+// Four independent accumulators per 32-element block: a lone wavefront on a SIMD (small models keep
+// the chip nearly empty) is bound by the dependent-FMA chain, not by issue rate.
+struct Acc4 { float a, b, c, d; };
+
+__device__ __forceinline__ void dot4_i8(uint32_t w, float4 x, Acc4 &s) {
+    s.a = fmaf((float)(int)(int8_t)(w & 0xff), x.x, s.a);
+    s.b = fmaf((float)(int)(int8_t)((w >> 8) & 0xff), x.y, s.b);
+    s.c = fmaf((float)(int)(int8_t)((w >> 16) & 0xff), x.z, s.c);
+    s.d = fmaf((float)(int)(int8_t)(w >> 24), x.w, s.d);
 }
 
 template <int WT> struct PairDot;
@@ -144,34 +152,33 @@ template <> struct PairDot<WT_Q8_0> {
         const float4 *x4 = reinterpret_cast<const float4 *>(xp);
 #pragma unroll
         for (int b = 0; b < 2; b++) {
-            float dot = 0.f;
+            Acc4 s{0.f, 0.f, 0.f, 0.f};
             uint4 lo = c[2 * b], hi = c[2 * b + 1];
-            dot = dot4_i8(lo.x, x4[8 * b + 0], dot);
-            dot = dot4_i8(lo.y, x4[8 * b + 1], dot);
-            dot = dot4_i8(lo.z, x4[8 * b + 2], dot);
-            dot = dot4_i8(lo.w, x4[8 * b + 3], dot);
-            dot = dot4_i8(hi.x, x4[8 * b + 4], dot);
-            dot = dot4_i8(hi.y, x4[8 * b + 5], dot);
-            dot = dot4_i8(hi.z, x4[8 * b + 6], dot);
-            dot = dot4_i8(hi.w, x4[8 * b + 7], dot);
-            acc = fmaf(dot, h2f_bits((sc >> (16 * b)) & 0xffff), acc);
+            dot4_i8(lo.x, x4[8 * b + 0], s);
+            dot4_i8(lo.y, x4[8 * b + 1], s);
+            dot4_i8(lo.z, x4[8 * b + 2], s);
+            dot4_i8(lo.w, x4[8 * b + 3], s);
+            dot4_i8(hi.x, x4[8 * b + 4], s);
+            dot4_i8(hi.y, x4[8 * b + 5], s);
+            dot4_i8(hi.z, x4[8 * b + 6], s);
+            dot4_i8(hi.w, x4[8 * b + 7], s);
+            acc = fmaf((s.a + s.b) + (s.c + s.d), h2f_bits((sc >> (16 * b)) & 0xffff), acc);
         }
         return acc;
     }
 };
 
-__device__ __forceinline__ float dot_q4_word(uint32_t w, float4 xl, float4 xh, float acc) {
+__device__ __forceinline__ void dot_q4_word(uint32_t w, float4 xl, float4 xh, Acc4 &s) {
     // byte k of w: low nibble = element k, high nibble = element k+16 (go/quant.go:84-88)
     uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;
-    acc = fmaf((float)(int)(lo & 0xff) - 8.f, xl.x, acc);
-    acc = fmaf((float)(int)(hi & 0xff) - 8.f, xh.x, acc);
-    acc = fmaf((float)(int)((lo >> 8) & 0xff) - 8.f, xl.y, acc);
-    acc = fmaf((float)(int)((hi >> 8) & 0xff) - 8.f, xh.y, acc);
-    acc = fmaf((float)(int)((lo >> 16) & 0xff) - 8.f, xl.z, acc);
-    acc = fmaf((float)(int)((hi >> 16) & 0xff) - 8.f, xh.z, acc);
-    acc = fmaf((float)(int)(lo >> 24) - 8.f, xl.w, acc);
-    acc = fmaf((float)(int)(hi >> 24) - 8.f, xh.w, acc);
-    return acc;
+    s.a = fmaf((float)(int)(lo & 0xff) - 8.f, xl.x, s.a);
+    s.b = fmaf((float)(int)(hi & 0xff) - 8.f, xh.x, s.b);
+    s.c = fmaf((float)(int)((lo >> 8) & 0xff) - 8.f, xl.y, s.c);
+    s.d = fmaf((float)(int)((hi >> 8) & 0xff) - 8.f, xh.y, s.d);
+    s.a = fmaf((float)(int)((lo >> 16) & 0xff) - 8.f, xl.z, s.a);
+    s.b = fmaf((float)(int)((hi >> 16) & 0xff) - 8.f, xh.z, s.b);
+    s.c = fmaf((float)(int)(lo >> 24) - 8.f, xl.w, s.c);
+    s.d = fmaf((float)(int)(hi >> 24) - 8.f, xh.w, s.d);
 }
 
 template <> struct PairDot<WT_Q4_0> {
@@ -179,13 +186,13 @@ template <> struct PairDot<WT_Q4_0> {
         const float4 *x4 = reinterpret_cast<const float4 *>(xp);
 #pragma unroll
         for (int b = 0; b < 2; b++) {
-            float dot = 0.f;
+            Acc4 s{0.f, 0.f, 0.f, 0.f};
             uint4 q = c[b];
-            dot = dot_q4_word(q.x, x4[8 * b + 0], x4[8 * b + 4], dot);
-            dot = dot_q4_word(q.y, x4[8 * b + 1], x4[8 * b + 5], dot);
-            dot = dot_q4_word(q.z, x4[8 * b + 2], x4[8 * b + 6], dot);
-            dot = dot_q4_word(q.w, x4[8 * b + 3], x4[8 * b + 7], dot);
-            acc = fmaf(dot, h2f_bits((sc >> (16 * b)) & 0xffff), acc);
+            dot_q4_word(q.x, x4[8 * b + 0], x4[8 * b + 4], s);
+            dot_q4_word(q.y, x4[8 * b + 1], x4[8 * b + 5], s);
+            dot_q4_word(q.z, x4[8 * b + 2], x4[8 * b + 6], s);
+            dot_q4_word(q.w, x4[8 * b + 3], x4[8 * b + 7], s);
+            acc = fmaf((s.a + s.b) + (s.c + s.d), h2f_bits((sc >> (16 * b)) & 0xffff), acc);
         }
         return acc;
     }
@@ -194,36 +201,38 @@ template <> struct PairDot<WT_Q4_0> {
 template <> struct PairDot<WT_F16> {
     static __device__ __forceinline__ float run(const uint4 *c, uint32_t, const float *xp, float acc) {
         const float4 *x4 = reinterpret_cast<const float4 *>(xp);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             uint4 q = c[k];
             float4 a = x4[2 * k], b = x4[2 * k + 1];
-            acc = fmaf(h2f_bits(q.x & 0xffff), a.x, acc);
-            acc = fmaf(h2f_bits(q.x >> 16), a.y, acc);
-            acc = fmaf(h2f_bits(q.y & 0xffff), a.z, acc);
-            acc = fmaf(h2f_bits(q.y >> 16), a.w, acc);
-            acc = fmaf(h2f_bits(q.z & 0xffff), b.x, acc);
-            acc = fmaf(h2f_bits(q.z >> 16), b.y, acc);
-            acc = fmaf(h2f_bits(q.w & 0xffff), b.z, acc);
-            acc = fmaf(h2f_bits(q.w >> 16), b.w, acc);
+            a0 = fmaf(h2f_bits(q.x & 0xffff), a.x, a0);
+            a1 = fmaf(h2f_bits(q.x >> 16), a.y, a1);
+            a2 = fmaf(h2f_bits(q.y & 0xffff), a.z, a2);
+            a3 = fmaf(h2f_bits(q.y >> 16), a.w, a3);
+            a0 = fmaf(h2f_bits(q.z & 0xffff), b.x, a0);
+            a1 = fmaf(h2f_bits(q.z >> 16), b.y, a1);
+            a2 = fmaf(h2f_bits(q.w & 0xffff), b.z, a2);
+            a3 = fmaf(h2f_bits(q.w >> 16), b.w, a3);
         }
-        return acc;
+        return acc + ((a0 + a1) + (a2 + a3));
     }
 };
 
 template <> struct PairDot<WT_F32> {
     static __device__ __forceinline__ float run(const uint4 *c, uint32_t, const float *xp, float acc) {
         const float4 *x4 = reinterpret_cast<const float4 *>(xp);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             uint4 q = c[k];
             float4 a = x4[k];
-            acc = fmaf(__uint_as_float(q.x), a.x, acc);
-            acc = fmaf(__uint_as_float(q.y), a.y, acc);
-            acc = fmaf(__uint_as_float(q.z), a.z, acc);
-            acc = fmaf(__uint_as_float(q.w), a.w, acc);
+            a0 = fmaf(__uint_as_float(q.x), a.x, a0);
+            a1 = fmaf(__uint_as_float(q.y), a.y, a1);
+            a2 = fmaf(__uint_as_float(q.z), a.z, a2);
+            a3 = fmaf(__uint_as_float(q.w), a.w, a3);
         }
-        return acc;
+        return acc + ((a0 + a1) + (a2 + a3));
     }
 };
 
@@ -254,176 +263,256 @@ struct GemvParams {
     float *kcache, *vcache;            // this layer, stream 0: [kv][seq][hd]
     long long kv_stream_stride;        // floats between streams
     int n_q_heads, n_kv_heads, seq_len, rope_conj;
+    // EPI_STORE: optional fused partial argmax (one slot per workgroup, or per wave when tw*16 > 64)
+    float *amax_val;
+    int *amax_idx;
+    long long *dbg;  // optional phase timestamps (clock64) written by workgroup 0, lane 0 of each wave
 };
 
+// ---- cross-lane helpers on DPP (hipcc lowers __shfl_xor to ds_bpermute: ~100+ cycles a hop) ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;   // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;   // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+// sum over the 4 lanes of each quad, result in every lane of the quad
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_f32<DPP_QUAD_XOR1>(v);
+    v += dpp_f32<DPP_QUAD_XOR2>(v);
+    return v;
+}
+// full-wave float64 sum, result valid in every lane
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v += dpp_f64<DPP_QUAD_XOR1>(v);
+    v += dpp_f64<DPP_QUAD_XOR2>(v);
+    v += dpp_f64<DPP_HALF_MIRROR>(v);
+    v += dpp_f64<DPP_ROW_MIRROR>(v);   // every lane: sum of its row of 16
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
     return v;
 }
 
+constexpr int XS_PAIR = PAIR + 4;            // LDS floats per pair (16-byte pad: the 4 pairs of a group hit distinct banks)
+constexpr int XS_WAVE = KL * XS_PAIR;        // LDS floats per wavefront (one 256-column group)
+
+// The 4 input-vector elements (columns col..col+3) this lane stages for its wavefront's current group.
 template <int PRO>
-__device__ __forceinline__ void stage_x(const GemvParams &P, float *xs, double *dred, int padded) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    if (PRO == PRO_PLAIN) {
-        for (int i = tid * 4; i < P.cols; i += nt * 4) {
-            float4 v = *reinterpret_cast<const float4 *>(P.x + i);
-            if (P.add) {
-                float4 a = *reinterpret_cast<const float4 *>(P.add + i);
-                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-            }
-            *reinterpret_cast<float4 *>(xs + i) = v;
+__device__ __forceinline__ float4 load_x4(const GemvParams &P, int col, float4 &g, int ns) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    g = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (col >= P.cols) return v;
+    if (PRO == PRO_ATTN) {
+        // merge the position-split attention partials (online softmax): x = sum_c w_c o_c / sum_c w_c l_c
+        const int hd = P.head_dim, h = col / hd, d = col - h * hd;
+        const float *ml = P.part_ml + (long long)h * P.nsplit_max * 2;
+        const float *po = P.part_o + (long long)h * P.nsplit_max * hd + d;
+        if (ns == 1) {
+            float4 o = *reinterpret_cast<const float4 *>(po);
+            float il = 1.0f / ml[1];
+            return make_float4(o.x * il, o.y * il, o.z * il, o.w * il);
         }
-    } else if (PRO == PRO_NORM) {
-        // RMSNormInto go/quant.go:597-607: float64 sum of squares, inv cast to f32, (x*inv)*w
-        double ss = 0.0;
-        for (int i = tid * 4; i < P.cols; i += nt * 4) {
-            float4 v = *reinterpret_cast<const float4 *>(P.x + i);
-            if (P.add) {
-                float4 a = *reinterpret_cast<const float4 *>(P.add + i);
-                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-            }
-            if (P.x_out && blockIdx.x == 0) *reinterpret_cast<float4 *>(P.x_out + i) = v;
-            *reinterpret_cast<float4 *>(xs + i) = v;
-            ss += (double)v.x * (double)v.x;
-            ss += (double)v.y * (double)v.y;
-            ss += (double)v.z * (double)v.z;
-            ss += (double)v.w * (double)v.w;
+        float M = ml[0];
+        for (int c = 1; c < ns; c++) M = fmaxf(M, ml[2 * c]);
+        float L = 0.f;
+        for (int c = 0; c < ns; c++) {
+            float w = (float)exp((double)(ml[2 * c] - M));
+            float4 o = *reinterpret_cast<const float4 *>(po + (long long)c * hd);
+            L += w * ml[2 * c + 1];
+            v.x += w * o.x; v.y += w * o.y; v.z += w * o.z; v.w += w * o.w;
         }
-        ss = wave_sum_f64(ss);
-        if ((tid & 63) == 0) dred[tid >> 6] = ss;
-        __syncthreads();
-        double tot = 0.0;
-        for (int w = 0; w < (nt >> 6); w++) tot += dred[w];
-        float inv = (float)(1.0 / sqrt(tot / (double)P.cols + (double)P.eps));
-        for (int i = tid * 4; i < P.cols; i += nt * 4) {
-            float4 v = *reinterpret_cast<float4 *>(xs + i);
-            float4 w = *reinterpret_cast<const float4 *>(P.normw + i);
-            v.x = (v.x * inv) * w.x;
-            v.y = (v.y * inv) * w.y;
-            v.z = (v.z * inv) * w.z;
-            v.w = (v.w * inv) * w.w;
-            *reinterpret_cast<float4 *>(xs + i) = v;
-        }
-    } else {
-        // combine the position-split attention partials (online-softmax merge)
-        const int pos = P.ctl[CTL_POS];
-        const int ns = pos / ATT_CH + 1;
-        const int hd = P.head_dim;
-        for (int i = tid; i < P.cols; i += nt) {
-            int h = i / hd, d = i - h * hd;
-            const float *ml = P.part_ml + (long long)h * P.nsplit_max * 2;
-            float M = ml[0];
-            for (int c = 1; c < ns; c++) M = fmaxf(M, ml[2 * c]);
-            float L = 0.f, o = 0.f;
-            for (int c = 0; c < ns; c++) {
-                float w = (float)exp((double)(ml[2 * c] - M));
-                L += w * ml[2 * c + 1];
-                o += w * P.part_o[((long long)h * P.nsplit_max + c) * hd + d];
-            }
-            xs[i] = o * (1.0f / L);
-        }
+        float il = 1.0f / L;
+        return make_float4(v.x * il, v.y * il, v.z * il, v.w * il);
     }
-    for (int i = P.cols + tid; i < padded; i += nt) xs[i] = 0.f;
-    __syncthreads();
+    v = *reinterpret_cast<const float4 *>(P.x + col);
+    if (PRO == PRO_NORM) g = *reinterpret_cast<const float4 *>(P.normw + col);
+    if (P.add) {
+        float4 a = *reinterpret_cast<const float4 *>(P.add + col);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    return v;
 }
 
 template <int WT>
-__device__ __forceinline__ void load_pair(const uint8_t *q, const uint32_t *s, long long pair_index, int r,
-                                          uint4 *c, uint32_t &sc) {
+__device__ __forceinline__ void load_pair(const uint8_t *q, const uint32_t *s, long long tile_pair0, int g, int gsz,
+                                          int r, int k, uint4 *c, uint32_t &sc) {
     constexpr int CPP = WTraits<WT>::CPP;
-    const uint4 *qp = reinterpret_cast<const uint4 *>(q) + pair_index * (CPP * TR) + r;
+    const uint4 *qp = reinterpret_cast<const uint4 *>(q) + tile_pair0 * (CPP * TR) + (long long)g * (KL * CPP * TR) + r * gsz + k;
 #pragma unroll
-    for (int k = 0; k < CPP; k++) c[k] = qp[k * TR];
-    sc = WTraits<WT>::SCALED ? s[pair_index * TR + r] : 0u;
+    for (int j = 0; j < CPP; j++) c[j] = qp[j * TR * gsz];
+    sc = WTraits<WT>::SCALED ? s[tile_pair0 * TR + g * (KL * TR) + r * gsz + k] : 0u;
 }
 
-// One wavefront = one 16-row tile x a 1/kw share of the columns; a workgroup
-// holds tw tiles x kw column shares.  See the layout comment at the top.
+// One wavefront = one 16-row tile x a 1/kw share of the 256-column groups; a workgroup holds
+// tw tiles x kw shares.  Decode kernels form a dependent-launch chain, so for small models the
+// critical path INSIDE a launch is what matters.  Per wavefront it is:
+//   issue {x slice, norm weights, weight chunks, scales} together  ->  one memory latency
+//   x*g -> wave-private LDS (no workgroup barrier) -> 128 cvt + 128 fma per lane (8 chains)
+//   quad DPP adds -> LDS -> ONE workgroup barrier -> epilogue (inputs prefetched at entry).
 template <int WT, int PRO, int EPI>
-__global__ void __launch_bounds__(1024) gemv_kernel(GemvParams P) {
+__global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CPP = WTraits<WT>::CPP;
     constexpr int NM = EPI == EPI_SWIGLU ? 2 : 1;
-    const int padded = P.npairs * PAIR;
-    float *xs = reinterpret_cast<float *>(smem);
-    float *red = xs + padded;                         // [NM][waves][TR]
     const int nwaves = blockDim.x >> 6;
+    float *xs_all = reinterpret_cast<float *>(smem);          // [waves][XS_WAVE]
+    float *red = xs_all + nwaves * XS_WAVE;                   // [NM][waves][TR]
     double *dred = reinterpret_cast<double *>(red + NM * nwaves * TR);  // [waves]
 
-    stage_x<PRO>(P, xs, dred, padded);
-
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = lane & (TR - 1), kl = lane >> 4;
-    const int tile = blockIdx.x * P.tw + wave / P.kw;
-    const int kw = wave % P.kw;
-    float acc0 = 0.f, acc1 = 0.f;
-    if (tile < P.ntiles) {
-        const long long tbase = (long long)tile * P.npairs;
-        const int stride = P.kw * KL;
-        int p = kw * KL + kl;
-        // two pairs in flight per lane
-        for (; p + stride < P.npairs; p += 2 * stride) {
-            uint4 ca[CPP], cb[CPP], ga[NM > 1 ? CPP : 1], gb[NM > 1 ? CPP : 1];
-            uint32_t sa, sb, ta = 0, tb = 0;
-            load_pair<WT>(P.q0, P.s0, tbase + p, r, ca, sa);
-            load_pair<WT>(P.q0, P.s0, tbase + p + stride, r, cb, sb);
-            if (NM > 1) {
-                load_pair<WT>(P.q1, P.s1, tbase + p, r, ga, ta);
-                load_pair<WT>(P.q1, P.s1, tbase + p + stride, r, gb, tb);
-            }
-            acc0 = PairDot<WT>::run(ca, sa, xs + p * PAIR, acc0);
-            if (NM > 1) acc1 = PairDot<WT>::run(ga, ta, xs + p * PAIR, acc1);
-            acc0 = PairDot<WT>::run(cb, sb, xs + (p + stride) * PAIR, acc0);
-            if (NM > 1) acc1 = PairDot<WT>::run(gb, tb, xs + (p + stride) * PAIR, acc1);
-        }
-        if (p < P.npairs) {
-            uint4 ca[CPP], ga[NM > 1 ? CPP : 1];
-            uint32_t sa, ta = 0;
-            load_pair<WT>(P.q0, P.s0, tbase + p, r, ca, sa);
-            if (NM > 1) load_pair<WT>(P.q1, P.s1, tbase + p, r, ga, ta);
-            acc0 = PairDot<WT>::run(ca, sa, xs + p * PAIR, acc0);
-            if (NM > 1) acc1 = PairDot<WT>::run(ga, ta, xs + p * PAIR, acc1);
-        }
-    }
-    // k-lanes -> row sums (lanes 0..15 of each wave)
-    acc0 += __shfl_xor(acc0, 16);
-    acc0 += __shfl_xor(acc0, 32);
-    if (NM > 1) {
-        acc1 += __shfl_xor(acc1, 16);
-        acc1 += __shfl_xor(acc1, 32);
-    }
-    if (lane < TR) {
-        red[wave * TR + lane] = acc0;
-        if (NM > 1) red[(nwaves + wave) * TR + lane] = acc1;
-    }
-    __syncthreads();
+#define NL_STAMP(k) do { if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + (k)] = clock64(); } while (0)
+    NL_STAMP(0);
+    const int r = lane >> 2, k = lane & 3;
+    const int tin = wave / P.kw, kw = wave - tin * P.kw;
+    const int tile = blockIdx.x * P.tw + tin;
+    const bool live = tile < P.ntiles;
+    const long long tp0 = (long long)(live ? tile : 0) * P.npairs;
+    const int ngroups = (P.npairs + KL - 1) / KL;
+    float *xs = xs_all + wave * XS_WAVE;
 
+    // ---- epilogue inputs, fetched now so their latency hides under the weight stream ----
     const int t = threadIdx.x;
-    if (t >= P.tw * TR) return;
-    const int tin = t / TR, rr = t % TR;
-    const int otile = blockIdx.x * P.tw + tin;
-    if (otile >= P.ntiles) return;
+    const int nact = P.tw * TR;
+    const int e_tin = t / TR, e_rr = t % TR;
+    const int e_tile = blockIdx.x * P.tw + e_tin;
+    const bool e_act = t < nact && e_tile < P.ntiles;
+    float e_resid = 0.f, e_cos = 0.f, e_sin = 0.f;
+    int e_pos = 0;
+    if (EPI == EPI_RESID) {
+        if (e_act && e_tile * TR + e_rr < P.rows) e_resid = P.resid[e_tile * TR + e_rr];
+    }
+    if (EPI == EPI_QKV) {
+        if (e_act) {
+            e_pos = P.ctl[CTL_POS];
+            const int half = P.head_dim >> 1, tph = P.head_dim / 16;
+            const int i = (e_tile % tph) * 8 + (e_rr & 7);
+            e_cos = P.rope_cos[e_pos * half + i];
+            e_sin = P.rope_sin[e_pos * half + i];
+        }
+    }
+    int ns = 1;
+    if (PRO == PRO_ATTN) ns = P.ctl[CTL_POS] / ATT_CH + 1;
+
+    float acc0 = 0.f, acc1 = 0.f;
+    double ss = 0.0;
+    NL_STAMP(1);
+    // two groups in flight per wavefront where the registers allow it
+    constexpr bool TWO = !(NM > 1 || CPP > 8);
+    for (int g = kw; g < ngroups; g += (TWO ? 2 : 1) * P.kw) {
+        const int gb = g + P.kw;
+        const bool hasb = TWO && gb < ngroups;
+        const int gsa = min(KL, P.npairs - g * KL), gsb = hasb ? min(KL, P.npairs - gb * KL) : 0;
+        float4 ga4, gb4;
+        float4 xa = load_x4<PRO>(P, g * (KL * PAIR) + lane * 4, ga4, ns);
+        float4 xb = hasb ? load_x4<PRO>(P, gb * (KL * PAIR) + lane * 4, gb4, ns) : make_float4(0.f, 0.f, 0.f, 0.f);
+        uint4 ca[CPP], cb[CPP], ua[NM > 1 ? CPP : 1], ub[NM > 1 ? CPP : 1];
+        uint32_t sa = 0, sb = 0, ta = 0, tb = 0;
+        const bool la = live && k < gsa, lb = live && k < gsb;
+        if (la) {
+            load_pair<WT>(P.q0, P.s0, tp0, g, gsa, r, k, ca, sa);
+            if (NM > 1) load_pair<WT>(P.q1, P.s1, tp0, g, gsa, r, k, ua, ta);
+        }
+        if (lb) {
+            load_pair<WT>(P.q0, P.s0, tp0, gb, gsb, r, k, cb, sb);
+            if (NM > 1) load_pair<WT>(P.q1, P.s1, tp0, gb, gsb, r, k, ub, tb);
+        }
+        // ---- group a ----
+        if (PRO == PRO_NORM) {
+            // RMSNormInto go/quant.go:597-607.  inv = 1/sqrt(mean(x^2)+eps) multiplies the GEMV OUTPUT
+            // (out = inv * sum_j w_ij (x_j g_j)), so its float64 reduction is off the critical path.
+            if (tin == 0) {
+                ss += (double)xa.x * (double)xa.x; ss += (double)xa.y * (double)xa.y;
+                ss += (double)xa.z * (double)xa.z; ss += (double)xa.w * (double)xa.w;
+                if (P.x_out && blockIdx.x == 0 && g * (KL * PAIR) + lane * 4 < P.cols)
+                    *reinterpret_cast<float4 *>(P.x_out + g * (KL * PAIR) + lane * 4) = xa;
+            }
+            xa.x *= ga4.x; xa.y *= ga4.y; xa.z *= ga4.z; xa.w *= ga4.w;
+        }
+        *reinterpret_cast<float4 *>(xs + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
+        __builtin_amdgcn_wave_barrier();
+        if (la) {
+            acc0 = PairDot<WT>::run(ca, sa, xs + k * XS_PAIR, acc0);
+            if (NM > 1) acc1 = PairDot<WT>::run(ua, ta, xs + k * XS_PAIR, acc1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- group b ----
+        if (hasb) {
+            if (PRO == PRO_NORM) {
+                if (tin == 0) {
+                    ss += (double)xb.x * (double)xb.x; ss += (double)xb.y * (double)xb.y;
+                    ss += (double)xb.z * (double)xb.z; ss += (double)xb.w * (double)xb.w;
+                    if (P.x_out && blockIdx.x == 0 && gb * (KL * PAIR) + lane * 4 < P.cols)
+                        *reinterpret_cast<float4 *>(P.x_out + gb * (KL * PAIR) + lane * 4) = xb;
+                }
+                xb.x *= gb4.x; xb.y *= gb4.y; xb.z *= gb4.z; xb.w *= gb4.w;
+            }
+            *reinterpret_cast<float4 *>(xs + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xb;
+            __builtin_amdgcn_wave_barrier();
+            if (lb) {
+                acc0 = PairDot<WT>::run(cb, sb, xs + k * XS_PAIR, acc0);
+                if (NM > 1) acc1 = PairDot<WT>::run(ub, tb, xs + k * XS_PAIR, acc1);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    NL_STAMP(4);
+    // the 4 pair-lanes of a row form a quad
+    acc0 = quad_sum(acc0);
+    if (NM > 1) acc1 = quad_sum(acc1);
+    if (k == 0) {
+        red[wave * TR + r] = acc0;
+        if (NM > 1) red[(nwaves + wave) * TR + r] = acc1;
+    }
+    if (PRO == PRO_NORM && tin == 0) {
+        ss = wave_sum_f64(ss);
+        if (lane == 0) dred[kw] = ss;
+    }
+    NL_STAMP(5);
+    __syncthreads();
+    NL_STAMP(6);
+
+    if ((t & ~63) >= nact) return;  // this wave holds no output rows
+    const int rr = e_rr, otile = e_tile;
+    const bool act = e_act;
     float v = 0.f, v1 = 0.f;
-    for (int k = 0; k < P.kw; k++) {  // fixed order: deterministic
-        v += red[(tin * P.kw + k) * TR + rr];
-        if (NM > 1) v1 += red[(nwaves + tin * P.kw + k) * TR + rr];
+    if (act)
+        for (int j = 0; j < P.kw; j++) {  // fixed order: deterministic
+            v += red[(e_tin * P.kw + j) * TR + rr];
+            if (NM > 1) v1 += red[(nwaves + e_tin * P.kw + j) * TR + rr];
+        }
+    if (PRO == PRO_NORM) {
+        double tot = 0.0;
+        for (int w = 0; w < P.kw; w++) tot += dred[w];
+        float inv = (float)(1.0 / sqrt(tot / (double)P.cols + (double)P.eps));
+        v *= inv;
+        if (NM > 1) v1 *= inv;
     }
     if (EPI == EPI_QKV) {
         // RoPE (go/model.go:449-477), KV store (:552-554).  Tile rows 0-7 hold
         // element i, rows 8-15 element i + hd/2 of the same head (ROWMAP_HEADPERM).
+        if (!act) return;  // 16-lane groups are uniformly active, so RoPE partners stay together
         const int hd = P.head_dim, half = hd >> 1, tph = hd / 16;
         const int head = otile / tph, j = otile % tph;
         const int i = j * 8 + (rr & 7);
         const int e = i + (rr >> 3) * half;
-        const int pos = P.ctl[CTL_POS];
+        const int pos = e_pos;
         float partner = __shfl_xor(v, 8);
         float outv = v;
         if (head < P.n_q_heads + P.n_kv_heads) {
-            float c = P.rope_cos[pos * half + i], s = P.rope_sin[pos * half + i];
+            float c = e_cos, sn = e_sin;
             float x0 = (rr < 8) ? v : partner, x1 = (rr < 8) ? partner : v;
-            if (!P.rope_conj) outv = (rr < 8) ? (x0 * c - x1 * s) : (x0 * s + x1 * c);
-            else outv = (rr < 8) ? (x0 * c + x1 * s) : (-x0 * s + x1 * c);
+            if (!P.rope_conj) outv = (rr < 8) ? (x0 * c - x1 * sn) : (x0 * sn + x1 * c);
+            else outv = (rr < 8) ? (x0 * c + x1 * sn) : (-x0 * sn + x1 * c);
         }
         if (head < P.n_q_heads) {
             P.qbuf[head * hd + e] = outv;
@@ -440,16 +529,38 @@ __global__ void __launch_bounds__(1024) gemv_kernel(GemvParams P) {
         return;
     }
     const int row = otile * TR + rr;
-    if (row >= P.rows) return;
     if (EPI == EPI_STORE) {
-        P.out[row] = v;
-    } else if (EPI == EPI_RESID) {
-        P.out[row] = P.resid[row] + v;
+        const bool ok = act && row < P.rows;
+        if (ok) P.out[row] = v;
+        if (P.amax_val) {
+            // fused partial argmax over this wave's rows (go/main.go:400-408: strict '>' => lowest index
+            // wins ties); one slot per wave that holds rows, reduced by argmax_kernel
+            float bv = ok ? v : -INFINITY;
+            int bi = ok ? row : 0x7fffffff;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                float ov = __shfl_xor(bv, o);
+                int oi = __shfl_xor(bi, o);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if ((t & 63) == 0) {
+                const int spb = (nact + 63) >> 6;
+                P.amax_val[blockIdx.x * spb + (t >> 6)] = bv;
+                P.amax_idx[blockIdx.x * spb + (t >> 6)] = bi;
+            }
+        }
+        return;
+    }
+    if (!act || row >= P.rows) return;
+    if (EPI == EPI_RESID) {
+        P.out[row] = e_resid + v;
     } else if (EPI == EPI_SWIGLU) {
         // SiLU go/quant.go:629-631: x / (1 + f32(exp(f64(-x)))), then * up (go/model.go:604-606)
         float ex = (float)exp((double)(-v));
         P.out[row] = (v / (1.0f + ex)) * v1;
     }
+    NL_STAMP(7);
+#undef NL_STAMP
 }
 
 // ------------------------------------------------------------- embedding ---
@@ -497,86 +608,159 @@ struct AttnParams {
     const int *ctl;
     int n_kv_heads, seq_len, nsplit_max;
     float scale;
+    int single_stream;  // max_streams == 1: stream offset is 0 without reading ctl
 };
 
 // GQA decode attention for one token (go/model.go:557-587): one workgroup per
 // (kv head, 128-position split); the G query heads of the group share every K
 // and V element read.  Emits un-normalised partials (max, sum, sum p*v) that
-// the WO GEMV prologue merges.
+// the WO GEMV prologue merges.  All global loads (q, this split's K and V rows)
+// are issued up front so the launch pays ONE memory latency: K goes to LDS
+// (padded rows, for the per-position dot), V stays in registers for P*V.
+// full-wave f32 max / sum on DPP (row of 16) + two cross-row hops, result valid in every lane
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, dpp_f32<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_f32<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f32<DPP_ROW_MIRROR>(v));
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += dpp_f32<DPP_QUAD_XOR1>(v);
+    v += dpp_f32<DPP_QUAD_XOR2>(v);
+    v += dpp_f32<DPP_HALF_MIRROR>(v);
+    v += dpp_f32<DPP_ROW_MIRROR>(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
 template <int HD, int G>
 __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
-    const int pos = P.ctl[CTL_POS];
     const int split = blockIdx.y, t0 = split * ATT_CH;
-    if (t0 > pos) return;
-    const int n = min(ATT_CH, pos + 1 - t0);
     const int kvh = blockIdx.x, tid = threadIdx.x;
-    const long long soff = (long long)P.ctl[CTL_STREAM] * P.kv_stream_stride;
-    const float *K = P.kcache + soff + ((long long)kvh * P.seq_len + t0) * HD;
-    const float *V = P.vcache + soff + ((long long)kvh * P.seq_len + t0) * HD;
-
-    constexpr int KS = HD + 1;  // padded row stride: conflict-free column walks
+    constexpr int KS = HD + 1;               // padded row stride: conflict-free column walks
+    constexpr int R4 = HD / 4;               // float4 per row
+    constexpr int NG = ATT_THREADS / R4;     // row groups
+    constexpr int NV = ATT_CH / NG;          // rows per thread
     __shared__ float Kt[ATT_CH * KS];
     __shared__ float qs[G * HD];
     __shared__ float sc[G * ATT_CH];
-    __shared__ float ored[(ATT_THREADS / HD) * G * HD];
+    __shared__ __attribute__((aligned(16))) float ored[NG * G * HD];
     __shared__ float ml[G * 2];
 
+    const int c4 = tid % R4, tg = tid / R4;
+    float4 kreg[NV], vreg[NV];
+    int pos, n;
+    // Split 0 of a single-stream engine does not need ctl to know WHERE its K/V rows are, so it loads
+    // all 128 rows speculatively (rows > pos hold finite stale data and are masked below) and the
+    // ctl round trip overlaps the K/V fetch instead of preceding it.
+    const bool spec = split == 0 && P.single_stream;
+    if (spec) {
+        const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + (long long)kvh * P.seq_len * HD);
+        const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + (long long)kvh * P.seq_len * HD);
+        const int lim = min(ATT_CH, P.seq_len);
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            int row = tg + k * NG;
+            if (row < lim) {
+                kreg[k] = K4[row * R4 + c4];
+                vreg[k] = V4[row * R4 + c4];
+            } else {
+                kreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                vreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        pos = P.ctl[CTL_POS];
+        n = min(ATT_CH, pos + 1);
+    } else {
+        pos = P.ctl[CTL_POS];
+        if (t0 > pos) return;
+        n = min(ATT_CH, pos + 1 - t0);
+        const long long soff = (long long)P.ctl[CTL_STREAM] * P.kv_stream_stride;
+        const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
+        const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            int row = tg + k * NG;
+            if (row < n) {
+                kreg[k] = K4[row * R4 + c4];
+                vreg[k] = V4[row * R4 + c4];
+            } else {
+                kreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                vreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
     for (int i = tid; i < G * HD; i += ATT_THREADS) qs[i] = P.qbuf[kvh * G * HD + i];
-    for (int i = tid; i < n * (HD / 4); i += ATT_THREADS) {
-        int row = i / (HD / 4), c4 = i % (HD / 4);
-        float4 v = *reinterpret_cast<const float4 *>(K + row * HD + c4 * 4);
-        float *dst = Kt + row * KS + c4 * 4;
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        int row = tg + k * NG;
+        if (row < n) {
+            float *dst = Kt + row * KS + c4 * 4;
+            dst[0] = kreg[k].x; dst[1] = kreg[k].y; dst[2] = kreg[k].z; dst[3] = kreg[k].w;
+        }
     }
     __syncthreads();
 
-    // scores: thread (t, g) -> dot over d in the reference's order
+    // scores: thread (t, g) -> q.k over d (four partial sums: a lone wavefront is latency-bound)
     for (int i = tid; i < n * G; i += ATT_THREADS) {
         int t = i % n, g = i / n;
         const float *kr = Kt + t * KS, *qr = qs + g * HD;
-        float dot = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < HD; d++) dot += qr[d] * kr[d];
-        sc[g * ATT_CH + t] = dot * P.scale;
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            d0 = fmaf(qr[d], kr[d], d0);
+            d1 = fmaf(qr[d + 1], kr[d + 1], d1);
+            d2 = fmaf(qr[d + 2], kr[d + 2], d2);
+            d3 = fmaf(qr[d + 3], kr[d + 3], d3);
+        }
+        sc[g * ATT_CH + t] = ((d0 + d1) + (d2 + d3)) * P.scale;
     }
     __syncthreads();
 
     // softmax pieces per head: wave w handles heads w, w+4, ...
     const int wave = tid >> 6, lane = tid & 63;
     for (int g = wave; g < G; g += ATT_THREADS / 64) {
-        float m = -INFINITY;
-        for (int t = lane; t < n; t += 64) m = fmaxf(m, sc[g * ATT_CH + t]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        float l = 0.f;
-        for (int t = lane; t < n; t += 64) {
-            float p = (float)exp((double)(sc[g * ATT_CH + t] - m));  // go/quant.go:619
-            sc[g * ATT_CH + t] = p;
-            l += p;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+        float s0 = lane < n ? sc[g * ATT_CH + lane] : -INFINITY;
+        float s1 = lane + 64 < n ? sc[g * ATT_CH + lane + 64] : -INFINITY;
+        float m = wave_max_f32(fmaxf(s0, s1));
+        float p0 = lane < n ? (float)exp((double)(s0 - m)) : 0.f;       // go/quant.go:619
+        float p1 = lane + 64 < n ? (float)exp((double)(s1 - m)) : 0.f;
+        if (lane < n) sc[g * ATT_CH + lane] = p0;
+        if (lane + 64 < n) sc[g * ATT_CH + lane + 64] = p1;
+        float l = wave_sum_f32(p0 + p1);
         if (lane == 0) { ml[2 * g] = m; ml[2 * g + 1] = l; }
     }
     __syncthreads();
 
-    // P*V: thread = (position group, d); V rows are read coalesced from global
-    constexpr int NG = ATT_THREADS / HD;
-    const int d = tid % HD, tg = tid / HD;
-    float o[G];
+    // P*V from the V rows already in registers
+    float4 o[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) o[g] = 0.f;
-    for (int t = tg; t < n; t += NG) {
-        float v = V[t * HD + d];
+    for (int g = 0; g < G; g++) o[g] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int g = 0; g < G; g++) o[g] = fmaf(sc[g * ATT_CH + t], v, o[g]);
+    for (int k = 0; k < NV; k++) {
+        int row = tg + k * NG;
+        if (row < n) {
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                float pw = sc[g * ATT_CH + row];
+                o[g].x = fmaf(pw, vreg[k].x, o[g].x);
+                o[g].y = fmaf(pw, vreg[k].y, o[g].y);
+                o[g].z = fmaf(pw, vreg[k].z, o[g].z);
+                o[g].w = fmaf(pw, vreg[k].w, o[g].w);
+            }
+        }
     }
 #pragma unroll
-    for (int g = 0; g < G; g++) ored[(tg * G + g) * HD + d] = o[g];
+    for (int g = 0; g < G; g++) *reinterpret_cast<float4 *>(ored + (tg * G + g) * HD + c4 * 4) = o[g];
     __syncthreads();
     for (int i = tid; i < G * HD; i += ATT_THREADS) {
         int g = i / HD, dd = i % HD;
         float s = 0.f;
+#pragma unroll 8
         for (int k = 0; k < NG; k++) s += ored[(k * G + g) * HD + dd];
         int h = kvh * G + g;
         P.part_o[((long long)h * P.nsplit_max + split) * HD + dd] = s;
@@ -616,8 +800,11 @@ __global__ void qknorm_kernel(QkNormParams P) {
 // ---------------------------------------------------------------- argmax ---
 
 struct ArgmaxParams {
-    const float *logits;
+    const float *logits;   // full scan source (used when part_val == nullptr)
     int n;
+    const float *part_val; // per-wave partial maxima written by the LM-head GEMV epilogue
+    const int *part_idx;
+    int npart;
     int *ctl;
     int *ids;     // ring of sampled ids (chained decode)
     int *result;  // last argmax
@@ -630,9 +817,17 @@ __global__ void __launch_bounds__(1024) argmax_kernel(ArgmaxParams P) {
     const int tid = threadIdx.x;
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int i = tid; i < P.n; i += blockDim.x) {
-        float v = P.logits[i];
-        if (v > best || idx == 0x7fffffff) { best = v; idx = i; }
+    if (P.part_val) {
+        for (int i = tid; i < P.npart; i += blockDim.x) {
+            float v = P.part_val[i];
+            int vi = P.part_idx[i];
+            if (v > best || (v == best && vi < idx)) { best = v; idx = vi; }
+        }
+    } else {
+        for (int i = tid; i < P.n; i += blockDim.x) {
+            float v = P.logits[i];
+            if (v > best || idx == 0x7fffffff) { best = v; idx = i; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -645,6 +840,7 @@ __global__ void __launch_bounds__(1024) argmax_kernel(ArgmaxParams P) {
     if (tid == 0) {
         for (int w = 1; w < (int)(blockDim.x >> 6); w++)
             if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        if (idx == 0x7fffffff) idx = 0;  // all-NaN logits: the reference's loop never leaves index 0
         *P.result = idx;
         if (P.ctl[CTL_CHAIN]) {
             int step = P.ctl[CTL_STEP];
