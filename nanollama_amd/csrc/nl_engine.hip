@@ -92,6 +92,10 @@ struct Op {
     float *buf;
     size_t count;
     std::function<hipError_t(hipStream_t)> fn;
+    // GEMV launches keep their parameters here so a later pass can point each one at its successor
+    bool is_gemv = false;
+    int wtype = 0, pro = 0, epi = 0;
+    GemvParams gp{};
 };
 
 }  // namespace
@@ -304,6 +308,33 @@ hipError_t launch_attn(int hd, int gqa, AttnParams P, dim3 grid, hipStream_t st)
     return hipErrorInvalidValue;
 }
 
+hipError_t launch_gemv_dyn(int wt, int pro, int epi, const GemvParams &P, hipStream_t st) {
+    if (pro == PRO_NORM && epi == EPI_QKV) return launch_gemv_t<PRO_NORM, EPI_QKV>(wt, P, st);
+    if (pro == PRO_ATTN && epi == EPI_RESID) return launch_gemv_t<PRO_ATTN, EPI_RESID>(wt, P, st);
+    if (pro == PRO_ATTN && epi == EPI_STORE) return launch_gemv_t<PRO_ATTN, EPI_STORE>(wt, P, st);
+    if (pro == PRO_NORM && epi == EPI_SWIGLU) return launch_gemv_t<PRO_NORM, EPI_SWIGLU>(wt, P, st);
+    if (pro == PRO_PLAIN && epi == EPI_RESID) return launch_gemv_t<PRO_PLAIN, EPI_RESID>(wt, P, st);
+    if (pro == PRO_PLAIN && epi == EPI_STORE) return launch_gemv_t<PRO_PLAIN, EPI_STORE>(wt, P, st);
+    if (pro == PRO_NORM && epi == EPI_STORE) return launch_gemv_t<PRO_NORM, EPI_STORE>(wt, P, st);
+    return hipErrorInvalidValue;
+}
+
+void push_gemv(nl_engine *e, int kind, int coll, float *buf, size_t count, int wt, int pro, int epi, const GemvParams &P) {
+    Op op{kind, coll, buf, count, nullptr};
+    op.is_gemv = true; op.wtype = wt; op.pro = pro; op.epi = epi; op.gp = P;
+    e->plan.push_back(op);
+}
+
+// Freeze the launch closures once every GEMV's parameters are final.
+void link_prefetch(nl_engine *e) {
+    for (Op &cur : e->plan) {
+        if (!cur.is_gemv) continue;
+        const int wt = cur.wtype, pro = cur.pro, epi = cur.epi;
+        const GemvParams P = cur.gp;
+        cur.fn = [wt, pro, epi, P](hipStream_t st) { return launch_gemv_dyn(wt, pro, epi, P, st); };
+    }
+}
+
 // Build the per-token launch plan: the device-side restatement of Forward
 // (go/model.go:490-620).  token / pos / stream are read from e->ctl by the
 // kernels, so one captured graph serves every step.
@@ -334,8 +365,7 @@ void build_plan(nl_engine *e) {
             P.qbuf = e->qbuf; P.kcache = kc; P.vcache = vc; P.kv_stream_stride = e->kv_stream_stride;
             P.n_q_heads = e->Hs; P.n_kv_heads = e->KVs; P.seq_len = c.seq_len; P.rope_conj = c.rope_conjugate;
             int wt = L.qkv.wtype;
-            e->plan.push_back({K_QKV, 0, nullptr, 0,
-                               [wt, P](hipStream_t st) { return launch_gemv_t<PRO_NORM, EPI_QKV>(wt, P, st); }});
+            push_gemv(e, K_QKV, 0, nullptr, 0, wt, PRO_NORM, EPI_QKV, P);
             if (pending) { cur ^= 1; pending = nullptr; }
         }
         if (c.qk_norm) {
@@ -360,12 +390,10 @@ void build_plan(nl_engine *e) {
             int wt = L.wo.wtype;
             if (!tp) {
                 P.out = e->x[cur]; P.resid = e->x[cur];
-                e->plan.push_back({K_WO, 0, nullptr, 0,
-                                   [wt, P](hipStream_t st) { return launch_gemv_t<PRO_ATTN, EPI_RESID>(wt, P, st); }});
+                push_gemv(e, K_WO, 0, nullptr, 0, wt, PRO_ATTN, EPI_RESID, P);
             } else {
                 P.out = e->ar;
-                e->plan.push_back({K_WO, 1, e->ar, (size_t)c.dim,
-                                   [wt, P](hipStream_t st) { return launch_gemv_t<PRO_ATTN, EPI_STORE>(wt, P, st); }});
+                push_gemv(e, K_WO, 1, e->ar, (size_t)c.dim, wt, PRO_ATTN, EPI_STORE, P);
                 pending = e->ar;
             }
         }
@@ -375,8 +403,7 @@ void build_plan(nl_engine *e) {
             P.x = e->x[cur]; P.normw = L.ffn_norm; P.out = e->hb;
             if (pending) { P.add = pending; P.x_out = e->x[cur ^ 1]; }
             int wt = L.gate.wtype;
-            e->plan.push_back({K_GATEUP, 0, nullptr, 0,
-                               [wt, P](hipStream_t st) { return launch_gemv_t<PRO_NORM, EPI_SWIGLU>(wt, P, st); }});
+            push_gemv(e, K_GATEUP, 0, nullptr, 0, wt, PRO_NORM, EPI_SWIGLU, P);
             if (pending) { cur ^= 1; pending = nullptr; }
         }
         {   // down + residual (go/model.go:609-612)
@@ -385,12 +412,10 @@ void build_plan(nl_engine *e) {
             int wt = L.down.wtype;
             if (!tp) {
                 P.out = e->x[cur]; P.resid = e->x[cur];
-                e->plan.push_back({K_DOWN, 0, nullptr, 0,
-                                   [wt, P](hipStream_t st) { return launch_gemv_t<PRO_PLAIN, EPI_RESID>(wt, P, st); }});
+                push_gemv(e, K_DOWN, 0, nullptr, 0, wt, PRO_PLAIN, EPI_RESID, P);
             } else {
                 P.out = e->ar;
-                e->plan.push_back({K_DOWN, 1, e->ar, (size_t)c.dim,
-                                   [wt, P](hipStream_t st) { return launch_gemv_t<PRO_PLAIN, EPI_STORE>(wt, P, st); }});
+                push_gemv(e, K_DOWN, 1, e->ar, (size_t)c.dim, wt, PRO_PLAIN, EPI_STORE, P);
                 pending = e->ar;
             }
         }
@@ -404,8 +429,7 @@ void build_plan(nl_engine *e) {
         int wt = e->lm_head.wtype;
         lm_blocks = (P.ntiles + P.tw - 1) / P.tw;
         lm_spb = (P.tw * TR + 63) / 64;
-        e->plan.push_back({K_LMHEAD, tp ? 2 : 0, e->logits, (size_t)e->Vs,
-                           [wt, P](hipStream_t st) { return launch_gemv_t<PRO_NORM, EPI_STORE>(wt, P, st); }});
+        push_gemv(e, K_LMHEAD, tp ? 2 : 0, e->logits, (size_t)e->Vs, wt, PRO_NORM, EPI_STORE, P);
     }
     {
         ArgmaxParams P{e->logits, c.vocab, tp ? nullptr : e->amax_val, e->amax_idx, lm_blocks * lm_spb, e->ctl, e->ids,
@@ -415,6 +439,7 @@ void build_plan(nl_engine *e) {
                                return hipGetLastError();
                            }});
     }
+    link_prefetch(e);
 }
 
 int run_collective(nl_engine *e, const Op &op) {

@@ -168,17 +168,51 @@ template <> struct PairDot<WT_Q8_0> {
     }
 };
 
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2_t bits_h2(uint32_t u) { return __builtin_bit_cast(h2_t, u); }
+
+// (a & mask) | c in one VALU op (hipcc splits it because VOP3 takes no 32-bit literal: mask rides in an SGPR)
+__device__ __forceinline__ uint32_t and_or_b32(uint32_t a, uint32_t mask, uint32_t c) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(c));
+    return r;
+}
+// acc + float(half) * x with the fp16 operand read straight from the low / high half of a packed register
+__device__ __forceinline__ float fma_mix_lo(uint32_t h2, float x, float acc) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ float fma_mix_hi(uint32_t h2, float x, float acc) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t h2_bits(h2_t v) { return __builtin_bit_cast(uint32_t, v); }
+
 __device__ __forceinline__ void dot_q4_word(uint32_t w, float4 xl, float4 xh, Acc4 &s) {
-    // byte k of w: low nibble = element k, high nibble = element k+16 (go/quant.go:84-88)
-    uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;
-    s.a = fmaf((float)(int)(lo & 0xff) - 8.f, xl.x, s.a);
-    s.b = fmaf((float)(int)(hi & 0xff) - 8.f, xh.x, s.b);
-    s.c = fmaf((float)(int)((lo >> 8) & 0xff) - 8.f, xl.y, s.c);
-    s.d = fmaf((float)(int)((hi >> 8) & 0xff) - 8.f, xh.y, s.d);
-    s.a = fmaf((float)(int)((lo >> 16) & 0xff) - 8.f, xl.z, s.a);
-    s.b = fmaf((float)(int)((hi >> 16) & 0xff) - 8.f, xh.z, s.b);
-    s.c = fmaf((float)(int)(lo >> 24) - 8.f, xl.w, s.c);
-    s.d = fmaf((float)(int)(hi >> 24) - 8.f, xh.w, s.d);
+    // byte k of w: low nibble = element k, high nibble = element k+16 (go/quant.go:84-88).
+    // Nibble -> (n - 8) without integer unpacking: OR the nibble into the mantissa of fp16 1024.0
+    // (0x6400): bits 0-3 give 1024+n, bits 4-7 give 1024+16n; one packed fp16 op then yields n-8
+    // EXACTLY for two nibbles at once, and v_fma_mix_f32 multiplies it into the f32 accumulator:
+    // 17 VALU ops per 8 weights.
+    const h2_t k1032 = {(_Float16)1032.0f, (_Float16)1032.0f};
+    const h2_t k16th = {(_Float16)0.0625f, (_Float16)0.0625f};
+    const h2_t km72 = {(_Float16)-72.0f, (_Float16)-72.0f};
+    const uint32_t magic = 0x64006400u;
+    const uint32_t w8 = w >> 8;
+    uint32_t e02 = h2_bits(bits_h2(and_or_b32(w, 0x000F000Fu, magic)) - k1032);                                    // elems 0, 2
+    uint32_t e13 = h2_bits(bits_h2(and_or_b32(w8, 0x000F000Fu, magic)) - k1032);                                   // elems 1, 3
+    uint32_t f02 = h2_bits(__builtin_elementwise_fma(bits_h2(and_or_b32(w, 0x00F000F0u, magic)), k16th, km72));    // elems 16, 18
+    uint32_t f13 = h2_bits(__builtin_elementwise_fma(bits_h2(and_or_b32(w8, 0x00F000F0u, magic)), k16th, km72));   // elems 17, 19
+    s.a = fma_mix_lo(e02, xl.x, s.a);
+    s.b = fma_mix_lo(f02, xh.x, s.b);
+    s.c = fma_mix_lo(e13, xl.y, s.c);
+    s.d = fma_mix_lo(f13, xh.y, s.d);
+    s.a = fma_mix_hi(e02, xl.z, s.a);
+    s.b = fma_mix_hi(f02, xh.z, s.b);
+    s.c = fma_mix_hi(e13, xl.w, s.c);
+    s.d = fma_mix_hi(f13, xh.w, s.d);
 }
 
 template <> struct PairDot<WT_Q4_0> {
@@ -407,7 +441,11 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     double ss = 0.0;
     NL_STAMP(1);
     // two groups in flight per wavefront where the registers allow it
-    constexpr bool TWO = !(NM > 1 || CPP > 8);
+#ifdef NL_FORCE_ONE
+    constexpr bool TWO = false;
+#else
+    constexpr bool TWO = NM == 1 && CPP <= 8;
+#endif
     for (int g = kw; g < ngroups; g += (TWO ? 2 : 1) * P.kw) {
         const int gb = g + P.kw;
         const bool hasb = TWO && gb < ngroups;

@@ -136,21 +136,24 @@ def draw_float(shape: ModelShape, seed: int, ckpt_name: str, tshape, kind: str) 
 
 
 def _draw_qrand(shape: ModelShape, seed: int, ckpt_name: str, tshape, kind: str, wtype: int) -> np.ndarray:
+    """Random quantised blocks drawn directly: every quant byte uniform, every fp16 scale
+    d = 2^e * (1 + m/1024) with random mantissa m and e = floor(log2(amax / qmax)), i.e. the same
+    magnitude the reference quantiser would produce for U(-amax, amax) weights."""
     rng = _tensor_rng(seed, ckpt_name)
     nel = int(np.prod(tshape))
     nb = nel // 32
+    bsz = 34 if wtype == GGML_Q8_0 else 18
     amax = 4.0 if kind == "embedding" else (3.0 ** 0.5) * (shape.dim ** -0.5)
-    u = rng.random(size=nb, dtype=np.float32)
-    if wtype == GGML_Q8_0:
-        out = np.empty((nb, 34), dtype=np.uint8)
-        d = (amax / 127.0) * (1.0 - 0.1 * u * u)
-        out[:, 2:] = rng.integers(0, 256, size=(nb, 32), dtype=np.uint8)
-    else:
-        out = np.empty((nb, 18), dtype=np.uint8)
-        d = (amax / 8.0) * (1.0 - 0.1 * u * u)
-        out[:, 2:] = rng.integers(0, 256, size=(nb, 16), dtype=np.uint8)
-    out[:, 0:2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
-    return out.reshape(-1)
+    target = amax / (127.0 if wtype == GGML_Q8_0 else 8.0)
+    efield = max(1, min(30, int(np.floor(np.log2(target))) + 15))
+    nbytes = nb * bsz
+    raw = rng.integers(0, 1 << 63, size=(nbytes + 7) // 8, dtype=np.int64).view(np.uint8)[:nbytes]
+    blocks = raw.reshape(nb, bsz)
+    sc = blocks[:, 0:2].copy().view(np.uint16)
+    sc &= np.uint16(0x03FF)
+    sc |= np.uint16(efield << 10)
+    blocks[:, 0:2] = sc.view(np.uint8)
+    return raw
 
 
 def generate_gguf(path: str, shape: ModelShape, wtype: str = "q8_0", seed: Optional[int] = None,

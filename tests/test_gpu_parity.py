@@ -248,3 +248,17 @@ def test_mid_size_model_matches_oracle(hip, orc, tmp_path, tier, wtype):
     worst, scale = _run_teacher_forced(hip, orc, str(p), synth.prompt_ids(40, shape.vocab, seed=11))
     print(f"\n{tier}/{wtype}: max|gpu-oracle|={worst:.2e} (logit std {scale:.2f})")
     assert worst <= LOGIT_TOL * scale
+
+
+@pytest.mark.parametrize("tier,wtype,ntok", [("nano", "q8_0", 6), ("nano", "f16", 3), ("mini", "q4_0", 4),
+                                              ("goldie", "q4_0", 3)])
+def test_full_size_tiers_match_oracle(hip, orc, tmp_path, tier, wtype, ntok):
+    # BASELINE.json's own shapes (89M / 173M / 841M), teacher-forced, against the CPU oracle
+    shape = synth.TIERS[tier]
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, wtype, mode="qrand" if tier == "goldie" else "float")
+    orc.set_threads(min(32, os.cpu_count() or 1))
+    worst, scale = _run_teacher_forced(hip, orc, str(p), synth.prompt_ids(ntok, shape.vocab, seed=5))
+    orc.set_threads(1)
+    print(f"\n{tier}/{wtype}: max|gpu-oracle|={worst:.2e} (logit std {scale:.2f})")
+    assert worst <= LOGIT_TOL * scale
