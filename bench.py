@@ -108,9 +108,12 @@ def main():
     ap.add_argument("--profile-pos", type=int, default=PROMPT_LEN + SEGMENT // 2)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # the product library is loaded before torch so it binds /opt/rocm's HIP runtime
+    from nanollama_amd import _lib, model
+    from nanollama_amd.dist import Rendezvous
+    _lib.lib()
+    rdv = Rendezvous()
+    rank, world, local_rank = rdv.rank, rdv.world, rdv.local_rank
     n = args.gpus
     if world != n and world != 1:
         raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}")
@@ -122,22 +125,10 @@ def main():
     shape = synth.TIERS[tier]
     mode = "qrand" if tier in ("big", "goldie") else "float"
 
-    # the product library is loaded before torch so it binds /opt/rocm's HIP runtime
-    from nanollama_amd import _lib, model
-    _lib.lib()
-
-    dist = None
-    comm_id = None
-    if world > 1:
-        import torch.distributed as dist  # gloo: host-side rendezvous only; the data path is RCCL inside the library
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        box = [model.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        comm_id = box[0]
+    comm_id = rdv.broadcast_bytes(model.comm_unique_id) if world > 1 else None
 
     path = ensure_gguf(shape, wtype, mode, rank)
-    if dist:
-        dist.barrier()
+    rdv.barrier()
     g = gguf.load_gguf(path)
     dev = model.load_llama_model(g, device=local_rank, tp_rank=rank if world > 1 else 0, tp_size=world,
                                  comm_id=comm_id)
@@ -163,20 +154,15 @@ def main():
     first, pos0 = prefill()
     run_steps(args.warmup, first, pos0)
     dev.synchronize()
-    if dist:
-        dist.barrier()
+    rdv.barrier()
     dev.timer_start()
     t0 = time.perf_counter()
     ids = run_steps(args.steps, first, pos0)
     dev.synchronize()
     wall_ms = (time.perf_counter() - t0) * 1e3
     ev_ms = dev.timer_stop()
-    if dist:
-        dist.barrier()
-        import torch
-        tmax = torch.tensor([wall_ms], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall_ms = float(tmax.item())
+    rdv.barrier()
+    wall_ms = rdv.max_over_ranks(wall_ms)
 
     ms_per_step = wall_ms / args.steps
     tok_s = args.steps / (wall_ms / 1e3)
@@ -222,8 +208,7 @@ def main():
     dev.close()
     if rank == 0:
         print(json.dumps(out))
-    if dist:
-        dist.destroy_process_group()
+    rdv.close()
 
 
 if __name__ == "__main__":

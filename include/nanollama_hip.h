@@ -60,6 +60,7 @@ typedef struct {
 } nl_config;
 
 #define NL_FLAG_NO_GRAPH 1 /* launch kernels eagerly instead of replaying a hipGraph */
+#define NL_FLAG_LOCAL_GROUP 2 /* tp_size > 1 shards living in ONE process, stepped by nl_group_forward */
 
 /* Library / device probes (no handle, no device work for nl_abi_version). */
 NL_API int nl_abi_version(void);
@@ -138,6 +139,12 @@ NL_API int nl_op_rmsnorm(int device, const float *x, const float *w, float eps, 
  * rank passes it to nl_comm_init before nl_finalize. */
 NL_API int nl_comm_get_unique_id(void *id_out /* NL_COMM_ID_BYTES */);
 NL_API int nl_comm_init(nl_handle h, const void *id /* NL_COMM_ID_BYTES */);
+
+/* In-process tensor-parallel group: `n` handles created with tp_size = n, tp_rank = 0..n-1 and
+ * NL_FLAG_LOCAL_GROUP (all on devices this process can reach; the same device is allowed).  Steps
+ * every shard's launch plan in lockstep and performs the all-reduce / all-gather seams itself, so the
+ * sharding arithmetic can be verified on a single GPU.  Same result contract as nl_forward. */
+NL_API int nl_group_forward(nl_handle *shards, int n, int stream, int token, int pos, float *logits_out);
 
 #ifdef __cplusplus
 }

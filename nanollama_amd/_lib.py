@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libnanollama_hip.so")
 NL_NUM_KINDS = 8
 NL_COMM_ID_BYTES = 128
 NL_FLAG_NO_GRAPH = 1
+NL_FLAG_LOCAL_GROUP = 2
 
 STATUS = {0: "NL_OK", -1: "NL_ERR_INVALID", -2: "NL_ERR_UNSUPPORTED", -3: "NL_ERR_HIP", -4: "NL_ERR_STATE",
           -5: "NL_ERR_MISSING", -6: "NL_ERR_COMM"}
@@ -50,7 +51,7 @@ EXPORTS = ["nl_abi_version", "nl_device_count", "nl_create", "nl_upload_tensor",
            "nl_last_error", "nl_reset", "nl_forward", "nl_forward_argmax", "nl_decode_greedy", "nl_get_config",
            "nl_synchronize", "nl_timer_start", "nl_timer_stop", "nl_kernel_kind_name", "nl_profile_forward",
            "nl_memory_usage", "nl_debug_read", "nl_op_matmul", "nl_op_rmsnorm", "nl_comm_get_unique_id",
-           "nl_comm_init"]
+           "nl_comm_init", "nl_group_forward", "nl_debug_stamps"]
 
 
 def lib():
@@ -88,6 +89,7 @@ def lib():
     L.nl_op_rmsnorm.argtypes = [i32, fp, fp, C.c_float, fp, i32]
     L.nl_comm_get_unique_id.argtypes = [vp]
     L.nl_comm_init.argtypes = [vp, vp]
+    L.nl_group_forward.argtypes = [C.POINTER(vp), i32, i32, i32, i32, fp]
     _lib = L
     return L
 

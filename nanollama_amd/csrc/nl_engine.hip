@@ -758,7 +758,8 @@ int nl_finalize(nl_handle e) {
     HIPCK(e, hipHostMalloc((void **)&e->h_ctl, CTL_WORDS * sizeof(int), hipHostMallocDefault));
     memset(e->h_ctl, 0, CTL_WORDS * sizeof(int));
     HIPCK(e, hipMemcpy(e->ctl, e->h_ctl, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice));
-    if (e->G > 1 && !e->comm) return e->fail(NL_ERR_STATE, "tp_size %d needs nl_comm_init before nl_finalize", e->G);
+    if (e->G > 1 && !e->comm && !(c.flags & NL_FLAG_LOCAL_GROUP))
+        return e->fail(NL_ERR_STATE, "tp_size %d needs nl_comm_init before nl_finalize", e->G);
     if (e->stage) { hipFree(e->stage); e->stage = nullptr; e->stage_cap = 0; }
     build_plan(e);
     HIPCK(e, hipStreamSynchronize(e->stream));
@@ -1030,6 +1031,55 @@ int nl_op_rmsnorm(int device, const float *x, const float *w, float eps, float *
     } while (0);
     hipFree(d);
     return rc;
+}
+
+// ---- in-process tensor-parallel group ----------------------------------------
+
+int nl_group_forward(nl_handle *hs, int n, int stream, int token, int pos, float *logits_out) {
+    if (!hs || n < 1 || n > 8) return NL_ERR_INVALID;
+    nl_engine *e0 = hs[0];
+    if (!e0) return NL_ERR_INVALID;
+    for (int r = 0; r < n; r++) {
+        if (!hs[r] || hs[r]->G != n || hs[r]->rank != r || !(hs[r]->cfg.flags & NL_FLAG_LOCAL_GROUP))
+            return e0->fail(NL_ERR_INVALID, "nl_group_forward: shard %d is not rank %d of a local group of %d", r, r, n);
+        int rc = check_step_args(hs[r], stream, token, pos);
+        if (rc) return rc;
+        if (hs[r]->plan.size() != e0->plan.size()) return e0->fail(NL_ERR_STATE, "shards disagree on the launch plan");
+        if (hs[r]->dev != e0->dev) return e0->fail(NL_ERR_UNSUPPORTED, "local group across devices is not implemented");
+    }
+    HIPCK(e0, hipSetDevice(e0->dev));
+    hipStream_t st = e0->stream;  // one stream serialises the whole group
+    for (int r = 0; r < n; r++) {
+        nl_engine *e = hs[r];
+        e->h_ctl[CTL_TOKEN] = token; e->h_ctl[CTL_POS] = pos; e->h_ctl[CTL_CHAIN] = 0;
+        e->h_ctl[CTL_STEP] = 0; e->h_ctl[CTL_STREAM] = stream;
+        HIPCK(e0, hipMemcpyAsync(e->ctl, e->h_ctl, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    for (size_t i = 0; i < e0->plan.size(); i++) {
+        for (int r = 0; r < n; r++) {
+            hipError_t s = hs[r]->plan[i].fn(st);
+            if (s != hipSuccess) return e0->fail(NL_ERR_HIP, "group launch %s: %s", kKindNames[e0->plan[i].kind], hipGetErrorString(s));
+        }
+        const Op &op = e0->plan[i];
+        if (op.coll == 1) {
+            PtrList8 pl{};
+            for (int r = 0; r < n; r++) pl.p[r] = hs[r]->plan[i].buf;
+            int cnt = (int)op.count;
+            hipLaunchKernelGGL(local_allreduce_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, pl, n, cnt);
+            HIPCK(e0, hipGetLastError());
+        } else if (op.coll == 2) {
+            for (int src = 0; src < n; src++)
+                for (int dst = 0; dst < n; dst++)
+                    if (src != dst)
+                        HIPCK(e0, hipMemcpyAsync(hs[dst]->plan[i].buf + (size_t)src * op.count,
+                                                 hs[src]->plan[i].buf + (size_t)src * op.count, op.count * 4,
+                                                 hipMemcpyDeviceToDevice, st));
+        }
+    }
+    if (logits_out)
+        HIPCK(e0, hipMemcpyAsync(logits_out, e0->logits, (size_t)e0->cfg.vocab * 4, hipMemcpyDeviceToHost, st));
+    HIPCK(e0, hipStreamSynchronize(st));
+    return NL_OK;
 }
 
 // ---- tensor-parallel communicator -------------------------------------------

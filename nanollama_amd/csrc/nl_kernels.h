@@ -890,14 +890,15 @@ __global__ void __launch_bounds__(1024) argmax_kernel(ArgmaxParams P) {
     }
 }
 
-// sum of tensor-parallel partial vectors living on ONE device (single-process
-// emulation of the all-reduce, used by tests): dst[r][i] = sum_k src[k][i]
-__global__ void local_allreduce_kernel(float *const *bufs, int nranks, int n) {
+// Sum of tensor-parallel partial vectors living in ONE process (the in-process stand-in for the
+// RCCL all-reduce, used by nl_group_forward): every buffer ends up holding the sum.
+struct PtrList8 { float *p[8]; };
+__global__ void local_allreduce_kernel(PtrList8 bufs, int nranks, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
-    for (int k = 0; k < nranks; k++) s += bufs[k][i];
-    for (int k = 0; k < nranks; k++) bufs[k][i] = s;
+    for (int k = 0; k < nranks; k++) s += bufs.p[k][i];   // fixed rank order: deterministic
+    for (int k = 0; k < nranks; k++) bufs.p[k][i] = s;
 }
 
 }  // namespace nl

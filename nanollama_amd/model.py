@@ -143,7 +143,7 @@ def load_llama_model(gguf: GGUFFile, device: int = 0, max_streams: int = 1, tp_r
     if rc != 0:
         raise _lib.NlError(rc, (L.nl_last_error(None) or b"").decode())
     try:
-        if tp_size > 1:
+        if tp_size > 1 and not (flags & _lib.NL_FLAG_LOCAL_GROUP):
             if comm_id is None or len(comm_id) != _lib.NL_COMM_ID_BYTES:
                 raise ValueError("tp_size > 1 needs the communicator id from nl_comm_get_unique_id")
             _lib.check(h, L.nl_comm_init(h, C.c_char_p(comm_id)))
@@ -165,6 +165,29 @@ def load_llama_model(gguf: GGUFFile, device: int = 0, max_streams: int = 1, tp_r
         print(f"[model] loaded: {config.num_layers} layers, {config.embed_dim} dim, {config.num_heads} heads, "
               f"{config.num_kv_heads} kv_heads, {config.vocab_size} vocab, bias=False")
     return LlamaModel(config, h, max_streams)
+
+
+class LocalTPGroup:
+    """n tensor-parallel shards of one model in THIS process (nl_group_forward): the same sharding
+    arithmetic as the one-process-per-GPU RCCL path, with the all-reduce / all-gather seams done
+    in-process so it can be checked on a single GPU."""
+
+    def __init__(self, gguf: GGUFFile, n: int, device: int = 0):
+        self.shards = [load_llama_model(gguf, device=device, tp_rank=r, tp_size=n, flags=_lib.NL_FLAG_LOCAL_GROUP)
+                       for r in range(n)]
+        self.n = n
+        self.logits = np.zeros(self.shards[0].config.vocab_size, dtype=np.float32)
+
+    def forward(self, token: int, pos: int, stream: int = 0) -> np.ndarray:
+        hs = (C.c_void_p * self.n)(*[s._h for s in self.shards])
+        rc = _lib.lib().nl_group_forward(hs, self.n, stream, int(token), int(pos),
+                                         self.logits.ctypes.data_as(C.POINTER(C.c_float)))
+        _lib.check(self.shards[0]._h, rc)
+        return self.logits
+
+    def close(self):
+        for s in self.shards:
+            s.close()
 
 
 def comm_unique_id() -> bytes:

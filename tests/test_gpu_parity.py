@@ -262,3 +262,49 @@ def test_full_size_tiers_match_oracle(hip, orc, tmp_path, tier, wtype, ntok):
     orc.set_threads(1)
     print(f"\n{tier}/{wtype}: max|gpu-oracle|={worst:.2e} (logit std {scale:.2f})")
     assert worst <= LOGIT_TOL * scale
+
+
+@pytest.mark.parametrize("tag,n", [("tiny_q8_0", 2), ("tiny_q4_0", 2), ("tiny_mha_q4_0", 2)])
+def test_tensor_parallel_shards_match_single_gpu(hip, orc, tag, n):
+    # the TP sharding arithmetic (row-split QKV/gate/up/LM head, column-split WO/down, all-reduce seams)
+    # stepped in-process on one GPU; must agree with the unsharded engine and the oracle
+    g = gguf.load_gguf(os.path.join(GOLDEN, tag + ".gguf"))
+    grp = hip.LocalTPGroup(g, n)
+    one = hip.load_llama_model(g)
+    ref = orc.OracleModel(g)
+    v = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    worst1 = worst_o = 0.0
+    for pos, tok in enumerate(v["prompt"]):
+        lg = grp.forward(int(tok), pos)
+        one.forward(int(tok), pos)
+        want = ref.forward(int(tok), pos)
+        worst1 = max(worst1, float(np.abs(lg - one.state.logits).max()))
+        worst_o = max(worst_o, float(np.abs(lg - want).max()))
+        assert int(np.argmax(lg)) == int(np.argmax(want))
+    print(f"\n{tag} tp{n}: max|tp-single|={worst1:.2e} max|tp-oracle|={worst_o:.2e}")
+    assert worst_o <= LOGIT_TOL and worst1 <= LOGIT_TOL
+    grp.close(); one.close()
+
+
+def test_tensor_parallel_big_shapes(hip, orc, tmp_path):
+    # 2 layers with big-like ratios (GQA 2:1 over 16 heads, FFN multiple of 32*8) on 4 and 8 shards,
+    # context long enough for two attention splits
+    shape = synth.ModelShape("tp_probe", 2, 1024, 16, 8, 2048, seq_len=160, interm=2816)
+    p = tmp_path / "tp.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", 9)
+    g = gguf.load_gguf(str(p))
+    ref = orc.OracleModel(g)
+    toks = synth.prompt_ids(140, shape.vocab, seed=2)
+    wants = []
+    for pos, t in enumerate(toks):
+        wants.append(ref.forward(t, pos).copy())
+    for n in (4, 8):
+        grp = hip.LocalTPGroup(g, n)
+        worst = 0.0
+        for pos, t in enumerate(toks):
+            lg = grp.forward(t, pos)
+            if pos % 20 == 0 or pos > 130:
+                worst = max(worst, float(np.abs(lg - wants[pos]).max()))
+        print(f"\ntp{n}: max|tp-oracle|={worst:.2e}")
+        assert worst <= LOGIT_TOL * max(1.0, float(wants[-1].std()))
+        grp.close()
