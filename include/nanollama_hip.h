@@ -102,6 +102,17 @@ NL_API int nl_forward_argmax(nl_handle h, int stream, int token, int pos, int *n
  * count in *n_done) when pos reaches seq_len, as go/main.go:216 does. */
 NL_API int nl_decode_greedy(nl_handle h, int stream, int token, int pos, int n_steps, int *ids_out, int *n_done);
 
+/* Prompt prefill (go/main.go:160-166 feeds the prompt token-at-a-time through Forward): runs
+ * tokens[0..n) at positions pos0..pos0+n-1 of `stream` back to back on the device with no host
+ * round trip; last_logits_out (may be NULL) receives the logits after the last token.  Results are
+ * bitwise those of n nl_forward calls.  pos0 + n must be <= seq_len. */
+NL_API int nl_prefill(nl_handle h, int stream, const int *tokens, int n, int pos0, float *last_logits_out);
+/* One Forward for each of n (stream, token, pos) triples -- the concurrent decode streams of a
+ * serving host.  logits_out (may be NULL) is n x vocab; next_ids (may be NULL) receives each
+ * stream's greedy argmax.  Streams must be distinct. */
+NL_API int nl_forward_batch(nl_handle h, const int *streams, const int *tokens, const int *pos, int n,
+                            float *logits_out, int *next_ids);
+
 /* == introspection / measurement ========================================== */
 NL_API int nl_get_config(nl_handle h, nl_config *out); /* effective config (after seq_len cap etc.) */
 NL_API int nl_synchronize(nl_handle h);

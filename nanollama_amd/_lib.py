@@ -48,7 +48,7 @@ def build(force: bool = False) -> str:
 _lib = None
 
 EXPORTS = ["nl_abi_version", "nl_device_count", "nl_create", "nl_upload_tensor", "nl_finalize", "nl_destroy",
-           "nl_last_error", "nl_reset", "nl_forward", "nl_forward_argmax", "nl_decode_greedy", "nl_get_config",
+           "nl_last_error", "nl_reset", "nl_forward", "nl_forward_argmax", "nl_decode_greedy", "nl_prefill", "nl_forward_batch", "nl_get_config",
            "nl_synchronize", "nl_timer_start", "nl_timer_stop", "nl_kernel_kind_name", "nl_profile_forward",
            "nl_memory_usage", "nl_debug_read", "nl_op_matmul", "nl_op_rmsnorm", "nl_comm_get_unique_id",
            "nl_comm_init", "nl_group_forward", "nl_debug_stamps"]
@@ -75,6 +75,8 @@ def lib():
     L.nl_forward.argtypes = [vp, i32, i32, i32, fp]
     L.nl_forward_argmax.argtypes = [vp, i32, i32, i32, ip]
     L.nl_decode_greedy.argtypes = [vp, i32, i32, i32, i32, ip, ip]
+    L.nl_prefill.argtypes = [vp, i32, ip, i32, i32, fp]
+    L.nl_forward_batch.argtypes = [vp, ip, ip, ip, i32, fp, ip]
     L.nl_get_config.argtypes = [vp, C.POINTER(NlConfig)]
     L.nl_synchronize.argtypes = [vp]
     L.nl_timer_start.argtypes = [vp]

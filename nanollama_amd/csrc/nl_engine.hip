@@ -136,6 +136,8 @@ struct nl_engine {
     int *amax_idx = nullptr;
     int amax_slots = 0;
     int *h_ctl = nullptr;  // pinned staging
+    int *h_ctl_ring = nullptr;  // pinned: one ctl block per queued step (prefill / batch)
+    int ctl_ring_cap = 0;
     int ids_cap = 0;
     size_t bytes_weights = 0, bytes_kv = 0, bytes_state = 0;
 
@@ -757,6 +759,8 @@ int nl_finalize(nl_handle e) {
     HIPCK(e, dalloc(&e->amax_idx, (size_t)e->amax_slots, &e->bytes_state));
     HIPCK(e, hipHostMalloc((void **)&e->h_ctl, CTL_WORDS * sizeof(int), hipHostMallocDefault));
     memset(e->h_ctl, 0, CTL_WORDS * sizeof(int));
+    e->ctl_ring_cap = std::max(c.seq_len, c.max_streams);
+    HIPCK(e, hipHostMalloc((void **)&e->h_ctl_ring, (size_t)e->ctl_ring_cap * CTL_WORDS * sizeof(int), hipHostMallocDefault));
     HIPCK(e, hipMemcpy(e->ctl, e->h_ctl, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice));
     if (e->G > 1 && !e->comm && !(c.flags & NL_FLAG_LOCAL_GROUP))
         return e->fail(NL_ERR_STATE, "tp_size %d needs nl_comm_init before nl_finalize", e->G);
@@ -788,6 +792,7 @@ int nl_destroy(nl_handle e) {
                     e->amax_idx};
     for (void *b : bufs) if (b) hipFree(b);
     if (e->h_ctl) hipHostFree(e->h_ctl);
+    if (e->h_ctl_ring) hipHostFree(e->h_ctl_ring);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
@@ -844,6 +849,52 @@ int nl_decode_greedy(nl_handle e, int stream, int token, int pos, int n_steps, i
     if (n > 0) HIPCK(e, hipMemcpyAsync(ids_out, e->ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCK(e, hipStreamSynchronize(e->stream));
     if (n_done) *n_done = n;
+    return NL_OK;
+}
+
+int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, float *last_logits_out) {
+    if (!e || !tokens || n < 0) return NL_ERR_INVALID;
+    if (n == 0) return NL_OK;
+    int rc = check_step_args(e, stream, tokens[0], pos0);
+    if (rc) return rc;
+    if (pos0 + n > e->cfg.seq_len) return e->fail(NL_ERR_INVALID, "prefill of %d tokens at pos %d exceeds seq_len %d", n, pos0, e->cfg.seq_len);
+    for (int i = 0; i < n; i++)
+        if (tokens[i] < 0 || tokens[i] >= e->cfg.vocab) return e->fail(NL_ERR_INVALID, "token %d out of range [0,%d)", tokens[i], e->cfg.vocab);
+    HIPCK(e, hipSetDevice(e->dev));
+    for (int i = 0; i < n; i++) {
+        int *c = e->h_ctl_ring + (size_t)i * CTL_WORDS;
+        c[CTL_TOKEN] = tokens[i]; c[CTL_POS] = pos0 + i; c[CTL_CHAIN] = 0; c[CTL_STEP] = 0; c[CTL_STREAM] = stream;
+        HIPCK(e, hipMemcpyAsync(e->ctl, c, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        if ((rc = launch_step(e))) return rc;
+    }
+    if (last_logits_out)
+        HIPCK(e, hipMemcpyAsync(last_logits_out, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCK(e, hipStreamSynchronize(e->stream));
+    return NL_OK;
+}
+
+int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const int *pos, int n, float *logits_out,
+                     int *next_ids) {
+    if (!e || !streams || !tokens || !pos || n < 0) return NL_ERR_INVALID;
+    if (n > e->cfg.max_streams) return e->fail(NL_ERR_INVALID, "batch of %d exceeds max_streams %d", n, e->cfg.max_streams);
+    int rc;
+    for (int i = 0; i < n; i++) {
+        if ((rc = check_step_args(e, streams[i], tokens[i], pos[i]))) return rc;
+        for (int j = 0; j < i; j++)
+            if (streams[j] == streams[i]) return e->fail(NL_ERR_INVALID, "stream %d appears twice in one batch", streams[i]);
+    }
+    HIPCK(e, hipSetDevice(e->dev));
+    for (int i = 0; i < n; i++) {
+        int *c = e->h_ctl_ring + (size_t)i * CTL_WORDS;
+        c[CTL_TOKEN] = tokens[i]; c[CTL_POS] = pos[i]; c[CTL_CHAIN] = 0; c[CTL_STEP] = 0; c[CTL_STREAM] = streams[i];
+        HIPCK(e, hipMemcpyAsync(e->ctl, c, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        if ((rc = launch_step(e))) return rc;
+        if (logits_out)
+            HIPCK(e, hipMemcpyAsync(logits_out + (size_t)i * e->cfg.vocab, e->logits, (size_t)e->cfg.vocab * 4,
+                                    hipMemcpyDeviceToHost, e->stream));
+        if (next_ids) HIPCK(e, hipMemcpyAsync(next_ids + i, e->result, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCK(e, hipStreamSynchronize(e->stream));
     return NL_OK;
 }
 

@@ -73,6 +73,22 @@ class LlamaModel:
                                                         C.byref(done)))
         return [int(ids[i]) for i in range(done.value)]
 
+    def prefill(self, tokens: List[int], pos0: int = 0, stream: int = 0, want_logits: bool = True) -> None:
+        """The prompt loop of Generate (go/main.go:160-166) queued on the device in one call."""
+        arr = (C.c_int * len(tokens))(*[int(t) for t in tokens])
+        out = self.state.logits.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None
+        _lib.check(self._h, _lib.lib().nl_prefill(self._h, stream, arr, len(tokens), int(pos0), out))
+
+    def forward_batch(self, streams: List[int], tokens: List[int], pos: List[int], want_logits: bool = False):
+        n = len(streams)
+        ia = lambda v: (C.c_int * n)(*[int(x) for x in v])
+        ids = (C.c_int * n)()
+        lg = np.zeros((n, self.config.vocab_size), dtype=np.float32) if want_logits else None
+        _lib.check(self._h, _lib.lib().nl_forward_batch(
+            self._h, ia(streams), ia(tokens), ia(pos), n,
+            lg.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None, ids))
+        return [int(ids[i]) for i in range(n)], lg
+
     # --- Reset go/model.go:623 ---
     def reset(self, stream: int = 0) -> None:
         _lib.check(self._h, _lib.lib().nl_reset(self._h, stream))

@@ -308,3 +308,51 @@ def test_tensor_parallel_big_shapes(hip, orc, tmp_path):
         print(f"\ntp{n}: max|tp-oracle|={worst:.2e}")
         assert worst <= LOGIT_TOL * max(1.0, float(wants[-1].std()))
         grp.close()
+
+
+def test_prefill_equals_token_at_a_time(hip, orc):
+    g = gguf.load_gguf(os.path.join(GOLDEN, "tiny_q4_0.gguf"))
+    v = np.load(os.path.join(GOLDEN, "tiny_q4_0.npz"))
+    toks = [int(t) for t in v["prompt"]]
+    a = hip.load_llama_model(g)
+    b = hip.load_llama_model(g)
+    a.prefill(toks)
+    for pos, t in enumerate(toks):
+        b.forward(t, pos)
+    assert a.state.logits.tobytes() == b.state.logits.tobytes()
+    assert np.abs(a.state.logits - v["logits_full"][len(toks) - 1]).max() <= LOGIT_TOL
+    # decode continues identically from a prefilled cache; prefill in two pieces == one piece
+    assert a.decode_greedy(int(np.argmax(a.state.logits)), len(toks), 8) == \
+        b.decode_greedy(int(np.argmax(b.state.logits)), len(toks), 8)
+    c = hip.load_llama_model(g)
+    c.prefill(toks[:5], want_logits=False)
+    c.prefill(toks[5:], pos0=5)
+    assert c.state.logits.tobytes() == b.state.logits.tobytes()
+    from nanollama_amd._lib import NlError
+    with pytest.raises(NlError, match="exceeds seq_len"):
+        c.prefill([1] * 10, pos0=60)
+    c.prefill([])  # empty prompt is a no-op
+    a.close(); b.close(); c.close()
+
+
+def test_forward_batch_equals_individual_forwards(hip):
+    g = gguf.load_gguf(os.path.join(GOLDEN, "tiny_q8_0.gguf"))
+    dev = hip.load_llama_model(g, max_streams=4)
+    solo = hip.load_llama_model(g, max_streams=4)
+    seqs = [[1, 7, 8, 9], [1, 300, 301, 302], [1, 44, 45, 46]]   # ragged: stream 2 joins late
+    for step in range(4):
+        streams = [s for s in range(3) if not (s == 2 and step == 0)]
+        toks = [seqs[s][step - (1 if s == 2 else 0)] for s in streams]
+        pos = [step - (1 if s == 2 else 0) for s in streams]
+        ids, lg = dev.forward_batch(streams, toks, pos, want_logits=True)
+        for k, s in enumerate(streams):
+            solo.forward(toks[k], pos[k], stream=s)
+            assert lg[k].tobytes() == solo.state.logits.tobytes()
+            assert ids[k] == int(np.argmax(solo.state.logits))
+    from nanollama_amd._lib import NlError
+    with pytest.raises(NlError, match="twice"):
+        dev.forward_batch([0, 0], [1, 1], [0, 0])
+    with pytest.raises(NlError, match="max_streams"):
+        dev.forward_batch([0, 1, 2, 3, 0], [1] * 5, [0] * 5)
+    assert dev.forward_batch([], [], []) == ([], None)
+    dev.close(); solo.close()
