@@ -1,0 +1,54 @@
+"""The C-ABI library builds for gfx950 without a GPU, loads, and exports every symbol the header declares
+(no compute calls here: those are the -m gpu tests)."""
+import ctypes
+import os
+import re
+
+from nanollama_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "nanollama_hip.h")).read()
+    return sorted(set(re.findall(r"NL_API\s+[\w\s\*]+?\b(nl_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 25, names
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(_lib.EXPORTS) <= set(names)
+
+
+def test_probes_work_without_a_gpu():
+    L = _lib.lib()
+    assert L.nl_abi_version() == 1
+    assert L.nl_device_count() >= 0
+    assert L.nl_kernel_kind_name(6) == b"lm_head" and L.nl_kernel_kind_name(99) == b""
+
+
+def test_create_without_gpu_fails_loudly_or_succeeds_with_one():
+    L = _lib.lib()
+    cfg = _lib.NlConfig(2, 128, 4, 2, 32, 512, 512, 64, 1e-5, 10000.0, 0, 0, 1, 0, 0, 1, 0)
+    h = ctypes.c_void_p()
+    rc = L.nl_create(ctypes.byref(cfg), ctypes.byref(h))
+    if L.nl_device_count() == 0:
+        assert rc == -3 and b"no HIP device" in L.nl_last_error(None)   # NL_ERR_HIP, never a CPU fallback
+    else:
+        assert rc == 0
+        L.nl_destroy(h)
+    bad = _lib.NlConfig(2, 100, 4, 2, 25, 512, 512, 64, 1e-5, 10000.0, 0, 0, 1, 0, 0, 1, 0)
+    assert L.nl_create(ctypes.byref(bad), ctypes.byref(h)) in (-1, -2, -3)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "nanollama_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in src.replace("oracle/", "ORACLE_DIR_MENTION"), f
