@@ -98,50 +98,23 @@ def cpu_baseline(path, prompt, budget_s=20.0):
                       f"C restatement of go/quant.go+go/model.go with the Go row partition on {cores} threads (best of 1..64 on a {ncpu}-cpu host)"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
-    ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--workload", default=None, help="tier:wtype override, e.g. big:q4_0 (default by --gpus)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-pos", type=int, default=PROMPT_LEN + SEGMENT // 2)
-    args = ap.parse_args()
-
-    # the product library is loaded before torch so it binds /opt/rocm's HIP runtime
-    from nanollama_amd import _lib, model
-    from nanollama_amd.dist import Rendezvous
-    _lib.lib()
-    rdv = Rendezvous()
+def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model):
+    """Load the tier's random-weight GGUF, run `warmup` + `steps` chained greedy decode steps, profile the
+    launches.  Returns the result dict (rank 0's view; timing is the max over ranks)."""
     rank, world, local_rank = rdv.rank, rdv.world, rdv.local_rank
-    n = args.gpus
-    if world != n and world != 1:
-        raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}")
-
-    if args.workload:
-        tier, wtype = args.workload.split(":")
-    else:
-        tier, wtype = ("nano", "q8_0") if n == 1 else ("big", "q4_0")
     shape = synth.TIERS[tier]
     mode = "qrand" if tier in ("big", "goldie") else "float"
-
     comm_id = rdv.broadcast_bytes(model.comm_unique_id) if world > 1 else None
-
     path = ensure_gguf(shape, wtype, mode, rank)
     rdv.barrier()
     g = gguf.load_gguf(path)
     dev = model.load_llama_model(g, device=local_rank, tp_rank=rank if world > 1 else 0, tp_size=world,
                                  comm_id=comm_id)
     prompt = synth.prompt_ids(PROMPT_LEN, shape.vocab)
+    dev.prefill(prompt)
+    first, pos0 = int(np.argmax(dev.state.logits)), len(prompt)
 
-    def prefill():
-        pos = 0
-        for t in prompt:
-            dev.forward(t, pos)
-            pos += 1
-        return int(np.argmax(dev.state.logits)), pos
-
-    def run_steps(k, first, pos0):
+    def run_steps(k):
         """k chained decode steps in segments of SEGMENT tokens; every segment restarts at pos0 on
         the still-valid prompt prefix of the KV cache, so no prefill is inside the loop."""
         done, ids = 0, []
@@ -151,24 +124,22 @@ def main():
             done += seg
         return ids
 
-    first, pos0 = prefill()
-    run_steps(args.warmup, first, pos0)
+    run_steps(warmup)
     dev.synchronize()
     rdv.barrier()
     dev.timer_start()
     t0 = time.perf_counter()
-    ids = run_steps(args.steps, first, pos0)
+    ids = run_steps(steps)
     dev.synchronize()
     wall_ms = (time.perf_counter() - t0) * 1e3
     ev_ms = dev.timer_stop()
     rdv.barrier()
     wall_ms = rdv.max_over_ranks(wall_ms)
+    ms_per_step = wall_ms / steps
 
-    ms_per_step = wall_ms / args.steps
-    tok_s = args.steps / (wall_ms / 1e3)
-
-    # per-kernel device time (HIP events on the engine's stream, eager launches) at a mid-run position
-    ppos = min(args.profile_pos, shape.seq_len - 1)
+    # per-launch device time: every launch of the plan replayed 20x back to back between HIP events on the
+    # engine's stream (nl_profile_forward), at a mid-run position
+    ppos = min(profile_pos, shape.seq_len - 1)
     prof = dev.profile_forward(first, ppos, iters=20)
     kb = kernel_bytes(shape, wtype, ppos, tp=world)
     kernels = {}
@@ -177,35 +148,86 @@ def main():
             per = ms / calls
             kernels[kind] = {"launches": calls, "us_per_launch": round(per * 1e3, 3),
                              "GBps": round(kb[kind] / (per * 1e-3) / 1e9, 1)}
+    traffic = None
+    try:  # HBM bytes per launch measured with rocprofv3 PMC counters in a separate pass (profiles/README.md)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        traffic = tj.get(f"{tier}_{wtype}") if world == 1 else None
+    except (OSError, ValueError):
+        pass
     dom = max((k for k in kernels if k != "argmax"), key=lambda k: prof[k][0])
     dom_gbs = kernels[dom]["GBps"]
-    mean_pos = pos0 + (min(SEGMENT, args.steps) - 1) / 2.0
-    step_bytes = (synth.weight_bytes_per_token(shape, wtype) + synth.kv_bytes_per_token(shape, int(mean_pos)))
+    mean_pos = pos0 + (min(SEGMENT, steps) - 1) / 2.0
+    step_bytes = synth.weight_bytes_per_token(shape, wtype) + synth.kv_bytes_per_token(shape, int(mean_pos))
     step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
+    dev.close()
+    return {
+        "tier": tier, "wtype": wtype, "path": path, "prompt": prompt,
+        "tok_s": steps / (wall_ms / 1e3), "ms_per_step": ms_per_step, "device_ms_per_step": ev_ms / steps,
+        "step_bytes": int(step_bytes), "hbm_frac_whole_step": step_gbs / (HBM_PEAK_GBS * max(world, 1)),
+        "kernels": kernels, "last_ids": ids[-4:],
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": (traffic or {}).get(dom),
+                     "bytes_per_launch": int(kb[dom]), "us_per_launch": kernels[dom]["us_per_launch"]},
+    }
 
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--workload", default=None, help="tier:wtype override, e.g. big:q4_0 (default by --gpus)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the big Q4_0 single-GPU side measurement")
+    ap.add_argument("--profile-pos", type=int, default=PROMPT_LEN + SEGMENT // 2)
+    args = ap.parse_args()
+
+    # the product library is loaded before torch so it binds /opt/rocm's HIP runtime
+    from nanollama_amd import _lib, model
+    from nanollama_amd.dist import Rendezvous
+    _lib.lib()
+    rdv = Rendezvous()
+    rank, world = rdv.rank, rdv.world
+    n = args.gpus
+    if world != n and world != 1:
+        raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}")
+    if args.workload:
+        tier, wtype = args.workload.split(":")
+    else:
+        tier, wtype = ("nano", "q8_0") if n == 1 else ("big", "q4_0")
+    shape = synth.TIERS[tier]
+
+    r = run_workload(tier, wtype, rdv, args.steps, args.warmup, args.profile_pos, model)
     out = {
         "metric": f"decode tokens/sec, {tier} {wtype.upper()} single-stream greedy"
                   + (f", tensor-parallel over {world} GPUs" if world > 1 else ""),
-        "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+        "value": round(r["tok_s"], 2), "unit": "tokens/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(r["ms_per_step"], 5), "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (random-weight GGUF, reference exporter layout, nanollama_amd.synth)",
         "config": {"workload": f"{tier} ({shape.matrix_params() / 1e6:.0f}M matrix params) {wtype.upper()} GGUF, "
                                f"{PROMPT_LEN}-token prompt + {SEGMENT}-token greedy decode segments, 1 stream",
                    "parallelism": f"tp{world}" if world > 1 else "single-gpu",
                    "weights": f"{wtype} blocks dequantised in-register, f32 activations and KV cache"},
-        "device_ms_per_step": round(ev_ms / args.steps, 5),
-        "hbm_frac_whole_step": round(step_gbs / (HBM_PEAK_GBS * max(world, 1)), 4),
-        "algorithmic_bytes_per_step": int(step_bytes),
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                     "bytes_per_launch": int(kb[dom]), "us_per_launch": kernels[dom]["us_per_launch"]},
-        "kernels": kernels,
-        "last_ids": ids[-4:],
+        "device_ms_per_step": round(r["device_ms_per_step"], 5),
+        "hbm_frac_whole_step": round(r["hbm_frac_whole_step"], 4),
+        "algorithmic_bytes_per_step": r["step_bytes"],
+        "roofline": r["roofline"], "kernels": r["kernels"], "last_ids": r["last_ids"],
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(path, prompt)
-    dev.close()
+        out["cpu_baseline"] = cpu_baseline(r["path"], r["prompt"])
+    if world == 1 and not args.workload and not args.no_secondary:
+        # BASELINE.json's metric also names big Q4_0 @ 1 GPU: measured here as a side result (bandwidth-bound
+        # regime; the headline nano config is launch-latency-bound)
+        try:
+            b = run_workload("big", "q4_0", rdv, 96, 16, args.profile_pos, model)
+            out["secondary"] = {"workload": "big (7.9B) Q4_0 single-stream greedy decode, 1 GPU",
+                                "value": round(b["tok_s"], 2), "unit": "tokens/s",
+                                "ms_per_step": round(b["ms_per_step"], 5),
+                                "hbm_frac_whole_step": round(b["hbm_frac_whole_step"], 4),
+                                "roofline": b["roofline"], "kernels": b["kernels"]}
+        except Exception as exc:  # the headline result must survive a failure of the side measurement
+            out["secondary"] = {"error": repr(exc)}
     if rank == 0:
         print(json.dumps(out))
     rdv.close()
