@@ -104,7 +104,7 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model):
     rank, world, local_rank = rdv.rank, rdv.world, rdv.local_rank
     shape = synth.TIERS[tier]
     mode = "qrand" if tier in ("big", "goldie") else "float"
-    comm_id = rdv.broadcast_bytes(model.comm_unique_id) if world > 1 else None
+    comm_id = rdv.broadcast_bytes(model.comm_unique_id) if (world > 1 or os.environ.get("NL_FORCE_TP_PLAN")) else None
     path = ensure_gguf(shape, wtype, mode, rank)
     rdv.barrier()
     g = gguf.load_gguf(path)

@@ -154,6 +154,7 @@ struct nl_engine {
     bool use_graph = true;
     void *comm = nullptr;
     int tw_override = 0, kw_override = 0;
+    bool force_tp_plan = false;  // NL_FORCE_TP_PLAN: use the all-reduce / all-gather seams even with one rank
 
     int fail(int code, const char *fmt, ...) {
         char buf[512];
@@ -249,25 +250,26 @@ hipError_t alloc_packed(nl_engine *e, PackedMat &m, int wtype, int rows_padded_t
     return hipSuccess;
 }
 
-void choose_geometry(const nl_engine *e, const PackedMat &m, int &tw, int &kw) {
+void choose_geometry(const nl_engine *e, const PackedMat &m, int &tw, int &kw, int mats = 1) {
     // kw wavefronts share a tile's 256-column groups, tw tiles share a workgroup.  Aim for >= ~2048
     // wavefronts in flight (8 per CU); small matrices go all the way to one group per wavefront,
     // which is what minimises the in-launch latency of small models.
     const int ngroups = (m.npairs + KL - 1) / KL;
     kw = (2048 + m.ntiles - 1) / std::max(1, m.ntiles);
-    kw = std::max(1, std::min(kw, std::min(ngroups, 8)));  // workgroups are capped at 8 wavefronts (256 VGPRs each)
-    tw = std::max(1, 4 / kw);
-    if (e->kw_override > 0) kw = std::min(e->kw_override, 8);
+    const int cap = 8 / mats;  // workgroups are capped at 8 wavefronts (256 VGPRs each)
+    kw = (kw + mats - 1) / mats;
+    kw = std::max(1, std::min(kw, std::min(ngroups, cap)));
+    tw = std::max(1, 4 / (kw * mats));
+    if (e->kw_override > 0) kw = std::min(e->kw_override, cap);
     if (e->tw_override > 0) tw = e->tw_override;
-    if (tw * kw > 8) tw = std::max(1, 8 / kw);
+    if (tw * kw * mats > 8) tw = std::max(1, 8 / (kw * mats));
     if (tw > m.ntiles) tw = m.ntiles;
 }
 
 template <int PRO, int EPI>
 hipError_t launch_gemv_t(int wtype, GemvParams P, hipStream_t st) {
-    const int nm = EPI == EPI_SWIGLU ? 2 : 1;
-    const int nwaves = P.tw * P.kw;
-    const size_t lds = (size_t)nwaves * XS_WAVE * 4 + (size_t)nm * nwaves * TR * 4 + (size_t)nwaves * 8;
+    const int nwaves = P.tw * P.kw * (EPI == EPI_SWIGLU ? 2 : 1);
+    const size_t lds = (size_t)nwaves * XS_WAVE * 4 + (size_t)nwaves * TR * 4 + (size_t)nwaves * 8;
     const dim3 grid((P.ntiles + P.tw - 1) / P.tw), block(nwaves * 64);
     switch (wtype) {
     case WT_Q8_0: hipLaunchKernelGGL((gemv_kernel<WT_Q8_0, PRO, EPI>), grid, block, lds, st, P); break;
@@ -279,11 +281,11 @@ hipError_t launch_gemv_t(int wtype, GemvParams P, hipStream_t st) {
     return hipGetLastError();
 }
 
-GemvParams base_params(const nl_engine *e, const PackedMat &m) {
+GemvParams base_params(const nl_engine *e, const PackedMat &m, int mats = 1) {
     GemvParams P{};
     P.q0 = m.q; P.s0 = m.s;
     P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
-    choose_geometry(e, m, P.tw, P.kw);
+    choose_geometry(e, m, P.tw, P.kw, mats);
     P.eps = e->cfg.rms_eps;
     P.ctl = e->ctl;
     P.head_dim = e->hd;
@@ -343,7 +345,7 @@ void link_prefetch(nl_engine *e) {
 void build_plan(nl_engine *e) {
     e->plan.clear();
     const nl_config &c = e->cfg;
-    const bool tp = e->G > 1;
+    const bool tp = e->G > 1 || e->force_tp_plan;
     int cur = 0;
     int lm_blocks = 0, lm_spb = 1;
     const float *pending = nullptr;  // all-reduced partial still to be added to the residual stream
@@ -400,7 +402,7 @@ void build_plan(nl_engine *e) {
             }
         }
         {   // RMSNorm + gate/up GEMV + SiLU*up (go/model.go:597-606)
-            GemvParams P = base_params(e, L.gate);
+            GemvParams P = base_params(e, L.gate, 2);
             P.q1 = L.up.q; P.s1 = L.up.s;
             P.x = e->x[cur]; P.normw = L.ffn_norm; P.out = e->hb;
             if (pending) { P.add = pending; P.x_out = e->x[cur ^ 1]; }
@@ -446,7 +448,7 @@ void build_plan(nl_engine *e) {
 
 int run_collective(nl_engine *e, const Op &op) {
     if (!op.coll) return NL_OK;
-    if (!e->comm) return e->fail(NL_ERR_COMM, "tensor-parallel forward without nl_comm_init");
+    if (!e->comm) return e->fail(NL_ERR_COMM, "tensor-parallel forward without nl_comm_init (local groups use nl_group_forward)");
     int rc;
     if (op.coll == 1) rc = g_rccl.AllReduce(op.buf, op.buf, op.count, kNcclFloat, kNcclSum, e->comm, e->stream);
     else rc = g_rccl.AllGather(op.buf + (size_t)e->rank * op.count, op.buf, op.count, kNcclFloat, e->comm, e->stream);
@@ -560,6 +562,7 @@ int nl_create(const nl_config *cfg, nl_handle *out) {
     e->nsplit_max = (c.seq_len + ATT_CH - 1) / ATT_CH;
     e->layers.resize(c.n_layers);
     e->use_graph = !(c.flags & NL_FLAG_NO_GRAPH) && !getenv("NL_NO_GRAPH");
+    if (getenv("NL_FORCE_TP_PLAN")) e->force_tp_plan = true;
     if (const char *v = getenv("NL_TW")) e->tw_override = atoi(v);
     if (const char *v = getenv("NL_KW")) e->kw_override = atoi(v);
     if ((s = hipSetDevice(e->dev)) != hipSuccess || (s = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -767,9 +770,19 @@ int nl_finalize(nl_handle e) {
     if (e->stage) { hipFree(e->stage); e->stage = nullptr; e->stage_cap = 0; }
     build_plan(e);
     HIPCK(e, hipStreamSynchronize(e->stream));
-    if (e->use_graph && e->G == 1) {
+    const bool has_coll = e->G > 1 || e->force_tp_plan;
+    if (has_coll && !e->comm && !(c.flags & NL_FLAG_LOCAL_GROUP))
+        return e->fail(NL_ERR_STATE, "collective plan needs nl_comm_init before nl_finalize");
+    if (e->use_graph && !(c.flags & NL_FLAG_LOCAL_GROUP)) {
         int rc = capture_graph(e);
-        if (rc) return rc;
+        if (rc && has_coll) {
+            // RCCL inside a captured graph is not guaranteed on every RCCL build: fall back to eager launches
+            hipGetLastError();
+            e->graph = nullptr; e->graph_exec = nullptr;
+            if (!getenv("NL_QUIET")) fprintf(stderr, "[nanollama_hip] graph capture with RCCL failed (%s); using eager launches\n", e->err.c_str());
+        } else if (rc) {
+            return rc;
+        }
     }
     e->finalized = true;
     return NL_OK;
@@ -990,7 +1003,7 @@ int nl_debug_stamps(nl_handle e, int kind, long long *out /* 16 waves x 8 */) {
     nl_engine::Layer &L = e->layers[0];
     hipError_t s = hipErrorInvalidValue;
     if (kind == K_GATEUP) {
-        GemvParams P = base_params(e, L.gate);
+        GemvParams P = base_params(e, L.gate, 2);
         P.q1 = L.up.q; P.s1 = L.up.s; P.x = e->x[0]; P.normw = L.ffn_norm; P.out = e->hb; P.dbg = d;
         s = launch_gemv_t<PRO_NORM, EPI_SWIGLU>(L.gate.wtype, P, e->stream);
     } else if (kind == K_DOWN) {
@@ -1148,7 +1161,7 @@ int nl_comm_get_unique_id(void *id_out) {
 int nl_comm_init(nl_handle e, const void *id) {
     if (!e || !id) return NL_ERR_INVALID;
     if (e->finalized) return e->fail(NL_ERR_STATE, "nl_comm_init after nl_finalize");
-    if (e->G <= 1) return NL_OK;
+    if (e->G <= 1 && !e->force_tp_plan) return NL_OK;
     std::string err;
     if (!g_rccl.load(err)) return e->fail(NL_ERR_COMM, "%s", err.c_str());
     HIPCK(e, hipSetDevice(e->dev));

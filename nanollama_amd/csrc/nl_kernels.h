@@ -397,7 +397,7 @@ template <int WT, int PRO, int EPI>
 __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CPP = WTraits<WT>::CPP;
-    constexpr int NM = EPI == EPI_SWIGLU ? 2 : 1;
+    constexpr int NM = 1;  // gate and up run in separate wavefronts of the same workgroup (see wpt below)
     const int nwaves = blockDim.x >> 6;
     float *xs_all = reinterpret_cast<float *>(smem);          // [waves][XS_WAVE]
     float *red = xs_all + nwaves * XS_WAVE;                   // [NM][waves][TR]
@@ -407,7 +407,13 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
 #define NL_STAMP(k) do { if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + (k)] = clock64(); } while (0)
     NL_STAMP(0);
     const int r = lane >> 2, k = lane & 3;
-    const int tin = wave / P.kw, kw = wave - tin * P.kw;
+    // EPI_SWIGLU: a tile slot is served by 2*kw wavefronts, the first kw on the gate matrix, the rest on up
+    const int wpt = EPI == EPI_SWIGLU ? 2 * P.kw : P.kw;
+    const int tin = wave / wpt;
+    const int msel = EPI == EPI_SWIGLU ? (wave - tin * wpt) / P.kw : 0;
+    const int kw = (wave - tin * wpt) - msel * P.kw;
+    const uint8_t *const Wq = msel ? P.q1 : P.q0;
+    const uint32_t *const Ws = msel ? P.s1 : P.s0;
     const int tile = blockIdx.x * P.tw + tin;
     const bool live = tile < P.ntiles;
     const long long tp0 = (long long)(live ? tile : 0) * P.npairs;
@@ -457,18 +463,18 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
         uint32_t sa = 0, sb = 0, ta = 0, tb = 0;
         const bool la = live && k < gsa, lb = live && k < gsb;
         if (la) {
-            load_pair<WT>(P.q0, P.s0, tp0, g, gsa, r, k, ca, sa);
+            load_pair<WT>(Wq, Ws, tp0, g, gsa, r, k, ca, sa);
             if (NM > 1) load_pair<WT>(P.q1, P.s1, tp0, g, gsa, r, k, ua, ta);
         }
         if (lb) {
-            load_pair<WT>(P.q0, P.s0, tp0, gb, gsb, r, k, cb, sb);
+            load_pair<WT>(Wq, Ws, tp0, gb, gsb, r, k, cb, sb);
             if (NM > 1) load_pair<WT>(P.q1, P.s1, tp0, gb, gsb, r, k, ub, tb);
         }
         // ---- group a ----
         if (PRO == PRO_NORM) {
             // RMSNormInto go/quant.go:597-607.  inv = 1/sqrt(mean(x^2)+eps) multiplies the GEMV OUTPUT
             // (out = inv * sum_j w_ij (x_j g_j)), so its float64 reduction is off the critical path.
-            if (tin == 0) {
+            if (tin == 0 && msel == 0) {
                 ss += (double)xa.x * (double)xa.x; ss += (double)xa.y * (double)xa.y;
                 ss += (double)xa.z * (double)xa.z; ss += (double)xa.w * (double)xa.w;
                 if (P.x_out && blockIdx.x == 0 && g * (KL * PAIR) + lane * 4 < P.cols)
@@ -486,7 +492,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
         // ---- group b ----
         if (hasb) {
             if (PRO == PRO_NORM) {
-                if (tin == 0) {
+                if (tin == 0 && msel == 0) {
                     ss += (double)xb.x * (double)xb.x; ss += (double)xb.y * (double)xb.y;
                     ss += (double)xb.z * (double)xb.z; ss += (double)xb.w * (double)xb.w;
                     if (P.x_out && blockIdx.x == 0 && gb * (KL * PAIR) + lane * 4 < P.cols)
@@ -511,7 +517,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
         red[wave * TR + r] = acc0;
         if (NM > 1) red[(nwaves + wave) * TR + r] = acc1;
     }
-    if (PRO == PRO_NORM && tin == 0) {
+    if (PRO == PRO_NORM && tin == 0 && msel == 0) {
         ss = wave_sum_f64(ss);
         if (lane == 0) dred[kw] = ss;
     }
@@ -525,15 +531,15 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     float v = 0.f, v1 = 0.f;
     if (act)
         for (int j = 0; j < P.kw; j++) {  // fixed order: deterministic
-            v += red[(e_tin * P.kw + j) * TR + rr];
-            if (NM > 1) v1 += red[(nwaves + e_tin * P.kw + j) * TR + rr];
+            v += red[(e_tin * wpt + j) * TR + rr];
+            if (EPI == EPI_SWIGLU) v1 += red[(e_tin * wpt + P.kw + j) * TR + rr];
         }
     if (PRO == PRO_NORM) {
         double tot = 0.0;
         for (int w = 0; w < P.kw; w++) tot += dred[w];
         float inv = (float)(1.0 / sqrt(tot / (double)P.cols + (double)P.eps));
         v *= inv;
-        if (NM > 1) v1 *= inv;
+        if (EPI == EPI_SWIGLU) v1 *= inv;
     }
     if (EPI == EPI_QKV) {
         // RoPE (go/model.go:449-477), KV store (:552-554).  Tile rows 0-7 hold

@@ -159,7 +159,7 @@ def load_llama_model(gguf: GGUFFile, device: int = 0, max_streams: int = 1, tp_r
     if rc != 0:
         raise _lib.NlError(rc, (L.nl_last_error(None) or b"").decode())
     try:
-        if tp_size > 1 and not (flags & _lib.NL_FLAG_LOCAL_GROUP):
+        if (tp_size > 1 or comm_id is not None) and not (flags & _lib.NL_FLAG_LOCAL_GROUP):
             if comm_id is None or len(comm_id) != _lib.NL_COMM_ID_BYTES:
                 raise ValueError("tp_size > 1 needs the communicator id from nl_comm_get_unique_id")
             _lib.check(h, L.nl_comm_init(h, C.c_char_p(comm_id)))

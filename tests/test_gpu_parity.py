@@ -356,3 +356,20 @@ def test_forward_batch_equals_individual_forwards(hip):
         dev.forward_batch([0, 1, 2, 3, 0], [1] * 5, [0] * 5)
     assert dev.forward_batch([], [], []) == ([], None)
     dev.close(); solo.close()
+
+
+def test_rccl_plan_single_rank_matches_plain_plan(hip, monkeypatch):
+    # the tensor-parallel launch plan (partial GEMVs + RCCL all-reduce / all-gather seams, residual added in
+    # the next prologue) driven through a real one-rank RCCL communicator
+    g = gguf.load_gguf(os.path.join(GOLDEN, "tiny_q8_0.gguf"))
+    plain = hip.load_llama_model(g)
+    monkeypatch.setenv("NL_FORCE_TP_PLAN", "1")
+    monkeypatch.setenv("NL_QUIET", "1")
+    tp1 = hip.load_llama_model(g, comm_id=hip.comm_unique_id())
+    monkeypatch.delenv("NL_FORCE_TP_PLAN")
+    for pos, tok in enumerate([1, 17, 400, 3, 99, 250]):
+        plain.forward(tok, pos)
+        tp1.forward(tok, pos)
+        assert np.abs(plain.state.logits - tp1.state.logits).max() <= 1e-6
+    assert tp1.decode_greedy(5, 6, 10) == plain.decode_greedy(5, 6, 10)
+    plain.close(); tp1.close()
