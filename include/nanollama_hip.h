@@ -141,6 +141,10 @@ NL_API int nl_debug_stamps(nl_handle h, int kind, long long *out /* 128 */);
  * re-pack + GEMV kernel as Forward. */
 NL_API int nl_op_matmul(int device, uint32_t ggml_type, const void *w, uint64_t nbytes, const float *x, float *out,
                         int rows, int cols);
+/* The same product for n_tokens input vectors at once through the MFMA path (x: [n_tokens][cols],
+ * out: [n_tokens][rows], host pointers); Q4_0 / Q8_0. */
+NL_API int nl_op_matmul_batch(int device, uint32_t ggml_type, const void *w, uint64_t nbytes, const float *x,
+                               float *out, int rows, int cols, int n_tokens);
 /* RMSNormInto (go/quant.go:597-607). */
 NL_API int nl_op_rmsnorm(int device, const float *x, const float *w, float eps, float *out, int n);
 

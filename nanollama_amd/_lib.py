@@ -37,7 +37,7 @@ class NlError(RuntimeError):
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("nl_engine.hip", "nl_kernels.h")] + \
+    srcs = [os.path.join(src_dir, f) for f in ("nl_engine.hip", "nl_kernels.h", "nl_qgemm.h")] + \
            [os.path.join(os.path.dirname(_HERE), "include", "nanollama_hip.h")]
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
@@ -50,7 +50,7 @@ _lib = None
 EXPORTS = ["nl_abi_version", "nl_device_count", "nl_create", "nl_upload_tensor", "nl_finalize", "nl_destroy",
            "nl_last_error", "nl_reset", "nl_forward", "nl_forward_argmax", "nl_decode_greedy", "nl_prefill", "nl_forward_batch", "nl_get_config",
            "nl_synchronize", "nl_timer_start", "nl_timer_stop", "nl_kernel_kind_name", "nl_profile_forward",
-           "nl_memory_usage", "nl_debug_read", "nl_op_matmul", "nl_op_rmsnorm", "nl_comm_get_unique_id",
+           "nl_memory_usage", "nl_debug_read", "nl_op_matmul", "nl_op_matmul_batch", "nl_op_rmsnorm", "nl_comm_get_unique_id",
            "nl_comm_init", "nl_group_forward", "nl_debug_stamps"]
 
 
@@ -88,6 +88,7 @@ def lib():
     L.nl_debug_read.restype = C.c_int64
     L.nl_debug_read.argtypes = [vp, C.c_char_p, i32, fp, C.c_int64]
     L.nl_op_matmul.argtypes = [i32, C.c_uint32, vp, C.c_uint64, fp, fp, i32, i32]
+    L.nl_op_matmul_batch.argtypes = [i32, C.c_uint32, vp, C.c_uint64, fp, fp, i32, i32, i32]
     L.nl_op_rmsnorm.argtypes = [i32, fp, fp, C.c_float, fp, i32]
     L.nl_comm_get_unique_id.argtypes = [vp]
     L.nl_comm_init.argtypes = [vp, vp]

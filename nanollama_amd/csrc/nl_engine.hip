@@ -9,6 +9,7 @@
 // HIP device every entry point that computes returns NL_ERR_HIP.
 #include "../../include/nanollama_hip.h"
 #include "nl_kernels.h"
+#include "nl_qgemm.h"
 
 #include <dlfcn.h>
 #include <algorithm>
@@ -1052,6 +1053,59 @@ int nl_op_matmul(int device, uint32_t type, const void *w, uint64_t nbytes, cons
         P.x = d_x; P.out = d_out;
         if (launch_gemv_t<PRO_PLAIN, EPI_STORE>((int)type, P, st) != hipSuccess) break;
         if (hipMemcpyAsync(out, d_out, (size_t)rows * 4, hipMemcpyDeviceToHost, st) != hipSuccess) break;
+        if (hipStreamSynchronize(st) != hipSuccess) break;
+        rc = NL_OK;
+    } while (0);
+    for (void *c : tmp.arena_chunks) hipFree(c);
+    if (d_raw) hipFree(d_raw);
+    if (d_x) hipFree(d_x);
+    if (d_out) hipFree(d_out);
+    hipStreamDestroy(st);
+    tmp.stream = nullptr;
+    return rc;
+}
+
+namespace {
+hipError_t launch_qgemm(int wtype, const QGemmParams &P, hipStream_t st) {
+    dim3 grid((P.ntiles + QG_WAVES * QG_RT - 1) / (QG_WAVES * QG_RT), (P.n_tokens + QG_TOK - 1) / QG_TOK);
+    switch (wtype) {
+    case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
+    case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+}  // namespace
+
+// Multi-token matmul through the MFMA path: out[n][rows] = W @ x[n] for n_tokens vectors (host in/out).
+int nl_op_matmul_batch(int device, uint32_t type, const void *w, uint64_t nbytes, const float *x, float *out,
+                       int rows, int cols, int n_tokens) {
+    if (!w || !x || !out || rows <= 0 || cols <= 0 || cols % 32 || n_tokens <= 0) return NL_ERR_INVALID;
+    if (type != WT_Q4_0 && type != WT_Q8_0) return NL_ERR_UNSUPPORTED;
+    if (raw_bytes(type, (uint64_t)rows * cols) != nbytes) return NL_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return NL_ERR_HIP;
+    nl_engine tmp;
+    tmp.hd = 64;
+    hipStream_t st;
+    if (hipStreamCreate(&st) != hipSuccess) return NL_ERR_HIP;
+    tmp.stream = st;
+    PackedMat m;
+    uint8_t *d_raw = nullptr;
+    float *d_x = nullptr, *d_out = nullptr;
+    int rc = NL_ERR_HIP;
+    do {
+        if (alloc_packed(&tmp, m, (int)type, (rows + TR - 1) / TR, rows, cols) != hipSuccess) break;
+        if (hipMalloc((void **)&d_raw, nbytes) != hipSuccess) break;
+        if (hipMalloc((void **)&d_x, (size_t)cols * n_tokens * 4) != hipSuccess) break;
+        if (hipMalloc((void **)&d_out, (size_t)rows * n_tokens * 4) != hipSuccess) break;
+        if (hipMemcpyAsync(d_raw, w, nbytes, hipMemcpyHostToDevice, st) != hipSuccess) break;
+        if (hipMemcpyAsync(d_x, x, (size_t)cols * n_tokens * 4, hipMemcpyHostToDevice, st) != hipSuccess) break;
+        if (repack(&tmp, m, d_raw, (int)type, cols, 0, rows, 0, cols, 0, m.ntiles, ROWMAP_IDENT) != hipSuccess) break;
+        QGemmParams P{};
+        P.q = m.q; P.s = m.s; P.rows = rows; P.cols = cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
+        P.x = d_x; P.ldx = cols; P.n_tokens = n_tokens; P.out = d_out; P.ldo = rows;
+        if (launch_qgemm((int)type, P, st) != hipSuccess) break;
+        if (hipMemcpyAsync(out, d_out, (size_t)rows * n_tokens * 4, hipMemcpyDeviceToHost, st) != hipSuccess) break;
         if (hipStreamSynchronize(st) != hipSuccess) break;
         rc = NL_OK;
     } while (0);

@@ -227,6 +227,19 @@ def op_matmul(w_raw: np.ndarray, ggml_type: int, x: np.ndarray, rows: int, cols:
     return out
 
 
+def op_matmul_batch(w_raw: np.ndarray, ggml_type: int, x: np.ndarray, rows: int, cols: int, device: int = 0) -> np.ndarray:
+    """W @ x[n] for every row of x ([n_tokens, cols]) through the MFMA multi-token path."""
+    w_raw = np.ascontiguousarray(w_raw)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros((x.shape[0], rows), dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    rc = _lib.lib().nl_op_matmul_batch(device, ggml_type, w_raw.ctypes.data, w_raw.nbytes, x.ctypes.data_as(fp),
+                                       out.ctypes.data_as(fp), rows, cols, x.shape[0])
+    if rc != 0:
+        raise _lib.NlError(rc, "nl_op_matmul_batch")
+    return out
+
+
 def op_rmsnorm(x: np.ndarray, w: np.ndarray, eps: float, device: int = 0) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.float32)
     w = np.ascontiguousarray(w, dtype=np.float32)

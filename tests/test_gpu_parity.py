@@ -373,3 +373,27 @@ def test_rccl_plan_single_rank_matches_plain_plan(hip, monkeypatch):
         assert np.abs(plain.state.logits - tp1.state.logits).max() <= 1e-6
     assert tp1.decode_greedy(5, 6, 10) == plain.decode_greedy(5, 6, 10)
     plain.close(); tp1.close()
+
+
+@pytest.mark.parametrize("wtype", ["q4_0", "q8_0"])
+@pytest.mark.parametrize("rows,cols,ntok", [(128, 256, 64), (576, 576, 5), (1536, 576, 64), (192, 768, 17),
+                                             (100, 96, 3), (4096, 4096, 64), (2304, 1536, 130)])
+def test_mfma_multi_token_matmul_matches_oracle(hip, orc, wtype, rows, cols, ntok):
+    # the batched / prefill path: fp16-hi/lo activations x exact integer quants on the matrix cores, block
+    # sums scaled by d in f32 -- must hold the same GEMV tolerance as the VALU decode kernel
+    rng = np.random.Generator(np.random.PCG64(rows + cols * 3 + ntok))
+    raw = _rand_matrix(rng, rows, cols, wtype)
+    x = rng.standard_normal((ntok, cols), dtype=np.float32)
+    x[0, :8] = [0.0, 1e-6, -1e-6, 300.0, -150.0, 1e-3, 7.0, -7.0]      # spread of magnitudes in the hi/lo split
+    if ntok > 1:
+        x[1, :4] = [6.0e4, -3.5e4, 2.0e-7, 1.0]                          # near the fp16 range limits
+    t = synth.WTYPES[wtype]
+    got = hip.op_matmul_batch(raw, t, x, rows, cols)
+    worst = 0.0
+    for n in range(ntok):
+        want = orc.matmul(raw, t, x[n], rows, cols)
+        # row 1 carries 6e4-sized inputs: both paths are float32 sums of ~3e3-sized terms, so bound it by the
+        # float32 summation error of those terms instead of by the (much smaller) result
+        scale = np.abs(want) + (np.abs(x[n]).max() * 0.05 * 127 * 1e-2 if n == 1 else 0.0)
+        worst = max(worst, float((np.abs(got[n] - want) / (1 + scale)).max()))
+    assert worst <= 2e-5, worst
