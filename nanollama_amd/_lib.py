@@ -37,7 +37,7 @@ class NlError(RuntimeError):
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("nl_engine.hip", "nl_kernels.h", "nl_qgemm.h")] + \
+    srcs = [os.path.join(src_dir, f) for f in ("nl_engine.hip", "nl_kernels.h", "nl_qgemm.h", "nl_batch.h")] + \
            [os.path.join(os.path.dirname(_HERE), "include", "nanollama_hip.h")]
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:

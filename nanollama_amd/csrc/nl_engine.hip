@@ -10,6 +10,7 @@
 #include "../../include/nanollama_hip.h"
 #include "nl_kernels.h"
 #include "nl_qgemm.h"
+#include "nl_batch.h"
 
 #include <dlfcn.h>
 #include <algorithm>
@@ -148,6 +149,16 @@ struct nl_engine {
     size_t arena_left = 0;
     uint8_t *stage = nullptr;  // grow-only device staging buffer for raw GGUF bytes
     size_t stage_cap = 0;
+
+    // multi-token step (batched decode streams / prefill): MFMA path, allocated on first use
+    struct Batch {
+        bool ready = false;
+        int cap = 0;
+        float *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *att = nullptr, *g = nullptr, *u = nullptr,
+              *h = nullptr, *logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
+        int *tok = nullptr, *pos = nullptr, *stream = nullptr, *ids = nullptr;
+        int *h_meta = nullptr;  // pinned [3][cap]
+    } bt;
 
     std::vector<Op> plan;
     hipGraph_t graph = nullptr;
@@ -383,7 +394,8 @@ void build_plan(nl_engine *e) {
         }
         {   // GQA attention over the cache (go/model.go:557-587)
             AttnParams P{e->qbuf, kc, vc, e->kv_stream_stride, e->part_o, e->part_ml, e->ctl,
-                         e->KVs, c.seq_len, e->nsplit_max, (float)(1.0 / std::sqrt((double)e->hd)), c.max_streams == 1 ? 1 : 0};
+                         e->KVs, c.seq_len, e->nsplit_max, (float)(1.0 / std::sqrt((double)e->hd)), c.max_streams == 1 ? 1 : 0,
+                         nullptr, nullptr, 0, 0};
             dim3 grid(e->KVs, e->nsplit_max);
             int hd = e->hd, gqa = e->gqa;
             e->plan.push_back({K_ATTN, 0, nullptr, 0,
@@ -509,6 +521,129 @@ bool parse_name(const char *name, Slot &s) {
     if (sscanf(name, "blk.%d.%n", &li, &off) >= 1 && off > 0) { s.layer = li; s.field = name + off; return true; }
     s.layer = -1; s.field = name;
     return true;
+}
+
+}  // namespace
+
+namespace {
+hipError_t launch_qgemm(int wtype, const QGemmParams &P, hipStream_t st) {
+    dim3 grid((P.ntiles + QG_WAVES * QG_RT - 1) / (QG_WAVES * QG_RT), (P.n_tokens + QG_TOK - 1) / QG_TOK);
+    switch (wtype) {
+    case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
+    case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+}  // namespace
+
+namespace {
+
+bool batch_supported(const nl_engine *e) {
+    if (e->G != 1 || e->force_tp_plan) return false;
+    auto ok = [](const PackedMat &m) { return m.wtype == WT_Q4_0 || m.wtype == WT_Q8_0; };
+    for (const auto &L : e->layers)
+        if (!ok(L.qkv) || !ok(L.wo) || !ok(L.gate) || !ok(L.up) || !ok(L.down)) return false;
+    return ok(e->lm_head) && !getenv("NL_NO_BATCH_PATH");
+}
+
+int batch_alloc(nl_engine *e) {
+    if (e->bt.ready) return NL_OK;
+    const nl_config &c = e->cfg;
+    nl_engine::Batch &b = e->bt;
+    b.cap = QG_TOK;
+    const size_t n = b.cap, R = (size_t)(e->Hs + 2 * e->KVs) * e->hd, HQ = (size_t)e->Hs * e->hd;
+    HIPCK(e, dalloc(&b.x, n * c.dim, &e->bytes_state));
+    HIPCK(e, dalloc(&b.xn, n * c.dim, &e->bytes_state));
+    HIPCK(e, dalloc(&b.qkv, n * R, &e->bytes_state));
+    HIPCK(e, dalloc(&b.q, n * HQ, &e->bytes_state));
+    HIPCK(e, dalloc(&b.att, n * HQ, &e->bytes_state));
+    HIPCK(e, dalloc(&b.g, n * e->Is, &e->bytes_state));
+    HIPCK(e, dalloc(&b.u, n * e->Is, &e->bytes_state));
+    HIPCK(e, dalloc(&b.h, n * e->Is, &e->bytes_state));
+    HIPCK(e, dalloc(&b.logits, n * c.vocab, &e->bytes_state));
+    HIPCK(e, dalloc(&b.part_o, n * e->Hs * e->nsplit_max * e->hd, &e->bytes_state));
+    HIPCK(e, dalloc(&b.part_ml, n * e->Hs * e->nsplit_max * 2, &e->bytes_state));
+    HIPCK(e, dalloc(&b.tok, n, &e->bytes_state));
+    HIPCK(e, dalloc(&b.pos, n, &e->bytes_state));
+    HIPCK(e, dalloc(&b.stream, n, &e->bytes_state));
+    HIPCK(e, dalloc(&b.ids, n, &e->bytes_state));
+    HIPCK(e, hipHostMalloc((void **)&b.h_meta, 3 * n * sizeof(int), hipHostMallocDefault));
+    b.ready = true;
+    return NL_OK;
+}
+
+hipError_t qg(const PackedMat &m, const float *x, int ldx, int n, float *out, int ldo, const float *resid, hipStream_t st) {
+    QGemmParams P{};
+    P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
+    P.x = x; P.ldx = ldx; P.n_tokens = n; P.out = out; P.ldo = ldo; P.resid = resid;
+    return launch_qgemm(m.wtype, P, st);
+}
+
+// One multi-token step: n <= 64 (token, pos, stream) triples through every layer on the MFMA path.
+// lm_mode: 0 = no LM head, 1 = logits + argmax for every token, 2 = logits + argmax for the LAST token only.
+// The caller has filled bt.h_meta; stream-ordered, no synchronisation inside.
+int batched_step(nl_engine *e, int n, int lm_mode) {
+    const nl_config &c = e->cfg;
+    nl_engine::Batch &b = e->bt;
+    hipStream_t st = e->stream;
+    const int D = c.dim, hd = e->hd, HQ = e->Hs * hd, R = (e->Hs + 2 * e->KVs) * hd;
+#define LCK(expr) do { hipError_t s_ = (expr); if (s_ != hipSuccess) return e->fail(NL_ERR_HIP, "batched step: %s: %s", #expr, hipGetErrorString(s_)); } while (0)
+    LCK(hipMemcpyAsync(b.tok, b.h_meta, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    LCK(hipMemcpyAsync(b.pos, b.h_meta + b.cap, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    LCK(hipMemcpyAsync(b.stream, b.h_meta + 2 * b.cap, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    {
+        BEmbedParams P{e->embd_raw, e->embd_type, D, b.tok, b.x};
+        hipLaunchKernelGGL(bembed_kernel, dim3(n), dim3(256), 0, st, P);
+        LCK(hipGetLastError());
+    }
+    for (int l = 0; l < c.n_layers; l++) {
+        nl_engine::Layer &L = e->layers[l];
+        float *kc = e->kcache + (long long)l * e->kv_layer_stride;
+        float *vc = e->vcache + (long long)l * e->kv_layer_stride;
+        hipLaunchKernelGGL(brmsnorm_kernel, dim3(n), dim3(256), 0, st, b.x, L.attn_norm, c.rms_eps, b.xn, D);
+        LCK(hipGetLastError());
+        LCK(qg(L.qkv, b.xn, D, n, b.qkv, R, nullptr, st));
+        {
+            BRopeParams P{b.qkv, R, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate, c.qk_norm, c.rms_eps, b.pos, b.stream,
+                          e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride};
+            hipLaunchKernelGGL(brope_kv_kernel, dim3(n), dim3(256), (size_t)R * 4, st, P);
+            LCK(hipGetLastError());
+        }
+        {
+            AttnParams P{b.q, kc, vc, e->kv_stream_stride, b.part_o, b.part_ml, e->ctl, e->KVs, c.seq_len, e->nsplit_max,
+                         (float)(1.0 / std::sqrt((double)hd)), 0, b.pos, b.stream, (long long)HQ,
+                         (long long)e->Hs * e->nsplit_max};
+            LCK(launch_attn(hd, e->gqa, P, dim3(e->KVs, e->nsplit_max, n), st));
+            BMergeParams M{b.part_o, b.part_ml, b.pos, e->Hs, e->nsplit_max, hd, b.att};
+            hipLaunchKernelGGL(battn_merge_kernel, dim3(n), dim3(256), 0, st, M);
+            LCK(hipGetLastError());
+        }
+        LCK(qg(L.wo, b.att, HQ, n, b.x, D, b.x, st));
+        hipLaunchKernelGGL(brmsnorm_kernel, dim3(n), dim3(256), 0, st, b.x, L.ffn_norm, c.rms_eps, b.xn, D);
+        LCK(hipGetLastError());
+        LCK(qg(L.gate, b.xn, D, n, b.g, e->Is, nullptr, st));
+        LCK(qg(L.up, b.xn, D, n, b.u, e->Is, nullptr, st));
+        {
+            long long tot = (long long)n * e->Is;
+            hipLaunchKernelGGL(bswiglu_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 4096)), dim3(256), 0, st,
+                               b.g, b.u, b.h, tot);
+            LCK(hipGetLastError());
+        }
+        LCK(qg(L.down, b.h, e->Is, n, b.x, D, b.x, st));
+    }
+    if (lm_mode) {
+        const int first = lm_mode == 2 ? n - 1 : 0, cnt = lm_mode == 2 ? 1 : n;
+        hipLaunchKernelGGL(brmsnorm_kernel, dim3(cnt), dim3(256), 0, st, b.x + (size_t)first * D, e->output_norm, c.rms_eps,
+                           b.xn + (size_t)first * D, D);
+        LCK(hipGetLastError());
+        LCK(qg(e->lm_head, b.xn + (size_t)first * D, D, cnt, b.logits + (size_t)first * c.vocab, c.vocab, nullptr, st));
+        hipLaunchKernelGGL(bargmax_kernel, dim3(cnt), dim3(1024), 0, st, b.logits + (size_t)first * c.vocab, c.vocab,
+                           b.ids + first);
+        LCK(hipGetLastError());
+    }
+#undef LCK
+    return NL_OK;
 }
 
 }  // namespace
@@ -801,6 +936,12 @@ int nl_destroy(nl_handle e) {
     }
     for (void *c : e->arena_chunks) hipFree(c);
     if (e->stage) hipFree(e->stage);
+    {
+        nl_engine::Batch &b = e->bt;
+        void *bb[] = {b.x, b.xn, b.qkv, b.q, b.att, b.g, b.u, b.h, b.logits, b.part_o, b.part_ml, b.tok, b.pos, b.stream, b.ids};
+        for (void *p : bb) if (p) hipFree(p);
+        if (b.h_meta) hipHostFree(b.h_meta);
+    }
     void *bufs[] = {e->embd_raw, e->output_norm, e->rope_cos, e->rope_sin, e->x[0], e->x[1], e->qbuf, e->part_o,
                     e->part_ml, e->hb, e->ar, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result, e->amax_val,
                     e->amax_idx};
@@ -875,11 +1016,34 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
     for (int i = 0; i < n; i++)
         if (tokens[i] < 0 || tokens[i] >= e->cfg.vocab) return e->fail(NL_ERR_INVALID, "token %d out of range [0,%d)", tokens[i], e->cfg.vocab);
     HIPCK(e, hipSetDevice(e->dev));
-    for (int i = 0; i < n; i++) {
-        int *c = e->h_ctl_ring + (size_t)i * CTL_WORDS;
-        c[CTL_TOKEN] = tokens[i]; c[CTL_POS] = pos0 + i; c[CTL_CHAIN] = 0; c[CTL_STEP] = 0; c[CTL_STREAM] = stream;
-        HIPCK(e, hipMemcpyAsync(e->ctl, c, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, e->stream));
-        if ((rc = launch_step(e))) return rc;
+    if (n >= 2 && batch_supported(e)) {
+        // multi-token path: 64-token tiles on the matrix cores; causality comes from each token's own pos
+        if ((rc = batch_alloc(e))) return rc;
+        nl_engine::Batch &b = e->bt;
+        for (int t0 = 0; t0 < n; t0 += b.cap) {
+            const int m = std::min(b.cap, n - t0);
+            HIPCK(e, hipStreamSynchronize(e->stream));  // h_meta is reused per tile
+            for (int i = 0; i < m; i++) {
+                b.h_meta[i] = tokens[t0 + i];
+                b.h_meta[b.cap + i] = pos0 + t0 + i;
+                b.h_meta[2 * b.cap + i] = stream;
+            }
+            const bool last = t0 + m == n;
+            if ((rc = batched_step(e, m, last ? 2 : 0))) return rc;
+            if (last) {
+                // keep the single-token state coherent: logits / argmax of the last token
+                HIPCK(e, hipMemcpyAsync(e->logits, b.logits + (size_t)(m - 1) * e->cfg.vocab, (size_t)e->cfg.vocab * 4,
+                                        hipMemcpyDeviceToDevice, e->stream));
+                HIPCK(e, hipMemcpyAsync(e->result, b.ids + (m - 1), sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+            }
+        }
+    } else {
+        for (int i = 0; i < n; i++) {
+            int *c = e->h_ctl_ring + (size_t)i * CTL_WORDS;
+            c[CTL_TOKEN] = tokens[i]; c[CTL_POS] = pos0 + i; c[CTL_CHAIN] = 0; c[CTL_STEP] = 0; c[CTL_STREAM] = stream;
+            HIPCK(e, hipMemcpyAsync(e->ctl, c, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, e->stream));
+            if ((rc = launch_step(e))) return rc;
+        }
     }
     if (last_logits_out)
         HIPCK(e, hipMemcpyAsync(last_logits_out, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
@@ -897,7 +1061,28 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
         for (int j = 0; j < i; j++)
             if (streams[j] == streams[i]) return e->fail(NL_ERR_INVALID, "stream %d appears twice in one batch", streams[i]);
     }
+    if (n == 0) return NL_OK;
     HIPCK(e, hipSetDevice(e->dev));
+    if (n >= 2 && batch_supported(e)) {
+        if ((rc = batch_alloc(e))) return rc;
+        nl_engine::Batch &b = e->bt;
+        for (int t0 = 0; t0 < n; t0 += b.cap) {
+            const int m = std::min(b.cap, n - t0);
+            HIPCK(e, hipStreamSynchronize(e->stream));
+            for (int i = 0; i < m; i++) {
+                b.h_meta[i] = tokens[t0 + i];
+                b.h_meta[b.cap + i] = pos[t0 + i];
+                b.h_meta[2 * b.cap + i] = streams[t0 + i];
+            }
+            if ((rc = batched_step(e, m, 1))) return rc;
+            if (logits_out)
+                HIPCK(e, hipMemcpyAsync(logits_out + (size_t)t0 * e->cfg.vocab, b.logits, (size_t)m * e->cfg.vocab * 4,
+                                        hipMemcpyDeviceToHost, e->stream));
+            if (next_ids) HIPCK(e, hipMemcpyAsync(next_ids + t0, b.ids, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        }
+        HIPCK(e, hipStreamSynchronize(e->stream));
+        return NL_OK;
+    }
     for (int i = 0; i < n; i++) {
         int *c = e->h_ctl_ring + (size_t)i * CTL_WORDS;
         c[CTL_TOKEN] = tokens[i]; c[CTL_POS] = pos[i]; c[CTL_CHAIN] = 0; c[CTL_STEP] = 0; c[CTL_STREAM] = streams[i];
@@ -1065,17 +1250,7 @@ int nl_op_matmul(int device, uint32_t type, const void *w, uint64_t nbytes, cons
     return rc;
 }
 
-namespace {
-hipError_t launch_qgemm(int wtype, const QGemmParams &P, hipStream_t st) {
-    dim3 grid((P.ntiles + QG_WAVES * QG_RT - 1) / (QG_WAVES * QG_RT), (P.n_tokens + QG_TOK - 1) / QG_TOK);
-    switch (wtype) {
-    case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
-    case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-}  // namespace
+
 
 // Multi-token matmul through the MFMA path: out[n][rows] = W @ x[n] for n_tokens vectors (host in/out).
 int nl_op_matmul_batch(int device, uint32_t type, const void *w, uint64_t nbytes, const float *x, float *out,

@@ -653,6 +653,9 @@ struct AttnParams {
     int n_kv_heads, seq_len, nsplit_max;
     float scale;
     int single_stream;  // max_streams == 1: stream offset is 0 without reading ctl
+    // multi-token step: blockIdx.z = item, per-item position / stream arrays and buffer strides (floats)
+    const int *bpos, *bstream;
+    long long q_item_stride, part_item_stride;
 };
 
 // GQA decode attention for one token (go/model.go:557-587): one workgroup per
@@ -701,7 +704,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
     // Split 0 of a single-stream engine does not need ctl to know WHERE its K/V rows are, so it loads
     // all 128 rows speculatively (rows > pos hold finite stale data and are masked below) and the
     // ctl round trip overlaps the K/V fetch instead of preceding it.
-    const bool spec = split == 0 && P.single_stream;
+    const int item = blockIdx.z;
+    const float *const qsrc = P.qbuf + (long long)item * P.q_item_stride;
+    float *const part_o = P.part_o + (long long)item * P.part_item_stride * HD;
+    float *const part_ml = P.part_ml + (long long)item * P.part_item_stride * 2;
+    const bool spec = split == 0 && P.single_stream && !P.bpos;
     if (spec) {
         const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + (long long)kvh * P.seq_len * HD);
         const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + (long long)kvh * P.seq_len * HD);
@@ -720,10 +727,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
         pos = P.ctl[CTL_POS];
         n = min(ATT_CH, pos + 1);
     } else {
-        pos = P.ctl[CTL_POS];
+        pos = P.bpos ? P.bpos[item] : P.ctl[CTL_POS];
         if (t0 > pos) return;
         n = min(ATT_CH, pos + 1 - t0);
-        const long long soff = (long long)P.ctl[CTL_STREAM] * P.kv_stream_stride;
+        const long long soff = (long long)(P.bstream ? P.bstream[item] : P.ctl[CTL_STREAM]) * P.kv_stream_stride;
         const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
         const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
 #pragma unroll
@@ -738,7 +745,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
             }
         }
     }
-    for (int i = tid; i < G * HD; i += ATT_THREADS) qs[i] = P.qbuf[kvh * G * HD + i];
+    for (int i = tid; i < G * HD; i += ATT_THREADS) qs[i] = qsrc[kvh * G * HD + i];
 #pragma unroll
     for (int k = 0; k < NV; k++) {
         int row = tg + k * NG;
@@ -807,10 +814,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
 #pragma unroll 8
         for (int k = 0; k < NG; k++) s += ored[(k * G + g) * HD + dd];
         int h = kvh * G + g;
-        P.part_o[((long long)h * P.nsplit_max + split) * HD + dd] = s;
+        part_o[((long long)h * P.nsplit_max + split) * HD + dd] = s;
         if (dd == 0) {
-            P.part_ml[((long long)h * P.nsplit_max + split) * 2] = ml[2 * g];
-            P.part_ml[((long long)h * P.nsplit_max + split) * 2 + 1] = ml[2 * g + 1];
+            part_ml[((long long)h * P.nsplit_max + split) * 2] = ml[2 * g];
+            part_ml[((long long)h * P.nsplit_max + split) * 2 + 1] = ml[2 * g + 1];
         }
     }
 }
