@@ -153,7 +153,9 @@ struct nl_engine {
     // multi-token step (batched decode streams / prefill): MFMA path, allocated on first use
     struct Batch {
         bool ready = false;
-        int cap = 0;
+        int cap = 0, lm_cap = 0;
+        float *kpart = nullptr;  // split-K partial sums
+        size_t kpart_cap = 0;    // floats
         float *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *att = nullptr, *g = nullptr, *u = nullptr,
               *h = nullptr, *logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
         int *tok = nullptr, *pos = nullptr, *stream = nullptr, *ids = nullptr;
@@ -526,13 +528,29 @@ bool parse_name(const char *name, Slot &s) {
 }  // namespace
 
 namespace {
-hipError_t launch_qgemm(int wtype, const QGemmParams &P, hipStream_t st) {
-    dim3 grid((P.ntiles + QG_WAVES * QG_RT - 1) / (QG_WAVES * QG_RT), (P.n_tokens + QG_TOK - 1) / QG_TOK);
+hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_buf = nullptr, size_t part_cap = 0) {
+    const int row_groups = (P.ntiles + QG_WAVES * QG_RT - 1) / (QG_WAVES * QG_RT);
+    const int tok_tiles = (P.n_tokens + QG_TOK - 1) / QG_TOK;
+    const int nchunks = (P.cols / 32 + QG_KC - 1) / QG_KC;
+    // split K until ~128 workgroups exist (small-N decode batches would otherwise leave most CUs idle)
+    int ks = 1;
+    if (part_buf && P.ldo == P.rows) {
+        while (row_groups * tok_tiles * ks < 128 && ks * 2 <= nchunks && ks < 16) ks *= 2;
+        while (ks > 1 && (size_t)ks * P.n_tokens * P.ldo > part_cap) ks /= 2;
+    }
+    P.ksplit = ks;
+    P.part = part_buf;
+    dim3 grid(row_groups, tok_tiles, ks);
     switch (wtype) {
     case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
     case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
     default: return hipErrorInvalidValue;
     }
+    hipError_t s = hipGetLastError();
+    if (s != hipSuccess || ks == 1) return s;
+    const long long count = (long long)P.n_tokens * P.ldo;
+    hipLaunchKernelGGL(qgemm_sum_kernel, dim3((unsigned)std::min<long long>((count + 255) / 256, 2048)), dim3(256), 0, st,
+                       part_buf, ks, count, P.resid, P.out);
     return hipGetLastError();
 }
 }  // namespace
@@ -551,7 +569,8 @@ int batch_alloc(nl_engine *e) {
     if (e->bt.ready) return NL_OK;
     const nl_config &c = e->cfg;
     nl_engine::Batch &b = e->bt;
-    b.cap = QG_TOK;
+    b.cap = 512;        // tokens per multi-token step (prefill tiles); the LM head runs on <= 64 of them
+    b.lm_cap = QG_TOK;
     const size_t n = b.cap, R = (size_t)(e->Hs + 2 * e->KVs) * e->hd, HQ = (size_t)e->Hs * e->hd;
     HIPCK(e, dalloc(&b.x, n * c.dim, &e->bytes_state));
     HIPCK(e, dalloc(&b.xn, n * c.dim, &e->bytes_state));
@@ -561,7 +580,9 @@ int batch_alloc(nl_engine *e) {
     HIPCK(e, dalloc(&b.g, n * e->Is, &e->bytes_state));
     HIPCK(e, dalloc(&b.u, n * e->Is, &e->bytes_state));
     HIPCK(e, dalloc(&b.h, n * e->Is, &e->bytes_state));
-    HIPCK(e, dalloc(&b.logits, n * c.vocab, &e->bytes_state));
+    HIPCK(e, dalloc(&b.logits, (size_t)b.lm_cap * c.vocab, &e->bytes_state));
+    b.kpart_cap = (size_t)16 * QG_TOK * std::max<size_t>(std::max<size_t>(R, c.dim), e->Is);
+    HIPCK(e, dalloc(&b.kpart, b.kpart_cap, &e->bytes_state));
     HIPCK(e, dalloc(&b.part_o, n * e->Hs * e->nsplit_max * e->hd, &e->bytes_state));
     HIPCK(e, dalloc(&b.part_ml, n * e->Hs * e->nsplit_max * 2, &e->bytes_state));
     HIPCK(e, dalloc(&b.tok, n, &e->bytes_state));
@@ -573,11 +594,12 @@ int batch_alloc(nl_engine *e) {
     return NL_OK;
 }
 
-hipError_t qg(const PackedMat &m, const float *x, int ldx, int n, float *out, int ldo, const float *resid, hipStream_t st) {
+hipError_t qg(nl_engine *e, const PackedMat &m, const float *x, int ldx, int n, float *out, int ldo, const float *resid,
+              hipStream_t st) {
     QGemmParams P{};
     P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
     P.x = x; P.ldx = ldx; P.n_tokens = n; P.out = out; P.ldo = ldo; P.resid = resid;
-    return launch_qgemm(m.wtype, P, st);
+    return launch_qgemm(m.wtype, P, st, e->bt.kpart, e->bt.kpart_cap);
 }
 
 // One multi-token step: n <= 64 (token, pos, stream) triples through every layer on the MFMA path.
@@ -603,7 +625,7 @@ int batched_step(nl_engine *e, int n, int lm_mode) {
         float *vc = e->vcache + (long long)l * e->kv_layer_stride;
         hipLaunchKernelGGL(brmsnorm_kernel, dim3(n), dim3(256), 0, st, b.x, L.attn_norm, c.rms_eps, b.xn, D);
         LCK(hipGetLastError());
-        LCK(qg(L.qkv, b.xn, D, n, b.qkv, R, nullptr, st));
+        LCK(qg(e, L.qkv, b.xn, D, n, b.qkv, R, nullptr, st));
         {
             BRopeParams P{b.qkv, R, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate, c.qk_norm, c.rms_eps, b.pos, b.stream,
                           e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride};
@@ -619,27 +641,28 @@ int batched_step(nl_engine *e, int n, int lm_mode) {
             hipLaunchKernelGGL(battn_merge_kernel, dim3(n), dim3(256), 0, st, M);
             LCK(hipGetLastError());
         }
-        LCK(qg(L.wo, b.att, HQ, n, b.x, D, b.x, st));
+        LCK(qg(e, L.wo, b.att, HQ, n, b.x, D, b.x, st));
         hipLaunchKernelGGL(brmsnorm_kernel, dim3(n), dim3(256), 0, st, b.x, L.ffn_norm, c.rms_eps, b.xn, D);
         LCK(hipGetLastError());
-        LCK(qg(L.gate, b.xn, D, n, b.g, e->Is, nullptr, st));
-        LCK(qg(L.up, b.xn, D, n, b.u, e->Is, nullptr, st));
+        LCK(qg(e, L.gate, b.xn, D, n, b.g, e->Is, nullptr, st));
+        LCK(qg(e, L.up, b.xn, D, n, b.u, e->Is, nullptr, st));
         {
             long long tot = (long long)n * e->Is;
             hipLaunchKernelGGL(bswiglu_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 4096)), dim3(256), 0, st,
                                b.g, b.u, b.h, tot);
             LCK(hipGetLastError());
         }
-        LCK(qg(L.down, b.h, e->Is, n, b.x, D, b.x, st));
+        LCK(qg(e, L.down, b.h, e->Is, n, b.x, D, b.x, st));
     }
     if (lm_mode) {
+        // logits rows [0, cnt) of bt.logits / ids [0, cnt): all tokens (mode 1, n <= lm_cap) or just the last (mode 2)
         const int first = lm_mode == 2 ? n - 1 : 0, cnt = lm_mode == 2 ? 1 : n;
+        if (cnt > b.lm_cap) return e->fail(NL_ERR_INVALID, "LM head batch %d exceeds %d", cnt, b.lm_cap);
         hipLaunchKernelGGL(brmsnorm_kernel, dim3(cnt), dim3(256), 0, st, b.x + (size_t)first * D, e->output_norm, c.rms_eps,
                            b.xn + (size_t)first * D, D);
         LCK(hipGetLastError());
-        LCK(qg(e->lm_head, b.xn + (size_t)first * D, D, cnt, b.logits + (size_t)first * c.vocab, c.vocab, nullptr, st));
-        hipLaunchKernelGGL(bargmax_kernel, dim3(cnt), dim3(1024), 0, st, b.logits + (size_t)first * c.vocab, c.vocab,
-                           b.ids + first);
+        LCK(qg(e, e->lm_head, b.xn + (size_t)first * D, D, cnt, b.logits, c.vocab, nullptr, st));
+        hipLaunchKernelGGL(bargmax_kernel, dim3(cnt), dim3(1024), 0, st, b.logits, c.vocab, b.ids);
         LCK(hipGetLastError());
     }
 #undef LCK
@@ -938,7 +961,7 @@ int nl_destroy(nl_handle e) {
     if (e->stage) hipFree(e->stage);
     {
         nl_engine::Batch &b = e->bt;
-        void *bb[] = {b.x, b.xn, b.qkv, b.q, b.att, b.g, b.u, b.h, b.logits, b.part_o, b.part_ml, b.tok, b.pos, b.stream, b.ids};
+        void *bb[] = {b.x, b.xn, b.qkv, b.q, b.att, b.g, b.u, b.h, b.logits, b.part_o, b.part_ml, b.tok, b.pos, b.stream, b.ids, b.kpart};
         for (void *p : bb) if (p) hipFree(p);
         if (b.h_meta) hipHostFree(b.h_meta);
     }
@@ -1032,9 +1055,8 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
             if ((rc = batched_step(e, m, last ? 2 : 0))) return rc;
             if (last) {
                 // keep the single-token state coherent: logits / argmax of the last token
-                HIPCK(e, hipMemcpyAsync(e->logits, b.logits + (size_t)(m - 1) * e->cfg.vocab, (size_t)e->cfg.vocab * 4,
-                                        hipMemcpyDeviceToDevice, e->stream));
-                HIPCK(e, hipMemcpyAsync(e->result, b.ids + (m - 1), sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+                HIPCK(e, hipMemcpyAsync(e->logits, b.logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToDevice, e->stream));
+                HIPCK(e, hipMemcpyAsync(e->result, b.ids, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
             }
         }
     } else {
@@ -1066,8 +1088,8 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
     if (n >= 2 && batch_supported(e)) {
         if ((rc = batch_alloc(e))) return rc;
         nl_engine::Batch &b = e->bt;
-        for (int t0 = 0; t0 < n; t0 += b.cap) {
-            const int m = std::min(b.cap, n - t0);
+        for (int t0 = 0; t0 < n; t0 += b.lm_cap) {
+            const int m = std::min(b.lm_cap, n - t0);
             HIPCK(e, hipStreamSynchronize(e->stream));
             for (int i = 0; i < m; i++) {
                 b.h_meta[i] = tokens[t0 + i];

@@ -30,6 +30,10 @@ struct QGemmParams {
     float *out;          // [N][ldo]
     int ldo;
     const float *resid;  // optional [N][ldo]: out = resid + y
+    // split-K: blockIdx.z handles chunks z, z+ksplit, ...; with ksplit > 1 the kernel writes partial sums to
+    // part[z][N][ldo] and qgemm_sum_kernel adds them in a fixed order (deterministic, no atomics)
+    int ksplit;
+    float *part;
 };
 
 // k-slot -> element-of-block map shared by both MFMA operands.
@@ -119,7 +123,7 @@ __global__ void __launch_bounds__(QG_WAVES * 64) qgemm_kernel(QGemmParams P) {
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[rt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    for (int b0 = 0; b0 < nblocks; b0 += QG_KC) {
+    for (int b0 = blockIdx.z * QG_KC; b0 < nblocks; b0 += QG_KC * P.ksplit) {
         const int nb = min(QG_KC, nblocks - b0);
         // this wavefront's weight fragments + scales for the chunk (issued before the staging work)
         half8_t wf[QG_RT][QG_KC];
@@ -194,10 +198,24 @@ __global__ void __launch_bounds__(QG_WAVES * 64) qgemm_kernel(QGemmParams P) {
                 const int n = tok0 + t * 16 + lw * 4 + j;
                 if (n < P.n_tokens) {
                     float v = acc[rt][t][j];
-                    if (P.resid) v += P.resid[(long long)n * P.ldo + row];
-                    P.out[(long long)n * P.ldo + row] = v;
+                    if (P.ksplit > 1) {
+                        P.part[((long long)blockIdx.z * P.n_tokens + n) * P.ldo + row] = v;
+                    } else {
+                        if (P.resid) v += P.resid[(long long)n * P.ldo + row];
+                        P.out[(long long)n * P.ldo + row] = v;
+                    }
                 }
             }
+    }
+}
+
+// out[n][row] = (resid) + sum_z part[z][n][row], z in ascending order
+__global__ void qgemm_sum_kernel(const float *part, int ksplit, long long count, const float *resid, float *out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        float v = part[i];
+        for (int z = 1; z < ksplit; z++) v += part[(long long)z * count + i];
+        if (resid) v += resid[i];
+        out[i] = v;
     }
 }
 
