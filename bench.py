@@ -171,6 +171,51 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model):
     }
 
 
+def side_configs(model):
+    """BASELINE.json configs[2] and [3] as side results of the single-GPU run: mini Q4_0 2047-token prefill
+    (MFMA multi-token path) + one decode step, and goldie Q4_0 with 64 concurrent decode streams."""
+    out = {}
+    # -- mini: prefill + decode
+    shape = synth.TIERS["mini"]
+    g = gguf.load_gguf(ensure_gguf(shape, "q4_0", "qrand"))
+    dev = model.load_llama_model(g)
+    toks = synth.prompt_ids(2047, shape.vocab)
+    dev.prefill(toks[:128])
+    dev.synchronize()
+    t0 = time.perf_counter()
+    dev.prefill(toks)
+    dt = time.perf_counter() - t0
+    first = int(np.argmax(dev.state.logits))
+    t1 = time.perf_counter()
+    dev.decode_greedy(first, 2047, 1)
+    dt1 = time.perf_counter() - t1
+    gemm_flop = 2.0 * shape.matrix_params() * 2047 - 2.0 * shape.vocab * shape.dim * 2046  # LM head on the last token only
+    out["mini_q4_0_prefill_2047"] = {"prefill_tokens_per_s": round(2047 / dt, 1), "prefill_ms": round(dt * 1e3, 2),
+                                     "gemm_TFLOPs_algorithmic": round(gemm_flop / dt / 1e12, 2),
+                                     "mfma_peak_frac_f16_dense": round(gemm_flop / dt / 2.5e15, 5),
+                                     "decode_step_ms_at_pos_2047": round(dt1 * 1e3, 3)}
+    dev.close()
+    # -- goldie: 64 streams
+    shape = synth.TIERS["goldie"]
+    g = gguf.load_gguf(ensure_gguf(shape, "q4_0", "qrand"))
+    ns, steps, pos0 = 64, 32, 8
+    dev = model.load_llama_model(g, max_streams=ns)
+    rng = np.random.Generator(np.random.PCG64(3))
+    ids = [int(t) for t in rng.integers(3, shape.vocab, size=ns)]
+    streams = list(range(ns))
+    for p in range(pos0):
+        ids, _ = dev.forward_batch(streams, ids, [p] * ns)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ids, _ = dev.forward_batch(streams, ids, [pos0 + k] * ns)
+    dt = time.perf_counter() - t0
+    step_bytes = synth.weight_bytes_per_token(shape, "q4_0") + ns * synth.kv_bytes_per_token(shape, pos0 + steps // 2)
+    out["goldie_q4_0_64_streams"] = {"tokens_per_s_aggregate": round(ns * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+                                     "hbm_frac": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
+    dev.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,6 +273,10 @@ def main():
                                 "roofline": b["roofline"], "kernels": b["kernels"]}
         except Exception as exc:  # the headline result must survive a failure of the side measurement
             out["secondary"] = {"error": repr(exc)}
+        try:
+            out["other_configs"] = side_configs(model)
+        except Exception as exc:
+            out["other_configs"] = {"error": repr(exc)}
     if rank == 0:
         print(json.dumps(out))
     rdv.close()
