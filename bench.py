@@ -98,10 +98,13 @@ def cpu_baseline(path, prompt, budget_s=20.0):
                       f"C restatement of go/quant.go+go/model.go with the Go row partition on {cores} threads (best of 1..64 on a {ncpu}-cpu host)"}
 
 
-def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model):
+def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True):
     """Load the tier's random-weight GGUF, run `warmup` + `steps` chained greedy decode steps, profile the
-    launches.  Returns the result dict (rank 0's view; timing is the max over ranks)."""
-    rank, world, local_rank = rdv.rank, rdv.world, rdv.local_rank
+    launches.  tp=True: the ranks of rdv form one tensor-parallel engine; tp=False: every rank is an
+    independent replica (no data-path collective).  Returns the result dict (timing = max over ranks)."""
+    rank, local_rank = rdv.rank, rdv.local_rank
+    replicas = 1 if tp else rdv.world
+    world = rdv.world if tp else 1
     shape = synth.TIERS[tier]
     mode = "qrand" if tier in ("big", "goldie") else "float"
     comm_id = rdv.broadcast_bytes(model.comm_unique_id) if (world > 1 or os.environ.get("NL_FORCE_TP_PLAN")) else None
@@ -162,7 +165,8 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model):
     dev.close()
     return {
         "tier": tier, "wtype": wtype, "path": path, "prompt": prompt,
-        "tok_s": steps / (wall_ms / 1e3), "ms_per_step": ms_per_step, "device_ms_per_step": ev_ms / steps,
+        "tok_s": replicas * steps / (wall_ms / 1e3), "ms_per_step": ms_per_step, "device_ms_per_step": ev_ms / steps,
+        "replicas": replicas, "tp": world,
         "step_bytes": int(step_bytes), "hbm_frac_whole_step": step_gbs / (HBM_PEAK_GBS * max(world, 1)),
         "kernels": kernels, "last_ids": ids[-4:],
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -223,7 +227,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--workload", default=None, help="tier:wtype override, e.g. big:q4_0 (default by --gpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the big Q4_0 single-GPU side measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the big Q4_0 side measurement")
+    ap.add_argument("--tp-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--profile-pos", type=int, default=PROMPT_LEN + SEGMENT // 2)
     args = ap.parse_args()
 
@@ -231,28 +236,53 @@ def main():
     from nanollama_amd import _lib, model
     from nanollama_amd.dist import Rendezvous
     _lib.lib()
+    n = args.gpus
+    tp_child = None
+    if args.tp_worker is None and n > 1 and not args.workload and not args.no_secondary:
+        # big Q4_0 tensor-parallel over the N GPUs runs in a child process per rank (own rendezvous port, hard
+        # timeout): a collective that hangs must not take the headline line down with it
+        tp_child = spawn_tp_child(args)
     rdv = Rendezvous()
     rank, world = rdv.rank, rdv.world
-    n = args.gpus
     if world != n and world != 1:
         raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}")
+    tp_res = None
+    if tp_child is not None:
+        # the child owns the GPU until it exits: parent and child never hold the device at the same time
+        tp_res = collect_tp_child(tp_child)
+        rdv.barrier()
+
+    if args.tp_worker is not None:   # child: big Q4_0, tensor-parallel over all ranks
+        r = run_workload("big", "q4_0", rdv, args.steps, args.warmup, args.profile_pos, model, tp=True)
+        if rank == 0:
+            print("TPJSON " + json.dumps({k: r[k] for k in ("tok_s", "ms_per_step", "hbm_frac_whole_step", "roofline",
+                                                              "kernels", "tp")}))
+        rdv.close()
+        return
+
     if args.workload:
         tier, wtype = args.workload.split(":")
+        tp = world > 1
     else:
-        tier, wtype = ("nano", "q8_0") if n == 1 else ("big", "q4_0")
+        # N = 1: BASELINE configs[1], nano Q8_0.  N > 1: nano does not shard (SURVEY 8e "replicas only"), so the
+        # same workload runs as N independent replicas (weak scaling, no collective); big Q4_0 over the N GPUs
+        # (tensor parallel, RCCL all-reduce, strong scaling) is reported next to it under "secondary".
+        tier, wtype, tp = "nano", "q8_0", False
     shape = synth.TIERS[tier]
 
-    r = run_workload(tier, wtype, rdv, args.steps, args.warmup, args.profile_pos, model)
+    r = run_workload(tier, wtype, rdv, args.steps, args.warmup, args.profile_pos, model, tp=tp)
+    par = f"tp{world}" if (tp and world > 1) else (f"{world} independent replicas" if world > 1 else "single-gpu")
     out = {
         "metric": f"decode tokens/sec, {tier} {wtype.upper()} single-stream greedy"
-                  + (f", tensor-parallel over {world} GPUs" if world > 1 else ""),
+                  + (f", tensor-parallel over {world} GPUs" if tp and world > 1 else "")
+                  + (f", {world} replicas (one per GPU)" if (not tp) and world > 1 else ""),
         "value": round(r["tok_s"], 2), "unit": "tokens/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(r["ms_per_step"], 5), "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
+        "scaling": "strong" if (tp and world > 1) else "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (random-weight GGUF, reference exporter layout, nanollama_amd.synth)",
         "config": {"workload": f"{tier} ({shape.matrix_params() / 1e6:.0f}M matrix params) {wtype.upper()} GGUF, "
-                               f"{PROMPT_LEN}-token prompt + {SEGMENT}-token greedy decode segments, 1 stream",
-                   "parallelism": f"tp{world}" if world > 1 else "single-gpu",
+                               f"{PROMPT_LEN}-token prompt + {SEGMENT}-token greedy decode segments, 1 stream per GPU",
+                   "parallelism": par,
                    "weights": f"{wtype} blocks dequantised in-register, f32 activations and KV cache"},
         "device_ms_per_step": round(r["device_ms_per_step"], 5),
         "hbm_frac_whole_step": round(r["hbm_frac_whole_step"], 4),
@@ -277,9 +307,47 @@ def main():
             out["other_configs"] = side_configs(model)
         except Exception as exc:
             out["other_configs"] = {"error": repr(exc)}
+    if tp_res is not None:
+        res = tp_res
+        if rank == 0:
+            if "tok_s" in res:
+                out["secondary"] = {"workload": f"big (7.9B) Q4_0 single-stream greedy decode, tensor-parallel over {n} GPUs "
+                                                "(RCCL all-reduce after WO and down, logits all-gather)",
+                                    "scaling": "strong", "value": round(res["tok_s"], 2), "unit": "tokens/s",
+                                    "ms_per_step": round(res["ms_per_step"], 5),
+                                    "hbm_frac_whole_step": round(res["hbm_frac_whole_step"], 4),
+                                    "roofline": res["roofline"], "kernels": res["kernels"]}
+            else:
+                out["secondary"] = res
     if rank == 0:
         print(json.dumps(out))
     rdv.close()
+
+
+def spawn_tp_child(args):
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--tp-worker", "1", "--steps", "96",
+           "--warmup", "16", "--no-cpu-baseline"]
+    return subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def collect_tp_child(proc, timeout_s=420):
+    import subprocess
+    timeout_s = int(os.environ.get("NL_TP_CHILD_TIMEOUT", timeout_s))
+    try:
+        so, se = proc.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        return {"error": f"tensor-parallel child did not finish within {timeout_s}s"}
+    for line in so.splitlines():
+        if line.startswith("TPJSON "):
+            return json.loads(line[7:])
+    return {"error": "tensor-parallel child failed", "rc": proc.returncode, "stderr_tail": se[-600:]} if proc.returncode else {}
 
 
 if __name__ == "__main__":

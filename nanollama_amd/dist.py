@@ -1,48 +1,163 @@
-"""Host-side rendezvous for one-process-per-GPU runs (bench.py, launched by torch.distributed.run).
+"""Host-side rendezvous for one-process-per-GPU runs (bench.py under torch.distributed.run).
 
-torch.distributed (gloo) is used ONLY to hand the RCCL unique id from rank 0 to the other ranks, to
-barrier around the timed region and to take the max over ranks; the data path (all-reduce over xGMI)
-is RCCL inside libnanollama_hip.so on the engine's own HIP stream.
+Only three things cross ranks on the host: the 128-byte RCCL unique id (rank 0 -> all), a barrier around
+the timed region, and the max over ranks of the measured time.  They travel over a plain TCP star rooted at
+rank 0 (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the launcher's environment).  torch is NOT
+imported here on purpose: the PyTorch wheel bundles its own ROCm 7.0 HIP runtime, and a process that loads
+it next to /opt/rocm's runtime (which libnanollama_hip.so links) ends up with two HIP runtimes and
+`hipErrorNoDevice` in the second one.  The data path (all-reduce over xGMI) is RCCL inside the library.
 """
 from __future__ import annotations
 
 import os
-from typing import Callable, Optional
+import socket
+import struct
+import time
+from typing import Callable, List, Optional
+
+_MAGIC = b"NLRDV1"
+_PORT_OFFSET = 23      # MASTER_PORT itself belongs to the launcher's own store
+_PORT_TRIES = 8
+
+
+def _send(sock: socket.socket, payload: bytes) -> None:
+    sock.sendall(struct.pack("<I", len(payload)) + payload)
+
+
+def _recv(sock: socket.socket) -> bytes:
+    hdr = b""
+    while len(hdr) < 4:
+        chunk = sock.recv(4 - len(hdr))
+        if not chunk:
+            raise ConnectionError("rendezvous peer closed the connection")
+        hdr += chunk
+    n = struct.unpack("<I", hdr)[0]
+    buf = b""
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("rendezvous peer closed the connection")
+        buf += chunk
+    return buf
 
 
 class Rendezvous:
-    def __init__(self):
+    def __init__(self, timeout_s: float = 300.0):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self._dist = None
+        if os.environ.get("NL_BENCH_ONE_DEVICE"):  # developer switch: several ranks share GPU 0 (1-GPU box)
+            self.local_rank = 0
+        self._peers: List[socket.socket] = []   # rank 0: sockets of ranks 1..world-1 (index = rank-1)
+        self._root: Optional[socket.socket] = None
+        self._listener: Optional[socket.socket] = None
         if self.world > 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            import torch.distributed as dist
-            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
-            self._dist = dist
+            addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+            base = int(os.environ.get("MASTER_PORT", "29500")) + _PORT_OFFSET
+            if self.rank == 0:
+                self._serve(addr, base, timeout_s)
+            else:
+                self._connect(addr, base, timeout_s)
 
-    def broadcast_bytes(self, make: Callable[[], bytes]) -> Optional[bytes]:
+    # ---- wiring ----
+    def _serve(self, addr: str, base: int, timeout_s: float) -> None:
+        last = None
+        for k in range(_PORT_TRIES):
+            try:
+                s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                s.bind(("0.0.0.0" if addr not in ("127.0.0.1", "localhost") else "127.0.0.1", base + k))
+                s.listen(self.world)
+                self._listener = s
+                break
+            except OSError as exc:
+                last = exc
+                s.close()
+        if self._listener is None:
+            raise RuntimeError(f"rendezvous: no free port in [{base}, {base + _PORT_TRIES}): {last}")
+        slots: List[Optional[socket.socket]] = [None] * (self.world - 1)
+        deadline = time.time() + timeout_s
+        self._listener.settimeout(1.0)
+        while any(x is None for x in slots):
+            if time.time() > deadline:
+                raise TimeoutError("rendezvous: not every rank connected")
+            try:
+                c, _ = self._listener.accept()
+            except socket.timeout:
+                continue
+            try:
+                c.settimeout(10.0)
+                hello = _recv(c)
+                if not hello.startswith(_MAGIC):
+                    c.close()
+                    continue
+                r = struct.unpack("<I", hello[len(_MAGIC):len(_MAGIC) + 4])[0]
+                if not 1 <= r < self.world or slots[r - 1] is not None:
+                    c.close()
+                    continue
+                _send(c, _MAGIC)
+                c.settimeout(timeout_s)
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                slots[r - 1] = c
+            except (OSError, ConnectionError, struct.error):
+                c.close()
+        self._peers = [s for s in slots if s is not None]
+
+    def _connect(self, addr: str, base: int, timeout_s: float) -> None:
+        deadline = time.time() + timeout_s
+        while time.time() < deadline:
+            for k in range(_PORT_TRIES):
+                try:
+                    s = socket.create_connection((addr, base + k), timeout=2.0)
+                    s.settimeout(10.0)
+                    _send(s, _MAGIC + struct.pack("<I", self.rank))
+                    if _recv(s) == _MAGIC:
+                        s.settimeout(timeout_s)
+                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        self._root = s
+                        return
+                    s.close()
+                except (OSError, ConnectionError):
+                    continue
+            time.sleep(0.2)
+        raise TimeoutError("rendezvous: could not reach rank 0")
+
+    # ---- collectives over the star ----
+    def broadcast_bytes(self, make: Callable[[], bytes]) -> bytes:
         """Rank 0 calls make(); every rank returns the same bytes."""
-        if not self._dist:
+        if self.world == 1:
             return make()
-        box = [make() if self.rank == 0 else None]
-        self._dist.broadcast_object_list(box, src=0)
-        return box[0]
+        if self.rank == 0:
+            data = make()
+            for p in self._peers:
+                _send(p, data)
+            return data
+        return _recv(self._root)
+
+    def _gather_floats(self, value: float) -> List[float]:
+        vals = [value]
+        for p in self._peers:
+            vals.append(struct.unpack("<d", _recv(p))[0])
+        return vals
 
     def barrier(self) -> None:
-        if self._dist:
-            self._dist.barrier()
+        self.max_over_ranks(0.0)
 
     def max_over_ranks(self, value: float) -> float:
-        if not self._dist:
+        if self.world == 1:
             return value
-        import torch
-        t = torch.tensor([value], dtype=torch.float64)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
-        return float(t.item())
+        if self.rank == 0:
+            m = max(self._gather_floats(value))
+            for p in self._peers:
+                _send(p, struct.pack("<d", m))
+            return m
+        _send(self._root, struct.pack("<d", value))
+        return struct.unpack("<d", _recv(self._root))[0]
 
     def close(self) -> None:
-        if self._dist:
-            self._dist.destroy_process_group()
-            self._dist = None
+        for s in self._peers + [x for x in (self._root, self._listener) if x is not None]:
+            try:
+                s.close()
+            except OSError:
+                pass
+        self._peers, self._root, self._listener = [], None, None

@@ -1,5 +1,6 @@
 """CPU coverage of the N>1 path: the tensor-parallel slicing arithmetic (checked with the oracle's
-GEMVs on sliced raw bytes) and the world_size-2 gloo rendezvous bench.py uses."""
+GEMVs on sliced raw bytes) and the world_size-2 rendezvous bench.py uses under torch.distributed.run
+(a torch-free TCP star: importing torch next to the HIP library loads a second HIP runtime)."""
 import os
 import subprocess
 import sys
@@ -59,8 +60,8 @@ def test_big_tier_divides_for_1_2_4_8_gpus():
         tp.slice_raw(np.zeros(36, np.uint8), gguf.GGML_Q4_0, 1, 64, tp.Slice(0, 1, 16, 32))
 
 
-def test_world_size_2_gloo_rendezvous(tmp_path):
-    # bench.py's multi-process scaffolding (id broadcast, barrier, max over ranks) on CPU with gloo
+def test_world_size_2_rendezvous(tmp_path):
+    # bench.py multi-process scaffolding (id broadcast, barrier, max over ranks) under torch.distributed.run, CPU only
     script = tmp_path / "w.py"
     script.write_text(textwrap.dedent(f"""
         import sys
@@ -72,6 +73,7 @@ def test_world_size_2_gloo_rendezvous(tmp_path):
         r.barrier()
         m = r.max_over_ranks(10.0 + r.rank)
         assert m == 11.0, m
+        assert "torch" not in sys.modules, "the rendezvous must not import torch"
         r.close()
         print("rank", r.rank, "ok")
     """))
