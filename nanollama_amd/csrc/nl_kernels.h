@@ -397,11 +397,10 @@ template <int WT, int PRO, int EPI>
 __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CPP = WTraits<WT>::CPP;
-    constexpr int NM = 1;  // gate and up run in separate wavefronts of the same workgroup (see wpt below)
     const int nwaves = blockDim.x >> 6;
     float *xs_all = reinterpret_cast<float *>(smem);          // [waves][XS_WAVE]
-    float *red = xs_all + nwaves * XS_WAVE;                   // [NM][waves][TR]
-    double *dred = reinterpret_cast<double *>(red + NM * nwaves * TR);  // [waves]
+    float *red = xs_all + nwaves * XS_WAVE;                   // [waves][TR]
+    double *dred = reinterpret_cast<double *>(red + nwaves * TR);  // [waves]
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #define NL_STAMP(k) do { if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + (k)] = clock64(); } while (0)
@@ -443,80 +442,57 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     int ns = 1;
     if (PRO == PRO_ATTN) ns = P.ctl[CTL_POS] / ATT_CH + 1;
 
-    float acc0 = 0.f, acc1 = 0.f;
+    float acc0 = 0.f;
     double ss = 0.0;
     NL_STAMP(1);
-    // two groups in flight per wavefront where the registers allow it
-#ifdef NL_FORCE_ONE
-    constexpr bool TWO = false;
+    // NF groups in flight per wavefront (all loads of a round are issued before the first dot product)
+#ifdef NL_NF
+    constexpr int NF = NL_NF;
 #else
-    constexpr bool TWO = NM == 1 && CPP <= 8;
+    constexpr int NF = CPP <= 8 ? 2 : 1;  // 4 in flight for Q4_0 cost occupancy: 5.36 -> 4.77 TB/s on big's LM head
 #endif
-    for (int g = kw; g < ngroups; g += (TWO ? 2 : 1) * P.kw) {
-        const int gb = g + P.kw;
-        const bool hasb = TWO && gb < ngroups;
-        const int gsa = min(KL, P.npairs - g * KL), gsb = hasb ? min(KL, P.npairs - gb * KL) : 0;
-        float4 ga4, gb4;
-        float4 xa = load_x4<PRO>(P, g * (KL * PAIR) + lane * 4, ga4, ns);
-        float4 xb = hasb ? load_x4<PRO>(P, gb * (KL * PAIR) + lane * 4, gb4, ns) : make_float4(0.f, 0.f, 0.f, 0.f);
-        uint4 ca[CPP], cb[CPP], ua[NM > 1 ? CPP : 1], ub[NM > 1 ? CPP : 1];
-        uint32_t sa = 0, sb = 0, ta = 0, tb = 0;
-        const bool la = live && k < gsa, lb = live && k < gsb;
-        if (la) {
-            load_pair<WT>(Wq, Ws, tp0, g, gsa, r, k, ca, sa);
-            if (NM > 1) load_pair<WT>(P.q1, P.s1, tp0, g, gsa, r, k, ua, ta);
+    for (int g0 = kw; g0 < ngroups; g0 += NF * P.kw) {
+        float4 xv[NF], gv[NF];
+        uint4 cw[NF][CPP];
+        uint32_t sw[NF];
+        bool lv[NF];
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            const int g = g0 + f * P.kw;
+            const bool has = g < ngroups;
+            const int gs = has ? min(KL, P.npairs - g * KL) : 0;
+            lv[f] = live && k < gs;
+            sw[f] = 0;
+            xv[f] = has ? load_x4<PRO>(P, g * (KL * PAIR) + lane * 4, gv[f], ns) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lv[f]) load_pair<WT>(Wq, Ws, tp0, g, gs, r, k, cw[f], sw[f]);
         }
-        if (lb) {
-            load_pair<WT>(Wq, Ws, tp0, gb, gsb, r, k, cb, sb);
-            if (NM > 1) load_pair<WT>(P.q1, P.s1, tp0, gb, gsb, r, k, ub, tb);
-        }
-        // ---- group a ----
-        if (PRO == PRO_NORM) {
-            // RMSNormInto go/quant.go:597-607.  inv = 1/sqrt(mean(x^2)+eps) multiplies the GEMV OUTPUT
-            // (out = inv * sum_j w_ij (x_j g_j)), so its float64 reduction is off the critical path.
-            if (tin == 0 && msel == 0) {
-                ss += (double)xa.x * (double)xa.x; ss += (double)xa.y * (double)xa.y;
-                ss += (double)xa.z * (double)xa.z; ss += (double)xa.w * (double)xa.w;
-                if (P.x_out && blockIdx.x == 0 && g * (KL * PAIR) + lane * 4 < P.cols)
-                    *reinterpret_cast<float4 *>(P.x_out + g * (KL * PAIR) + lane * 4) = xa;
-            }
-            xa.x *= ga4.x; xa.y *= ga4.y; xa.z *= ga4.z; xa.w *= ga4.w;
-        }
-        *reinterpret_cast<float4 *>(xs + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
-        __builtin_amdgcn_wave_barrier();
-        if (la) {
-            acc0 = PairDot<WT>::run(ca, sa, xs + k * XS_PAIR, acc0);
-            if (NM > 1) acc1 = PairDot<WT>::run(ua, ta, xs + k * XS_PAIR, acc1);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- group b ----
-        if (hasb) {
-            if (PRO == PRO_NORM) {
-                if (tin == 0 && msel == 0) {
-                    ss += (double)xb.x * (double)xb.x; ss += (double)xb.y * (double)xb.y;
-                    ss += (double)xb.z * (double)xb.z; ss += (double)xb.w * (double)xb.w;
-                    if (P.x_out && blockIdx.x == 0 && gb * (KL * PAIR) + lane * 4 < P.cols)
-                        *reinterpret_cast<float4 *>(P.x_out + gb * (KL * PAIR) + lane * 4) = xb;
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            const int g = g0 + f * P.kw;
+            if (g < ngroups) {
+                float4 xa = xv[f];
+                if (PRO == PRO_NORM) {
+                    // RMSNormInto go/quant.go:597-607.  inv = 1/sqrt(mean(x^2)+eps) multiplies the GEMV OUTPUT
+                    // (out = inv * sum_j w_ij (x_j g_j)), so its float64 reduction is off the critical path.
+                    if (tin == 0 && msel == 0) {
+                        ss += (double)xa.x * (double)xa.x; ss += (double)xa.y * (double)xa.y;
+                        ss += (double)xa.z * (double)xa.z; ss += (double)xa.w * (double)xa.w;
+                        if (P.x_out && blockIdx.x == 0 && g * (KL * PAIR) + lane * 4 < P.cols)
+                            *reinterpret_cast<float4 *>(P.x_out + g * (KL * PAIR) + lane * 4) = xa;
+                    }
+                    xa.x *= gv[f].x; xa.y *= gv[f].y; xa.z *= gv[f].z; xa.w *= gv[f].w;
                 }
-                xb.x *= gb4.x; xb.y *= gb4.y; xb.z *= gb4.z; xb.w *= gb4.w;
+                *reinterpret_cast<float4 *>(xs + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
+                __builtin_amdgcn_wave_barrier();
+                if (lv[f]) acc0 = PairDot<WT>::run(cw[f], sw[f], xs + k * XS_PAIR, acc0);
+                __builtin_amdgcn_wave_barrier();
             }
-            *reinterpret_cast<float4 *>(xs + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xb;
-            __builtin_amdgcn_wave_barrier();
-            if (lb) {
-                acc0 = PairDot<WT>::run(cb, sb, xs + k * XS_PAIR, acc0);
-                if (NM > 1) acc1 = PairDot<WT>::run(ub, tb, xs + k * XS_PAIR, acc1);
-            }
-            __builtin_amdgcn_wave_barrier();
         }
     }
     NL_STAMP(4);
     // the 4 pair-lanes of a row form a quad
     acc0 = quad_sum(acc0);
-    if (NM > 1) acc1 = quad_sum(acc1);
-    if (k == 0) {
-        red[wave * TR + r] = acc0;
-        if (NM > 1) red[(nwaves + wave) * TR + r] = acc1;
-    }
+    if (k == 0) red[wave * TR + r] = acc0;
     if (PRO == PRO_NORM && tin == 0 && msel == 0) {
         ss = wave_sum_f64(ss);
         if (lane == 0) dred[kw] = ss;
