@@ -44,7 +44,8 @@ typedef enum {
 } nl_status;
 
 /* ggml tensor types accepted by nl_upload_tensor (go/gguf.go:43-57). */
-enum { NL_GGML_F32 = 0, NL_GGML_F16 = 1, NL_GGML_Q4_0 = 2, NL_GGML_Q8_0 = 8 };
+enum { NL_GGML_F32 = 0, NL_GGML_F16 = 1, NL_GGML_Q4_0 = 2, NL_GGML_Q5_0 = 6, NL_GGML_Q8_0 = 8, NL_GGML_Q4_K = 12,
+       NL_GGML_Q6_K = 14 };  /* every format go/quant.go multiplies with */
 
 /* Mirrors LlamaConfig (go/model.go:27-42) + placement.  head_dim == 0 means
  * dim / n_heads (go/model.go:140-142); seq_len is capped to 2048 exactly as

@@ -16,26 +16,7 @@ struct BEmbedParams {
 __global__ void bembed_kernel(BEmbedParams P) {
     const int token = P.tokens[blockIdx.x];
     float *x = P.x + (long long)blockIdx.x * P.dim;
-    for (int i = threadIdx.x; i < P.dim; i += blockDim.x) {
-        float v;
-        if (P.wtype == WT_Q8_0) {
-            const uint8_t *blk = P.table + ((long long)token * (P.dim / 32) + i / 32) * 34;
-            float d = h2f_bits((uint32_t)blk[0] | ((uint32_t)blk[1] << 8));
-            v = (float)(int)(int8_t)blk[2 + (i & 31)] * d;
-        } else if (P.wtype == WT_Q4_0) {
-            const uint8_t *blk = P.table + ((long long)token * (P.dim / 32) + i / 32) * 18;
-            float d = h2f_bits((uint32_t)blk[0] | ((uint32_t)blk[1] << 8));
-            int j = i & 31;
-            int nib = j < 16 ? (blk[2 + j] & 0x0F) : (blk[2 + j - 16] >> 4);
-            v = (float)(nib - 8) * d;
-        } else if (P.wtype == WT_F16) {
-            const uint8_t *p = P.table + ((long long)token * P.dim + i) * 2;
-            v = h2f_bits((uint32_t)p[0] | ((uint32_t)p[1] << 8));
-        } else {
-            v = reinterpret_cast<const float *>(P.table)[(long long)token * P.dim + i];
-        }
-        x[i] = v;
-    }
+    for (int i = threadIdx.x; i < P.dim; i += blockDim.x) x[i] = embed_value(P.table, P.wtype, P.dim, token, i);
 }
 
 // RMSNormInto go/quant.go:597-607, one workgroup per token

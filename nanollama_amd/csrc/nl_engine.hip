@@ -36,20 +36,28 @@ const char *kKindNames[NL_NUM_KINDS] = {"embed", "qkv_rope", "attention", "wo_re
 struct PackedMat {
     uint8_t *q = nullptr;
     uint32_t *s = nullptr;
-    int wtype = -1, rows = 0, cols = 0, ntiles = 0, npairs = 0;
+    int wtype = -1, src_type = -1, rows = 0, cols = 0, ntiles = 0, npairs = 0;  // wtype = device layout type
     size_t q_bytes = 0, s_bytes = 0;
     bool ready = false;
 };
 
-int chunks_per_pair(int wt) { return wt == WT_Q8_0 ? 4 : wt == WT_Q4_0 ? 2 : wt == WT_F16 ? 8 : 16; }
-bool is_scaled(int wt) { return wt == WT_Q8_0 || wt == WT_Q4_0; }
-bool type_supported(uint32_t t) { return t == WT_F32 || t == WT_F16 || t == WT_Q4_0 || t == WT_Q8_0; }
+// device layout type of a source ggml type (Q5_0 is expanded into the Q8_0 layout by repack_kernel)
+int device_type(int src) { return src == WT_Q5_0 ? WT_Q8_0 : src; }
+int chunks_per_pair(int wt) { return (wt == WT_Q8_0 || wt == WT_Q6_K) ? 4 : (wt == WT_Q4_0 || wt == WT_Q4_K) ? 2 : wt == WT_F16 ? 8 : 16; }
+bool is_scaled(int wt) { return wt == WT_Q8_0 || wt == WT_Q4_0 || wt == WT_Q4_K || wt == WT_Q6_K; }
+bool type_supported(uint32_t t) {
+    return t == WT_F32 || t == WT_F16 || t == WT_Q4_0 || t == WT_Q5_0 || t == WT_Q8_0 || t == WT_Q4_K || t == WT_Q6_K;
+}
+bool is_kquant(uint32_t t) { return t == WT_Q4_K || t == WT_Q6_K; }
 size_t raw_bytes(uint32_t t, uint64_t nel) {
     switch (t) {
     case WT_F32: return nel * 4;
     case WT_F16: return nel * 2;
     case WT_Q4_0: return nel / 32 * 18;
+    case WT_Q5_0: return nel / 32 * 22;
     case WT_Q8_0: return nel / 32 * 34;
+    case WT_Q4_K: return nel / 256 * 144;
+    case WT_Q6_K: return nel / 256 * 210;
     default: return 0;
     }
 }
@@ -229,11 +237,11 @@ hipError_t stage_reserve(nl_engine *e, size_t bytes) {
 // [tile0, tile0 + ntiles) of a PackedMat.
 hipError_t repack(nl_engine *e, PackedMat &m, const uint8_t *d_src, int wtype, int src_cols, int row0, int nrows,
                   int col0, int ncols, int tile0, int ntiles, int rowmap) {
-    const int cpp = chunks_per_pair(wtype);
+    const int cpp = chunks_per_pair(device_type(wtype));
     RepackParams P{};
     P.src = d_src;
     P.q = m.q + (size_t)tile0 * m.npairs * cpp * TR * 16;
-    P.s = m.s ? m.s + (size_t)tile0 * m.npairs * TR : nullptr;
+    P.s = m.s ? m.s + (size_t)tile0 * m.npairs * TR * scale_words(wtype) : nullptr;
     P.wtype = wtype;
     P.src_cols = src_cols;
     P.row0 = row0; P.nrows = nrows; P.col0 = col0; P.ncols = ncols;
@@ -247,13 +255,14 @@ hipError_t repack(nl_engine *e, PackedMat &m, const uint8_t *d_src, int wtype, i
 }
 
 hipError_t alloc_packed(nl_engine *e, PackedMat &m, int wtype, int rows_padded_tiles, int rows, int cols) {
-    m.wtype = wtype;
+    m.src_type = wtype;
+    m.wtype = wtype = device_type(wtype);
     m.rows = rows;
     m.cols = cols;
     m.ntiles = rows_padded_tiles;
     m.npairs = (cols + PAIR - 1) / PAIR;
     m.q_bytes = (size_t)m.ntiles * m.npairs * chunks_per_pair(wtype) * TR * 16;
-    m.s_bytes = is_scaled(wtype) ? (size_t)m.ntiles * m.npairs * TR * 4 : 0;
+    m.s_bytes = is_scaled(wtype) ? (size_t)m.ntiles * m.npairs * TR * 4 * scale_words(wtype) : 0;
     hipError_t s = arena_alloc(e, (void **)&m.q, m.q_bytes);
     if (s != hipSuccess) return s;
     if (m.s_bytes) {
@@ -290,6 +299,8 @@ hipError_t launch_gemv_t(int wtype, GemvParams P, hipStream_t st) {
     case WT_Q4_0: hipLaunchKernelGGL((gemv_kernel<WT_Q4_0, PRO, EPI>), grid, block, lds, st, P); break;
     case WT_F16: hipLaunchKernelGGL((gemv_kernel<WT_F16, PRO, EPI>), grid, block, lds, st, P); break;
     case WT_F32: hipLaunchKernelGGL((gemv_kernel<WT_F32, PRO, EPI>), grid, block, lds, st, P); break;
+    case WT_Q4_K: hipLaunchKernelGGL((gemv_kernel<WT_Q4_K, PRO, EPI>), grid, block, lds, st, P); break;
+    case WT_Q6_K: hipLaunchKernelGGL((gemv_kernel<WT_Q6_K, PRO, EPI>), grid, block, lds, st, P); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -776,9 +787,12 @@ int nl_upload_tensor(nl_handle e, const char *name, uint32_t type, const void *d
                            (unsigned long long)cols, exp_rows, exp_cols);
         if (first) {
             HIPCK(e, alloc_packed(e, m, (int)type, tiles_total, rowmap == ROWMAP_HEADPERM ? tiles_total * TR : nrows, ncols));
-        } else if (m.wtype != (int)type) {
+        } else if (m.src_type != (int)type) {
             return e->fail(NL_ERR_UNSUPPORTED, "tensor %s: q/k/v (or gate/up) of one layer must share a type", name);
         }
+        if (is_kquant(type) && (exp_cols % 256 || col0 % 256 || ncols % 256))
+            return e->fail(NL_ERR_INVALID, "tensor %s: K-quant rows must be whole 256-column super blocks (cols %d, slice %d+%d)",
+                           name, exp_cols, col0, ncols);
         // row-sliced tensors (tensor-parallel shards) only move their own rows to the device
         const size_t row_bytes = raw_bytes(type, (uint64_t)exp_cols);
         const uint8_t *src = (const uint8_t *)data + (size_t)row0 * row_bytes;
@@ -796,6 +810,7 @@ int nl_upload_tensor(nl_handle e, const char *name, uint32_t type, const void *d
     if (sl.layer < 0) {
         if (f == "token_embd.weight") {
             if ((int)rows != c.vocab || (int)cols != D) return e->fail(NL_ERR_INVALID, "token_embd.weight: bad shape");
+            if (is_kquant(type) && D % 256) return e->fail(NL_ERR_INVALID, "token_embd.weight: K-quant rows need dim %% 256 == 0");
             if (e->embd_raw) hipFree(e->embd_raw);
             HIPCK(e, hipMalloc((void **)&e->embd_raw, nbytes));
             HIPCK(e, hipMemcpy(e->embd_raw, data, nbytes, hipMemcpyHostToDevice));
@@ -871,7 +886,7 @@ int nl_finalize(nl_handle e) {
                          : !L.have_v ? "attn_v" : !L.wo.ready ? "attn_output" : !L.gate.ready ? "ffn_gate"
                          : !L.up.ready ? "ffn_up" : !L.down.ready ? "ffn_down" : nullptr;
         if (miss) return e->fail(NL_ERR_MISSING, "layer %d %s: tensor not found", l, miss);
-        if (L.gate.wtype != L.up.wtype) return e->fail(NL_ERR_UNSUPPORTED, "layer %d: ffn_gate and ffn_up types differ", l);
+        if (L.gate.src_type != L.up.src_type) return e->fail(NL_ERR_UNSUPPORTED, "layer %d: ffn_gate and ffn_up types differ", l);
     }
     if (!e->have_output) {
         // tied embeddings: output.weight missing -> LM head reads token_embd (go/model.go:195-201)
@@ -1233,6 +1248,7 @@ int nl_op_matmul(int device, uint32_t type, const void *w, uint64_t nbytes, cons
                  int cols) {
     if (!w || !x || !out || rows <= 0 || cols <= 0 || cols % 32) return NL_ERR_INVALID;
     if (!type_supported(type)) return NL_ERR_UNSUPPORTED;  // matmulDispatch default arm, go/model.go:383-385
+    if (is_kquant(type) && cols % 256) return NL_ERR_INVALID;
     if (raw_bytes(type, (uint64_t)rows * cols) != nbytes) return NL_ERR_INVALID;
     if (hipSetDevice(device) != hipSuccess) return NL_ERR_HIP;
     nl_engine tmp;
@@ -1258,7 +1274,7 @@ int nl_op_matmul(int device, uint32_t type, const void *w, uint64_t nbytes, cons
         if (const char *v = getenv("NL_KW")) tmp.kw_override = atoi(v);
         choose_geometry(&tmp, m, P.tw, P.kw);
         P.x = d_x; P.out = d_out;
-        if (launch_gemv_t<PRO_PLAIN, EPI_STORE>((int)type, P, st) != hipSuccess) break;
+        if (launch_gemv_t<PRO_PLAIN, EPI_STORE>(m.wtype, P, st) != hipSuccess) break;
         if (hipMemcpyAsync(out, d_out, (size_t)rows * 4, hipMemcpyDeviceToHost, st) != hipSuccess) break;
         if (hipStreamSynchronize(st) != hipSuccess) break;
         rc = NL_OK;
@@ -1278,7 +1294,7 @@ int nl_op_matmul(int device, uint32_t type, const void *w, uint64_t nbytes, cons
 int nl_op_matmul_batch(int device, uint32_t type, const void *w, uint64_t nbytes, const float *x, float *out,
                        int rows, int cols, int n_tokens) {
     if (!w || !x || !out || rows <= 0 || cols <= 0 || cols % 32 || n_tokens <= 0) return NL_ERR_INVALID;
-    if (type != WT_Q4_0 && type != WT_Q8_0) return NL_ERR_UNSUPPORTED;
+    if (device_type((int)type) != WT_Q4_0 && device_type((int)type) != WT_Q8_0) return NL_ERR_UNSUPPORTED;
     if (raw_bytes(type, (uint64_t)rows * cols) != nbytes) return NL_ERR_INVALID;
     if (hipSetDevice(device) != hipSuccess) return NL_ERR_HIP;
     nl_engine tmp;
@@ -1301,7 +1317,7 @@ int nl_op_matmul_batch(int device, uint32_t type, const void *w, uint64_t nbytes
         QGemmParams P{};
         P.q = m.q; P.s = m.s; P.rows = rows; P.cols = cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
         P.x = d_x; P.ldx = cols; P.n_tokens = n_tokens; P.out = d_out; P.ldo = rows;
-        if (launch_qgemm((int)type, P, st) != hipSuccess) break;
+        if (launch_qgemm(m.wtype, P, st) != hipSuccess) break;
         if (hipMemcpyAsync(out, d_out, (size_t)rows * n_tokens * 4, hipMemcpyDeviceToHost, st) != hipSuccess) break;
         if (hipStreamSynchronize(st) != hipSuccess) break;
         rc = NL_OK;

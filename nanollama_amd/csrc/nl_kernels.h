@@ -30,7 +30,10 @@ constexpr int ATT_CH = 128;      // positions per attention split
 constexpr int ATT_THREADS = 256;
 constexpr int CTL_TOKEN = 0, CTL_POS = 1, CTL_CHAIN = 2, CTL_STEP = 3, CTL_STREAM = 4, CTL_WORDS = 8;
 
-enum { WT_F32 = 0, WT_F16 = 1, WT_Q4_0 = 2, WT_Q8_0 = 8 };
+// ggml ids (go/gguf.go:43-57).  Device layouts: Q5_0 is expanded to the Q8_0 layout at upload (5-bit value - 16 as
+// int8, same fp16 d); Q6_K to WT_Q6_K = int8 (6-bit value - 32) with four int8 sub-scales per 64 columns;
+// Q4_K keeps its nibbles with an 8-byte {d, dmin, sc0, m0, sc1, m1} entry per 64 columns.
+enum { WT_F32 = 0, WT_F16 = 1, WT_Q4_0 = 2, WT_Q5_0 = 6, WT_Q8_0 = 8, WT_Q4_K = 12, WT_Q6_K = 14 };
 enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_ATTN = 2 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
 enum { ROWMAP_IDENT = 0, ROWMAP_HEADPERM = 1 };
@@ -40,6 +43,9 @@ template <> struct WTraits<WT_Q8_0> { static constexpr int CPP = 4; static const
 template <> struct WTraits<WT_Q4_0> { static constexpr int CPP = 2; static constexpr bool SCALED = true; };
 template <> struct WTraits<WT_F16> { static constexpr int CPP = 8; static constexpr bool SCALED = false; };
 template <> struct WTraits<WT_F32> { static constexpr int CPP = 16; static constexpr bool SCALED = false; };
+template <> struct WTraits<WT_Q4_K> { static constexpr int CPP = 2; static constexpr bool SCALED = true; };
+template <> struct WTraits<WT_Q6_K> { static constexpr int CPP = 4; static constexpr bool SCALED = true; };
+__host__ __device__ constexpr int scale_words(int wt) { return (wt == WT_Q4_K || wt == WT_Q6_K) ? 2 : 1; }
 
 __device__ __forceinline__ float h2f_bits(uint32_t h) {
     // exact IEEE binary16 -> binary32 (subnormals kept), == go/gguf.go:603-636
@@ -70,8 +76,27 @@ __device__ __forceinline__ int map_row(int rowmap, int head_dim, int tile, int r
     return tile * TR + r;
 }
 
+// go/quant.go:285-294
+__device__ __forceinline__ void scale_min_k4(int j, const uint8_t *sc, uint32_t &s, uint32_t &m) {
+    if (j < 4) { s = sc[j] & 63; m = sc[j + 4] & 63; }
+    else { s = (sc[j + 4] & 0x0F) | ((sc[j - 4] >> 6) << 4); m = (sc[j + 4] >> 4) | ((sc[j] >> 6) << 4); }
+}
+// 6-bit value of element e (0..255) of a Q6_K super block (go/quant.go:193-203) and its scale index
+__device__ __forceinline__ int q6k_value(const uint8_t *blk, int e, int &sidx) {
+    const int n = e >> 7, within = e & 127, which = within >> 5, l = within & 31;
+    const uint8_t *ql = blk + n * 64, *qh = blk + 128 + n * 32;
+    sidx = n * 8 + (l >> 4) + 2 * which;
+    const int lo = (which & 1) ? ql[l + 32] : ql[l];
+    const int nib = (which >> 1) ? (lo >> 4) : (lo & 0x0F);
+    return nib | (((qh[l] >> (2 * which)) & 3) << 4);
+}
+
 __global__ void repack_kernel(RepackParams P) {
-    const int cpp = P.wtype == WT_Q8_0 ? 4 : P.wtype == WT_Q4_0 ? 2 : P.wtype == WT_F16 ? 8 : 16;
+    // P.wtype is the SOURCE ggml type; the destination layout is Q8_0-like for Q5_0 / Q6_K (see the enum)
+    const int src = P.wtype;
+    const int cpp = (src == WT_Q8_0 || src == WT_Q5_0 || src == WT_Q6_K) ? 4 : (src == WT_Q4_0 || src == WT_Q4_K) ? 2
+                    : src == WT_F16 ? 8 : 16;
+    const int sw = scale_words(src);
     const int per_tile = P.npairs * cpp * TR;
     const long long nchunks = (long long)P.ntiles * per_tile;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < nchunks;
@@ -88,22 +113,50 @@ __global__ void repack_kernel(RepackParams P) {
         int row = map_row(P.rowmap, P.head_dim, tile, r);
         uint4 v = make_uint4(0, 0, 0, 0);
         uint8_t *vb = reinterpret_cast<uint8_t *>(&v);
-        if (row < P.nrows) {
-            long long srow = (long long)(P.row0 + row);
-            if (P.wtype == WT_Q8_0) {
+        uint32_t sc0 = 0, sc1 = 0;
+        const bool in_row = row < P.nrows;
+        const long long srow = (long long)(P.row0 + (in_row ? row : 0));
+        if (in_row) {
+            if (src == WT_Q8_0) {
                 int b = 2 * p + (c >> 1);
                 if (b * 32 < P.ncols) {
                     const uint8_t *blk = P.src + (srow * (P.src_cols / 32) + (P.col0 / 32 + b)) * 34;
                     for (int j = 0; j < 16; j++) vb[j] = blk[2 + (c & 1) * 16 + j];
                 }
-            } else if (P.wtype == WT_Q4_0) {
+            } else if (src == WT_Q4_0) {
                 int b = 2 * p + c;
                 if (b * 32 < P.ncols) {
                     const uint8_t *blk = P.src + (srow * (P.src_cols / 32) + (P.col0 / 32 + b)) * 18;
                     for (int j = 0; j < 16; j++) vb[j] = blk[2 + j];
                 }
+            } else if (src == WT_Q5_0) {
+                // go/quant.go:405-420: 5-bit q = nibble | high bit << 4, value (q - 16) * d
+                int b = 2 * p + (c >> 1);
+                if (b * 32 < P.ncols) {
+                    const uint8_t *blk = P.src + (srow * (P.src_cols / 32) + (P.col0 / 32 + b)) * 22;
+                    const uint32_t qh = (uint32_t)blk[2] | ((uint32_t)blk[3] << 8) | ((uint32_t)blk[4] << 16) | ((uint32_t)blk[5] << 24);
+                    for (int j = 0; j < 16; j++) {
+                        int e = (c & 1) * 16 + j;
+                        int nib = e < 16 ? (blk[6 + e] & 0x0F) : (blk[6 + e - 16] >> 4);
+                        vb[j] = (uint8_t)(int8_t)((nib | (int)(((qh >> e) & 1u) << 4)) - 16);
+                    }
+                }
+            } else if (src == WT_Q4_K) {
+                // super block = 4 pairs; pair j holds qs[32j .. 32j+31] (low nibbles = first 32 columns, high = next 32)
+                if (p * PAIR < P.ncols) {
+                    const uint8_t *blk = P.src + (srow * (P.src_cols / 256) + (P.col0 / 256 + (p >> 2))) * 144;
+                    for (int j = 0; j < 16; j++) vb[j] = blk[16 + 32 * (p & 3) + 16 * c + j];
+                }
+            } else if (src == WT_Q6_K) {
+                if (p * PAIR < P.ncols) {
+                    const uint8_t *blk = P.src + (srow * (P.src_cols / 256) + (P.col0 / 256 + (p >> 2))) * 210;
+                    for (int j = 0; j < 16; j++) {
+                        int sidx;
+                        vb[j] = (uint8_t)(int8_t)(q6k_value(blk, 64 * (p & 3) + 16 * c + j, sidx) - 32);
+                    }
+                }
             } else {
-                int esz = P.wtype == WT_F16 ? 2 : 4;
+                int esz = src == WT_F16 ? 2 : 4;
                 int per = 16 / esz;
                 int e0 = p * PAIR + c * per;
                 const uint8_t *sp = P.src + (srow * P.src_cols + P.col0 + e0) * esz;
@@ -114,19 +167,36 @@ __global__ void repack_kernel(RepackParams P) {
         }
         reinterpret_cast<uint4 *>(P.q)[idx] = v;
         if (P.s && c == 0) {
-            uint32_t sc = 0;
-            if (row < P.nrows) {
-                long long srow = (long long)(P.row0 + row);
-                int bsz = P.wtype == WT_Q8_0 ? 34 : 18;
-                for (int hb = 0; hb < 2; hb++) {
-                    int b = 2 * p + hb;
-                    if (b * 32 < P.ncols) {
-                        const uint8_t *blk = P.src + (srow * (P.src_cols / 32) + (P.col0 / 32 + b)) * bsz;
-                        sc |= ((uint32_t)blk[0] | ((uint32_t)blk[1] << 8)) << (16 * hb);
+            if (in_row) {
+                if (src == WT_Q8_0 || src == WT_Q4_0 || src == WT_Q5_0) {
+                    const int bsz = src == WT_Q8_0 ? 34 : src == WT_Q4_0 ? 18 : 22;
+                    for (int hb = 0; hb < 2; hb++) {
+                        int b = 2 * p + hb;
+                        if (b * 32 < P.ncols) {
+                            const uint8_t *blk = P.src + (srow * (P.src_cols / 32) + (P.col0 / 32 + b)) * bsz;
+                            sc0 |= ((uint32_t)blk[0] | ((uint32_t)blk[1] << 8)) << (16 * hb);
+                        }
+                    }
+                } else if (src == WT_Q4_K && p * PAIR < P.ncols) {
+                    const uint8_t *blk = P.src + (srow * (P.src_cols / 256) + (P.col0 / 256 + (p >> 2))) * 144;
+                    uint32_t s0, m0, s1, m1;
+                    scale_min_k4(2 * (p & 3), blk + 4, s0, m0);
+                    scale_min_k4(2 * (p & 3) + 1, blk + 4, s1, m1);
+                    sc0 = (uint32_t)blk[0] | ((uint32_t)blk[1] << 8) | ((uint32_t)blk[2] << 16) | ((uint32_t)blk[3] << 24);  // d | dmin
+                    sc1 = s0 | (m0 << 8) | (s1 << 16) | (m1 << 24);
+                } else if (src == WT_Q6_K && p * PAIR < P.ncols) {
+                    const uint8_t *blk = P.src + (srow * (P.src_cols / 256) + (P.col0 / 256 + (p >> 2))) * 210;
+                    sc0 = (uint32_t)blk[208] | ((uint32_t)blk[209] << 8);
+                    for (int i = 0; i < 4; i++) {
+                        int sidx;
+                        q6k_value(blk, 64 * (p & 3) + 16 * i, sidx);
+                        sc1 |= (uint32_t)blk[192 + sidx] << (8 * i);
                     }
                 }
             }
-            P.s[(long long)tile * P.npairs * TR + g * KL * TR + r * gsz + k] = sc;
+            const long long si = (long long)tile * P.npairs * TR + g * KL * TR + r * gsz + k;
+            if (sw == 1) P.s[si] = sc0;
+            else { P.s[2 * si] = sc0; P.s[2 * si + 1] = sc1; }
         }
     }
 }
@@ -148,7 +218,8 @@ template <int WT> struct PairDot;
 
 template <> struct PairDot<WT_Q8_0> {
     // out = sum_b d_b * sum_j q_bj x_j  (go/quant.go:149-165)
-    static __device__ __forceinline__ float run(const uint4 *c, uint32_t sc, const float *xp, float acc) {
+    static __device__ __forceinline__ float run(const uint4 *c, uint2 sc2, const float *xp, float acc) {
+        const uint32_t sc = sc2.x;
         const float4 *x4 = reinterpret_cast<const float4 *>(xp);
 #pragma unroll
         for (int b = 0; b < 2; b++) {
@@ -216,7 +287,8 @@ __device__ __forceinline__ void dot_q4_word(uint32_t w, float4 xl, float4 xh, Ac
 }
 
 template <> struct PairDot<WT_Q4_0> {
-    static __device__ __forceinline__ float run(const uint4 *c, uint32_t sc, const float *xp, float acc) {
+    static __device__ __forceinline__ float run(const uint4 *c, uint2 sc2, const float *xp, float acc) {
+        const uint32_t sc = sc2.x;
         const float4 *x4 = reinterpret_cast<const float4 *>(xp);
 #pragma unroll
         for (int b = 0; b < 2; b++) {
@@ -233,7 +305,7 @@ template <> struct PairDot<WT_Q4_0> {
 };
 
 template <> struct PairDot<WT_F16> {
-    static __device__ __forceinline__ float run(const uint4 *c, uint32_t, const float *xp, float acc) {
+    static __device__ __forceinline__ float run(const uint4 *c, uint2, const float *xp, float acc) {
         const float4 *x4 = reinterpret_cast<const float4 *>(xp);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -254,7 +326,7 @@ template <> struct PairDot<WT_F16> {
 };
 
 template <> struct PairDot<WT_F32> {
-    static __device__ __forceinline__ float run(const uint4 *c, uint32_t, const float *xp, float acc) {
+    static __device__ __forceinline__ float run(const uint4 *c, uint2, const float *xp, float acc) {
         const float4 *x4 = reinterpret_cast<const float4 *>(xp);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -267,6 +339,53 @@ template <> struct PairDot<WT_F32> {
             a3 = fmaf(__uint_as_float(q.w), a.w, a3);
         }
         return acc + ((a0 + a1) + (a2 + a3));
+    }
+};
+
+template <> struct PairDot<WT_Q4_K> {
+    // go/quant.go:364-396: out += (d*sc * q - dmin*m) * x per element; this pair = sub-blocks 2j, 2j+1 of a super block
+    static __device__ __forceinline__ float run(const uint4 *c, uint2 sc, const float *xp, float acc) {
+        const float d = h2f_bits(sc.x & 0xffff), dmin = h2f_bits(sc.x >> 16);
+        const float d1 = d * (float)(sc.y & 0xff), m1 = dmin * (float)((sc.y >> 8) & 0xff);
+        const float d2 = d * (float)((sc.y >> 16) & 0xff), m2 = dmin * (float)(sc.y >> 24);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            const uint32_t w[4] = {c[ch].x, c[ch].y, c[ch].z, c[ch].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float *xl = xp + 16 * ch + 4 * i, *xh = xp + 32 + 16 * ch + 4 * i;
+                const uint32_t u = w[i];
+                a0 = fmaf(d1 * (float)(u & 0xF) - m1, xl[0], a0);
+                a1 = fmaf(d2 * (float)((u >> 4) & 0xF) - m2, xh[0], a1);
+                a2 = fmaf(d1 * (float)((u >> 8) & 0xF) - m1, xl[1], a2);
+                a3 = fmaf(d2 * (float)((u >> 12) & 0xF) - m2, xh[1], a3);
+                a0 = fmaf(d1 * (float)((u >> 16) & 0xF) - m1, xl[2], a0);
+                a1 = fmaf(d2 * (float)((u >> 20) & 0xF) - m2, xh[2], a1);
+                a2 = fmaf(d1 * (float)((u >> 24) & 0xF) - m1, xl[3], a2);
+                a3 = fmaf(d2 * (float)(u >> 28) - m2, xh[3], a3);
+            }
+        }
+        return acc + ((a0 + a1) + (a2 + a3));
+    }
+};
+
+template <> struct PairDot<WT_Q6_K> {
+    // go/quant.go:239-276: out += d * sc_i * (q - 32) * x; four 16-column sub-blocks per pair, q - 32 stored as int8
+    static __device__ __forceinline__ float run(const uint4 *c, uint2 sc, const float *xp, float acc) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(xp);
+        const float d = h2f_bits(sc.x & 0xffff);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            Acc4 s{0.f, 0.f, 0.f, 0.f};
+            dot4_i8(c[i].x, x4[4 * i + 0], s);
+            dot4_i8(c[i].y, x4[4 * i + 1], s);
+            dot4_i8(c[i].z, x4[4 * i + 2], s);
+            dot4_i8(c[i].w, x4[4 * i + 3], s);
+            const float si = d * (float)(int)(int8_t)((sc.y >> (8 * i)) & 0xff);
+            acc = fmaf((s.a + s.b) + (s.c + s.d), si, acc);
+        }
+        return acc;
     }
 };
 
@@ -379,12 +498,15 @@ __device__ __forceinline__ float4 load_x4(const GemvParams &P, int col, float4 &
 
 template <int WT>
 __device__ __forceinline__ void load_pair(const uint8_t *q, const uint32_t *s, long long tile_pair0, int g, int gsz,
-                                          int r, int k, uint4 *c, uint32_t &sc) {
+                                          int r, int k, uint4 *c, uint2 &sc) {
     constexpr int CPP = WTraits<WT>::CPP;
     const uint4 *qp = reinterpret_cast<const uint4 *>(q) + tile_pair0 * (CPP * TR) + (long long)g * (KL * CPP * TR) + r * gsz + k;
 #pragma unroll
     for (int j = 0; j < CPP; j++) c[j] = qp[j * TR * gsz];
-    sc = WTraits<WT>::SCALED ? s[tile_pair0 * TR + g * (KL * TR) + r * gsz + k] : 0u;
+    const long long si = tile_pair0 * TR + g * (KL * TR) + r * gsz + k;
+    if (!WTraits<WT>::SCALED) sc = make_uint2(0u, 0u);
+    else if (scale_words(WT) == 2) sc = reinterpret_cast<const uint2 *>(s)[si];
+    else sc = make_uint2(s[si], 0u);
 }
 
 // One wavefront = one 16-row tile x a 1/kw share of the 256-column groups; a workgroup holds
@@ -454,7 +576,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     for (int g0 = kw; g0 < ngroups; g0 += NF * P.kw) {
         float4 xv[NF], gv[NF];
         uint4 cw[NF][CPP];
-        uint32_t sw[NF];
+        uint2 sw[NF];
         bool lv[NF];
 #pragma unroll
         for (int f = 0; f < NF; f++) {
@@ -462,7 +584,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
             const bool has = g < ngroups;
             const int gs = has ? min(KL, P.npairs - g * KL) : 0;
             lv[f] = live && k < gs;
-            sw[f] = 0;
+            sw[f] = make_uint2(0u, 0u);
             xv[f] = has ? load_x4<PRO>(P, g * (KL * PAIR) + lane * 4, gv[f], ns) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (lv[f]) load_pair<WT>(Wq, Ws, tp0, g, gs, r, k, cw[f], sw[f]);
         }
@@ -592,29 +714,56 @@ struct EmbedParams {
     float *x;
 };
 
-// embedLookupInto go/model.go:389-446 (row `token` of token_embd, dequantised)
+// element i of row `token` of a raw GGUF tensor, dequantised (embedLookupInto go/model.go:389-446 and the
+// block dequantisers go/quant.go:22-31,103-108,405-420,296-323,174-208)
+__device__ __forceinline__ float embed_value(const uint8_t *table, int wtype, int dim, int token, int i) {
+    if (wtype == WT_Q8_0) {
+        const uint8_t *blk = table + ((long long)token * (dim / 32) + i / 32) * 34;
+        float d = h2f_bits((uint32_t)blk[0] | ((uint32_t)blk[1] << 8));
+        return (float)(int)(int8_t)blk[2 + (i & 31)] * d;
+    }
+    if (wtype == WT_Q4_0) {
+        const uint8_t *blk = table + ((long long)token * (dim / 32) + i / 32) * 18;
+        float d = h2f_bits((uint32_t)blk[0] | ((uint32_t)blk[1] << 8));
+        int j = i & 31;
+        int nib = j < 16 ? (blk[2 + j] & 0x0F) : (blk[2 + j - 16] >> 4);
+        return (float)(nib - 8) * d;
+    }
+    if (wtype == WT_Q5_0) {
+        const uint8_t *blk = table + ((long long)token * (dim / 32) + i / 32) * 22;
+        float d = h2f_bits((uint32_t)blk[0] | ((uint32_t)blk[1] << 8));
+        const uint32_t qh = (uint32_t)blk[2] | ((uint32_t)blk[3] << 8) | ((uint32_t)blk[4] << 16) | ((uint32_t)blk[5] << 24);
+        int e = i & 31;
+        int nib = e < 16 ? (blk[6 + e] & 0x0F) : (blk[6 + e - 16] >> 4);
+        return (float)((nib | (int)(((qh >> e) & 1u) << 4)) - 16) * d;
+    }
+    if (wtype == WT_Q4_K) {
+        const uint8_t *blk = table + ((long long)token * (dim / 256) + i / 256) * 144;
+        const float d = h2f_bits((uint32_t)blk[0] | ((uint32_t)blk[1] << 8)), dmin = h2f_bits((uint32_t)blk[2] | ((uint32_t)blk[3] << 8));
+        const int e = i & 255, j = e >> 6, within = e & 63;
+        uint32_t sc, m;
+        scale_min_k4(2 * j + (within >> 5), blk + 4, sc, m);
+        const uint8_t qb = blk[16 + 32 * j + (within & 31)];
+        const float d1 = d * (float)sc, m1 = dmin * (float)m;
+        return d1 * (float)(within < 32 ? (qb & 0x0F) : (qb >> 4)) - m1;
+    }
+    if (wtype == WT_Q6_K) {
+        const uint8_t *blk = table + ((long long)token * (dim / 256) + i / 256) * 210;
+        const float d = h2f_bits((uint32_t)blk[208] | ((uint32_t)blk[209] << 8));
+        int sidx;
+        const int q = q6k_value(blk, i & 255, sidx);
+        return d * (float)(int)(int8_t)blk[192 + sidx] * (float)(q - 32);
+    }
+    if (wtype == WT_F16) {
+        const uint8_t *p = table + ((long long)token * dim + i) * 2;
+        return h2f_bits((uint32_t)p[0] | ((uint32_t)p[1] << 8));
+    }
+    return reinterpret_cast<const float *>(table)[(long long)token * dim + i];
+}
+
 __global__ void embed_kernel(EmbedParams P) {
     const int token = P.ctl[CTL_TOKEN];
-    for (int i = threadIdx.x; i < P.dim; i += blockDim.x) {
-        float v;
-        if (P.wtype == WT_Q8_0) {
-            const uint8_t *blk = P.table + ((long long)token * (P.dim / 32) + i / 32) * 34;
-            float d = h2f_bits((uint32_t)blk[0] | ((uint32_t)blk[1] << 8));
-            v = (float)(int)(int8_t)blk[2 + (i & 31)] * d;
-        } else if (P.wtype == WT_Q4_0) {
-            const uint8_t *blk = P.table + ((long long)token * (P.dim / 32) + i / 32) * 18;
-            float d = h2f_bits((uint32_t)blk[0] | ((uint32_t)blk[1] << 8));
-            int j = i & 31;
-            int nib = j < 16 ? (blk[2 + j] & 0x0F) : (blk[2 + j - 16] >> 4);
-            v = (float)(nib - 8) * d;
-        } else if (P.wtype == WT_F16) {
-            const uint8_t *p = P.table + ((long long)token * P.dim + i) * 2;
-            v = h2f_bits((uint32_t)p[0] | ((uint32_t)p[1] << 8));
-        } else {
-            v = reinterpret_cast<const float *>(P.table)[(long long)token * P.dim + i];
-        }
-        P.x[i] = v;
-    }
+    for (int i = threadIdx.x; i < P.dim; i += blockDim.x) P.x[i] = embed_value(P.table, P.wtype, P.dim, token, i);
 }
 
 // ------------------------------------------------------------- attention ---

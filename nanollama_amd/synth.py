@@ -25,7 +25,8 @@ from typing import Dict, Iterator, List, Optional, Tuple
 import numpy as np
 
 from . import quant
-from .gguf import GGML_F16, GGML_F32, GGML_Q4_0, GGML_Q8_0, GGUFWriter, ggml_block_elements, ggml_block_size
+from .gguf import (GGML_F16, GGML_F32, GGML_Q4_0, GGML_Q4_K, GGML_Q5_0, GGML_Q6_K, GGML_Q8_0, GGUFWriter,
+                   ggml_block_elements, ggml_block_size)
 
 
 @dataclass(frozen=True)
@@ -81,7 +82,11 @@ TIERS: Dict[str, ModelShape] = {
 
 TIER_SEED = {"nano": 1000, "mini": 1001, "goldie": 1002, "big": 1003}
 
-WTYPES = {"f32": GGML_F32, "f16": GGML_F16, "q8_0": GGML_Q8_0, "q4_0": GGML_Q4_0}
+WTYPES = {"f32": GGML_F32, "f16": GGML_F16, "q8_0": GGML_Q8_0, "q4_0": GGML_Q4_0,
+          # the remaining formats the Go engine reads (go/quant.go:171-484); no reference quantiser exists for them,
+          # so these are always drawn directly as random blocks (mode "qrand")
+          "q5_0": GGML_Q5_0, "q4_k": GGML_Q4_K, "q6_k": GGML_Q6_K}
+QRAND_ONLY = (GGML_Q5_0, GGML_Q4_K, GGML_Q6_K)
 
 
 def token_list(vocab: int) -> List[str]:
@@ -141,18 +146,32 @@ def _draw_qrand(shape: ModelShape, seed: int, ckpt_name: str, tshape, kind: str,
     magnitude the reference quantiser would produce for U(-amax, amax) weights."""
     rng = _tensor_rng(seed, ckpt_name)
     nel = int(np.prod(tshape))
-    nb = nel // 32
-    bsz = 34 if wtype == GGML_Q8_0 else 18
     amax = 4.0 if kind == "embedding" else (3.0 ** 0.5) * (shape.dim ** -0.5)
-    target = amax / (127.0 if wtype == GGML_Q8_0 else 8.0)
-    efield = max(1, min(30, int(np.floor(np.log2(target))) + 15))
+
+    def f16_bits(target: float, n: int) -> np.ndarray:
+        """n fp16 values 2^e * (1 + m/1024), random mantissa, e = floor(log2(target))."""
+        efield = max(1, min(30, int(np.floor(np.log2(target))) + 15))
+        return ((rng.integers(0, 1 << 16, size=n, dtype=np.int64).astype(np.uint16) & np.uint16(0x03FF))
+                | np.uint16(efield << 10))
+
+    if wtype in (GGML_Q4_K, GGML_Q6_K):
+        nsb = nel // 256
+        bsz = 144 if wtype == GGML_Q4_K else 210
+        raw = rng.integers(0, 1 << 63, size=(nsb * bsz + 7) // 8, dtype=np.int64).view(np.uint8)[:nsb * bsz]
+        blocks = raw.reshape(nsb, bsz)
+        if wtype == GGML_Q4_K:   # w = d*sc*q - dmin*m, sc,m in 0..63, q in 0..15
+            blocks[:, 0:2] = f16_bits(amax / 470.0, nsb).view(np.uint8).reshape(nsb, 2)
+            blocks[:, 2:4] = f16_bits(amax / 64.0, nsb).view(np.uint8).reshape(nsb, 2)
+        else:                    # w = d*sc*(q-32), sc int8, q in 0..63
+            blocks[:, 208:210] = f16_bits(amax / 4096.0, nsb).view(np.uint8).reshape(nsb, 2)
+        return raw
+    nb = nel // 32
+    bsz = {GGML_Q8_0: 34, GGML_Q4_0: 18, GGML_Q5_0: 22}[wtype]
+    target = amax / {GGML_Q8_0: 127.0, GGML_Q4_0: 8.0, GGML_Q5_0: 16.0}[wtype]
     nbytes = nb * bsz
     raw = rng.integers(0, 1 << 63, size=(nbytes + 7) // 8, dtype=np.int64).view(np.uint8)[:nbytes]
     blocks = raw.reshape(nb, bsz)
-    sc = blocks[:, 0:2].copy().view(np.uint16)
-    sc &= np.uint16(0x03FF)
-    sc |= np.uint16(efield << 10)
-    blocks[:, 0:2] = sc.view(np.uint8)
+    blocks[:, 0:2] = f16_bits(target, nb).view(np.uint8).reshape(nb, 2)
     return raw
 
 
@@ -197,7 +216,7 @@ def generate_gguf(path: str, shape: ModelShape, wtype: str = "q8_0", seed: Optio
             if keep_float:
                 floats[gname] = f32
             continue
-        if mode == "qrand" and t in (GGML_Q8_0, GGML_Q4_0):
+        if (mode == "qrand" and t in (GGML_Q8_0, GGML_Q4_0)) or t in QRAND_ONLY:
             w.add_tensor_raw(gname, _draw_qrand(shape, seed, ckpt, tshape, kind, t), t, tshape)
             continue
         f32 = draw_float(shape, seed, ckpt, tshape, kind)

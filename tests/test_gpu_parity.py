@@ -78,9 +78,10 @@ def test_gemv_edge_values(hip, orc):
 
 
 def test_gemv_rejects_unsupported_type(hip):
+    # Q4_1 (type 3) is parsed by go/gguf.go but has no MatMul in go/quant.go either
     from nanollama_amd._lib import NlError
     with pytest.raises(NlError):
-        hip.op_matmul(np.zeros(144, np.uint8), gguf.GGML_Q4_K, np.zeros(256, np.float32), 1, 256)
+        hip.op_matmul(np.zeros(20 * 8, np.uint8), gguf.GGML_Q4_1, np.zeros(256, np.float32), 1, 256)
 
 
 def test_rmsnorm_matches_oracle(hip, orc):
@@ -449,3 +450,57 @@ def test_mfma_multi_token_matmul_matches_oracle(hip, orc, wtype, rows, cols, nto
         scale = np.abs(want) + (np.abs(x[n]).max() * 0.05 * 127 * 1e-2 if n == 1 else 0.0)
         worst = max(worst, float((np.abs(got[n] - want) / (1 + scale)).max()))
     assert worst <= 2e-5, worst
+
+
+def _rand_blocks(rng, rows, cols, wtype):
+    """raw random blocks of the formats that have no reference quantiser (Q5_0, Q4_K, Q6_K)"""
+    shape = synth.ModelShape("x", 1, cols, 1, 1, 32)
+    return synth._draw_qrand(shape, int(rng.integers(1 << 30)), "t", (rows, cols), "matrix", synth.WTYPES[wtype])
+
+
+@pytest.mark.parametrize("wtype", ["q5_0", "q4_k", "q6_k"])
+@pytest.mark.parametrize("rows,cols", [(16, 256), (100, 512), (576, 768), (1536, 2048), (4096, 4096)])
+def test_gemv_remaining_formats_match_oracle(hip, orc, wtype, rows, cols):
+    rng = np.random.Generator(np.random.PCG64(rows * 17 + cols))
+    raw = _rand_blocks(rng, rows, cols, wtype)
+    x = rng.standard_normal(cols, dtype=np.float32)
+    t = synth.WTYPES[wtype]
+    want = orc.matmul(raw, t, x, rows, cols)
+    got = hip.op_matmul(raw, t, x, rows, cols)
+    err = np.abs(got - want) / (1 + np.abs(want))
+    assert err.max() <= 2e-5, (err.max(), int(err.argmax()))
+
+
+def test_q5_0_rows_not_multiple_of_64(hip, orc):
+    rng = np.random.Generator(np.random.PCG64(12))
+    raw = _rand_blocks(rng, 48, 96, "q5_0")
+    x = rng.standard_normal(96, dtype=np.float32)
+    want = orc.matmul(raw, gguf.GGML_Q5_0, x, 48, 96)
+    got = hip.op_matmul(raw, gguf.GGML_Q5_0, x, 48, 96)
+    assert np.all(np.abs(got - want) <= 2e-5 * (1 + np.abs(want)))
+
+
+@pytest.mark.parametrize("wtype", ["q5_0", "q4_k", "q6_k"])
+def test_forward_remaining_formats_match_oracle(hip, orc, tmp_path, wtype):
+    # whole Forward (embedding rows included) on the formats of go/quant.go:171-484
+    shape = synth.ModelShape("kq_probe", 2, 256, 4, 2, 1024, seq_len=64)
+    p = tmp_path / "kq.gguf"
+    synth.generate_gguf(str(p), shape, wtype, 5)
+    worst, scale = _run_teacher_forced(hip, orc, str(p), synth.prompt_ids(20, shape.vocab, seed=6))
+    print(f"\n{wtype}: max|gpu-oracle|={worst:.2e} (logit std {scale:.2f})")
+    assert worst <= LOGIT_TOL * scale
+    g = gguf.load_gguf(str(p))
+    dev = hip.load_llama_model(g)
+    ref = orc.OracleModel(g)
+    prompt = synth.prompt_ids(6, shape.vocab, seed=1)
+    dev.prefill(prompt)
+    nxt = int(np.argmax(dev.state.logits))
+    ref_ids, _ = ref.generate_greedy(prompt, 10)
+    assert [nxt] + dev.decode_greedy(nxt, len(prompt), 9) == ref_ids
+    dev.close()
+
+
+def test_kquant_shape_constraint_is_reported(hip):
+    from nanollama_amd._lib import NlError
+    with pytest.raises(NlError):
+        hip.op_matmul(np.zeros(144 // 2 * 16, np.uint8), gguf.GGML_Q4_K, np.zeros(128, np.float32), 16, 128)
