@@ -75,13 +75,18 @@ NL_API int nl_create(const nl_config *cfg, nl_handle *out);
  * copied during the call; the library re-packs them for the device and keeps
  * only this rank's tensor-parallel shard.  Unknown names -> NL_ERR_INVALID,
  * unsupported types -> NL_ERR_UNSUPPORTED (the Go engine would print a WARNING
- * and compute garbage, go/model.go:383-385; we refuse instead). */
+ * and compute garbage, go/model.go:383-385; we refuse instead).  Optional
+ * blk.N.attn_{q,k,v,output}.bias tensors (go/model.go:244-247) are accepted as F32/F16. */
 NL_API int nl_upload_tensor(nl_handle h, const char *gguf_name, uint32_t ggml_type, const void *data,
                             uint64_t nbytes, uint64_t rows, uint64_t cols);
 /* allocState + precomputeRoPE (go/model.go:324-358), tied-embedding fallback
  * (:195-201), graph capture.  NL_ERR_MISSING if a required tensor is absent. */
 NL_API int nl_finalize(nl_handle h);
 NL_API int nl_destroy(nl_handle h);
+/* Gamma essence (go/gamma.go:22-35, ApplyToEmbedding :272-290; go/main.go:70-83): embed[token] += gamma[token]
+ * for the n listed token ids.  values: [n][dim] float32, or raw IEEE binary16 when is_f16.  May be called before or
+ * after nl_finalize; n == 0 removes it. */
+NL_API int nl_set_gamma(nl_handle h, const int32_t *indices, int n, const void *values, int is_f16);
 NL_API const char *nl_last_error(nl_handle h); /* h may be NULL: last create error */
 
 /* == Reset (go/model.go:623-631) ========================================== */

@@ -47,7 +47,7 @@ def build(force: bool = False) -> str:
 
 _lib = None
 
-EXPORTS = ["nl_abi_version", "nl_device_count", "nl_create", "nl_upload_tensor", "nl_finalize", "nl_destroy",
+EXPORTS = ["nl_set_gamma", "nl_abi_version", "nl_device_count", "nl_create", "nl_upload_tensor", "nl_finalize", "nl_destroy",
            "nl_last_error", "nl_reset", "nl_forward", "nl_forward_argmax", "nl_decode_greedy", "nl_prefill", "nl_forward_batch", "nl_get_config",
            "nl_synchronize", "nl_timer_start", "nl_timer_stop", "nl_kernel_kind_name", "nl_profile_forward",
            "nl_memory_usage", "nl_debug_read", "nl_op_matmul", "nl_op_matmul_batch", "nl_op_rmsnorm", "nl_comm_get_unique_id",
@@ -69,6 +69,7 @@ def lib():
     L.nl_upload_tensor.argtypes = [vp, C.c_char_p, C.c_uint32, vp, C.c_uint64, C.c_uint64, C.c_uint64]
     L.nl_finalize.argtypes = [vp]
     L.nl_destroy.argtypes = [vp]
+    L.nl_set_gamma.argtypes = [vp, C.POINTER(C.c_int32), i32, vp, i32]
     L.nl_last_error.restype = C.c_char_p
     L.nl_last_error.argtypes = [vp]
     L.nl_reset.argtypes = [vp, i32]

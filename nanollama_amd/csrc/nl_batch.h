@@ -11,12 +11,19 @@ struct BEmbedParams {
     int wtype, dim;
     const int *tokens;
     float *x;  // [N][dim]
+    const int *gamma_row;
+    const float *gamma_val;
 };
 
 __global__ void bembed_kernel(BEmbedParams P) {
     const int token = P.tokens[blockIdx.x];
     float *x = P.x + (long long)blockIdx.x * P.dim;
-    for (int i = threadIdx.x; i < P.dim; i += blockDim.x) x[i] = embed_value(P.table, P.wtype, P.dim, token, i);
+    const int gr = P.gamma_row ? P.gamma_row[token] : -1;
+    for (int i = threadIdx.x; i < P.dim; i += blockDim.x) {
+        float v = embed_value(P.table, P.wtype, P.dim, token, i);
+        if (gr >= 0) v += P.gamma_val[(long long)gr * P.dim + i];
+        x[i] = v;
+    }
 }
 
 // RMSNormInto go/quant.go:597-607, one workgroup per token
@@ -44,6 +51,7 @@ struct BRopeParams {
     float *q;               // [N][n_q_heads*hd] natural order
     float *kcache, *vcache; // this layer, stream 0
     long long kv_stream_stride;
+    const float *bias_q, *bias_k, *bias_v;  // optional, natural (head, element) order
 };
 
 // RoPE (go/model.go:449-477) + optional QK-norm (:542-549) + KV store (:552-554) for one token per workgroup
@@ -57,8 +65,16 @@ __global__ void brope_kv_kernel(BRopeParams P) {
         const int head = tile / tph, j = tile % tph;
         const int i = j * 8 + (r & 7), e = i + (r >> 3) * half;
         float v = src[rho], outv = v;
+        float partner = src[rho ^ 8];
+        if (P.bias_q) {
+            const int ep = i + ((r ^ 8) >> 3) * half;   // the partner's element index
+            if (head < P.n_q_heads) { v += P.bias_q[head * hd + e]; partner += P.bias_q[head * hd + ep]; }
+            else if (head < P.n_q_heads + P.n_kv_heads) {
+                v += P.bias_k[(head - P.n_q_heads) * hd + e]; partner += P.bias_k[(head - P.n_q_heads) * hd + ep];
+            } else v += P.bias_v[(head - P.n_q_heads - P.n_kv_heads) * hd + e];
+            outv = v;
+        }
         if (head < P.n_q_heads + P.n_kv_heads) {
-            float partner = src[rho ^ 8];
             float c = P.rope_cos[pos * half + i], s = P.rope_sin[pos * half + i];
             float x0 = (r < 8) ? v : partner, x1 = (r < 8) ? partner : v;
             if (!P.rope_conj) outv = (r < 8) ? (x0 * c - x1 * s) : (x0 * s + x1 * c);

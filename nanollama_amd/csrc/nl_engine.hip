@@ -126,6 +126,7 @@ struct nl_engine {
     struct Layer {
         PackedMat qkv, wo, gate, up, down;
         float *attn_norm = nullptr, *ffn_norm = nullptr;
+        float *bq = nullptr, *bk = nullptr, *bv = nullptr, *bo = nullptr;  // optional biases (this rank's slice)
         bool have_q = false, have_k = false, have_v = false;
     };
     std::vector<Layer> layers;
@@ -136,6 +137,8 @@ struct nl_engine {
     bool have_output = false;
     float *output_norm = nullptr;
 
+    int *gamma_row = nullptr;      // [vocab] -> row of gamma_val or -1 (go/gamma.go IndexMap)
+    float *gamma_val = nullptr;    // [n][dim]
     float *rope_cos = nullptr, *rope_sin = nullptr;
     float *x[2] = {nullptr, nullptr};
     float *qbuf = nullptr, *part_o = nullptr, *part_ml = nullptr, *hb = nullptr, *ar = nullptr, *logits = nullptr;
@@ -376,7 +379,7 @@ void build_plan(nl_engine *e) {
     const float *pending = nullptr;  // all-reduced partial still to be added to the residual stream
 
     {
-        EmbedParams P{e->embd_raw, e->embd_type, c.dim, e->ctl, e->x[0]};
+        EmbedParams P{e->embd_raw, e->embd_type, c.dim, e->ctl, e->x[0], e->gamma_row, e->gamma_val};
         e->plan.push_back({K_EMBED, 0, nullptr, 0, [P](hipStream_t st) {
                                hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, P);
                                return hipGetLastError();
@@ -393,6 +396,7 @@ void build_plan(nl_engine *e) {
             P.rope_cos = e->rope_cos; P.rope_sin = e->rope_sin;
             P.qbuf = e->qbuf; P.kcache = kc; P.vcache = vc; P.kv_stream_stride = e->kv_stream_stride;
             P.n_q_heads = e->Hs; P.n_kv_heads = e->KVs; P.seq_len = c.seq_len; P.rope_conj = c.rope_conjugate;
+            P.bias_q = L.bq; P.bias_k = L.bk; P.bias_v = L.bv;
             int wt = L.qkv.wtype;
             push_gemv(e, K_QKV, 0, nullptr, 0, wt, PRO_NORM, EPI_QKV, P);
             if (pending) { cur ^= 1; pending = nullptr; }
@@ -417,6 +421,7 @@ void build_plan(nl_engine *e) {
         {   // WO + residual (go/model.go:590-594); the prologue merges the attention splits
             GemvParams P = base_params(e, L.wo);
             P.part_o = e->part_o; P.part_ml = e->part_ml;
+            P.bias_out = L.bo;
             int wt = L.wo.wtype;
             if (!tp) {
                 P.out = e->x[cur]; P.resid = e->x[cur];
@@ -561,7 +566,7 @@ hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_bu
     if (s != hipSuccess || ks == 1) return s;
     const long long count = (long long)P.n_tokens * P.ldo;
     hipLaunchKernelGGL(qgemm_sum_kernel, dim3((unsigned)std::min<long long>((count + 255) / 256, 2048)), dim3(256), 0, st,
-                       part_buf, ks, count, P.resid, P.out);
+                       part_buf, ks, count, P.resid, P.out, P.bias, P.ldo);
     return hipGetLastError();
 }
 }  // namespace
@@ -606,8 +611,9 @@ int batch_alloc(nl_engine *e) {
 }
 
 hipError_t qg(nl_engine *e, const PackedMat &m, const float *x, int ldx, int n, float *out, int ldo, const float *resid,
-              hipStream_t st) {
+              hipStream_t st, const float *bias = nullptr) {
     QGemmParams P{};
+    P.bias = bias;
     P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
     P.x = x; P.ldx = ldx; P.n_tokens = n; P.out = out; P.ldo = ldo; P.resid = resid;
     return launch_qgemm(m.wtype, P, st, e->bt.kpart, e->bt.kpart_cap);
@@ -626,7 +632,7 @@ int batched_step(nl_engine *e, int n, int lm_mode) {
     LCK(hipMemcpyAsync(b.pos, b.h_meta + b.cap, (size_t)n * 4, hipMemcpyHostToDevice, st));
     LCK(hipMemcpyAsync(b.stream, b.h_meta + 2 * b.cap, (size_t)n * 4, hipMemcpyHostToDevice, st));
     {
-        BEmbedParams P{e->embd_raw, e->embd_type, D, b.tok, b.x};
+        BEmbedParams P{e->embd_raw, e->embd_type, D, b.tok, b.x, e->gamma_row, e->gamma_val};
         hipLaunchKernelGGL(bembed_kernel, dim3(n), dim3(256), 0, st, P);
         LCK(hipGetLastError());
     }
@@ -639,7 +645,7 @@ int batched_step(nl_engine *e, int n, int lm_mode) {
         LCK(qg(e, L.qkv, b.xn, D, n, b.qkv, R, nullptr, st));
         {
             BRopeParams P{b.qkv, R, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate, c.qk_norm, c.rms_eps, b.pos, b.stream,
-                          e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride};
+                          e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride, L.bq, L.bk, L.bv};
             hipLaunchKernelGGL(brope_kv_kernel, dim3(n), dim3(256), (size_t)R * 4, st, P);
             LCK(hipGetLastError());
         }
@@ -652,7 +658,7 @@ int batched_step(nl_engine *e, int n, int lm_mode) {
             hipLaunchKernelGGL(battn_merge_kernel, dim3(n), dim3(256), 0, st, M);
             LCK(hipGetLastError());
         }
-        LCK(qg(e, L.wo, b.att, HQ, n, b.x, D, b.x, st));
+        LCK(qg(e, L.wo, b.att, HQ, n, b.x, D, b.x, st, L.bo));
         hipLaunchKernelGGL(brmsnorm_kernel, dim3(n), dim3(256), 0, st, b.x, L.ffn_norm, c.rms_eps, b.xn, D);
         LCK(hipGetLastError());
         LCK(qg(e, L.gate, b.xn, D, n, b.g, e->Is, nullptr, st));
@@ -868,8 +874,25 @@ int nl_upload_tensor(nl_handle e, const char *name, uint32_t type, const void *d
         if (!rc) L.down.ready = true;
         return rc;
     }
-    if (f.size() > 5 && f.compare(f.size() - 5, 5, ".bias") == 0)
-        return e->fail(NL_ERR_UNSUPPORTED, "tensor %s: attention biases are not implemented on device", name);
+    if (f == "attn_q.bias" || f == "attn_k.bias" || f == "attn_v.bias" || f == "attn_output.bias") {
+        // getF32TensorOptional go/model.go:244-247; only this rank's heads are kept, the output bias lives on rank 0
+        const bool isq = f == "attn_q.bias", iso = f == "attn_output.bias";
+        const int full = isq ? c.n_heads * hd : iso ? D : c.n_kv_heads * hd;
+        const int loc = isq ? e->Hs * hd : iso ? D : e->KVs * hd;
+        const int off = iso ? 0 : e->rank * loc;
+        if ((int)(rows * cols) != full) return e->fail(NL_ERR_INVALID, "tensor %s: expected %d elements", name, full);
+        std::vector<float> tmp(full);
+        if (type == WT_F32) memcpy(tmp.data(), data, (size_t)full * 4);
+        else if (type == WT_F16) {
+            const uint16_t *hp = (const uint16_t *)data;
+            for (int i = 0; i < full; i++) tmp[i] = __half2float(__ushort_as_half(hp[i]));
+        } else return e->fail(NL_ERR_UNSUPPORTED, "tensor %s: biases must be F32 or F16", name);
+        if (iso && e->rank != 0) std::fill(tmp.begin(), tmp.end(), 0.f);
+        float **dst = isq ? &L.bq : f == "attn_k.bias" ? &L.bk : f == "attn_v.bias" ? &L.bv : &L.bo;
+        if (!*dst) HIPCK(e, dalloc(dst, (size_t)loc, &e->bytes_weights));
+        HIPCK(e, hipMemcpy(*dst, tmp.data() + off, (size_t)loc * 4, hipMemcpyHostToDevice));
+        return NL_OK;
+    }
     return e->fail(NL_ERR_INVALID, "unknown tensor %s", name);
 }
 
@@ -886,6 +909,8 @@ int nl_finalize(nl_handle e) {
                          : !L.have_v ? "attn_v" : !L.wo.ready ? "attn_output" : !L.gate.ready ? "ffn_gate"
                          : !L.up.ready ? "ffn_up" : !L.down.ready ? "ffn_down" : nullptr;
         if (miss) return e->fail(NL_ERR_MISSING, "layer %d %s: tensor not found", l, miss);
+        if ((L.bq || L.bk || L.bv) && !(L.bq && L.bk && L.bv))
+            return e->fail(NL_ERR_MISSING, "layer %d: attn_q/k/v.bias must come together", l);
         if (L.gate.src_type != L.up.src_type) return e->fail(NL_ERR_UNSUPPORTED, "layer %d: ffn_gate and ffn_up types differ", l);
     }
     if (!e->have_output) {
@@ -962,6 +987,44 @@ int nl_finalize(nl_handle e) {
     return NL_OK;
 }
 
+// Gamma essence (go/gamma.go): embed[token] += gamma[token] for the listed tokens (go/model.go:503-505).
+// indices: n token ids; values: [n][dim] float32, or raw IEEE binary16 when is_f16.  n == 0 clears it.
+int nl_set_gamma(nl_handle e, const int32_t *indices, int n, const void *values, int is_f16) {
+    if (!e || n < 0 || (n > 0 && (!indices || !values))) return NL_ERR_INVALID;
+    const nl_config &c = e->cfg;
+    HIPCK(e, hipSetDevice(e->dev));
+    HIPCK(e, hipStreamSynchronize(e->stream));
+    if (e->gamma_row) { hipFree(e->gamma_row); e->gamma_row = nullptr; }
+    if (e->gamma_val) { hipFree(e->gamma_val); e->gamma_val = nullptr; }
+    if (n > 0) {
+        std::vector<int> rowmap(c.vocab, -1);
+        for (int i = 0; i < n; i++) {
+            if (indices[i] < 0 || indices[i] >= c.vocab) return e->fail(NL_ERR_INVALID, "gamma index %d out of range", indices[i]);
+            rowmap[indices[i]] = i;  // later entries win, like the Go map build
+        }
+        std::vector<float> vals((size_t)n * c.dim);
+        if (is_f16) {
+            const uint16_t *hp = (const uint16_t *)values;
+            for (size_t i = 0; i < vals.size(); i++) vals[i] = __half2float(__ushort_as_half(hp[i]));
+        } else memcpy(vals.data(), values, vals.size() * 4);
+        HIPCK(e, dalloc(&e->gamma_row, (size_t)c.vocab, &e->bytes_weights));
+        HIPCK(e, dalloc(&e->gamma_val, vals.size(), &e->bytes_weights));
+        HIPCK(e, hipMemcpy(e->gamma_row, rowmap.data(), (size_t)c.vocab * 4, hipMemcpyHostToDevice));
+        HIPCK(e, hipMemcpy(e->gamma_val, vals.data(), vals.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (e->finalized) {  // the launch closures hold the old pointers: rebuild plan and graph
+        if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+        if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
+        build_plan(e);
+        if (e->use_graph && !(c.flags & NL_FLAG_LOCAL_GROUP)) {
+            int rc = capture_graph(e);
+            if (rc && (e->G > 1 || e->force_tp_plan)) { hipGetLastError(); e->graph = nullptr; e->graph_exec = nullptr; }
+            else if (rc) return rc;
+        }
+    }
+    return NL_OK;
+}
+
 int nl_destroy(nl_handle e) {
     if (!e) return NL_OK;
     hipSetDevice(e->dev);
@@ -971,7 +1034,11 @@ int nl_destroy(nl_handle e) {
     for (auto &L : e->layers) {
         if (L.attn_norm) hipFree(L.attn_norm);
         if (L.ffn_norm) hipFree(L.ffn_norm);
+        float *bs[] = {L.bq, L.bk, L.bv, L.bo};
+        for (float *b : bs) if (b) hipFree(b);
     }
+    if (e->gamma_row) hipFree(e->gamma_row);
+    if (e->gamma_val) hipFree(e->gamma_val);
     for (void *c : e->arena_chunks) hipFree(c);
     if (e->stage) hipFree(e->stage);
     {

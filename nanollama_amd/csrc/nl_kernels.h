@@ -419,6 +419,9 @@ struct GemvParams {
     // EPI_STORE: optional fused partial argmax (one slot per workgroup, or per wave when tw*16 > 64)
     float *amax_val;
     int *amax_idx;
+    // optional attention biases (go/model.go:244-247,525-527,591): EPI_QKV adds bias_q/k/v[head*hd+e] before RoPE,
+    // EPI_RESID / EPI_STORE add bias_out[row]
+    const float *bias_q, *bias_k, *bias_v, *bias_out;
     long long *dbg;  // optional phase timestamps (clock64) written by workgroup 0, lane 0 of each wave
 };
 
@@ -648,6 +651,11 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
         const int i = j * 8 + (rr & 7);
         const int e = i + (rr >> 3) * half;
         const int pos = e_pos;
+        if (P.bias_q) {  // addBias before RoPE, go/model.go:525-527
+            if (head < P.n_q_heads) v += P.bias_q[head * hd + e];
+            else if (head < P.n_q_heads + P.n_kv_heads) v += P.bias_k[(head - P.n_q_heads) * hd + e];
+            else v += P.bias_v[(head - P.n_q_heads - P.n_kv_heads) * hd + e];
+        }
         float partner = __shfl_xor(v, 8);
         float outv = v;
         if (head < P.n_q_heads + P.n_kv_heads) {
@@ -671,6 +679,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
         return;
     }
     const int row = otile * TR + rr;
+    if (P.bias_out && act && row < P.rows && (EPI == EPI_STORE || EPI == EPI_RESID)) v += P.bias_out[row];
     if (EPI == EPI_STORE) {
         const bool ok = act && row < P.rows;
         if (ok) P.out[row] = v;
@@ -712,6 +721,9 @@ struct EmbedParams {
     int wtype, dim;
     const int *ctl;
     float *x;
+    // gamma injection (go/gamma.go:272-290, go/model.go:503-505): embed[token] += gamma[token] for listed tokens
+    const int *gamma_row;     // [vocab] row in gamma_val or -1; nullptr = no gamma
+    const float *gamma_val;   // [n][dim]
 };
 
 // element i of row `token` of a raw GGUF tensor, dequantised (embedLookupInto go/model.go:389-446 and the
@@ -763,7 +775,12 @@ __device__ __forceinline__ float embed_value(const uint8_t *table, int wtype, in
 
 __global__ void embed_kernel(EmbedParams P) {
     const int token = P.ctl[CTL_TOKEN];
-    for (int i = threadIdx.x; i < P.dim; i += blockDim.x) P.x[i] = embed_value(P.table, P.wtype, P.dim, token, i);
+    const int gr = P.gamma_row ? P.gamma_row[token] : -1;
+    for (int i = threadIdx.x; i < P.dim; i += blockDim.x) {
+        float v = embed_value(P.table, P.wtype, P.dim, token, i);
+        if (gr >= 0) v += P.gamma_val[(long long)gr * P.dim + i];
+        P.x[i] = v;
+    }
 }
 
 // ------------------------------------------------------------- attention ---

@@ -30,6 +30,7 @@ struct QGemmParams {
     float *out;          // [N][ldo]
     int ldo;
     const float *resid;  // optional [N][ldo]: out = resid + y
+    const float *bias;   // optional [rows]: y += bias[row] (attention output bias)
     // split-K: blockIdx.z handles chunks z, z+ksplit, ...; with ksplit > 1 the kernel writes partial sums to
     // part[z][N][ldo] and qgemm_sum_kernel adds them in a fixed order (deterministic, no atomics)
     int ksplit;
@@ -201,6 +202,7 @@ __global__ void __launch_bounds__(QG_WAVES * 64) qgemm_kernel(QGemmParams P) {
                     if (P.ksplit > 1) {
                         P.part[((long long)blockIdx.z * P.n_tokens + n) * P.ldo + row] = v;
                     } else {
+                        if (P.bias) v += P.bias[row];
                         if (P.resid) v += P.resid[(long long)n * P.ldo + row];
                         P.out[(long long)n * P.ldo + row] = v;
                     }
@@ -210,10 +212,12 @@ __global__ void __launch_bounds__(QG_WAVES * 64) qgemm_kernel(QGemmParams P) {
 }
 
 // out[n][row] = (resid) + sum_z part[z][n][row], z in ascending order
-__global__ void qgemm_sum_kernel(const float *part, int ksplit, long long count, const float *resid, float *out) {
+__global__ void qgemm_sum_kernel(const float *part, int ksplit, long long count, const float *resid, float *out,
+                                 const float *bias, int ldo) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
         float v = part[i];
         for (int z = 1; z < ksplit; z++) v += part[(long long)z * count + i];
+        if (bias) v += bias[i % ldo];
         if (resid) v += resid[i];
         out[i] = v;
     }

@@ -89,6 +89,18 @@ class LlamaModel:
             lg.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None, ids))
         return [int(ids[i]) for i in range(n)], lg
 
+    def set_gamma(self, indices, values) -> None:
+        """model.Gamma = gamma (go/main.go:79): indices int32 [n], values [n, dim] float32 or float16."""
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        vals = np.ascontiguousarray(values)
+        if vals.dtype not in (np.float32, np.float16):
+            vals = vals.astype(np.float32)
+        if idx.size and (vals.ndim != 2 or vals.shape != (idx.size, self.config.embed_dim)):
+            raise ValueError(f"gamma embed_dim {vals.shape} != model dim {self.config.embed_dim}")  # go/main.go:75-77
+        _lib.check(self._h, _lib.lib().nl_set_gamma(self._h, idx.ctypes.data_as(C.POINTER(C.c_int32)), int(idx.size),
+                                                    vals.ctypes.data, int(vals.dtype == np.float16)))
+        self.gamma = (idx, vals) if idx.size else None
+
     # --- Reset go/model.go:623 ---
     def reset(self, stream: int = 0) -> None:
         _lib.check(self._h, _lib.lib().nl_reset(self._h, stream))

@@ -44,6 +44,7 @@ class ModelShape:
     rope_conjugate: bool = False
     tied: bool = False
     interm: int = 0  # 0 -> SwiGLU rule
+    attn_bias: bool = False  # Qwen-style attention biases (go/model.go:244-247); nanollama models have none
 
     @property
     def head_dim(self) -> int:
@@ -112,6 +113,11 @@ def tensor_plan(shape: ModelShape) -> List[Tuple[str, str, Tuple[int, ...], str]
         plan[p + "attn.c_v.weight"] = (g + "attn_v.weight", (kv, d), "matrix")
         plan[p + "attn.c_proj.weight"] = (g + "attn_output.weight", (d, d), "matrix")
         plan[p + "attn_norm.weight"] = (g + "attn_norm.weight", (d,), "norm")
+        if shape.attn_bias:
+            plan[p + "attn.c_q.bias"] = (g + "attn_q.bias", (shape.n_head * shape.head_dim,), "bias")
+            plan[p + "attn.c_k.bias"] = (g + "attn_k.bias", (kv,), "bias")
+            plan[p + "attn.c_v.bias"] = (g + "attn_v.bias", (kv,), "bias")
+            plan[p + "attn.c_proj.bias"] = (g + "attn_output.bias", (d,), "bias")
         plan[p + "ffn.gate_proj.weight"] = (g + "ffn_gate.weight", (i, d), "matrix")
         plan[p + "ffn.up_proj.weight"] = (g + "ffn_up.weight", (i, d), "matrix")
         plan[p + "ffn.down_proj.weight"] = (g + "ffn_down.weight", (d, i), "matrix")
@@ -134,6 +140,8 @@ def draw_float(shape: ModelShape, seed: int, ckpt_name: str, tshape, kind: str) 
     rng = _tensor_rng(seed, ckpt_name)
     if kind == "norm":
         return rng.uniform(0.5, 1.5, size=tshape).astype(np.float32)
+    if kind == "bias":
+        return rng.uniform(-0.5, 0.5, size=tshape).astype(np.float32)
     if kind == "embedding":
         return rng.standard_normal(size=tshape, dtype=np.float32)
     s = np.float32((3.0 ** 0.5) * (shape.dim ** -0.5))
@@ -210,7 +218,7 @@ def generate_gguf(path: str, shape: ModelShape, wtype: str = "q8_0", seed: Optio
 
     floats: Dict[str, np.ndarray] = {}
     for ckpt, gname, tshape, kind in tensor_plan(shape):
-        if kind == "norm":
+        if kind in ("norm", "bias"):
             f32 = draw_float(shape, seed, ckpt, tshape, kind)
             w.add_tensor_raw(gname, quant.to_f32_bytes(f32), GGML_F32, tshape)
             if keep_float:

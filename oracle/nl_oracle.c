@@ -464,6 +464,8 @@ typedef struct nlo_model {
     /* LlamaState go/model.go:93-118 */
     float *x, *xb, *xb2, *hb, *hb2, *q, *k, *v, *att, *logits;
     float *key_cache, *value_cache, *cos_cache, *sin_cache, *emb_buf;
+    /* GammaEssence go/gamma.go:22-35 (values already float32) */
+    int32_t *gamma_idx; float *gamma_val; int gamma_n;
     int finalized;
     char err[256];
 } nlo_model;
@@ -568,6 +570,7 @@ NLO_API void nlo_destroy(nlo_model *m) {
     free(m->x); free(m->xb); free(m->xb2); free(m->hb); free(m->hb2); free(m->q); free(m->k); free(m->v);
     free(m->att); free(m->logits); free(m->key_cache); free(m->value_cache);
     free(m->cos_cache); free(m->sin_cache); free(m->emb_buf);
+    free(m->gamma_idx); free(m->gamma_val);
     free(m);
 }
 
@@ -608,6 +611,12 @@ NLO_API void nlo_forward(nlo_model *m, int token, int pos) {
     int group = c->n_heads / c->n_kv_heads;
 
     nlo_embed_lookup(m->emb_buf, m->token_embd.w, m->token_embd.type, token, dim);
+    /* ApplyToEmbedding go/gamma.go:272-290 (go/model.go:503-505); the Go map keeps the LAST duplicate index */
+    for (int gi = m->gamma_n - 1; gi >= 0; gi--)
+        if (m->gamma_idx[gi] == token) {
+            for (int i = 0; i < dim; i++) m->emb_buf[i] = m->emb_buf[i] + m->gamma_val[(size_t)gi * dim + i];
+            break;
+        }
     memcpy(m->x, m->emb_buf, (size_t)dim * 4);
 
     float attn_scale = (float)(1.0 / sqrt((double)hd));
@@ -677,6 +686,16 @@ NLO_API void nlo_reset(nlo_model *m) {
     size_t kvn = (size_t)c->n_layers * c->seq_len * c->n_kv_heads * c->head_dim;
     memset(m->key_cache, 0, kvn * 4);
     memset(m->value_cache, 0, kvn * 4);
+}
+
+NLO_API void nlo_set_gamma(nlo_model *m, const int32_t *idx, int n, const float *values) {
+    free(m->gamma_idx); free(m->gamma_val);
+    m->gamma_idx = NULL; m->gamma_val = NULL; m->gamma_n = n;
+    if (n <= 0) { m->gamma_n = 0; return; }
+    m->gamma_idx = (int32_t *)malloc((size_t)n * 4);
+    m->gamma_val = (float *)malloc((size_t)n * m->cfg.dim * 4);
+    memcpy(m->gamma_idx, idx, (size_t)n * 4);
+    memcpy(m->gamma_val, values, (size_t)n * m->cfg.dim * 4);
 }
 
 NLO_API float *nlo_logits(nlo_model *m) { return m->logits; }

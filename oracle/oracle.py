@@ -67,6 +67,7 @@ def lib():
         L.nlo_state_buffer.argtypes = [vp, C.c_char_p]
         L.nlo_generate_greedy.argtypes = [vp, C.POINTER(i32), i32, i32, i32, C.POINTER(i32), fp]
         L.nlo_set_threads.argtypes = [i32]
+        L.nlo_set_gamma.argtypes = [vp, C.POINTER(i32), i32, fp]
         _lib = L
     return _lib
 
@@ -171,6 +172,11 @@ class OracleModel:
     def state(self, which: str, n: int) -> np.ndarray:
         p = lib().nlo_state_buffer(self.h, which.encode())
         return np.ctypeslib.as_array(p, shape=(n,))
+
+    def set_gamma(self, indices, values):
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        vals = np.ascontiguousarray(values, dtype=np.float32)   # f16 -> f32 is exact, as half2float is
+        lib().nlo_set_gamma(self.h, idx.ctypes.data_as(C.POINTER(C.c_int32)), int(idx.size), _fp(vals))
 
     def reset(self):
         lib().nlo_reset(self.h)

@@ -504,3 +504,68 @@ def test_kquant_shape_constraint_is_reported(hip):
     from nanollama_amd._lib import NlError
     with pytest.raises(NlError):
         hip.op_matmul(np.zeros(144 // 2 * 16, np.uint8), gguf.GGML_Q4_K, np.zeros(128, np.float32), 16, 128)
+
+
+@pytest.mark.parametrize("wtype", ["q8_0", "q4_0"])
+def test_attention_biases_match_oracle(hip, orc, tmp_path, wtype):
+    # Qwen-style attn_q/k/v/output biases (go/model.go:244-247,525-527,591): decode path, prefill path, tp
+    shape = synth.ModelShape("bias_probe", 2, 128, 4, 2, 512, seq_len=64, interm=512, attn_bias=True)
+    p = tmp_path / "b.gguf"
+    synth.generate_gguf(str(p), shape, wtype, 41)
+    g = gguf.load_gguf(str(p))
+    assert "blk.0.attn_q.bias" in g.tensors and "blk.1.attn_output.bias" in g.tensors
+    dev = hip.load_llama_model(g)
+    ref = orc.OracleModel(g)
+    toks = synth.prompt_ids(14, shape.vocab, seed=9)
+    worst = 0.0
+    for pos, t in enumerate(toks):
+        dev.forward(t, pos)
+        want = ref.forward(t, pos).copy()
+        worst = max(worst, float(np.abs(dev.state.logits - want).max()))
+    assert worst <= LOGIT_TOL
+    pre = hip.load_llama_model(g)
+    pre.prefill(toks)
+    assert np.abs(pre.state.logits - want).max() <= LOGIT_TOL
+    grp = hip.LocalTPGroup(g, 2)
+    for pos, t in enumerate(toks):
+        lg = grp.forward(t, pos)
+    assert np.abs(lg - want).max() <= LOGIT_TOL
+    dev.close(); pre.close(); grp.close()
+
+
+def test_gamma_injection_matches_oracle(hip, orc, tmp_path):
+    # go/gamma.go: embed[token] += gamma[token] for the listed tokens only; f32 and f16 value files
+    from nanollama_amd import gamma as gm
+    g = gguf.load_gguf(os.path.join(GOLDEN, "tiny_q8_0.gguf"))
+    rng = np.random.Generator(np.random.PCG64(77))
+    idx = np.array([1, 17, 45, 301, 300], dtype=np.int32)
+    for dtype in (np.float32, np.float16):
+        vals = (rng.standard_normal((len(idx), 128)) * 0.3).astype(dtype)
+        path = tmp_path / f"gamma_{np.dtype(dtype).name}.npz"
+        np.savez(path, indices=idx, values=vals, vocab_size=np.array(512), embed_dim=np.array(128))
+        ge = gm.load_gamma(str(path))
+        assert ge.num_tokens == 5 and ge.embed_dim == 128 and ge.is_f16 == (dtype == np.float16)
+        dev = hip.load_llama_model(g)
+        plain = hip.load_llama_model(g)
+        ref = orc.OracleModel(g)
+        dev.set_gamma(ge.indices, ge.values)          # after finalize: plan + graph are rebuilt
+        ref.set_gamma(ge.indices, ge.values)
+        toks = [1, 17, 9, 301, 5, 45]
+        diff_seen = False
+        for pos, t in enumerate(toks):
+            dev.forward(t, pos)
+            plain.forward(t, pos)
+            want = ref.forward(t, pos)
+            assert np.abs(dev.state.logits - want).max() <= LOGIT_TOL
+            diff_seen |= bool(np.abs(dev.state.logits - plain.state.logits).max() > 1e-3)
+        assert diff_seen                               # gamma really changes the output
+        pre = hip.load_llama_model(g)
+        pre.set_gamma(ge.indices, ge.values)
+        pre.prefill(toks)                              # multi-token path applies it too
+        assert np.abs(pre.state.logits - want).max() <= LOGIT_TOL
+        dev.set_gamma([], np.zeros((0, 128), np.float32))   # removing it restores the plain model
+        dev.forward(17, 0); plain.forward(17, 0)
+        assert dev.state.logits.tobytes() == plain.state.logits.tobytes()
+        with pytest.raises(ValueError):
+            dev.set_gamma([1], np.zeros((1, 64), np.float32))   # embed_dim mismatch, go/main.go:75-77
+        dev.close(); plain.close(); pre.close()
