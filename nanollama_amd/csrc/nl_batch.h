@@ -182,3 +182,204 @@ __global__ void __launch_bounds__(1024) bargmax_kernel(const float *logits, int 
 }
 
 }  // namespace nl
+
+namespace nl {
+
+// Prefill attention: the tokens of a multi-token step that belong to ONE stream at consecutive positions.
+// One workgroup per (kv head, 128-position split, tile of QT query tokens).  The QT x G (token, query head)
+// pairs of the tile are the rows of two fp32 GEMMs on the matrix cores (v_mfma_f32_16x16x4_f32, full fp32
+// products and accumulation -- no reduced-precision inputs):
+//     S[row][key] = q[row] . K[key]          (rows x 128 keys, reduction over head_dim)
+//     O[row][d]   = sum_key P[row][key] V[key][d]
+// Each wavefront owns 16 rows.  The split's K and V rows are staged in LDS once per workgroup and shared by
+// all rows; causality is each row's own position (nv[row] = number of keys of this split it may see).
+// MFMA operand layout (A[i][k]: lane = 16k+i, B[k][j]: lane = 16k+j, D[i][j]: lane = 16(i/4)+j, vgpr i%4)
+// leaves the order of the reduction index free, so lane group k owns a CONTIGUOUS slice of head_dim (QK) or
+// 4 consecutive keys (PV) and every LDS read is a 16-byte ds_read_b128; the output tile's column index is
+// permuted (d = NTO*j + nt) so each lane stores NTO consecutive floats.
+// The first product is computed transposed (S^T = K q^T) so that its D layout IS the A layout P needs in the
+// second: P never leaves registers and there is one barrier.  The partial (max, sum, sum p*v) layout
+// is the decode kernel's, so battn_merge_kernel is unchanged.  exp is float32 here (the decode kernel follows
+// go/quant.go:619 with a float64 exp; the difference is ~1e-7 relative and this path has ~N^2/2 of them).
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f32<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_f32<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f32<DPP_ROW_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<DPP_QUAD_XOR1>(v);
+    v += dpp_f32<DPP_QUAD_XOR2>(v);
+    v += dpp_f32<DPP_HALF_MIRROR>(v);
+    v += dpp_f32<DPP_ROW_MIRROR>(v);
+    return v;
+}
+
+template <int HD, int G, int QT>
+__global__ void __launch_bounds__(QT * G * 4, 2) attn_tile_kernel(AttnParams P, int n_items) {
+    constexpr int VH = QT * G;               // rows (token, query head) per workgroup
+    static_assert(VH % 16 == 0 && VH <= 64, "16 rows per wavefront");
+    constexpr int NTH = VH * 4;              // threads: one wavefront per 16 rows
+    constexpr int KS = HD + 4;               // K row stride in LDS (floats): b128 reads of 8 rows hit 32 banks
+    constexpr int DK = HD / 4;               // head_dim slice of one lane group in the QK reduction
+    constexpr int NTO = HD / 16;             // output column tiles
+    constexpr int R4 = HD / 4;
+    __shared__ __attribute__((aligned(16))) float Ks[ATT_CH * KS];
+    __shared__ __attribute__((aligned(16))) float Vs[ATT_CH * HD];
+    __shared__ int nv[VH];
+
+    const int kvh = blockIdx.x, split = blockIdx.y, i0 = blockIdx.z * QT, tid = threadIdx.x;
+    const int t0 = split * ATT_CH;
+    int maxpos = -1;
+    for (int i = 0; i < QT; i++)
+        if (i0 + i < n_items) maxpos = max(maxpos, P.bpos[i0 + i]);
+    if (t0 > maxpos) return;
+    const int nrows = min(ATT_CH, maxpos + 1 - t0);
+    const int lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+
+    // A operand of QK: row w*16+j, head_dim slice [DK*kq, DK*kq+DK)
+    float qa[DK];
+    {
+        const int vh = w * 16 + j, item = i0 + vh / G, g = vh % G;
+        if (item < n_items) {
+            const float4 *q4 = reinterpret_cast<const float4 *>(
+                P.qbuf + (long long)item * P.q_item_stride + (kvh * G + g) * HD + DK * kq);
+#pragma unroll
+            for (int s = 0; s < DK / 4; s++) {
+                float4 t = q4[s];
+                qa[4 * s] = t.x; qa[4 * s + 1] = t.y; qa[4 * s + 2] = t.z; qa[4 * s + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < DK; s++) qa[s] = 0.f;
+        }
+    }
+    const long long soff = (long long)P.bstream[i0] * P.kv_stream_stride;
+    const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
+    const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
+    // every global load of the staging pass is issued before the first LDS store (one memory latency, not NIT);
+    // all 8 key tiles are always computed (uniform, branch-free MFMA stream); rows beyond nrows are zero-filled
+    // (masked to p = 0 by the softmax, and 0 * garbage could be NaN in P V otherwise)
+    constexpr int NIT = (ATT_CH * R4 + NTH - 1) / NTH;
+    float4 kreg[NIT], vreg[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int i = tid + it * NTH;
+        kreg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        vreg[it] = kreg[it];
+        if (i / R4 < nrows) { kreg[it] = K4[i]; vreg[it] = V4[i]; }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int i = tid + it * NTH, row = i / R4, c4 = i % R4;
+        if (i < ATT_CH * R4) {
+            *reinterpret_cast<float4 *>(Ks + row * KS + c4 * 4) = kreg[it];
+            *reinterpret_cast<float4 *>(Vs + row * HD + c4 * 4) = vreg[it];
+        }
+    }
+    if (tid < VH) {
+        const int item = i0 + tid / G;
+        nv[tid] = item < n_items ? min(ATT_CH, max(0, P.bpos[item] + 1 - t0)) : 0;
+    }
+    __syncthreads();
+
+    // ---- S^T = K q^T: 8 key tiles (M) x 16 rows (N); lane (j, kq) ends up holding row j's scores for keys
+    //      16*mt + 4*kq + r -- exactly the A-operand layout of P in P V, so P never leaves registers ----
+    v4f acc[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; mt++) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < DK / 4; s4++) {
+        float4 kb[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++)
+            kb[mt] = *reinterpret_cast<const float4 *>(Ks + (mt * 16 + j) * KS + DK * kq + 4 * s4);
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[mt].x, qa[4 * s4], acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[mt].y, qa[4 * s4 + 1], acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[mt].z, qa[4 * s4 + 2], acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[mt].w, qa[4 * s4 + 3], acc[mt], 0, 0, 0);
+    }
+
+    // ---- softmax pieces of row j: 32 keys in this lane, the rest in lanes j+16, j+32, j+48 ----
+    const int nvj = nv[w * 16 + j];
+    float m = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < 8; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float sv = mt * 16 + 4 * kq + r < nvj ? acc[mt][r] * P.scale : -INFINITY;
+            acc[mt][r] = sv;
+            m = fmaxf(m, sv);
+        }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 8; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float pv = mt * 16 + 4 * kq + r < nvj ? expf(acc[mt][r] - m) : 0.f;
+            acc[mt][r] = pv;
+            l += pv;
+        }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+
+    // ---- O = P V: A = P[row j][key 16s+4kq+i] = acc[s][i], B = V rows from LDS ----
+    v4f o[NTO];
+#pragma unroll
+    for (int nt = 0; nt < NTO; nt++) o[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float *vr = Vs + (16 * s + 4 * kq + i) * HD + NTO * j;
+                if constexpr (NTO == 4) {
+                    const float4 vb = *reinterpret_cast<const float4 *>(vr);
+                    o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[s][i], vb.x, o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[s][i], vb.y, o[1], 0, 0, 0);
+                    o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[s][i], vb.z, o[2], 0, 0, 0);
+                    o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[s][i], vb.w, o[3], 0, 0, 0);
+                } else {
+                    const float2 vb = *reinterpret_cast<const float2 *>(vr);
+                    o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[s][i], vb.x, o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[s][i], vb.y, o[1], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // O tile: this lane holds rows 4*kq+r, columns d = NTO*j .. NTO*j+NTO-1
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int vh = w * 16 + 4 * kq + r;
+        if (nv[vh] == 0) continue;
+        const int item = i0 + vh / G, h = kvh * G + vh % G;
+        const long long slot = (long long)item * P.part_item_stride + (long long)h * P.nsplit_max + split;
+        float *po = P.part_o + slot * HD + NTO * j;
+        if constexpr (NTO == 4) *reinterpret_cast<float4 *>(po) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
+        else *reinterpret_cast<float2 *>(po) = make_float2(o[0][r], o[1][r]);
+    }
+    if (kq == 0 && nvj > 0) {
+        const int vh = w * 16 + j, item = i0 + vh / G, h = kvh * G + vh % G;
+        const long long slot = (long long)item * P.part_item_stride + (long long)h * P.nsplit_max + split;
+        P.part_ml[slot * 2] = m;
+        P.part_ml[slot * 2 + 1] = l;
+    }
+}
+
+template <int G> struct AttnTileQT { static constexpr int value = G == 1 ? 64 : G == 2 ? 32 : G == 8 ? 8 : 16; };
+
+}  // namespace nl

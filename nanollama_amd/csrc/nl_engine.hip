@@ -340,6 +340,25 @@ hipError_t launch_attn(int hd, int gqa, AttnParams P, dim3 grid, hipStream_t st)
     return hipErrorInvalidValue;
 }
 
+template <int HD, int G>
+void launch_attn_tile_g(const AttnParams &P, int n, int kvs, int nsplit, hipStream_t st) {
+    constexpr int QT = AttnTileQT<G>::value;
+    hipLaunchKernelGGL((attn_tile_kernel<HD, G, QT>), dim3(kvs, nsplit, (n + QT - 1) / QT), dim3(QT * G * 4), 0, st, P, n);
+}
+inline bool attn_tile_supported(int gqa) { return gqa == 1 || gqa == 2 || gqa == 3 || gqa == 4 || gqa == 8; }
+template <int HD>
+hipError_t launch_attn_tile_hd(int gqa, const AttnParams &P, int n, int kvs, int nsplit, hipStream_t st) {
+    switch (gqa) {
+    case 1: launch_attn_tile_g<HD, 1>(P, n, kvs, nsplit, st); break;
+    case 2: launch_attn_tile_g<HD, 2>(P, n, kvs, nsplit, st); break;
+    case 3: launch_attn_tile_g<HD, 3>(P, n, kvs, nsplit, st); break;
+    case 4: launch_attn_tile_g<HD, 4>(P, n, kvs, nsplit, st); break;
+    case 8: launch_attn_tile_g<HD, 8>(P, n, kvs, nsplit, st); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_gemv_dyn(int wt, int pro, int epi, const GemvParams &P, hipStream_t st) {
     if (pro == PRO_NORM && epi == EPI_QKV) return launch_gemv_t<PRO_NORM, EPI_QKV>(wt, P, st);
     if (pro == PRO_ATTN && epi == EPI_RESID) return launch_gemv_t<PRO_ATTN, EPI_RESID>(wt, P, st);
@@ -622,7 +641,7 @@ hipError_t qg(nl_engine *e, const PackedMat &m, const float *x, int ldx, int n, 
 // One multi-token step: n <= 64 (token, pos, stream) triples through every layer on the MFMA path.
 // lm_mode: 0 = no LM head, 1 = logits + argmax for every token, 2 = logits + argmax for the LAST token only.
 // The caller has filled bt.h_meta; stream-ordered, no synchronisation inside.
-int batched_step(nl_engine *e, int n, int lm_mode) {
+int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
     const nl_config &c = e->cfg;
     nl_engine::Batch &b = e->bt;
     hipStream_t st = e->stream;
@@ -653,7 +672,13 @@ int batched_step(nl_engine *e, int n, int lm_mode) {
             AttnParams P{b.q, kc, vc, e->kv_stream_stride, b.part_o, b.part_ml, e->ctl, e->KVs, c.seq_len, e->nsplit_max,
                          (float)(1.0 / std::sqrt((double)hd)), 0, b.pos, b.stream, (long long)HQ,
                          (long long)e->Hs * e->nsplit_max};
-            LCK(launch_attn(hd, e->gqa, P, dim3(e->KVs, e->nsplit_max, n), st));
+            if (one_stream && n >= 8 && attn_tile_supported(e->gqa) && !getenv("NL_NO_ATTN_TILE")) {
+                // prefill: the step's tokens share a stream -> K/V split staged once per tile of tokens, MFMA fp32
+                LCK(hd == 64 ? launch_attn_tile_hd<64>(e->gqa, P, n, e->KVs, e->nsplit_max, st)
+                             : launch_attn_tile_hd<32>(e->gqa, P, n, e->KVs, e->nsplit_max, st));
+            } else {
+                LCK(launch_attn(hd, e->gqa, P, dim3(e->KVs, e->nsplit_max, n), st));
+            }
             BMergeParams M{b.part_o, b.part_ml, b.pos, e->Hs, e->nsplit_max, hd, b.att};
             hipLaunchKernelGGL(battn_merge_kernel, dim3(n), dim3(256), 0, st, M);
             LCK(hipGetLastError());
@@ -1134,7 +1159,7 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
                 b.h_meta[2 * b.cap + i] = stream;
             }
             const bool last = t0 + m == n;
-            if ((rc = batched_step(e, m, last ? 2 : 0))) return rc;
+            if ((rc = batched_step(e, m, last ? 2 : 0, true))) return rc;
             if (last) {
                 // keep the single-token state coherent: logits / argmax of the last token
                 HIPCK(e, hipMemcpyAsync(e->logits, b.logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToDevice, e->stream));

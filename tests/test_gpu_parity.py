@@ -381,6 +381,30 @@ def test_long_prefill_crosses_tiles_and_attention_splits(hip, orc, tmp_path):
     dev.close()
 
 
+@pytest.mark.parametrize("heads,kv,hd", [(4, 4, 64), (4, 2, 64), (6, 2, 32), (8, 2, 64), (8, 1, 32), (3, 1, 64)])
+def test_prefill_attention_tiles_every_gqa_ratio(hip, orc, tmp_path, heads, kv, hd):
+    # the MFMA prefill attention kernel is instantiated per (head_dim, query heads per kv head); a 333-token
+    # prompt in two calls (pos0 > 0, ragged last tile, three 128-position splits) against the oracle.
+    shape = replace(synth.TIERS["tiny"], name=f"t{heads}_{kv}_{hd}", dim=heads * hd, n_head=heads, n_kv_head=kv,
+                    seq_len=400, interm=256, n_layer=2)
+    p = tmp_path / "g.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 31)
+    g = gguf.load_gguf(str(p))
+    dev = hip.load_llama_model(g)
+    ref = orc.OracleModel(g)
+    toks = synth.prompt_ids(333, shape.vocab, seed=9)
+    for pos, t in enumerate(toks):
+        want = ref.forward(t, pos)
+    dev.prefill(toks[:77], want_logits=False)
+    dev.prefill(toks[77:], pos0=77)
+    err = float(np.abs(dev.state.logits - want).max())
+    print(f"\nheads={heads} kv={kv} hd={hd}: max|gpu-oracle|={err:.2e}")
+    assert err <= LOGIT_TOL * max(1.0, float(want.std()))
+    nxt = int(np.argmax(want))
+    assert dev.decode_greedy(nxt, len(toks), 3)[0] == int(np.argmax(ref.forward(nxt, len(toks))))
+    dev.close()
+
+
 def test_forward_batch_matches_individual_forwards(hip):
     g = gguf.load_gguf(os.path.join(GOLDEN, "tiny_q8_0.gguf"))
     dev = hip.load_llama_model(g, max_streams=4)
