@@ -165,6 +165,7 @@ struct nl_engine {
     struct Batch {
         bool ready = false;
         int cap = 0, lm_cap = 0;
+        uint4 *xfrag = nullptr;  // fp16 hi/lo activation fragments of the GEMM being run
         float *kpart = nullptr;  // split-K partial sums
         size_t kpart_cap = 0;    // floats
         float *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *att = nullptr, *g = nullptr, *u = nullptr,
@@ -563,7 +564,17 @@ bool parse_name(const char *name, Slot &s) {
 }  // namespace
 
 namespace {
+// x[n][ldx] (f32) -> the fp16 hi/lo fragment store the MFMA kernel DMAs into LDS (layout: nl_qgemm.h)
+hipError_t launch_xsplit(int wtype, const float *x, int ldx, int cols, int n_tokens, uint4 *xf, hipStream_t st) {
+    const int nt16 = ((n_tokens + 63) / 64) * 4;
+    const long long total = (long long)(cols / 32) * nt16 * 64;
+    hipLaunchKernelGGL(xsplit_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 8192)), dim3(256), 0, st,
+                       x, ldx, cols / 32, n_tokens, nt16, wtype == WT_Q4_0 ? 1 : 0, xf);
+    return hipGetLastError();
+}
+
 hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_buf = nullptr, size_t part_cap = 0) {
+    P.nt16 = ((P.n_tokens + 63) / 64) * 4;
     const int row_groups = (P.ntiles + QG_WAVES * QG_RT - 1) / (QG_WAVES * QG_RT);
     const int tok_tiles = (P.n_tokens + QG_TOK - 1) / QG_TOK;
     const int nchunks = (P.cols / 32 + QG_KC - 1) / QG_KC;
@@ -616,6 +627,12 @@ int batch_alloc(nl_engine *e) {
     HIPCK(e, dalloc(&b.u, n * e->Is, &e->bytes_state));
     HIPCK(e, dalloc(&b.h, n * e->Is, &e->bytes_state));
     HIPCK(e, dalloc(&b.logits, (size_t)b.lm_cap * c.vocab, &e->bytes_state));
+    {
+        const size_t nx = xfrag_uint4((int)std::max<size_t>(std::max<size_t>(HQ, c.dim), e->Is), (int)n);
+        float *raw = nullptr;
+        HIPCK(e, dalloc(&raw, nx * 4, &e->bytes_state));
+        b.xfrag = reinterpret_cast<uint4 *>(raw);
+    }
     b.kpart_cap = (size_t)16 * QG_TOK * std::max<size_t>(std::max<size_t>(R, c.dim), e->Is);
     HIPCK(e, dalloc(&b.kpart, b.kpart_cap, &e->bytes_state));
     HIPCK(e, dalloc(&b.part_o, n * e->Hs * e->nsplit_max * e->hd, &e->bytes_state));
@@ -634,7 +651,11 @@ hipError_t qg(nl_engine *e, const PackedMat &m, const float *x, int ldx, int n, 
     QGemmParams P{};
     P.bias = bias;
     P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
-    P.x = x; P.ldx = ldx; P.n_tokens = n; P.out = out; P.ldo = ldo; P.resid = resid;
+    P.xf = e->bt.xfrag; P.n_tokens = n; P.out = out; P.ldo = ldo; P.resid = resid;
+    if (x) {   // x == nullptr: the fragments of the previous call are reused (gate and up share their input)
+        hipError_t s = launch_xsplit(m.wtype, x, ldx, m.cols, n, e->bt.xfrag, st);
+        if (s != hipSuccess) return s;
+    }
     return launch_qgemm(m.wtype, P, st, e->bt.kpart, e->bt.kpart_cap);
 }
 
@@ -687,7 +708,7 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
         hipLaunchKernelGGL(brmsnorm_kernel, dim3(n), dim3(256), 0, st, b.x, L.ffn_norm, c.rms_eps, b.xn, D);
         LCK(hipGetLastError());
         LCK(qg(e, L.gate, b.xn, D, n, b.g, e->Is, nullptr, st));
-        LCK(qg(e, L.up, b.xn, D, n, b.u, e->Is, nullptr, st));
+        LCK(qg(e, L.up, L.up.wtype == L.gate.wtype ? nullptr : b.xn, D, n, b.u, e->Is, nullptr, st));
         {
             long long tot = (long long)n * e->Is;
             hipLaunchKernelGGL(bswiglu_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 4096)), dim3(256), 0, st,
@@ -1068,7 +1089,7 @@ int nl_destroy(nl_handle e) {
     if (e->stage) hipFree(e->stage);
     {
         nl_engine::Batch &b = e->bt;
-        void *bb[] = {b.x, b.xn, b.qkv, b.q, b.att, b.g, b.u, b.h, b.logits, b.part_o, b.part_ml, b.tok, b.pos, b.stream, b.ids, b.kpart};
+        void *bb[] = {b.x, b.xn, b.qkv, b.q, b.att, b.g, b.u, b.h, b.logits, b.part_o, b.part_ml, b.tok, b.pos, b.stream, b.ids, b.kpart, b.xfrag};
         for (void *p : bb) if (p) hipFree(p);
         if (b.h_meta) hipHostFree(b.h_meta);
     }
@@ -1397,6 +1418,7 @@ int nl_op_matmul_batch(int device, uint32_t type, const void *w, uint64_t nbytes
     PackedMat m;
     uint8_t *d_raw = nullptr;
     float *d_x = nullptr, *d_out = nullptr;
+    uint4 *d_xf = nullptr;
     int rc = NL_ERR_HIP;
     do {
         if (alloc_packed(&tmp, m, (int)type, (rows + TR - 1) / TR, rows, cols) != hipSuccess) break;
@@ -1408,7 +1430,9 @@ int nl_op_matmul_batch(int device, uint32_t type, const void *w, uint64_t nbytes
         if (repack(&tmp, m, d_raw, (int)type, cols, 0, rows, 0, cols, 0, m.ntiles, ROWMAP_IDENT) != hipSuccess) break;
         QGemmParams P{};
         P.q = m.q; P.s = m.s; P.rows = rows; P.cols = cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
-        P.x = d_x; P.ldx = cols; P.n_tokens = n_tokens; P.out = d_out; P.ldo = rows;
+        if (hipMalloc((void **)&d_xf, xfrag_uint4(cols, n_tokens) * sizeof(uint4)) != hipSuccess) break;
+        if (launch_xsplit(m.wtype, d_x, cols, cols, n_tokens, d_xf, st) != hipSuccess) break;
+        P.xf = d_xf; P.n_tokens = n_tokens; P.out = d_out; P.ldo = rows;
         if (launch_qgemm(m.wtype, P, st) != hipSuccess) break;
         if (hipMemcpyAsync(out, d_out, (size_t)rows * n_tokens * 4, hipMemcpyDeviceToHost, st) != hipSuccess) break;
         if (hipStreamSynchronize(st) != hipSuccess) break;
@@ -1416,6 +1440,7 @@ int nl_op_matmul_batch(int device, uint32_t type, const void *w, uint64_t nbytes
     } while (0);
     for (void *c : tmp.arena_chunks) hipFree(c);
     if (d_raw) hipFree(d_raw);
+    if (d_xf) hipFree(d_xf);
     if (d_x) hipFree(d_x);
     if (d_out) hipFree(d_out);
     hipStreamDestroy(st);

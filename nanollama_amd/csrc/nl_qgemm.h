@@ -17,16 +17,27 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int QG_TOK = 64;      // tokens per workgroup tile (4 MFMA column tiles of 16)
-constexpr int QG_KC = 8;        // 32-element blocks staged per chunk (256 columns)
+#ifndef NL_QG_KC
+#define NL_QG_KC 4
+#endif
+#ifndef NL_QG_OCC
+#define NL_QG_OCC 2
+#endif
+constexpr int QG_KC = NL_QG_KC;  // 32-element blocks per K chunk (128 columns)
 constexpr int QG_WAVES = 4;
 constexpr int QG_RT = 2;        // 16-row weight tiles per wavefront
+constexpr int QG_FRAG = 64;     // uint4 per activation fragment: 64 lanes x 16 bytes, lane-linear (= one LDS-DMA)
 
+// Activation fragments live in global memory in MFMA operand order, produced ONCE per activation matrix
+// (xsplit_kernel or the producing kernel's epilogue) instead of once per weight row block:
+//   xf[block b][16-token tile t][hi/lo p][lane (token n%16, slot group w)] = 8 fp16 k-slots
+// nt16 (the t extent) is padded to a multiple of 4 so a 64-token workgroup tile is 8 KB contiguous per block.
 struct QGemmParams {
     const uint8_t *q;
     const uint32_t *s;
     int rows, cols, npairs, ntiles;
-    const float *x;      // [N][ldx] activations
-    int ldx, n_tokens;
+    const uint4 *xf;     // activation fragments
+    int nt16, n_tokens;
     float *out;          // [N][ldo]
     int ldo;
     const float *resid;  // optional [N][ldo]: out = resid + y
@@ -36,6 +47,10 @@ struct QGemmParams {
     int ksplit;
     float *part;
 };
+
+inline size_t xfrag_uint4(int cols, int n_tokens) {   // uint4 elements of a fragment store
+    return (size_t)(cols / 32) * (size_t)(((n_tokens + 63) / 64) * 4) * 2 * QG_FRAG;
+}
 
 // k-slot -> element-of-block map shared by both MFMA operands.
 //   Q4_0: dword w of the 16 quant bytes holds elements 4w..4w+3 (low nibbles) and 16+4w..16+4w+3 (high);
@@ -56,17 +71,22 @@ __device__ __forceinline__ void load_x_slots(const float *xb, int w, float (&v)[
     }
 }
 
-// weight fragment (8 fp16 k-slots of one row of one block) straight from the tile layout
+// weight fragment (8 fp16 k-slots of one row of one block) straight from the tile layout: raw() issues the
+// load (kept in its packed form while the previous chunk computes), expand() makes the fp16 operand
 template <int WT> struct WFrag;
 
 template <> struct WFrag<WT_Q4_0> {
+    typedef uint32_t raw_t;
     // chunk c of pair p == block 2p+c; lane (row i, dword w) reads one dword
-    static __device__ __forceinline__ half8_t load(const uint8_t *q, long long tile_pair0, int npairs, int blk, int i, int w) {
+    static __device__ __forceinline__ raw_t raw(const uint8_t *q, long long tile_pair0, int npairs, int blk, int i, int w) {
         const int p = blk >> 1, c = blk & 1, g = p >> 2, k = p & 3;
         const int gsz = min(KL, npairs - g * KL);
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(
-            q + ((tile_pair0 * 2 * TR) + (long long)g * (KL * 2 * TR) + (c * TR + i) * gsz + k) * 16) + w;
-        const uint32_t u = *src, u8 = u >> 8;
+        return *(reinterpret_cast<const uint32_t *>(
+            q + ((tile_pair0 * 2 * TR) + (long long)g * (KL * 2 * TR) + (c * TR + i) * gsz + k) * 16) + w);
+    }
+    static __device__ __forceinline__ raw_t zero() { return 0x88888888u; }
+    static __device__ __forceinline__ half8_t expand(raw_t u) {
+        const uint32_t u8 = u >> 8;
         const h2_t k1032 = {(_Float16)1032.0f, (_Float16)1032.0f};
         const h2_t k16th = {(_Float16)0.0625f, (_Float16)0.0625f};
         const h2_t km72 = {(_Float16)-72.0f, (_Float16)-72.0f};
@@ -83,12 +103,16 @@ template <> struct WFrag<WT_Q4_0> {
 };
 
 template <> struct WFrag<WT_Q8_0> {
+    typedef uint2 raw_t;
     // block 2p+h = chunks 2h, 2h+1 of pair p; lane (row i, slot group w) reads bytes 8w..8w+7 of the block
-    static __device__ __forceinline__ half8_t load(const uint8_t *q, long long tile_pair0, int npairs, int blk, int i, int w) {
+    static __device__ __forceinline__ raw_t raw(const uint8_t *q, long long tile_pair0, int npairs, int blk, int i, int w) {
         const int p = blk >> 1, c = (blk & 1) * 2 + (w >> 1), g = p >> 2, k = p & 3;
         const int gsz = min(KL, npairs - g * KL);
-        const uint2 u = *reinterpret_cast<const uint2 *>(
+        return *reinterpret_cast<const uint2 *>(
             q + ((tile_pair0 * 4 * TR) + (long long)g * (KL * 4 * TR) + (c * TR + i) * gsz + k) * 16 + (w & 1) * 8);
+    }
+    static __device__ __forceinline__ raw_t zero() { return make_uint2(0u, 0u); }
+    static __device__ __forceinline__ half8_t expand(raw_t u) {
         half8_t r;
         r[0] = (_Float16)(int)(int8_t)(u.x & 0xff); r[1] = (_Float16)(int)(int8_t)((u.x >> 8) & 0xff);
         r[2] = (_Float16)(int)(int8_t)((u.x >> 16) & 0xff); r[3] = (_Float16)(int)(int8_t)(u.x >> 24);
@@ -98,25 +122,61 @@ template <> struct WFrag<WT_Q8_0> {
     }
 };
 
+// the scale word of (tile, pair of block blk, row i): both blocks' fp16 d; scale_of() picks this block's
 template <int WT>
-__device__ __forceinline__ float load_scale(const uint32_t *s, long long tile_pair0, int npairs, int blk, int i) {
+__device__ __forceinline__ uint32_t load_scale_word(const uint32_t *s, long long tile_pair0, int npairs, int blk, int i) {
     const int p = blk >> 1, g = p >> 2, k = p & 3;
     const int gsz = min(KL, npairs - g * KL);
-    const uint32_t sc = s[tile_pair0 * TR + g * (KL * TR) + i * gsz + k];
-    return h2f_bits((sc >> (16 * (blk & 1))) & 0xffff);
+    return s[tile_pair0 * TR + g * (KL * TR) + i * gsz + k];
+}
+__device__ __forceinline__ float scale_of(uint32_t word, int blk) { return h2f_bits((word >> (16 * (blk & 1))) & 0xffff); }
+
+// x -> fp16 hi/lo fragments.  One thread per (block, 16-token tile, slot group w, token): reads the 8 k-slot
+// elements of its token (two float4), writes the hi and the lo fragment entry (16 bytes each; the 16 tokens of a
+// tile are adjacent, so a 16-lane group writes 256 contiguous bytes).  Tokens beyond n_tokens are zero.
+__global__ void xsplit_kernel(const float *x, int ldx, int nblocks, int n_tokens, int nt16, int q4, uint4 *xf) {
+    const long long total = (long long)nblocks * nt16 * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int fl = (int)(i & 63), w = fl >> 4;
+        const long long bt = i >> 6;
+        const int t = (int)(bt % nt16), b = (int)(bt / nt16);
+        const int n = t * 16 + (fl & 15);
+        float v[8];
+        if (n < n_tokens) {
+            const float *xb = x + (long long)n * ldx + b * 32;
+            if (q4) load_x_slots<WT_Q4_0>(xb, w, v);
+            else load_x_slots<WT_Q8_0>(xb, w, v);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = 0.f;
+        }
+        half8_t hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            hi[j] = (_Float16)v[j];
+            lo[j] = (_Float16)(v[j] - (float)hi[j]);
+        }
+        xf[(bt * 2 + 0) * QG_FRAG + fl] = __builtin_bit_cast(uint4, hi);
+        xf[(bt * 2 + 1) * QG_FRAG + fl] = __builtin_bit_cast(uint4, lo);
+    }
 }
 
-// Workgroup = 4 wavefronts x QG_RT row tiles (128 weight rows) x 64 tokens; K walked in 256-column chunks
-// whose activations are split into fp16 hi/lo MFMA fragments in LDS once and shared by all wavefronts.
+// Workgroup = 4 wavefronts x QG_RT row tiles (128 weight rows) x 64 tokens; K walked in 128-column chunks.
+// Software pipeline, one barrier per chunk: while chunk c is on the matrix cores, chunk c+1's activation
+// fragments travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: the fragment store is lane-linear, one
+// instruction per 1 KB fragment, no VGPR round trip) and its packed weights + scales travel to registers.
 template <int WT>
-__global__ void __launch_bounds__(QG_WAVES * 64) qgemm_kernel(QGemmParams P) {
-    // fragment store: [block in chunk][token tile][hi/lo][lane] x 16 bytes
-    __shared__ __attribute__((aligned(16))) uint4 xfrag[QG_KC * 4 * 2 * 64];
+__global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmParams P) {
+    typedef typename WFrag<WT>::raw_t raw_t;
+    // fragment buffers: [buffer][block in chunk][token tile][hi/lo][lane] x 16 bytes
+    __shared__ __attribute__((aligned(16))) uint4 xfrag[2][QG_KC * 8 * QG_FRAG];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lw = lane >> 4;
     const int tok0 = blockIdx.y * QG_TOK;
     const int nblocks = P.cols / 32;
+    const int nchunks = (nblocks + QG_KC - 1) / QG_KC;
     const int tile0 = (blockIdx.x * QG_WAVES + wave) * QG_RT;
+    const uint4 *xsrc = P.xf + (long long)blockIdx.y * (8 * QG_FRAG) + lane;   // + block * nt16 * 2 * QG_FRAG
 
     f32x4_t acc[QG_RT][4];
 #pragma unroll
@@ -124,89 +184,136 @@ __global__ void __launch_bounds__(QG_WAVES * 64) qgemm_kernel(QGemmParams P) {
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[rt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    for (int b0 = blockIdx.z * QG_KC; b0 < nblocks; b0 += QG_KC * P.ksplit) {
-        const int nb = min(QG_KC, nblocks - b0);
-        // this wavefront's weight fragments + scales for the chunk (issued before the staging work)
-        half8_t wf[QG_RT][QG_KC];
-        float wd[QG_RT][QG_KC];
+    // Both prefetch lambdas are BRANCH-FREE: out-of-range blocks / tiles are clamped to a valid address and
+    // neutralised afterwards (scale 0, or simply never consumed).  A per-element "load or zero" branch makes
+    // hipcc wait vmcnt(0) after every load -- one dependent memory round trip per block instead of one per chunk.
+    auto stage = [&](int chunk, int buf) {
+        const int b0 = chunk * QG_KC;
+#pragma unroll
+        for (int i = 0; i < 2 * QG_KC; i++) {
+            const int f = wave + QG_WAVES * i;        // fragment of the chunk: block f/8, (tile, part) f%8
+            const int blk = min(b0 + (f >> 3), nblocks - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(xsrc + (long long)blk * P.nt16 * (2 * QG_FRAG) + (f & 7) * QG_FRAG),
+                (__attribute__((address_space(3))) void *)&xfrag[buf][f * QG_FRAG], 16, 0, 0);
+        }
+    };
+    auto wload = [&](int chunk, raw_t (&wq)[QG_RT][QG_KC], uint32_t (&wd)[QG_RT][QG_KC]) {
+        const int b0 = chunk * QG_KC;
 #pragma unroll
         for (int rt = 0; rt < QG_RT; rt++) {
-            const int tile = tile0 + rt;
-            const bool live = tile < P.ntiles;
-            const long long tp0 = (long long)(live ? tile : 0) * P.npairs;
+            const bool live = tile0 + rt < P.ntiles;
+            const long long tp0 = (long long)(live ? tile0 + rt : 0) * P.npairs;
 #pragma unroll
             for (int b = 0; b < QG_KC; b++) {
-                if (live && b < nb) {
-                    wf[rt][b] = WFrag<WT>::load(P.q, tp0, P.npairs, b0 + b, li, lw);
-                    wd[rt][b] = load_scale<WT>(P.s, tp0, P.npairs, b0 + b, li);
-                } else {
-                    wf[rt][b] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-                    wd[rt][b] = 0.f;
-                }
+                const int blk = min(b0 + b, nblocks - 1);
+                wq[rt][b] = WFrag<WT>::raw(P.q, tp0, P.npairs, blk, li, lw);
+                wd[rt][b] = load_scale_word<WT>(P.s, tp0, P.npairs, blk, li);   // tiles past ntiles are never stored
             }
         }
-        __syncthreads();  // previous chunk's fragments fully consumed
-        // stage activations: fragment (block b, token tile t, lane (n, w)) = 8 k-slots of token tok0+16t+n
-        for (int f = tid; f < nb * 4 * 64; f += QG_WAVES * 64) {
-            const int fl = f & 63, t = (f >> 6) & 3, b = f >> 8;
-            const int n = tok0 + t * 16 + (fl & 15), w = fl >> 4;
-            float v[8];
-            if (n < P.n_tokens) load_x_slots<WT>(P.x + (long long)n * P.ldx + (b0 + b) * 32, w, v);
-            else
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = 0.f;
-            half8_t hi, lo;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                hi[j] = (_Float16)v[j];
-                lo[j] = (_Float16)(v[j] - (float)hi[j]);
-            }
-            xfrag[((b * 4 + t) * 2 + 0) * 64 + fl] = __builtin_bit_cast(uint4, hi);
-            xfrag[((b * 4 + t) * 2 + 1) * 64 + fl] = __builtin_bit_cast(uint4, lo);
+    };
+
+    raw_t wq[QG_RT][QG_KC], wqn[QG_RT][QG_KC];
+    uint32_t wd[QG_RT][QG_KC], wdn[QG_RT][QG_KC];
+    int chunk = blockIdx.z;
+    if (chunk < nchunks) {
+        stage(chunk, 0);
+        wload(chunk, wq, wd);
+    }
+    __syncthreads();                 // (drains the LDS-DMA queue: chunk 0 has landed)
+    for (int k = 0; chunk < nchunks; k++, chunk += P.ksplit) {
+        const int buf = k & 1, nb = min(QG_KC, nblocks - chunk * QG_KC);
+        const bool more = chunk + P.ksplit < nchunks;
+        if (more) {
+#ifndef NL_QG_NODMA
+            stage(chunk + P.ksplit, buf ^ 1);
+#endif
+#ifndef NL_QG_NOW
+            wload(chunk + P.ksplit, wqn, wdn);
+#endif
         }
-        __syncthreads();
+        // Straight-line over the chunk's blocks (no per-block branch: a block past the end of K was clamped to
+        // the last valid one by the prefetch and gets scale 0).  Per block: the 8 lo-part MFMAs go first on 8
+        // independent accumulators, then the 8 hi-part MFMAs -- each dependent pair is 8 issues apart, so no MFMA
+        // waits for its predecessor -- then the 32 "* d" FMAs.
 #pragma unroll
         for (int b = 0; b < QG_KC; b++) {
-            if (b < nb) {
+            half8_t wf[QG_RT], xh[4], xl[4];
+            float dsc[QG_RT];
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const half8_t xh = __builtin_bit_cast(half8_t, xfrag[((b * 4 + t) * 2 + 0) * 64 + lane]);
-                    const half8_t xl = __builtin_bit_cast(half8_t, xfrag[((b * 4 + t) * 2 + 1) * 64 + lane]);
-#pragma unroll
-                    for (int rt = 0; rt < QG_RT; rt++) {
-                        f32x4_t z = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wf[rt][b], z, 0, 0, 0);
-                        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wf[rt][b], z, 0, 0, 0);
-                        const float d = wd[rt][b];
-                        acc[rt][t][0] = fmaf(z[0], d, acc[rt][t][0]);
-                        acc[rt][t][1] = fmaf(z[1], d, acc[rt][t][1]);
-                        acc[rt][t][2] = fmaf(z[2], d, acc[rt][t][2]);
-                        acc[rt][t][3] = fmaf(z[3], d, acc[rt][t][3]);
-                    }
-                }
+            for (int t = 0; t < 4; t++) {
+                xh[t] = __builtin_bit_cast(half8_t, xfrag[buf][((b * 4 + t) * 2 + 0) * QG_FRAG + lane]);
+                xl[t] = __builtin_bit_cast(half8_t, xfrag[buf][((b * 4 + t) * 2 + 1) * QG_FRAG + lane]);
             }
+#pragma unroll
+            for (int rt = 0; rt < QG_RT; rt++) {
+                wf[rt] = WFrag<WT>::expand(wq[rt][b]);
+                const float d = scale_of(wd[rt][b], chunk * QG_KC + b);
+                dsc[rt] = b < nb ? d : 0.f;
+            }
+            f32x4_t z[QG_RT][4];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int rt = 0; rt < QG_RT; rt++)
+                    z[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[t], wf[rt], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int rt = 0; rt < QG_RT; rt++)
+                    z[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], wf[rt], z[rt][t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int rt = 0; rt < QG_RT; rt++) {
+                    acc[rt][t][0] = fmaf(z[rt][t][0], dsc[rt], acc[rt][t][0]);
+                    acc[rt][t][1] = fmaf(z[rt][t][1], dsc[rt], acc[rt][t][1]);
+                    acc[rt][t][2] = fmaf(z[rt][t][2], dsc[rt], acc[rt][t][2]);
+                    acc[rt][t][3] = fmaf(z[rt][t][3], dsc[rt], acc[rt][t][3]);
+                }
+        }
+        __syncthreads();             // this chunk's buffer is free again; the next chunk's DMA has landed
+        if (more) {
+#pragma unroll
+            for (int rt = 0; rt < QG_RT; rt++)
+#pragma unroll
+                for (int b = 0; b < QG_KC; b++) { wq[rt][b] = wqn[rt][b]; wd[rt][b] = wdn[rt][b]; }
         }
     }
-    // D[token = (lane>>4)*4 + j][weight row = lane & 15]
+    // D[token = (lane>>4)*4 + j][weight row = lane & 15].  The optional bias / residual operands are loaded for
+    // the whole tile first (clamped addresses, no per-element branch -> one memory latency), then added.
 #pragma unroll
     for (int rt = 0; rt < QG_RT; rt++) {
         const int row = (tile0 + rt) * TR + li;
         if (tile0 + rt >= P.ntiles || row >= P.rows) continue;
+        if (P.ksplit > 1) {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int n = tok0 + t * 16 + lw * 4 + j;
+                    if (n < P.n_tokens) P.part[((long long)blockIdx.z * P.n_tokens + n) * P.ldo + row] = acc[rt][t][j];
+                }
+            continue;
+        }
+        const float bv = P.bias ? P.bias[row] : 0.f;
+        float rv[4][4];
+        if (P.resid) {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    rv[t][j] = P.resid[(long long)min(tok0 + t * 16 + lw * 4 + j, P.n_tokens - 1) * P.ldo + row];
+        }
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int n = tok0 + t * 16 + lw * 4 + j;
-                if (n < P.n_tokens) {
-                    float v = acc[rt][t][j];
-                    if (P.ksplit > 1) {
-                        P.part[((long long)blockIdx.z * P.n_tokens + n) * P.ldo + row] = v;
-                    } else {
-                        if (P.bias) v += P.bias[row];
-                        if (P.resid) v += P.resid[(long long)n * P.ldo + row];
-                        P.out[(long long)n * P.ldo + row] = v;
-                    }
-                }
+                float v = acc[rt][t][j];
+                if (P.bias) v += bv;
+                if (P.resid) v += rv[t][j];
+                if (n < P.n_tokens) P.out[(long long)n * P.ldo + row] = v;
             }
     }
 }
