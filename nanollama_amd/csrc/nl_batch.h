@@ -2,9 +2,55 @@
 // The heavy lifting is qgemm_kernel (nl_qgemm.h) and the per-token attention kernel (nl_kernels.h, batched
 // over blockIdx.z); everything here is one workgroup per token.
 #pragma once
-#include "nl_kernels.h"
+#include "nl_qgemm.h"
 
 namespace nl {
+
+// A multi-token GEMM result as its consumer sees it: final values, or -- when the GEMM ran split-K -- the ks
+// partial-sum slabs, which the consumer adds in ascending z order (then bias), exactly as qgemm_sum_kernel does.
+// Folding the reduction into the consumer removes one launch per GEMM from the batched-decode step.
+struct GemmOut {
+    const float *val;     // [N][ld], used when ks <= 1 (bias / residual already applied by the GEMM epilogue)
+    const float *part;    // [ks][N][ld]
+    int ks;
+    long long zstride;    // N * ld
+    const float *bias;    // optional [ld], applied after the partials when ks > 1
+};
+
+__device__ __forceinline__ float gemm_out_at(const GemmOut &g, long long idx, int col) {
+    if (g.ks <= 1) return g.val[idx];
+    // slabs are fetched four at a time (clamped index, no per-load branch) so the adds wait for ks/4 memory
+    // round trips, not ks; slabs past ks contribute +0.0f
+    float v = 0.f;
+    for (int z0 = 0; z0 < g.ks; z0 += 4) {
+        float p[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) p[k] = g.part[(long long)min(z0 + k, g.ks - 1) * g.zstride + idx];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v += z0 + k < g.ks ? p[k] : 0.f;
+    }
+    if (g.bias) v += g.bias[col];
+    return v;
+}
+
+// element (0..31) of a 32-column block that k-slot (w, j) of the MFMA operands holds (nl_qgemm.h load_x_slots)
+__device__ __forceinline__ int slot_elem(int q4, int w, int j) {
+    return q4 ? ((j >> 2) * 16 + 4 * w + ((j & 1) << 1) + ((j >> 1) & 1)) : 8 * w + j;
+}
+
+// the 8 k-slots (block blk, slot group w) of token n -> hi/lo entries of the fragment store
+__device__ __forceinline__ void store_frag(uint4 *xf, int nt16, int n, int blk, int w, const float (&v)[8]) {
+    half8_t hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        hi[j] = (_Float16)v[j];
+        lo[j] = (_Float16)(v[j] - (float)hi[j]);
+    }
+    const long long bt = (long long)blk * nt16 + (n >> 4);
+    const int fl = w * 16 + (n & 15);
+    xf[(bt * 2 + 0) * QG_FRAG + fl] = __builtin_bit_cast(uint4, hi);
+    xf[(bt * 2 + 1) * QG_FRAG + fl] = __builtin_bit_cast(uint4, lo);
+}
 
 struct BEmbedParams {
     const uint8_t *table;
@@ -26,24 +72,54 @@ __global__ void bembed_kernel(BEmbedParams P) {
     }
 }
 
-// RMSNormInto go/quant.go:597-607, one workgroup per token
-__global__ void brmsnorm_kernel(const float *x, const float *w, float eps, float *out, int n) {
+// RMSNormInto go/quant.go:597-607, one workgroup per token, fused on both sides:
+//   in : the residual stream x, or (pend.ks > 1) x + the pending split-K slabs of the GEMM that feeds it
+//        (attention output / down projection) -- the sum is written back to x, which stays the residual
+//   out: the normalised row as fp16 hi/lo MFMA fragments for the next GEMM (no f32 copy, no split pass)
+struct BNormParams {
+    float *x;            // [N][dim] residual stream (updated in place when pend.ks > 1)
+    GemmOut pend;        // pending GEMM output to fold in (val unused: with ks <= 1 the GEMM already wrote x)
+    const float *w;
+    float eps;
+    int dim, item0;      // token of workgroup b = item0 + b; its fragment column is b
+    uint4 *xf;
+    int nt16, q4;
+};
+
+__global__ void __launch_bounds__(256) bnorm_kernel(BNormParams P) {
     __shared__ double dred[4];
-    const float *xr = x + (long long)blockIdx.x * n;
-    float *o = out + (long long)blockIdx.x * n;
+    const int item = P.item0 + blockIdx.x, n = P.dim;
+    float *xr = P.x + (long long)item * n;
     double ss = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) ss += (double)xr[i] * (double)xr[i];
+    if (P.pend.ks > 1) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const float v = gemm_out_at(P.pend, (long long)item * n + i, i) + xr[i];
+            xr[i] = v;
+            ss += (double)v * (double)v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) ss += (double)xr[i] * (double)xr[i];
+    }
     ss = wave_sum_f64(ss);
     if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = ss;
-    __syncthreads();
+    __syncthreads();   // also orders the x write-back above before the re-read below (same workgroup)
     double tot = 0.0;
     for (int k = 0; k < (int)(blockDim.x >> 6); k++) tot += dred[k];
-    float inv = (float)(1.0 / sqrt(tot / (double)n + (double)eps));
-    for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = (xr[i] * inv) * w[i];
+    const float inv = (float)(1.0 / sqrt(tot / (double)n + (double)P.eps));
+    for (int u = threadIdx.x; u < n / 8; u += blockDim.x) {
+        const int blk = u >> 2, w = u & 3;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = blk * 32 + slot_elem(P.q4, w, j);
+            v[j] = (xr[i] * inv) * P.w[i];
+        }
+        store_frag(P.xf, P.nt16, blockIdx.x, blk, w, v);
+    }
 }
 
 struct BRopeParams {
-    const float *qkv;       // [N][R], rows in the packed (ROWMAP_HEADPERM) tile order of the QKV matrix
+    GemmOut qkv;            // [N][R], rows in the packed (ROWMAP_HEADPERM) tile order of the QKV matrix
     int R, head_dim, n_q_heads, n_kv_heads, seq_len, rope_conj, qk_norm;
     float eps;
     const int *pos, *stream;
@@ -59,13 +135,13 @@ __global__ void brope_kv_kernel(BRopeParams P) {
     extern __shared__ float vals[];  // [R] in natural (head, element) order after RoPE
     const int item = blockIdx.x, hd = P.head_dim, half = hd >> 1, tph = hd / 16;
     const int pos = P.pos[item];
-    const float *src = P.qkv + (long long)item * P.R;
+    const long long src0 = (long long)item * P.R;
     for (int rho = threadIdx.x; rho < P.R; rho += blockDim.x) {
         const int tile = rho / TR, r = rho % TR;
         const int head = tile / tph, j = tile % tph;
         const int i = j * 8 + (r & 7), e = i + (r >> 3) * half;
-        float v = src[rho], outv = v;
-        float partner = src[rho ^ 8];
+        float v = gemm_out_at(P.qkv, src0 + rho, rho), outv = v;
+        float partner = gemm_out_at(P.qkv, src0 + (rho ^ 8), rho ^ 8);
         if (P.bias_q) {
             const int ep = i + ((r ^ 8) >> 3) * half;   // the partner's element index
             if (head < P.n_q_heads) { v += P.bias_q[head * hd + e]; partner += P.bias_q[head * hd + ep]; }
@@ -115,42 +191,74 @@ struct BMergeParams {
     const float *part_o, *part_ml;  // [N][heads][nsplit_max][hd] / [..][2]
     const int *pos;
     int heads, nsplit_max, head_dim;
-    float *out;  // [N][heads*hd]
+    uint4 *xf;   // attention output [N][heads*hd] as MFMA fragments for the WO GEMM
+    int nt16, q4;
 };
 
-// online-softmax merge of the position splits (same arithmetic as the decode GEMV's PRO_ATTN prologue)
+// online-softmax merge of the position splits (same arithmetic as the decode GEMV's PRO_ATTN prologue);
+// one thread per 8 k-slots of the output row
 __global__ void battn_merge_kernel(BMergeParams P) {
     const int item = blockIdx.x, hd = P.head_dim;
     const int ns = P.pos[item] / ATT_CH + 1;
     const long long pbase = (long long)item * P.heads * P.nsplit_max;
-    for (int i = threadIdx.x; i < P.heads * hd; i += blockDim.x) {
-        const int h = i / hd, d = i - h * hd;
+    for (int u = threadIdx.x; u < P.heads * hd / 8; u += blockDim.x) {
+        const int blk = u >> 2, w = u & 3;
+        const int h = blk * 32 / hd;                 // a 32-column block never straddles heads (hd = 32 or 64)
         const float *ml = P.part_ml + (pbase + (long long)h * P.nsplit_max) * 2;
-        const float *po = P.part_o + (pbase + (long long)h * P.nsplit_max) * hd + d;
-        float r;
+        float wt[16], scale;
         if (ns == 1) {
-            r = po[0] * (1.0f / ml[1]);
+            scale = 1.0f / ml[1];
         } else {
             float M = ml[0];
             for (int c = 1; c < ns; c++) M = fmaxf(M, ml[2 * c]);
-            float L = 0.f, o = 0.f;
+            float L = 0.f;
             for (int c = 0; c < ns; c++) {
-                float w = (float)exp((double)(ml[2 * c] - M));
-                L += w * ml[2 * c + 1];
-                o += w * po[(long long)c * hd];
+                wt[c] = (float)exp((double)(ml[2 * c] - M));
+                L += wt[c] * ml[2 * c + 1];
             }
-            r = o * (1.0f / L);
+            scale = 1.0f / L;
         }
-        P.out[(long long)item * P.heads * hd + i] = r;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int d = blk * 32 + slot_elem(P.q4, w, j) - h * hd;
+            const float *po = P.part_o + (pbase + (long long)h * P.nsplit_max) * hd + d;
+            float o;
+            if (ns == 1) o = po[0];
+            else {
+                o = 0.f;
+                for (int c = 0; c < ns; c++) o += wt[c] * po[(long long)c * hd];
+            }
+            v[j] = o * scale;
+        }
+        store_frag(P.xf, P.nt16, item, blk, w, v);
     }
 }
 
-// SiLU(gate) * up, go/quant.go:629-631 + go/model.go:604-606
-__global__ void bswiglu_kernel(const float *g, const float *u, float *out, long long n) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float v = g[i];
-        float ex = (float)exp((double)(-v));
-        out[i] = (v / (1.0f + ex)) * u[i];
+// SiLU(gate) * up, go/quant.go:629-631 + go/model.go:604-606; one thread per (token, block, slot group);
+// gate / up may still be split-K slabs; h leaves as MFMA fragments for the down projection
+struct BSwigluParams {
+    GemmOut g, u;        // [N][interm]
+    int interm, n_tokens;
+    uint4 *xf;
+    int nt16, q4;
+};
+
+__global__ void bswiglu_kernel(BSwigluParams P) {
+    const int upt = P.interm / 8;                     // units per token
+    const long long total = (long long)P.n_tokens * upt;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / upt), u = (int)(i - (long long)n * upt), blk = u >> 2, w = u & 3;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int col = blk * 32 + slot_elem(P.q4, w, j);
+            const long long idx = (long long)n * P.interm + col;
+            const float gv = gemm_out_at(P.g, idx, col), uv = gemm_out_at(P.u, idx, col);
+            const float ex = (float)exp((double)(-gv));
+            v[j] = (gv / (1.0f + ex)) * uv;
+        }
+        store_frag(P.xf, P.nt16, n, blk, w, v);
     }
 }
 

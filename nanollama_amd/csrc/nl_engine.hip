@@ -166,10 +166,10 @@ struct nl_engine {
         bool ready = false;
         int cap = 0, lm_cap = 0;
         uint4 *xfrag = nullptr;  // fp16 hi/lo activation fragments of the GEMM being run
-        float *kpart = nullptr;  // split-K partial sums
-        size_t kpart_cap = 0;    // floats
-        float *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *att = nullptr, *g = nullptr, *u = nullptr,
-              *h = nullptr, *logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
+        float *kpart = nullptr, *kpart2 = nullptr;  // split-K partial sums (second buffer: up, alive beside gate)
+        size_t kpart_cap = 0;    // floats, each
+        float *x = nullptr, *qkv = nullptr, *q = nullptr, *g = nullptr, *u = nullptr, *logits = nullptr,
+              *part_o = nullptr, *part_ml = nullptr;
         int *tok = nullptr, *pos = nullptr, *stream = nullptr, *ids = nullptr;
         int *h_meta = nullptr;  // pinned [3][cap]
     } bt;
@@ -573,26 +573,30 @@ hipError_t launch_xsplit(int wtype, const float *x, int ldx, int cols, int n_tok
     return hipGetLastError();
 }
 
-hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_buf = nullptr, size_t part_cap = 0) {
+hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_buf = nullptr, size_t part_cap = 0,
+                        int *ks_out = nullptr) {
     P.nt16 = ((P.n_tokens + 63) / 64) * 4;
     const int row_groups = (P.ntiles + QG_WAVES * QG_RT - 1) / (QG_WAVES * QG_RT);
     const int tok_tiles = (P.n_tokens + QG_TOK - 1) / QG_TOK;
     const int nchunks = (P.cols / 32 + QG_KC - 1) / QG_KC;
     // split K until ~128 workgroups exist (small-N decode batches would otherwise leave most CUs idle)
+    const int mats = P.q1 ? 2 : 1;
+    P.row_groups = row_groups;
     int ks = 1;
     if (part_buf && P.ldo == P.rows) {
-        while (row_groups * tok_tiles * ks < 128 && ks * 2 <= nchunks && ks < 16) ks *= 2;
+        while (row_groups * mats * tok_tiles * ks < 128 && ks * 2 <= nchunks && ks < 16) ks *= 2;
         while (ks > 1 && (size_t)ks * P.n_tokens * P.ldo > part_cap) ks /= 2;
     }
     P.ksplit = ks;
     P.part = part_buf;
-    dim3 grid(row_groups, tok_tiles, ks);
+    dim3 grid(row_groups * mats, tok_tiles, ks);
     switch (wtype) {
     case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
     case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
     default: return hipErrorInvalidValue;
     }
     hipError_t s = hipGetLastError();
+    if (ks_out) { *ks_out = ks; return s; }     // the consumer kernel adds the slabs (GemmOut, nl_batch.h)
     if (s != hipSuccess || ks == 1) return s;
     const long long count = (long long)P.n_tokens * P.ldo;
     hipLaunchKernelGGL(qgemm_sum_kernel, dim3((unsigned)std::min<long long>((count + 255) / 256, 2048)), dim3(256), 0, st,
@@ -615,17 +619,23 @@ int batch_alloc(nl_engine *e) {
     if (e->bt.ready) return NL_OK;
     const nl_config &c = e->cfg;
     nl_engine::Batch &b = e->bt;
-    b.cap = 512;        // tokens per multi-token step (prefill tiles); the LM head runs on <= 64 of them
+    // tokens per multi-token step: a whole prompt when it fits (one launch per op and layer, enough workgroups
+    // that no GEMM needs split-K); halved until the activation set stays under 4 GiB.  The LM head runs on
+    // <= 64 of them.
+    const size_t R = (size_t)(e->Hs + 2 * e->KVs) * e->hd, HQ = (size_t)e->Hs * e->hd;
+    b.cap = std::min(2048, ((c.seq_len + QG_TOK - 1) / QG_TOK) * QG_TOK);
+    {
+        const size_t per_tok = 4 * (2 * (size_t)c.dim + R + 2 * HQ + 3 * (size_t)e->Is + (size_t)e->Hs * e->nsplit_max * (e->hd + 2) +
+                                    std::max<size_t>(std::max<size_t>(HQ, c.dim), e->Is));
+        while (b.cap > 512 && per_tok * b.cap > ((size_t)4 << 30)) b.cap /= 2;
+    }
     b.lm_cap = QG_TOK;
-    const size_t n = b.cap, R = (size_t)(e->Hs + 2 * e->KVs) * e->hd, HQ = (size_t)e->Hs * e->hd;
+    const size_t n = b.cap;
     HIPCK(e, dalloc(&b.x, n * c.dim, &e->bytes_state));
-    HIPCK(e, dalloc(&b.xn, n * c.dim, &e->bytes_state));
     HIPCK(e, dalloc(&b.qkv, n * R, &e->bytes_state));
     HIPCK(e, dalloc(&b.q, n * HQ, &e->bytes_state));
-    HIPCK(e, dalloc(&b.att, n * HQ, &e->bytes_state));
     HIPCK(e, dalloc(&b.g, n * e->Is, &e->bytes_state));
     HIPCK(e, dalloc(&b.u, n * e->Is, &e->bytes_state));
-    HIPCK(e, dalloc(&b.h, n * e->Is, &e->bytes_state));
     HIPCK(e, dalloc(&b.logits, (size_t)b.lm_cap * c.vocab, &e->bytes_state));
     {
         const size_t nx = xfrag_uint4((int)std::max<size_t>(std::max<size_t>(HQ, c.dim), e->Is), (int)n);
@@ -635,6 +645,7 @@ int batch_alloc(nl_engine *e) {
     }
     b.kpart_cap = (size_t)16 * QG_TOK * std::max<size_t>(std::max<size_t>(R, c.dim), e->Is);
     HIPCK(e, dalloc(&b.kpart, b.kpart_cap, &e->bytes_state));
+    HIPCK(e, dalloc(&b.kpart2, b.kpart_cap, &e->bytes_state));
     HIPCK(e, dalloc(&b.part_o, n * e->Hs * e->nsplit_max * e->hd, &e->bytes_state));
     HIPCK(e, dalloc(&b.part_ml, n * e->Hs * e->nsplit_max * 2, &e->bytes_state));
     HIPCK(e, dalloc(&b.tok, n, &e->bytes_state));
@@ -646,17 +657,25 @@ int batch_alloc(nl_engine *e) {
     return NL_OK;
 }
 
-hipError_t qg(nl_engine *e, const PackedMat &m, const float *x, int ldx, int n, float *out, int ldo, const float *resid,
-              hipStream_t st, const float *bias = nullptr) {
+// GEMM of the multi-token step: input = the fragment store the producing kernel just filled; output = `out`
+// (with resid / bias applied) when it ran unsplit, else split-K slabs in `part` for the consumer to add.
+hipError_t qg(nl_engine *e, const PackedMat &m, int n, float *out, int ldo, const float *resid, hipStream_t st,
+              GemmOut *res, float *part, const float *bias = nullptr) {
     QGemmParams P{};
     P.bias = bias;
     P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
     P.xf = e->bt.xfrag; P.n_tokens = n; P.out = out; P.ldo = ldo; P.resid = resid;
-    if (x) {   // x == nullptr: the fragments of the previous call are reused (gate and up share their input)
-        hipError_t s = launch_xsplit(m.wtype, x, ldx, m.cols, n, e->bt.xfrag, st);
-        if (s != hipSuccess) return s;
-    }
-    return launch_qgemm(m.wtype, P, st, e->bt.kpart, e->bt.kpart_cap);
+    int ks = 1;
+    hipError_t s = launch_qgemm(m.wtype, P, st, part, e->bt.kpart_cap, &ks);
+    *res = GemmOut{out, part, ks, (long long)n * ldo, bias};
+    return s;
+}
+
+hipError_t launch_qgemm_plain(nl_engine *e, const PackedMat &m, int n, float *out, int ldo, hipStream_t st) {
+    QGemmParams P{};
+    P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
+    P.xf = e->bt.xfrag; P.n_tokens = n; P.out = out; P.ldo = ldo;
+    return launch_qgemm(m.wtype, P, st, e->bt.kpart, e->bt.kpart_cap);   // split-K + its own sum launch
 }
 
 // One multi-token step: n <= 64 (token, pos, stream) triples through every layer on the MFMA path.
@@ -676,15 +695,23 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
         hipLaunchKernelGGL(bembed_kernel, dim3(n), dim3(256), 0, st, P);
         LCK(hipGetLastError());
     }
+    const int nt16 = ((n + 63) / 64) * 4;
+    GemmOut pend{nullptr, nullptr, 1, 0, nullptr};   // GEMM output not yet folded into the residual stream
+    auto norm = [&](const float *w, const PackedMat &next, int item0, int cnt) {
+        BNormParams P{b.x, pend, w, c.rms_eps, D, item0, b.xfrag, ((cnt + 63) / 64) * 4, next.wtype == WT_Q4_0 ? 1 : 0};
+        hipLaunchKernelGGL(bnorm_kernel, dim3(cnt), dim3(256), 0, st, P);
+        pend = GemmOut{nullptr, nullptr, 1, 0, nullptr};
+        return hipGetLastError();
+    };
     for (int l = 0; l < c.n_layers; l++) {
         nl_engine::Layer &L = e->layers[l];
         float *kc = e->kcache + (long long)l * e->kv_layer_stride;
         float *vc = e->vcache + (long long)l * e->kv_layer_stride;
-        hipLaunchKernelGGL(brmsnorm_kernel, dim3(n), dim3(256), 0, st, b.x, L.attn_norm, c.rms_eps, b.xn, D);
-        LCK(hipGetLastError());
-        LCK(qg(e, L.qkv, b.xn, D, n, b.qkv, R, nullptr, st));
+        LCK(norm(L.attn_norm, L.qkv, 0, n));
+        GemmOut qkv;
+        LCK(qg(e, L.qkv, n, b.qkv, R, nullptr, st, &qkv, b.kpart));
         {
-            BRopeParams P{b.qkv, R, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate, c.qk_norm, c.rms_eps, b.pos, b.stream,
+            BRopeParams P{qkv, R, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate, c.qk_norm, c.rms_eps, b.pos, b.stream,
                           e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride, L.bq, L.bk, L.bv};
             hipLaunchKernelGGL(brope_kv_kernel, dim3(n), dim3(256), (size_t)R * 4, st, P);
             LCK(hipGetLastError());
@@ -700,31 +727,40 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
             } else {
                 LCK(launch_attn(hd, e->gqa, P, dim3(e->KVs, e->nsplit_max, n), st));
             }
-            BMergeParams M{b.part_o, b.part_ml, b.pos, e->Hs, e->nsplit_max, hd, b.att};
+            BMergeParams M{b.part_o, b.part_ml, b.pos, e->Hs, e->nsplit_max, hd, b.xfrag, nt16, L.wo.wtype == WT_Q4_0 ? 1 : 0};
             hipLaunchKernelGGL(battn_merge_kernel, dim3(n), dim3(256), 0, st, M);
             LCK(hipGetLastError());
         }
-        LCK(qg(e, L.wo, b.att, HQ, n, b.x, D, b.x, st, L.bo));
-        hipLaunchKernelGGL(brmsnorm_kernel, dim3(n), dim3(256), 0, st, b.x, L.ffn_norm, c.rms_eps, b.xn, D);
-        LCK(hipGetLastError());
-        LCK(qg(e, L.gate, b.xn, D, n, b.g, e->Is, nullptr, st));
-        LCK(qg(e, L.up, L.up.wtype == L.gate.wtype ? nullptr : b.xn, D, n, b.u, e->Is, nullptr, st));
+        LCK(qg(e, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo));
+        LCK(norm(L.ffn_norm, L.gate, 0, n));
+        GemmOut gate, up;
+        if (L.up.wtype != L.gate.wtype)   // (a mixed-type file: the fragment k-slot order differs per type)
+            return e->fail(NL_ERR_UNSUPPORTED, "gate and up projections of different quantisation types");
+        {   // gate and up in ONE launch: same input fragments, twice the workgroups, half the split-K
+            QGemmParams P{};
+            const PackedMat &m = L.gate;
+            P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
+            P.xf = b.xfrag; P.n_tokens = n; P.out = b.g; P.ldo = e->Is;
+            P.q1 = L.up.q; P.s1 = L.up.s; P.out1 = b.u; P.part1 = b.kpart2;
+            int ks = 1;
+            LCK(launch_qgemm(m.wtype, P, st, b.kpart, b.kpart_cap, &ks));
+            gate = GemmOut{b.g, b.kpart, ks, (long long)n * e->Is, nullptr};
+            up = GemmOut{b.u, b.kpart2, ks, (long long)n * e->Is, nullptr};
+        }
         {
-            long long tot = (long long)n * e->Is;
-            hipLaunchKernelGGL(bswiglu_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 4096)), dim3(256), 0, st,
-                               b.g, b.u, b.h, tot);
+            BSwigluParams P{gate, up, e->Is, n, b.xfrag, nt16, L.down.wtype == WT_Q4_0 ? 1 : 0};
+            const long long tot = (long long)n * e->Is / 8;
+            hipLaunchKernelGGL(bswiglu_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 4096)), dim3(256), 0, st, P);
             LCK(hipGetLastError());
         }
-        LCK(qg(e, L.down, b.h, e->Is, n, b.x, D, b.x, st));
+        LCK(qg(e, L.down, n, b.x, D, b.x, st, &pend, b.kpart));
     }
     if (lm_mode) {
         // logits rows [0, cnt) of bt.logits / ids [0, cnt): all tokens (mode 1, n <= lm_cap) or just the last (mode 2)
         const int first = lm_mode == 2 ? n - 1 : 0, cnt = lm_mode == 2 ? 1 : n;
         if (cnt > b.lm_cap) return e->fail(NL_ERR_INVALID, "LM head batch %d exceeds %d", cnt, b.lm_cap);
-        hipLaunchKernelGGL(brmsnorm_kernel, dim3(cnt), dim3(256), 0, st, b.x + (size_t)first * D, e->output_norm, c.rms_eps,
-                           b.xn + (size_t)first * D, D);
-        LCK(hipGetLastError());
-        LCK(qg(e, e->lm_head, b.xn + (size_t)first * D, D, cnt, b.logits, c.vocab, nullptr, st));
+        LCK(norm(e->output_norm, e->lm_head, first, cnt));
+        LCK(launch_qgemm_plain(e, e->lm_head, cnt, b.logits, c.vocab, st));
         hipLaunchKernelGGL(bargmax_kernel, dim3(cnt), dim3(1024), 0, st, b.logits, c.vocab, b.ids);
         LCK(hipGetLastError());
     }
@@ -1089,7 +1125,7 @@ int nl_destroy(nl_handle e) {
     if (e->stage) hipFree(e->stage);
     {
         nl_engine::Batch &b = e->bt;
-        void *bb[] = {b.x, b.xn, b.qkv, b.q, b.att, b.g, b.u, b.h, b.logits, b.part_o, b.part_ml, b.tok, b.pos, b.stream, b.ids, b.kpart, b.xfrag};
+        void *bb[] = {b.x, b.qkv, b.q, b.g, b.u, b.logits, b.part_o, b.part_ml, b.tok, b.pos, b.stream, b.ids, b.kpart, b.kpart2, b.xfrag};
         for (void *p : bb) if (p) hipFree(p);
         if (b.h_meta) hipHostFree(b.h_meta);
     }

@@ -46,6 +46,12 @@ struct QGemmParams {
     // part[z][N][ldo] and qgemm_sum_kernel adds them in a fixed order (deterministic, no atomics)
     int ksplit;
     float *part;
+    // optional second matrix of the same shape and type sharing the input (gate + up in one launch): workgroup
+    // columns [row_groups, 2*row_groups) run it and write out1 / part1
+    const uint8_t *q1;
+    const uint32_t *s1;
+    float *out1, *part1;
+    int row_groups;
 };
 
 inline size_t xfrag_uint4(int cols, int n_tokens) {   // uint4 elements of a fragment store
@@ -175,7 +181,11 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
     const int tok0 = blockIdx.y * QG_TOK;
     const int nblocks = P.cols / 32;
     const int nchunks = (nblocks + QG_KC - 1) / QG_KC;
-    const int tile0 = (blockIdx.x * QG_WAVES + wave) * QG_RT;
+    const bool second = P.q1 && (int)blockIdx.x >= P.row_groups;
+    const uint8_t *const Wq = second ? P.q1 : P.q;
+    const uint32_t *const Ws = second ? P.s1 : P.s;
+    float *const outp = second ? P.out1 : P.out, *const partp = second ? P.part1 : P.part;
+    const int tile0 = (((int)blockIdx.x - (second ? P.row_groups : 0)) * QG_WAVES + wave) * QG_RT;
     const uint4 *xsrc = P.xf + (long long)blockIdx.y * (8 * QG_FRAG) + lane;   // + block * nt16 * 2 * QG_FRAG
 
     f32x4_t acc[QG_RT][4];
@@ -207,8 +217,8 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
 #pragma unroll
             for (int b = 0; b < QG_KC; b++) {
                 const int blk = min(b0 + b, nblocks - 1);
-                wq[rt][b] = WFrag<WT>::raw(P.q, tp0, P.npairs, blk, li, lw);
-                wd[rt][b] = load_scale_word<WT>(P.s, tp0, P.npairs, blk, li);   // tiles past ntiles are never stored
+                wq[rt][b] = WFrag<WT>::raw(Wq, tp0, P.npairs, blk, li, lw);
+                wd[rt][b] = load_scale_word<WT>(Ws, tp0, P.npairs, blk, li);   // tiles past ntiles are never stored
             }
         }
     };
@@ -292,7 +302,7 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int n = tok0 + t * 16 + lw * 4 + j;
-                    if (n < P.n_tokens) P.part[((long long)blockIdx.z * P.n_tokens + n) * P.ldo + row] = acc[rt][t][j];
+                    if (n < P.n_tokens) partp[((long long)blockIdx.z * P.n_tokens + n) * P.ldo + row] = acc[rt][t][j];
                 }
             continue;
         }
@@ -313,7 +323,7 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
                 float v = acc[rt][t][j];
                 if (P.bias) v += bv;
                 if (P.resid) v += rv[t][j];
-                if (n < P.n_tokens) P.out[(long long)n * P.ldo + row] = v;
+                if (n < P.n_tokens) outp[(long long)n * P.ldo + row] = v;
             }
     }
 }
