@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnanollama_hip.so")
+LIB_PATH = os.environ.get("NL_LIB_PATH") or os.path.join(_HERE, "libnanollama_hip.so")  # NL_LIB_PATH: A/B builds (tools/)
 NL_NUM_KINDS = 8
 NL_COMM_ID_BYTES = 128
 NL_FLAG_NO_GRAPH = 1

@@ -295,6 +295,7 @@ void choose_geometry(const nl_engine *e, const PackedMat &m, int &tw, int &kw, i
 
 template <int PRO, int EPI>
 hipError_t launch_gemv_t(int wtype, GemvParams P, hipStream_t st) {
+    P.add_src = P.add ? P.add : P.x;   // PRO_ATTN kernels never read it
     const int nwaves = P.tw * P.kw * (EPI == EPI_SWIGLU ? 2 : 1);
     const size_t lds = (size_t)nwaves * XS_WAVE * 4 + (size_t)nwaves * TR * 4 + (size_t)nwaves * 8;
     const dim3 grid((P.ntiles + P.tw - 1) / P.tw), block(nwaves * 64);

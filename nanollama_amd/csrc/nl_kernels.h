@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace nl {
 
@@ -399,6 +400,7 @@ struct GemvParams {
     // prologue: input vector
     const float *x;      // PRO_PLAIN / PRO_NORM input [cols]
     const float *add;    // optional addend (tensor-parallel: all-reduced partial of the previous block)
+    const float *add_src;  // what the kernel actually loads: add, or x when there is no addend (set by launch_gemv_t)
     float *x_out;        // optional: block 0 writes x (+ add) here (the updated residual stream)
     const float *normw;  // PRO_NORM weights
     float eps;
@@ -463,23 +465,28 @@ constexpr int XS_PAIR = PAIR + 4;            // LDS floats per pair (16-byte pad
 constexpr int XS_WAVE = KL * XS_PAIR;        // LDS floats per wavefront (one 256-column group)
 
 // The 4 input-vector elements (columns col..col+3) this lane stages for its wavefront's current group.
+// BRANCH-FREE on purpose: the caller passes an in-range column (clamped) and zeroes the result itself.  An early
+// "if (col >= cols) return 0" makes every loaded value a phi, and hipcc then waits vmcnt(0) INSIDE the branch --
+// i.e. the x / norm-weight round trip completed before the first weight load was even issued.
 template <int PRO>
-__device__ __forceinline__ float4 load_x4(const GemvParams &P, int col, float4 &g, int ns) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+__device__ __forceinline__ float4 load_x4(const GemvParams &P, int col, float4 &g, float4 &addv, int ns) {
     g = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (col >= P.cols) return v;
+    addv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (PRO == PRO_ATTN) {
-        // merge the position-split attention partials (online softmax): x = sum_c w_c o_c / sum_c w_c l_c
+        // merge the position-split attention partials (online softmax): x = sum_c w_c o_c / sum_c w_c l_c.
+        // Split 0 is fetched unconditionally; the loop over further splits only runs once pos >= 128.
         const int hd = P.head_dim, h = col / hd, d = col - h * hd;
         const float *ml = P.part_ml + (long long)h * P.nsplit_max * 2;
         const float *po = P.part_o + (long long)h * P.nsplit_max * hd + d;
+        const float4 o0 = *reinterpret_cast<const float4 *>(po);
+        const float m0 = ml[0], l0 = ml[1];
         if (ns == 1) {
-            float4 o = *reinterpret_cast<const float4 *>(po);
-            float il = 1.0f / ml[1];
-            return make_float4(o.x * il, o.y * il, o.z * il, o.w * il);
+            float il = 1.0f / l0;
+            return make_float4(o0.x * il, o0.y * il, o0.z * il, o0.w * il);
         }
-        float M = ml[0];
+        float M = m0;
         for (int c = 1; c < ns; c++) M = fmaxf(M, ml[2 * c]);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         float L = 0.f;
         for (int c = 0; c < ns; c++) {
             float w = (float)exp((double)(ml[2 * c] - M));
@@ -490,12 +497,12 @@ __device__ __forceinline__ float4 load_x4(const GemvParams &P, int col, float4 &
         float il = 1.0f / L;
         return make_float4(v.x * il, v.y * il, v.z * il, v.w * il);
     }
-    v = *reinterpret_cast<const float4 *>(P.x + col);
+    float4 v = *reinterpret_cast<const float4 *>(P.x + col);
     if (PRO == PRO_NORM) g = *reinterpret_cast<const float4 *>(P.normw + col);
-    if (P.add) {
-        float4 a = *reinterpret_cast<const float4 *>(P.add + col);
-        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-    }
+    // optional addend (gamma row / tensor-parallel residual): always LOADED (from x itself when absent: same
+    // cache line, the launcher resolves
+    // the pointer so there is no select here for hipcc to turn back into a branch) and handed back; the caller adds it when it consumes x, after every load of the round is out
+    addv = *reinterpret_cast<const float4 *>(P.add_src + col);
     return v;
 }
 
@@ -589,43 +596,57 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
 #else
     constexpr int NF = CPP <= 8 ? 2 : 1;  // 4 in flight for Q4_0 cost occupancy: 5.36 -> 4.77 TB/s on big's LM head
 #endif
-    for (int g0 = kw; g0 < ngroups; g0 += NF * P.kw) {
-        float4 xv[NF], gv[NF];
-        uint4 cw[NF][CPP];
-        uint2 sw[NF];
-        bool lv[NF];
+    // One round = NFR groups of this wavefront.  ALL loads of the round are issued before anything consumes one,
+    // activations first (L2-resident: the staging below starts while the weights are still streaming in), and
+    // none sits behind a branch: out-of-range lanes load a clamped address and are masked at the use.
+    auto round = [&](auto nf_tag, int g0) {
+        constexpr int NFR = decltype(nf_tag)::value;
+        float4 xv[NFR], gv[NFR], av[NFR];
+        uint4 cw[NFR][CPP];
+        uint2 sw[NFR];
+        bool lv[NFR], inb[NFR];
 #pragma unroll
-        for (int f = 0; f < NF; f++) {
+        for (int f = 0; f < NFR; f++) {
+            const int col = (g0 + f * P.kw) * (KL * PAIR) + lane * 4;
+            inb[f] = col < P.cols;
+            xv[f] = load_x4<PRO>(P, inb[f] ? col : 0, gv[f], av[f], ns);
+        }
+#pragma unroll
+        for (int f = 0; f < NFR; f++) {
             const int g = g0 + f * P.kw;
-            const bool has = g < ngroups;
-            const int gs = has ? min(KL, P.npairs - g * KL) : 0;
+            const int gs = min(KL, P.npairs - g * KL);
             lv[f] = live && k < gs;
-            sw[f] = make_uint2(0u, 0u);
-            xv[f] = has ? load_x4<PRO>(P, g * (KL * PAIR) + lane * 4, gv[f], ns) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (lv[f]) load_pair<WT>(Wq, Ws, tp0, g, gs, r, k, cw[f], sw[f]);
+            load_pair<WT>(Wq, Ws, tp0, g, gs, r, min(k, gs - 1), cw[f], sw[f]);
         }
 #pragma unroll
-        for (int f = 0; f < NF; f++) {
+        for (int f = 0; f < NFR; f++) {
             const int g = g0 + f * P.kw;
-            if (g < ngroups) {
-                float4 xa = xv[f];
-                if (PRO == PRO_NORM) {
-                    // RMSNormInto go/quant.go:597-607.  inv = 1/sqrt(mean(x^2)+eps) multiplies the GEMV OUTPUT
-                    // (out = inv * sum_j w_ij (x_j g_j)), so its float64 reduction is off the critical path.
-                    if (tin == 0 && msel == 0) {
-                        ss += (double)xa.x * (double)xa.x; ss += (double)xa.y * (double)xa.y;
-                        ss += (double)xa.z * (double)xa.z; ss += (double)xa.w * (double)xa.w;
-                        if (P.x_out && blockIdx.x == 0 && g * (KL * PAIR) + lane * 4 < P.cols)
-                            *reinterpret_cast<float4 *>(P.x_out + g * (KL * PAIR) + lane * 4) = xa;
-                    }
-                    xa.x *= gv[f].x; xa.y *= gv[f].y; xa.z *= gv[f].z; xa.w *= gv[f].w;
+            float4 xa = xv[f];
+            if (PRO != PRO_ATTN && P.add) { xa.x += av[f].x; xa.y += av[f].y; xa.z += av[f].z; xa.w += av[f].w; }
+            if (!inb[f]) xa = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PRO == PRO_NORM) {
+                // RMSNormInto go/quant.go:597-607.  inv = 1/sqrt(mean(x^2)+eps) multiplies the GEMV OUTPUT
+                // (out = inv * sum_j w_ij (x_j g_j)), so its float64 reduction is off the critical path.
+                if (tin == 0 && msel == 0) {
+                    ss += (double)xa.x * (double)xa.x; ss += (double)xa.y * (double)xa.y;
+                    ss += (double)xa.z * (double)xa.z; ss += (double)xa.w * (double)xa.w;
+                    if (P.x_out && blockIdx.x == 0 && inb[f])
+                        *reinterpret_cast<float4 *>(P.x_out + g * (KL * PAIR) + lane * 4) = xa;
                 }
-                *reinterpret_cast<float4 *>(xs + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
-                __builtin_amdgcn_wave_barrier();
-                if (lv[f]) acc0 = PairDot<WT>::run(cw[f], sw[f], xs + k * XS_PAIR, acc0);
-                __builtin_amdgcn_wave_barrier();
+                xa.x *= gv[f].x; xa.y *= gv[f].y; xa.z *= gv[f].z; xa.w *= gv[f].w;
             }
+            *reinterpret_cast<float4 *>(xs + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
+            __builtin_amdgcn_wave_barrier();
+            const float a1 = PairDot<WT>::run(cw[f], sw[f], xs + k * XS_PAIR, acc0);
+            acc0 = lv[f] ? a1 : acc0;
+            __builtin_amdgcn_wave_barrier();
         }
+    };
+    {
+        int g0 = kw;
+        if (NF > 1)
+            for (; g0 + (NF - 1) * P.kw < ngroups; g0 += NF * P.kw) round(std::integral_constant<int, NF>{}, g0);
+        for (; g0 < ngroups; g0 += P.kw) round(std::integral_constant<int, 1>{}, g0);
     }
     NL_STAMP(4);
     // the 4 pair-lanes of a row form a quad
