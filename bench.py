@@ -157,7 +157,9 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True):
         traffic = tj.get(f"{tier}_{wtype}") if world == 1 else None
     except (OSError, ValueError):
         pass
-    dom = max((k for k in kernels if k != "argmax"), key=lambda k: prof[k][0])
+    # dominant kernel = the kind that moves the most algorithmic bytes per step (stable from run to run; for the
+    # launch-bound nano tier the five per-layer kinds have near-equal time shares and a time ranking flips)
+    dom = max((k for k in kernels if k != "argmax"), key=lambda k: kb[k] * prof[k][1])
     dom_gbs = kernels[dom]["GBps"]
     mean_pos = pos0 + (min(SEGMENT, steps) - 1) / 2.0
     step_bytes = synth.weight_bytes_per_token(shape, wtype) + synth.kv_bytes_per_token(shape, int(mean_pos))
@@ -184,12 +186,16 @@ def side_configs(model):
     g = gguf.load_gguf(ensure_gguf(shape, "q4_0", "qrand"))
     dev = model.load_llama_model(g)
     toks = synth.prompt_ids(2047, shape.vocab)
-    dev.prefill(toks[:128])
+    dev.prefill(toks)              # warm-up: allocates and first-touches the 2048-token step buffers
     dev.synchronize()
-    t0 = time.perf_counter()
-    dev.prefill(toks)
-    dt = time.perf_counter() - t0
+    dt = 1e9
+    for _ in range(3):             # steady state (a server's n-th prompt), host wall clock incl. logits read-back
+        dev.reset()
+        t0 = time.perf_counter()
+        dev.prefill(toks)
+        dt = min(dt, time.perf_counter() - t0)
     first = int(np.argmax(dev.state.logits))
+    dev.decode_greedy(first, 2047, 1)   # first replay uploads the graph
     t1 = time.perf_counter()
     dev.decode_greedy(first, 2047, 1)
     dt1 = time.perf_counter() - t1
