@@ -110,8 +110,11 @@ NL_API int nl_decode_greedy(nl_handle h, int stream, int token, int pos, int n_s
 
 /* Prompt prefill (go/main.go:160-166 feeds the prompt token-at-a-time through Forward): runs
  * tokens[0..n) at positions pos0..pos0+n-1 of `stream` back to back on the device with no host
- * round trip; last_logits_out (may be NULL) receives the logits after the last token.  Results are
- * bitwise those of n nl_forward calls.  pos0 + n must be <= seq_len. */
+ * round trip; last_logits_out (may be NULL) receives the logits after the last token.  Q4_0 / Q8_0
+ * models take the multi-token matrix-core path (up to 2048 tokens per step): the KV
+ * cache and logits agree with n nl_forward calls to the stated logit tolerance (1e-4, summation order
+ * and an fp16 hi+lo activation split differ), greedy continuations are identical; other formats run
+ * the single-token plan n times (bitwise equal).  pos0 + n must be <= seq_len. */
 NL_API int nl_prefill(nl_handle h, int stream, const int *tokens, int n, int pos0, float *last_logits_out);
 /* One Forward for each of n (stream, token, pos) triples -- the concurrent decode streams of a
  * serving host.  logits_out (may be NULL) is n x vocab; next_ids (may be NULL) receives each
