@@ -24,8 +24,14 @@ constexpr int QG_TOK = 64;      // tokens per workgroup tile (4 MFMA column tile
 #define NL_QG_OCC 2
 #endif
 constexpr int QG_KC = NL_QG_KC;  // 32-element blocks per K chunk (128 columns)
-constexpr int QG_WAVES = 4;
-constexpr int QG_RT = 2;        // 16-row weight tiles per wavefront
+#ifndef NL_QG_WAVES
+#define NL_QG_WAVES 4
+#endif
+#ifndef NL_QG_RT
+#define NL_QG_RT 2
+#endif
+constexpr int QG_WAVES = NL_QG_WAVES;
+constexpr int QG_RT = NL_QG_RT;  // 16-row weight tiles per wavefront
 constexpr int QG_FRAG = 64;     // uint4 per activation fragment: 64 lanes x 16 bytes, lane-linear (= one LDS-DMA)
 
 // Activation fragments live in global memory in MFMA operand order, produced ONCE per activation matrix
@@ -199,8 +205,9 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
     // hipcc wait vmcnt(0) after every load -- one dependent memory round trip per block instead of one per chunk.
     auto stage = [&](int chunk, int buf) {
         const int b0 = chunk * QG_KC;
+        static_assert((8 * QG_KC) % QG_WAVES == 0, "fragments of a chunk divide evenly over the wavefronts");
 #pragma unroll
-        for (int i = 0; i < 2 * QG_KC; i++) {
+        for (int i = 0; i < 8 * QG_KC / QG_WAVES; i++) {
             const int f = wave + QG_WAVES * i;        // fragment of the chunk: block f/8, (tile, part) f%8
             const int blk = min(b0 + (f >> 3), nblocks - 1);
             __builtin_amdgcn_global_load_lds(

@@ -405,6 +405,65 @@ def test_prefill_attention_tiles_every_gqa_ratio(hip, orc, tmp_path, heads, kv, 
     dev.close()
 
 
+def test_mini_full_size_long_prefill_matches_oracle(hip, orc, tmp_path):
+    # BASELINE.json configs[2] at its own shape (mini, 173M, Q4_0): a 1920-token prompt through the matrix-core
+    # path in ONE step vs the CPU oracle fed token by token (1920 prompt positions for parity), then a
+    # greedy continuation on the decode path from the cache the prefill wrote.
+    shape = synth.TIERS["mini"]
+    p = tmp_path / "mini.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", mode="float")
+    g = gguf.load_gguf(str(p))
+    dev = hip.load_llama_model(g)
+    ref = orc.OracleModel(g)
+    toks = synth.prompt_ids(1920, shape.vocab, seed=6)
+    orc.set_threads(min(32, os.cpu_count() or 1))
+    for pos, t in enumerate(toks):
+        want = ref.forward(t, pos)
+    dev.prefill(toks)
+    err = float(np.abs(dev.state.logits - want).max())
+    scale = max(1.0, float(want.std()))
+    print(f"\nmini 1920-token prefill: max|gpu-oracle|={err:.2e} (logit std {scale:.2f})")
+    assert err <= LOGIT_TOL * scale
+    cur = int(np.argmax(want))
+    ids = dev.decode_greedy(cur, len(toks), 8)
+    ref_ids = []
+    for k in range(8):
+        cur = int(np.argmax(ref.forward(cur, len(toks) + k)))
+        ref_ids.append(cur)
+    orc.set_threads(1)
+    assert ids == ref_ids
+    dev.close()
+
+
+def test_full_length_prefill_is_consistent_with_the_decode_path(hip, tmp_path):
+    # BASELINE size (2047 prompt positions, the most the Go loop prefills): properties that do not need the oracle.
+    # (1) one 2047-token step == a 1000-token step followed by a 1047-token step (pos0 > 0, different tiling);
+    # (2) == 2040 tokens through the matrix-core path + 7 tokens through the single-token decode kernels.
+    shape = synth.TIERS["mini"]
+    p = tmp_path / "mini.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", mode="qrand")
+    g = gguf.load_gguf(str(p))
+    toks = synth.prompt_ids(2047, shape.vocab, seed=8)
+    a = hip.load_llama_model(g)
+    a.prefill(toks)
+    la = a.state.logits.copy()
+    scale = max(1.0, float(la.std()))
+    a.reset()
+    a.prefill(toks[:1000], want_logits=False)
+    a.prefill(toks[1000:], pos0=1000)
+    assert np.abs(a.state.logits - la).max() <= LOGIT_TOL * scale
+    a.reset()
+    a.prefill(toks[:2040], want_logits=False)
+    for i in range(2040, 2047):
+        a.forward(toks[i], i)
+    assert np.abs(a.state.logits - la).max() <= LOGIT_TOL * scale
+    assert int(np.argmax(a.state.logits)) == int(np.argmax(la))
+    from nanollama_amd._lib import NlError
+    with pytest.raises(NlError, match="exceeds seq_len"):
+        a.prefill([1, 2], pos0=2047)
+    a.close()
+
+
 def test_forward_batch_matches_individual_forwards(hip):
     g = gguf.load_gguf(os.path.join(GOLDEN, "tiny_q8_0.gguf"))
     dev = hip.load_llama_model(g, max_streams=4)
