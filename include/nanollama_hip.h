@@ -108,6 +108,24 @@ NL_API int nl_forward_argmax(nl_handle h, int stream, int token, int pos, int *n
  * count in *n_done) when pos reaches seq_len, as go/main.go:216 does. */
 NL_API int nl_decode_greedy(nl_handle h, int stream, int token, int pos, int n_steps, int *ids_out, int *n_done);
 
+/* The sampling half of Engine.Generate's decode loop (go/main.go:173-219) on the device, for temp > 0 and / or
+ * rep_penalty > 1: starting from the logits the last nl_forward / nl_prefill of `stream` left on the device
+ * (those of position pos - 1), repeat n_steps times { repetition penalty over the recent window (:177-187);
+ * sampleTopP when top_p < 1, else sampleTopK (:191-195, :294-398; temp <= 0 -> argmax); append to the window
+ * (:197-200); Forward(sampled, pos++) (:213) } with no host round trip and no read-back of the V logits.
+ * uniforms[i] (float32 in [0,1)) is the e.rng.Float32() of step i -- the host owns the generator.
+ * recent / n_recent (in/out, capacity rep_window <= 1024) is recentTokens.  ids_out[i] is the id sampled at
+ * step i; the caller applies the EOS stop (:203) by truncating (steps after an EOS are wasted work, so call in
+ * chunks).  Stops early, *n_done < n_steps, when pos reaches seq_len (:216). */
+typedef struct {
+    float temperature, top_p;
+    int32_t top_k;
+    float rep_penalty;
+    int32_t rep_window;
+} nl_sample_params;
+NL_API int nl_sample_decode(nl_handle h, int stream, int pos, int n_steps, const nl_sample_params *p,
+                            const float *uniforms, int *recent, int *n_recent, int *ids_out, int *n_done);
+
 /* Prompt prefill (go/main.go:160-166 feeds the prompt token-at-a-time through Forward): runs
  * tokens[0..n) at positions pos0..pos0+n-1 of `stream` back to back on the device with no host
  * round trip; last_logits_out (may be NULL) receives the logits after the last token.  Q4_0 / Q8_0
@@ -156,6 +174,12 @@ NL_API int nl_op_matmul_batch(int device, uint32_t ggml_type, const void *w, uin
                                float *out, int rows, int cols, int n_tokens);
 /* RMSNormInto (go/quant.go:597-607). */
 NL_API int nl_op_rmsnorm(int device, const float *x, const float *w, float eps, float *out, int n);
+
+/* Sampling operator on host logits: one decision of sampleTopP / sampleTopK / argmax (go/main.go:294-408)
+ * after the in-place repetition penalty (:177-187), on the device.  logits (in/out: the penalty is applied in
+ * place, as in the reference) is [vocab]; recent (in/out, capacity rep_window) / n_recent follow :197-200. */
+NL_API int nl_op_sample(int device, float *logits, int vocab, const nl_sample_params *p, float uniform,
+                        int *recent, int *n_recent, int *picked);
 
 /* == tensor-parallel communicator (RCCL over xGMI) ========================= */
 #define NL_COMM_ID_BYTES 128

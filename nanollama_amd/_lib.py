@@ -28,6 +28,12 @@ class NlConfig(C.Structure):
                                          "flags")]
 
 
+class NlSampleParams(C.Structure):
+    """nl_sample_params: the knobs of Engine.Generate's sampling branch (go/main.go:29-34, :135-140)."""
+    _fields_ = [("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_int32), ("rep_penalty", C.c_float),
+                ("rep_window", C.c_int32)]
+
+
 class NlError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"{STATUS.get(code, code)}: {msg}")
@@ -37,7 +43,7 @@ class NlError(RuntimeError):
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("nl_engine.hip", "nl_kernels.h", "nl_qgemm.h", "nl_batch.h")] + \
+    srcs = [os.path.join(src_dir, f) for f in ("nl_engine.hip", "nl_kernels.h", "nl_qgemm.h", "nl_batch.h", "nl_sample.h")] + \
            [os.path.join(os.path.dirname(_HERE), "include", "nanollama_hip.h")]
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
@@ -51,7 +57,7 @@ EXPORTS = ["nl_set_gamma", "nl_abi_version", "nl_device_count", "nl_create", "nl
            "nl_last_error", "nl_reset", "nl_forward", "nl_forward_argmax", "nl_decode_greedy", "nl_prefill", "nl_forward_batch", "nl_get_config",
            "nl_synchronize", "nl_timer_start", "nl_timer_stop", "nl_kernel_kind_name", "nl_profile_forward",
            "nl_memory_usage", "nl_debug_read", "nl_op_matmul", "nl_op_matmul_batch", "nl_op_rmsnorm", "nl_comm_get_unique_id",
-           "nl_comm_init", "nl_group_forward", "nl_debug_stamps"]
+           "nl_comm_init", "nl_group_forward", "nl_debug_stamps", "nl_sample_decode", "nl_op_sample"]
 
 
 def lib():
@@ -94,6 +100,8 @@ def lib():
     L.nl_comm_get_unique_id.argtypes = [vp]
     L.nl_comm_init.argtypes = [vp, vp]
     L.nl_group_forward.argtypes = [C.POINTER(vp), i32, i32, i32, i32, fp]
+    L.nl_sample_decode.argtypes = [vp, i32, i32, i32, C.POINTER(NlSampleParams), fp, ip, ip, ip, ip]
+    L.nl_op_sample.argtypes = [i32, fp, i32, C.POINTER(NlSampleParams), C.c_float, ip, ip, ip]
     _lib = L
     return L
 

@@ -11,6 +11,7 @@
 #include "nl_kernels.h"
 #include "nl_qgemm.h"
 #include "nl_batch.h"
+#include "nl_sample.h"
 
 #include <dlfcn.h>
 #include <algorithm>
@@ -22,6 +23,9 @@
 #include <functional>
 #include <string>
 #include <vector>
+#include <rocprim/device/device_radix_sort.hpp>   // the descending candidate order of sampleTopP / sampleTopK
+
+namespace { void samp_free(nl::SampScratch &s); }
 
 using namespace nl;
 
@@ -173,6 +177,11 @@ struct nl_engine {
         int *tok = nullptr, *pos = nullptr, *stream = nullptr, *ids = nullptr;
         int *h_meta = nullptr;  // pinned [3][cap]
     } bt;
+
+    // on-device sampling (nl_sample_decode): scratch for one vocabulary, allocated on first use
+    SampScratch sp;
+    bool sp_ready = false;
+    int sp_uniforms_cap = 0;
 
     std::vector<Op> plan;
     hipGraph_t graph = nullptr;
@@ -1112,6 +1121,7 @@ int nl_destroy(nl_handle e) {
     if (!e) return NL_OK;
     hipSetDevice(e->dev);
     hipDeviceSynchronize();
+    samp_free(e->sp);
     if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
     if (e->graph) hipGraphDestroy(e->graph);
     for (auto &L : e->layers) {
@@ -1193,6 +1203,134 @@ int nl_decode_greedy(nl_handle e, int stream, int token, int pos, int n_steps, i
     HIPCK(e, hipStreamSynchronize(e->stream));
     if (n_done) *n_done = n;
     return NL_OK;
+}
+
+namespace {
+
+// ---- on-device sampling ----------------------------------------------------
+hipError_t samp_alloc(SampScratch &s, int vocab, int n_uniforms) {
+    hipError_t rc;
+    const int nblocks = (vocab + 255) / 256;
+#define SA(ptr, count) if ((rc = hipMalloc((void **)&(ptr), (size_t)(count) * 4)) != hipSuccess) return rc
+    SA(s.keys_in, vocab); SA(s.keys_out, vocab); SA(s.idx_in, vocab); SA(s.idx_out, vocab);
+    SA(s.partial, nblocks); SA(s.scal, 4); SA(s.uniforms, std::max(n_uniforms, 1)); SA(s.recent, SAMP_THREADS); SA(s.recent_n, 1);
+#undef SA
+    if ((rc = rocprim::radix_sort_pairs_desc(nullptr, s.sort_tmp_bytes, s.keys_in, s.keys_out, s.idx_in, s.idx_out,
+                                             (unsigned)vocab, 0, 32, (hipStream_t)0)) != hipSuccess) return rc;
+    return hipMalloc(&s.sort_tmp, std::max<size_t>(s.sort_tmp_bytes, 16));
+}
+
+void samp_free(SampScratch &s) {
+    void *p[] = {s.keys_in, s.keys_out, s.idx_in, s.idx_out, s.partial, s.scal, s.uniforms, s.recent, s.recent_n, s.sort_tmp};
+    for (void *q : p) if (q) (void)hipFree(q);
+    s = SampScratch{};
+}
+
+// one sampling decision on `logits` (device); advances ctl / ids / the recent window
+hipError_t launch_sample(const SampScratch &s, float *logits, int vocab, const nl_sample_params &p, int *ctl, int *ids,
+                         hipStream_t st) {
+    SampleParams P{};
+    P.logits = logits; P.vocab = vocab; P.temp = p.temperature; P.top_p = p.top_p; P.top_k = std::max(p.top_k, 1);
+    P.rep_penalty = p.rep_penalty; P.recent = s.recent; P.recent_n = s.recent_n; P.rep_window = p.rep_window;
+    P.uniforms = s.uniforms; P.ctl = ctl; P.ids = ids;
+    P.keys_in = s.keys_in; P.keys_out = s.keys_out; P.idx_in = s.idx_in; P.idx_out = s.idx_out;
+    P.partial = s.partial; P.scal = s.scal; P.nblocks = (vocab + 255) / 256;
+    hipLaunchKernelGGL(samp_penalty_kernel, dim3(1), dim3(SAMP_THREADS), 0, st, P);
+    if (p.temperature > 0.f) {
+        hipLaunchKernelGGL(samp_prob_kernel, dim3(P.nblocks), dim3(256), 0, st, P);
+        size_t tmp = s.sort_tmp_bytes;
+        hipError_t rc = rocprim::radix_sort_pairs_desc(s.sort_tmp, tmp, s.keys_in, s.keys_out, s.idx_in, s.idx_out,
+                                                       (unsigned)vocab, 0, 32, st);
+        if (rc != hipSuccess) return rc;
+    }
+    hipLaunchKernelGGL(samp_select_kernel, dim3(1), dim3(SAMP_THREADS), 0, st, P);
+    return hipGetLastError();
+}
+
+int check_sample_params(nl_engine *e, const nl_sample_params *p) {
+    auto bad = [&](const char *m) { return e ? e->fail(NL_ERR_INVALID, "%s", m) : (int)NL_ERR_INVALID; };
+    if (!p) return bad("sample params missing");
+    if (p->rep_window < 0 || p->rep_window > SAMP_THREADS) return bad("rep_window must be in [0, 1024] for on-device sampling");
+    if (!(p->top_p > 0.f)) return bad("top_p must be > 0");
+    if (p->top_k < 1 && p->top_p >= 1.f && p->temperature > 0.f) return bad("top_k must be >= 1");
+    return NL_OK;
+}
+
+}  // namespace
+
+int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sample_params *p, const float *uniforms,
+                     int *recent, int *n_recent, int *ids_out, int *n_done) {
+    if (!e || !ids_out || !uniforms || !recent || !n_recent || n_steps < 0) return NL_ERR_INVALID;
+    int rc = check_sample_params(e, p);
+    if (rc) return rc;
+    if (!e->finalized) return e->fail(NL_ERR_STATE, "sample before nl_finalize");
+    if (stream < 0 || stream >= e->cfg.max_streams) return e->fail(NL_ERR_INVALID, "stream %d out of range", stream);
+    if (pos < 1 || pos > e->cfg.seq_len) return e->fail(NL_ERR_INVALID, "pos %d out of range [1,%d]", pos, e->cfg.seq_len);
+    if (*n_recent < 0 || *n_recent > p->rep_window) return e->fail(NL_ERR_INVALID, "n_recent %d exceeds rep_window %d", *n_recent, p->rep_window);
+    HIPCK(e, hipSetDevice(e->dev));
+    int n = std::min(n_steps, e->cfg.seq_len - pos);
+    n = std::min(n, e->ids_cap);
+    if (n_done) *n_done = std::max(n, 0);
+    if (n <= 0) return NL_OK;
+    if (!e->sp_ready || e->sp_uniforms_cap < n) {
+        HIPCK(e, hipStreamSynchronize(e->stream));
+        samp_free(e->sp);
+        e->sp_ready = false;
+        e->sp_uniforms_cap = std::max(n, e->cfg.seq_len);
+        HIPCK(e, samp_alloc(e->sp, e->cfg.vocab, e->sp_uniforms_cap));
+        e->sp_ready = true;
+    }
+    const SampScratch &s = e->sp;
+    // ctl: the select kernel writes token = sampled id and pos + 1; the forward that follows runs unchained
+    // (its argmax does not advance the state).  ctl.pos is primed to pos - 1 so the first increment lands on pos.
+    if ((rc = set_ctl(e, 0, pos - 1, 0, stream))) return rc;
+    HIPCK(e, hipMemcpyAsync(s.uniforms, uniforms, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+    if (*n_recent > 0) HIPCK(e, hipMemcpyAsync(s.recent, recent, (size_t)*n_recent * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCK(e, hipMemcpyAsync(s.recent_n, n_recent, 4, hipMemcpyHostToDevice, e->stream));
+    for (int i = 0; i < n; i++) {
+        HIPCK(e, launch_sample(s, e->logits, e->cfg.vocab, *p, e->ctl, e->ids, e->stream));
+        if ((rc = launch_step(e))) return rc;
+    }
+    HIPCK(e, hipMemcpyAsync(ids_out, e->ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCK(e, hipMemcpyAsync(n_recent, s.recent_n, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCK(e, hipStreamSynchronize(e->stream));
+    if (*n_recent > 0) HIPCK(e, hipMemcpy(recent, s.recent, (size_t)*n_recent * 4, hipMemcpyDeviceToHost));
+    return NL_OK;
+}
+
+int nl_op_sample(int device, float *logits, int vocab, const nl_sample_params *p, float uniform, int *recent, int *n_recent,
+                 int *picked) {
+    if (!logits || vocab <= 0 || !recent || !n_recent || !picked) return NL_ERR_INVALID;
+    int rc = check_sample_params(nullptr, p);
+    if (rc) return rc;
+    if (*n_recent < 0 || *n_recent > p->rep_window) return NL_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return NL_ERR_HIP;
+    SampScratch s;
+    float *d_logits = nullptr;
+    int *d_ctl = nullptr, *d_ids = nullptr;
+    rc = NL_ERR_HIP;
+    do {
+        if (samp_alloc(s, vocab, 1) != hipSuccess) break;
+        if (hipMalloc((void **)&d_logits, (size_t)vocab * 4) != hipSuccess) break;
+        if (hipMalloc((void **)&d_ctl, CTL_WORDS * 4) != hipSuccess || hipMalloc((void **)&d_ids, 16) != hipSuccess) break;
+        if (hipMemset(d_ctl, 0, CTL_WORDS * 4) != hipSuccess) break;
+        if (hipMemcpy(d_logits, logits, (size_t)vocab * 4, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(s.uniforms, &uniform, 4, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (*n_recent > 0 && hipMemcpy(s.recent, recent, (size_t)*n_recent * 4, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(s.recent_n, n_recent, 4, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (launch_sample(s, d_logits, vocab, *p, d_ctl, d_ids, (hipStream_t)0) != hipSuccess) break;
+        if (hipDeviceSynchronize() != hipSuccess) break;
+        if (hipMemcpy(picked, d_ids, 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (hipMemcpy(logits, d_logits, (size_t)vocab * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (hipMemcpy(n_recent, s.recent_n, 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (*n_recent > 0 && hipMemcpy(recent, s.recent, (size_t)*n_recent * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = NL_OK;
+    } while (0);
+    samp_free(s);
+    if (d_logits) (void)hipFree(d_logits);
+    if (d_ctl) (void)hipFree(d_ctl);
+    if (d_ids) (void)hipFree(d_ids);
+    return rc;
 }
 
 int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, float *last_logits_out) {

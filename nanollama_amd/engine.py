@@ -1,10 +1,13 @@
 """Generation loop -- mirror of Engine.Generate / GenerateQuiet (go/main.go:143-408).
 
-Prefill is token-at-a-time through model.forward exactly like the reference
-(go/main.go:160-166); decode applies the in-place repetition penalty
-(:177-187), then top-p / top-k / argmax (:191-195, :294-408).  Sampling stays
-on the host over the logits the device returns; the pure-greedy configuration
-(temp <= 0, rep_penalty <= 1) takes the chained on-device loop instead.
+The prompt positions the reference forwards token by token (go/main.go:160-166)
+go through model.prefill in one call; decode applies the in-place repetition penalty
+(:177-187), then top-p / top-k / argmax (:191-195, :294-408).  By default the
+whole loop -- penalty, sampling, recent window, next Forward -- runs on the device
+(nl_sample_decode) with the host owning only the random generator and the EOS
+stop; `device_sampling=False` keeps the literal per-token host loop over the
+logits the device returns.  The pure-greedy configuration (temp <= 0,
+rep_penalty <= 1) takes the chained on-device argmax loop.
 """
 from __future__ import annotations
 
@@ -33,12 +36,14 @@ def argmax(logits: np.ndarray, n: int) -> int:
 
 class Engine:
     def __init__(self, model: LlamaModel, eos_id: int = 2, rep_penalty: float = 1.15, rep_window: int = 64,
-                 seed: Optional[int] = None):
+                 seed: Optional[int] = None, device_sampling: bool = True, sample_chunk: int = 32):
         self.model = model
         self.eos_id = eos_id
         self.rep_penalty = np.float32(rep_penalty)
         self.rep_window = rep_window
         self.rng = np.random.default_rng(seed)
+        self.device_sampling = device_sampling   # False: read the logits back and sample on the host every token
+        self.sample_chunk = sample_chunk         # tokens per nl_sample_decode call (steps after an EOS are wasted)
         self.last_tok_per_s = 0.0
         self.last_tokens = 0
 
@@ -77,16 +82,18 @@ class Engine:
         """Engine.Generate go/main.go:152-230 on token ids (Encode/Decode stay with the tokenizer)."""
         m, cfg = self.model, self.model.config
         m.reset()
-        pos = 0
-        for tok in tokens:                       # prefill, go/main.go:160-166
-            m.forward(tok, pos)
-            pos += 1
-            if pos >= cfg.seq_len - 1:
-                break
+        # prefill, go/main.go:160-166: the Go loop forwards token after token and stops once pos reaches SeqLen-1;
+        # the same positions go through nl_prefill in one call (matrix-core path for Q4_0 / Q8_0 files)
+        n_prompt = min(len(tokens), max(cfg.seq_len - 1, 0))
+        if n_prompt > 0:
+            m.prefill(tokens[:n_prompt])
+        pos = n_prompt
         out: List[int] = []
         recent: List[int] = []
         start = time.perf_counter()              # timer starts after prefill, go/main.go:171
         greedy_fast = p.temperature <= 0 and self.rep_penalty <= 1.0
+        device_sampling = (not greedy_fast and self.device_sampling and n_prompt > 0 and self.rep_window <= 1024
+                           and p.top_p > 0 and (p.top_p < 1.0 or p.top_k >= 1 or p.temperature <= 0))
         if greedy_fast and p.max_tokens > 0:
             # sample_0 comes from the prefill logits; sample_k (k >= 1) exists iff k < max_tokens, the
             # k-th Forward left pos + k < SeqLen (go/main.go:216) and sample_{k-1} was not EOS (:203).
@@ -103,6 +110,40 @@ class Engine:
                     if t != self.eos_id:
                         on_token(t)
             recent = out[-self.rep_window:] if self.rep_window > 0 else []
+        elif device_sampling:
+            # the same loop with penalty, sampling and the recent window on the device (nl_sample_decode): no
+            # read-back of the logits; the host keeps the generator and applies the EOS stop per chunk
+            remaining = p.max_tokens
+            while remaining > 0 and pos < cfg.seq_len:
+                k = min(self.sample_chunk, remaining)
+                rng_state = self.rng.bit_generator.state
+                us = self.rng.random(k, dtype=np.float32) if p.temperature > 0 else np.zeros(k, np.float32)
+                ids, new_recent = m.sample_decode(pos, k, p.temperature, p.top_p, max(p.top_k, 1), float(self.rep_penalty),
+                                                  self.rep_window, us, recent)
+                used, stop = len(ids), False
+                for i, t in enumerate(ids):
+                    if t == self.eos_id:
+                        used, stop = i + 1, True
+                        break
+                if used < k and p.temperature > 0:      # leave the generator where the per-token loop would be
+                    self.rng.bit_generator.state = rng_state
+                    self.rng.random(used, dtype=np.float32)
+                if used < len(ids):
+                    for t in ids[:used]:
+                        recent.append(t)
+                        if len(recent) > self.rep_window:
+                            recent = recent[1:]
+                else:
+                    recent = new_recent
+                out.extend(ids[:used])
+                if on_token:
+                    for t in ids[:used]:
+                        if t != self.eos_id:
+                            on_token(t)
+                pos += used
+                remaining -= used
+                if stop or len(ids) < k:
+                    break
         else:
             for _ in range(p.max_tokens):
                 logits = m.state.logits

@@ -73,6 +73,24 @@ class LlamaModel:
                                                         C.byref(done)))
         return [int(ids[i]) for i in range(done.value)]
 
+    def sample_decode(self, pos: int, n_steps: int, temperature: float, top_p: float, top_k: int, rep_penalty: float,
+                      rep_window: int, uniforms, recent: List[int], stream: int = 0):
+        """The sampling loop of Generate (go/main.go:173-219) on the device: from the logits the last forward /
+        prefill left there, n_steps x { penalty, sample, Forward(sampled, pos++) }.  uniforms: one float32 per
+        step (the host generator's Float32 stream).  Returns (ids, recent window afterwards)."""
+        p = _lib.NlSampleParams(float(temperature), float(top_p), int(top_k), float(rep_penalty), int(rep_window))
+        u = np.ascontiguousarray(uniforms, dtype=np.float32)
+        if u.size < n_steps:
+            raise ValueError("one uniform per step is required")
+        rec = (C.c_int * max(int(rep_window), 1))(*[int(t) for t in recent])
+        nrec = C.c_int(len(recent))
+        ids = (C.c_int * max(n_steps, 1))()
+        done = C.c_int(0)
+        _lib.check(self._h, _lib.lib().nl_sample_decode(self._h, stream, int(pos), int(n_steps), C.byref(p),
+                                                        u.ctypes.data_as(C.POINTER(C.c_float)), rec, C.byref(nrec), ids,
+                                                        C.byref(done)))
+        return [int(ids[i]) for i in range(done.value)], [int(rec[i]) for i in range(nrec.value)]
+
     def prefill(self, tokens: List[int], pos0: int = 0, stream: int = 0, want_logits: bool = True) -> None:
         """The prompt loop of Generate (go/main.go:160-166) queued on the device in one call."""
         arr = (C.c_int * len(tokens))(*[int(t) for t in tokens])
@@ -250,6 +268,22 @@ def op_matmul_batch(w_raw: np.ndarray, ggml_type: int, x: np.ndarray, rows: int,
     if rc != 0:
         raise _lib.NlError(rc, "nl_op_matmul_batch")
     return out
+
+
+def op_sample(logits: np.ndarray, temperature: float, top_p: float, top_k: int, rep_penalty: float, rep_window: int,
+              uniform: float, recent: List[int], device: int = 0):
+    """One on-device sampling decision (go/main.go:177-200, :294-408) on host logits.
+    Returns (picked id, logits after the in-place penalty, recent window afterwards)."""
+    lg = np.array(logits, dtype=np.float32, copy=True)
+    p = _lib.NlSampleParams(float(temperature), float(top_p), int(top_k), float(rep_penalty), int(rep_window))
+    rec = (C.c_int * max(int(rep_window), 1))(*[int(t) for t in recent])
+    nrec = C.c_int(len(recent))
+    picked = C.c_int(-1)
+    rc = _lib.lib().nl_op_sample(device, lg.ctypes.data_as(C.POINTER(C.c_float)), int(lg.size), C.byref(p),
+                                 C.c_float(uniform), rec, C.byref(nrec), C.byref(picked))
+    if rc != 0:
+        raise _lib.NlError(rc, "nl_op_sample")
+    return picked.value, lg, [int(rec[i]) for i in range(nrec.value)]
 
 
 def op_rmsnorm(x: np.ndarray, w: np.ndarray, eps: float, device: int = 0) -> np.ndarray:

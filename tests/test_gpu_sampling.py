@@ -1,0 +1,152 @@
+"""On-device sampling (nl_op_sample / nl_sample_decode) against the host mirrors of go/main.go:177-200, :294-408."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import sampling_mirror as sm  # noqa: E402
+from nanollama_amd import gguf  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from nanollama_amd import _lib, model
+    if _lib.lib().nl_device_count() < 1:
+        pytest.fail("no HIP device visible: the GPU tests must run on the MI355X box")
+    return model
+
+
+def _case(rng, V):
+    lg = (rng.standard_normal(V) * rng.choice([0.7, 1.0, 3.0, 8.0])).astype(np.float32)
+    window = int(rng.choice([0, 1, 8, 64]))
+    recent = [int(t) for t in rng.integers(0, V, size=int(rng.integers(0, window + 1)))]
+    if len(recent) >= 3:
+        recent[-1] = recent[0]                 # a repeated token is penalised once per occurrence
+    return lg, window, recent, float(rng.random(dtype=np.float32))
+
+
+@pytest.mark.parametrize("V", [512, 4096, 32000, 96000])
+def test_top_p_matches_the_mirrors(hip, V):
+    rng = np.random.default_rng(V)
+    go_mismatch = 0
+    trials = 24 if V <= 32000 else 8
+    for _ in range(trials):
+        lg, window, recent, u = _case(rng, V)
+        temp, top_p, pen = float(rng.choice([0.8, 1.5])), float(rng.choice([0.5, 0.9, 0.95])), 1.15
+        pick, lg_after, rec_after = hip.op_sample(lg, temp, top_p, 50, pen, window, u, recent)
+        want_lg = sm.apply_penalty(lg, recent, pen, V)
+        assert np.array_equal(lg_after, want_lg)                       # in-place penalty, bit for bit
+        want, margin = sm.device_top_p(want_lg, temp, top_p, u)
+        assert pick == want, (V, temp, top_p, u, margin)               # same summation order: exact
+        assert rec_after == sm.push_recent(recent, pick, window)
+        if pick != sm.go_top_p(want_lg, temp, top_p, u):               # Go's single float32 chain
+            go_mismatch += 1
+            assert margin < 5e-4, margin                               # only ever on a cdf boundary
+    assert go_mismatch <= max(2, trials // 8)
+
+
+@pytest.mark.parametrize("V", [64, 512, 32000])
+def test_top_k_is_the_go_loop_exactly(hip, V):
+    rng = np.random.default_rng(1000 + V)
+    for _ in range(16):
+        lg, window, recent, u = _case(rng, V)
+        if rng.random() < 0.3:
+            lg[int(rng.integers(0, V))] = lg.max()                     # tie for the largest logit: earlier index first
+        temp, k, pen = float(rng.choice([0.5, 1.0])), int(rng.choice([1, 5, 50, 200])), float(rng.choice([1.0, 1.3]))
+        pick, lg_after, rec_after = hip.op_sample(lg, temp, 1.0, k, pen, window, u, recent)
+        want_lg = sm.apply_penalty(lg, recent, pen, V)
+        assert np.array_equal(lg_after, want_lg)
+        assert pick == sm.go_top_k(want_lg, temp, k, u)
+        assert rec_after == sm.push_recent(recent, pick, window)
+
+
+def test_zero_temperature_is_argmax_of_the_penalised_logits(hip):
+    rng = np.random.default_rng(5)
+    for _ in range(8):
+        lg, window, recent, u = _case(rng, 4096)
+        top = int(np.argmax(lg))
+        recent = (recent + [top])[-window:] if window else []
+        pick, lg_after, _ = hip.op_sample(lg, 0.0, 0.9, 50, 1.5, window, u, recent)
+        want_lg = sm.apply_penalty(lg, recent, 1.5, 4096)
+        assert np.array_equal(lg_after, want_lg) and pick == int(np.argmax(want_lg))
+
+
+def test_sampler_argument_errors(hip):
+    from nanollama_amd._lib import NlError
+    lg = np.zeros(64, np.float32)
+    with pytest.raises(NlError):
+        hip.op_sample(lg, 0.8, 0.9, 50, 1.1, 2048, 0.5, [])       # window beyond the on-device limit
+    with pytest.raises(NlError):
+        hip.op_sample(lg, 0.8, 0.0, 50, 1.1, 8, 0.5, [])          # top_p must be positive
+
+
+@pytest.mark.parametrize("mode", ["top_p", "top_k", "greedy_penalty"])
+def test_sample_decode_loop_matches_host_loop(hip, mode):
+    # The whole loop of go/main.go:173-219 on the device vs the same loop driven from the host with the logits read
+    # back every step and the mirror sampler: identical ids, window and final logits.
+    g = gguf.load_gguf(os.path.join(GOLDEN, "tiny_q8_0.gguf"))
+    v = np.load(os.path.join(GOLDEN, "tiny_q8_0.npz"))
+    prompt = [int(t) for t in v["prompt"]]
+    temp, top_p, top_k, pen, window = {"top_p": (0.9, 0.9, 50, 1.15, 8), "top_k": (0.7, 1.0, 20, 1.15, 8),
+                                       "greedy_penalty": (0.0, 0.9, 50, 1.3, 4)}[mode]
+    n = 24
+    us = np.random.default_rng(3).random(n, dtype=np.float32)
+    V = g.meta.vocab_size
+    host = hip.load_llama_model(g)
+    host.prefill(prompt)
+    recent, want_ids, pos = [], [], len(prompt)
+    for i in range(n):
+        lg = sm.apply_penalty(host.state.logits[:V].copy(), recent, pen, V)
+        if temp <= 0:
+            tok = int(np.argmax(lg))
+        elif top_p < 1.0:
+            tok = sm.device_top_p(lg, temp, top_p, float(us[i]))[0]
+        else:
+            tok = sm.go_top_k(lg, temp, top_k, float(us[i]))
+        recent = sm.push_recent(recent, tok, window)
+        want_ids.append(tok)
+        host.forward(tok, pos)
+        pos += 1
+    dev = hip.load_llama_model(g)
+    dev.prefill(prompt)
+    ids1, rec1 = dev.sample_decode(len(prompt), 10, temp, top_p, top_k, pen, window, us[:10], [])
+    ids2, rec2 = dev.sample_decode(len(prompt) + 10, n - 10, temp, top_p, top_k, pen, window, us[10:], rec1)   # chunked
+    assert ids1 + ids2 == want_ids
+    assert rec2 == recent
+    dev.forward(want_ids[-1], pos - 1)          # same state afterwards: re-running the last position gives the host's logits
+    assert np.array_equal(dev.state.logits, host.state.logits)
+    # stops at seq_len like go/main.go:216
+    ids3, _ = dev.sample_decode(g.meta.seq_len - 2, 10, temp, top_p, top_k, pen, window, us[:10], [])
+    assert len(ids3) == 2
+    host.close(); dev.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_engine_device_sampling_equals_the_host_loop(hip, seed):
+    # Engine.generate_ids with the loop on the device vs the literal per-token host loop (logits read back every
+    # token): same generator seed -> same ids, same token counter, and the generator ends in the same state.
+    from nanollama_amd.engine import Engine, GenParams
+    g = gguf.load_gguf(os.path.join(GOLDEN, "tiny_q8_0.gguf"))
+    dev = hip.load_llama_model(g)
+    outs = []
+    for on_device in (True, False):
+        # an EOS id that actually occurs mid-stream exercises the chunk truncation + generator rewind
+        probe = Engine(dev, eos_id=-1, rep_penalty=1.15, rep_window=16, seed=seed, device_sampling=on_device, sample_chunk=8)
+        ids = probe.generate_ids([1, 5, 6, 9], GenParams(max_tokens=40, temperature=0.9, top_p=0.9))
+        eos = ids[21]
+        eng = Engine(dev, eos_id=eos, rep_penalty=1.15, rep_window=16, seed=seed, device_sampling=on_device, sample_chunk=8)
+        cut = eng.generate_ids([1, 5, 6, 9], GenParams(max_tokens=40, temperature=0.9, top_p=0.9))
+        nxt = float(eng.rng.random(dtype=np.float32))
+        topk = Engine(dev, eos_id=-1, rep_penalty=1.2, rep_window=4, seed=seed, device_sampling=on_device).generate_ids(
+            [1, 5, 6, 9], GenParams(max_tokens=30, temperature=0.7, top_p=1.0, top_k=12))
+        outs.append((ids, cut, eng.last_tokens, nxt, topk))
+    assert outs[0] == outs[1]
+    ids, cut = outs[0][0], outs[0][1]
+    assert len(ids) == 40 and cut == ids[:len(cut)] and cut[-1] == ids[21] and len(cut) <= 22
+    dev.close()
