@@ -223,6 +223,22 @@ def side_configs(model):
     out["goldie_q4_0_64_streams"] = {"tokens_per_s_aggregate": round(ns * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
                                      "hbm_frac": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
     dev.close()
+    # -- nano at the reference's DEFAULT generation settings (go/main.go:29-34: temp 0.8, top-p 0.9, repetition
+    #    penalty 1.15 over 64 tokens): sampling loop on the device vs logits read back and sampled on the host
+    from nanollama_amd.engine import Engine, GenParams
+    shape = synth.TIERS["nano"]
+    g = gguf.load_gguf(ensure_gguf(shape, "q8_0", "float"))
+    dev = model.load_llama_model(g)
+    prompt = synth.prompt_ids(PROMPT_LEN, shape.vocab)
+    res = {}
+    for key, on_device, n in (("device_loop_tokens_per_s", True, 256), ("host_loop_tokens_per_s", False, 48)):
+        eng = Engine(dev, eos_id=-1, rep_penalty=1.15, rep_window=64, seed=1, device_sampling=on_device)
+        eng.generate_ids(prompt, GenParams(max_tokens=16, temperature=0.8, top_p=0.9))
+        t0 = time.perf_counter()
+        ids = eng.generate_ids(prompt, GenParams(max_tokens=n, temperature=0.8, top_p=0.9))
+        res[key] = round(len(ids) / (time.perf_counter() - t0), 1)
+    out["nano_q8_0_default_sampling"] = res
+    dev.close()
     return out
 
 
