@@ -1208,11 +1208,16 @@ int nl_decode_greedy(nl_handle e, int stream, int token, int pos, int n_steps, i
 namespace {
 
 // ---- on-device sampling ----------------------------------------------------
+// lane chunk of the select kernel: a multiple of 32 covering vocab / 1024 (vocab <= 131072)
+inline int samp_chunk(int vocab) { return ((vocab + SAMP_THREADS - 1) / SAMP_THREADS + 31) / 32 * 32; }
+
 hipError_t samp_alloc(SampScratch &s, int vocab, int n_uniforms) {
     hipError_t rc;
+    if (samp_chunk(vocab) > 128) return hipErrorInvalidValue;   // vocab > 131072
     const int nblocks = (vocab + 255) / 256;
 #define SA(ptr, count) if ((rc = hipMalloc((void **)&(ptr), (size_t)(count) * 4)) != hipSuccess) return rc
-    SA(s.keys_in, vocab); SA(s.keys_out, vocab); SA(s.idx_in, vocab); SA(s.idx_out, vocab);
+    SA(s.keys_in, vocab); SA(s.keys_out, SAMP_THREADS * samp_chunk(vocab)); SA(s.idx_in, vocab); SA(s.idx_out, vocab);
+    if ((rc = hipMemset(s.keys_out, 0, (size_t)SAMP_THREADS * samp_chunk(vocab) * 4)) != hipSuccess) return rc;  // zero tail past vocab
     SA(s.partial, nblocks); SA(s.scal, 4); SA(s.uniforms, std::max(n_uniforms, 1)); SA(s.recent, SAMP_THREADS); SA(s.recent_n, 1);
 #undef SA
     if ((rc = rocprim::radix_sort_pairs_desc(nullptr, s.sort_tmp_bytes, s.keys_in, s.keys_out, s.idx_in, s.idx_out,
@@ -1243,7 +1248,13 @@ hipError_t launch_sample(const SampScratch &s, float *logits, int vocab, const n
                                                        (unsigned)vocab, 0, 32, st);
         if (rc != hipSuccess) return rc;
     }
-    hipLaunchKernelGGL(samp_select_kernel, dim3(1), dim3(SAMP_THREADS), 0, st, P);
+    switch (samp_chunk(vocab)) {
+    case 32: hipLaunchKernelGGL(samp_select_kernel<32>, dim3(1), dim3(SAMP_THREADS), 0, st, P); break;
+    case 64: hipLaunchKernelGGL(samp_select_kernel<64>, dim3(1), dim3(SAMP_THREADS), 0, st, P); break;
+    case 96: hipLaunchKernelGGL(samp_select_kernel<96>, dim3(1), dim3(SAMP_THREADS), 0, st, P); break;
+    case 128: hipLaunchKernelGGL(samp_select_kernel<128>, dim3(1), dim3(SAMP_THREADS), 0, st, P); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -50,24 +50,36 @@ struct SampScratch {
 // 1 workgroup: repetition penalty, then the maximum logit
 __global__ void __launch_bounds__(SAMP_THREADS) samp_penalty_kernel(SampleParams P) {
     __shared__ float red[SAMP_THREADS / 64];
+    __shared__ int win[SAMP_THREADS];
     const int tid = threadIdx.x, n = *P.recent_n;
-    if (P.rep_penalty > 1.0f) {
-        for (int t = tid; t < n; t += SAMP_THREADS) {
-            const int tok = P.recent[t];
-            if (tok < 0 || tok >= P.vocab) continue;
-            bool first = true;
-            for (int s = 0; s < t; s++) first = first && P.recent[s] != tok;
-            if (!first) continue;
-            int count = 0;
-            for (int s = t; s < n; s++) count += P.recent[s] == tok;
-            float v = P.logits[tok];
-            for (int c = 0; c < count; c++) v = v > 0.f ? v / P.rep_penalty : v * P.rep_penalty;
-            P.logits[tok] = v;
+    // the maximum scan's loads do not depend on the penalty: issue the first batch now
+    float m = -INFINITY;
+    if (P.rep_penalty > 1.0f && n > 0) {
+        if (tid < n) win[tid] = P.recent[tid];
+        __syncthreads();
+        if (tid < n) {
+            const int tok = win[tid];
+            if (tok >= 0 && tok < P.vocab) {
+                bool first = true;
+                for (int s = 0; s < tid; s++) first = first && win[s] != tok;
+                if (first) {
+                    int count = 0;
+                    for (int s = tid; s < n; s++) count += win[s] == tok;
+                    float v = P.logits[tok];
+                    for (int c = 0; c < count; c++) v = v > 0.f ? v / P.rep_penalty : v * P.rep_penalty;
+                    P.logits[tok] = v;
+                }
+            }
         }
     }
-    __syncthreads();
-    float m = -INFINITY;
-    for (int i = tid; i < P.vocab; i += SAMP_THREADS) m = fmaxf(m, P.logits[i]);
+    __syncthreads();   // (orders the penalty stores before the scan below; same workgroup)
+    for (int i0 = tid; i0 < P.vocab; i0 += 8 * SAMP_THREADS) {   // 8 independent loads per round (clamped, masked)
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = P.logits[min(i0 + k * SAMP_THREADS, P.vocab - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; k++) m = i0 + k * SAMP_THREADS < P.vocab ? fmaxf(m, v[k]) : m;
+    }
     m = wave_max_f32(m);
     if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
@@ -101,16 +113,18 @@ __global__ void __launch_bounds__(256) samp_prob_kernel(SampleParams P) {
 }
 
 // 1 workgroup: pick the token from the sorted candidates and advance the decode state
+template <int C>   // chunk length per lane: a multiple of 32 with 1024 * C >= vocab (keys_out is zero-padded to 1024 * C)
 __global__ void __launch_bounds__(SAMP_THREADS) samp_select_kernel(SampleParams P) {
     __shared__ float chunk[SAMP_THREADS];
     __shared__ float bval[SAMP_THREADS / 64];
     __shared__ int bidx[SAMP_THREADS / 64];
-    __shared__ int s_cut, s_pick;
+    __shared__ float wtot[SAMP_THREADS / 64];
+    __shared__ int s_cut, s_pick, s_pick_pos;
     __shared__ float s_cum, s_inv;
     const int tid = threadIdx.x, V = P.vocab;
     const int step = P.ctl[CTL_STEP];
     const float u = P.uniforms[step];
-    if (tid == 0) { s_cut = -1; s_pick = -1; s_cum = 0.f; }
+    if (tid == 0) { s_cut = 0x7fffffff; s_pick = -1; s_pick_pos = 0x7fffffff; s_cum = 0.f; }
     int pick = 0;
     if (P.temp <= 0.f) {
         // argmax over the penalised logits, lowest index wins ties
@@ -141,42 +155,84 @@ __global__ void __launch_bounds__(SAMP_THREADS) samp_select_kernel(SampleParams 
         }
         __syncthreads();
         const float inv = s_inv;
-        const int C = (V + SAMP_THREADS - 1) / SAMP_THREADS;
-        const int lo = min(tid * C, V), hi = min(lo + C, V);
+        // cum(i) = (prefix of the earlier wavefronts' totals + prefix of the earlier lanes' chunk totals) + the
+        // left-to-right sum inside this lane's contiguous chunk: every chain is a fixed left-to-right order
+        const int lo = tid * C, hi = min(lo + C, V);
+        float q[C];                                        // this lane's chunk, normalised; one round of loads
+#pragma unroll
+        for (int k = 0; k < C; k += 4) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(P.keys_out + lo + k);
+            q[k] = t4.x * inv; q[k + 1] = t4.y * inv; q[k + 2] = t4.z * inv; q[k + 3] = t4.w * inv;
+        }
         float local = 0.f;
-        for (int i = lo; i < hi; i++) local += P.keys_out[i] * inv;
+#pragma unroll
+        for (int k = 0; k < C; k++) local += q[k];         // entries past vocab are +0.0f
         chunk[tid] = local;
         __syncthreads();
+        const int wv = tid >> 6, ln = tid & 63;
+        float within = 0.f;
+        for (int t = wv * 64; t < tid; t++) within += chunk[t];
+        if (ln == 63) wtot[wv] = within + local;
+        __syncthreads();
         float pre = 0.f;
-        for (int t = 0; t < tid; t++) pre += chunk[t];
-        // (1) the cut: first i with cum(i) >= top_p, cum(i) = pre + (in-chunk left-to-right sum)
-        if (pre < P.top_p && lo < hi) {
+        for (int w = 0; w < wv; w++) pre += wtot[w];
+        pre += within;
+        // (1) the cut: the smallest i with cum(i) >= top_p.  Every lane scans its own chunk and the minimum wins, so
+        //     a one-ulp disagreement between a chunk's last cum and the next chunk's prefix cannot lose the cut.
+        {
             float part = 0.f;
-            for (int i = lo; i < hi; i++) {
-                part += P.keys_out[i] * inv;
-                if (pre + part >= P.top_p) { s_cut = i; s_cum = pre + part; break; }
+            int found = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < C; k++) {
+                part += q[k];
+                if (found == 0x7fffffff && lo + k < hi && pre + part >= P.top_p) found = lo + k;
             }
+            if (found != 0x7fffffff) atomicMin(&s_cut, found);
         }
         __syncthreads();
         const int cut = s_cut;
-        if (cut >= 0) {
-            // (2) first j <= cut with r <= cum(j)
-            const float r = u * s_cum;
-            if (lo <= cut && (tid == 0 || pre < r)) {
+        if (cut < 0x7fffffff) {
+            if (lo <= cut && cut < hi) {
                 float part = 0.f;
-                for (int i = lo; i < hi && i <= cut; i++) {
-                    part += P.keys_out[i] * inv;
-                    if (r <= pre + part) { s_pick = i; break; }
-                }
+#pragma unroll
+                for (int k = 0; k < C; k++) part += lo + k <= cut ? q[k] : 0.f;
+                s_cum = pre + part;
             }
+            __syncthreads();
+            // (2) the smallest j <= cut with r <= cum(j)
+            const float r = u * s_cum;
+            float part = 0.f;
+            int found = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < C; k++) {
+                part += q[k];
+                if (found == 0x7fffffff && lo + k < hi && lo + k <= cut && r <= pre + part) found = lo + k;
+            }
+            if (found != 0x7fffffff) atomicMin(&s_pick_pos, found);
         }
         __syncthreads();
-        if (tid == 0) s_pick = P.idx_out[s_pick >= 0 ? s_pick : 0];
+        if (tid == 0) s_pick = P.idx_out[s_pick_pos < 0x7fffffff ? s_pick_pos : 0];
     } else {
-        // top-k: sequential, exactly the Go loop (go/main.go:325-342)
-        if (tid == 0) {
-            const int K = min(P.top_k, V);
-            const float v0 = P.keys_out[0];
+        // top-k: the Go loop (go/main.go:325-342).  The <= 1024 candidate probabilities are computed one per lane
+        // (each is a pure function of its own logit), the two sums run left to right on lane 0 exactly as in Go.
+        const int K = min(P.top_k, V);
+        const float v0 = P.keys_out[0];
+        if (K <= SAMP_THREADS) {
+            if (tid < K) chunk[tid] = (float)exp((double)((P.keys_out[tid] - v0) / P.temp));
+            __syncthreads();
+            if (tid == 0) {
+                float sum = 0.f;
+                for (int i = 0; i < K; i++) sum += chunk[i];
+                const float r = u * sum;
+                float cdf = 0.f;
+                int sel = 0;
+                for (int i = 0; i < K; i++) {
+                    cdf += chunk[i];
+                    if (r <= cdf) { sel = i; break; }
+                }
+                s_pick = P.idx_out[sel];
+            }
+        } else if (tid == 0) {
             float sum = 0.f;
             for (int i = 0; i < K; i++) sum += (float)exp((double)((P.keys_out[i] - v0) / P.temp));
             const float r = u * sum;

@@ -3,7 +3,7 @@
 go_*      : the Go code's arithmetic literally -- float32 everywhere, exp in float64, every sum one left-to-right
             chain; the descending sort is stable (Go's sort.Slice leaves ties unspecified).
 device_*  : the same algorithm with the summation ORDER of nanollama_amd/csrc/nl_sample.h (256-element tree
-            partials for the normaliser, 1024 contiguous chunks for the cumulative sums), so the device result can
+            partials for the normaliser; cumulative sums = wavefront prefix + lane prefix + in-chunk chain), so the device result can
             be checked for exact equality.
 """
 import numpy as np
@@ -83,16 +83,28 @@ def device_top_p(lg, temp, top_p, u):
     inv = F(1.0) / total
     order = np.argsort(-p, kind="stable")
     q = (p[order] * inv).astype(np.float32)
-    C = (V + 1023) // 1024
+    C = ((V + 1023) // 1024 + 31) // 32 * 32
     cum = np.empty(V, np.float32)
-    pre = F(0.0)
+    local = np.zeros(1024, np.float32)
+    parts = {}
     for t in range(1024):
         lo, hi = min(t * C, V), min(t * C + C, V)
-        if lo >= hi:
-            break
-        part = np.cumsum(q[lo:hi], dtype=np.float32)
-        cum[lo:hi] = (pre + part).astype(np.float32)
-        pre = F(pre + part[-1])
+        if lo < hi:
+            parts[t] = np.cumsum(q[lo:hi], dtype=np.float32)
+            local[t] = parts[t][-1]
+    pw = F(0.0)                                     # prefix over the earlier wavefronts' totals
+    for w in range(16):
+        within = F(0.0)                             # prefix over the earlier lanes of this wavefront
+        for ln in range(64):
+            t = w * 64 + ln
+            pre = F(pw + within)
+            if t in parts:
+                lo = t * C
+                cum[lo:lo + parts[t].size] = (pre + parts[t]).astype(np.float32)
+            if ln == 63:
+                wtot = F(within + local[t])
+            within = F(within + local[t])
+        pw = F(pw + wtot)
     hit = np.nonzero(cum >= F(top_p))[0]
     if len(hit) == 0:
         return int(order[0]), 1.0
