@@ -357,7 +357,7 @@ def spawn_tp_child(args):
     return subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 
 
-def collect_tp_child(proc, timeout_s=420):
+def collect_tp_child(proc, timeout_s=300):
     import subprocess
     timeout_s = int(os.environ.get("NL_TP_CHILD_TIMEOUT", timeout_s))
     try:

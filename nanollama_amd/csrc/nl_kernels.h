@@ -506,26 +506,13 @@ __device__ __forceinline__ float4 load_x4(const GemvParams &P, int col, float4 &
     return v;
 }
 
-#ifndef NL_NT_WEIGHTS
-#define NL_NT_WEIGHTS 0
-#endif
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-
 template <int WT>
 __device__ __forceinline__ void load_pair(const uint8_t *q, const uint32_t *s, long long tile_pair0, int g, int gsz,
                                           int r, int k, uint4 *c, uint2 &sc) {
     constexpr int CPP = WTraits<WT>::CPP;
     const uint4 *qp = reinterpret_cast<const uint4 *>(q) + tile_pair0 * (CPP * TR) + (long long)g * (KL * CPP * TR) + r * gsz + k;
 #pragma unroll
-    for (int j = 0; j < CPP; j++) {
-#if NL_NT_WEIGHTS
-        // decode reads every weight byte exactly once per token: non-temporal policy (global_load_dwordx4 ... nt)
-        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(qp + j * TR * gsz));
-        c[j] = make_uint4(v.x, v.y, v.z, v.w);
-#else
-        c[j] = qp[j * TR * gsz];
-#endif
-    }
+    for (int j = 0; j < CPP; j++) c[j] = qp[j * TR * gsz];
     const long long si = tile_pair0 * TR + g * (KL * TR) + r * gsz + k;
     if (!WTraits<WT>::SCALED) sc = make_uint2(0u, 0u);
     else if (scale_words(WT) == 2) sc = reinterpret_cast<const uint2 *>(s)[si];

@@ -242,12 +242,8 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
         const int buf = k & 1, nb = min(QG_KC, nblocks - chunk * QG_KC);
         const bool more = chunk + P.ksplit < nchunks;
         if (more) {
-#ifndef NL_QG_NODMA
             stage(chunk + P.ksplit, buf ^ 1);
-#endif
-#ifndef NL_QG_NOW
             wload(chunk + P.ksplit, wqn, wdn);
-#endif
         }
         // Straight-line over the chunk's blocks (no per-block branch: a block past the end of K was clamped to
         // the last valid one by the prefetch and gets scale 0).  Per block: the 8 lo-part MFMAs go first on 8
