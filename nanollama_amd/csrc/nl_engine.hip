@@ -291,7 +291,8 @@ void choose_geometry(const nl_engine *e, const PackedMat &m, int &tw, int &kw, i
     // wavefronts in flight (8 per CU); small matrices go all the way to one group per wavefront,
     // which is what minimises the in-launch latency of small models.
     const int ngroups = (m.npairs + KL - 1) / KL;
-    kw = (2048 + m.ntiles - 1) / std::max(1, m.ntiles);
+    static const int target = getenv("NL_WAVES") ? atoi(getenv("NL_WAVES")) : 2048;   // developer knob (tools/)
+    kw = (target + m.ntiles - 1) / std::max(1, m.ntiles);
     const int cap = 8 / mats;  // workgroups are capped at 8 wavefronts (256 VGPRs each)
     kw = (kw + mats - 1) / mats;
     kw = std::max(1, std::min(kw, std::min(ngroups, cap)));
