@@ -219,6 +219,33 @@ def test_long_context_split_attention(hip, orc, tmp_path):
     dev.close()
 
 
+def test_maximum_context_2048_positions(hip, orc, tmp_path):
+    # the largest context the Go engine allows (SeqLen is capped to 2048, go/model.go:145-148): all 16 attention
+    # splits in use at the last position; the decode loop stops when pos reaches SeqLen (go/main.go:216)
+    shape = replace(synth.TIERS["tiny"], name="tiny_max", seq_len=4096)      # the file says 4096, the engine caps it
+    p = tmp_path / "max.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", 27)
+    g = gguf.load_gguf(str(p))
+    dev = hip.load_llama_model(g)
+    assert dev.config.seq_len == 2048
+    ref = orc.OracleModel(g)
+    toks = synth.prompt_ids(2048, shape.vocab, seed=2)
+    for pos, t in enumerate(toks):
+        want = ref.forward(t, pos)
+    dev.prefill(toks[:2040])                       # positions 0..2039 in one multi-token step
+    for pos in range(2040, 2048):                  # the last eight through the single-token kernels
+        dev.forward(toks[pos], pos)
+    err = float(np.abs(dev.state.logits - want).max())
+    print(f"\nposition 2047: max|gpu-oracle|={err:.2e}")
+    assert err <= LOGIT_TOL * max(1.0, float(want.std()))
+    from nanollama_amd._lib import NlError
+    with pytest.raises(NlError):
+        dev.forward(1, 2048)                       # past the cache
+    assert dev.decode_greedy(toks[2046], 2046, 10) == dev.decode_greedy(toks[2046], 2046, 2)   # stops at SeqLen: 2 steps
+    assert len(dev.decode_greedy(toks[2047], 2047, 5)) == 1
+    dev.close()
+
+
 def test_argument_and_state_errors(hip):
     from nanollama_amd._lib import NlError
     g = gguf.load_gguf(os.path.join(GOLDEN, "tiny_q8_0.gguf"))
