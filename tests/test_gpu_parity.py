@@ -352,6 +352,33 @@ def test_tensor_parallel_shards_match_single_gpu(hip, orc, tag, n):
     grp.close(); one.close()
 
 
+@pytest.mark.parametrize("tag", ["tiny_q8_0", "tiny_q4_0", "tiny_tied_q8_0"])
+def test_collective_plan_runs_through_rccl_with_one_rank(hip, tag, monkeypatch):
+    # The tensor-parallel launch plan (all-reduce after WO and after down, all-gather of the logit slices, residual
+    # added in the next kernel's prologue) on the ONE GPU of this box: a 1-rank RCCL communicator makes every
+    # collective an identity, so logits and greedy ids must equal the ordinary plan's -- this is the code path the
+    # 8-GPU run takes, minus the data exchange itself.  Captured in the hipGraph (eager fallback if capture fails).
+    g = gguf.load_gguf(os.path.join(GOLDEN, tag + ".gguf"))
+    v = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    toks = [int(t) for t in v["prompt"]]
+    base = hip.load_llama_model(g)
+    monkeypatch.setenv("NL_FORCE_TP_PLAN", "1")
+    try:
+        cid = hip.comm_unique_id()
+    except Exception as exc:      # no RCCL library on the box
+        pytest.skip(f"RCCL unavailable: {exc}")
+    tp = hip.load_llama_model(g, comm_id=cid)
+    monkeypatch.delenv("NL_FORCE_TP_PLAN")
+    for pos, t in enumerate(toks):
+        base.forward(t, pos)
+        tp.forward(t, pos)
+        assert np.abs(tp.state.logits - base.state.logits).max() <= 2e-6, pos
+    assert np.abs(tp.state.logits - v["logits_full"][len(toks) - 1]).max() <= LOGIT_TOL
+    nxt = int(np.argmax(base.state.logits))
+    assert tp.decode_greedy(nxt, len(toks), 8) == base.decode_greedy(nxt, len(toks), 8)
+    base.close(); tp.close()
+
+
 def test_tensor_parallel_big_shapes(hip, orc, tmp_path):
     # 2 layers with big-like ratios (GQA 2:1 over 16 heads, FFN multiple of 32*8) on 4 and 8 shards,
     # context long enough for two attention splits
