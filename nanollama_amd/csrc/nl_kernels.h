@@ -534,7 +534,8 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     float *red = xs_all + nwaves * XS_WAVE;                   // [waves][TR]
     double *dred = reinterpret_cast<double *>(red + nwaves * TR);  // [waves]
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wavefront index as an SGPR value: tile, matrix and group bases become scalar arithmetic + a 32-bit lane offset
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 #define NL_STAMP(k) do { if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + (k)] = clock64(); } while (0)
     NL_STAMP(0);
     const int r = lane >> 2, k = lane & 3;
