@@ -469,13 +469,16 @@ constexpr int XS_WAVE = KL * XS_PAIR;        // LDS floats per wavefront (one 25
 // "if (col >= cols) return 0" makes every loaded value a phi, and hipcc then waits vmcnt(0) INSIDE the branch --
 // i.e. the x / norm-weight round trip completed before the first weight load was even issued.
 template <int PRO>
-__device__ __forceinline__ float4 load_x4(const GemvParams &P, int col, float4 &g, float4 &addv, int ns) {
+// Addresses are a wave-UNIFORM base (the group's first column, scalar arithmetic) plus an unsigned 32-bit lane
+// offset: no 64-bit VALU address arithmetic, no sign extensions.
+__device__ __forceinline__ float4 load_x4(const GemvParams &P, int gcol, unsigned lcol, float4 &g, float4 &addv, int ns) {
     g = make_float4(1.f, 1.f, 1.f, 1.f);
     addv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (PRO == PRO_ATTN) {
         // merge the position-split attention partials (online softmax): x = sum_c w_c o_c / sum_c w_c l_c.
         // Split 0 is fetched unconditionally; the loop over further splits only runs once pos >= 128.
-        const int hd = P.head_dim, h = col / hd, d = col - h * hd;
+        const int col = gcol + (int)lcol, hd = P.head_dim;
+        const int h = (hd & (hd - 1)) == 0 ? col >> (__ffs(hd) - 1) : col / hd, d = col - h * hd;
         const float *ml = P.part_ml + (long long)h * P.nsplit_max * 2;
         const float *po = P.part_o + (long long)h * P.nsplit_max * hd + d;
         const float4 o0 = *reinterpret_cast<const float4 *>(po);
@@ -497,12 +500,12 @@ __device__ __forceinline__ float4 load_x4(const GemvParams &P, int col, float4 &
         float il = 1.0f / L;
         return make_float4(v.x * il, v.y * il, v.z * il, v.w * il);
     }
-    float4 v = *reinterpret_cast<const float4 *>(P.x + col);
-    if (PRO == PRO_NORM) g = *reinterpret_cast<const float4 *>(P.normw + col);
+    float4 v = *reinterpret_cast<const float4 *>((P.x + gcol) + lcol);
+    if (PRO == PRO_NORM) g = *reinterpret_cast<const float4 *>((P.normw + gcol) + lcol);
     // optional addend (gamma row / tensor-parallel residual): always LOADED (from x itself when absent: same
     // cache line, the launcher resolves
     // the pointer so there is no select here for hipcc to turn back into a branch) and handed back; the caller adds it when it consumes x, after every load of the round is out
-    addv = *reinterpret_cast<const float4 *>(P.add_src + col);
+    addv = *reinterpret_cast<const float4 *>((P.add_src + gcol) + lcol);
     return v;
 }
 
@@ -510,13 +513,15 @@ template <int WT>
 __device__ __forceinline__ void load_pair(const uint8_t *q, const uint32_t *s, long long tile_pair0, int g, int gsz,
                                           int r, int k, uint4 *c, uint2 &sc) {
     constexpr int CPP = WTraits<WT>::CPP;
-    const uint4 *qp = reinterpret_cast<const uint4 *>(q) + tile_pair0 * (CPP * TR) + (long long)g * (KL * CPP * TR) + r * gsz + k;
+    // uniform bases (tile, group) + one unsigned lane offset shared by the quant chunks and the scale entry
+    const uint4 *qb = reinterpret_cast<const uint4 *>(q) + (tile_pair0 * (CPP * TR) + (long long)g * (KL * CPP * TR));
+    const unsigned off = __umul24((unsigned)r, (unsigned)gsz) + (unsigned)k;
 #pragma unroll
-    for (int j = 0; j < CPP; j++) c[j] = qp[j * TR * gsz];
-    const long long si = tile_pair0 * TR + g * (KL * TR) + r * gsz + k;
+    for (int j = 0; j < CPP; j++) c[j] = (qb + j * TR * gsz)[off];
+    const long long sb = tile_pair0 * TR + (long long)g * (KL * TR);
     if (!WTraits<WT>::SCALED) sc = make_uint2(0u, 0u);
-    else if (scale_words(WT) == 2) sc = reinterpret_cast<const uint2 *>(s)[si];
-    else sc = make_uint2(s[si], 0u);
+    else if (scale_words(WT) == 2) sc = (reinterpret_cast<const uint2 *>(s) + sb)[off];
+    else sc = make_uint2((s + sb)[off], 0u);
 }
 
 // One wavefront = one 16-row tile x a 1/kw share of the 256-column groups; a workgroup holds
@@ -595,9 +600,9 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
         bool lv[NFR], inb[NFR];
 #pragma unroll
         for (int f = 0; f < NFR; f++) {
-            const int col = (g0 + f * P.kw) * (KL * PAIR) + lane * 4;
-            inb[f] = col < P.cols;
-            xv[f] = load_x4<PRO>(P, inb[f] ? col : 0, gv[f], av[f], ns);
+            const int gcol = (g0 + f * P.kw) * (KL * PAIR);
+            inb[f] = gcol + lane * 4 < P.cols;
+            xv[f] = load_x4<PRO>(P, gcol, inb[f] ? (unsigned)lane * 4u : 0u, gv[f], av[f], ns);
         }
 #pragma unroll
         for (int f = 0; f < NFR; f++) {
@@ -616,8 +621,10 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
                 // RMSNormInto go/quant.go:597-607.  inv = 1/sqrt(mean(x^2)+eps) multiplies the GEMV OUTPUT
                 // (out = inv * sum_j w_ij (x_j g_j)), so its float64 reduction is off the critical path.
                 if (tin == 0 && msel == 0) {
-                    ss += (double)xa.x * (double)xa.x; ss += (double)xa.y * (double)xa.y;
-                    ss += (double)xa.z * (double)xa.z; ss += (double)xa.w * (double)xa.w;
+                    // (the product of two float32 values is exact in float64, so the fused form rounds exactly as
+                    // the reference's separate multiply and add do)
+                    ss = fma((double)xa.x, (double)xa.x, ss); ss = fma((double)xa.y, (double)xa.y, ss);
+                    ss = fma((double)xa.z, (double)xa.z, ss); ss = fma((double)xa.w, (double)xa.w, ss);
                     if (P.x_out && blockIdx.x == 0 && inb[f])
                         *reinterpret_cast<float4 *>(P.x_out + g * (KL * PAIR) + lane * 4) = xa;
                 }
