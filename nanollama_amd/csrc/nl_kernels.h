@@ -805,10 +805,19 @@ __device__ __forceinline__ float embed_value(const uint8_t *table, int wtype, in
 __global__ void embed_kernel(EmbedParams P) {
     const int token = P.ctl[CTL_TOKEN];
     const int gr = P.gamma_row ? P.gamma_row[token] : -1;
-    for (int i = threadIdx.x; i < P.dim; i += blockDim.x) {
-        float v = embed_value(P.table, P.wtype, P.dim, token, i);
-        if (gr >= 0) v += P.gamma_val[(long long)gr * P.dim + i];
-        P.x[i] = v;
+    // four elements per lane and round, their byte loads issued together (clamped index, masked store): one memory
+    // latency per round instead of one per element
+    for (int i0 = threadIdx.x; i0 < P.dim; i0 += 4 * blockDim.x) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = embed_value(P.table, P.wtype, P.dim, token, min(i0 + k * (int)blockDim.x, P.dim - 1));
+        if (gr >= 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] += P.gamma_val[(long long)gr * P.dim + min(i0 + k * (int)blockDim.x, P.dim - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (i0 + k * (int)blockDim.x < P.dim) P.x[i0 + k * blockDim.x] = v[k];
     }
 }
 
