@@ -195,42 +195,61 @@ struct BMergeParams {
     int nt16, q4;
 };
 
-// online-softmax merge of the position splits (same arithmetic as the decode GEMV's PRO_ATTN prologue);
-// one thread per 8 k-slots of the output row
-__global__ void battn_merge_kernel(BMergeParams P) {
-    const int item = blockIdx.x, hd = P.head_dim;
-    const int ns = P.pos[item] / ATT_CH + 1;
-    const long long pbase = (long long)item * P.heads * P.nsplit_max;
-    for (int u = threadIdx.x; u < P.heads * hd / 8; u += blockDim.x) {
+// online-softmax merge of the position splits (same arithmetic and summation order as the decode GEMV's
+// PRO_ATTN prologue); one thread per 8 k-slots of the output row.  The (max, sum) pairs of all splits and the
+// partial rows of four splits at a time are fetched with clamped indices before anything consumes them
+// (a runtime-bounded "for c < ns: load" loop is ns dependent round trips); splits past ns get weight 0.
+__global__ void battn_merge_kernel(BMergeParams P, int n_items) {
+    constexpr int MAXS = 16;                         // seq_len <= 2048 (go/model.go:145-148) => at most 16 splits
+    const int hd = P.head_dim, upi = P.heads * hd / 8;
+    const long long total = (long long)n_items * upi;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int item = (int)(idx / upi), u = (int)(idx - (long long)item * upi);
+        const int ns = min(P.pos[item] / ATT_CH + 1, MAXS);
+        const long long pbase = (long long)item * P.heads * P.nsplit_max;
         const int blk = u >> 2, w = u & 3;
         const int h = blk * 32 / hd;                 // a 32-column block never straddles heads (hd = 32 or 64)
-        const float *ml = P.part_ml + (pbase + (long long)h * P.nsplit_max) * 2;
-        float wt[16], scale;
-        if (ns == 1) {
-            scale = 1.0f / ml[1];
-        } else {
-            float M = ml[0];
-            for (int c = 1; c < ns; c++) M = fmaxf(M, ml[2 * c]);
-            float L = 0.f;
-            for (int c = 0; c < ns; c++) {
-                wt[c] = (float)exp((double)(ml[2 * c] - M));
-                L += wt[c] * ml[2 * c + 1];
-            }
-            scale = 1.0f / L;
+        const float2 *ml = reinterpret_cast<const float2 *>(P.part_ml) + (pbase + (long long)h * P.nsplit_max);
+        float2 mlv[MAXS];
+#pragma unroll
+        for (int c = 0; c < MAXS; c++) mlv[c] = ml[min(c, ns - 1)];
+        float M = mlv[0].x;
+#pragma unroll
+        for (int c = 1; c < MAXS; c++) M = c < ns ? fmaxf(M, mlv[c].x) : M;
+        float wt[MAXS], L = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXS; c++) {
+            wt[c] = 0.f;
+            if (c < ns) wt[c] = (float)exp((double)(mlv[c].x - M));
+            L += wt[c] * mlv[c].y;
         }
+        const float scale = 1.0f / L;
+        const float *po = P.part_o + (pbase + (long long)h * P.nsplit_max) * hd + (blk * 32 - h * hd);
+        const int offa = P.q4 ? 4 * w : 8 * w, offb = P.q4 ? 16 + 4 * w : 8 * w + 4;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int d = blk * 32 + slot_elem(P.q4, w, j) - h * hd;
-            const float *po = P.part_o + (pbase + (long long)h * P.nsplit_max) * hd + d;
-            float o;
-            if (ns == 1) o = po[0];
-            else {
-                o = 0.f;
-                for (int c = 0; c < ns; c++) o += wt[c] * po[(long long)c * hd];
+        for (int j = 0; j < 8; j++) v[j] = 0.f;
+        for (int c0 = 0; c0 < ns; c0 += 4) {
+            float pv[4][8];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // slots (w, j) of the block, as load_x_slots: only the two middle lanes of each float4 differ by type
+                const float *src = po + (long long)min(c0 + k, ns - 1) * hd;
+                const float4 a = *reinterpret_cast<const float4 *>(src + offa), b = *reinterpret_cast<const float4 *>(src + offb);
+                pv[k][0] = a.x; pv[k][1] = P.q4 ? a.z : a.y; pv[k][2] = P.q4 ? a.y : a.z; pv[k][3] = a.w;
+                pv[k][4] = b.x; pv[k][5] = P.q4 ? b.z : b.y; pv[k][6] = P.q4 ? b.y : b.z; pv[k][7] = b.w;
             }
-            v[j] = o * scale;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float wk = 0.f;
+#pragma unroll
+                for (int c = 0; c < MAXS; c++) wk = (c == c0 + k) ? wt[c] : wk;
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] += wk * pv[k][j];
+            }
         }
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] *= scale;
         store_frag(P.xf, P.nt16, item, blk, w, v);
     }
 }

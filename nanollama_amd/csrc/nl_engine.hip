@@ -744,7 +744,10 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
                 LCK(launch_attn(hd, e->gqa, P, dim3(e->KVs, e->nsplit_max, n), st));
             }
             BMergeParams M{b.part_o, b.part_ml, b.pos, e->Hs, e->nsplit_max, hd, b.xfrag, nt16, L.wo.wtype == WT_Q4_0 ? 1 : 0};
-            hipLaunchKernelGGL(battn_merge_kernel, dim3(n), dim3(256), 0, st, M);
+            {
+                const long long units = (long long)n * e->Hs * hd / 8;
+                hipLaunchKernelGGL(battn_merge_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, M, n);
+            }
             LCK(hipGetLastError());
         }
         LCK(qg(e, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo));
