@@ -33,6 +33,38 @@ __device__ __forceinline__ float gemm_out_at(const GemmOut &g, long long idx, in
     return v;
 }
 
+// four consecutive columns (idx, col multiples of 4): same arithmetic per element as gemm_out_at
+__device__ __forceinline__ float4 gemm_out_at4(const GemmOut &g, long long idx, int col) {
+    if (g.ks <= 1) return *reinterpret_cast<const float4 *>(g.val + idx);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z0 = 0; z0 < g.ks; z0 += 4) {
+        float4 p[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) p[k] = *reinterpret_cast<const float4 *>(g.part + (long long)min(z0 + k, g.ks - 1) * g.zstride + idx);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool on = z0 + k < g.ks;
+            v.x += on ? p[k].x : 0.f; v.y += on ? p[k].y : 0.f; v.z += on ? p[k].z : 0.f; v.w += on ? p[k].w : 0.f;
+        }
+    }
+    if (g.bias) {
+        const float4 b = *reinterpret_cast<const float4 *>(g.bias + col);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    return v;
+}
+
+// the 8 k-slots (w, j) of a 32-column block from its two float4 groups a (columns offa..+3) and b (offb..+3),
+// slot_offsets() below: only the two middle lanes of each group differ between the Q4_0 and the linear order
+__device__ __forceinline__ void slots_from(int q4, const float4 &a, const float4 &b, float (&v)[8]) {
+    v[0] = a.x; v[1] = q4 ? a.z : a.y; v[2] = q4 ? a.y : a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = q4 ? b.z : b.y; v[6] = q4 ? b.y : b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void slot_offsets(int q4, int w, int &offa, int &offb) {
+    offa = q4 ? 4 * w : 8 * w;
+    offb = q4 ? 16 + 4 * w : 8 * w + 4;
+}
+
 // element (0..31) of a 32-column block that k-slot (w, j) of the MFMA operands holds (nl_qgemm.h load_x_slots)
 __device__ __forceinline__ int slot_elem(int q4, int w, int j) {
     return q4 ? ((j >> 2) * 16 + 4 * w + ((j & 1) << 1) + ((j >> 1) & 1)) : 8 * w + j;
@@ -86,7 +118,75 @@ struct BNormParams {
     int nt16, q4;
 };
 
+// UPT = 8-slot units per thread (host: dim / 8 <= UPT * blockDim.x).  A thread's units stay in registers
+// from the sum of squares to the fragment store: one trip to memory per row, 16-byte loads.
+template <int UPT>
 __global__ void __launch_bounds__(256) bnorm_kernel(BNormParams P) {
+    __shared__ double dred[4];
+    const int item = P.item0 + blockIdx.x, n = P.dim, nu = n / 8;
+    float *xr = P.x + (long long)item * n;
+    const bool fold = P.pend.ks > 1;
+    float4 xa[UPT], xb[UPT];
+    int ca[UPT], cb[UPT];
+#pragma unroll
+    for (int k = 0; k < UPT; k++) {
+        const int u = min((int)threadIdx.x + k * (int)blockDim.x, nu - 1);
+        int offa, offb;
+        slot_offsets(P.q4, u & 3, offa, offb);
+        ca[k] = (u >> 2) * 32 + offa; cb[k] = (u >> 2) * 32 + offb;
+        xa[k] = *reinterpret_cast<const float4 *>(xr + ca[k]);
+        xb[k] = *reinterpret_cast<const float4 *>(xr + cb[k]);
+    }
+    if (fold) {
+#pragma unroll
+        for (int k = 0; k < UPT; k++) {
+            const float4 pa = gemm_out_at4(P.pend, (long long)item * n + ca[k], ca[k]);
+            const float4 pb = gemm_out_at4(P.pend, (long long)item * n + cb[k], cb[k]);
+            xa[k] = make_float4(pa.x + xa[k].x, pa.y + xa[k].y, pa.z + xa[k].z, pa.w + xa[k].w);
+            xb[k] = make_float4(pb.x + xb[k].x, pb.y + xb[k].y, pb.z + xb[k].z, pb.w + xb[k].w);
+            if ((int)threadIdx.x + k * (int)blockDim.x < nu) {
+                *reinterpret_cast<float4 *>(xr + ca[k]) = xa[k];
+                *reinterpret_cast<float4 *>(xr + cb[k]) = xb[k];
+            }
+        }
+    }
+    float4 wa[UPT], wb[UPT];
+#pragma unroll
+    for (int k = 0; k < UPT; k++) {
+        wa[k] = *reinterpret_cast<const float4 *>(P.w + ca[k]);
+        wb[k] = *reinterpret_cast<const float4 *>(P.w + cb[k]);
+    }
+    double ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < UPT; k++) {
+        double t = 0.0;
+        t = fma((double)xa[k].x, (double)xa[k].x, t); t = fma((double)xa[k].y, (double)xa[k].y, t);
+        t = fma((double)xa[k].z, (double)xa[k].z, t); t = fma((double)xa[k].w, (double)xa[k].w, t);
+        t = fma((double)xb[k].x, (double)xb[k].x, t); t = fma((double)xb[k].y, (double)xb[k].y, t);
+        t = fma((double)xb[k].z, (double)xb[k].z, t); t = fma((double)xb[k].w, (double)xb[k].w, t);
+        ss += (int)threadIdx.x + k * (int)blockDim.x < nu ? t : 0.0;
+    }
+    ss = wave_sum_f64(ss);
+    if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    double tot = 0.0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); k++) tot += dred[k];
+    const float inv = (float)(1.0 / sqrt(tot / (double)n + (double)P.eps));
+#pragma unroll
+    for (int k = 0; k < UPT; k++) {
+        const int u = (int)threadIdx.x + k * (int)blockDim.x;
+        if (u >= nu) continue;
+        float xv[8], wv[8], v[8];
+        slots_from(P.q4, xa[k], xb[k], xv);
+        slots_from(P.q4, wa[k], wb[k], wv);
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (xv[j] * inv) * wv[j];
+        store_frag(P.xf, P.nt16, blockIdx.x, u >> 2, u & 3, v);
+    }
+}
+
+// any dim: strided passes over the row (the row is re-read after the reduction)
+__global__ void __launch_bounds__(256) bnorm_generic_kernel(BNormParams P) {
     __shared__ double dred[4];
     const int item = P.item0 + blockIdx.x, n = P.dim;
     float *xr = P.x + (long long)item * n;
@@ -225,7 +325,8 @@ __global__ void battn_merge_kernel(BMergeParams P, int n_items) {
         }
         const float scale = 1.0f / L;
         const float *po = P.part_o + (pbase + (long long)h * P.nsplit_max) * hd + (blk * 32 - h * hd);
-        const int offa = P.q4 ? 4 * w : 8 * w, offb = P.q4 ? 16 + 4 * w : 8 * w + 4;
+        int offa, offb;
+        slot_offsets(P.q4, w, offa, offb);
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) v[j] = 0.f;
@@ -236,8 +337,7 @@ __global__ void battn_merge_kernel(BMergeParams P, int n_items) {
                 // slots (w, j) of the block, as load_x_slots: only the two middle lanes of each float4 differ by type
                 const float *src = po + (long long)min(c0 + k, ns - 1) * hd;
                 const float4 a = *reinterpret_cast<const float4 *>(src + offa), b = *reinterpret_cast<const float4 *>(src + offb);
-                pv[k][0] = a.x; pv[k][1] = P.q4 ? a.z : a.y; pv[k][2] = P.q4 ? a.y : a.z; pv[k][3] = a.w;
-                pv[k][4] = b.x; pv[k][5] = P.q4 ? b.z : b.y; pv[k][6] = P.q4 ? b.y : b.z; pv[k][7] = b.w;
+                slots_from(P.q4, a, b, pv[k]);
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -268,14 +368,25 @@ __global__ void bswiglu_kernel(BSwigluParams P) {
     const long long total = (long long)P.n_tokens * upt;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int n = (int)(i / upt), u = (int)(i - (long long)n * upt), blk = u >> 2, w = u & 3;
-        float v[8];
+        int offa, offb;
+        slot_offsets(P.q4, w, offa, offb);
+        const int ca = blk * 32 + offa, cb = blk * 32 + offb;
+        const long long row = (long long)n * P.interm;
+        float4 ga, gb, ua, ub;
+        if (P.g.ks <= 1 && P.u.ks <= 1) {   // one branch around all four loads: they are in flight together
+            ga = *reinterpret_cast<const float4 *>(P.g.val + row + ca); gb = *reinterpret_cast<const float4 *>(P.g.val + row + cb);
+            ua = *reinterpret_cast<const float4 *>(P.u.val + row + ca); ub = *reinterpret_cast<const float4 *>(P.u.val + row + cb);
+        } else {
+            ga = gemm_out_at4(P.g, row + ca, ca); gb = gemm_out_at4(P.g, row + cb, cb);
+            ua = gemm_out_at4(P.u, row + ca, ca); ub = gemm_out_at4(P.u, row + cb, cb);
+        }
+        float gv[8], uv[8], v[8];
+        slots_from(P.q4, ga, gb, gv);
+        slots_from(P.q4, ua, ub, uv);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const int col = blk * 32 + slot_elem(P.q4, w, j);
-            const long long idx = (long long)n * P.interm + col;
-            const float gv = gemm_out_at(P.g, idx, col), uv = gemm_out_at(P.u, idx, col);
-            const float ex = (float)exp((double)(-gv));
-            v[j] = (gv / (1.0f + ex)) * uv;
+            const float ex = (float)exp((double)(-gv[j]));
+            v[j] = (gv[j] / (1.0f + ex)) * uv[j];
         }
         store_frag(P.xf, P.nt16, n, blk, w, v);
     }

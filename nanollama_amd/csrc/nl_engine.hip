@@ -715,7 +715,11 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
     GemmOut pend{nullptr, nullptr, 1, 0, nullptr};   // GEMM output not yet folded into the residual stream
     auto norm = [&](const float *w, const PackedMat &next, int item0, int cnt) {
         BNormParams P{b.x, pend, w, c.rms_eps, D, item0, b.xfrag, ((cnt + 63) / 64) * 4, next.wtype == WT_Q4_0 ? 1 : 0};
-        hipLaunchKernelGGL(bnorm_kernel, dim3(cnt), dim3(256), 0, st, P);
+        const int nu = D / 8;
+        if (nu <= 256) hipLaunchKernelGGL(bnorm_kernel<1>, dim3(cnt), dim3(std::min(256, (nu + 63) / 64 * 64)), 0, st, P);
+        else if (nu <= 512) hipLaunchKernelGGL(bnorm_kernel<2>, dim3(cnt), dim3(256), 0, st, P);
+        else if (nu <= 1024) hipLaunchKernelGGL(bnorm_kernel<4>, dim3(cnt), dim3(256), 0, st, P);
+        else hipLaunchKernelGGL(bnorm_generic_kernel, dim3(cnt), dim3(256), 0, st, P);
         pend = GemmOut{nullptr, nullptr, 1, 0, nullptr};
         return hipGetLastError();
     };

@@ -26,7 +26,7 @@ int main(int argc, char **argv) {
     struct Shape { const char *name; int rows, cols; };
     std::vector<Shape> shapes = {{"goldie qkv", 2304, 1536}, {"goldie wo", 1536, 1536}, {"goldie gate", 4096, 1536},
                                  {"goldie down", 1536, 4096}, {"mini gate", 2048, 768}, {"mini down", 768, 2048},
-                                 {"big gate", 11008, 4096}};
+                                 {"big gate", 11008, 4096}, {"mini qkv", 1152, 768}, {"mini wo", 768, 768}};
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (size_t si = 0; si < shapes.size(); si++) {
