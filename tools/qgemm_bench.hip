@@ -1,6 +1,6 @@
 // qgemm_bench.hip -- developer microbenchmark of the multi-token MFMA kernel (nl_qgemm.h) on random packed
 // weights: time per launch for the GEMM shapes of a tier at N tokens, cycling through enough weight copies
-// that every launch streams from HBM.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off
+// that every launch streams from HBM.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize
 //        -I nanollama_amd/csrc tools/qgemm_bench.hip -o /tmp/qgemm_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
