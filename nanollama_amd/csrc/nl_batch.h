@@ -75,9 +75,10 @@ __device__ __forceinline__ void store_frag(uint4 *xf, int nt16, int n, int blk, 
     half8_t hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        hi[j] = (_Float16)v[j];
-        lo[j] = (_Float16)(v[j] - (float)hi[j]);
-    }
+            _Float16 h, l;
+            split_hi_lo(v[j], h, l);
+            hi[j] = h; lo[j] = l;
+        }
     const long long bt = (long long)blk * nt16 + (n >> 4);
     const int fl = w * 16 + (n & 15);
     xf[(bt * 2 + 0) * QG_FRAG + fl] = __builtin_bit_cast(uint4, hi);

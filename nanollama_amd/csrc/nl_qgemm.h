@@ -83,19 +83,19 @@ __device__ __forceinline__ void load_x_slots(const float *xb, int w, float (&v)[
     }
 }
 
-// weight fragment (8 fp16 k-slots of one row of one block) straight from the tile layout: raw() issues the
+// weight fragment (8 fp16 k-slots of one row of one block) straight from the tile layout: the kernel issues the
 // load (kept in its packed form while the previous chunk computes), expand() makes the fp16 operand
 template <int WT> struct WFrag;
 
 template <> struct WFrag<WT_Q4_0> {
     typedef uint32_t raw_t;
-    // chunk c of pair p == block 2p+c; lane (row i, dword w) reads one dword
-    static __device__ __forceinline__ raw_t raw(const uint8_t *q, long long tile_pair0, int npairs, int blk, int i, int w) {
-        const int p = blk >> 1, c = blk & 1, g = p >> 2, k = p & 3;
-        const int gsz = min(KL, npairs - g * KL);
-        return *(reinterpret_cast<const uint32_t *>(
-            q + ((tile_pair0 * 2 * TR) + (long long)g * (KL * 2 * TR) + (c * TR + i) * gsz + k) * 16) + w);
-    }
+    // chunk c of pair p == block 2p+c; lane (row i, dword w) reads one dword at
+    //   q + ((tile*npairs + g*KL)*2*TR + (c*TR + i)*gsz + k)*16 + 4w,   p = 4g + k, gsz = pairs in group g,
+    // split into a wave-uniform part (group base + blk_off) and a per-lane part that only depends on the group's
+    // size: the uniform part lives in SGPRs and the loads take the saddr form
+    static constexpr int CPP = 2;
+    static __device__ __forceinline__ unsigned lane_off(int i, int w, int gsz) { return (unsigned)(i * gsz) * 16u + (unsigned)w * 4u; }
+    static __device__ __forceinline__ unsigned blk_off(int odd, int k, int gsz) { return (unsigned)(odd * TR * gsz + k) * 16u; }
     static __device__ __forceinline__ raw_t zero() { return 0x88888888u; }
     static __device__ __forceinline__ half8_t expand(raw_t u) {
         const uint32_t u8 = u >> 8;
@@ -116,13 +116,13 @@ template <> struct WFrag<WT_Q4_0> {
 
 template <> struct WFrag<WT_Q8_0> {
     typedef uint2 raw_t;
-    // block 2p+h = chunks 2h, 2h+1 of pair p; lane (row i, slot group w) reads bytes 8w..8w+7 of the block
-    static __device__ __forceinline__ raw_t raw(const uint8_t *q, long long tile_pair0, int npairs, int blk, int i, int w) {
-        const int p = blk >> 1, c = (blk & 1) * 2 + (w >> 1), g = p >> 2, k = p & 3;
-        const int gsz = min(KL, npairs - g * KL);
-        return *reinterpret_cast<const uint2 *>(
-            q + ((tile_pair0 * 4 * TR) + (long long)g * (KL * 4 * TR) + (c * TR + i) * gsz + k) * 16 + (w & 1) * 8);
+    // block 2p+h = chunks 2h, 2h+1 of pair p; lane (row i, slot group w) reads bytes 8w..8w+7 of the block:
+    //   q + ((tile*npairs + g*KL)*4*TR + (c*TR + i)*gsz + k)*16 + (w&1)*8,   c = 2h + (w>>1)
+    static constexpr int CPP = 4;
+    static __device__ __forceinline__ unsigned lane_off(int i, int w, int gsz) {
+        return (unsigned)(((w >> 1) * TR + i) * gsz) * 16u + (unsigned)(w & 1) * 8u;
     }
+    static __device__ __forceinline__ unsigned blk_off(int odd, int k, int gsz) { return (unsigned)(odd * 2 * TR * gsz + k) * 16u; }
     static __device__ __forceinline__ raw_t zero() { return make_uint2(0u, 0u); }
     static __device__ __forceinline__ half8_t expand(raw_t u) {
         half8_t r;
@@ -134,14 +134,19 @@ template <> struct WFrag<WT_Q8_0> {
     }
 };
 
-// the scale word of (tile, pair of block blk, row i): both blocks' fp16 d; scale_of() picks this block's
-template <int WT>
-__device__ __forceinline__ uint32_t load_scale_word(const uint32_t *s, long long tile_pair0, int npairs, int blk, int i) {
-    const int p = blk >> 1, g = p >> 2, k = p & 3;
-    const int gsz = min(KL, npairs - g * KL);
-    return s[tile_pair0 * TR + g * (KL * TR) + i * gsz + k];
-}
+// the scale word of (tile, pair, row i) holds both blocks' fp16 d: s[(tile*npairs + g*KL)*TR + i*gsz + k]; scale_of() picks one
 __device__ __forceinline__ float scale_of(uint32_t word, int blk) { return h2f_bits((word >> (16 * (blk & 1))) & 0xffff); }
+
+// x = hi + lo, two fp16 values (~2^-22 relative).  The f32 value is pinned in a register first: when v is a
+// product the compiler otherwise derives hi TWICE -- once as cvt(f32 product) for the store, once as
+// v_fma_mixlo_f16 (one rounding of the exact product) inside the lo computation -- and on the rare double-rounding
+// ties the stored hi and the lo no longer add up to v (error 2^-11 of that element; seen as sporadic 1e-4 logits).
+__device__ __forceinline__ void split_hi_lo(float v, _Float16 &hi, _Float16 &lo) {
+    asm("" : "+v"(v));
+    const _Float16 h = (_Float16)v;
+    hi = h;
+    lo = (_Float16)(v - (float)h);
+}
 
 // x -> fp16 hi/lo fragments.  One thread per (block, 16-token tile, slot group w, token): reads the 8 k-slot
 // elements of its token (two float4), writes the hi and the lo fragment entry (16 bytes each; the 16 tokens of a
@@ -165,8 +170,9 @@ __global__ void xsplit_kernel(const float *x, int ldx, int nblocks, int n_tokens
         half8_t hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            hi[j] = (_Float16)v[j];
-            lo[j] = (_Float16)(v[j] - (float)hi[j]);
+            _Float16 h, l;
+            split_hi_lo(v[j], h, l);
+            hi[j] = h; lo[j] = l;
         }
         xf[(bt * 2 + 0) * QG_FRAG + fl] = __builtin_bit_cast(uint4, hi);
         xf[(bt * 2 + 1) * QG_FRAG + fl] = __builtin_bit_cast(uint4, lo);
@@ -182,17 +188,17 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
     typedef typename WFrag<WT>::raw_t raw_t;
     // fragment buffers: [buffer][block in chunk][token tile][hi/lo][lane] x 16 bytes
     __shared__ __attribute__((aligned(16))) uint4 xfrag[2][QG_KC * 8 * QG_FRAG];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 15, lw = lane >> 4;
     const int tok0 = blockIdx.y * QG_TOK;
     const int nblocks = P.cols / 32;
     const int nchunks = (nblocks + QG_KC - 1) / QG_KC;
     const bool second = P.q1 && (int)blockIdx.x >= P.row_groups;
     const uint8_t *const Wq = second ? P.q1 : P.q;
-    const uint32_t *const Ws = second ? P.s1 : P.s;
+    const uint8_t *const Ws = reinterpret_cast<const uint8_t *>(second ? P.s1 : P.s);
     float *const outp = second ? P.out1 : P.out, *const partp = second ? P.part1 : P.part;
     const int tile0 = (((int)blockIdx.x - (second ? P.row_groups : 0)) * QG_WAVES + wave) * QG_RT;
-    const uint4 *xsrc = P.xf + (long long)blockIdx.y * (8 * QG_FRAG) + lane;   // + block * nt16 * 2 * QG_FRAG
+    const uint8_t *const xsrc = reinterpret_cast<const uint8_t *>(P.xf + (long long)blockIdx.y * (8 * QG_FRAG));
 
     f32x4_t acc[QG_RT][4];
 #pragma unroll
@@ -203,52 +209,59 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
     // Both prefetch lambdas are BRANCH-FREE: out-of-range blocks / tiles are clamped to a valid address and
     // neutralised afterwards (scale 0, or simply never consumed).  A per-element "load or zero" branch makes
     // hipcc wait vmcnt(0) after every load -- one dependent memory round trip per block instead of one per chunk.
+    // Every address is "kernel-argument base + 32-bit offset", the offset being scalar arithmetic plus ONE VALU
+    // add of the lane's part (a packed matrix and a fragment store are each < 4 GiB): the prefetch of a chunk
+    // was ~130 VALU + ~80 SALU instructions of 64-bit address math in front of the MFMA stream, measured at a
+    // third of the kernel's time.
+    static_assert(QG_KC == 2 || QG_KC == 4 || QG_KC == 8, "a chunk is a whole number of pairs inside one group");
+    const unsigned xlane = (unsigned)lane * 16u;
+    const unsigned xblock = (unsigned)P.nt16 * (2 * QG_FRAG * 16);   // bytes of one block's fragments
     auto stage = [&](int chunk, int buf) {
         const int b0 = chunk * QG_KC;
         static_assert((8 * QG_KC) % QG_WAVES == 0, "fragments of a chunk divide evenly over the wavefronts");
 #pragma unroll
         for (int i = 0; i < 8 * QG_KC / QG_WAVES; i++) {
             const int f = wave + QG_WAVES * i;        // fragment of the chunk: block f/8, (tile, part) f%8
-            const int blk = min(b0 + (f >> 3), nblocks - 1);
+            const unsigned uo = (unsigned)min(b0 + (f >> 3), nblocks - 1) * xblock + (unsigned)(f & 7) * (QG_FRAG * 16);
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(xsrc + (long long)blk * P.nt16 * (2 * QG_FRAG) + (f & 7) * QG_FRAG),
+                (const __attribute__((address_space(1))) void *)(xsrc + (uo + xlane)),
                 (__attribute__((address_space(3))) void *)&xfrag[buf][f * QG_FRAG], 16, 0, 0);
         }
     };
-    auto wload = [&](int chunk, raw_t (&wq)[QG_RT][QG_KC], uint32_t (&wd)[QG_RT][QG_KC]) {
+    auto wload = [&](int chunk, raw_t (&wq)[QG_RT][QG_KC], uint32_t (&wd)[QG_RT][QG_KC / 2]) {
         const int b0 = chunk * QG_KC;
+        const int g = b0 >> 3;                         // 8 blocks per group; a chunk never straddles groups
+        const int gsz = min(KL, P.npairs - g * KL);
+        const unsigned lq = WFrag<WT>::lane_off(li, lw, gsz), ls = (unsigned)(li * gsz) * 4u;
 #pragma unroll
         for (int rt = 0; rt < QG_RT; rt++) {
-            const bool live = tile0 + rt < P.ntiles;
-            const long long tp0 = (long long)(live ? tile0 + rt : 0) * P.npairs;
+            const unsigned gp = (unsigned)(min(tile0 + rt, P.ntiles - 1) * P.npairs + g * KL);   // tiles past ntiles are never stored
+            const unsigned gq = gp * (WFrag<WT>::CPP * TR * 16), gs = gp * (TR * 4);
 #pragma unroll
             for (int b = 0; b < QG_KC; b++) {
                 const int blk = min(b0 + b, nblocks - 1);
-                wq[rt][b] = WFrag<WT>::raw(Wq, tp0, P.npairs, blk, li, lw);
-                wd[rt][b] = load_scale_word<WT>(Ws, tp0, P.npairs, blk, li);   // tiles past ntiles are never stored
+                wq[rt][b] = *reinterpret_cast<const raw_t *>(Wq + ((gq + WFrag<WT>::blk_off(blk & 1, (blk >> 1) & 3, gsz)) + lq));
+            }
+#pragma unroll
+            for (int pp = 0; pp < QG_KC / 2; pp++) {
+                const int blk = min(b0 + 2 * pp, nblocks - 1);
+                wd[rt][pp] = *reinterpret_cast<const uint32_t *>(Ws + ((gs + (unsigned)((blk >> 1) & 3) * 4u) + ls));
             }
         }
     };
 
-    raw_t wq[QG_RT][QG_KC], wqn[QG_RT][QG_KC];
-    uint32_t wd[QG_RT][QG_KC], wdn[QG_RT][QG_KC];
-    int chunk = blockIdx.z;
-    if (chunk < nchunks) {
-        stage(chunk, 0);
-        wload(chunk, wq, wd);
-    }
-    __syncthreads();                 // (drains the LDS-DMA queue: chunk 0 has landed)
-    for (int k = 0; chunk < nchunks; k++, chunk += P.ksplit) {
-        const int buf = k & 1, nb = min(QG_KC, nblocks - chunk * QG_KC);
-        const bool more = chunk + P.ksplit < nchunks;
-        if (more) {
-            stage(chunk + P.ksplit, buf ^ 1);
-            wload(chunk + P.ksplit, wqn, wdn);
-        }
-        // Straight-line over the chunk's blocks (no per-block branch: a block past the end of K was clamped to
-        // the last valid one by the prefetch and gets scale 0).  Per block: the 8 lo-part MFMAs go first on 8
-        // independent accumulators, then the 8 hi-part MFMAs -- each dependent pair is 8 issues apart, so no MFMA
-        // waits for its predecessor -- then the 32 "* d" FMAs.
+    // One chunk: issue the next chunk's prefetch (on the last chunk: the same chunk again, into the idle buffers
+    // -- no branch around the loads, so the scheduler may spread them through the MFMA stream), then straight-line
+    // over the chunk's blocks (a block past the end of K was clamped to the last valid one by the prefetch and
+    // gets scale 0).  Per block: the 8 lo-part MFMAs go first on 8 independent accumulators, then the 8 hi-part
+    // MFMAs -- each dependent pair is 8 issues apart, so no MFMA waits for its predecessor -- then the 32 "* d"
+    // FMAs.  The two register sets swap roles from call to call (no copies).
+    auto body = [&](int chunk, int buf, raw_t (&wq)[QG_RT][QG_KC], uint32_t (&wd)[QG_RT][QG_KC / 2],
+                    raw_t (&wqn)[QG_RT][QG_KC], uint32_t (&wdn)[QG_RT][QG_KC / 2]) {
+        const int nb = min(QG_KC, nblocks - chunk * QG_KC);
+        const int nxt = chunk + P.ksplit < nchunks ? chunk + P.ksplit : chunk;
+        stage(nxt, buf ^ 1);
+        wload(nxt, wqn, wdn);
 #pragma unroll
         for (int b = 0; b < QG_KC; b++) {
             half8_t wf[QG_RT], xh[4], xl[4];
@@ -261,7 +274,7 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
 #pragma unroll
             for (int rt = 0; rt < QG_RT; rt++) {
                 wf[rt] = WFrag<WT>::expand(wq[rt][b]);
-                const float d = scale_of(wd[rt][b], chunk * QG_KC + b);
+                const float d = scale_of(wd[rt][b >> 1], b);
                 dsc[rt] = b < nb ? d : 0.f;
             }
             f32x4_t z[QG_RT][4];
@@ -286,12 +299,22 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
                 }
         }
         __syncthreads();             // this chunk's buffer is free again; the next chunk's DMA has landed
-        if (more) {
-#pragma unroll
-            for (int rt = 0; rt < QG_RT; rt++)
-#pragma unroll
-                for (int b = 0; b < QG_KC; b++) { wq[rt][b] = wqn[rt][b]; wd[rt][b] = wdn[rt][b]; }
-        }
+    };
+
+    raw_t wqa[QG_RT][QG_KC], wqb[QG_RT][QG_KC];
+    uint32_t wda[QG_RT][QG_KC / 2], wdb[QG_RT][QG_KC / 2];
+    int chunk = blockIdx.z;
+    if (chunk < nchunks) {
+        stage(chunk, 0);
+        wload(chunk, wqa, wda);
+    }
+    __syncthreads();                 // (drains the LDS-DMA queue: chunk 0 has landed)
+    while (chunk < nchunks) {
+        body(chunk, 0, wqa, wda, wqb, wdb);
+        chunk += P.ksplit;
+        if (chunk >= nchunks) break;
+        body(chunk, 1, wqb, wdb, wqa, wda);
+        chunk += P.ksplit;
     }
     // D[token = (lane>>4)*4 + j][weight row = lane & 15].  The optional bias / residual operands are loaded for
     // the whole tile first (clamped addresses, no per-element branch -> one memory latency), then added.
