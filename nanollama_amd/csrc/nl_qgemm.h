@@ -21,14 +21,14 @@ constexpr int QG_TOK = 64;      // tokens per workgroup tile (4 MFMA column tile
 #define NL_QG_KC 4
 #endif
 #ifndef NL_QG_OCC
-#define NL_QG_OCC 2
+#define NL_QG_OCC 4
 #endif
 constexpr int QG_KC = NL_QG_KC;  // 32-element blocks per K chunk (128 columns)
 #ifndef NL_QG_WAVES
-#define NL_QG_WAVES 4
+#define NL_QG_WAVES 8
 #endif
 #ifndef NL_QG_RT
-#define NL_QG_RT 2
+#define NL_QG_RT 1
 #endif
 constexpr int QG_WAVES = NL_QG_WAVES;
 constexpr int QG_RT = NL_QG_RT;  // 16-row weight tiles per wavefront
@@ -179,7 +179,9 @@ __global__ void xsplit_kernel(const float *x, int ldx, int nblocks, int n_tokens
     }
 }
 
-// Workgroup = 4 wavefronts x QG_RT row tiles (128 weight rows) x 64 tokens; K walked in 128-column chunks.
+// Workgroup = QG_WAVES wavefronts x QG_RT row tiles (8 x 1: 128 weight rows) x 64 tokens; K walked in 128-column
+// chunks.  Eight light wavefronts (one row tile, ~100 VGPRs) at four per SIMD measured 5-15 % faster than four
+// heavy ones at two per SIMD for 64-512 tokens and equal at 2047 (tools/qgemm_variants.sh).
 // Software pipeline, one barrier per chunk: while chunk c is on the matrix cores, chunk c+1's activation
 // fragments travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: the fragment store is lane-linear, one
 // instruction per 1 KB fragment, no VGPR round trip) and its packed weights + scales travel to registers.
