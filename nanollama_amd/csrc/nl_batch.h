@@ -619,6 +619,203 @@ __global__ void __launch_bounds__(QT * G * 4, 2) attn_tile_kernel(AttnParams P, 
     }
 }
 
+// ---- the same tile on the fp16 matrix cores -------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate (1/16 of the fp16 MFMA rate); the f32 kernel above spends
+// 256 of them (8192 SIMD cycles) per wavefront.  Here every f32 operand is split x = hi + lo into two fp16 values
+// (split_hi_lo, ~2^-22 relative; the lo x lo term is dropped) and each product becomes three
+// v_mfma_f32_16x16x32_f16 (hi*hi + lo*hi + hi*lo, f32 accumulation): 96 MFMAs of 16 cycles per wavefront.
+//   * K is split while it is staged: Kh / Kl[key][hd] fp16, natural layout (A operand of S^T = K q^T: a lane
+//     reads 8 consecutive head_dim elements of its key with one ds_read_b128).
+//   * V is split AND transposed while it is staged: VTh / VTl[d][key position] -- the 16-bit MFMA wants a lane
+//     to hold 8 reduction indices (keys) of one output column d.  Two adjacent keys are packed per ds_write_b32.
+//     The key -> position map inside each 32-key group puts the 8 keys a lane owns side by side
+//     (key = 32m + 16h + 4kg + e  ->  position 32m + 8kg + 4h + e), which is exactly how the S^T accumulators
+//     leave P in registers (lane (row, kg) holds keys 16*mt + 4kg + e of key tile mt): P is converted in place,
+//     never moved, and V^T is read with one ds_read_b128 per operand.
+//   * p is scaled by 2^10 before its split (exact; keeps p down to 3e-11 above the fp16 underflow) and the
+//     output by 2^-10; max / sum are taken from the unscaled f32 values.
+// Partials (max, sum, sum p*v) leave in the decode kernel's layout, so battn_merge_kernel is shared.
+template <int HD, int G, int QT>
+__global__ void __launch_bounds__(QT * G * 4, 2) attn_tile16_kernel(AttnParams P, int n_items) {
+    constexpr int VH = QT * G;               // rows (token, query head) per workgroup
+    static_assert(VH % 16 == 0 && VH <= 64, "16 rows per wavefront");
+    constexpr int NTH = VH * 4;
+    constexpr int KS = HD + 8;               // K row stride (halves): 144 B rows
+    constexpr int VS = ATT_CH + 8;           // V^T row stride (halves): 272 B rows, 16-byte aligned
+    constexpr int NKS = HD / 32;             // 32-wide reduction steps of q.k
+    constexpr int NTO = HD / 16;             // output column tiles
+    constexpr int R4 = HD / 4;
+    static_assert(ATT_CH == 128, "key position map below assumes 4 groups of 32 keys");
+    __shared__ __attribute__((aligned(16))) _Float16 Kh[ATT_CH * KS], Kl[ATT_CH * KS];
+    __shared__ __attribute__((aligned(16))) _Float16 VTh[HD * VS], VTl[HD * VS];
+    __shared__ int nv[VH];
+
+    const int kvh = blockIdx.x, split = blockIdx.y, i0 = blockIdx.z * QT, tid = threadIdx.x;
+    const int t0 = split * ATT_CH;
+    int maxpos = -1;
+    for (int i = 0; i < QT; i++)
+        if (i0 + i < n_items) maxpos = max(maxpos, P.bpos[i0 + i]);
+    if (t0 > maxpos) return;
+    const int nrows = min(ATT_CH, maxpos + 1 - t0);
+    const int lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+
+    // B operand of S^T: row w*16+j, head_dim elements 32*ks + 8*kq .. +7, as hi / lo halves
+    half8_t qh[NKS], ql[NKS];
+    {
+        const int vh = w * 16 + j, item = min(i0 + vh / G, n_items - 1), g = vh % G;
+        const float *qp = P.qbuf + (long long)item * P.q_item_stride + (kvh * G + g) * HD + 8 * kq;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ks++) {
+            const float4 a = *reinterpret_cast<const float4 *>(qp + 32 * ks), b = *reinterpret_cast<const float4 *>(qp + 32 * ks + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                _Float16 h, l;
+                split_hi_lo(v[e], h, l);
+                qh[ks][e] = h; ql[ks][e] = l;
+            }
+        }
+    }
+    const long long soff = (long long)P.bstream[i0] * P.kv_stream_stride;
+    const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
+    const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
+    // staging: thread (key pair rp, float4 column c4) owns keys 2rp, 2rp+1 (clamped loads, zero beyond nrows so
+    // that masked probabilities meet finite values); all loads are issued before the first LDS store
+    constexpr int NIT = (ATT_CH / 2 * R4 + NTH - 1) / NTH;
+    float4 kreg[NIT][2], vreg[NIT][2];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int i = min(tid + it * NTH, ATT_CH / 2 * R4 - 1), rp = i / R4, c4 = i % R4;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int row = min(2 * rp + h, nrows - 1);
+            kreg[it][h] = K4[row * R4 + c4];
+            vreg[it][h] = V4[row * R4 + c4];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int i = tid + it * NTH, rp = i / R4, c4 = i % R4;
+        if (i >= ATT_CH / 2 * R4) continue;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const bool live = 2 * rp + h < nrows;
+            const float kv[4] = {kreg[it][h].x, kreg[it][h].y, kreg[it][h].z, kreg[it][h].w};
+            _Float16 hh[4], ll[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) split_hi_lo(live ? kv[e] : 0.f, hh[e], ll[e]);
+            typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<h4_t *>(Kh + (2 * rp + h) * KS + c4 * 4) = h4_t{hh[0], hh[1], hh[2], hh[3]};
+            *reinterpret_cast<h4_t *>(Kl + (2 * rp + h) * KS + c4 * 4) = h4_t{ll[0], ll[1], ll[2], ll[3]};
+        }
+        // V^T: keys 2rp, 2rp+1 sit side by side at position 32m + 8kg + 4h + e (e even)
+        const int r = 2 * rp, pos = (r & ~31) + 8 * ((r >> 2) & 3) + 4 * ((r >> 4) & 1) + (r & 3);
+        const float v0[4] = {vreg[it][0].x, vreg[it][0].y, vreg[it][0].z, vreg[it][0].w};
+        const float v1[4] = {vreg[it][1].x, vreg[it][1].y, vreg[it][1].z, vreg[it][1].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            _Float16 h0, l0, h1, l1;
+            split_hi_lo(r < nrows ? v0[e] : 0.f, h0, l0);
+            split_hi_lo(r + 1 < nrows ? v1[e] : 0.f, h1, l1);
+            *reinterpret_cast<h2_t *>(VTh + (c4 * 4 + e) * VS + pos) = h2_t{h0, h1};
+            *reinterpret_cast<h2_t *>(VTl + (c4 * 4 + e) * VS + pos) = h2_t{l0, l1};
+        }
+    }
+    if (tid < VH) {
+        const int item = i0 + tid / G;
+        nv[tid] = item < n_items ? min(ATT_CH, max(0, P.bpos[item] + 1 - t0)) : 0;
+    }
+    __syncthreads();
+
+    // ---- S^T = K q^T: 8 key tiles x 16 rows; lane (j, kq) ends up with row j's scores for keys 16*mt + 4*kq + r
+    v4f acc[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; mt++) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) {
+        half8_t kh[8], kl[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) {
+            kh[mt] = *reinterpret_cast<const half8_t *>(Kh + (mt * 16 + j) * KS + 32 * ks + 8 * kq);
+            kl[mt] = *reinterpret_cast<const half8_t *>(Kl + (mt * 16 + j) * KS + 32 * ks + 8 * kq);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[mt], qh[ks], acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt], ql[ks], acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt], qh[ks], acc[mt], 0, 0, 0);
+    }
+
+    // ---- softmax pieces of row j: 32 keys in this lane, the rest in lanes j+16, j+32, j+48 ----
+    const int nvj = nv[w * 16 + j];
+    float m = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < 8; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float sv = mt * 16 + 4 * kq + r < nvj ? acc[mt][r] * P.scale : -INFINITY;
+            acc[mt][r] = sv;
+            m = fmaxf(m, sv);
+        }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 8; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float pv = mt * 16 + 4 * kq + r < nvj ? expf(acc[mt][r] - m) : 0.f;
+            acc[mt][r] = pv;
+            l += pv;
+        }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+
+    // ---- O = P V: A = P (this lane's own accumulators, key tiles 2m and 2m+1), B = V^T rows from LDS ----
+    v4f o[NTO];
+#pragma unroll
+    for (int nt = 0; nt < NTO; nt++) o[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mm = 0; mm < 4; mm++) {
+        half8_t ph, pl;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            _Float16 h, lo;
+            split_hi_lo(acc[2 * mm + (e >> 2)][e & 3] * 1024.0f, h, lo);
+            ph[e] = h; pl[e] = lo;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTO; nt++) {
+            const half8_t vh = *reinterpret_cast<const half8_t *>(VTh + (NTO * j + nt) * VS + 32 * mm + 8 * kq);
+            const half8_t vl = *reinterpret_cast<const half8_t *>(VTl + (NTO * j + nt) * VS + 32 * mm + 8 * kq);
+            o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, o[nt], 0, 0, 0);
+            o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, o[nt], 0, 0, 0);
+            o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, o[nt], 0, 0, 0);
+        }
+    }
+
+    // O tile: this lane holds rows 4*kq+r, columns d = NTO*j .. NTO*j+NTO-1
+    constexpr float unscale = 1.0f / 1024.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int vh = w * 16 + 4 * kq + r;
+        if (nv[vh] == 0) continue;
+        const int item = i0 + vh / G, h = kvh * G + vh % G;
+        const long long slot = (long long)item * P.part_item_stride + (long long)h * P.nsplit_max + split;
+        float *po = P.part_o + slot * HD + NTO * j;
+        if constexpr (NTO == 4)
+            *reinterpret_cast<float4 *>(po) = make_float4(o[0][r] * unscale, o[1][r] * unscale, o[2][r] * unscale, o[3][r] * unscale);
+        else *reinterpret_cast<float2 *>(po) = make_float2(o[0][r] * unscale, o[1][r] * unscale);
+    }
+    if (kq == 0 && nvj > 0) {
+        const int vh = w * 16 + j, item = i0 + vh / G, h = kvh * G + vh % G;
+        const long long slot = (long long)item * P.part_item_stride + (long long)h * P.nsplit_max + split;
+        P.part_ml[slot * 2] = m;
+        P.part_ml[slot * 2 + 1] = l;
+    }
+}
+
 template <int G> struct AttnTileQT { static constexpr int value = G == 1 ? 64 : G == 2 ? 32 : G == 8 ? 8 : 16; };
 
 }  // namespace nl

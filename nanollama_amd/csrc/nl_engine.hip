@@ -355,7 +355,9 @@ hipError_t launch_attn(int hd, int gqa, AttnParams P, dim3 grid, hipStream_t st)
 template <int HD, int G>
 void launch_attn_tile_g(const AttnParams &P, int n, int kvs, int nsplit, hipStream_t st) {
     constexpr int QT = AttnTileQT<G>::value;
-    hipLaunchKernelGGL((attn_tile_kernel<HD, G, QT>), dim3(kvs, nsplit, (n + QT - 1) / QT), dim3(QT * G * 4), 0, st, P, n);
+    static const bool f32_tile = getenv("NL_ATTN_F32") != nullptr;   // developer knob: the f32-MFMA tile kernel
+    if (f32_tile) hipLaunchKernelGGL((attn_tile_kernel<HD, G, QT>), dim3(kvs, nsplit, (n + QT - 1) / QT), dim3(QT * G * 4), 0, st, P, n);
+    else hipLaunchKernelGGL((attn_tile16_kernel<HD, G, QT>), dim3(kvs, nsplit, (n + QT - 1) / QT), dim3(QT * G * 4), 0, st, P, n);
 }
 inline bool attn_tile_supported(int gqa) { return gqa == 1 || gqa == 2 || gqa == 3 || gqa == 4 || gqa == 8; }
 template <int HD>
@@ -621,7 +623,7 @@ namespace {
 
 // below this many tokens the ~10 launches per layer of the multi-token step cost more than n single-token steps
 // (measured: nano 2 streams 0.92 ms batched vs 0.60 ms as two single steps; break-even at 4)
-constexpr int NL_BATCH_MIN = 4;
+const int NL_BATCH_MIN = getenv("NL_BATCH_MIN") ? atoi(getenv("NL_BATCH_MIN")) : 4;   // env: developer knob (tools/)
 
 bool batch_supported(const nl_engine *e) {
     if (e->G != 1 || e->force_tp_plan) return false;

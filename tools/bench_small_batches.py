@@ -8,7 +8,7 @@ for tier, wtype in (("nano", "q8_0"), ("goldie", "q4_0")):
     g = b.gen(tier, wtype)
     dev = model.load_llama_model(g, max_streams=64)
     rng = np.random.Generator(np.random.PCG64(3))
-    for ns in (2, 4, 8, 16, 32, 64):
+    for ns in (2, 3, 4, 6, 8, 16, 32, 64):
         toks = [int(t) for t in rng.integers(3, g.meta.vocab_size, size=ns)]
         streams = list(range(ns))
         for p in range(4):
