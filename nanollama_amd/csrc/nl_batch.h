@@ -652,11 +652,15 @@ __global__ void __launch_bounds__(QT * G * 4, 2) attn_tile16_kernel(AttnParams P
 
     const int kvh = blockIdx.x, split = blockIdx.y, i0 = blockIdx.z * QT, tid = threadIdx.x;
     const int t0 = split * ATT_CH;
-    int maxpos = -1;
-    for (int i = 0; i < QT; i++)
-        if (i0 + i < n_items) maxpos = max(maxpos, P.bpos[i0 + i]);
+    int maxpos = -1, minpos = 0x7fffffff;
+    for (int i = 0; i < QT; i++) {
+        const int pp = i0 + i < n_items ? P.bpos[i0 + i] : -1;
+        maxpos = max(maxpos, pp);
+        minpos = min(minpos, pp);
+    }
     if (t0 > maxpos) return;
     const int nrows = min(ATT_CH, maxpos + 1 - t0);
+    const bool full = minpos >= t0 + ATT_CH - 1;   // every row of the tile sees every key of this split
     const int lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
 
     // B operand of S^T: row w*16+j, head_dim elements 32*ks + 8*kq .. +7, as hi / lo halves
@@ -747,28 +751,50 @@ __global__ void __launch_bounds__(QT * G * 4, 2) attn_tile16_kernel(AttnParams P
         for (int mt = 0; mt < 8; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt], qh[ks], acc[mt], 0, 0, 0);
     }
 
-    // ---- softmax pieces of row j: 32 keys in this lane, the rest in lanes j+16, j+32, j+48 ----
+    // ---- softmax pieces of row j: 32 keys in this lane, the rest in lanes j+16, j+32, j+48.  Splits below the
+    //      tile's diagonal see all 128 keys in every row (uniform test): no per-element masks there.
+    //      p = exp2((s - m) * log2 e) on v_exp_f32 (~1 ulp; the argument's rounding adds |s - m| * 6e-8 relative,
+    //      i.e. < 1e-6 wherever p matters) ----
     const int nvj = nv[w * 16 + j];
-    float m = -INFINITY;
+    constexpr float LOG2E = 1.44269504088896340736f;
+    float m = -INFINITY, l = 0.f;
+    if (full) {
 #pragma unroll
-    for (int mt = 0; mt < 8; mt++)
+        for (int mt = 0; mt < 8; mt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float sv = mt * 16 + 4 * kq + r < nvj ? acc[mt][r] * P.scale : -INFINITY;
-            acc[mt][r] = sv;
-            m = fmaxf(m, sv);
-        }
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float l = 0.f;
+            for (int r = 0; r < 4; r++) {
+                acc[mt][r] *= P.scale;
+                m = fmaxf(m, acc[mt][r]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
 #pragma unroll
-    for (int mt = 0; mt < 8; mt++)
+        for (int mt = 0; mt < 8; mt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float pv = mt * 16 + 4 * kq + r < nvj ? expf(acc[mt][r] - m) : 0.f;
-            acc[mt][r] = pv;
-            l += pv;
-        }
+            for (int r = 0; r < 4; r++) {
+                acc[mt][r] = __builtin_amdgcn_exp2f((acc[mt][r] - m) * LOG2E);
+                l += acc[mt][r];
+            }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float sv = mt * 16 + 4 * kq + r < nvj ? acc[mt][r] * P.scale : -INFINITY;
+                acc[mt][r] = sv;
+                m = fmaxf(m, sv);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float pv = mt * 16 + 4 * kq + r < nvj ? __builtin_amdgcn_exp2f((acc[mt][r] - m) * LOG2E) : 0.f;
+                acc[mt][r] = pv;
+                l += pv;
+            }
+    }
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
 
