@@ -357,7 +357,10 @@ void launch_attn_tile_g(const AttnParams &P, int n, int kvs, int nsplit, hipStre
     constexpr int QT = AttnTileQT<G>::value;
     static const bool f32_tile = getenv("NL_ATTN_F32") != nullptr;   // developer knob: the f32-MFMA tile kernel
     if (f32_tile) hipLaunchKernelGGL((attn_tile_kernel<HD, G, QT>), dim3(kvs, nsplit, (n + QT - 1) / QT), dim3(QT * G * 4), 0, st, P, n);
-    else hipLaunchKernelGGL((attn_tile16_kernel<HD, G, QT>), dim3(kvs, nsplit, (n + QT - 1) / QT), dim3(QT * G * 4), 0, st, P, n);
+    else {
+        constexpr int QT16 = AttnTile16QT<G>::value;
+        hipLaunchKernelGGL((attn_tile16_kernel<HD, G, QT16>), dim3(kvs, nsplit, (n + QT16 - 1) / QT16), dim3(QT16 * G * 4), 0, st, P, n);
+    }
 }
 inline bool attn_tile_supported(int gqa) { return gqa == 1 || gqa == 2 || gqa == 3 || gqa == 4 || gqa == 8; }
 template <int HD>
