@@ -319,40 +319,50 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
         chunk += P.ksplit;
     }
     // D[token = (lane>>4)*4 + j][weight row = lane & 15].  The optional bias / residual operands are loaded for
-    // the whole tile first (clamped addresses, no per-element branch -> one memory latency), then added.
+    // the whole tile first (clamped addresses, no per-element branch -> one memory latency), then added.  A
+    // workgroup whose 64 tokens all exist (every one but the last of a prompt) stores without per-element tests.
+    const bool split = P.ksplit > 1, whole = tok0 + QG_TOK <= P.n_tokens;
+    float *const dst = split ? partp + (long long)blockIdx.z * P.n_tokens * P.ldo : outp;
+    const float *const resid = split ? nullptr : P.resid, *const bias = split ? nullptr : P.bias;
 #pragma unroll
     for (int rt = 0; rt < QG_RT; rt++) {
         const int row = (tile0 + rt) * TR + li;
         if (tile0 + rt >= P.ntiles || row >= P.rows) continue;
-        if (P.ksplit > 1) {
+        const float bv = bias ? bias[row] : 0.f;
+        unsigned off[4][4];
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+        for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int n = tok0 + t * 16 + lw * 4 + j;
-                    if (n < P.n_tokens) partp[((long long)blockIdx.z * P.n_tokens + n) * P.ldo + row] = acc[rt][t][j];
-                }
-            continue;
-        }
-        const float bv = P.bias ? P.bias[row] : 0.f;
+            for (int j = 0; j < 4; j++)
+                off[t][j] = (unsigned)min(tok0 + t * 16 + lw * 4 + j, P.n_tokens - 1) * (unsigned)P.ldo + (unsigned)row;
         float rv[4][4];
-        if (P.resid) {
+        if (resid) {
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    rv[t][j] = P.resid[(long long)min(tok0 + t * 16 + lw * 4 + j, P.n_tokens - 1) * P.ldo + row];
+                for (int j = 0; j < 4; j++) rv[t][j] = resid[off[t][j]];
         }
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int n = tok0 + t * 16 + lw * 4 + j;
                 float v = acc[rt][t][j];
-                if (P.bias) v += bv;
-                if (P.resid) v += rv[t][j];
-                if (n < P.n_tokens) outp[(long long)n * P.ldo + row] = v;
+                if (bias) v += bv;
+                if (resid) v += rv[t][j];
+                acc[rt][t][j] = v;
             }
+        if (whole) {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) dst[off[t][j]] = acc[rt][t][j];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (tok0 + t * 16 + lw * 4 + j < P.n_tokens) dst[off[t][j]] = acc[rt][t][j];
+        }
     }
 }
 
