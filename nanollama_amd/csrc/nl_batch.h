@@ -54,37 +54,6 @@ __device__ __forceinline__ float4 gemm_out_at4(const GemmOut &g, long long idx, 
     return v;
 }
 
-// the 8 k-slots (w, j) of a 32-column block from its two float4 groups a (columns offa..+3) and b (offb..+3),
-// slot_offsets() below: only the two middle lanes of each group differ between the Q4_0 and the linear order
-__device__ __forceinline__ void slots_from(int q4, const float4 &a, const float4 &b, float (&v)[8]) {
-    v[0] = a.x; v[1] = q4 ? a.z : a.y; v[2] = q4 ? a.y : a.z; v[3] = a.w;
-    v[4] = b.x; v[5] = q4 ? b.z : b.y; v[6] = q4 ? b.y : b.z; v[7] = b.w;
-}
-__device__ __forceinline__ void slot_offsets(int q4, int w, int &offa, int &offb) {
-    offa = q4 ? 4 * w : 8 * w;
-    offb = q4 ? 16 + 4 * w : 8 * w + 4;
-}
-
-// element (0..31) of a 32-column block that k-slot (w, j) of the MFMA operands holds (nl_qgemm.h load_x_slots)
-__device__ __forceinline__ int slot_elem(int q4, int w, int j) {
-    return q4 ? ((j >> 2) * 16 + 4 * w + ((j & 1) << 1) + ((j >> 1) & 1)) : 8 * w + j;
-}
-
-// the 8 k-slots (block blk, slot group w) of token n -> hi/lo entries of the fragment store
-__device__ __forceinline__ void store_frag(uint4 *xf, int nt16, int n, int blk, int w, const float (&v)[8]) {
-    half8_t hi, lo;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-            _Float16 h, l;
-            split_hi_lo(v[j], h, l);
-            hi[j] = h; lo[j] = l;
-        }
-    const long long bt = (long long)blk * nt16 + (n >> 4);
-    const int fl = w * 16 + (n & 15);
-    xf[(bt * 2 + 0) * QG_FRAG + fl] = __builtin_bit_cast(uint4, hi);
-    xf[(bt * 2 + 1) * QG_FRAG + fl] = __builtin_bit_cast(uint4, lo);
-}
-
 struct BEmbedParams {
     const uint8_t *table;
     int wtype, dim;

@@ -170,6 +170,7 @@ struct nl_engine {
         bool ready = false;
         int cap = 0, lm_cap = 0;
         uint4 *xfrag = nullptr;  // fp16 hi/lo activation fragments of the GEMM being run
+        uint4 *xfrag2 = nullptr; // second store: output of the fused gate/up/SwiGLU GEMM, input of down
         float *kpart = nullptr, *kpart2 = nullptr;  // split-K partial sums (second buffer: up, alive beside gate)
         size_t kpart_cap = 0;    // floats, each
         float *x = nullptr, *qkv = nullptr, *q = nullptr, *g = nullptr, *u = nullptr, *logits = nullptr,
@@ -589,6 +590,25 @@ hipError_t launch_xsplit(int wtype, const float *x, int ldx, int cols, int n_tok
     return hipGetLastError();
 }
 
+// gate || up with the SwiGLU epilogue (nl_qgemm.h): 4 wavefronts x (gate tile, up tile) per workgroup, no split-K.
+// Worth it only when the unsplit grid fills the chip; the caller falls back to the plain launch + bswiglu otherwise.
+constexpr int QG_FUSED_WAVES = 4;
+bool qgemm_swiglu_fits(int ntiles, int n_tokens) {
+    static const int min_wg = getenv("NL_FUSED_SWIGLU_MIN_WG") ? atoi(getenv("NL_FUSED_SWIGLU_MIN_WG")) : 128;   // knob: tests force 1, tools disable with a huge value
+    return ((ntiles + QG_FUSED_WAVES - 1) / QG_FUSED_WAVES) * ((n_tokens + QG_TOK - 1) / QG_TOK) >= min_wg;
+}
+hipError_t launch_qgemm_swiglu(int wtype, QGemmParams P, hipStream_t st) {
+    P.nt16 = ((P.n_tokens + 63) / 64) * 4;
+    P.ksplit = 1;
+    const dim3 grid((P.ntiles + QG_FUSED_WAVES - 1) / QG_FUSED_WAVES, (P.n_tokens + QG_TOK - 1) / QG_TOK, 1);
+    switch (wtype) {
+    case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0, QG_FUSED_WAVES, 2, QG_EPI_SWIGLU>), grid, dim3(QG_FUSED_WAVES * 64), 0, st, P); break;
+    case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0, QG_FUSED_WAVES, 2, QG_EPI_SWIGLU>), grid, dim3(QG_FUSED_WAVES * 64), 0, st, P); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_buf = nullptr, size_t part_cap = 0,
                         int *ks_out = nullptr) {
     P.nt16 = ((P.n_tokens + 63) / 64) * 4;
@@ -608,8 +628,8 @@ hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_bu
     P.part = part_buf;
     dim3 grid(row_groups * mats, tok_tiles, ks);
     switch (wtype) {
-    case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
-    case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
+    case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0, QG_WAVES, QG_RT, QG_EPI_PLAIN>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
+    case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0, QG_WAVES, QG_RT, QG_EPI_PLAIN>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
     default: return hipErrorInvalidValue;
     }
     hipError_t s = hipGetLastError();
@@ -663,6 +683,10 @@ int batch_alloc(nl_engine *e) {
         float *raw = nullptr;
         HIPCK(e, dalloc(&raw, nx * 4, &e->bytes_state));
         b.xfrag = reinterpret_cast<uint4 *>(raw);
+        const size_t nx2 = xfrag_uint4(e->Is, (int)n);   // SiLU(gate) * up, written by the fused gate/up GEMM
+        raw = nullptr;
+        HIPCK(e, dalloc(&raw, nx2 * 4, &e->bytes_state));
+        b.xfrag2 = reinterpret_cast<uint4 *>(raw);
     }
     b.kpart_cap = (size_t)16 * QG_TOK * std::max<size_t>(std::max<size_t>(R, c.dim), e->Is);
     HIPCK(e, dalloc(&b.kpart, b.kpart_cap, &e->bytes_state));
@@ -681,11 +705,11 @@ int batch_alloc(nl_engine *e) {
 // GEMM of the multi-token step: input = the fragment store the producing kernel just filled; output = `out`
 // (with resid / bias applied) when it ran unsplit, else split-K slabs in `part` for the consumer to add.
 hipError_t qg(nl_engine *e, const PackedMat &m, int n, float *out, int ldo, const float *resid, hipStream_t st,
-              GemmOut *res, float *part, const float *bias = nullptr) {
+              GemmOut *res, float *part, const float *bias = nullptr, const uint4 *xf = nullptr) {
     QGemmParams P{};
     P.bias = bias;
     P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
-    P.xf = e->bt.xfrag; P.n_tokens = n; P.out = out; P.ldo = ldo; P.resid = resid;
+    P.xf = xf ? xf : e->bt.xfrag; P.n_tokens = n; P.out = out; P.ldo = ldo; P.resid = resid;
     int ks = 1;
     hipError_t s = launch_qgemm(m.wtype, P, st, part, e->bt.kpart_cap, &ks);
     *res = GemmOut{out, part, ks, (long long)n * ldo, bias};
@@ -761,27 +785,39 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
         }
         LCK(qg(e, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo));
         LCK(norm(L.ffn_norm, L.gate, 0, n));
-        GemmOut gate, up;
         if (L.up.wtype != L.gate.wtype)   // (a mixed-type file: the fragment k-slot order differs per type)
             return e->fail(NL_ERR_UNSUPPORTED, "gate and up projections of different quantisation types");
-        {   // gate and up in ONE launch: same input fragments, twice the workgroups, half the split-K
+        const uint4 *down_in = b.xfrag;
+        if (qgemm_swiglu_fits(L.gate.ntiles, n)) {
+            // gate, up and SiLU(gate) * up in ONE launch; h leaves as fragments in the second fragment store
+            // (the first is still being read by other workgroups of this launch)
             QGemmParams P{};
             const PackedMat &m = L.gate;
             P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
-            P.xf = b.xfrag; P.n_tokens = n; P.out = b.g; P.ldo = e->Is;
-            P.q1 = L.up.q; P.s1 = L.up.s; P.out1 = b.u; P.part1 = b.kpart2;
-            int ks = 1;
-            LCK(launch_qgemm(m.wtype, P, st, b.kpart, b.kpart_cap, &ks));
-            gate = GemmOut{b.g, b.kpart, ks, (long long)n * e->Is, nullptr};
-            up = GemmOut{b.u, b.kpart2, ks, (long long)n * e->Is, nullptr};
-        }
-        {
+            P.xf = b.xfrag; P.n_tokens = n; P.ldo = e->Is;
+            P.q1 = L.up.q; P.s1 = L.up.s;
+            P.xf_out = b.xfrag2; P.out_q4 = L.down.wtype == WT_Q4_0 ? 1 : 0;
+            LCK(launch_qgemm_swiglu(m.wtype, P, st));
+            down_in = b.xfrag2;
+        } else {
+            GemmOut gate, up;
+            {   // gate and up in ONE launch: same input fragments, twice the workgroups, half the split-K
+                QGemmParams P{};
+                const PackedMat &m = L.gate;
+                P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
+                P.xf = b.xfrag; P.n_tokens = n; P.out = b.g; P.ldo = e->Is;
+                P.q1 = L.up.q; P.s1 = L.up.s; P.out1 = b.u; P.part1 = b.kpart2;
+                int ks = 1;
+                LCK(launch_qgemm(m.wtype, P, st, b.kpart, b.kpart_cap, &ks));
+                gate = GemmOut{b.g, b.kpart, ks, (long long)n * e->Is, nullptr};
+                up = GemmOut{b.u, b.kpart2, ks, (long long)n * e->Is, nullptr};
+            }
             BSwigluParams P{gate, up, e->Is, n, b.xfrag, nt16, L.down.wtype == WT_Q4_0 ? 1 : 0};
             const long long tot = (long long)n * e->Is / 8;
             hipLaunchKernelGGL(bswiglu_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 4096)), dim3(256), 0, st, P);
             LCK(hipGetLastError());
         }
-        LCK(qg(e, L.down, n, b.x, D, b.x, st, &pend, b.kpart));
+        LCK(qg(e, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in));
     }
     if (lm_mode) {
         // logits rows [0, cnt) of bt.logits / ids [0, cnt): all tokens (mode 1, n <= lm_cap) or just the last (mode 2)

@@ -32,6 +32,7 @@ constexpr int QG_KC = NL_QG_KC;  // 32-element blocks per K chunk (128 columns)
 #endif
 constexpr int QG_WAVES = NL_QG_WAVES;
 constexpr int QG_RT = NL_QG_RT;  // 16-row weight tiles per wavefront
+constexpr int QG_EPI_PLAIN = 0, QG_EPI_SWIGLU = 1;
 constexpr int QG_FRAG = 64;     // uint4 per activation fragment: 64 lanes x 16 bytes, lane-linear (= one LDS-DMA)
 
 // Activation fragments live in global memory in MFMA operand order, produced ONCE per activation matrix
@@ -58,6 +59,9 @@ struct QGemmParams {
     const uint32_t *s1;
     float *out1, *part1;
     int row_groups;
+    // fused SwiGLU epilogue (QG_EPI_SWIGLU): q = gate, q1 = up; the result leaves as fragments for the next GEMM
+    uint4 *xf_out;
+    int out_q4;          // k-slot order of the consumer's weight type
 };
 
 inline size_t xfrag_uint4(int cols, int n_tokens) {   // uint4 elements of a fragment store
@@ -179,14 +183,46 @@ __global__ void xsplit_kernel(const float *x, int ldx, int nblocks, int n_tokens
     }
 }
 
+// the 8 k-slots (w, j) of a 32-column block from its two float4 groups a (columns offa..+3) and b (offb..+3),
+// slot_offsets() below: only the two middle lanes of each group differ between the Q4_0 and the linear order
+__device__ __forceinline__ void slots_from(int q4, const float4 &a, const float4 &b, float (&v)[8]) {
+    v[0] = a.x; v[1] = q4 ? a.z : a.y; v[2] = q4 ? a.y : a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = q4 ? b.z : b.y; v[6] = q4 ? b.y : b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void slot_offsets(int q4, int w, int &offa, int &offb) {
+    offa = q4 ? 4 * w : 8 * w;
+    offb = q4 ? 16 + 4 * w : 8 * w + 4;
+}
+
+// element (0..31) of a 32-column block that k-slot (w, j) of the MFMA operands holds (nl_qgemm.h load_x_slots)
+__device__ __forceinline__ int slot_elem(int q4, int w, int j) {
+    return q4 ? ((j >> 2) * 16 + 4 * w + ((j & 1) << 1) + ((j >> 1) & 1)) : 8 * w + j;
+}
+
+// the 8 k-slots (block blk, slot group w) of token n -> hi/lo entries of the fragment store
+__device__ __forceinline__ void store_frag(uint4 *xf, int nt16, int n, int blk, int w, const float (&v)[8]) {
+    half8_t hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+            _Float16 h, l;
+            split_hi_lo(v[j], h, l);
+            hi[j] = h; lo[j] = l;
+        }
+    const long long bt = (long long)blk * nt16 + (n >> 4);
+    const int fl = w * 16 + (n & 15);
+    xf[(bt * 2 + 0) * QG_FRAG + fl] = __builtin_bit_cast(uint4, hi);
+    xf[(bt * 2 + 1) * QG_FRAG + fl] = __builtin_bit_cast(uint4, lo);
+}
+
 // Workgroup = QG_WAVES wavefronts x QG_RT row tiles (8 x 1: 128 weight rows) x 64 tokens; K walked in 128-column
 // chunks.  Eight light wavefronts (one row tile, ~100 VGPRs) at four per SIMD measured 5-15 % faster than four
 // heavy ones at two per SIMD for 64-512 tokens and equal at 2047 (tools/qgemm_variants.sh).
 // Software pipeline, one barrier per chunk: while chunk c is on the matrix cores, chunk c+1's activation
 // fragments travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: the fragment store is lane-linear, one
 // instruction per 1 KB fragment, no VGPR round trip) and its packed weights + scales travel to registers.
-template <int WT>
-__global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmParams P) {
+template <int WT, int WAVES, int RT, int EPI>
+__global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_kernel(QGemmParams P) {
+    static_assert(EPI == QG_EPI_PLAIN || RT == 2, "the fused epilogue pairs a gate tile with its up tile");
     typedef typename WFrag<WT>::raw_t raw_t;
     // fragment buffers: [buffer][block in chunk][token tile][hi/lo][lane] x 16 bytes
     __shared__ __attribute__((aligned(16))) uint4 xfrag[2][QG_KC * 8 * QG_FRAG];
@@ -195,16 +231,19 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
     const int tok0 = blockIdx.y * QG_TOK;
     const int nblocks = P.cols / 32;
     const int nchunks = (nblocks + QG_KC - 1) / QG_KC;
-    const bool second = P.q1 && (int)blockIdx.x >= P.row_groups;
+    // plain: workgroup columns [row_groups, 2*row_groups) run the optional second matrix; wavefront tiles tile0 + rt.
+    // fused: row tile rt = 0 is the gate tile and rt = 1 the up tile of the SAME 16 rows (q / q1).
+    constexpr bool FUSED = EPI == QG_EPI_SWIGLU;
+    const bool second = !FUSED && P.q1 && (int)blockIdx.x >= P.row_groups;
     const uint8_t *const Wq = second ? P.q1 : P.q;
     const uint8_t *const Ws = reinterpret_cast<const uint8_t *>(second ? P.s1 : P.s);
     float *const outp = second ? P.out1 : P.out, *const partp = second ? P.part1 : P.part;
-    const int tile0 = (((int)blockIdx.x - (second ? P.row_groups : 0)) * QG_WAVES + wave) * QG_RT;
+    const int tile0 = FUSED ? (int)blockIdx.x * WAVES + wave : (((int)blockIdx.x - (second ? P.row_groups : 0)) * WAVES + wave) * RT;
     const uint8_t *const xsrc = reinterpret_cast<const uint8_t *>(P.xf + (long long)blockIdx.y * (8 * QG_FRAG));
 
-    f32x4_t acc[QG_RT][4];
+    f32x4_t acc[RT][4];
 #pragma unroll
-    for (int rt = 0; rt < QG_RT; rt++)
+    for (int rt = 0; rt < RT; rt++)
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[rt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -220,25 +259,27 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
     const unsigned xblock = (unsigned)P.nt16 * (2 * QG_FRAG * 16);   // bytes of one block's fragments
     auto stage = [&](int chunk, int buf) {
         const int b0 = chunk * QG_KC;
-        static_assert((8 * QG_KC) % QG_WAVES == 0, "fragments of a chunk divide evenly over the wavefronts");
+        static_assert((8 * QG_KC) % WAVES == 0, "fragments of a chunk divide evenly over the wavefronts");
 #pragma unroll
-        for (int i = 0; i < 8 * QG_KC / QG_WAVES; i++) {
-            const int f = wave + QG_WAVES * i;        // fragment of the chunk: block f/8, (tile, part) f%8
+        for (int i = 0; i < 8 * QG_KC / WAVES; i++) {
+            const int f = wave + WAVES * i;        // fragment of the chunk: block f/8, (tile, part) f%8
             const unsigned uo = (unsigned)min(b0 + (f >> 3), nblocks - 1) * xblock + (unsigned)(f & 7) * (QG_FRAG * 16);
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(xsrc + (uo + xlane)),
                 (__attribute__((address_space(3))) void *)&xfrag[buf][f * QG_FRAG], 16, 0, 0);
         }
     };
-    auto wload = [&](int chunk, raw_t (&wq)[QG_RT][QG_KC], uint32_t (&wd)[QG_RT][QG_KC / 2]) {
+    const uint8_t *const wq_base = Wq, *const ws_base = Ws;
+    auto wload = [&](int chunk, raw_t (&wq)[RT][QG_KC], uint32_t (&wd)[RT][QG_KC / 2]) {
         const int b0 = chunk * QG_KC;
         const int g = b0 >> 3;                         // 8 blocks per group; a chunk never straddles groups
         const int gsz = min(KL, P.npairs - g * KL);
         const unsigned lq = WFrag<WT>::lane_off(li, lw, gsz), ls = (unsigned)(li * gsz) * 4u;
 #pragma unroll
-        for (int rt = 0; rt < QG_RT; rt++) {
-            const unsigned gp = (unsigned)(min(tile0 + rt, P.ntiles - 1) * P.npairs + g * KL);   // tiles past ntiles are never stored
+        for (int rt = 0; rt < RT; rt++) {
+            const unsigned gp = (unsigned)(min(FUSED ? tile0 : tile0 + rt, P.ntiles - 1) * P.npairs + g * KL);   // tiles past ntiles are never stored
             const unsigned gq = gp * (WFrag<WT>::CPP * TR * 16), gs = gp * (TR * 4);
+            const uint8_t *const Wq = FUSED && rt ? P.q1 : wq_base, *const Ws = FUSED && rt ? reinterpret_cast<const uint8_t *>(P.s1) : ws_base;
 #pragma unroll
             for (int b = 0; b < QG_KC; b++) {
                 const int blk = min(b0 + b, nblocks - 1);
@@ -258,42 +299,42 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
     // gets scale 0).  Per block: the 8 lo-part MFMAs go first on 8 independent accumulators, then the 8 hi-part
     // MFMAs -- each dependent pair is 8 issues apart, so no MFMA waits for its predecessor -- then the 32 "* d"
     // FMAs.  The two register sets swap roles from call to call (no copies).
-    auto body = [&](int chunk, int buf, raw_t (&wq)[QG_RT][QG_KC], uint32_t (&wd)[QG_RT][QG_KC / 2],
-                    raw_t (&wqn)[QG_RT][QG_KC], uint32_t (&wdn)[QG_RT][QG_KC / 2]) {
+    auto body = [&](int chunk, int buf, raw_t (&wq)[RT][QG_KC], uint32_t (&wd)[RT][QG_KC / 2],
+                    raw_t (&wqn)[RT][QG_KC], uint32_t (&wdn)[RT][QG_KC / 2]) {
         const int nb = min(QG_KC, nblocks - chunk * QG_KC);
         const int nxt = chunk + P.ksplit < nchunks ? chunk + P.ksplit : chunk;
         stage(nxt, buf ^ 1);
         wload(nxt, wqn, wdn);
 #pragma unroll
         for (int b = 0; b < QG_KC; b++) {
-            half8_t wf[QG_RT], xh[4], xl[4];
-            float dsc[QG_RT];
+            half8_t wf[RT], xh[4], xl[4];
+            float dsc[RT];
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 xh[t] = __builtin_bit_cast(half8_t, xfrag[buf][((b * 4 + t) * 2 + 0) * QG_FRAG + lane]);
                 xl[t] = __builtin_bit_cast(half8_t, xfrag[buf][((b * 4 + t) * 2 + 1) * QG_FRAG + lane]);
             }
 #pragma unroll
-            for (int rt = 0; rt < QG_RT; rt++) {
+            for (int rt = 0; rt < RT; rt++) {
                 wf[rt] = WFrag<WT>::expand(wq[rt][b]);
                 const float d = scale_of(wd[rt][b >> 1], b);
                 dsc[rt] = b < nb ? d : 0.f;
             }
-            f32x4_t z[QG_RT][4];
+            f32x4_t z[RT][4];
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int rt = 0; rt < QG_RT; rt++)
+                for (int rt = 0; rt < RT; rt++)
                     z[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[t], wf[rt], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int rt = 0; rt < QG_RT; rt++)
+                for (int rt = 0; rt < RT; rt++)
                     z[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], wf[rt], z[rt][t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int rt = 0; rt < QG_RT; rt++) {
+                for (int rt = 0; rt < RT; rt++) {
                     acc[rt][t][0] = fmaf(z[rt][t][0], dsc[rt], acc[rt][t][0]);
                     acc[rt][t][1] = fmaf(z[rt][t][1], dsc[rt], acc[rt][t][1]);
                     acc[rt][t][2] = fmaf(z[rt][t][2], dsc[rt], acc[rt][t][2]);
@@ -303,8 +344,8 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
         __syncthreads();             // this chunk's buffer is free again; the next chunk's DMA has landed
     };
 
-    raw_t wqa[QG_RT][QG_KC], wqb[QG_RT][QG_KC];
-    uint32_t wda[QG_RT][QG_KC / 2], wdb[QG_RT][QG_KC / 2];
+    raw_t wqa[RT][QG_KC], wqb[RT][QG_KC];
+    uint32_t wda[RT][QG_KC / 2], wdb[RT][QG_KC / 2];
     int chunk = blockIdx.z;
     if (chunk < nchunks) {
         stage(chunk, 0);
@@ -318,6 +359,37 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
         body(chunk, 1, wqb, wdb, wqa, wda);
         chunk += P.ksplit;
     }
+    if constexpr (FUSED) {
+        // h = SiLU(gate) * up (go/quant.go:629-631, go/model.go:604-606) for this wavefront's 16 rows x 64 tokens,
+        // transposed through LDS (the fragment buffers are idle after the loop's last barrier) into the fp16 hi/lo
+        // fragments the down projection reads: the f32 gate / up matrices never exist in memory.
+        constexpr int HS = WAVES * TR + 4;           // floats per token row of the staging tile (16-byte aligned)
+        static_assert(64 * HS * 4 <= (int)sizeof(xfrag), "staging tile fits the fragment buffers");
+        float *const hb = reinterpret_cast<float *>(&xfrag[0][0]);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float gv = acc[0][t][j], uv = acc[1][t][j];
+                const float ex = (float)exp((double)(-gv));
+                hb[(t * 16 + lw * 4 + j) * HS + wave * TR + li] = (gv / (1.0f + ex)) * uv;
+            }
+        __syncthreads();
+        constexpr int NBLK = WAVES * TR / 32;        // 32-row blocks of the workgroup's rows
+        const int blk0 = (int)blockIdx.x * NBLK;
+        for (int u = tid; u < 64 * NBLK * 4; u += WAVES * 64) {
+            const int token = u / (NBLK * 4), bl = (u >> 2) % NBLK, w = u & 3, n = tok0 + token;
+            if (n >= P.n_tokens || (blk0 + bl) * 32 >= P.rows) continue;
+            int offa, offb;
+            slot_offsets(P.out_q4, w, offa, offb);
+            const float4 a = *reinterpret_cast<const float4 *>(hb + token * HS + bl * 32 + offa);
+            const float4 b = *reinterpret_cast<const float4 *>(hb + token * HS + bl * 32 + offb);
+            float v[8];
+            slots_from(P.out_q4, a, b, v);
+            store_frag(P.xf_out, P.nt16, n, blk0 + bl, w, v);
+        }
+        return;
+    }
     // D[token = (lane>>4)*4 + j][weight row = lane & 15].  The optional bias / residual operands are loaded for
     // the whole tile first (clamped addresses, no per-element branch -> one memory latency), then added.  A
     // workgroup whose 64 tokens all exist (every one but the last of a prompt) stores without per-element tests.
@@ -325,7 +397,7 @@ __global__ void __launch_bounds__(QG_WAVES * 64, NL_QG_OCC) qgemm_kernel(QGemmPa
     float *const dst = split ? partp + (long long)blockIdx.z * P.n_tokens * P.ldo : outp;
     const float *const resid = split ? nullptr : P.resid, *const bias = split ? nullptr : P.bias;
 #pragma unroll
-    for (int rt = 0; rt < QG_RT; rt++) {
+    for (int rt = 0; rt < RT; rt++) {
         const int row = (tile0 + rt) * TR + li;
         if (tile0 + rt >= P.ntiles || row >= P.rows) continue;
         const float bv = bias ? bias[row] : 0.f;

@@ -431,6 +431,39 @@ def test_prefill_matches_token_at_a_time(hip, orc):
     a.close(); b.close(); c.close()
 
 
+_FUSED_SNIPPET = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from nanollama_amd import gguf, model as hip
+G = sys.argv[2]
+for tag in ("tiny_q8_0", "tiny_q4_0", "tiny_tied_q8_0", "tiny_mha_q4_0"):
+    g = gguf.load_gguf(os.path.join(G, tag + ".gguf"))
+    v = np.load(os.path.join(G, tag + ".npz"))
+    toks = [int(t) for t in v["prompt"]]
+    dev = hip.load_llama_model(g)
+    dev.prefill(toks)
+    scale = max(1.0, float(v["logits_full"].std()))
+    err = float(np.abs(dev.state.logits - v["logits_full"][len(toks) - 1]).max())
+    assert err <= 1e-4 * scale, (tag, err)
+    nxt = int(np.argmax(dev.state.logits))
+    assert [nxt] + dev.decode_greedy(nxt, len(toks), 6) == [int(t) for t in v["greedy_ids"][:7]], tag
+    dev.close()
+print("fused ok")
+"""
+
+
+def test_fused_gate_up_swiglu_gemm_on_golden_models(hip):
+    # the gate || up GEMM with the SwiGLU epilogue normally needs >= 128 workgroups (1000+ token prompts, covered
+    # by the mini 1920-token test); NL_FUSED_SWIGLU_MIN_WG=1 forces it onto the tiny golden models.  The knob is
+    # read once per process, hence the child interpreter.
+    import subprocess, sys
+    env = dict(os.environ, NL_FUSED_SWIGLU_MIN_WG="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FUSED_SNIPPET, root, GOLDEN], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fused ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("tag", ["tiny_q8_0", "tiny_qknorm_q8_0", "tiny_conj_q4_0", "tiny_tied_q8_0", "tiny_mha_q4_0"])
 def test_prefill_variants_match_golden(hip, tag):
     g = gguf.load_gguf(os.path.join(GOLDEN, tag + ".gguf"))

@@ -55,7 +55,7 @@ int main(int argc, char **argv) {
             CK(hipEventRecord(a, st));
             for (int i = 0; i < iters; i++) {
                 P.q = q + (size_t)(i % copies) * qbytes; P.s = s + (size_t)(i % copies) * swords;
-                hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0>), dim3(row_groups, tok_tiles, ks), dim3(QG_WAVES * 64), 0, st, P);
+                hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0, QG_WAVES, QG_RT, QG_EPI_PLAIN>), dim3(row_groups, tok_tiles, ks), dim3(QG_WAVES * 64), 0, st, P);
                 if (ks > 1) {
                     const long long count = (long long)N * sh.rows;
                     hipLaunchKernelGGL(qgemm_sum_kernel, dim3((unsigned)std::min<long long>((count + 255) / 256, 2048)), dim3(256), 0, st,
