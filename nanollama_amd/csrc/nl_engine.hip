@@ -620,7 +620,7 @@ hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_bu
     P.row_groups = row_groups;
     int ks = 1;
     if (part_buf && P.ldo == P.rows) {
-        static const int ks_cap = getenv("NL_KS_CAP") ? atoi(getenv("NL_KS_CAP")) : 8;   // developer knob (tools/)
+        static const int ks_cap = getenv("NL_KS_CAP") ? atoi(getenv("NL_KS_CAP")) : 16;   // developer knob (tools/)
         while (row_groups * mats * tok_tiles * ks < 128 && ks * 2 <= nchunks && ks < ks_cap) ks *= 2;
         while (ks > 1 && (size_t)ks * P.n_tokens * P.ldo > part_cap) ks /= 2;
     }
