@@ -33,6 +33,24 @@ __device__ __forceinline__ float gemm_out_at(const GemmOut &g, long long idx, in
     return v;
 }
 
+// two elements at once (RoPE: a value and its rotation partner), slabs fetched EIGHT at a time for both, so a
+// 16-way split costs two memory round trips instead of eight; per element the same additions in the same order
+__device__ __forceinline__ void gemm_out_at2(const GemmOut &g, long long ia, int ca, long long ib, int cb, float &a, float &b) {
+    if (g.ks <= 1) { a = g.val[ia]; b = g.val[ib]; return; }
+    a = 0.f; b = 0.f;
+    for (int z0 = 0; z0 < g.ks; z0 += 8) {
+        float pa[8], pb[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const long long zo = (long long)min(z0 + k, g.ks - 1) * g.zstride;
+            pa[k] = g.part[zo + ia]; pb[k] = g.part[zo + ib];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { a += z0 + k < g.ks ? pa[k] : 0.f; b += z0 + k < g.ks ? pb[k] : 0.f; }
+    }
+    if (g.bias) { a += g.bias[ca]; b += g.bias[cb]; }
+}
+
 // four consecutive columns (idx, col multiples of 4): same arithmetic per element as gemm_out_at
 __device__ __forceinline__ float4 gemm_out_at4(const GemmOut &g, long long idx, int col) {
     if (g.ks <= 1) return *reinterpret_cast<const float4 *>(g.val + idx);
@@ -210,8 +228,9 @@ __global__ void brope_kv_kernel(BRopeParams P) {
         const int tile = rho / TR, r = rho % TR;
         const int head = tile / tph, j = tile % tph;
         const int i = j * 8 + (r & 7), e = i + (r >> 3) * half;
-        float v = gemm_out_at(P.qkv, src0 + rho, rho), outv = v;
-        float partner = gemm_out_at(P.qkv, src0 + (rho ^ 8), rho ^ 8);
+        float v, partner;
+        gemm_out_at2(P.qkv, src0 + rho, rho, src0 + (rho ^ 8), rho ^ 8, v, partner);
+        float outv = v;
         if (P.bias_q) {
             const int ep = i + ((r ^ 8) >> 3) * half;   // the partner's element index
             if (head < P.n_q_heads) { v += P.bias_q[head * hd + e]; partner += P.bias_q[head * hd + ep]; }
