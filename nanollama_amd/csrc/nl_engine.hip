@@ -741,6 +741,11 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
         LCK(hipGetLastError());
     }
     const int nt16 = ((n + 63) / 64) * 4;
+    // position splits any token of this step can see: the attention grids skip the rest (a decode batch at short
+    // contexts would otherwise dispatch 15 empty workgroups for every live one)
+    int nsplit = 1;
+    for (int i = 0; i < n; i++) nsplit = std::max(nsplit, b.h_meta[b.cap + i] / ATT_CH + 1);
+    nsplit = std::min(nsplit, e->nsplit_max);
     GemmOut pend{nullptr, nullptr, 1, 0, nullptr};   // GEMM output not yet folded into the residual stream
     auto norm = [&](const float *w, const PackedMat &next, int item0, int cnt) {
         BNormParams P{b.x, pend, w, c.rms_eps, D, item0, b.xfrag, ((cnt + 63) / 64) * 4, next.wtype == WT_Q4_0 ? 1 : 0};
@@ -774,10 +779,10 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
                          (long long)e->Hs * e->nsplit_max};
             if (one_stream && n >= 8 && attn_tile_supported(e->gqa) && !getenv("NL_NO_ATTN_TILE")) {
                 // prefill: the step's tokens share a stream -> K/V split staged once per tile of tokens, MFMA fp32
-                LCK(hd == 64 ? launch_attn_tile_hd<64>(e->gqa, P, n, e->KVs, e->nsplit_max, st)
-                             : launch_attn_tile_hd<32>(e->gqa, P, n, e->KVs, e->nsplit_max, st));
+                LCK(hd == 64 ? launch_attn_tile_hd<64>(e->gqa, P, n, e->KVs, nsplit, st)
+                             : launch_attn_tile_hd<32>(e->gqa, P, n, e->KVs, nsplit, st));
             } else {
-                LCK(launch_attn(hd, e->gqa, P, dim3(e->KVs, e->nsplit_max, n), st));
+                LCK(launch_attn(hd, e->gqa, P, dim3(e->KVs, nsplit, n), st));
             }
             BMergeParams M{b.part_o, b.part_ml, b.pos, e->Hs, e->nsplit_max, hd, b.xfrag, nt16, L.wo.wtype == WT_Q4_0 ? 1 : 0};
             {
