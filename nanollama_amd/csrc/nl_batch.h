@@ -51,6 +51,32 @@ __device__ __forceinline__ void gemm_out_at2(const GemmOut &g, long long ia, int
     if (g.bias) { a += g.bias[ca]; b += g.bias[cb]; }
 }
 
+// two float4 groups at once (the a / b halves of an 8-slot unit), slabs fetched eight at a time for both
+__device__ __forceinline__ void gemm_out_at4x2(const GemmOut &g, long long ia, int ca, long long ib, int cb, float4 &a, float4 &b) {
+    if (g.ks <= 1) { a = *reinterpret_cast<const float4 *>(g.val + ia); b = *reinterpret_cast<const float4 *>(g.val + ib); return; }
+    a = make_float4(0.f, 0.f, 0.f, 0.f); b = a;
+    for (int z0 = 0; z0 < g.ks; z0 += 8) {
+        float4 pa[8], pb[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const long long zo = (long long)min(z0 + k, g.ks - 1) * g.zstride;
+            pa[k] = *reinterpret_cast<const float4 *>(g.part + zo + ia);
+            pb[k] = *reinterpret_cast<const float4 *>(g.part + zo + ib);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool on = z0 + k < g.ks;
+            a.x += on ? pa[k].x : 0.f; a.y += on ? pa[k].y : 0.f; a.z += on ? pa[k].z : 0.f; a.w += on ? pa[k].w : 0.f;
+            b.x += on ? pb[k].x : 0.f; b.y += on ? pb[k].y : 0.f; b.z += on ? pb[k].z : 0.f; b.w += on ? pb[k].w : 0.f;
+        }
+    }
+    if (g.bias) {
+        const float4 ba = *reinterpret_cast<const float4 *>(g.bias + ca), bb = *reinterpret_cast<const float4 *>(g.bias + cb);
+        a.x += ba.x; a.y += ba.y; a.z += ba.z; a.w += ba.w;
+        b.x += bb.x; b.y += bb.y; b.z += bb.z; b.w += bb.w;
+    }
+}
+
 // four consecutive columns (idx, col multiples of 4): same arithmetic per element as gemm_out_at
 __device__ __forceinline__ float4 gemm_out_at4(const GemmOut &g, long long idx, int col) {
     if (g.ks <= 1) return *reinterpret_cast<const float4 *>(g.val + idx);
@@ -128,8 +154,8 @@ __global__ void __launch_bounds__(256) bnorm_kernel(BNormParams P) {
     if (fold) {
 #pragma unroll
         for (int k = 0; k < UPT; k++) {
-            const float4 pa = gemm_out_at4(P.pend, (long long)item * n + ca[k], ca[k]);
-            const float4 pb = gemm_out_at4(P.pend, (long long)item * n + cb[k], cb[k]);
+            float4 pa, pb;
+            gemm_out_at4x2(P.pend, (long long)item * n + ca[k], ca[k], (long long)item * n + cb[k], cb[k], pa, pb);
             xa[k] = make_float4(pa.x + xa[k].x, pa.y + xa[k].y, pa.z + xa[k].z, pa.w + xa[k].w);
             xb[k] = make_float4(pb.x + xb[k].x, pb.y + xb[k].y, pb.z + xb[k].z, pb.w + xb[k].w);
             if ((int)threadIdx.x + k * (int)blockDim.x < nu) {
@@ -366,8 +392,8 @@ __global__ void bswiglu_kernel(BSwigluParams P) {
             ga = *reinterpret_cast<const float4 *>(P.g.val + row + ca); gb = *reinterpret_cast<const float4 *>(P.g.val + row + cb);
             ua = *reinterpret_cast<const float4 *>(P.u.val + row + ca); ub = *reinterpret_cast<const float4 *>(P.u.val + row + cb);
         } else {
-            ga = gemm_out_at4(P.g, row + ca, ca); gb = gemm_out_at4(P.g, row + cb, cb);
-            ua = gemm_out_at4(P.u, row + ca, ca); ub = gemm_out_at4(P.u, row + cb, cb);
+            gemm_out_at4x2(P.g, row + ca, ca, row + cb, cb, ga, gb);
+            gemm_out_at4x2(P.u, row + ca, ca, row + cb, cb, ua, ub);
         }
         float gv[8], uv[8], v[8];
         slots_from(P.q4, ga, gb, gv);
