@@ -612,11 +612,17 @@ hipError_t launch_qgemm_swiglu(int wtype, QGemmParams P, hipStream_t st) {
 hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_buf = nullptr, size_t part_cap = 0,
                         int *ks_out = nullptr) {
     P.nt16 = ((P.n_tokens + 63) / 64) * 4;
-    const int row_groups = (P.ntiles + QG_WAVES * QG_RT - 1) / (QG_WAVES * QG_RT);
     const int tok_tiles = (P.n_tokens + QG_TOK - 1) / QG_TOK;
     const int nchunks = (P.cols / 32 + QG_KC - 1) / QG_KC;
-    // split K until ~128 workgroups exist (small-N decode batches would otherwise leave most CUs idle)
     const int mats = P.q1 ? 2 : 1;
+    // Workgroup height: 128 rows (8 wavefronts) when that alone fills the chip, else 64 rows (4 wavefronts) --
+    // twice the workgroups and half the split-K for the small-N decode batches (goldie shapes at 16-128 tokens:
+    // -4...-18 % per launch, tools/qgemm_variants.sh); then split K until ~128 workgroups exist.
+    static const int force_waves = getenv("NL_QG_FORCE_WAVES") ? atoi(getenv("NL_QG_FORCE_WAVES")) : 0;   // developer knob
+    int waves = QG_WAVES;
+    if (((P.ntiles + QG_WAVES - 1) / QG_WAVES) * mats * tok_tiles < 128) waves = 4;
+    if (force_waves == 4 || force_waves == 8) waves = force_waves;
+    const int row_groups = (P.ntiles + waves * QG_RT - 1) / (waves * QG_RT);
     P.row_groups = row_groups;
     int ks = 1;
     if (part_buf && P.ldo == P.rows) {
@@ -627,10 +633,18 @@ hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_bu
     P.ksplit = ks;
     P.part = part_buf;
     dim3 grid(row_groups * mats, tok_tiles, ks);
-    switch (wtype) {
-    case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0, QG_WAVES, QG_RT, QG_EPI_PLAIN>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
-    case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0, QG_WAVES, QG_RT, QG_EPI_PLAIN>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
-    default: return hipErrorInvalidValue;
+    if (waves == 4) {
+        switch (wtype) {
+        case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0, 4, QG_RT, QG_EPI_PLAIN>), grid, dim3(256), 0, st, P); break;
+        case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0, 4, QG_RT, QG_EPI_PLAIN>), grid, dim3(256), 0, st, P); break;
+        default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (wtype) {
+        case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0, QG_WAVES, QG_RT, QG_EPI_PLAIN>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
+        case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0, QG_WAVES, QG_RT, QG_EPI_PLAIN>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
+        default: return hipErrorInvalidValue;
+        }
     }
     hipError_t s = hipGetLastError();
     if (ks_out) { *ks_out = ks; return s; }     // the consumer kernel adds the slabs (GemmOut, nl_batch.h)
