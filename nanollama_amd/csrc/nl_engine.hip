@@ -792,7 +792,7 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
                          (float)(1.0 / std::sqrt((double)hd)), 0, b.pos, b.stream, (long long)HQ,
                          (long long)e->Hs * e->nsplit_max};
             if (one_stream && n >= 8 && attn_tile_supported(e->gqa) && !getenv("NL_NO_ATTN_TILE")) {
-                // prefill: the step's tokens share a stream -> K/V split staged once per tile of tokens, MFMA fp32
+                // prefill: the step's tokens share a stream -> K/V split staged once per tile of tokens, fp16 MFMA with hi/lo-split operands (attn_tile16_kernel)
                 LCK(hd == 64 ? launch_attn_tile_hd<64>(e->gqa, P, n, e->KVs, nsplit, st)
                              : launch_attn_tile_hd<32>(e->gqa, P, n, e->KVs, nsplit, st));
             } else {
