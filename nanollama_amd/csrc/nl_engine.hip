@@ -609,6 +609,15 @@ hipError_t launch_qgemm_swiglu(int wtype, QGemmParams P, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int WT, int WAVES>
+void launch_qgemm_nt(int nt, dim3 grid, hipStream_t st, const QGemmParams &P) {
+    switch (nt) {
+    case 1: hipLaunchKernelGGL((qgemm_kernel<WT, WAVES, QG_RT, QG_EPI_PLAIN, 1>), grid, dim3(WAVES * 64), 0, st, P); break;
+    case 2: hipLaunchKernelGGL((qgemm_kernel<WT, WAVES, QG_RT, QG_EPI_PLAIN, 2>), grid, dim3(WAVES * 64), 0, st, P); break;
+    default: hipLaunchKernelGGL((qgemm_kernel<WT, WAVES, QG_RT, QG_EPI_PLAIN, 4>), grid, dim3(WAVES * 64), 0, st, P); break;
+    }
+}
+
 hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_buf = nullptr, size_t part_cap = 0,
                         int *ks_out = nullptr) {
     P.nt16 = ((P.n_tokens + 63) / 64) * 4;
@@ -633,18 +642,15 @@ hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_bu
     P.ksplit = ks;
     P.part = part_buf;
     dim3 grid(row_groups * mats, tok_tiles, ks);
+    // a step of <= 16 / 32 tokens fetches and multiplies only the first one / two 16-token tiles of its group
+    const int nt = tok_tiles > 1 || P.n_tokens > 32 ? 4 : P.n_tokens > 16 ? 2 : 1;
+    if (wtype != WT_Q4_0 && wtype != WT_Q8_0) return hipErrorInvalidValue;
     if (waves == 4) {
-        switch (wtype) {
-        case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0, 4, QG_RT, QG_EPI_PLAIN>), grid, dim3(256), 0, st, P); break;
-        case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0, 4, QG_RT, QG_EPI_PLAIN>), grid, dim3(256), 0, st, P); break;
-        default: return hipErrorInvalidValue;
-        }
+        if (wtype == WT_Q4_0) launch_qgemm_nt<WT_Q4_0, 4>(nt, grid, st, P);
+        else launch_qgemm_nt<WT_Q8_0, 4>(nt, grid, st, P);
     } else {
-        switch (wtype) {
-        case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0, QG_WAVES, QG_RT, QG_EPI_PLAIN>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
-        case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0, QG_WAVES, QG_RT, QG_EPI_PLAIN>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
-        default: return hipErrorInvalidValue;
-        }
+        if (wtype == WT_Q4_0) launch_qgemm_nt<WT_Q4_0, QG_WAVES>(nt, grid, st, P);
+        else launch_qgemm_nt<WT_Q8_0, QG_WAVES>(nt, grid, st, P);
     }
     hipError_t s = hipGetLastError();
     if (ks_out) { *ks_out = ks; return s; }     // the consumer kernel adds the slabs (GemmOut, nl_batch.h)
@@ -659,8 +665,9 @@ hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_bu
 namespace {
 
 // below this many tokens the ~10 launches per layer of the multi-token step cost more than n single-token steps
-// (measured: nano 2 streams 0.92 ms batched vs 0.60 ms as two single steps; break-even at 4)
-const int NL_BATCH_MIN = getenv("NL_BATCH_MIN") ? atoi(getenv("NL_BATCH_MIN")) : 4;   // env: developer knob (tools/)
+// (measured: 2 streams nano 0.61 ms batched vs 0.55 ms as two single steps, goldie 1.77 vs 1.47; 3 streams 0.61 vs
+// 0.82 and 1.77 vs 2.19)
+const int NL_BATCH_MIN = getenv("NL_BATCH_MIN") ? atoi(getenv("NL_BATCH_MIN")) : 3;   // env: developer knob (tools/)
 
 bool batch_supported(const nl_engine *e) {
     if (e->G != 1 || e->force_tp_plan) return false;

@@ -220,12 +220,14 @@ __device__ __forceinline__ void store_frag(uint4 *xf, int nt16, int n, int blk, 
 // Software pipeline, one barrier per chunk: while chunk c is on the matrix cores, chunk c+1's activation
 // fragments travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: the fragment store is lane-linear, one
 // instruction per 1 KB fragment, no VGPR round trip) and its packed weights + scales travel to registers.
-template <int WT, int WAVES, int RT, int EPI>
+template <int WT, int WAVES, int RT, int EPI, int NT = 4>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_kernel(QGemmParams P) {
-    static_assert(EPI == QG_EPI_PLAIN || RT == 2, "the fused epilogue pairs a gate tile with its up tile");
+    static_assert(EPI == QG_EPI_PLAIN || (RT == 2 && NT == 4), "the fused epilogue pairs a gate tile with its up tile");
+    static_assert(NT == 1 || NT == 2 || NT == 4, "16-token tiles of the 64-token group this workgroup computes");
     typedef typename WFrag<WT>::raw_t raw_t;
-    // fragment buffers: [buffer][block in chunk][token tile][hi/lo][lane] x 16 bytes
-    __shared__ __attribute__((aligned(16))) uint4 xfrag[2][QG_KC * 8 * QG_FRAG];
+    // fragment buffers: [buffer][block in chunk][token tile < NT][hi/lo][lane] x 16 bytes.  NT < 4 (decode batches
+    // and prompts of <= 16 / 32 tokens): only the first NT tiles of the group are fetched and multiplied.
+    __shared__ __attribute__((aligned(16))) uint4 xfrag[2][QG_KC * 2 * NT * QG_FRAG];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 15, lw = lane >> 4;
     const int tok0 = blockIdx.y * QG_TOK;
@@ -241,11 +243,11 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
     const int tile0 = FUSED ? (int)blockIdx.x * WAVES + wave : (((int)blockIdx.x - (second ? P.row_groups : 0)) * WAVES + wave) * RT;
     const uint8_t *const xsrc = reinterpret_cast<const uint8_t *>(P.xf + (long long)blockIdx.y * (8 * QG_FRAG));
 
-    f32x4_t acc[RT][4];
+    f32x4_t acc[RT][NT];
 #pragma unroll
     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc[rt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; t++) acc[rt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // Both prefetch lambdas are BRANCH-FREE: out-of-range blocks / tiles are clamped to a valid address and
     // neutralised afterwards (scale 0, or simply never consumed).  A per-element "load or zero" branch makes
@@ -259,11 +261,11 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
     const unsigned xblock = (unsigned)P.nt16 * (2 * QG_FRAG * 16);   // bytes of one block's fragments
     auto stage = [&](int chunk, int buf) {
         const int b0 = chunk * QG_KC;
-        static_assert((8 * QG_KC) % WAVES == 0, "fragments of a chunk divide evenly over the wavefronts");
+        static_assert((2 * NT * QG_KC) % WAVES == 0, "fragments of a chunk divide evenly over the wavefronts");
 #pragma unroll
-        for (int i = 0; i < 8 * QG_KC / WAVES; i++) {
-            const int f = wave + WAVES * i;        // fragment of the chunk: block f/8, (tile, part) f%8
-            const unsigned uo = (unsigned)min(b0 + (f >> 3), nblocks - 1) * xblock + (unsigned)(f & 7) * (QG_FRAG * 16);
+        for (int i = 0; i < 2 * NT * QG_KC / WAVES; i++) {
+            const int f = wave + WAVES * i;        // fragment of the chunk: block f / 2NT, (tile, part) f % 2NT
+            const unsigned uo = (unsigned)min(b0 + f / (2 * NT), nblocks - 1) * xblock + (unsigned)(f % (2 * NT)) * (QG_FRAG * 16);
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(xsrc + (uo + xlane)),
                 (__attribute__((address_space(3))) void *)&xfrag[buf][f * QG_FRAG], 16, 0, 0);
@@ -307,12 +309,12 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
         wload(nxt, wqn, wdn);
 #pragma unroll
         for (int b = 0; b < QG_KC; b++) {
-            half8_t wf[RT], xh[4], xl[4];
+            half8_t wf[RT], xh[NT], xl[NT];
             float dsc[RT];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                xh[t] = __builtin_bit_cast(half8_t, xfrag[buf][((b * 4 + t) * 2 + 0) * QG_FRAG + lane]);
-                xl[t] = __builtin_bit_cast(half8_t, xfrag[buf][((b * 4 + t) * 2 + 1) * QG_FRAG + lane]);
+            for (int t = 0; t < NT; t++) {
+                xh[t] = __builtin_bit_cast(half8_t, xfrag[buf][((b * NT + t) * 2 + 0) * QG_FRAG + lane]);
+                xl[t] = __builtin_bit_cast(half8_t, xfrag[buf][((b * NT + t) * 2 + 1) * QG_FRAG + lane]);
             }
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
@@ -320,19 +322,19 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
                 const float d = scale_of(wd[rt][b >> 1], b);
                 dsc[rt] = b < nb ? d : 0.f;
             }
-            f32x4_t z[RT][4];
+            f32x4_t z[RT][NT];
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < NT; t++)
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
                     z[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[t], wf[rt], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < NT; t++)
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
                     z[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], wf[rt], z[rt][t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < NT; t++)
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) {
                     acc[rt][t][0] = fmaf(z[rt][t][0], dsc[rt], acc[rt][t][0]);
@@ -367,7 +369,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
         static_assert(64 * HS * 4 <= (int)sizeof(xfrag), "staging tile fits the fragment buffers");
         float *const hb = reinterpret_cast<float *>(&xfrag[0][0]);
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+        for (int t = 0; t < NT; t++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float gv = acc[0][t][j], uv = acc[1][t][j];
@@ -393,7 +395,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
     // D[token = (lane>>4)*4 + j][weight row = lane & 15].  The optional bias / residual operands are loaded for
     // the whole tile first (clamped addresses, no per-element branch -> one memory latency), then added.  A
     // workgroup whose 64 tokens all exist (every one but the last of a prompt) stores without per-element tests.
-    const bool split = P.ksplit > 1, whole = tok0 + QG_TOK <= P.n_tokens;
+    const bool split = P.ksplit > 1, whole = tok0 + NT * 16 <= P.n_tokens;
     float *const dst = split ? partp + (long long)blockIdx.z * P.n_tokens * P.ldo : outp;
     const float *const resid = split ? nullptr : P.resid, *const bias = split ? nullptr : P.bias;
 #pragma unroll
@@ -401,21 +403,21 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
         const int row = (tile0 + rt) * TR + li;
         if (tile0 + rt >= P.ntiles || row >= P.rows) continue;
         const float bv = bias ? bias[row] : 0.f;
-        unsigned off[4][4];
+        unsigned off[NT][4];
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+        for (int t = 0; t < NT; t++)
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 off[t][j] = (unsigned)min(tok0 + t * 16 + lw * 4 + j, P.n_tokens - 1) * (unsigned)P.ldo + (unsigned)row;
-        float rv[4][4];
+        float rv[NT][4];
         if (resid) {
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < NT; t++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) rv[t][j] = resid[off[t][j]];
         }
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+        for (int t = 0; t < NT; t++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float v = acc[rt][t][j];
@@ -425,12 +427,12 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
             }
         if (whole) {
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < NT; t++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) dst[off[t][j]] = acc[rt][t][j];
         } else {
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < NT; t++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     if (tok0 + t * 16 + lw * 4 + j < P.n_tokens) dst[off[t][j]] = acc[rt][t][j];
