@@ -595,7 +595,8 @@ hipError_t launch_xsplit(int wtype, const float *x, int ldx, int cols, int n_tok
 constexpr int QG_FUSED_WAVES = 4;
 bool qgemm_swiglu_fits(int ntiles, int n_tokens) {
     static const int min_wg = getenv("NL_FUSED_SWIGLU_MIN_WG") ? atoi(getenv("NL_FUSED_SWIGLU_MIN_WG")) : 128;   // knob: tests force 1, tools disable with a huge value
-    return ((ntiles + QG_FUSED_WAVES - 1) / QG_FUSED_WAVES) * ((n_tokens + QG_TOK - 1) / QG_TOK) >= min_wg;
+    // (a step of <= 32 tokens runs the plain kernel on one / two 16-token tiles instead: big x 8 streams 7.76 -> 7.55 ms)
+    return (n_tokens > 32 || min_wg <= 1) && ((ntiles + QG_FUSED_WAVES - 1) / QG_FUSED_WAVES) * ((n_tokens + QG_TOK - 1) / QG_TOK) >= min_wg;
 }
 hipError_t launch_qgemm_swiglu(int wtype, QGemmParams P, hipStream_t st) {
     P.nt16 = ((P.n_tokens + 63) / 64) * 4;
