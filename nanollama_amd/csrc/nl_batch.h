@@ -302,6 +302,27 @@ __global__ void brope_kv_kernel(BRopeParams P) {
     }
 }
 
+// FIN epilogue of attn_kernel (nl_kernels.h): the only split of every row is complete, so x = o / l -- the ns == 1
+// arithmetic of battn_merge_kernel -- goes straight into the WO GEMM's fragments.  One thread per 8 k-slots.
+template <int HD, int G>
+__device__ void attn_finalize(const AttnParams &P, const float *ored, const float *ml, int kvh, int item) {
+    constexpr int NG = ATT_THREADS / (HD / 4);
+    const int tid = threadIdx.x;
+    if (tid >= G * HD / 8) return;
+    const int g = tid / (HD / 8), u = tid % (HD / 8), bl = u >> 2, w = u & 3;
+    const float scale = 1.0f / ml[2 * g + 1];
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int d = bl * 32 + slot_elem(P.fin_q4, w, j);
+        float s = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < NG; k++) s += ored[(k * G + g) * HD + d];
+        v[j] = s * scale;
+    }
+    store_frag(P.fin_xf, P.fin_nt16, item, ((kvh * G + g) * HD) / 32 + bl, w, v);
+}
+
 struct BMergeParams {
     const float *part_o, *part_ml;  // [N][heads][nsplit_max][hd] / [..][2]
     const int *pos;

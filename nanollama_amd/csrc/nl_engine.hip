@@ -347,6 +347,19 @@ hipError_t launch_attn_hd(int gqa, AttnParams P, dim3 grid, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int HD>
+hipError_t launch_attn_fin_hd(int gqa, AttnParams P, dim3 grid, hipStream_t st) {
+    switch (gqa) {
+    case 1: hipLaunchKernelGGL((attn_kernel<HD, 1, true>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    case 2: hipLaunchKernelGGL((attn_kernel<HD, 2, true>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    case 3: hipLaunchKernelGGL((attn_kernel<HD, 3, true>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    case 4: hipLaunchKernelGGL((attn_kernel<HD, 4, true>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    case 8: hipLaunchKernelGGL((attn_kernel<HD, 8, true>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_attn(int hd, int gqa, AttnParams P, dim3 grid, hipStream_t st) {
     if (hd == 64) return launch_attn_hd<64>(gqa, P, grid, st);
     if (hd == 32) return launch_attn_hd<32>(gqa, P, grid, st);
@@ -799,17 +812,26 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
             AttnParams P{b.q, kc, vc, e->kv_stream_stride, b.part_o, b.part_ml, e->ctl, e->KVs, c.seq_len, e->nsplit_max,
                          (float)(1.0 / std::sqrt((double)hd)), 0, b.pos, b.stream, (long long)HQ,
                          (long long)e->Hs * e->nsplit_max};
+            bool merged = false;
             if (one_stream && n >= 8 && attn_tile_supported(e->gqa) && !getenv("NL_NO_ATTN_TILE")) {
                 // prefill: the step's tokens share a stream -> K/V split staged once per tile of tokens, fp16 MFMA with hi/lo-split operands (attn_tile16_kernel)
                 LCK(hd == 64 ? launch_attn_tile_hd<64>(e->gqa, P, n, e->KVs, nsplit, st)
                              : launch_attn_tile_hd<32>(e->gqa, P, n, e->KVs, nsplit, st));
+            } else if (nsplit == 1 && !getenv("NL_NO_ATTN_FIN")) {
+                // every position < 128: one split per row, the attention kernel normalises and writes the fragments
+                P.fin_xf = b.xfrag; P.fin_nt16 = nt16; P.fin_q4 = L.wo.wtype == WT_Q4_0 ? 1 : 0;
+                LCK(hd == 64 ? launch_attn_fin_hd<64>(e->gqa, P, dim3(e->KVs, 1, n), st)
+                             : launch_attn_fin_hd<32>(e->gqa, P, dim3(e->KVs, 1, n), st));
+                merged = true;
             } else {
                 LCK(launch_attn(hd, e->gqa, P, dim3(e->KVs, nsplit, n), st));
             }
+            if (!merged) {
             BMergeParams M{b.part_o, b.part_ml, b.pos, e->Hs, e->nsplit_max, hd, b.xfrag, nt16, L.wo.wtype == WT_Q4_0 ? 1 : 0};
             {
                 const long long units = (long long)n * e->Hs * hd / 8;
                 hipLaunchKernelGGL(battn_merge_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, M, n);
+            }
             }
             LCK(hipGetLastError());
         }

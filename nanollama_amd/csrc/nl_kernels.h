@@ -836,7 +836,14 @@ struct AttnParams {
     // multi-token step: blockIdx.z = item, per-item position / stream arrays and buffer strides (floats)
     const int *bpos, *bstream;
     long long q_item_stride, part_item_stride;
+    // FIN variant (multi-token step whose positions are all < 128, i.e. one split): the normalised output leaves
+    // as the WO GEMM's fp16 hi/lo fragments and battn_merge_kernel is not launched
+    uint4 *fin_xf;
+    int fin_nt16, fin_q4;
 };
+
+template <int HD, int G>
+__device__ void attn_finalize(const AttnParams &P, const float *ored, const float *ml, int kvh, int item);   // nl_batch.h
 
 // GQA decode attention for one token (go/model.go:557-587): one workgroup per
 // (kv head, 128-position split); the G query heads of the group share every K
@@ -864,7 +871,7 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return v;
 }
 
-template <int HD, int G>
+template <int HD, int G, bool FIN = false>
 __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
     const int split = blockIdx.y, t0 = split * ATT_CH;
     const int kvh = blockIdx.x, tid = threadIdx.x;
@@ -988,6 +995,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
 #pragma unroll
     for (int g = 0; g < G; g++) *reinterpret_cast<float4 *>(ored + (tg * G + g) * HD + c4 * 4) = o[g];
     __syncthreads();
+    if constexpr (FIN) {
+        attn_finalize<HD, G>(P, ored, ml, kvh, item);
+        return;
+    }
     for (int i = tid; i < G * HD; i += ATT_THREADS) {
         int g = i / HD, dd = i % HD;
         float s = 0.f;
