@@ -612,6 +612,30 @@ def test_forward_batch_matches_individual_forwards(hip):
     dev.close(); solo.close()
 
 
+def test_batched_decode_across_the_128_position_split(hip, orc, tmp_path):
+    # three streams stepped together from position 0 to 135: below 128 every row has one attention split and the
+    # attention kernel writes the WO fragments itself; from 128 on the split partials go through battn_merge.
+    # Stream 1 is checked against the oracle on both sides of the boundary.
+    shape = synth.ModelShape("split_probe", 2, 256, 4, 2, 1024, seq_len=192, interm=768)
+    p = tmp_path / "s.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 37)
+    g = gguf.load_gguf(str(p))
+    dev = hip.load_llama_model(g, max_streams=3)
+    ref = orc.OracleModel(g)
+    rng = np.random.Generator(np.random.PCG64(12))
+    seqs = rng.integers(3, shape.vocab, size=(3, 136))
+    worst = 0.0
+    for step in range(136):
+        ids, lg = dev.forward_batch([0, 1, 2], [int(seqs[s, step]) for s in range(3)], [step] * 3, want_logits=True)
+        want = ref.forward(int(seqs[1, step]), step)
+        if step >= 120:
+            worst = max(worst, float(np.abs(lg[1] - want).max()))
+            assert ids[1] == int(np.argmax(want)), step
+    print(f"\n3 streams across pos 128: max|gpu-oracle|={worst:.2e}")
+    assert worst <= LOGIT_TOL
+    dev.close()
+
+
 def test_64_concurrent_streams_match_oracle(hip, orc, tmp_path):
     # BASELINE config 4 in miniature: 64 decode streams stepped together (GQA model, Q4_0), every stream's
     # logits checked against its own oracle run
