@@ -623,6 +623,25 @@ hipError_t launch_qgemm_swiglu(int wtype, QGemmParams P, hipStream_t st) {
     return hipGetLastError();
 }
 
+// Q|K|V GEMM with the RoPE + KV-store epilogue (nl_qgemm.h): 128-row workgroups, no split-K -- for steps whose
+// unsplit grid fills the chip (prompts); decode batches keep the split-K GEMM + brope_kv.
+bool qgemm_rope_fits(int ntiles, int n_tokens) {
+    static const int min_wg = getenv("NL_FUSED_ROPE_MIN_WG") ? atoi(getenv("NL_FUSED_ROPE_MIN_WG")) : 128;   // knob: tests force 1
+    return ((ntiles + QG_WAVES - 1) / QG_WAVES) * ((n_tokens + QG_TOK - 1) / QG_TOK) >= min_wg;
+}
+hipError_t launch_qgemm_rope(int wtype, QGemmParams P, hipStream_t st) {
+    P.nt16 = ((P.n_tokens + 63) / 64) * 4;
+    P.ksplit = 1;
+    P.row_groups = (P.ntiles + QG_WAVES - 1) / QG_WAVES;
+    const dim3 grid(P.row_groups, (P.n_tokens + QG_TOK - 1) / QG_TOK, 1);
+    switch (wtype) {
+    case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0, QG_WAVES, 1, QG_EPI_ROPE>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
+    case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0, QG_WAVES, 1, QG_EPI_ROPE>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 template <int WT, int WAVES>
 void launch_qgemm_nt(int nt, dim3 grid, hipStream_t st, const QGemmParams &P) {
     switch (nt) {
@@ -797,16 +816,27 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
         float *kc = e->kcache + (long long)l * e->kv_layer_stride;
         float *vc = e->vcache + (long long)l * e->kv_layer_stride;
         LCK(norm(L.attn_norm, L.qkv, 0, n));
-        GemmOut qkv;
-        LCK(qg(e, L.qkv, n, b.qkv, R, nullptr, st, &qkv, b.kpart));
-        {
-            BRopeParams P{qkv, R, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate, c.qk_norm, c.rms_eps, b.pos, b.stream,
-                          e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride, L.bq, L.bk, L.bv};
-            // few tokens (decode batches): one element per thread where the row fits, so the per-element chain (slabs ->
-            // rotate -> LDS) is paid once (goldie x 64 streams: 15 -> 5.6 us); long prompts keep 256-thread workgroups
-            const int threads = n <= 256 ? std::min(1024, std::max(256, (int)((R + 63) / 64 * 64))) : 256;
-            hipLaunchKernelGGL(brope_kv_kernel, dim3(n), dim3(threads), (size_t)R * 4, st, P);
-            LCK(hipGetLastError());
+        if (!c.qk_norm && qgemm_rope_fits(L.qkv.ntiles, n)) {
+            // Q|K|V, RoPE, biases and the KV store in ONE launch (QK-norm needs whole heads: unfused path)
+            QGemmParams P{};
+            const PackedMat &m = L.qkv;
+            P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
+            P.xf = b.xfrag; P.n_tokens = n; P.ldo = (int)R;
+            P.rope = QGemmParams::Rope{b.pos, b.stream, e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride,
+                                       L.bq, L.bk, L.bv, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate};
+            LCK(launch_qgemm_rope(m.wtype, P, st));
+        } else {
+            GemmOut qkv;
+            LCK(qg(e, L.qkv, n, b.qkv, R, nullptr, st, &qkv, b.kpart));
+            {
+                BRopeParams P{qkv, R, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate, c.qk_norm, c.rms_eps, b.pos, b.stream,
+                              e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride, L.bq, L.bk, L.bv};
+                // few tokens (decode batches): one element per thread where the row fits, so the per-element chain (slabs ->
+                // rotate -> LDS) is paid once (goldie x 64 streams: 15 -> 5.6 us); long prompts keep 256-thread workgroups
+                const int threads = n <= 256 ? std::min(1024, std::max(256, (int)((R + 63) / 64 * 64))) : 256;
+                hipLaunchKernelGGL(brope_kv_kernel, dim3(n), dim3(threads), (size_t)R * 4, st, P);
+                LCK(hipGetLastError());
+            }
         }
         {
             AttnParams P{b.q, kc, vc, e->kv_stream_stride, b.part_o, b.part_ml, e->ctl, e->KVs, c.seq_len, e->nsplit_max,

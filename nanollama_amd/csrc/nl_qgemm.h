@@ -32,7 +32,7 @@ constexpr int QG_KC = NL_QG_KC;  // 32-element blocks per K chunk (128 columns)
 #endif
 constexpr int QG_WAVES = NL_QG_WAVES;
 constexpr int QG_RT = NL_QG_RT;  // 16-row weight tiles per wavefront
-constexpr int QG_EPI_PLAIN = 0, QG_EPI_SWIGLU = 1;
+constexpr int QG_EPI_PLAIN = 0, QG_EPI_SWIGLU = 1, QG_EPI_ROPE = 2;
 constexpr int QG_FRAG = 64;     // uint4 per activation fragment: 64 lanes x 16 bytes, lane-linear (= one LDS-DMA)
 
 // Activation fragments live in global memory in MFMA operand order, produced ONCE per activation matrix
@@ -62,6 +62,16 @@ struct QGemmParams {
     // fused SwiGLU epilogue (QG_EPI_SWIGLU): q = gate, q1 = up; the result leaves as fragments for the next GEMM
     uint4 *xf_out;
     int out_q4;          // k-slot order of the consumer's weight type
+    // fused RoPE + KV-store epilogue (QG_EPI_ROPE): the matrix is a layer's packed Q|K|V (ROWMAP_HEADPERM tiles)
+    struct Rope {
+        const int *pos, *stream;             // per token
+        const float *cos, *sin;              // [seq][hd/2]
+        float *q;                            // [N][n_q_heads*hd], natural order
+        float *kcache, *vcache;              // this layer, stream 0: [kv][seq][hd]
+        long long kv_stream_stride;
+        const float *bias_q, *bias_k, *bias_v;
+        int head_dim, n_q_heads, n_kv_heads, seq_len, conj;
+    } rope;
 };
 
 inline size_t xfrag_uint4(int cols, int n_tokens) {   // uint4 elements of a fragment store
@@ -222,7 +232,8 @@ __device__ __forceinline__ void store_frag(uint4 *xf, int nt16, int n, int blk, 
 // instruction per 1 KB fragment, no VGPR round trip) and its packed weights + scales travel to registers.
 template <int WT, int WAVES, int RT, int EPI, int NT = 4>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_kernel(QGemmParams P) {
-    static_assert(EPI == QG_EPI_PLAIN || (RT == 2 && NT == 4), "the fused epilogue pairs a gate tile with its up tile");
+    static_assert(EPI != QG_EPI_SWIGLU || (RT == 2 && NT == 4), "the fused epilogue pairs a gate tile with its up tile");
+    static_assert(EPI != QG_EPI_ROPE || (RT == 1 && NT == 4), "one Q|K|V tile per wavefront: rotation partners are rows r and r^8 of a tile");
     static_assert(NT == 1 || NT == 2 || NT == 4, "16-token tiles of the 64-token group this workgroup computes");
     typedef typename WFrag<WT>::raw_t raw_t;
     // fragment buffers: [buffer][block in chunk][token tile < NT][hi/lo][lane] x 16 bytes.  NT < 4 (decode batches
@@ -390,6 +401,60 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
             slots_from(P.out_q4, a, b, v);
             store_frag(P.xf_out, P.nt16, n, blk0 + bl, w, v);
         }
+        return;
+    }
+    if constexpr (EPI == QG_EPI_ROPE) {
+        // RoPE (go/model.go:449-477) + attention biases (:525-527) + KV store (:552-554) on the accumulators, as the
+        // decode GEMV's QKV epilogue does it: tile rows 0-7 hold element i, rows 8-15 element i + hd/2 of one head,
+        // so a value's rotation partner is in lane ^ 8 (same token).  The f32 Q|K|V matrix never exists in memory
+        // and brope_kv_kernel is not launched.
+        const QGemmParams::Rope &R = P.rope;
+        if (tile0 >= P.ntiles) return;
+        const int hd = R.head_dim, half = hd >> 1, tph = hd / 16;
+        const int head = tile0 / tph, i = (tile0 % tph) * 8 + (li & 7), e = i + (li >> 3) * half;
+        const bool is_q = head < R.n_q_heads, is_k = !is_q && head < R.n_q_heads + R.n_kv_heads;
+        const int kvh = head - R.n_q_heads - (is_k ? 0 : R.n_kv_heads);
+        float bv = 0.f;
+        if (R.bias_q) bv = is_q ? R.bias_q[head * hd + e] : is_k ? R.bias_k[kvh * hd + e] : R.bias_v[kvh * hd + e];
+        int pos[NT][4], strm[NT][4];
+        float cs[NT][4], sn[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int n = min(tok0 + t * 16 + lw * 4 + j, P.n_tokens - 1);
+                pos[t][j] = R.pos[n];
+                strm[t][j] = R.stream[n];
+            }
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cs[t][j] = R.cos[pos[t][j] * half + i];
+                sn[t][j] = R.sin[pos[t][j] * half + i];
+            }
+        const int nq = R.n_q_heads * hd;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int n = tok0 + t * 16 + lw * 4 + j;
+                const float v = acc[0][t][j] + bv;
+                const float partner = __shfl_xor(v, 8);
+                float outv = v;
+                if (is_q || is_k) {
+                    const float c = cs[t][j], s1 = sn[t][j];
+                    const float x0 = li < 8 ? v : partner, x1 = li < 8 ? partner : v;
+                    if (!R.conj) outv = li < 8 ? (x0 * c - x1 * s1) : (x0 * s1 + x1 * c);
+                    else outv = li < 8 ? (x0 * c + x1 * s1) : (-x0 * s1 + x1 * c);
+                }
+                if (n >= P.n_tokens) continue;
+                if (is_q) R.q[(long long)n * nq + head * hd + e] = outv;
+                else {
+                    float *cache = is_k ? R.kcache : R.vcache;
+                    cache[(long long)strm[t][j] * R.kv_stream_stride + ((long long)kvh * R.seq_len + pos[t][j]) * hd + e] = outv;
+                }
+            }
         return;
     }
     // D[token = (lane>>4)*4 + j][weight row = lane & 15].  The optional bias / residual operands are loaded for

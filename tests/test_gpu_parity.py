@@ -437,7 +437,7 @@ import numpy as np
 sys.path.insert(0, sys.argv[1])
 from nanollama_amd import gguf, model as hip
 G = sys.argv[2]
-for tag in ("tiny_q8_0", "tiny_q4_0", "tiny_tied_q8_0", "tiny_mha_q4_0"):
+for tag in ("tiny_q8_0", "tiny_q4_0", "tiny_conj_q4_0", "tiny_tied_q8_0", "tiny_mha_q4_0", "tiny_qknorm_q8_0"):
     g = gguf.load_gguf(os.path.join(G, tag + ".gguf"))
     v = np.load(os.path.join(G, tag + ".npz"))
     toks = [int(t) for t in v["prompt"]]
@@ -453,12 +453,13 @@ print("fused ok")
 """
 
 
-def test_fused_gate_up_swiglu_gemm_on_golden_models(hip):
-    # the gate || up GEMM with the SwiGLU epilogue normally needs >= 128 workgroups (1000+ token prompts, covered
-    # by the mini 1920-token test); NL_FUSED_SWIGLU_MIN_WG=1 forces it onto the tiny golden models.  The knob is
-    # read once per process, hence the child interpreter.
+def test_fused_gemm_epilogues_on_golden_models(hip):
+    # the gate || up GEMM with the SwiGLU epilogue and the Q|K|V GEMM with the RoPE / KV-store epilogue normally need
+    # >= 128 workgroups (1000+ token prompts, covered by the mini 1920-token test); the two knobs force them onto
+    # the tiny golden models (standard and conjugate RoPE, tied head, MHA; the QK-norm model keeps the unfused
+    # RoPE path by design).  The knobs are read once per process, hence the child interpreter.
     import subprocess, sys
-    env = dict(os.environ, NL_FUSED_SWIGLU_MIN_WG="1")
+    env = dict(os.environ, NL_FUSED_SWIGLU_MIN_WG="1", NL_FUSED_ROPE_MIN_WG="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _FUSED_SNIPPET, root, GOLDEN], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fused ok" in r.stdout, r.stdout + r.stderr
