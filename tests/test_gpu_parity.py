@@ -449,6 +449,26 @@ for tag in ("tiny_q8_0", "tiny_q4_0", "tiny_conj_q4_0", "tiny_tied_q8_0", "tiny_
     nxt = int(np.argmax(dev.state.logits))
     assert [nxt] + dev.decode_greedy(nxt, len(toks), 6) == [int(t) for t in v["greedy_ids"][:7]], tag
     dev.close()
+# Qwen-style attention biases through the fused Q|K|V epilogue, against the oracle
+import tempfile
+sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import oracle as orc
+from nanollama_amd import synth
+for wtype in ("q8_0", "q4_0"):
+    shape = synth.ModelShape("bias_probe", 2, 128, 4, 2, 512, seq_len=64, interm=512, attn_bias=True)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "b.gguf")
+        synth.generate_gguf(path, shape, wtype, 41)
+        g = gguf.load_gguf(path)
+        ref = orc.OracleModel(g)
+        toks = synth.prompt_ids(14, shape.vocab, seed=9)
+        for pos, t in enumerate(toks):
+            want = ref.forward(t, pos).copy()
+        dev = hip.load_llama_model(g)
+        dev.prefill(toks)
+        err = float(np.abs(dev.state.logits - want).max())
+        assert err <= 1e-4, ("bias", wtype, err)
+        dev.close()
 print("fused ok")
 """
 
