@@ -485,6 +485,21 @@ def test_fused_gemm_epilogues_on_golden_models(hip):
     assert r.returncode == 0 and "fused ok" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("tag", ["tiny_q8_0", "tiny_mha_q4_0", "tiny_qknorm_q8_0"])
+@pytest.mark.parametrize("n", [3, 5, 7])
+def test_short_prefill_matches_golden(hip, tag, n):
+    # 3-7 tokens: the multi-token step with the per-token attention kernel, which (all positions < 128) normalises
+    # its single split and writes the WO fragments itself -- GQA 2 and 1, with and without QK-norm
+    g = gguf.load_gguf(os.path.join(GOLDEN, tag + ".gguf"))
+    v = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    toks = [int(t) for t in v["prompt"]][:n]
+    dev = hip.load_llama_model(g)
+    dev.prefill(toks)
+    scale = max(1.0, float(v["logits_full"].std()))
+    assert np.abs(dev.state.logits - v["logits_full"][n - 1]).max() <= LOGIT_TOL * scale
+    dev.close()
+
+
 @pytest.mark.parametrize("tag", ["tiny_q8_0", "tiny_qknorm_q8_0", "tiny_conj_q4_0", "tiny_tied_q8_0", "tiny_mha_q4_0"])
 def test_prefill_variants_match_golden(hip, tag):
     g = gguf.load_gguf(os.path.join(GOLDEN, tag + ".gguf"))
@@ -683,7 +698,9 @@ def test_64_concurrent_streams_match_oracle(hip, orc, tmp_path):
 
 @pytest.mark.parametrize("wtype", ["q4_0", "q8_0"])
 @pytest.mark.parametrize("rows,cols,ntok", [(128, 256, 64), (576, 576, 5), (1536, 576, 64), (192, 768, 17),
-                                             (100, 96, 3), (4096, 4096, 64), (2304, 1536, 130)])
+                                             (100, 96, 3), (4096, 4096, 64), (2304, 1536, 130),
+                                             # the one / two / four 16-token-tile variants at their boundaries
+                                             (320, 320, 16), (320, 320, 32), (320, 320, 33), (768, 2048, 48)])
 def test_mfma_multi_token_matmul_matches_oracle(hip, orc, wtype, rows, cols, ntok):
     # the batched / prefill path: fp16-hi/lo activations x exact integer quants on the matrix cores, block
     # sums scaled by d in f32 -- must hold the same GEMV tolerance as the VALU decode kernel
