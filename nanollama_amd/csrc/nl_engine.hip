@@ -797,6 +797,7 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
     const int nt16 = ((n + 63) / 64) * 4;
     // position splits any token of this step can see: the attention grids skip the rest (a decode batch at short
     // contexts would otherwise dispatch 15 empty workgroups for every live one)
+    static const bool no_tile = getenv("NL_NO_ATTN_TILE") != nullptr, no_fin = getenv("NL_NO_ATTN_FIN") != nullptr;   // developer knobs
     int nsplit = 1;
     for (int i = 0; i < n; i++) nsplit = std::max(nsplit, b.h_meta[b.cap + i] / ATT_CH + 1);
     nsplit = std::min(nsplit, e->nsplit_max);
@@ -843,11 +844,11 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
                          (float)(1.0 / std::sqrt((double)hd)), 0, b.pos, b.stream, (long long)HQ,
                          (long long)e->Hs * e->nsplit_max};
             bool merged = false;
-            if (one_stream && n >= 8 && attn_tile_supported(e->gqa) && !getenv("NL_NO_ATTN_TILE")) {
+            if (one_stream && n >= 8 && attn_tile_supported(e->gqa) && !no_tile) {
                 // prefill: the step's tokens share a stream -> K/V split staged once per tile of tokens, fp16 MFMA with hi/lo-split operands (attn_tile16_kernel)
                 LCK(hd == 64 ? launch_attn_tile_hd<64>(e->gqa, P, n, e->KVs, nsplit, st)
                              : launch_attn_tile_hd<32>(e->gqa, P, n, e->KVs, nsplit, st));
-            } else if (nsplit == 1 && !getenv("NL_NO_ATTN_FIN")) {
+            } else if (nsplit == 1 && !no_fin) {
                 // every position < 128: one split per row, the attention kernel normalises and writes the fragments
                 P.fin_xf = b.xfrag; P.fin_nt16 = nt16; P.fin_q4 = L.wo.wtype == WT_Q4_0 ? 1 : 0;
                 LCK(hd == 64 ? launch_attn_fin_hd<64>(e->gqa, P, dim3(e->KVs, 1, n), st)
