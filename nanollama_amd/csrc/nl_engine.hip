@@ -187,6 +187,9 @@ struct nl_engine {
     std::vector<Op> plan;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph_multi = nullptr;          // the same plan graph_steps times: chained greedy decode replays it
+    hipGraphExec_t graph_multi_exec = nullptr;  // (one inter-graph gap per graph_steps tokens instead of per token)
+    int graph_steps = 1;
     bool use_graph = true;
     void *comm = nullptr;
     int tw_override = 0, kw_override = 0;
@@ -556,6 +559,20 @@ int capture_graph(nl_engine *e) {
     if (s != hipSuccess) return e->fail(NL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(s));
     e->graph = g;
     HIPCK(e, hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+    // chained greedy decode replays a graph that holds the plan 16 times: the gap between two graph launches
+    // (~8 us on this stack) is then paid once per 16 tokens (nano 3834 -> 3945 tok/s; 4 steps: 3905; 32 / 64: as 16)
+    static const int steps = getenv("NL_GRAPH_STEPS") ? atoi(getenv("NL_GRAPH_STEPS")) : 16;   // developer knob (tools/)
+    if (steps > 1 && e->G == 1 && !e->force_tp_plan) {
+        HIPCK(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        int rc2 = NL_OK;
+        for (int k = 0; k < steps && !rc2; k++) rc2 = run_plan_eager(e);
+        hipGraph_t gm = nullptr;
+        hipError_t s2 = hipStreamEndCapture(e->stream, &gm);
+        if (rc2 || s2 != hipSuccess) { if (gm) hipGraphDestroy(gm); return rc2 ? rc2 : e->fail(NL_ERR_HIP, "multi-step capture"); }
+        e->graph_multi = gm;
+        HIPCK(e, hipGraphInstantiate(&e->graph_multi_exec, gm, nullptr, nullptr, 0));
+        e->graph_steps = steps;
+    }
     return NL_OK;
 }
 
@@ -1243,6 +1260,9 @@ int nl_set_gamma(nl_handle e, const int32_t *indices, int n, const void *values,
     }
     if (e->finalized) {  // the launch closures hold the old pointers: rebuild plan and graph
         if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+        if (e->graph_multi_exec) { hipGraphExecDestroy(e->graph_multi_exec); e->graph_multi_exec = nullptr; }
+        if (e->graph_multi) { hipGraphDestroy(e->graph_multi); e->graph_multi = nullptr; }
+        e->graph_steps = 1;
         if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
         build_plan(e);
         if (e->use_graph && !(c.flags & NL_FLAG_LOCAL_GROUP)) {
@@ -1260,6 +1280,8 @@ int nl_destroy(nl_handle e) {
     hipDeviceSynchronize();
     samp_free(e->sp);
     if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
+    if (e->graph_multi_exec) hipGraphExecDestroy(e->graph_multi_exec);
+    if (e->graph_multi) hipGraphDestroy(e->graph_multi);
     if (e->graph) hipGraphDestroy(e->graph);
     for (auto &L : e->layers) {
         if (L.attn_norm) hipFree(L.attn_norm);
@@ -1334,7 +1356,10 @@ int nl_decode_greedy(nl_handle e, int stream, int token, int pos, int n_steps, i
     int n = std::min(n_steps, e->cfg.seq_len - pos);
     n = std::min(n, e->ids_cap);
     if ((rc = set_ctl(e, token, pos, 1, stream))) return rc;
-    for (int i = 0; i < n; i++)
+    int i = 0;
+    if (e->graph_multi_exec)
+        for (; i + e->graph_steps <= n; i += e->graph_steps) HIPCK(e, hipGraphLaunch(e->graph_multi_exec, e->stream));
+    for (; i < n; i++)
         if ((rc = launch_step(e))) return rc;
     if (n > 0) HIPCK(e, hipMemcpyAsync(ids_out, e->ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCK(e, hipStreamSynchronize(e->stream));
