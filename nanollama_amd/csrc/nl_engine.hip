@@ -190,6 +190,11 @@ struct nl_engine {
     hipGraph_t graph_multi = nullptr;          // the same plan graph_steps times: chained greedy decode replays it
     hipGraphExec_t graph_multi_exec = nullptr;  // (one inter-graph gap per graph_steps tokens instead of per token)
     int graph_steps = 1;
+    // sampled chained decode: {sampler, plan} x graph_steps, captured per sampling-parameter set
+    hipGraph_t samp_graph = nullptr;
+    hipGraphExec_t samp_graph_exec = nullptr;
+    nl_sample_params samp_graph_params{};
+    bool samp_graph_failed = false;
     bool use_graph = true;
     void *comm = nullptr;
     int tw_override = 0, kw_override = 0;
@@ -1262,6 +1267,8 @@ int nl_set_gamma(nl_handle e, const int32_t *indices, int n, const void *values,
         if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
         if (e->graph_multi_exec) { hipGraphExecDestroy(e->graph_multi_exec); e->graph_multi_exec = nullptr; }
         if (e->graph_multi) { hipGraphDestroy(e->graph_multi); e->graph_multi = nullptr; }
+        if (e->samp_graph_exec) { hipGraphExecDestroy(e->samp_graph_exec); e->samp_graph_exec = nullptr; }
+        if (e->samp_graph) { hipGraphDestroy(e->samp_graph); e->samp_graph = nullptr; }
         e->graph_steps = 1;
         if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
         build_plan(e);
@@ -1282,6 +1289,8 @@ int nl_destroy(nl_handle e) {
     if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
     if (e->graph_multi_exec) hipGraphExecDestroy(e->graph_multi_exec);
     if (e->graph_multi) hipGraphDestroy(e->graph_multi);
+    if (e->samp_graph_exec) hipGraphExecDestroy(e->samp_graph_exec);
+    if (e->samp_graph) hipGraphDestroy(e->samp_graph);
     if (e->graph) hipGraphDestroy(e->graph);
     for (auto &L : e->layers) {
         if (L.attn_norm) hipFree(L.attn_norm);
@@ -1447,6 +1456,8 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
     if (n <= 0) return NL_OK;
     if (!e->sp_ready || e->sp_uniforms_cap < n) {
         HIPCK(e, hipStreamSynchronize(e->stream));
+        if (e->samp_graph_exec) { hipGraphExecDestroy(e->samp_graph_exec); e->samp_graph_exec = nullptr; }   // holds the old scratch pointers
+        if (e->samp_graph) { hipGraphDestroy(e->samp_graph); e->samp_graph = nullptr; }
         samp_free(e->sp);
         e->sp_ready = false;
         e->sp_uniforms_cap = std::max(n, e->cfg.seq_len);
@@ -1460,7 +1471,35 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
     HIPCK(e, hipMemcpyAsync(s.uniforms, uniforms, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
     if (*n_recent > 0) HIPCK(e, hipMemcpyAsync(s.recent, recent, (size_t)*n_recent * 4, hipMemcpyHostToDevice, e->stream));
     HIPCK(e, hipMemcpyAsync(s.recent_n, n_recent, 4, hipMemcpyHostToDevice, e->stream));
-    for (int i = 0; i < n; i++) {
+    int i = 0;
+    if (e->graph_multi_exec && !e->samp_graph_failed && n >= e->graph_steps) {
+        // {sampler kernels, plan} x graph_steps as one graph (its kernel arguments include the sampling parameters:
+        // re-captured when they change)
+        if (!e->samp_graph_exec || memcmp(&e->samp_graph_params, p, sizeof(*p)) != 0) {
+            if (e->samp_graph_exec) { hipGraphExecDestroy(e->samp_graph_exec); e->samp_graph_exec = nullptr; }
+            if (e->samp_graph) { hipGraphDestroy(e->samp_graph); e->samp_graph = nullptr; }
+            hipError_t cs = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+            int rc2 = NL_OK;
+            for (int k = 0; cs == hipSuccess && k < e->graph_steps && !rc2; k++) {
+                if (launch_sample(s, e->logits, e->cfg.vocab, *p, e->ctl, e->ids, e->stream) != hipSuccess) rc2 = NL_ERR_HIP;
+                else rc2 = run_plan_eager(e);
+            }
+            hipGraph_t g = nullptr;
+            if (cs == hipSuccess) cs = hipStreamEndCapture(e->stream, &g);
+            if (cs == hipSuccess && !rc2 && g && hipGraphInstantiate(&e->samp_graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                e->samp_graph = g;
+                e->samp_graph_params = *p;
+            } else {
+                if (g) hipGraphDestroy(g);
+                (void)hipGetLastError();
+                e->samp_graph_exec = nullptr;
+                e->samp_graph_failed = true;      // (e.g. a library call that cannot be captured): eager launches below
+            }
+        }
+        if (e->samp_graph_exec)
+            for (; i + e->graph_steps <= n; i += e->graph_steps) HIPCK(e, hipGraphLaunch(e->samp_graph_exec, e->stream));
+    }
+    for (; i < n; i++) {
         HIPCK(e, launch_sample(s, e->logits, e->cfg.vocab, *p, e->ctl, e->ids, e->stream));
         if ((rc = launch_step(e))) return rc;
     }
