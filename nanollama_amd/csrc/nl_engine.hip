@@ -190,6 +190,8 @@ struct nl_engine {
     hipGraph_t graph_multi = nullptr;          // the same plan graph_steps times: chained greedy decode replays it
     hipGraphExec_t graph_multi_exec = nullptr;  // (one inter-graph gap per graph_steps tokens instead of per token)
     int graph_steps = 1;
+    EmbedParams plan_embed{};    // kept for the fused argmax + embed launch of the multi-step graph
+    ArgmaxParams plan_argmax{};
     // sampled chained decode: {sampler, plan} x graph_steps, captured per sampling-parameter set
     hipGraph_t samp_graph = nullptr;
     hipGraphExec_t samp_graph_exec = nullptr;
@@ -438,6 +440,7 @@ void build_plan(nl_engine *e) {
 
     {
         EmbedParams P{e->embd_raw, e->embd_type, c.dim, e->ctl, e->x[0], e->gamma_row, e->gamma_val};
+        e->plan_embed = P;
         e->plan.push_back({K_EMBED, 0, nullptr, 0, [P](hipStream_t st) {
                                hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, P);
                                return hipGetLastError();
@@ -527,6 +530,7 @@ void build_plan(nl_engine *e) {
     {
         ArgmaxParams P{e->logits, c.vocab, tp ? nullptr : e->amax_val, e->amax_idx, lm_blocks * lm_spb, e->ctl, e->ids,
                        e->result};
+        e->plan_argmax = P;
         e->plan.push_back({K_ARGMAX, 0, nullptr, 0, [P](hipStream_t st) {
                                hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, P);
                                return hipGetLastError();
@@ -570,7 +574,18 @@ int capture_graph(nl_engine *e) {
     if (steps > 1 && e->G == 1 && !e->force_tp_plan) {
         HIPCK(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
         int rc2 = NL_OK;
-        for (int k = 0; k < steps && !rc2; k++) rc2 = run_plan_eager(e);
+        // step k's argmax also embeds step k+1's token (argmax_embed_kernel): the embed launch exists in step 0 only
+        static const bool fuse_embed = getenv("NL_NO_ARGMAX_EMBED") == nullptr;
+        for (int k = 0; k < steps && !rc2; k++)
+            for (const Op &op : e->plan) {
+                if (fuse_embed && op.kind == K_EMBED && k > 0) continue;
+                hipError_t ls;
+                if (fuse_embed && op.kind == K_ARGMAX) {
+                    hipLaunchKernelGGL(argmax_embed_kernel, dim3(1), dim3(1024), 0, e->stream, e->plan_argmax, e->plan_embed);
+                    ls = hipGetLastError();
+                } else ls = op.fn(e->stream);
+                if (ls != hipSuccess) { rc2 = e->fail(NL_ERR_HIP, "multi-step capture: %s", hipGetErrorString(ls)); break; }
+            }
         hipGraph_t gm = nullptr;
         hipError_t s2 = hipStreamEndCapture(e->stream, &gm);
         if (rc2 || s2 != hipSuccess) { if (gm) hipGraphDestroy(gm); return rc2 ? rc2 : e->fail(NL_ERR_HIP, "multi-step capture"); }

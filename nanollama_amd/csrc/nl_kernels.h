@@ -1094,6 +1094,60 @@ __global__ void __launch_bounds__(1024) argmax_kernel(ArgmaxParams P) {
     }
 }
 
+// argmax of step k + embedding lookup of step k+1 in one launch (chained greedy decode inside the multi-step
+// graph): the token goes from the reduction to the row fetch through LDS instead of through ctl and a kernel boundary
+__global__ void __launch_bounds__(1024) argmax_embed_kernel(ArgmaxParams P, EmbedParams E) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    __shared__ int tok;
+    const int tid = threadIdx.x;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    if (P.part_val) {
+        for (int i = tid; i < P.npart; i += blockDim.x) {
+            float v = P.part_val[i];
+            int vi = P.part_idx[i];
+            if (v > best || (v == best && vi < idx)) { best = v; idx = vi; }
+        }
+    } else {
+        for (int i = tid; i < P.n; i += blockDim.x) {
+            float v = P.logits[i];
+            if (v > best || idx == 0x7fffffff) { best = v; idx = i; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o);
+        int oi = __shfl_xor(idx, o);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        if (idx == 0x7fffffff) idx = 0;  // all-NaN logits: the reference's loop never leaves index 0
+        tok = idx;
+        *P.result = idx;
+        if (P.ctl[CTL_CHAIN]) {
+            int step = P.ctl[CTL_STEP];
+            P.ids[step] = idx;
+            P.ctl[CTL_STEP] = step + 1;
+            P.ctl[CTL_TOKEN] = idx;
+            P.ctl[CTL_POS] = P.ctl[CTL_POS] + 1;
+        }
+    }
+    __syncthreads();
+    const int token = tok;
+    const int gr = E.gamma_row ? E.gamma_row[token] : -1;
+    for (int i = tid; i < E.dim; i += blockDim.x) {
+        float v = embed_value(E.table, E.wtype, E.dim, token, i);
+        if (gr >= 0) v += E.gamma_val[(long long)gr * E.dim + i];
+        E.x[i] = v;
+    }
+}
+
+
 // Sum of tensor-parallel partial vectors living in ONE process (the in-process stand-in for the
 // RCCL all-reduce, used by nl_group_forward): every buffer ends up holding the sum.
 struct PtrList8 { float *p[8]; };
