@@ -784,9 +784,9 @@ int batch_alloc(nl_engine *e) {
     HIPCK(e, dalloc(&b.kpart2, b.kpart_cap, &e->bytes_state));
     HIPCK(e, dalloc(&b.part_o, n * e->Hs * e->nsplit_max * e->hd, &e->bytes_state));
     HIPCK(e, dalloc(&b.part_ml, n * e->Hs * e->nsplit_max * 2, &e->bytes_state));
-    HIPCK(e, dalloc(&b.tok, n, &e->bytes_state));
-    HIPCK(e, dalloc(&b.pos, n, &e->bytes_state));
-    HIPCK(e, dalloc(&b.stream, n, &e->bytes_state));
+    HIPCK(e, dalloc(&b.tok, 3 * n, &e->bytes_state));   // token | pos | stream, the layout of h_meta: one upload per step
+    b.pos = b.tok + n;
+    b.stream = b.tok + 2 * n;
     HIPCK(e, dalloc(&b.ids, n, &e->bytes_state));
     HIPCK(e, hipHostMalloc((void **)&b.h_meta, 3 * n * sizeof(int), hipHostMallocDefault));
     b.ready = true;
@@ -823,9 +823,7 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
     hipStream_t st = e->stream;
     const int D = c.dim, hd = e->hd, HQ = e->Hs * hd, R = (e->Hs + 2 * e->KVs) * hd;
 #define LCK(expr) do { hipError_t s_ = (expr); if (s_ != hipSuccess) return e->fail(NL_ERR_HIP, "batched step: %s: %s", #expr, hipGetErrorString(s_)); } while (0)
-    LCK(hipMemcpyAsync(b.tok, b.h_meta, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    LCK(hipMemcpyAsync(b.pos, b.h_meta + b.cap, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    LCK(hipMemcpyAsync(b.stream, b.h_meta + 2 * b.cap, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    LCK(hipMemcpyAsync(b.tok, b.h_meta, (size_t)3 * b.cap * 4, hipMemcpyHostToDevice, st));
     {
         BEmbedParams P{e->embd_raw, e->embd_type, D, b.tok, b.x, e->gamma_row, e->gamma_val};
         hipLaunchKernelGGL(bembed_kernel, dim3(n), dim3(256), 0, st, P);
@@ -1319,7 +1317,8 @@ int nl_destroy(nl_handle e) {
     if (e->stage) hipFree(e->stage);
     {
         nl_engine::Batch &b = e->bt;
-        void *bb[] = {b.x, b.qkv, b.q, b.g, b.u, b.logits, b.part_o, b.part_ml, b.tok, b.pos, b.stream, b.ids, b.kpart, b.kpart2, b.xfrag};
+        void *bb[] = {b.x, b.qkv, b.q, b.g, b.u, b.logits, b.part_o, b.part_ml, b.tok /* | pos | stream */, b.ids, b.kpart, b.kpart2,
+                      b.xfrag, b.xfrag2};
         for (void *p : bb) if (p) hipFree(p);
         if (b.h_meta) hipHostFree(b.h_meta);
     }
