@@ -76,7 +76,8 @@ NL_API int nl_create(const nl_config *cfg, nl_handle *out);
  * only this rank's tensor-parallel shard.  Unknown names -> NL_ERR_INVALID,
  * unsupported types -> NL_ERR_UNSUPPORTED (the Go engine would print a WARNING
  * and compute garbage, go/model.go:383-385; we refuse instead).  Optional
- * blk.N.attn_{q,k,v,output}.bias tensors (go/model.go:244-247) are accepted as F32/F16. */
+ * blk.N.attn_{q,k,v,output}.bias tensors (go/model.go:244-247) are accepted as F32/F16, each independently
+ * optional (an absent q/k/v bias is a zero vector).  Callers skip tensors the Go loader never reads. */
 NL_API int nl_upload_tensor(nl_handle h, const char *gguf_name, uint32_t ggml_type, const void *data,
                             uint64_t nbytes, uint64_t rows, uint64_t cols);
 /* allocState + precomputeRoPE (go/model.go:324-358), tied-embedding fallback
@@ -90,7 +91,9 @@ NL_API int nl_set_gamma(nl_handle h, const int32_t *indices, int n, const void *
 NL_API const char *nl_last_error(nl_handle h); /* h may be NULL: last create error */
 
 /* == Reset (go/model.go:623-631) ========================================== */
-/* O(1): positions >= the next pos are never read, so no memset is needed. */
+/* O(1): instead of zeroing 2*L*S*kvDim floats the library keeps a per-stream high-water mark (positions
+ * [0, mark) written since the last reset) and drops it here.  A later step at pos > mark is legal, as in the
+ * reference, and sees what the reference sees: the rows [mark, pos) are cleared to zero just before that step. */
 NL_API int nl_reset(nl_handle h, int stream);
 
 /* == Forward (go/model.go:490-620) ======================================== */
@@ -148,8 +151,9 @@ NL_API int nl_synchronize(nl_handle h);
 NL_API int nl_timer_start(nl_handle h);
 NL_API int nl_timer_stop(nl_handle h, float *ms);
 /* Per-kernel-kind device time of one eager Forward (events around every
- * launch).  kinds: see nl_kernel_kind_name.  ms_out/calls_out have NL_NUM_KINDS
- * entries. */
+ * launch, each replayed `iters` times).  kinds: see nl_kernel_kind_name.  ms_out/calls_out have NL_NUM_KINDS
+ * entries.  Measurement only: the replays leave x, the logits and the K/V rows at `pos` in a state no Forward
+ * produces, so the stream's positions >= pos count as unwritten afterwards (re-run them before decoding on). */
 #define NL_NUM_KINDS 8
 NL_API const char *nl_kernel_kind_name(int kind);
 NL_API int nl_profile_forward(nl_handle h, int stream, int token, int pos, int iters, float *ms_out, int *calls_out);

@@ -153,6 +153,7 @@ struct nl_engine {
     int *amax_idx = nullptr;
     int amax_slots = 0;
     int *h_ctl = nullptr;  // pinned staging
+    std::vector<int> hw;   // per stream: positions [0, hw) hold K/V written since the last nl_reset
     int *h_ctl_ring = nullptr;  // pinned: one ctl block per queued step (prefill / batch)
     int ctl_ring_cap = 0;
     int ids_cap = 0;
@@ -616,6 +617,23 @@ int check_step_args(nl_engine *e, int stream, int token, int pos) {
     if (stream < 0 || stream >= e->cfg.max_streams) return e->fail(NL_ERR_INVALID, "stream %d out of range", stream);
     if (token < 0 || token >= e->cfg.vocab) return e->fail(NL_ERR_INVALID, "token %d out of range [0,%d)", token, e->cfg.vocab);
     if (pos < 0 || pos >= e->cfg.seq_len) return e->fail(NL_ERR_INVALID, "pos %d out of range [0,%d)", pos, e->cfg.seq_len);
+    return NL_OK;
+}
+
+// Reset (go/model.go:623-631) zeroes both caches; here it only drops the stream's high-water mark.  A step at
+// pos > mark (legal through the ABI) would attend over rows the reference reads as zeros, so exactly those rows
+// [mark, pos) are cleared before the step: one strided memset per cache, only on that unusual call pattern.
+int note_positions(nl_engine *e, int stream, int pos, int n, hipStream_t st = nullptr) {
+    if (!st) st = e->stream;
+    int &mark = e->hw[stream];
+    if (pos > mark) {
+        const size_t pitch = (size_t)e->cfg.seq_len * e->hd * 4, width = (size_t)(pos - mark) * e->hd * 4;
+        const size_t height = (size_t)e->cfg.n_layers * e->KVs;
+        const size_t off = (size_t)stream * e->kv_stream_stride + (size_t)mark * e->hd;
+        HIPCK(e, hipMemset2DAsync(e->kcache + off, pitch, 0, width, height, st));
+        HIPCK(e, hipMemset2DAsync(e->vcache + off, pitch, 0, width, height, st));
+    }
+    mark = std::max(mark, std::min(pos + n, e->cfg.seq_len));
     return NL_OK;
 }
 
@@ -1173,8 +1191,16 @@ int nl_finalize(nl_handle e) {
                          : !L.have_v ? "attn_v" : !L.wo.ready ? "attn_output" : !L.gate.ready ? "ffn_gate"
                          : !L.up.ready ? "ffn_up" : !L.down.ready ? "ffn_down" : nullptr;
         if (miss) return e->fail(NL_ERR_MISSING, "layer %d %s: tensor not found", l, miss);
-        if ((L.bq || L.bk || L.bv) && !(L.bq && L.bk && L.bv))
-            return e->fail(NL_ERR_MISSING, "layer %d: attn_q/k/v.bias must come together", l);
+        if (L.bq || L.bk || L.bv) {
+            // each bias is independently optional in the reference (getF32TensorOptional, go/model.go:244-247):
+            // an absent one is a zero vector here
+            struct { float **p; int n; } want[3] = {{&L.bq, e->Hs * e->hd}, {&L.bk, e->KVs * e->hd}, {&L.bv, e->KVs * e->hd}};
+            for (auto &w : want)
+                if (!*w.p) {
+                    HIPCK(e, dalloc(w.p, (size_t)w.n, &e->bytes_weights));
+                    HIPCK(e, hipMemset(*w.p, 0, (size_t)w.n * 4));
+                }
+        }
         if (L.gate.src_type != L.up.src_type) return e->fail(NL_ERR_UNSUPPORTED, "layer %d: ffn_gate and ffn_up types differ", l);
     }
     if (!e->have_output) {
@@ -1216,6 +1242,7 @@ int nl_finalize(nl_handle e) {
     HIPCK(e, dalloc(&e->vcache, kvn, &e->bytes_kv));
     HIPCK(e, hipMemsetAsync(e->kcache, 0, kvn * 4, e->stream));
     HIPCK(e, hipMemsetAsync(e->vcache, 0, kvn * 4, e->stream));
+    e->hw.assign(c.max_streams, 0);
     e->ids_cap = c.seq_len + 1;
     HIPCK(e, dalloc(&e->ctl, (size_t)CTL_WORDS, &e->bytes_state));
     HIPCK(e, dalloc(&e->ids, (size_t)e->ids_cap, &e->bytes_state));
@@ -1258,24 +1285,34 @@ int nl_set_gamma(nl_handle e, const int32_t *indices, int n, const void *values,
     const nl_config &c = e->cfg;
     HIPCK(e, hipSetDevice(e->dev));
     HIPCK(e, hipStreamSynchronize(e->stream));
-    if (e->gamma_row) { hipFree(e->gamma_row); e->gamma_row = nullptr; }
-    if (e->gamma_val) { hipFree(e->gamma_val); e->gamma_val = nullptr; }
+    // Build and upload the new tables BEFORE touching the old ones: the plan closures and captured graphs hold the
+    // old device pointers until they are rebuilt below, so no error path may leave them dangling.  Indices outside
+    // [0, vocab) are dropped: the Go side keeps a map keyed by token id (go/gamma.go IndexMap) that such ids never hit.
+    int *new_row = nullptr;
+    float *new_val = nullptr;
     if (n > 0) {
         std::vector<int> rowmap(c.vocab, -1);
-        for (int i = 0; i < n; i++) {
-            if (indices[i] < 0 || indices[i] >= c.vocab) return e->fail(NL_ERR_INVALID, "gamma index %d out of range", indices[i]);
-            rowmap[indices[i]] = i;  // later entries win, like the Go map build
-        }
+        for (int i = 0; i < n; i++)
+            if (indices[i] >= 0 && indices[i] < c.vocab) rowmap[indices[i]] = i;  // later entries win, like the Go map build
         std::vector<float> vals((size_t)n * c.dim);
         if (is_f16) {
             const uint16_t *hp = (const uint16_t *)values;
             for (size_t i = 0; i < vals.size(); i++) vals[i] = __half2float(__ushort_as_half(hp[i]));
         } else memcpy(vals.data(), values, vals.size() * 4);
-        HIPCK(e, dalloc(&e->gamma_row, (size_t)c.vocab, &e->bytes_weights));
-        HIPCK(e, dalloc(&e->gamma_val, vals.size(), &e->bytes_weights));
-        HIPCK(e, hipMemcpy(e->gamma_row, rowmap.data(), (size_t)c.vocab * 4, hipMemcpyHostToDevice));
-        HIPCK(e, hipMemcpy(e->gamma_val, vals.data(), vals.size() * 4, hipMemcpyHostToDevice));
+        hipError_t s = dalloc(&new_row, (size_t)c.vocab);
+        if (s == hipSuccess) s = dalloc(&new_val, vals.size());
+        if (s == hipSuccess) s = hipMemcpy(new_row, rowmap.data(), (size_t)c.vocab * 4, hipMemcpyHostToDevice);
+        if (s == hipSuccess) s = hipMemcpy(new_val, vals.data(), vals.size() * 4, hipMemcpyHostToDevice);
+        if (s != hipSuccess) {
+            if (new_row) (void)hipFree(new_row);
+            if (new_val) (void)hipFree(new_val);
+            return e->fail(NL_ERR_HIP, "nl_set_gamma: %s", hipGetErrorString(s));   // old gamma still in force
+        }
     }
+    int *old_row = e->gamma_row;
+    float *old_val = e->gamma_val;
+    e->gamma_row = new_row;
+    e->gamma_val = new_val;
     if (e->finalized) {  // the launch closures hold the old pointers: rebuild plan and graph
         if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
         if (e->graph_multi_exec) { hipGraphExecDestroy(e->graph_multi_exec); e->graph_multi_exec = nullptr; }
@@ -1288,9 +1325,11 @@ int nl_set_gamma(nl_handle e, const int32_t *indices, int n, const void *values,
         if (e->use_graph && !(c.flags & NL_FLAG_LOCAL_GROUP)) {
             int rc = capture_graph(e);
             if (rc && (e->G > 1 || e->force_tp_plan)) { hipGetLastError(); e->graph = nullptr; e->graph_exec = nullptr; }
-            else if (rc) return rc;
+            else if (rc) { e->use_graph = false; }   // the rebuilt eager plan is valid; only the graph was lost
         }
     }
+    if (old_row) (void)hipFree(old_row);   // nothing references the old tables any more
+    if (old_val) (void)hipFree(old_val);
     return NL_OK;
 }
 
@@ -1340,9 +1379,9 @@ int nl_reset(nl_handle e, int stream) {
     if (!e) return NL_ERR_INVALID;
     if (!e->finalized) return e->fail(NL_ERR_STATE, "reset before nl_finalize");
     if (stream < 0 || stream >= e->cfg.max_streams) return e->fail(NL_ERR_INVALID, "stream %d out of range", stream);
-    // Forward at position p only ever reads cache positions <= p, all of which
-    // the caller has rewritten since the reset, so the reference's memset
-    // (go/model.go:623-631) has no observable effect and is skipped.
+    // O(1): the 2*L*S*kvDim memset of go/model.go:623-631 is replaced by dropping the stream's high-water mark;
+    // rows a later step could read without having rewritten them are cleared then (note_positions).
+    e->hw[stream] = 0;
     return NL_OK;
 }
 
@@ -1351,6 +1390,7 @@ int nl_forward(nl_handle e, int stream, int token, int pos, float *logits_out) {
     int rc = check_step_args(e, stream, token, pos);
     if (rc) return rc;
     HIPCK(e, hipSetDevice(e->dev));
+    if ((rc = note_positions(e, stream, pos, 1))) return rc;
     if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
     if ((rc = launch_step(e))) return rc;
     if (logits_out)
@@ -1364,6 +1404,7 @@ int nl_forward_argmax(nl_handle e, int stream, int token, int pos, int *next_id)
     int rc = check_step_args(e, stream, token, pos);
     if (rc) return rc;
     HIPCK(e, hipSetDevice(e->dev));
+    if ((rc = note_positions(e, stream, pos, 1))) return rc;
     if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
     if ((rc = launch_step(e))) return rc;
     HIPCK(e, hipMemcpyAsync(next_id, e->result, sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -1378,6 +1419,7 @@ int nl_decode_greedy(nl_handle e, int stream, int token, int pos, int n_steps, i
     HIPCK(e, hipSetDevice(e->dev));
     int n = std::min(n_steps, e->cfg.seq_len - pos);
     n = std::min(n, e->ids_cap);
+    if ((rc = note_positions(e, stream, pos, n))) return rc;
     if ((rc = set_ctl(e, token, pos, 1, stream))) return rc;
     int i = 0;
     if (e->graph_multi_exec)
@@ -1478,6 +1520,7 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
         HIPCK(e, samp_alloc(e->sp, e->cfg.vocab, e->sp_uniforms_cap));
         e->sp_ready = true;
     }
+    if ((rc = note_positions(e, stream, pos, n))) return rc;
     const SampScratch &s = e->sp;
     // ctl: the select kernel writes token = sampled id and pos + 1; the forward that follows runs unchained
     // (its argmax does not advance the state).  ctl.pos is primed to pos - 1 so the first increment lands on pos.
@@ -1568,6 +1611,7 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
     for (int i = 0; i < n; i++)
         if (tokens[i] < 0 || tokens[i] >= e->cfg.vocab) return e->fail(NL_ERR_INVALID, "token %d out of range [0,%d)", tokens[i], e->cfg.vocab);
     HIPCK(e, hipSetDevice(e->dev));
+    if ((rc = note_positions(e, stream, pos0, n))) return rc;
     if (n >= NL_BATCH_MIN && batch_supported(e)) {
         // multi-token path: 64-token tiles on the matrix cores; causality comes from each token's own pos
         if ((rc = batch_alloc(e))) return rc;
@@ -1614,6 +1658,8 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
     }
     if (n == 0) return NL_OK;
     HIPCK(e, hipSetDevice(e->dev));
+    for (int i = 0; i < n; i++)
+        if ((rc = note_positions(e, streams[i], pos[i], 1))) return rc;
     if (n >= NL_BATCH_MIN && batch_supported(e)) {
         if ((rc = batch_alloc(e))) return rc;
         nl_engine::Batch &b = e->bt;
@@ -1681,6 +1727,7 @@ int nl_profile_forward(nl_handle e, int stream, int token, int pos, int iters, f
     if (rc) return rc;
     HIPCK(e, hipSetDevice(e->dev));
     for (int k = 0; k < NL_NUM_KINDS; k++) { ms_out[k] = 0.f; calls_out[k] = 0; }
+    if ((rc = note_positions(e, stream, pos, 1))) return rc;
     if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
     if ((rc = run_plan_eager(e))) return rc;
     HIPCK(e, hipStreamSynchronize(e->stream));
@@ -1698,6 +1745,9 @@ int nl_profile_forward(nl_handle e, int stream, int token, int pos, int iters, f
         ms_out[op.kind] += ms / (float)iters;
         calls_out[op.kind]++;
     }
+    // the replays accumulated the residual epilogues `iters` times: x, logits and the K/V rows at `pos` of layers >= 1
+    // are no longer a Forward's.  Positions >= pos of this stream count as unwritten from here on.
+    e->hw[stream] = std::min(e->hw[stream], pos);
     return NL_OK;
 }
 
@@ -1900,6 +1950,7 @@ int nl_group_forward(nl_handle *hs, int n, int stream, int token, int pos, float
     hipStream_t st = e0->stream;  // one stream serialises the whole group
     for (int r = 0; r < n; r++) {
         nl_engine *e = hs[r];
+        if (int rc = note_positions(e, stream, pos, 1, st)) return rc;
         e->h_ctl[CTL_TOKEN] = token; e->h_ctl[CTL_POS] = pos; e->h_ctl[CTL_CHAIN] = 0;
         e->h_ctl[CTL_STEP] = 0; e->h_ctl[CTL_STREAM] = stream;
         HIPCK(e0, hipMemcpyAsync(e->ctl, e->h_ctl, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, st));

@@ -92,7 +92,9 @@ class Engine:
         recent: List[int] = []
         start = time.perf_counter()              # timer starts after prefill, go/main.go:171
         greedy_fast = p.temperature <= 0 and self.rep_penalty <= 1.0
+        # (the device sampler's select kernel covers vocabularies up to 131072 entries; larger ones take the host loop)
         device_sampling = (not greedy_fast and self.device_sampling and n_prompt > 0 and self.rep_window <= 1024
+                           and cfg.vocab_size <= 131072
                            and p.top_p > 0 and (p.top_p < 1.0 or p.top_k >= 1 or p.temperature <= 0))
         if greedy_fast and p.max_tokens > 0:
             # sample_0 comes from the prefill logits; sample_k (k >= 1) exists iff k < max_tokens, the

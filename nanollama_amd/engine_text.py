@@ -24,20 +24,23 @@ class TextEngine:
         out = bytearray()
 
         def on_token(t: int):
+            # the reference loop runs while len(output) < 8192 (go/main.go:173): the piece that crosses the cap is
+            # the last one emitted
+            if len(out) >= 8192:
+                return
             piece = self.tokenizer.decode_token_bytes(t)
             out.extend(piece)
             if stream is not None:
                 stream.write(dec.decode(piece))
                 stream.flush()
 
-        # output is capped at 8192 bytes in the reference loop (go/main.go:173); pieces are short, so cap tokens
         self.ids.generate_ids(tokens, p, on_token=on_token)
         if stream is not None:
             stream.write(dec.decode(b"", final=True) + "\n")
             if self.ids.last_tokens and self.ids.last_tok_per_s > 0:
                 stream.write("[%d tokens, %.1f tok/s]\n" % (self.ids.last_tokens, self.ids.last_tok_per_s))
             stream.flush()
-        return bytes(out[:8192 + 64]).decode("utf-8", errors="replace")
+        return bytes(out).decode("utf-8", errors="replace")
 
     def generate_quiet(self, prompt: str, p: GenParams) -> str:
         """GenerateQuiet (go/main.go:233-291)."""

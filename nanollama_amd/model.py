@@ -13,6 +13,7 @@ All arithmetic happens in libnanollama_hip.so; this file only moves bytes.
 from __future__ import annotations
 
 import ctypes as C
+import re
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -37,6 +38,12 @@ class LlamaConfig:
     rope_theta: float
     qk_norm: bool = False
     rope_conjugate: bool = False
+
+
+# the tensors loadWeights reads (go/model.go:177-265)
+_KNOWN_TENSOR = re.compile(r"^(token_embd\.weight|output_norm\.weight|output\.weight|blk\.\d+\.("
+                           r"(attn_norm|ffn_norm|attn_q|attn_k|attn_v|attn_output|ffn_gate|ffn_up|ffn_down)\.weight|"
+                           r"attn_(q|k|v|output)\.bias))$")
 
 
 class LlamaState:
@@ -194,6 +201,12 @@ def load_llama_model(gguf: GGUFFile, device: int = 0, max_streams: int = 1, tp_r
                 raise ValueError("tp_size > 1 needs the communicator id from nl_comm_get_unique_id")
             _lib.check(h, L.nl_comm_init(h, C.c_char_p(comm_id)))
         for name in gguf.tensor_order:
+            if not _KNOWN_TENSOR.match(name):
+                # the Go loader fetches tensors by name and never looks at the rest (go/model.go:177-265): files that
+                # carry extras such as rope_freqs.weight load there, so they are skipped here
+                if verbose:
+                    print(f"[model] skipping tensor {name}")
+                continue
             data, info = gguf.get_tensor(name)
             if info.ndims == 1:
                 rows, cols = 1, info.dims[0]

@@ -184,6 +184,32 @@ def test_reset_and_replay_is_deterministic(hip):
     dev.close()
 
 
+def test_step_beyond_the_reset_mark_reads_zero_rows(hip, orc):
+    # Reset zeroes both caches (go/model.go:623-631); the library drops a per-stream mark instead and clears the
+    # rows a later step could see without having rewritten them.  Forward straight at pos 5 after a reset therefore
+    # attends over zero rows 0-4, exactly as the reference does on its freshly zeroed cache.
+    g = gguf.load_gguf(os.path.join(GOLDEN, "tiny_q8_0.gguf"))
+    dev = hip.load_llama_model(g)
+    for pos, t in enumerate([1, 17, 45, 301, 7, 9, 12, 400]):     # dirty rows 0-7
+        dev.forward(t, pos)
+    dev.reset()
+    ref = orc.OracleModel(g)
+    for tok, pos in ((33, 5), (34, 6), (8, 2), (35, 7)):         # pos 5 first; 2 rewrites a cleared row later
+        dev.forward(tok, pos)
+        want = ref.forward(tok, pos)
+        assert np.abs(dev.state.logits - want).max() <= LOGIT_TOL * max(1.0, float(want.std()))
+    # chained decode and prefill beyond the mark clear their gap too
+    dev.reset(); ref.reset()
+    ids = dev.decode_greedy(21, 3, 4)
+    want_ids = []
+    tok = 21
+    for k in range(4):
+        tok = int(orc.argmax(ref.forward(tok, 3 + k)))
+        want_ids.append(tok)
+    assert ids == want_ids
+    dev.close(); ref.close()
+
+
 def test_streams_are_independent(hip):
     g = gguf.load_gguf(os.path.join(GOLDEN, "tiny_q8_0.gguf"))
     dev = hip.load_llama_model(g, max_streams=2)
@@ -803,6 +829,24 @@ def test_attention_biases_match_oracle(hip, orc, tmp_path, wtype):
     dev.close(); pre.close(); grp.close()
 
 
+def test_extra_tensors_are_skipped_and_biases_are_independently_optional(hip, orc, tmp_path):
+    # The Go loader fetches tensors by name and ignores the rest (go/model.go:177-265), and each attention bias is
+    # optional on its own (getF32TensorOptional, :244-247): a file with rope_freqs.weight and only a q bias loads.
+    shape = synth.ModelShape("bias_probe2", 2, 128, 4, 2, 512, seq_len=64, interm=512, attn_bias=True)
+    p = tmp_path / "b2.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 43)
+    g = gguf.load_gguf(str(p))
+    g.tensor_order = [n for n in g.tensor_order if not n.endswith(("attn_k.bias", "attn_v.bias", "attn_output.bias"))]
+    ref = orc.OracleModel(g)                         # the oracle sees the same reduced tensor list
+    g.tensors["rope_freqs.weight"] = g.tensors["output_norm.weight"]
+    g.tensor_order = g.tensor_order + ["rope_freqs.weight"]
+    dev = hip.load_llama_model(g)
+    for pos, t in enumerate(synth.prompt_ids(10, shape.vocab, seed=5)):
+        dev.forward(t, pos)
+        assert np.abs(dev.state.logits - ref.forward(t, pos)).max() <= LOGIT_TOL
+    dev.close(); ref.close()
+
+
 def test_gamma_injection_matches_oracle(hip, orc, tmp_path):
     # go/gamma.go: embed[token] += gamma[token] for the listed tokens only; f32 and f16 value files
     from nanollama_amd import gamma as gm
@@ -838,6 +882,17 @@ def test_gamma_injection_matches_oracle(hip, orc, tmp_path):
         assert dev.state.logits.tobytes() == plain.state.logits.tobytes()
         with pytest.raises(ValueError):
             dev.set_gamma([1], np.zeros((1, 64), np.float32))   # embed_dim mismatch, go/main.go:75-77
+        # token ids outside the vocabulary never match a lookup in the Go map (go/gamma.go IndexMap): they are
+        # dropped, the in-range rows apply, and the engine keeps running on valid tables
+        wide = np.concatenate([idx, np.array([100000, -3], np.int32)])
+        wvals = np.concatenate([vals, np.ones((2, 128), dtype)])
+        dev.set_gamma(wide, wvals)
+        ref2 = orc.OracleModel(g)
+        ref2.set_gamma(ge.indices, ge.values)
+        for pos, t in enumerate(toks):
+            dev.forward(t, pos)
+            assert np.abs(dev.state.logits - ref2.forward(t, pos)).max() <= LOGIT_TOL
+        ref2.close()
         dev.close(); plain.close(); pre.close()
 
 
