@@ -6,35 +6,84 @@
 A "step" is one decoded token: one pass of the hot path (Forward, go/model.go:490-620
 restated as HIP kernels) plus the greedy argmax, chained on the device.
 
-  N = 1 : BASELINE.json configs[1] -- nano (89M) Q8_0, single-stream greedy decode.
-  N > 1 : BASELINE.json configs[4] -- big (7.9B) Q4_0, tensor-parallel over N GPUs
-          (one process per GPU, RCCL all-reduce after WO and down), strong scaling.
+  N = 1 : headline = BASELINE.json configs[1], nano (89M) Q8_0 single-stream greedy decode;
+          "secondary" = big (7.9B) Q4_0 on the one GPU (the 1-GPU point of configs[4]);
+          "other_configs" = mini prefill, goldie x 64 streams.
+  N > 1 : headline = BASELINE.json configs[4], big (7.9B) Q4_0 tensor-parallel over the N GPUs,
+          one process per GPU, strong scaling ("scaling": "strong"): the two per-layer all-reduces are the
+          push all-reduce over xGMI (nl_p2p_*), RCCL when that cannot be set up.  "secondary" = N independent
+          nano replicas (no collective); "reference_1gpu" = the same big model on rank 0's GPU alone, measured in
+          the same run, with the first greedy ids compared against the tensor-parallel run.
 
-Weights are a deterministic random-weight GGUF written on the box in the
-reference exporter's layout (nanollama_amd.synth); inputs are resident in HBM
-before the timed region.  Prints ONE JSON line on rank 0.
+Launch: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks come from the
+environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  A plain `python bench.py --gpus N` starts the N rank
+processes itself (fresh children, before this process touches a GPU) and exits with their status.  In both cases a
+rank that finds WORLD_SIZE != N exits non-zero: a line can never carry n_gpus = N from fewer ranks, and the line
+reports "ranks" = the number of distinct ranks that met in the rendezvous.
+
+Weights are a deterministic random-weight GGUF written on the box in the reference exporter's layout
+(nanollama_amd.synth); inputs are resident in HBM before the timed region.  The timed region -- exactly K steps
+between barrier + synchronize -- is run REPEATS times and the median is the value (min / max beside it).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
-from nanollama_amd import gguf, synth  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PROMPT_LEN = 8
 SEGMENT = 128  # greedy 128-token decode (BASELINE.json configs)
+REPEATS = 5
 
 
-def kernel_bytes(shape: synth.ModelShape, wtype: str, pos: int, tp: int = 1):
+# ------------------------------------------------------------------ launcher (no GPU, no library) ---
+
+def launch_ranks(n, argv, timeout_s=None):
+    """`python bench.py --gpus N` outside a launcher: start N rank processes (this process has not loaded the HIP
+    library and never will), relay rank 0's stdout, exit non-zero unless every rank exits zero."""
+    timeout_s = timeout_s or int(os.environ.get("NL_BENCH_LAUNCH_TIMEOUT", "1500"))
+    port = int(os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 400)))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + timeout_s
+    rcs = [None] * n
+    out0 = b""
+    try:
+        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+        rcs[0] = procs[0].returncode
+        for r in range(1, n):
+            rcs[r] = procs[r].wait(timeout=max(1.0, deadline - time.time()))
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        print(f"[bench] rank processes did not finish within {timeout_s}s", file=sys.stderr)
+        return 3
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"[bench] ranks failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------ measurement ---
+
+def kernel_bytes(shape, wtype, pos, tp=1):
     """Algorithmic HBM bytes per LAUNCH of each kernel kind:
     every weight byte once + the vectors the kernel must read/write."""
+    from nanollama_amd import gguf, synth
     t = synth.WTYPES[wtype]
     bpe = gguf.ggml_block_size(t) / gguf.ggml_block_elements(t)
     d, i, v, kv, hd = shape.dim, shape.ffn // tp, shape.vocab // tp, shape.kv_dim // tp, shape.head_dim
@@ -43,15 +92,18 @@ def kernel_bytes(shape: synth.ModelShape, wtype: str, pos: int, tp: int = 1):
         "embed": d * bpe + d * 4,
         "qkv_rope": (hq + 2 * kv) * d * bpe + 2 * d * 4 + (hq + 2 * kv) * 4,
         "attention": (pos + 1) * kv * 2 * 4 + hq * 4 * 2,
+        "attn_block": (hq + 2 * kv) * d * bpe + d * hq * bpe + 2 * d * 4 + (pos + 1) * kv * 2 * 4,
         "wo_resid": d * hq * bpe + hq * 4 + 2 * d * 4,
         "gate_up_swiglu": 2 * i * d * bpe + 2 * d * 4 + i * 4,
         "down_resid": d * i * bpe + i * 4 + 2 * d * 4,
         "lm_head": v * d * bpe + 2 * d * 4 + v * 4,
         "argmax": shape.vocab * 4,
+        "allreduce": tp * d * 8 + 2 * d * 4,     # tp tagged 8-byte granules per element in, the residual in and out
     }
 
 
 def ensure_gguf(shape, wtype, mode, rank=0):
+    from nanollama_amd import synth
     path = os.path.join(os.environ.get("NL_BENCH_DIR", "/tmp"), f"nl_bench_{shape.name}_{wtype}_{mode}.gguf")
     if rank == 0 and not os.path.exists(path):
         t0 = time.time()
@@ -65,6 +117,7 @@ def ensure_gguf(shape, wtype, mode, rank=0):
 def cpu_baseline(path, prompt, budget_s=20.0):
     """The Go engine's algorithm (C restatement, oracle/) timed on this box's
     host cores on a bounded sample of the same workload.  Reported, not optimised against."""
+    from nanollama_amd import gguf
     from oracle import oracle
     ncpu = os.cpu_count() or 1
     m = oracle.OracleModel(gguf.load_gguf(path))
@@ -98,24 +151,47 @@ def cpu_baseline(path, prompt, budget_s=20.0):
                       f"C restatement of go/quant.go+go/model.go with the Go row partition on {cores} threads (best of 1..64 on a {ncpu}-cpu host)"}
 
 
-def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True):
-    """Load the tier's random-weight GGUF, run `warmup` + `steps` chained greedy decode steps, profile the
-    launches.  tp=True: the ranks of rdv form one tensor-parallel engine; tp=False: every rank is an
-    independent replica (no data-path collective).  Returns the result dict (timing = max over ranks)."""
+def measured_traffic(tier, wtype):
+    """HBM bytes per launch from the rocprofv3 PMC passes (profiles/README.md), only if they were collected on the
+    decode kernels the loaded library was built from (the file records the hash of nl_kernels.h)."""
+    from nanollama_amd import _lib
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        want = _lib.source_sha([os.path.join(ROOT, "nanollama_amd", "csrc", "nl_kernels.h")])
+        if tj.get("nl_kernels_sha16") != want:
+            continue
+        return tj.get(f"{tier}_{wtype}"), name
+    return None, None
+
+
+def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, comm=None, keep=None):
+    """Load the tier's random-weight GGUF, run `warmup` + REPEATS x `steps` chained greedy decode steps, profile the
+    launches.  tp=True: the ranks of rdv form one tensor-parallel engine (comm = "p2p" push all-reduce or "rccl");
+    tp=False: every rank is an independent replica (no data-path collective).  Timing = max over ranks."""
+    import numpy as np
+    from nanollama_amd import gguf, synth
     rank, local_rank = rdv.rank, rdv.local_rank
     replicas = 1 if tp else rdv.world
     world = rdv.world if tp else 1
     shape = synth.TIERS[tier]
     mode = "qrand" if tier in ("big", "goldie") else "float"
-    comm_id = rdv.broadcast_bytes(model.comm_unique_id) if (world > 1 or os.environ.get("NL_FORCE_TP_PLAN")) else None
     path = ensure_gguf(shape, wtype, mode, rank)
     rdv.barrier()
     g = gguf.load_gguf(path)
-    dev = model.load_llama_model(g, device=local_rank, tp_rank=rank if world > 1 else 0, tp_size=world,
-                                 comm_id=comm_id)
+    kw = {}
+    if world > 1 and comm == "p2p":
+        kw["p2p_allgather"] = rdv.allgather_bytes
+    elif world > 1 or os.environ.get("NL_FORCE_TP_PLAN"):
+        kw["comm_id"] = rdv.broadcast_bytes(model.comm_unique_id)
+    dev = model.load_llama_model(g, device=local_rank, tp_rank=rank if world > 1 else 0, tp_size=world, **kw)
     prompt = synth.prompt_ids(PROMPT_LEN, shape.vocab)
+    rdv.barrier()
     dev.prefill(prompt)
-    first, pos0 = int(np.argmax(dev.state.logits)), len(prompt)
+    prefill_logits = dev.state.logits.copy()
+    first, pos0 = int(np.argmax(prefill_logits)), len(prompt)
 
     def run_steps(k):
         """k chained decode steps in segments of SEGMENT tokens; every segment restarts at pos0 on
@@ -127,17 +203,23 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True):
             done += seg
         return ids
 
+    head_ids = dev.decode_greedy(first, pos0, 32)
     run_steps(warmup)
-    dev.synchronize()
-    rdv.barrier()
-    dev.timer_start()
-    t0 = time.perf_counter()
-    ids = run_steps(steps)
-    dev.synchronize()
-    wall_ms = (time.perf_counter() - t0) * 1e3
-    ev_ms = dev.timer_stop()
-    rdv.barrier()
-    wall_ms = rdv.max_over_ranks(wall_ms)
+    walls, evs, ids = [], [], []
+    for _ in range(REPEATS):
+        dev.synchronize()
+        rdv.barrier()
+        dev.timer_start()
+        t0 = time.perf_counter()
+        ids = run_steps(steps)
+        dev.synchronize()
+        wall_ms = (time.perf_counter() - t0) * 1e3
+        evs.append(dev.timer_stop())
+        rdv.barrier()
+        walls.append(rdv.max_over_ranks(wall_ms))
+    order = sorted(range(REPEATS), key=lambda i: walls[i])
+    med = order[REPEATS // 2]
+    wall_ms = walls[med]
     ms_per_step = wall_ms / steps
 
     # per-launch device time: every launch of the plan replayed 20x back to back between HIP events on the
@@ -151,35 +233,39 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True):
             per = ms / calls
             kernels[kind] = {"launches": calls, "us_per_launch": round(per * 1e3, 3),
                              "GBps": round(kb[kind] / (per * 1e-3) / 1e9, 1)}
-    traffic = None
-    try:  # HBM bytes per launch measured with rocprofv3 PMC counters in a separate pass (profiles/README.md)
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        traffic = tj.get(f"{tier}_{wtype}") if world == 1 else None
-    except (OSError, ValueError):
-        pass
+    traffic, traffic_file = measured_traffic(tier, wtype) if world == 1 else (None, None)
     # dominant kernel = the kind that moves the most algorithmic bytes per step (stable from run to run; for the
-    # launch-bound nano tier the five per-layer kinds have near-equal time shares and a time ranking flips)
-    dom = max((k for k in kernels if k != "argmax"), key=lambda k: kb[k] * prof[k][1])
+    # launch-bound nano tier the per-layer kinds have near-equal time shares and a time ranking flips)
+    dom = max((k for k in kernels if k not in ("argmax", "allreduce")), key=lambda k: kb[k] * prof[k][1])
     dom_gbs = kernels[dom]["GBps"]
     mean_pos = pos0 + (min(SEGMENT, steps) - 1) / 2.0
     step_bytes = synth.weight_bytes_per_token(shape, wtype) + synth.kv_bytes_per_token(shape, int(mean_pos))
     step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
-    dev.close()
-    return {
+    p2p = dev.p2p_info() if world > 1 else None
+    res = {
         "tier": tier, "wtype": wtype, "path": path, "prompt": prompt,
-        "tok_s": replicas * steps / (wall_ms / 1e3), "ms_per_step": ms_per_step, "device_ms_per_step": ev_ms / steps,
-        "replicas": replicas, "tp": world,
+        "tok_s": replicas * steps / (wall_ms / 1e3), "ms_per_step": ms_per_step, "device_ms_per_step": evs[med] / steps,
+        "ms_per_step_min": min(walls) / steps, "ms_per_step_max": max(walls) / steps,
+        "replicas": replicas, "tp": world, "p2p": p2p,
         "step_bytes": int(step_bytes), "hbm_frac_whole_step": step_gbs / (HBM_PEAK_GBS * max(world, 1)),
-        "kernels": kernels, "last_ids": ids[-4:],
+        "kernels": kernels, "last_ids": ids[-4:], "head_ids": head_ids, "prefill_logits": prefill_logits,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": (traffic or {}).get(dom),
+                     "traffic_source": traffic_file,
                      "bytes_per_launch": int(kb[dom]), "us_per_launch": kernels[dom]["us_per_launch"]},
     }
+    if keep is not None:
+        keep.append(dev)
+    else:
+        dev.close()
+    return res
 
 
 def side_configs(model):
     """BASELINE.json configs[2] and [3] as side results of the single-GPU run: mini Q4_0 2047-token prefill
     (MFMA multi-token path) + one decode step, and goldie Q4_0 with 64 concurrent decode streams."""
+    import numpy as np
+    from nanollama_amd import gguf, synth
     out = {}
     # -- mini: prefill + decode
     shape = synth.TIERS["mini"]
@@ -242,6 +328,20 @@ def side_configs(model):
     return out
 
 
+def workload_text(shape, tier, wtype):
+    return (f"{tier} ({shape.matrix_params() / 1e6:.0f}M matrix params) {wtype.upper()} GGUF, "
+            f"{PROMPT_LEN}-token prompt + {SEGMENT}-token greedy decode segments, 1 stream")
+
+
+def summary(r, keys=("kernels",)):
+    out = {"value": round(r["tok_s"], 2), "unit": "tokens/s", "ms_per_step": round(r["ms_per_step"], 5),
+           "ms_per_step_min": round(r["ms_per_step_min"], 5), "ms_per_step_max": round(r["ms_per_step_max"], 5),
+           "hbm_frac_whole_step": round(r["hbm_frac_whole_step"], 4), "roofline": r["roofline"]}
+    for k in keys:
+        out[k] = r[k]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,116 +349,200 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--workload", default=None, help="tier:wtype override, e.g. big:q4_0 (default by --gpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the big Q4_0 side measurement")
-    ap.add_argument("--tp-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the side measurements")
+    ap.add_argument("--comm", default=None, choices=("p2p", "rccl"), help="N > 1: force the all-reduce transport")
+    ap.add_argument("--rccl-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--profile-pos", type=int, default=PROMPT_LEN + SEGMENT // 2)
     args = ap.parse_args()
-
-    # the product library is loaded before torch so it binds /opt/rocm's HIP runtime
-    from nanollama_amd import _lib, model
-    from nanollama_amd.dist import Rendezvous
-    _lib.lib()
     n = args.gpus
-    tp_child = None
-    if args.tp_worker is None and n > 1 and not args.workload and not args.no_secondary:
-        # big Q4_0 tensor-parallel over the N GPUs runs in a child process per rank (own rendezvous port, hard
-        # timeout): a collective that hangs must not take the headline line down with it
-        tp_child = spawn_tp_child(args)
-    rdv = Rendezvous()
-    rank, world = rdv.rank, rdv.world
-    if world != n and world != 1:
-        raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}")
-    tp_res = None
-    if tp_child is not None:
-        # the child owns the GPU until it exits: parent and child never hold the device at the same time
-        tp_res = collect_tp_child(tp_child)
-        rdv.barrier()
+    if n < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if n > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: this process becomes one, before anything of it touches the GPU
+        raise SystemExit(launch_ranks(n, sys.argv[1:]))
 
-    if args.tp_worker is not None:   # child: big Q4_0, tensor-parallel over all ranks
-        r = run_workload("big", "q4_0", rdv, args.steps, args.warmup, args.profile_pos, model, tp=True)
+    # the product library is loaded before anything else that could pull in a second HIP runtime
+    import numpy as np
+    from nanollama_amd import _lib, model, synth
+    from nanollama_amd.dist import Rendezvous
+    dry = os.environ.get("NL_BENCH_DRYRUN")   # tests/test_bench_launcher.py: rank bookkeeping only, no GPU work
+    if not dry:
+        _lib.lib()
+    try:
+        rdv = Rendezvous(timeout_s=float(os.environ.get("NL_RDV_TIMEOUT", "300")))
+    except (TimeoutError, OSError) as exc:
+        print(f"[bench] rendezvous failed: {exc}", file=sys.stderr)
+        raise SystemExit(2)
+    rank, world = rdv.rank, rdv.world
+    if world != n:
+        print(f"[bench] --gpus {n} but this rank sees WORLD_SIZE={world}: refusing to report n_gpus={n}", file=sys.stderr)
+        raise SystemExit(2)
+    ranks_seen = len(set(rdv.allgather_bytes(str(rank).encode())))
+    if ranks_seen != n:
+        print(f"[bench] only {ranks_seen} of {n} ranks met in the rendezvous", file=sys.stderr)
+        raise SystemExit(2)
+    if dry:
         if rank == 0:
-            print("TPJSON " + json.dumps({k: r[k] for k in ("tok_s", "ms_per_step", "hbm_frac_whole_step", "roofline",
-                                                              "kernels", "tp")}))
+            print(json.dumps({"n_gpus": n, "ranks": ranks_seen, "dryrun": True}))
+        rdv.close()
+        return
+    common = {"unit": "tokens/s", "n_gpus": n, "ranks": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+              "repeats": REPEATS, "higher_is_better": True, "vs_baseline": None, "dtype": "f32",
+              "data": "synthetic (random-weight GGUF, reference exporter layout, nanollama_amd.synth)",
+              "build": _lib.build_info()}
+
+    if args.rccl_worker is not None:   # guarded child of an N > 1 run: big Q4_0 over RCCL
+        r = run_workload("big", "q4_0", rdv, args.steps, args.warmup, args.profile_pos, model, tp=True, comm="rccl")
+        if rank == 0:
+            r.pop("prefill_logits")
+            print("TPJSON " + json.dumps(r))
         rdv.close()
         return
 
     if args.workload:
         tier, wtype = args.workload.split(":")
-        tp = world > 1
-    else:
-        # N = 1: BASELINE configs[1], nano Q8_0.  N > 1: nano does not shard (SURVEY 8e "replicas only"), so the
-        # same workload runs as N independent replicas (weak scaling, no collective); big Q4_0 over the N GPUs
-        # (tensor parallel, RCCL all-reduce, strong scaling) is reported next to it under "secondary".
-        tier, wtype, tp = "nano", "q8_0", False
-    shape = synth.TIERS[tier]
-
-    r = run_workload(tier, wtype, rdv, args.steps, args.warmup, args.profile_pos, model, tp=tp)
-    par = f"tp{world}" if (tp and world > 1) else (f"{world} independent replicas" if world > 1 else "single-gpu")
-    out = {
-        "metric": f"decode tokens/sec, {tier} {wtype.upper()} single-stream greedy"
-                  + (f", tensor-parallel over {world} GPUs" if tp and world > 1 else "")
-                  + (f", {world} replicas (one per GPU)" if (not tp) and world > 1 else ""),
-        "value": round(r["tok_s"], 2), "unit": "tokens/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(r["ms_per_step"], 5), "higher_is_better": True,
-        "scaling": "strong" if (tp and world > 1) else "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic (random-weight GGUF, reference exporter layout, nanollama_amd.synth)",
-        "config": {"workload": f"{tier} ({shape.matrix_params() / 1e6:.0f}M matrix params) {wtype.upper()} GGUF, "
-                               f"{PROMPT_LEN}-token prompt + {SEGMENT}-token greedy decode segments, 1 stream per GPU",
-                   "parallelism": par,
-                   "weights": f"{wtype} blocks dequantised in-register, f32 activations and KV cache"},
-        "device_ms_per_step": round(r["device_ms_per_step"], 5),
-        "hbm_frac_whole_step": round(r["hbm_frac_whole_step"], 4),
-        "algorithmic_bytes_per_step": r["step_bytes"],
-        "roofline": r["roofline"], "kernels": r["kernels"], "last_ids": r["last_ids"],
-    }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(r["path"], r["prompt"])
-    if world == 1 and not args.workload and not args.no_secondary:
-        # BASELINE.json's metric also names big Q4_0 @ 1 GPU: measured here as a side result (bandwidth-bound
-        # regime; the headline nano config is launch-latency-bound)
-        try:
-            b = run_workload("big", "q4_0", rdv, 96, 16, args.profile_pos, model)
-            out["secondary"] = {"workload": "big (7.9B) Q4_0 single-stream greedy decode, 1 GPU",
-                                "value": round(b["tok_s"], 2), "unit": "tokens/s",
-                                "ms_per_step": round(b["ms_per_step"], 5),
-                                "hbm_frac_whole_step": round(b["hbm_frac_whole_step"], 4),
-                                "roofline": b["roofline"], "kernels": b["kernels"]}
-        except Exception as exc:  # the headline result must survive a failure of the side measurement
-            out["secondary"] = {"error": repr(exc)}
-        try:
-            out["other_configs"] = side_configs(model)
-        except Exception as exc:
-            out["other_configs"] = {"error": repr(exc)}
-    if tp_res is not None:
-        res = tp_res
+        shape = synth.TIERS[tier]
+        r = run_workload(tier, wtype, rdv, args.steps, args.warmup, args.profile_pos, model, tp=world > 1,
+                         comm=args.comm or "p2p")
+        out = dict(common, metric=f"decode tokens/sec, {tier} {wtype.upper()} single-stream greedy"
+                   + (f", tensor-parallel over {world} GPUs" if world > 1 else ""),
+                   scaling="strong" if world > 1 else "weak",
+                   config={"workload": workload_text(shape, tier, wtype), "parallelism": f"tp{world}" if world > 1 else "single-gpu",
+                           "allreduce": (args.comm or "p2p") if world > 1 else None},
+                   device_ms_per_step=round(r["device_ms_per_step"], 5), algorithmic_bytes_per_step=r["step_bytes"],
+                   last_ids=r["last_ids"], **summary(r))
         if rank == 0:
-            if "tok_s" in res:
-                out["secondary"] = {"workload": f"big (7.9B) Q4_0 single-stream greedy decode, tensor-parallel over {n} GPUs "
-                                                "(RCCL all-reduce after WO and down, logits all-gather)",
-                                    "scaling": "strong", "value": round(res["tok_s"], 2), "unit": "tokens/s",
-                                    "ms_per_step": round(res["ms_per_step"], 5),
-                                    "hbm_frac_whole_step": round(res["hbm_frac_whole_step"], 4),
-                                    "roofline": res["roofline"], "kernels": res["kernels"]}
-            else:
-                out["secondary"] = res
+            print(json.dumps(out))
+        rdv.close()
+        return
+
+    if n == 1:
+        tier, wtype = "nano", "q8_0"
+        shape = synth.TIERS[tier]
+        r = run_workload(tier, wtype, rdv, args.steps, args.warmup, args.profile_pos, model, tp=False)
+        out = dict(common, metric=f"decode tokens/sec, {tier} {wtype.upper()} single-stream greedy", scaling="weak",
+                   config={"workload": workload_text(shape, tier, wtype) + " per GPU", "parallelism": "single-gpu",
+                           "weights": f"{wtype} blocks dequantised in-register, f32 activations and KV cache"},
+                   device_ms_per_step=round(r["device_ms_per_step"], 5), algorithmic_bytes_per_step=r["step_bytes"],
+                   last_ids=r["last_ids"], **summary(r))
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(r["path"], r["prompt"])
+        if not args.no_secondary:
+            # BASELINE.json's metric also names big Q4_0 @ 1 GPU: the 1-GPU point of the tensor-parallel curve
+            try:
+                b = run_workload("big", "q4_0", rdv, 96, 16, args.profile_pos, model)
+                out["secondary"] = dict(workload="big (7.9B) Q4_0 single-stream greedy decode, 1 GPU", **summary(b))
+            except Exception as exc:  # the headline result must survive a failure of the side measurement
+                out["secondary"] = {"error": repr(exc)}
+            try:
+                out["other_configs"] = side_configs(model)
+            except Exception as exc:
+                out["other_configs"] = {"error": repr(exc)}
+        print(json.dumps(out))
+        rdv.close()
+        return
+
+    # ---- N > 1: big Q4_0, tensor-parallel over the N GPUs (BASELINE.json configs[4]) ----
+    shape = synth.TIERS["big"]
+    ref1 = None
+    if not args.no_secondary:
+        # the same model on rank 0's GPU alone, in the same run: the 1-GPU point of the curve and the parity anchor
+        if rank == 0:
+            try:
+                from nanollama_amd.dist import Rendezvous as _R
+                solo = _R.solo()
+                ref1 = run_workload("big", "q4_0", solo, 96, 16, args.profile_pos, model, tp=False)
+            except Exception as exc:
+                ref1 = {"error": repr(exc)}
+        rdv.barrier()
+    tp_res, transport, notes = None, None, []
+    for comm in ([args.comm] if args.comm else ["p2p", "rccl"]):
+        if comm == "p2p":
+            err = None
+            try:
+                cand = run_workload("big", "q4_0", rdv, args.steps, args.warmup, args.profile_pos, model, tp=True, comm="p2p")
+            except Exception as exc:
+                cand, err = None, repr(exc)
+            # every rank must have succeeded, and the tensor-parallel logits must be the 1-GPU logits (summation order only)
+            if cand is not None and rank == 0 and ref1 and "prefill_logits" in ref1:
+                d = float(np.abs(cand["prefill_logits"] - ref1["prefill_logits"]).max())
+                tol = 2e-3 * max(1.0, float(ref1["prefill_logits"].std()))
+                cand["max_abs_logit_diff_vs_1gpu"] = d
+                if not d <= tol:
+                    err = f"tensor-parallel logits differ from the 1-GPU logits by {d:.3g} (tolerance {tol:.3g})"
+            failed = rdv.max_over_ranks(1.0 if (cand is None or err) else 0.0) > 0
+            if failed:
+                notes.append({"transport": "p2p", "error": err or "another rank failed"})
+                continue
+            tp_res, transport = cand, "push all-reduce over xGMI (hipIpc-mapped receive slots, 8-byte tagged granules)"
+            break
+        else:
+            # RCCL can hang where the push path merely times out: run it in guarded child processes
+            child = spawn_rccl_child(args)
+            res = collect_child(child)
+            rdv.barrier()
+            if rank == 0 and res and "tok_s" in res:
+                tp_res, transport = res, "RCCL all-reduce / all-gather"
+            ok = rdv.max_over_ranks(0.0 if (rank != 0 or tp_res) else 1.0) == 0
+            if not ok:
+                notes.append({"transport": "rccl", "error": (res or {}).get("error", "child failed")})
+                tp_res = None
+    sec = None
+    if not args.no_secondary:
+        try:
+            rr = run_workload("nano", "q8_0", rdv, 512, 64, args.profile_pos, model, tp=False)
+            sec = dict(workload=f"nano Q8_0 single-stream greedy decode, {n} independent replicas (one per GPU, no collective)",
+                       scaling="weak", **summary(rr, keys=()))
+        except Exception as exc:
+            sec = {"error": repr(exc)}
     if rank == 0:
+        if tp_res is None:
+            print(json.dumps(dict(common, metric="decode tokens/sec, big Q4_0 tensor-parallel", value=None,
+                                  error="no tensor-parallel transport worked", attempts=notes, secondary=sec)))
+            rdv.close()
+            raise SystemExit(1)
+        out = dict(common, metric=f"decode tokens/sec, big Q4_0 single-stream greedy, tensor-parallel over {n} GPUs",
+                   scaling="strong",
+                   config={"workload": workload_text(shape, "big", "q4_0"), "parallelism": f"tp{n}", "allreduce": transport,
+                           "weights": "q4_0 blocks dequantised in-register, f32 activations and KV cache, rows/columns sharded per rank"},
+                   algorithmic_bytes_per_step=tp_res["step_bytes"], last_ids=tp_res["last_ids"],
+                   **summary(tp_res))
+        if "device_ms_per_step" in tp_res:
+            out["device_ms_per_step"] = round(tp_res["device_ms_per_step"], 5)
+        if tp_res.get("p2p"):
+            out["config"]["p2p_area"] = tp_res["p2p"]
+        if "max_abs_logit_diff_vs_1gpu" in tp_res:
+            out["max_abs_logit_diff_vs_1gpu"] = tp_res["max_abs_logit_diff_vs_1gpu"]
+        if ref1 and "tok_s" in ref1:
+            same = 0
+            for a, b in zip(ref1["head_ids"], tp_res.get("head_ids", [])):
+                if a != b:
+                    break
+                same += 1
+            out["reference_1gpu"] = dict(workload="the same big Q4_0 model on rank 0's GPU alone, same run",
+                                         greedy_ids_equal_prefix=f"{same}/{len(ref1['head_ids'])}", **summary(ref1, keys=()))
+            out["speedup_vs_1gpu"] = round(tp_res["tok_s"] / ref1["tok_s"], 3)
+        elif ref1:
+            out["reference_1gpu"] = ref1
+        if notes:
+            out["attempts"] = notes
+        if sec:
+            out["secondary"] = sec
         print(json.dumps(out))
     rdv.close()
 
 
-def spawn_tp_child(args):
-    import subprocess
+def spawn_rccl_child(args):
     env = dict(os.environ)
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env.pop("TORCHELASTIC_RUN_ID", None)
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--tp-worker", "1", "--steps", "96",
-           "--warmup", "16", "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--rccl-worker", "1", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--no-cpu-baseline"]
     return subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 
 
-def collect_tp_child(proc, timeout_s=300):
-    import subprocess
+def collect_child(proc, timeout_s=300):
     timeout_s = int(os.environ.get("NL_TP_CHILD_TIMEOUT", timeout_s))
     try:
         so, se = proc.communicate(timeout=timeout_s)

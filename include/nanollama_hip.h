@@ -66,6 +66,8 @@ typedef struct {
 /* Library / device probes (no handle, no device work for nl_abi_version). */
 NL_API int nl_abi_version(void);
 NL_API int nl_device_count(void);
+/* "src=<sha256[:16] of the library's sources at build time> git=<HEAD at build time>" */
+NL_API const char *nl_build_info(void);
 
 /* == LoadLlamaModel (go/model.go:121-174) ================================== */
 NL_API int nl_create(const nl_config *cfg, nl_handle *out);
@@ -154,7 +156,7 @@ NL_API int nl_timer_stop(nl_handle h, float *ms);
  * launch, each replayed `iters` times).  kinds: see nl_kernel_kind_name.  ms_out/calls_out have NL_NUM_KINDS
  * entries.  Measurement only: the replays leave x, the logits and the K/V rows at `pos` in a state no Forward
  * produces, so the stream's positions >= pos count as unwritten afterwards (re-run them before decoding on). */
-#define NL_NUM_KINDS 8
+#define NL_NUM_KINDS 9
 NL_API const char *nl_kernel_kind_name(int kind);
 NL_API int nl_profile_forward(nl_handle h, int stream, int token, int pos, int iters, float *ms_out, int *calls_out);
 /* Device bytes held by the handle (weights, KV, state). */
@@ -191,6 +193,20 @@ NL_API int nl_op_sample(int device, float *logits, int vocab, const nl_sample_pa
  * rank passes it to nl_comm_init before nl_finalize. */
 NL_API int nl_comm_get_unique_id(void *id_out /* NL_COMM_ID_BYTES */);
 NL_API int nl_comm_init(nl_handle h, const void *id /* NL_COMM_ID_BYTES */);
+
+/* Push all-reduce over xGMI (preferred data path of a tensor-parallel run; RCCL above stays as the fallback).
+ * The two seams per layer where go/model.go:590-594 and :609-612 add a projection into the residual stream carry a
+ * partial [dim] vector per rank.  Instead of 2*L latency-bound 16 KiB ring all-reduces, every rank writes its partial
+ * straight into a receive slot inside every peer's memory (one xGMI hop, 8-byte self-validating {tag, value} words)
+ * and sums the tp_size slots itself in rank order; the greedy argmax and the logits all-gather travel the same way.
+ * Setup, before nl_finalize, one process per GPU: every rank calls nl_p2p_export (allocates its receive area, returns a
+ * hipIpc handle), the host all-gathers the NL_P2P_HANDLE_BYTES handles over any side channel, every rank passes the
+ * rank-ordered array to nl_p2p_import.  tp_size must be 2, 4 or 8.  Every wait on a peer is bounded (NL_P2P_TIMEOUT_MS,
+ * default 10 s); a rank that gives up makes its calls return NL_ERR_COMM. */
+#define NL_P2P_HANDLE_BYTES 64
+NL_API int nl_p2p_export(nl_handle h, void *handle_out /* NL_P2P_HANDLE_BYTES */);
+NL_API int nl_p2p_import(nl_handle h, const void *handles /* tp_size x NL_P2P_HANDLE_BYTES, rank order */);
+NL_API int nl_p2p_info(nl_handle h, int *enabled, int *uncached_area);
 
 /* In-process tensor-parallel group: `n` handles created with tp_size = n, tp_rank = 0..n-1 and
  * NL_FLAG_LOCAL_GROUP (all on devices this process can reach; the same device is allowed).  Steps

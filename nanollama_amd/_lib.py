@@ -11,8 +11,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NL_LIB_PATH") or os.path.join(_HERE, "libnanollama_hip.so")  # NL_LIB_PATH: A/B builds (tools/)
-NL_NUM_KINDS = 8
+NL_NUM_KINDS = 9
 NL_COMM_ID_BYTES = 128
+NL_P2P_HANDLE_BYTES = 64
 NL_FLAG_NO_GRAPH = 1
 NL_FLAG_LOCAL_GROUP = 2
 
@@ -40,24 +41,55 @@ class NlError(RuntimeError):
         self.code = code
 
 
-def build(force: bool = False) -> str:
-    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+def source_files():
+    """The library's sources in the order csrc/Makefile hashes them."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("nl_engine.hip", "nl_kernels.h", "nl_qgemm.h", "nl_batch.h", "nl_sample.h")] + \
+    hdrs = sorted(f for f in os.listdir(src_dir) if f.endswith(".h"))
+    return [os.path.join(src_dir, "nl_engine.hip")] + [os.path.join(src_dir, f) for f in hdrs] + \
            [os.path.join(os.path.dirname(_HERE), "include", "nanollama_hip.h")]
+
+
+def source_sha(files=None) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for f in files or source_files():
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def build_info() -> dict:
+    """What the loaded binary says it was built from, next to the sources present now."""
+    L = lib()
+    L.nl_build_info.restype = C.c_char_p
+    info = dict(kv.split("=", 1) for kv in L.nl_build_info().decode().split())
+    tree = source_sha()
+    return {"lib_src_sha16": info.get("src"), "lib_git_head_at_build": info.get("git"), "tree_src_sha16": tree,
+            "lib_matches_tree": info.get("src") == tree}
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU).  Rebuilds when the binary is
+    missing, older than a source, or carries another source hash than the tree (mtimes do not survive every copy)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = source_files() + [os.path.join(src_dir, "Makefile")]
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if not stale and not force:
+        with open(LIB_PATH, "rb") as fh:       # read the embedded string without loading the library
+            stale = f"src={source_sha()} git=".encode() not in fh.read()
     if force or stale:
-        subprocess.check_call(["make", "-C", src_dir] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-C", src_dir, "-B"])
     return LIB_PATH
 
 
 _lib = None
 
-EXPORTS = ["nl_set_gamma", "nl_abi_version", "nl_device_count", "nl_create", "nl_upload_tensor", "nl_finalize", "nl_destroy",
+EXPORTS = ["nl_build_info", "nl_set_gamma", "nl_abi_version", "nl_device_count", "nl_create", "nl_upload_tensor", "nl_finalize", "nl_destroy",
            "nl_last_error", "nl_reset", "nl_forward", "nl_forward_argmax", "nl_decode_greedy", "nl_prefill", "nl_forward_batch", "nl_get_config",
            "nl_synchronize", "nl_timer_start", "nl_timer_stop", "nl_kernel_kind_name", "nl_profile_forward",
            "nl_memory_usage", "nl_debug_read", "nl_op_matmul", "nl_op_matmul_batch", "nl_op_rmsnorm", "nl_comm_get_unique_id",
-           "nl_comm_init", "nl_group_forward", "nl_debug_stamps", "nl_sample_decode", "nl_op_sample"]
+           "nl_comm_init", "nl_group_forward", "nl_debug_stamps", "nl_sample_decode", "nl_op_sample", "nl_p2p_export",
+           "nl_p2p_import", "nl_p2p_info"]
 
 
 def lib():
@@ -99,6 +131,9 @@ def lib():
     L.nl_op_rmsnorm.argtypes = [i32, fp, fp, C.c_float, fp, i32]
     L.nl_comm_get_unique_id.argtypes = [vp]
     L.nl_comm_init.argtypes = [vp, vp]
+    L.nl_p2p_export.argtypes = [vp, vp]
+    L.nl_p2p_import.argtypes = [vp, vp]
+    L.nl_p2p_info.argtypes = [vp, ip, ip]
     L.nl_group_forward.argtypes = [C.POINTER(vp), i32, i32, i32, i32, fp]
     L.nl_sample_decode.argtypes = [vp, i32, i32, i32, C.POINTER(NlSampleParams), fp, ip, ip, ip, ip]
     L.nl_op_sample.argtypes = [i32, fp, i32, C.POINTER(NlSampleParams), C.c_float, ip, ip, ip]

@@ -12,6 +12,7 @@
 #include "nl_qgemm.h"
 #include "nl_batch.h"
 #include "nl_sample.h"
+#include "nl_p2p.h"
 
 #include <dlfcn.h>
 #include <algorithm>
@@ -33,9 +34,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Kind { K_EMBED = 0, K_QKV, K_ATTN, K_WO, K_GATEUP, K_DOWN, K_LMHEAD, K_ARGMAX };
+enum Kind { K_EMBED = 0, K_QKV, K_ATTN, K_WO, K_GATEUP, K_DOWN, K_LMHEAD, K_ARGMAX, K_ALLREDUCE };
 const char *kKindNames[NL_NUM_KINDS] = {"embed", "qkv_rope", "attention", "wo_resid", "gate_up_swiglu",
-                                        "down_resid", "lm_head", "argmax"};
+                                        "down_resid", "lm_head", "argmax", "allreduce"};
 
 struct PackedMat {
     uint8_t *q = nullptr;
@@ -193,6 +194,7 @@ struct nl_engine {
     int graph_steps = 1;
     EmbedParams plan_embed{};    // kept for the fused argmax + embed launch of the multi-step graph
     ArgmaxParams plan_argmax{};
+    P2PArgmaxParams plan_p2p_argmax{};
     // sampled chained decode: {sampler, plan} x graph_steps, captured per sampling-parameter set
     hipGraph_t samp_graph = nullptr;
     hipGraphExec_t samp_graph_exec = nullptr;
@@ -200,6 +202,18 @@ struct nl_engine {
     bool samp_graph_failed = false;
     bool use_graph = true;
     void *comm = nullptr;
+    // one-shot push all-reduce between the ranks of a node (nl_p2p.h); replaces RCCL on the data path when set up
+    struct P2P {
+        bool on = false;          // nl_p2p_import succeeded: the plan uses the push seams
+        void *area = nullptr;     // this rank's receive area (uncached, exported over hipIpc)
+        size_t bytes = 0;
+        bool uncached = false;
+        void *peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // rank r's area mapped here
+        bool opened[8] = {false, false, false, false, false, false, false, false};
+        unsigned *epoch = nullptr, *status = nullptr;   // device words: forward counter, poll-timeout flags
+        long long timeout_ticks = 0;
+        size_t off_amax = 0, off_logits = 0;             // byte offsets inside an area
+    } p2p;
     int tw_override = 0, kw_override = 0;
     bool force_tp_plan = false;  // NL_FORCE_TP_PLAN: use the all-reduce / all-gather seams even with one rank
 
@@ -409,6 +423,8 @@ hipError_t launch_gemv_dyn(int wt, int pro, int epi, const GemvParams &P, hipStr
     if (pro == PRO_PLAIN && epi == EPI_RESID) return launch_gemv_t<PRO_PLAIN, EPI_RESID>(wt, P, st);
     if (pro == PRO_PLAIN && epi == EPI_STORE) return launch_gemv_t<PRO_PLAIN, EPI_STORE>(wt, P, st);
     if (pro == PRO_NORM && epi == EPI_STORE) return launch_gemv_t<PRO_NORM, EPI_STORE>(wt, P, st);
+    if (pro == PRO_ATTN && epi == EPI_P2P) return launch_gemv_t<PRO_ATTN, EPI_P2P>(wt, P, st);
+    if (pro == PRO_PLAIN && epi == EPI_P2P) return launch_gemv_t<PRO_PLAIN, EPI_P2P>(wt, P, st);
     return hipErrorInvalidValue;
 }
 
@@ -434,13 +450,37 @@ void link_prefetch(nl_engine *e) {
 void build_plan(nl_engine *e) {
     e->plan.clear();
     const nl_config &c = e->cfg;
-    const bool tp = e->G > 1 || e->force_tp_plan;
+    const bool p2p = e->p2p.on;
+    const bool tp = (e->G > 1 || e->force_tp_plan) && !p2p;   // RCCL seams (or the in-process group's own sums)
     int cur = 0;
     int lm_blocks = 0, lm_spb = 1;
     const float *pending = nullptr;  // all-reduced partial still to be added to the residual stream
+    // push seams (nl_p2p.h): the partial leaves the producing GEMV as granules into every rank's receive slots,
+    // a small kernel adds the G slots into the residual stream.  Slots alternate by seam parity.
+    const size_t slot_bytes = (size_t)c.dim * sizeof(u64);
+    auto p2p_producer = [&](GemvParams &P, int seam) {
+        for (int r = 0; r < e->G; r++)
+            P.p2p_dst[r] = reinterpret_cast<u64 *>((char *)e->p2p.peer[r] + ((size_t)(seam & 1) * e->G + e->rank) * slot_bytes);
+        P.p2p_n = e->G; P.p2p_epoch = e->p2p.epoch; P.p2p_seam = (unsigned)(seam + 1);
+    };
+    auto p2p_reduce = [&](int seam, float *x) {
+        P2PReduceParams R{reinterpret_cast<const u64 *>((char *)e->p2p.area + (size_t)(seam & 1) * e->G * slot_bytes), c.dim,
+                          (unsigned)(seam + 1), e->p2p.epoch, x, e->p2p.status, e->p2p.timeout_ticks};
+        const int G = e->G, blocks = (c.dim + 255) / 256;
+        e->plan.push_back({K_ALLREDUCE, 0, nullptr, 0, [R, G, blocks](hipStream_t st) {
+                               switch (G) {
+                               case 2: hipLaunchKernelGGL(p2p_reduce_kernel<2>, dim3(blocks), dim3(256), 0, st, R); break;
+                               case 4: hipLaunchKernelGGL(p2p_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, R); break;
+                               case 8: hipLaunchKernelGGL(p2p_reduce_kernel<8>, dim3(blocks), dim3(256), 0, st, R); break;
+                               default: return hipErrorInvalidValue;
+                               }
+                               return hipGetLastError();
+                           }});
+    };
+    int seam = 0;
 
     {
-        EmbedParams P{e->embd_raw, e->embd_type, c.dim, e->ctl, e->x[0], e->gamma_row, e->gamma_val};
+        EmbedParams P{e->embd_raw, e->embd_type, c.dim, e->ctl, e->x[0], e->gamma_row, e->gamma_val, p2p ? e->p2p.epoch : nullptr};
         e->plan_embed = P;
         e->plan.push_back({K_EMBED, 0, nullptr, 0, [P](hipStream_t st) {
                                hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, P);
@@ -485,7 +525,11 @@ void build_plan(nl_engine *e) {
             P.part_o = e->part_o; P.part_ml = e->part_ml;
             P.bias_out = L.bo;
             int wt = L.wo.wtype;
-            if (!tp) {
+            if (p2p) {
+                p2p_producer(P, seam);
+                push_gemv(e, K_WO, 0, nullptr, 0, wt, PRO_ATTN, EPI_P2P, P);
+                p2p_reduce(seam++, e->x[cur]);
+            } else if (!tp) {
                 P.out = e->x[cur]; P.resid = e->x[cur];
                 push_gemv(e, K_WO, 0, nullptr, 0, wt, PRO_ATTN, EPI_RESID, P);
             } else {
@@ -507,7 +551,11 @@ void build_plan(nl_engine *e) {
             GemvParams P = base_params(e, L.down);
             P.x = e->hb;
             int wt = L.down.wtype;
-            if (!tp) {
+            if (p2p) {
+                p2p_producer(P, seam);
+                push_gemv(e, K_DOWN, 0, nullptr, 0, wt, PRO_PLAIN, EPI_P2P, P);
+                p2p_reduce(seam++, e->x[cur]);
+            } else if (!tp) {
                 P.out = e->x[cur]; P.resid = e->x[cur];
                 push_gemv(e, K_DOWN, 0, nullptr, 0, wt, PRO_PLAIN, EPI_RESID, P);
             } else {
@@ -523,12 +571,29 @@ void build_plan(nl_engine *e) {
         if (pending) { P.add = pending; P.x_out = e->x[cur ^ 1]; }
         P.out = e->logits + (size_t)e->rank * e->Vs;
         if (!tp) { P.amax_val = e->amax_val; P.amax_idx = e->amax_idx; }
+        if (p2p)   // the logits all-gather: this rank's slice also lands in every peer's gathered buffer
+            for (int r = 0; r < e->G; r++)
+                if (r != e->rank)
+                    P.peer_out[r] = reinterpret_cast<float *>((char *)e->p2p.peer[r] + e->p2p.off_logits) + (size_t)e->rank * e->Vs;
         int wt = e->lm_head.wtype;
         lm_blocks = (P.ntiles + P.tw - 1) / P.tw;
         lm_spb = (P.tw * TR + 63) / 64;
         push_gemv(e, K_LMHEAD, tp ? 2 : 0, e->logits, (size_t)e->Vs, wt, PRO_NORM, EPI_STORE, P);
     }
-    {
+    if (p2p) {
+        P2PArgmaxParams P{};
+        P.A = ArgmaxParams{e->logits, c.vocab, e->amax_val, e->amax_idx, lm_blocks * lm_spb, e->ctl, e->ids, e->result};
+        for (int r = 0; r < e->G; r++)
+            P.dst[r] = reinterpret_cast<u64 *>((char *)e->p2p.peer[r] + e->p2p.off_amax) + 2 * e->rank;
+        P.slots = reinterpret_cast<const u64 *>((char *)e->p2p.area + e->p2p.off_amax);
+        P.G = e->G; P.row0 = e->rank * e->Vs; P.seam = 255u;
+        P.epoch = e->p2p.epoch; P.status = e->p2p.status; P.timeout_ticks = e->p2p.timeout_ticks;
+        e->plan_p2p_argmax = P;
+        e->plan.push_back({K_ARGMAX, 0, nullptr, 0, [P](hipStream_t st) {
+                               hipLaunchKernelGGL(p2p_argmax_kernel, dim3(1), dim3(1024), 0, st, P);
+                               return hipGetLastError();
+                           }});
+    } else {
         ArgmaxParams P{e->logits, c.vocab, tp ? nullptr : e->amax_val, e->amax_idx, lm_blocks * lm_spb, e->ctl, e->ids,
                        e->result};
         e->plan_argmax = P;
@@ -572,7 +637,7 @@ int capture_graph(nl_engine *e) {
     // chained greedy decode replays a graph that holds the plan 16 times: the gap between two graph launches
     // (~8 us on this stack) is then paid once per 16 tokens (nano 3834 -> 3945 tok/s; 4 steps: 3905; 32 / 64: as 16)
     static const int steps = getenv("NL_GRAPH_STEPS") ? atoi(getenv("NL_GRAPH_STEPS")) : 16;   // developer knob (tools/)
-    if (steps > 1 && e->G == 1 && !e->force_tp_plan) {
+    if (steps > 1 && ((e->G == 1 && !e->force_tp_plan) || e->p2p.on)) {
         HIPCK(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
         int rc2 = NL_OK;
         // step k's argmax also embeds step k+1's token (argmax_embed_kernel): the embed launch exists in step 0 only
@@ -581,7 +646,12 @@ int capture_graph(nl_engine *e) {
             for (const Op &op : e->plan) {
                 if (fuse_embed && op.kind == K_EMBED && k > 0) continue;
                 hipError_t ls;
-                if (fuse_embed && op.kind == K_ARGMAX) {
+                if (fuse_embed && op.kind == K_ARGMAX && e->p2p.on) {
+                    P2PArgmaxParams PA = e->plan_p2p_argmax;
+                    PA.E = e->plan_embed;     // the winner's embedding row opens the next step (and advances the counter)
+                    hipLaunchKernelGGL(p2p_argmax_kernel, dim3(1), dim3(1024), 0, e->stream, PA);
+                    ls = hipGetLastError();
+                } else if (fuse_embed && op.kind == K_ARGMAX) {
                     hipLaunchKernelGGL(argmax_embed_kernel, dim3(1), dim3(1024), 0, e->stream, e->plan_argmax, e->plan_embed);
                     ls = hipGetLastError();
                 } else ls = op.fn(e->stream);
@@ -634,6 +704,15 @@ int note_positions(nl_engine *e, int stream, int pos, int n, hipStream_t st = nu
         HIPCK(e, hipMemset2DAsync(e->vcache + off, pitch, 0, width, height, st));
     }
     mark = std::max(mark, std::min(pos + n, e->cfg.seq_len));
+    return NL_OK;
+}
+
+// after a synchronize: did any poll of the push all-reduce give up?
+int p2p_check(nl_engine *e) {
+    if (!e->p2p.on) return NL_OK;
+    unsigned st = 0;
+    HIPCK(e, hipMemcpy(&st, e->p2p.status, sizeof st, hipMemcpyDeviceToHost));
+    if (st) return e->fail(NL_ERR_COMM, "push all-reduce timed out waiting for a peer (status %u): a rank is missing or stalled", st);
     return NL_OK;
 }
 
@@ -976,6 +1055,14 @@ extern "C" {
 
 int nl_abi_version(void) { return 1; }
 
+#ifndef NL_SRC_SHA
+#define NL_SRC_SHA "unknown"
+#endif
+#ifndef NL_GIT_HEAD
+#define NL_GIT_HEAD "unknown"
+#endif
+const char *nl_build_info(void) { return "src=" NL_SRC_SHA " git=" NL_GIT_HEAD; }
+
 int nl_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1234,7 +1321,8 @@ int nl_finalize(nl_handle e) {
     HIPCK(e, dalloc(&e->part_ml, (size_t)e->Hs * e->nsplit_max * 2, &e->bytes_state));
     HIPCK(e, dalloc(&e->hb, (size_t)e->Is, &e->bytes_state));
     HIPCK(e, dalloc(&e->ar, (size_t)c.dim, &e->bytes_state));
-    HIPCK(e, dalloc(&e->logits, (size_t)c.vocab, &e->bytes_state));
+    if (e->p2p.on) e->logits = reinterpret_cast<float *>((char *)e->p2p.area + e->p2p.off_logits);   // gathered by the peers' LM heads
+    else HIPCK(e, dalloc(&e->logits, (size_t)c.vocab, &e->bytes_state));
     e->kv_layer_stride = (long long)e->KVs * c.seq_len * e->hd;
     e->kv_stream_stride = e->kv_layer_stride * c.n_layers;
     const size_t kvn = (size_t)e->kv_stream_stride * c.max_streams;
@@ -1255,12 +1343,12 @@ int nl_finalize(nl_handle e) {
     e->ctl_ring_cap = std::max(c.seq_len, c.max_streams);
     HIPCK(e, hipHostMalloc((void **)&e->h_ctl_ring, (size_t)e->ctl_ring_cap * CTL_WORDS * sizeof(int), hipHostMallocDefault));
     HIPCK(e, hipMemcpy(e->ctl, e->h_ctl, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice));
-    if (e->G > 1 && !e->comm && !(c.flags & NL_FLAG_LOCAL_GROUP))
-        return e->fail(NL_ERR_STATE, "tp_size %d needs nl_comm_init before nl_finalize", e->G);
+    if (e->G > 1 && !e->comm && !e->p2p.on && !(c.flags & NL_FLAG_LOCAL_GROUP))
+        return e->fail(NL_ERR_STATE, "tp_size %d needs nl_comm_init or nl_p2p_import before nl_finalize", e->G);
     if (e->stage) { hipFree(e->stage); e->stage = nullptr; e->stage_cap = 0; }
     build_plan(e);
     HIPCK(e, hipStreamSynchronize(e->stream));
-    const bool has_coll = e->G > 1 || e->force_tp_plan;
+    const bool has_coll = (e->G > 1 || e->force_tp_plan) && !e->p2p.on;
     if (has_coll && !e->comm && !(c.flags & NL_FLAG_LOCAL_GROUP))
         return e->fail(NL_ERR_STATE, "collective plan needs nl_comm_init before nl_finalize");
     if (e->use_graph && !(c.flags & NL_FLAG_LOCAL_GROUP)) {
@@ -1361,6 +1449,13 @@ int nl_destroy(nl_handle e) {
         for (void *p : bb) if (p) hipFree(p);
         if (b.h_meta) hipHostFree(b.h_meta);
     }
+    if (e->p2p.area) {
+        e->logits = nullptr;   // lives inside the receive area
+        for (int r = 0; r < 8; r++)
+            if (e->p2p.opened[r]) (void)hipIpcCloseMemHandle(e->p2p.peer[r]);
+        (void)hipFree(e->p2p.area);
+        if (e->p2p.epoch) (void)hipFree(e->p2p.epoch);
+    }
     void *bufs[] = {e->embd_raw, e->output_norm, e->rope_cos, e->rope_sin, e->x[0], e->x[1], e->qbuf, e->part_o,
                     e->part_ml, e->hb, e->ar, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result, e->amax_val,
                     e->amax_idx};
@@ -1396,6 +1491,7 @@ int nl_forward(nl_handle e, int stream, int token, int pos, float *logits_out) {
     if (logits_out)
         HIPCK(e, hipMemcpyAsync(logits_out, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCK(e, hipStreamSynchronize(e->stream));
+    if (int prc = p2p_check(e)) return prc;
     return NL_OK;
 }
 
@@ -1409,6 +1505,7 @@ int nl_forward_argmax(nl_handle e, int stream, int token, int pos, int *next_id)
     if ((rc = launch_step(e))) return rc;
     HIPCK(e, hipMemcpyAsync(next_id, e->result, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCK(e, hipStreamSynchronize(e->stream));
+    if (int prc = p2p_check(e)) return prc;
     return NL_OK;
 }
 
@@ -1428,6 +1525,7 @@ int nl_decode_greedy(nl_handle e, int stream, int token, int pos, int n_steps, i
         if ((rc = launch_step(e))) return rc;
     if (n > 0) HIPCK(e, hipMemcpyAsync(ids_out, e->ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCK(e, hipStreamSynchronize(e->stream));
+    if (int prc = p2p_check(e)) return prc;
     if (n_done) *n_done = n;
     return NL_OK;
 }
@@ -1563,6 +1661,7 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
     HIPCK(e, hipMemcpyAsync(ids_out, e->ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCK(e, hipMemcpyAsync(n_recent, s.recent_n, 4, hipMemcpyDeviceToHost, e->stream));
     HIPCK(e, hipStreamSynchronize(e->stream));
+    if (int prc = p2p_check(e)) return prc;
     if (*n_recent > 0) HIPCK(e, hipMemcpy(recent, s.recent, (size_t)*n_recent * 4, hipMemcpyDeviceToHost));
     return NL_OK;
 }
@@ -1643,6 +1742,7 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
     if (last_logits_out)
         HIPCK(e, hipMemcpyAsync(last_logits_out, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCK(e, hipStreamSynchronize(e->stream));
+    if (int prc = p2p_check(e)) return prc;
     return NL_OK;
 }
 
@@ -1698,6 +1798,7 @@ int nl_synchronize(nl_handle e) {
     if (!e) return NL_ERR_INVALID;
     HIPCK(e, hipSetDevice(e->dev));
     HIPCK(e, hipStreamSynchronize(e->stream));
+    if (int prc = p2p_check(e)) return prc;
     return NL_OK;
 }
 
@@ -2005,6 +2106,76 @@ int nl_comm_init(nl_handle e, const void *id) {
     memcpy(&nid, id, NL_COMM_ID_BYTES);
     int rc = g_rccl.CommInitRank(&e->comm, e->G, nid, e->rank);
     if (rc != 0) return e->fail(NL_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return NL_OK;
+}
+
+// ---- push all-reduce between the ranks of one node (nl_p2p.h) ------------------
+
+int nl_p2p_export(nl_handle e, void *handle_out) {
+    if (!e || !handle_out) return NL_ERR_INVALID;
+    if (e->finalized) return e->fail(NL_ERR_STATE, "nl_p2p_export after nl_finalize");
+    if (e->G < 2) return e->fail(NL_ERR_INVALID, "nl_p2p_export needs tp_size >= 2");
+    if (e->G != 2 && e->G != 4 && e->G != 8) return e->fail(NL_ERR_UNSUPPORTED, "push all-reduce supports 2, 4 or 8 ranks");
+    if (e->cfg.n_layers > 127) return e->fail(NL_ERR_UNSUPPORTED, "push all-reduce tags cover at most 127 layers");
+    if (e->cfg.flags & NL_FLAG_LOCAL_GROUP) return e->fail(NL_ERR_INVALID, "local groups sum in-process; no export");
+    HIPCK(e, hipSetDevice(e->dev));
+    nl_engine::P2P &p = e->p2p;
+    if (!p.area) {
+        const size_t ar = (size_t)2 * e->G * e->cfg.dim * sizeof(u64);
+        p.off_amax = (ar + 255) & ~(size_t)255;
+        p.off_logits = (p.off_amax + (size_t)e->G * 2 * sizeof(u64) + 255) & ~(size_t)255;
+        p.bytes = p.off_logits + (size_t)e->cfg.vocab * 4;
+        // written by the peers while this device reads it: uncached, so no L2 line of this device can shadow a push
+        hipError_t s = getenv("NL_P2P_CACHED") ? hipErrorNotSupported : hipExtMallocWithFlags(&p.area, p.bytes, hipDeviceMallocUncached);
+        p.uncached = s == hipSuccess;
+        if (s != hipSuccess) { (void)hipGetLastError(); HIPCK(e, hipMalloc(&p.area, p.bytes)); }
+        HIPCK(e, hipMemset(p.area, 0, p.bytes));
+        HIPCK(e, hipMalloc((void **)&p.epoch, 2 * sizeof(unsigned)));
+        HIPCK(e, hipMemset(p.epoch, 0, 2 * sizeof(unsigned)));
+        p.status = p.epoch + 1;
+        const char *tm = getenv("NL_P2P_TIMEOUT_MS");
+        p.timeout_ticks = (long long)(tm ? atoi(tm) : 10000) * 100000;   // wall_clock64: 100 MHz
+        e->bytes_state += p.bytes;
+    }
+    hipIpcMemHandle_t h;
+    hipError_t s = hipIpcGetMemHandle(&h, p.area);
+    if (s != hipSuccess && p.uncached) {
+        // this runtime cannot export an uncached allocation: fall back to a plain one
+        (void)hipGetLastError();
+        (void)hipFree(p.area);
+        p.area = nullptr; p.uncached = false;
+        HIPCK(e, hipMalloc(&p.area, p.bytes));
+        HIPCK(e, hipMemset(p.area, 0, p.bytes));
+        s = hipIpcGetMemHandle(&h, p.area);
+    }
+    if (s != hipSuccess) return e->fail(NL_ERR_COMM, "hipIpcGetMemHandle: %s", hipGetErrorString(s));
+    static_assert(sizeof(hipIpcMemHandle_t) == NL_P2P_HANDLE_BYTES, "handle size");
+    memcpy(handle_out, &h, NL_P2P_HANDLE_BYTES);
+    return NL_OK;
+}
+
+int nl_p2p_import(nl_handle e, const void *handles) {
+    if (!e || !handles) return NL_ERR_INVALID;
+    if (e->finalized) return e->fail(NL_ERR_STATE, "nl_p2p_import after nl_finalize");
+    nl_engine::P2P &p = e->p2p;
+    if (!p.area) return e->fail(NL_ERR_STATE, "nl_p2p_import before nl_p2p_export");
+    HIPCK(e, hipSetDevice(e->dev));
+    for (int r = 0; r < e->G; r++) {
+        if (r == e->rank) { p.peer[r] = p.area; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *)handles + (size_t)r * NL_P2P_HANDLE_BYTES, NL_P2P_HANDLE_BYTES);
+        hipError_t s = hipIpcOpenMemHandle(&p.peer[r], h, hipIpcMemLazyEnablePeerAccess);
+        if (s != hipSuccess) return e->fail(NL_ERR_COMM, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(s));
+        p.opened[r] = true;
+    }
+    p.on = true;
+    return NL_OK;
+}
+
+int nl_p2p_info(nl_handle e, int *enabled, int *uncached) {
+    if (!e) return NL_ERR_INVALID;
+    if (enabled) *enabled = e->p2p.on ? 1 : 0;
+    if (uncached) *uncached = e->p2p.uncached ? 1 : 0;
     return NL_OK;
 }
 

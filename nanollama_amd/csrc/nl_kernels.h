@@ -36,7 +36,7 @@ constexpr int CTL_TOKEN = 0, CTL_POS = 1, CTL_CHAIN = 2, CTL_STEP = 3, CTL_STREA
 // Q4_K keeps its nibbles with an 8-byte {d, dmin, sc0, m0, sc1, m1} entry per 64 columns.
 enum { WT_F32 = 0, WT_F16 = 1, WT_Q4_0 = 2, WT_Q5_0 = 6, WT_Q8_0 = 8, WT_Q4_K = 12, WT_Q6_K = 14 };
 enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_ATTN = 2 };
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3, EPI_P2P = 4 };
 enum { ROWMAP_IDENT = 0, ROWMAP_HEADPERM = 1 };
 
 template <int WT> struct WTraits;
@@ -425,6 +425,14 @@ struct GemvParams {
     // EPI_RESID / EPI_STORE add bias_out[row]
     const float *bias_q, *bias_k, *bias_v, *bias_out;
     long long *dbg;  // optional phase timestamps (clock64) written by workgroup 0, lane 0 of each wave
+    // tensor-parallel push (nl_p2p.h).  EPI_P2P: out[row] leaves as a tagged granule into the receive slot of every
+    // rank (p2p_dst[r] = rank r's slot for THIS rank's partial).  EPI_STORE with peer_out: the logits slice is also
+    // written into every peer's gathered logits buffer.
+    unsigned long long *p2p_dst[8];
+    const unsigned *p2p_epoch;
+    int p2p_n;
+    unsigned p2p_seam;
+    float *peer_out[8];
 };
 
 // ---- cross-lane helpers on DPP (hipcc lowers __shfl_xor to ds_bpermute: ~100+ cycles a hop) ----
@@ -577,6 +585,8 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
             e_sin = P.rope_sin[e_pos * half + i];
         }
     }
+    unsigned e_tag = 0;
+    if (EPI == EPI_P2P) e_tag = (*P.p2p_epoch << 8) | P.p2p_seam;
     int ns = 1;
     if (PRO == PRO_ATTN) ns = P.ctl[CTL_POS] / ATT_CH + 1;
 
@@ -708,10 +718,24 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
         return;
     }
     const int row = otile * TR + rr;
-    if (P.bias_out && act && row < P.rows && (EPI == EPI_STORE || EPI == EPI_RESID)) v += P.bias_out[row];
+    if (P.bias_out && act && row < P.rows && (EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_P2P)) v += P.bias_out[row];
+    if (EPI == EPI_P2P) {
+        // one 8-byte {tag, value} granule per rank, system scope: the value is its own arrival flag
+        if (!act || row >= P.rows) return;
+        const unsigned long long gran = ((unsigned long long)e_tag << 32) | __float_as_uint(v);
+#pragma unroll
+        for (int pr = 0; pr < 8; pr++)
+            if (pr < P.p2p_n) __hip_atomic_store(P.p2p_dst[pr] + row, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if (EPI == EPI_STORE) {
         const bool ok = act && row < P.rows;
-        if (ok) P.out[row] = v;
+        if (ok) {
+            P.out[row] = v;
+#pragma unroll
+            for (int pr = 0; pr < 8; pr++)
+                if (P.peer_out[pr]) P.peer_out[pr][row] = v;
+        }
         if (P.amax_val) {
             // fused partial argmax over this wave's rows (go/main.go:400-408: strict '>' => lowest index
             // wins ties); one slot per wave that holds rows, reduced by argmax_kernel
@@ -753,6 +777,7 @@ struct EmbedParams {
     // gamma injection (go/gamma.go:272-290, go/model.go:503-505): embed[token] += gamma[token] for listed tokens
     const int *gamma_row;     // [vocab] row in gamma_val or -1; nullptr = no gamma
     const float *gamma_val;   // [n][dim]
+    unsigned *epoch;          // tensor-parallel push (nl_p2p.h): forward counter, advanced here once per Forward
 };
 
 // element i of row `token` of a raw GGUF tensor, dequantised (embedLookupInto go/model.go:389-446 and the
@@ -803,6 +828,7 @@ __device__ __forceinline__ float embed_value(const uint8_t *table, int wtype, in
 }
 
 __global__ void embed_kernel(EmbedParams P) {
+    if (P.epoch && threadIdx.x == 0) *P.epoch = *P.epoch + 1;
     const int token = P.ctl[CTL_TOKEN];
     const int gr = P.gamma_row ? P.gamma_row[token] : -1;
     // four elements per lane and round, their byte loads issued together (clamped index, masked store): one memory

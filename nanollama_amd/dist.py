@@ -1,7 +1,7 @@
 """Host-side rendezvous for one-process-per-GPU runs (bench.py under torch.distributed.run).
 
-Only three things cross ranks on the host: the 128-byte RCCL unique id (rank 0 -> all), a barrier around
-the timed region, and the max over ranks of the measured time.  They travel over a plain TCP star rooted at
+Only small things cross ranks on the host: the 64-byte hipIpc handles of the push all-reduce (all-gather) or the
+128-byte RCCL unique id (rank 0 -> all), a barrier around the timed region, and the max over ranks of the measured time.  They travel over a plain TCP star rooted at
 rank 0 (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the launcher's environment).  torch is NOT
 imported here on purpose: the PyTorch wheel bundles its own ROCm 7.0 HIP runtime, and a process that loads
 it next to /opt/rocm's runtime (which libnanollama_hip.so links) ends up with two HIP runtimes and
@@ -58,6 +58,15 @@ class Rendezvous:
                 self._serve(addr, base, timeout_s)
             else:
                 self._connect(addr, base, timeout_s)
+
+    @classmethod
+    def solo(cls) -> "Rendezvous":
+        """A world of one on this rank's own GPU (a side measurement of a single rank of a larger run)."""
+        r = cls.__new__(cls)
+        r.rank, r.world = 0, 1
+        r.local_rank = 0 if os.environ.get("NL_BENCH_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
+        r._peers, r._root, r._listener = [], None, None
+        return r
 
     # ---- wiring ----
     def _serve(self, addr: str, base: int, timeout_s: float) -> None:
@@ -133,6 +142,24 @@ class Rendezvous:
                 _send(p, data)
             return data
         return _recv(self._root)
+
+    def allgather_bytes(self, mine: bytes) -> List[bytes]:
+        """Every rank contributes a byte string; every rank returns the rank-ordered list."""
+        if self.world == 1:
+            return [mine]
+        if self.rank == 0:
+            parts = [mine] + [_recv(p) for p in self._peers]
+            blob = b"".join(struct.pack("<I", len(x)) + x for x in parts)
+            for p in self._peers:
+                _send(p, blob)
+            return parts
+        _send(self._root, mine)
+        blob, parts, off = _recv(self._root), [], 0
+        while off < len(blob):
+            n = struct.unpack_from("<I", blob, off)[0]
+            parts.append(blob[off + 4:off + 4 + n])
+            off += 4 + n
+        return parts
 
     def _gather_floats(self, value: float) -> List[float]:
         vals = [value]

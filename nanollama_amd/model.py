@@ -155,6 +155,12 @@ class LlamaModel:
         _lib.check(self._h, _lib.lib().nl_memory_usage(self._h, C.byref(w), C.byref(kv), C.byref(st)))
         return {"weights": w.value, "kv_cache": kv.value, "state": st.value}
 
+    def p2p_info(self):
+        """Tensor-parallel transport of this handle: push all-reduce set up? receive area uncached?"""
+        on, unc = C.c_int(0), C.c_int(0)
+        _lib.check(self._h, _lib.lib().nl_p2p_info(self._h, C.byref(on), C.byref(unc)))
+        return {"push_allreduce": bool(on.value), "uncached_receive_area": bool(unc.value)}
+
     def debug_read(self, which: str, n: int, stream: int = 0) -> np.ndarray:
         out = np.zeros(n, dtype=np.float32)
         got = _lib.lib().nl_debug_read(self._h, which.encode(), stream, out.ctypes.data_as(C.POINTER(C.c_float)), n)
@@ -175,9 +181,14 @@ class LlamaModel:
 
 
 def load_llama_model(gguf: GGUFFile, device: int = 0, max_streams: int = 1, tp_rank: int = 0, tp_size: int = 1,
-                     comm_id: Optional[bytes] = None, flags: int = 0, verbose: bool = False) -> LlamaModel:
+                     comm_id: Optional[bytes] = None, flags: int = 0, verbose: bool = False,
+                     p2p_allgather=None) -> LlamaModel:
     """LoadLlamaModel go/model.go:121-174: config from GGUF metadata, every
-    tensor handed to the device library, state allocated there."""
+    tensor handed to the device library, state allocated there.
+
+    Tensor-parallel runs (one process per GPU, tp_size 2/4/8): `p2p_allgather(bytes) -> [bytes per rank]` (e.g.
+    Rendezvous.allgather_bytes) selects the push all-reduce over xGMI -- it carries the hipIpc handles of the ranks'
+    receive areas; `comm_id` selects RCCL instead."""
     L = _lib.lib()
     m = gguf.meta
     head_dim = m.head_dim
@@ -196,7 +207,14 @@ def load_llama_model(gguf: GGUFFile, device: int = 0, max_streams: int = 1, tp_r
     if rc != 0:
         raise _lib.NlError(rc, (L.nl_last_error(None) or b"").decode())
     try:
-        if (tp_size > 1 or comm_id is not None) and not (flags & _lib.NL_FLAG_LOCAL_GROUP):
+        if tp_size > 1 and p2p_allgather is not None and not (flags & _lib.NL_FLAG_LOCAL_GROUP):
+            mine = C.create_string_buffer(_lib.NL_P2P_HANDLE_BYTES)
+            _lib.check(h, L.nl_p2p_export(h, mine))
+            handles = p2p_allgather(mine.raw)
+            if len(handles) != tp_size or any(len(x) != _lib.NL_P2P_HANDLE_BYTES for x in handles):
+                raise ValueError("p2p_allgather must return one handle per rank, in rank order")
+            _lib.check(h, L.nl_p2p_import(h, C.c_char_p(b"".join(handles))))
+        elif (tp_size > 1 or comm_id is not None) and not (flags & _lib.NL_FLAG_LOCAL_GROUP):
             if comm_id is None or len(comm_id) != _lib.NL_COMM_ID_BYTES:
                 raise ValueError("tp_size > 1 needs the communicator id from nl_comm_get_unique_id")
             _lib.check(h, L.nl_comm_init(h, C.c_char_p(comm_id)))

@@ -1,0 +1,131 @@
+"""GPU tests of the push all-reduce (nl_p2p_*, nanollama_amd/csrc/nl_p2p.h): 2 and 4 rank PROCESSES sharing
+the box's one GPU, against the in-process shard group (bitwise: same shards, same summation order) and the
+CPU oracle (stated tolerance).  The cross-device wire itself (xGMI) cannot be exercised on a 1-GPU box."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from nanollama_amd import gguf, synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+LOGIT_TOL = 1e-4
+
+
+def run_ranks(n, path, out, n_tok, n_greedy, extra_env=None, timeout=150):
+    port = 29000 + (os.getpid() * 11 + n * 37) % 2000
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), NL_BENCH_ONE_DEVICE="1", NL_P2P_TIMEOUT_MS="5000", **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), path, out, str(n_tok),
+                                       str(n_greedy)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail(f"rank processes did not finish within {timeout}s")
+        outs.append((p.returncode, so, se))
+    for rc, so, se in outs:
+        assert rc == 0, se[-3000:]
+    return outs
+
+
+@pytest.mark.parametrize("n", [2, 4])
+@pytest.mark.parametrize("tag", ["tiny_q8_0", "tiny_mha_q4_0"])
+def test_push_allreduce_ranks_match_the_in_process_group(tmp_path, tag, n):
+    from nanollama_amd import model
+    from oracle import oracle
+    path = os.path.join(GOLDEN, f"{tag}.gguf")
+    g = gguf.load_gguf(path)
+    if g.meta.num_kv_heads % n:
+        pytest.skip("kv heads do not divide")
+    out = str(tmp_path / "r0.npz")
+    run_ranks(n, path, out, n_tok=12, n_greedy=40)
+    got = np.load(out)
+    toks = [int(t) for t in got["toks"]]
+    grp = model.LocalTPGroup(g, n)
+    ref = oracle.OracleModel(g)
+    for pos, t in enumerate(toks):
+        lg = grp.forward(t, pos)
+        assert lg.tobytes() == got["logits"][pos].tobytes(), f"pos {pos}: ranks != in-process group"
+        want = ref.forward(t, pos)
+        assert np.abs(got["logits"][pos] - want).max() <= LOGIT_TOL * max(1.0, float(want.std()))
+    # greedy continuation through the 16-step graphs: ids of the oracle, and a replay repeats them
+    tok, want_ids = int(np.argmax(got["logits"][-1])), []
+    for k in range(len(got["ids"])):
+        tok = int(oracle.argmax(ref.forward(tok, len(toks) + k)))
+        want_ids.append(tok)
+    assert [int(i) for i in got["ids"]] == want_ids
+    assert got["ids"].tobytes() == got["again"].tobytes()
+    ref.reset()
+    for pos, t in enumerate(toks[:5]):
+        want = ref.forward(t, pos)
+    assert np.abs(got["pre"] - want).max() <= LOGIT_TOL * max(1.0, float(want.std()))
+    grp.close(); ref.close()
+
+
+@pytest.mark.parametrize("n,dim,heads,kv,interm", [(4, 1024, 16, 4, 2048), (8, 512, 8, 8, 1024)])
+def test_push_allreduce_with_4_and_8_ranks(tmp_path, n, dim, heads, kv, interm):
+    # 4 ranks at D = 1024 (a slot spans 8 KiB, four reduce workgroups) and 8 ranks (the node size the 7.9B tier
+    # shards over), 3 layers, Q4_0
+    shape = synth.ModelShape("p2p_probe", 3, dim, heads, kv, 4096, seq_len=64, interm=interm)
+    p = str(tmp_path / "m.gguf")
+    synth.generate_gguf(p, shape, "q4_0", 51, mode="qrand")
+    from nanollama_amd import model
+    out = str(tmp_path / "r0.npz")
+    run_ranks(n, p, out, n_tok=6, n_greedy=20, timeout=240)
+    got = np.load(out)
+    g = gguf.load_gguf(p)
+    grp = model.LocalTPGroup(g, n)
+    for pos, t in enumerate(int(t) for t in got["toks"]):
+        assert grp.forward(t, pos).tobytes() == got["logits"][pos].tobytes()
+    assert got["ids"].tobytes() == got["again"].tobytes()
+    grp.close()
+
+
+def test_a_missing_rank_times_out_with_an_error(tmp_path):
+    # rank 1 of 2 never runs its forward: rank 0's poll gives up after NL_P2P_TIMEOUT_MS and the call returns
+    # NL_ERR_COMM instead of hanging the GPU
+    script = tmp_path / "w.py"
+    script.write_text(f"""
+import os, sys, time
+sys.path.insert(0, {ROOT!r})
+from nanollama_amd import gguf, model, _lib
+from nanollama_amd.dist import Rendezvous
+rdv = Rendezvous(timeout_s=60.0)
+g = gguf.load_gguf({os.path.join(GOLDEN, 'tiny_q8_0.gguf')!r})
+dev = model.load_llama_model(g, device=0, tp_rank=rdv.rank, tp_size=2, p2p_allgather=rdv.allgather_bytes)
+rdv.barrier()
+if rdv.rank == 0:
+    try:
+        dev.forward(1, 0)
+        print("NO ERROR")
+    except _lib.NlError as exc:
+        print("GOT", exc)
+rdv.barrier()
+dev.close(); rdv.close()
+""")
+    port = 29000 + (os.getpid() * 13 + 5) % 2000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   NL_P2P_TIMEOUT_MS="1500")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    for p in procs:
+        try:
+            res.append(p.communicate(timeout=120))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("timeout path hung")
+    assert "GOT NL_ERR_COMM" in res[0][0], res[0][0] + res[0][1][-1500:]

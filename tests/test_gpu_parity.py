@@ -318,6 +318,41 @@ def test_full_size_tiers_match_oracle(hip, orc, tmp_path, tier, wtype, ntok):
     assert worst <= LOGIT_TOL * scale
 
 
+def test_big_full_shape_matches_oracle(hip, orc, tmp_path):
+    # BASELINE.json configs[4] at its own shape (nanollama/llama.py:50: 40 layers, D 4096, 64 heads / 16 kv heads,
+    # FFN 11008, vocabulary 96000 -- 7.9B parameters, Q4_0): two teacher-forced tokens against the CPU oracle, on one
+    # GPU and as two tensor-parallel shards (the slicing and the partial sums of the 8-GPU plan, stepped in-process).
+    shape = synth.TIERS["big"]
+    p = os.path.join(os.environ.get("NL_BENCH_DIR", "/tmp"), "nl_bench_big_q4_0_qrand.gguf")   # bench.py's file when present
+    if not os.path.exists(p):
+        synth.generate_gguf(p + ".tmp", shape, "q4_0", mode="qrand")
+        os.replace(p + ".tmp", p)
+    g = gguf.load_gguf(p)
+    assert (g.meta.num_layers, g.meta.embed_dim, g.meta.num_heads, g.meta.num_kv_heads, g.meta.interm_size,
+            g.meta.vocab_size) == (40, 4096, 64, 16, 11008, 96000)
+    toks = synth.prompt_ids(2, shape.vocab, seed=5)
+    ref = orc.OracleModel(g)
+    orc.set_threads(min(32, os.cpu_count() or 1))
+    wants = [ref.forward(t, pos).copy() for pos, t in enumerate(toks)]
+    orc.set_threads(1)
+    ref.close()
+    dev = hip.load_llama_model(g)
+    for pos, t in enumerate(toks):
+        dev.forward(t, pos)
+        d, scale = float(np.abs(dev.state.logits - wants[pos]).max()), max(1.0, float(wants[pos].std()))
+        print(f"\nbig/q4_0 pos {pos}: max|gpu-oracle|={d:.2e} (logit std {scale:.2f})")
+        assert d <= LOGIT_TOL * scale
+        assert int(np.argmax(dev.state.logits)) == int(orc.argmax(wants[pos]))
+    dev.close()
+    grp = hip.LocalTPGroup(g, 2)
+    for pos, t in enumerate(toks):
+        lg = grp.forward(t, pos)
+        d = float(np.abs(lg - wants[pos]).max())
+        print(f"big/q4_0 tp2 pos {pos}: max|tp-oracle|={d:.2e}")
+        assert d <= LOGIT_TOL * max(1.0, float(wants[pos].std()))
+    grp.close()
+
+
 def test_nano_full_size_long_greedy_run_matches_oracle(hip, orc, tmp_path):
     # BASELINE.json configs[1] at its own shape and length and beyond: nano Q8_0, 8-token prompt, 320 greedy tokens
     # (positions cross two 128-position attention split boundaries).  The oracle generates; the device is fed the

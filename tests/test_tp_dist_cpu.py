@@ -73,6 +73,8 @@ def test_world_size_2_rendezvous(tmp_path):
         r.barrier()
         m = r.max_over_ranks(10.0 + r.rank)
         assert m == 11.0, m
+        parts = r.allgather_bytes(bytes([r.rank]) * (64 + r.rank))     # the hipIpc handle exchange of the push all-reduce
+        assert parts == [bytes([0]) * 64, bytes([1]) * 65], parts
         assert "torch" not in sys.modules, "the rendezvous must not import torch"
         r.close()
         print("rank", r.rank, "ok")
