@@ -1,0 +1,320 @@
+// nl_block.h -- the attention half of a decoder layer as ONE launch, for small models.
+//
+// go/model.go:517-594 is five dependent steps per token and layer: RMSNorm, Q/K/V projections, RoPE + KV store,
+// GQA attention over the cache, WO + residual.  Only the first and the last are all-to-all over the model width;
+// everything between is local to a head.  For the small tiers a decode launch costs ~3.8 us whatever it moves
+// (1.5 us boundary + one cold memory round trip + reductions), so three launches for this half is ~12 us per layer.
+//
+// Here a CLUSTER of four workgroups per query head does the whole chain in one launch:
+//     RMSNorm(x) -> each member projects one 16-row tile of q, of k and of v (the k / v rows of a GQA group are
+//     recomputed by every head of the group: the work is latency, not bytes) -> bias, RoPE -> the members exchange
+//     their 3 x 16 values through 8-byte {tag, value} granules (the only cross-workgroup step: 192 values per head,
+//     cdna_hip_programming.md G16 form R2; cluster members are the blocks b, b+8, b+16, b+24, which the dispatcher
+//     places on one XCD) -> QK-norm -> KV store (first head of the group) -> every member runs the head's softmax
+//     attention over the cache (the cache rows come from L2) -> each member multiplies ITS quarter of the head's
+//     64-column WO slice, a partial [D/4] vector.
+// The H partial vectors are added to the residual stream by the consuming gate/up GEMV (PRO_NORM_PARTS, fixed head
+// order).  All weight, x and cache loads are issued at entry, so the launch pays one memory latency; the WO rows
+// stream in while the attention runs.  A first version with ONE workgroup per head measured 10.6 us per launch on
+// nano -- a head's 156 KB of weights through a single compute unit -- against 12.1 us for the three launches it
+// replaces; spreading the head over four compute units is what makes the fusion pay.
+// The engine selects this path only where a head's weights are small (nano, mini) and only at short contexts
+// (every cache position of the head passes through each member).
+#pragma once
+#include "nl_kernels.h"
+
+namespace nl {
+
+constexpr int BLK_THREADS = 768;     // 12 wavefronts: {q, k, v tile of this member} x 4 groups of 256 columns
+constexpr int BLK_KV_THREADS = 512;  // threads that hold cache rows (32 row groups x 16 float4)
+constexpr int BLK_MEMBERS = 4;       // workgroups per head = 16-row tiles per 64-element head
+constexpr int BLK_MAXG = 4;          // 256-column groups per row: D <= 1024
+constexpr int BLK_MAX_PARTS = 12;    // heads whose partials the consumer adds (PRO_NORM_PARTS)
+
+struct BlockParams {
+    const uint8_t *qkv_q;        // packed Q|K|V of the layer (ROWMAP_HEADPERM tiles)
+    const uint32_t *qkv_s;
+    const uint8_t *wo_q;         // per-head WO slices: [H][D/16 tiles][1 pair]
+    const uint32_t *wo_s;
+    int D, npairs, n_q_heads, n_kv_heads, seq_len, rope_conj, qk_norm, single_stream;
+    const float *x, *normw;
+    float eps, scale;
+    const float *rope_cos, *rope_sin;
+    float *kcache, *vcache;      // this layer, stream 0: [kv][seq][64]
+    long long kv_stream_stride;
+    const int *ctl;
+    const float *bias_q, *bias_k, *bias_v, *bias_out;
+    float *parts;                // [H][D]: head h's share of WO * attention output (+ bias_out in head 0)
+    unsigned long long *xchg;    // [H][192] granules: the head's q | k | v of this position
+    const unsigned *tick;        // forward counter (advanced by the embedding launch): tag = tick << 8 | layer + 1
+    unsigned layer_tag;
+    unsigned *status;            // set non-zero if an exchange poll gave up (never expected: members are co-resident)
+    unsigned *host_status;       // the same flag in host-visible memory (read by the host without a copy)
+    long long *dbg;              // optional phase stamps (wall_clock64, 100 MHz... s_memtime shader clock) of block 0
+};
+
+__host__ __device__ constexpr int blk_xs_floats(int D) { return (D / PAIR) * XS_PAIR; }
+__host__ __device__ constexpr size_t blk_lds_bytes(int D) {
+    return sizeof(float) * (size_t)(12 * XS_WAVE + 12 * TR + 4 * 64 + 8 + ATT_CH + 32 * 66 + 2 * 32 * 64) + 16 * sizeof(double);
+}
+inline int blk_grid(int heads) { return ((heads + 7) / 8) * 32; }   // block b: head (b/32)*8 + b%8, member (b/8)%4
+
+template <int WT>
+__global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) {
+    constexpr int HD = 64, CPP = WTraits<WT>::CPP, R4 = HD / 4, NGR = BLK_KV_THREADS / R4, NV = ATT_CH / NGR, NW = BLK_THREADS / 64;
+    const int h = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7), jm = (blockIdx.x >> 3) & 3;
+    if (h >= P.n_q_heads) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *dred = reinterpret_cast<double *>(smem);                 // [16]
+    float *xs = reinterpret_cast<float *>(dred + 16);                // [12][XS_WAVE]: x * g of each wavefront's group
+    float *red = xs + NW * XS_WAVE;                                  // [12][16]
+    float *qs = red + NW * TR;                                        // [64]
+    float *kcur = qs + 64, *vcur = kcur + 64;                        // this position's K / V row
+    float *on = vcur + 64;                                           // [64] normalised attention output
+    float *ml = on + 64;                                             // [8]
+    float *sc = ml + 8;                                              // [128]
+    float *chunk = sc + ATT_CH;                                      // [32][66]: (m, l, o[64]) per 64-position half pass
+    float *ored = chunk + 32 * 66;                                   // [2][32][64]
+
+    const int G = P.n_q_heads / P.n_kv_heads, kvh = h / G;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane >> 2, k = lane & 3;
+    const int D = P.D;
+#define BLK_STAMP(i) do { if (P.dbg && blockIdx.x == 0 && tid == 0) P.dbg[i] = clock64(); } while (0)
+    BLK_STAMP(0);
+
+    // ---- every load of the launch that does not depend on a result is issued here ----
+    const int pos = P.ctl[CTL_POS];
+    const long long soff = P.single_stream ? 0 : (long long)P.ctl[CTL_STREAM] * P.kv_stream_stride;
+    const unsigned tag = (__hip_atomic_load(P.tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 8) | P.layer_tag;
+    const int sect = wave >> 2, grp = wave & 3;   // 0 q, 1 k, 2 v; this wavefront's 256-column group
+    const int tile = (sect == 0 ? h : sect == 1 ? P.n_q_heads + kvh : P.n_q_heads + P.n_kv_heads + kvh) * 4 + jm;
+    const long long tp0 = (long long)tile * P.npairs;
+    const int ngroups = (P.npairs + KL - 1) / KL;
+    uint4 cw[CPP];
+    uint2 sw;
+    const int gg = min(grp, ngroups - 1), gs = min(KL, P.npairs - gg * KL);
+    const bool lv = grp < ngroups && k < gs;
+    // x and the norm weights of this wavefront's own 256 columns (one float4 per lane), then its weights
+    const int xcol = gg * (KL * PAIR) + lane * 4;
+    const bool xin = xcol < D;
+    const float4 xv = *reinterpret_cast<const float4 *>(P.x + (xin ? xcol : 0));
+    const float4 gv = *reinterpret_cast<const float4 *>(P.normw + (xin ? xcol : 0));
+    load_pair<WT>(P.qkv_q, P.qkv_s, tp0, gg, gs, r, min(k, gs - 1), cw, sw);
+    // the first 128 cache rows of this kv head (rows >= pos hold stale finite data and are masked / replaced below)
+    const int c4 = tid % R4, tg = tid / R4;
+    float4 kreg[NV], vreg[NV];
+    const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + (long long)kvh * P.seq_len * HD);
+    const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + (long long)kvh * P.seq_len * HD);
+    if (tid < BLK_KV_THREADS) {
+        const int lim = min(ATT_CH, P.seq_len);
+#pragma unroll
+        for (int kk = 0; kk < NV; kk++) {
+            const int row = min(tg + kk * NGR, lim - 1);
+            kreg[kk] = K4[row * R4 + c4];
+            vreg[kk] = V4[row * R4 + c4];
+        }
+    }
+    // epilogue inputs of the projection rows (threads 0..47: one row each)
+    const int e_sect = tid >> 4, e_rr = tid & 15;
+    const int e_i = jm * 8 + (e_rr & 7), e_e = e_i + (e_rr >> 3) * (HD / 2);
+    float e_cos = 0.f, e_sin = 0.f, e_b = 0.f, e_bp = 0.f;
+    if (tid < 48) {
+        e_cos = P.rope_cos[pos * (HD / 2) + e_i];
+        e_sin = P.rope_sin[pos * (HD / 2) + e_i];
+        if (P.bias_q) {   // addBias before RoPE, go/model.go:525-527
+            const float *b = e_sect == 0 ? P.bias_q + h * HD : e_sect == 1 ? P.bias_k + kvh * HD : P.bias_v + kvh * HD;
+            e_b = b[e_e];
+            e_bp = b[e_e ^ (HD / 2)];
+        }
+    }
+
+    BLK_STAMP(15);
+    // ---- RMSNorm (go/quant.go:597-607): x * g into this wavefront's own LDS slice (no workgroup barrier before the
+    //      dot products); float64 sum of squares from the q wavefronts, which cover every column once ----
+    float *xw = xs + wave * XS_WAVE;
+    double ss = 0.0;
+    {
+        float4 xa = xin ? xv : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sect == 0 && grp < ngroups) {
+            ss = fma((double)xa.x, (double)xa.x, ss); ss = fma((double)xa.y, (double)xa.y, ss);
+            ss = fma((double)xa.z, (double)xa.z, ss); ss = fma((double)xa.w, (double)xa.w, ss);
+        }
+        xa.x *= gv.x; xa.y *= gv.y; xa.z *= gv.z; xa.w *= gv.w;
+        *reinterpret_cast<float4 *>(xw + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
+    }
+    BLK_STAMP(1);
+    __builtin_amdgcn_wave_barrier();
+    BLK_STAMP(2);
+
+    // ---- this member's q, k and v tile: each wavefront one 256-column group of one tile ----
+    float acc = PairDot<WT>::run(cw, sw, xw + k * XS_PAIR, 0.f);
+    acc = lv ? acc : 0.f;
+    BLK_STAMP(16);
+    acc = quad_sum(acc);
+    if (k == 0) red[wave * TR + r] = acc;
+    // sum of squares: 16-lane rows on DPP, four partials per q wavefront; the epilogue threads add the 16 partials
+    ss += dpp_f64<DPP_QUAD_XOR1>(ss);
+    ss += dpp_f64<DPP_QUAD_XOR2>(ss);
+    ss += dpp_f64<DPP_HALF_MIRROR>(ss);
+    ss += dpp_f64<DPP_ROW_MIRROR>(ss);
+    if (sect == 0 && (lane & 15) == 0) dred[grp * 4 + (lane >> 4)] = ss;
+    BLK_STAMP(3);
+    __syncthreads();
+    BLK_STAMP(4);
+
+    // this member's quarter of the head's WO slice streams in while the exchange and the attention run
+    const int wo_rows = D / BLK_MEMBERS, wo_tiles = D / TR;
+    const int wrow = jm * wo_rows + min(tid, wo_rows - 1);
+    uint4 wc[CPP];
+    uint2 wsc;
+    load_pair<WT>(P.wo_q, P.wo_s, (long long)h * wo_tiles + (wrow >> 4), 0, 1, wrow & 15, 0, wc, wsc);
+
+    // ---- scale, bias, RoPE (go/model.go:449-477); publish the 48 values to the other members ----
+    if (tid < 48) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) tot += dred[w];
+        const float inv = (float)(1.0 / sqrt(tot / (double)D + (double)P.eps));
+        const float *rt = red + e_sect * 4 * TR;   // the tile's four column-group partials, fixed order
+        const float dotv = ((rt[e_rr] + rt[TR + e_rr]) + rt[2 * TR + e_rr]) + rt[3 * TR + e_rr];
+        const float dotp = ((rt[e_rr ^ 8] + rt[TR + (e_rr ^ 8)]) + rt[2 * TR + (e_rr ^ 8)]) + rt[3 * TR + (e_rr ^ 8)];
+        const float v = dotv * inv + e_b, partner = dotp * inv + e_bp;
+        float outv = v;
+        if (e_sect < 2) {
+            const float x0 = (e_rr < 8) ? v : partner, x1 = (e_rr < 8) ? partner : v;
+            if (!P.rope_conj) outv = (e_rr < 8) ? (x0 * e_cos - x1 * e_sin) : (x0 * e_sin + x1 * e_cos);
+            else outv = (e_rr < 8) ? (x0 * e_cos + x1 * e_sin) : (-x0 * e_sin + x1 * e_cos);
+        }
+        __hip_atomic_store(P.xchg + (size_t)h * 192 + e_sect * 64 + e_e, ((unsigned long long)tag << 32) | __float_as_uint(outv),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    BLK_STAMP(5);
+    // ---- gather the head's q | k | v (192 granules; a wavefront retries until all of its lanes see the tag) ----
+    if (tid < 192) {
+        const bool dead = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        unsigned long long gq;
+        for (int spins = 0;; spins++) {
+            gq = __hip_atomic_load(P.xchg + (size_t)h * 192 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((unsigned)(gq >> 32) == tag)) break;
+            if (dead || spins > 400000) { if (lane == 0) { atomicOr(P.status, 4u); *P.host_status = 4u; } break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        qs[tid] = __uint_as_float((unsigned)gq);   // qs | kcur | vcur are contiguous
+    }
+    BLK_STAMP(6);
+    __syncthreads();
+    BLK_STAMP(7);
+    if (P.qk_norm) {   // RMSNormBare per head on q and k after RoPE, go/model.go:542-549
+        if (wave < 2) {
+            float *vec = wave == 0 ? qs : kcur;
+            const float val = vec[lane];
+            const double s2 = wave_sum_f64((double)val * (double)val);
+            const float inv = (float)(1.0 / sqrt(s2 / (double)HD + (double)P.eps));
+            vec[lane] = val * inv;
+        }
+        __syncthreads();
+    }
+    if (h == kvh * G && jm == 0 && tid < 128)   // KV store go/model.go:552-554, once per kv head
+        (tid < 64 ? P.kcache : P.vcache)[soff + ((long long)kvh * P.seq_len + pos) * HD + (tid & 63)] = kcur[tid];
+
+    BLK_STAMP(8);
+    // ---- GQA attention over positions 0..pos (go/model.go:557-587), 128 positions per pass ----
+    const int nch = pos / ATT_CH + 1;
+    for (int ch = 0; ch < nch; ch++) {
+        const int t0 = ch * ATT_CH, n = min(ATT_CH, pos + 1 - t0);
+        if (tid < BLK_KV_THREADS) {
+            if (ch > 0) {
+#pragma unroll
+                for (int kk = 0; kk < NV; kk++) {
+                    const int row = min(tg + kk * NGR, n - 1);
+                    kreg[kk] = K4[(long long)(t0 + row) * R4 + c4];
+                    vreg[kk] = V4[(long long)(t0 + row) * R4 + c4];
+                }
+            }
+            // scores: this thread holds 4 of the 64 dims of 4 cache rows; the 16 lanes of a row sum on DPP (no LDS staging)
+            const float4 q4 = *reinterpret_cast<const float4 *>(qs + c4 * 4);
+            const float4 kc4 = *reinterpret_cast<const float4 *>(kcur + c4 * 4), vc4 = *reinterpret_cast<const float4 *>(vcur + c4 * 4);
+#pragma unroll
+            for (int kk = 0; kk < NV; kk++) {
+                const int row = tg + kk * NGR;
+                const bool cur = t0 + row == pos;   // the row this launch produced: not in memory yet for this workgroup
+                kreg[kk].x = cur ? kc4.x : kreg[kk].x; kreg[kk].y = cur ? kc4.y : kreg[kk].y;
+                kreg[kk].z = cur ? kc4.z : kreg[kk].z; kreg[kk].w = cur ? kc4.w : kreg[kk].w;
+                vreg[kk].x = cur ? vc4.x : vreg[kk].x; vreg[kk].y = cur ? vc4.y : vreg[kk].y;
+                vreg[kk].z = cur ? vc4.z : vreg[kk].z; vreg[kk].w = cur ? vc4.w : vreg[kk].w;
+                float d = fmaf(q4.w, kreg[kk].w, fmaf(q4.z, kreg[kk].z, fmaf(q4.y, kreg[kk].y, q4.x * kreg[kk].x)));
+                d += dpp_f32<DPP_QUAD_XOR1>(d);
+                d += dpp_f32<DPP_QUAD_XOR2>(d);
+                d += dpp_f32<DPP_HALF_MIRROR>(d);
+                d += dpp_f32<DPP_ROW_MIRROR>(d);
+                if (c4 == 0 && row < n) sc[row] = d * P.scale;
+            }
+        }
+        __syncthreads();
+        if (ch == 0) BLK_STAMP(13);
+        if (wave < 2) {
+            // Softmax pieces (go/quant.go:610-626: max-subtract, f32(exp(f64)), f32 sum) per 64-position half; the halves
+            // are merged below like position splits, so no wavefront waits for the other one's maximum
+            const int row = wave * 64 + lane;
+            const float s0 = row < n ? sc[row] : -INFINITY;
+            const float m = wave_max_f32(s0);
+            const float p0 = row < n ? (float)exp((double)(s0 - m)) : 0.f;
+            if (row < n) sc[row] = p0;
+            const float l = wave_sum_f32(p0);
+            if (lane == 0) { chunk[(2 * ch + wave) * 66] = m; chunk[(2 * ch + wave) * 66 + 1] = l; }
+        }
+        __syncthreads();
+        if (ch == 0) BLK_STAMP(14);
+        if (tid < BLK_KV_THREADS) {
+            // rows tg, tg + 32 belong to the first half, tg + 64, tg + 96 to the second
+            float4 o[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll
+            for (int kk = 0; kk < NV; kk++) {
+                const int row = tg + kk * NGR;
+                const float pw = row < n ? sc[row] : 0.f;   // (a masked row's V may be stale but is finite)
+                float4 &a = o[kk >> 1];
+                a.x = fmaf(pw, vreg[kk].x, a.x); a.y = fmaf(pw, vreg[kk].y, a.y);
+                a.z = fmaf(pw, vreg[kk].z, a.z); a.w = fmaf(pw, vreg[kk].w, a.w);
+            }
+            *reinterpret_cast<float4 *>(ored + tg * HD + c4 * 4) = o[0];
+            *reinterpret_cast<float4 *>(ored + (NGR + tg) * HD + c4 * 4) = o[1];
+        }
+        __syncthreads();
+        if (tid < 2 * HD) {
+            const int half = tid >> 6, dd = tid & 63;
+            float s = 0.f;
+#pragma unroll 8
+            for (int kk = 0; kk < NGR; kk++) s += ored[(half * NGR + kk) * HD + dd];
+            chunk[(2 * ch + half) * 66 + 2 + dd] = s;
+        }
+        __syncthreads();   // sc / ored are rewritten by the next pass
+    }
+    BLK_STAMP(9);
+    if (tid < HD && pos < 64) on[tid] = chunk[2 + tid] * (1.0f / chunk[1]);   // one half pass: plain normalisation
+    else if (tid < HD) {   // merge the half passes by the rule of the five-launch plan's WO prologue (load_x4<PRO_ATTN>)
+        const int np = 2 * nch;
+        float M = chunk[0];
+        for (int c = 1; c < np; c++) M = fmaxf(M, chunk[c * 66]);
+        float v = 0.f, L = 0.f;
+        for (int c = 0; c < np; c++) {
+            const float w = (float)exp((double)(chunk[c * 66] - M));   // an empty half has max -inf: weight 0
+            L += w * chunk[c * 66 + 1];
+            v += w * chunk[c * 66 + 2 + tid];
+        }
+        on[tid] = v * (1.0f / L);
+    }
+    __syncthreads();
+    BLK_STAMP(10);
+
+    // ---- this member's rows of the head's 64 columns of WO (go/model.go:590): partial [D/4], added by the consumer ----
+    if (tid < wo_rows) {
+        float v = PairDot<WT>::run(wc, wsc, on, 0.f);
+        if (P.bias_out && h == 0) v += P.bias_out[wrow];
+        P.parts[(long long)h * D + wrow] = v;
+    }
+    BLK_STAMP(11);
+#undef BLK_STAMP
+}
+
+}  // namespace nl

@@ -13,6 +13,7 @@
 #include "nl_batch.h"
 #include "nl_sample.h"
 #include "nl_p2p.h"
+#include "nl_block.h"
 
 #include <dlfcn.h>
 #include <algorithm>
@@ -34,9 +35,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Kind { K_EMBED = 0, K_QKV, K_ATTN, K_WO, K_GATEUP, K_DOWN, K_LMHEAD, K_ARGMAX, K_ALLREDUCE };
+enum Kind { K_EMBED = 0, K_QKV, K_ATTN, K_WO, K_GATEUP, K_DOWN, K_LMHEAD, K_ARGMAX, K_ALLREDUCE, K_ATTNBLOCK };
 const char *kKindNames[NL_NUM_KINDS] = {"embed", "qkv_rope", "attention", "wo_resid", "gate_up_swiglu",
-                                        "down_resid", "lm_head", "argmax", "allreduce"};
+                                        "down_resid", "lm_head", "argmax", "allreduce", "attn_block"};
 
 struct PackedMat {
     uint8_t *q = nullptr;
@@ -130,6 +131,7 @@ struct nl_engine {
 
     struct Layer {
         PackedMat qkv, wo, gate, up, down;
+        PackedMat wo_head;   // per-head 64-column slices of WO for the fused attention block (nl_block.h); small models only
         float *attn_norm = nullptr, *ffn_norm = nullptr;
         float *bq = nullptr, *bk = nullptr, *bv = nullptr, *bo = nullptr;  // optional biases (this rank's slice)
         bool have_q = false, have_k = false, have_v = false;
@@ -186,11 +188,22 @@ struct nl_engine {
     bool sp_ready = false;
     int sp_uniforms_cap = 0;
 
-    std::vector<Op> plan;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    hipGraph_t graph_multi = nullptr;          // the same plan graph_steps times: chained greedy decode replays it
-    hipGraphExec_t graph_multi_exec = nullptr;  // (one inter-graph gap per graph_steps tokens instead of per token)
+    // A launch plan with its captured graphs.  ps[0]: five launches per layer, any context length.  ps[1] (small
+    // models, nl_block.h): the attention half of a layer as one launch -- chosen per step while the context is short.
+    struct PlanSet {
+        std::vector<Op> ops;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipGraph_t multi = nullptr;          // the same plan graph_steps times: chained greedy decode replays it
+        hipGraphExec_t multi_exec = nullptr;  // (one inter-graph gap per graph_steps tokens instead of per token)
+    } ps[2];
+    bool fused = false;           // ps[1] exists
+    int fused_max_pos = 0;        // ps[1] serves steps whose position is below this
+    float *parts = nullptr;       // [Hs][D] per-head WO partials of the fused block
+    unsigned long long *xchg = nullptr;   // [Hs][192] granules exchanged inside a head's cluster
+    unsigned *tick = nullptr;     // {forward counter, status} device words of the fused block
+    long long *dbg_block = nullptr;
+    unsigned *h_status = nullptr; // pinned, device-visible: non-zero after an in-kernel exchange gave up
     int graph_steps = 1;
     EmbedParams plan_embed{};    // kept for the fused argmax + embed launch of the multi-step graph
     ArgmaxParams plan_argmax{};
@@ -423,20 +436,21 @@ hipError_t launch_gemv_dyn(int wt, int pro, int epi, const GemvParams &P, hipStr
     if (pro == PRO_PLAIN && epi == EPI_RESID) return launch_gemv_t<PRO_PLAIN, EPI_RESID>(wt, P, st);
     if (pro == PRO_PLAIN && epi == EPI_STORE) return launch_gemv_t<PRO_PLAIN, EPI_STORE>(wt, P, st);
     if (pro == PRO_NORM && epi == EPI_STORE) return launch_gemv_t<PRO_NORM, EPI_STORE>(wt, P, st);
+    if (pro == PRO_NORM_PARTS && epi == EPI_SWIGLU) return launch_gemv_t<PRO_NORM_PARTS, EPI_SWIGLU>(wt, P, st);
     if (pro == PRO_ATTN && epi == EPI_P2P) return launch_gemv_t<PRO_ATTN, EPI_P2P>(wt, P, st);
     if (pro == PRO_PLAIN && epi == EPI_P2P) return launch_gemv_t<PRO_PLAIN, EPI_P2P>(wt, P, st);
     return hipErrorInvalidValue;
 }
 
-void push_gemv(nl_engine *e, int kind, int coll, float *buf, size_t count, int wt, int pro, int epi, const GemvParams &P) {
+void push_gemv(std::vector<Op> &plan, int kind, int coll, float *buf, size_t count, int wt, int pro, int epi, const GemvParams &P) {
     Op op{kind, coll, buf, count, nullptr};
     op.is_gemv = true; op.wtype = wt; op.pro = pro; op.epi = epi; op.gp = P;
-    e->plan.push_back(op);
+    plan.push_back(op);
 }
 
 // Freeze the launch closures once every GEMV's parameters are final.
-void link_prefetch(nl_engine *e) {
-    for (Op &cur : e->plan) {
+void link_prefetch(std::vector<Op> &plan) {
+    for (Op &cur : plan) {
         if (!cur.is_gemv) continue;
         const int wt = cur.wtype, pro = cur.pro, epi = cur.epi;
         const GemvParams P = cur.gp;
@@ -447,8 +461,8 @@ void link_prefetch(nl_engine *e) {
 // Build the per-token launch plan: the device-side restatement of Forward
 // (go/model.go:490-620).  token / pos / stream are read from e->ctl by the
 // kernels, so one captured graph serves every step.
-void build_plan(nl_engine *e) {
-    e->plan.clear();
+void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
+    plan.clear();
     const nl_config &c = e->cfg;
     const bool p2p = e->p2p.on;
     const bool tp = (e->G > 1 || e->force_tp_plan) && !p2p;   // RCCL seams (or the in-process group's own sums)
@@ -467,7 +481,7 @@ void build_plan(nl_engine *e) {
         P2PReduceParams R{reinterpret_cast<const u64 *>((char *)e->p2p.area + (size_t)(seam & 1) * e->G * slot_bytes), c.dim,
                           (unsigned)(seam + 1), e->p2p.epoch, x, e->p2p.status, e->p2p.timeout_ticks};
         const int G = e->G, blocks = (c.dim + 255) / 256;
-        e->plan.push_back({K_ALLREDUCE, 0, nullptr, 0, [R, G, blocks](hipStream_t st) {
+        plan.push_back({K_ALLREDUCE, 0, nullptr, 0, [R, G, blocks](hipStream_t st) {
                                switch (G) {
                                case 2: hipLaunchKernelGGL(p2p_reduce_kernel<2>, dim3(blocks), dim3(256), 0, st, R); break;
                                case 4: hipLaunchKernelGGL(p2p_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, R); break;
@@ -480,9 +494,9 @@ void build_plan(nl_engine *e) {
     int seam = 0;
 
     {
-        EmbedParams P{e->embd_raw, e->embd_type, c.dim, e->ctl, e->x[0], e->gamma_row, e->gamma_val, p2p ? e->p2p.epoch : nullptr};
+        EmbedParams P{e->embd_raw, e->embd_type, c.dim, e->ctl, e->x[0], e->gamma_row, e->gamma_val, p2p ? e->p2p.epoch : e->tick};
         e->plan_embed = P;
-        e->plan.push_back({K_EMBED, 0, nullptr, 0, [P](hipStream_t st) {
+        plan.push_back({K_EMBED, 0, nullptr, 0, [P](hipStream_t st) {
                                hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, P);
                                return hipGetLastError();
                            }});
@@ -491,6 +505,29 @@ void build_plan(nl_engine *e) {
         nl_engine::Layer &L = e->layers[l];
         float *kc = e->kcache + (long long)l * e->kv_layer_stride;
         float *vc = e->vcache + (long long)l * e->kv_layer_stride;
+        bool parts_pending = false;
+        if (fused) {
+            // the whole attention half as one launch per layer (nl_block.h); its H partial vectors are added to the
+            // residual stream by the gate/up prologue below
+            BlockParams B{};
+            B.qkv_q = L.qkv.q; B.qkv_s = L.qkv.s; B.wo_q = L.wo_head.q; B.wo_s = L.wo_head.s;
+            B.D = c.dim; B.npairs = L.qkv.npairs; B.n_q_heads = e->Hs; B.n_kv_heads = e->KVs; B.seq_len = c.seq_len;
+            B.rope_conj = c.rope_conjugate; B.qk_norm = c.qk_norm; B.single_stream = c.max_streams == 1 ? 1 : 0;
+            B.x = e->x[cur]; B.normw = L.attn_norm; B.eps = c.rms_eps; B.scale = (float)(1.0 / std::sqrt((double)e->hd));
+            B.rope_cos = e->rope_cos; B.rope_sin = e->rope_sin; B.kcache = kc; B.vcache = vc;
+            B.kv_stream_stride = e->kv_stream_stride; B.ctl = e->ctl;
+            B.bias_q = L.bq; B.bias_k = L.bk; B.bias_v = L.bv; B.bias_out = L.bo; B.parts = e->parts;
+            B.xchg = e->xchg; B.tick = e->tick; B.layer_tag = (unsigned)(l + 1); B.status = e->tick + 1; B.host_status = e->h_status;
+            const int wt = L.qkv.wtype, grid = blk_grid(e->Hs);
+            const size_t lds = blk_lds_bytes(c.dim);
+            plan.push_back({K_ATTNBLOCK, 0, nullptr, 0, [B, wt, grid, lds, e](hipStream_t st) mutable {
+                                   B.dbg = e->dbg_block;      // nl_debug_stamps only
+                                   if (wt == WT_Q8_0) hipLaunchKernelGGL(attn_block_kernel<WT_Q8_0>, dim3(grid), dim3(BLK_THREADS), lds, st, B);
+                                   else hipLaunchKernelGGL(attn_block_kernel<WT_Q4_0>, dim3(grid), dim3(BLK_THREADS), lds, st, B);
+                                   return hipGetLastError();
+                               }});
+            parts_pending = true;
+        } else {
         {   // RMSNorm + Q,K,V GEMV + RoPE + KV store   (go/model.go:517-554)
             GemvParams P = base_params(e, L.qkv);
             P.x = e->x[cur]; P.normw = L.attn_norm;
@@ -500,13 +537,13 @@ void build_plan(nl_engine *e) {
             P.n_q_heads = e->Hs; P.n_kv_heads = e->KVs; P.seq_len = c.seq_len; P.rope_conj = c.rope_conjugate;
             P.bias_q = L.bq; P.bias_k = L.bk; P.bias_v = L.bv;
             int wt = L.qkv.wtype;
-            push_gemv(e, K_QKV, 0, nullptr, 0, wt, PRO_NORM, EPI_QKV, P);
+            push_gemv(plan, K_QKV, 0, nullptr, 0, wt, PRO_NORM, EPI_QKV, P);
             if (pending) { cur ^= 1; pending = nullptr; }
         }
         if (c.qk_norm) {
             QkNormParams P{e->qbuf, kc, e->kv_stream_stride, e->ctl, e->Hs, e->KVs, e->hd, c.seq_len, c.rms_eps};
             int nh = e->Hs + e->KVs;
-            e->plan.push_back({K_QKV, 0, nullptr, 0, [P, nh](hipStream_t st) {
+            plan.push_back({K_QKV, 0, nullptr, 0, [P, nh](hipStream_t st) {
                                    hipLaunchKernelGGL(qknorm_kernel, dim3(nh), dim3(64), 0, st, P);
                                    return hipGetLastError();
                                }});
@@ -517,7 +554,7 @@ void build_plan(nl_engine *e) {
                          nullptr, nullptr, 0, 0};
             dim3 grid(e->KVs, e->nsplit_max);
             int hd = e->hd, gqa = e->gqa;
-            e->plan.push_back({K_ATTN, 0, nullptr, 0,
+            plan.push_back({K_ATTN, 0, nullptr, 0,
                                [hd, gqa, P, grid](hipStream_t st) { return launch_attn(hd, gqa, P, grid, st); }});
         }
         {   // WO + residual (go/model.go:590-594); the prologue merges the attention splits
@@ -527,24 +564,31 @@ void build_plan(nl_engine *e) {
             int wt = L.wo.wtype;
             if (p2p) {
                 p2p_producer(P, seam);
-                push_gemv(e, K_WO, 0, nullptr, 0, wt, PRO_ATTN, EPI_P2P, P);
+                push_gemv(plan, K_WO, 0, nullptr, 0, wt, PRO_ATTN, EPI_P2P, P);
                 p2p_reduce(seam++, e->x[cur]);
             } else if (!tp) {
                 P.out = e->x[cur]; P.resid = e->x[cur];
-                push_gemv(e, K_WO, 0, nullptr, 0, wt, PRO_ATTN, EPI_RESID, P);
+                push_gemv(plan, K_WO, 0, nullptr, 0, wt, PRO_ATTN, EPI_RESID, P);
             } else {
                 P.out = e->ar;
-                push_gemv(e, K_WO, 1, e->ar, (size_t)c.dim, wt, PRO_ATTN, EPI_STORE, P);
+                push_gemv(plan, K_WO, 1, e->ar, (size_t)c.dim, wt, PRO_ATTN, EPI_STORE, P);
                 pending = e->ar;
             }
         }
+        }   // !fused
         {   // RMSNorm + gate/up GEMV + SiLU*up (go/model.go:597-606)
             GemvParams P = base_params(e, L.gate, 2);
             P.q1 = L.up.q; P.s1 = L.up.s;
             P.x = e->x[cur]; P.normw = L.ffn_norm; P.out = e->hb;
             if (pending) { P.add = pending; P.x_out = e->x[cur ^ 1]; }
             int wt = L.gate.wtype;
-            push_gemv(e, K_GATEUP, 0, nullptr, 0, wt, PRO_NORM, EPI_SWIGLU, P);
+            if (parts_pending) {
+                P.parts = e->parts; P.nparts = e->Hs; P.x_out = e->x[cur ^ 1];
+                push_gemv(plan, K_GATEUP, 0, nullptr, 0, wt, PRO_NORM_PARTS, EPI_SWIGLU, P);
+                cur ^= 1;
+            } else {
+                push_gemv(plan, K_GATEUP, 0, nullptr, 0, wt, PRO_NORM, EPI_SWIGLU, P);
+            }
             if (pending) { cur ^= 1; pending = nullptr; }
         }
         {   // down + residual (go/model.go:609-612)
@@ -553,14 +597,14 @@ void build_plan(nl_engine *e) {
             int wt = L.down.wtype;
             if (p2p) {
                 p2p_producer(P, seam);
-                push_gemv(e, K_DOWN, 0, nullptr, 0, wt, PRO_PLAIN, EPI_P2P, P);
+                push_gemv(plan, K_DOWN, 0, nullptr, 0, wt, PRO_PLAIN, EPI_P2P, P);
                 p2p_reduce(seam++, e->x[cur]);
             } else if (!tp) {
                 P.out = e->x[cur]; P.resid = e->x[cur];
-                push_gemv(e, K_DOWN, 0, nullptr, 0, wt, PRO_PLAIN, EPI_RESID, P);
+                push_gemv(plan, K_DOWN, 0, nullptr, 0, wt, PRO_PLAIN, EPI_RESID, P);
             } else {
                 P.out = e->ar;
-                push_gemv(e, K_DOWN, 1, e->ar, (size_t)c.dim, wt, PRO_PLAIN, EPI_STORE, P);
+                push_gemv(plan, K_DOWN, 1, e->ar, (size_t)c.dim, wt, PRO_PLAIN, EPI_STORE, P);
                 pending = e->ar;
             }
         }
@@ -578,7 +622,7 @@ void build_plan(nl_engine *e) {
         int wt = e->lm_head.wtype;
         lm_blocks = (P.ntiles + P.tw - 1) / P.tw;
         lm_spb = (P.tw * TR + 63) / 64;
-        push_gemv(e, K_LMHEAD, tp ? 2 : 0, e->logits, (size_t)e->Vs, wt, PRO_NORM, EPI_STORE, P);
+        push_gemv(plan, K_LMHEAD, tp ? 2 : 0, e->logits, (size_t)e->Vs, wt, PRO_NORM, EPI_STORE, P);
     }
     if (p2p) {
         P2PArgmaxParams P{};
@@ -589,7 +633,7 @@ void build_plan(nl_engine *e) {
         P.G = e->G; P.row0 = e->rank * e->Vs; P.seam = 255u;
         P.epoch = e->p2p.epoch; P.status = e->p2p.status; P.timeout_ticks = e->p2p.timeout_ticks;
         e->plan_p2p_argmax = P;
-        e->plan.push_back({K_ARGMAX, 0, nullptr, 0, [P](hipStream_t st) {
+        plan.push_back({K_ARGMAX, 0, nullptr, 0, [P](hipStream_t st) {
                                hipLaunchKernelGGL(p2p_argmax_kernel, dim3(1), dim3(1024), 0, st, P);
                                return hipGetLastError();
                            }});
@@ -597,12 +641,12 @@ void build_plan(nl_engine *e) {
         ArgmaxParams P{e->logits, c.vocab, tp ? nullptr : e->amax_val, e->amax_idx, lm_blocks * lm_spb, e->ctl, e->ids,
                        e->result};
         e->plan_argmax = P;
-        e->plan.push_back({K_ARGMAX, 0, nullptr, 0, [P](hipStream_t st) {
+        plan.push_back({K_ARGMAX, 0, nullptr, 0, [P](hipStream_t st) {
                                hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, P);
                                return hipGetLastError();
                            }});
     }
-    link_prefetch(e);
+    link_prefetch(plan);
 }
 
 int run_collective(nl_engine *e, const Op &op) {
@@ -615,8 +659,8 @@ int run_collective(nl_engine *e, const Op &op) {
     return NL_OK;
 }
 
-int run_plan_eager(nl_engine *e) {
-    for (const Op &op : e->plan) {
+int run_plan_eager(nl_engine *e, const nl_engine::PlanSet &S) {
+    for (const Op &op : S.ops) {
         hipError_t s = op.fn(e->stream);
         if (s != hipSuccess) return e->fail(NL_ERR_HIP, "launch %s: %s", kKindNames[op.kind], hipGetErrorString(s));
         int rc = run_collective(e, op);
@@ -625,15 +669,22 @@ int run_plan_eager(nl_engine *e) {
     return NL_OK;
 }
 
-int capture_graph(nl_engine *e) {
+void destroy_graphs(nl_engine::PlanSet &S) {
+    if (S.exec) { (void)hipGraphExecDestroy(S.exec); S.exec = nullptr; }
+    if (S.multi_exec) { (void)hipGraphExecDestroy(S.multi_exec); S.multi_exec = nullptr; }
+    if (S.multi) { (void)hipGraphDestroy(S.multi); S.multi = nullptr; }
+    if (S.graph) { (void)hipGraphDestroy(S.graph); S.graph = nullptr; }
+}
+
+int capture_graph(nl_engine *e, nl_engine::PlanSet &S) {
     HIPCK(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-    int rc = run_plan_eager(e);
+    int rc = run_plan_eager(e, S);
     hipGraph_t g = nullptr;
     hipError_t s = hipStreamEndCapture(e->stream, &g);
     if (rc) { if (g) hipGraphDestroy(g); return rc; }
     if (s != hipSuccess) return e->fail(NL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(s));
-    e->graph = g;
-    HIPCK(e, hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+    S.graph = g;
+    HIPCK(e, hipGraphInstantiate(&S.exec, S.graph, nullptr, nullptr, 0));
     // chained greedy decode replays a graph that holds the plan 16 times: the gap between two graph launches
     // (~8 us on this stack) is then paid once per 16 tokens (nano 3834 -> 3945 tok/s; 4 steps: 3905; 32 / 64: as 16)
     static const int steps = getenv("NL_GRAPH_STEPS") ? atoi(getenv("NL_GRAPH_STEPS")) : 16;   // developer knob (tools/)
@@ -643,7 +694,7 @@ int capture_graph(nl_engine *e) {
         // step k's argmax also embeds step k+1's token (argmax_embed_kernel): the embed launch exists in step 0 only
         static const bool fuse_embed = getenv("NL_NO_ARGMAX_EMBED") == nullptr;
         for (int k = 0; k < steps && !rc2; k++)
-            for (const Op &op : e->plan) {
+            for (const Op &op : S.ops) {
                 if (fuse_embed && op.kind == K_EMBED && k > 0) continue;
                 hipError_t ls;
                 if (fuse_embed && op.kind == K_ARGMAX && e->p2p.on) {
@@ -660,19 +711,48 @@ int capture_graph(nl_engine *e) {
         hipGraph_t gm = nullptr;
         hipError_t s2 = hipStreamEndCapture(e->stream, &gm);
         if (rc2 || s2 != hipSuccess) { if (gm) hipGraphDestroy(gm); return rc2 ? rc2 : e->fail(NL_ERR_HIP, "multi-step capture"); }
-        e->graph_multi = gm;
-        HIPCK(e, hipGraphInstantiate(&e->graph_multi_exec, gm, nullptr, nullptr, 0));
+        S.multi = gm;
+        HIPCK(e, hipGraphInstantiate(&S.multi_exec, gm, nullptr, nullptr, 0));
         e->graph_steps = steps;
     }
     return NL_OK;
 }
 
-int launch_step(nl_engine *e) {
-    if (e->graph_exec) {
-        HIPCK(e, hipGraphLaunch(e->graph_exec, e->stream));
+// the plan that serves a step (or a run of steps) whose highest position is pos_last
+nl_engine::PlanSet &pick_plan(nl_engine *e, int pos_last) {
+    return e->ps[(e->fused && pos_last < e->fused_max_pos) ? 1 : 0];
+}
+
+int launch_step(nl_engine *e, int pos) {
+    nl_engine::PlanSet &S = pick_plan(e, pos);
+    if (S.exec) {
+        HIPCK(e, hipGraphLaunch(S.exec, e->stream));
         return NL_OK;
     }
-    return run_plan_eager(e);
+    return run_plan_eager(e, S);
+}
+
+// (re)build both plans and their graphs
+int build_all(nl_engine *e) {
+    for (auto &S : e->ps) destroy_graphs(S);
+    e->graph_steps = 1;
+    build_plan(e, e->ps[0].ops, false);
+    if (e->fused) build_plan(e, e->ps[1].ops, true);
+    const bool has_coll = (e->G > 1 || e->force_tp_plan) && !e->p2p.on;
+    if (e->use_graph && !(e->cfg.flags & NL_FLAG_LOCAL_GROUP)) {
+        for (int k = 0; k < (e->fused ? 2 : 1); k++) {
+            int rc = capture_graph(e, e->ps[k]);
+            if (rc && has_coll) {
+                // RCCL inside a captured graph is not guaranteed on every RCCL build: fall back to eager launches
+                (void)hipGetLastError();
+                destroy_graphs(e->ps[k]);
+                if (!getenv("NL_QUIET")) fprintf(stderr, "[nanollama_hip] graph capture with RCCL failed (%s); using eager launches\n", e->err.c_str());
+            } else if (rc) {
+                return rc;
+            }
+        }
+    }
+    return NL_OK;
 }
 
 int set_ctl(nl_engine *e, int token, int pos, int chain, int stream) {
@@ -709,6 +789,8 @@ int note_positions(nl_engine *e, int stream, int pos, int n, hipStream_t st = nu
 
 // after a synchronize: did any poll of the push all-reduce give up?
 int p2p_check(nl_engine *e) {
+    if (e->h_status && *e->h_status)
+        return e->fail(NL_ERR_HIP, "fused attention block: a cluster exchange timed out (status %u)", *e->h_status);
     if (!e->p2p.on) return NL_OK;
     unsigned st = 0;
     HIPCK(e, hipMemcpy(&st, e->p2p.status, sizeof st, hipMemcpyDeviceToHost));
@@ -1230,6 +1312,18 @@ int nl_upload_tensor(nl_handle e, const char *name, uint32_t type, const void *d
         int rc = matrix_upload(L.wo, D, c.n_heads * hd, 0, D, e->rank * e->Hs * hd, e->Hs * hd, 0, (D + TR - 1) / TR,
                                ROWMAP_IDENT, true);
         if (!rc) L.wo.ready = true;
+        // small models also keep WO as per-head 64-column slices for the fused attention block (nl_block.h): head h =
+        // D/16 tiles of one pair each.  The raw tensor is still in the staging buffer.
+        const int dt = device_type((int)type);
+        if (!rc && e->G == 1 && hd == 64 && D % PAIR == 0 && D <= BLK_MAXG * KL * PAIR && e->Hs <= BLK_MAX_PARTS &&
+            (dt == WT_Q8_0 || dt == WT_Q4_0) && !L.wo_head.ready) {
+            PackedMat &m = L.wo_head;
+            HIPCK(e, alloc_packed(e, m, (int)type, e->Hs * (D / TR), D, hd));
+            for (int hh = 0; hh < e->Hs; hh++)
+                HIPCK(e, repack(e, m, e->stage, (int)type, c.n_heads * hd, 0, D, hh * hd, hd, hh * (D / TR), D / TR, ROWMAP_IDENT));
+            HIPCK(e, hipStreamSynchronize(e->stream));
+            m.ready = true;
+        }
         return rc;
     }
     if (f == "ffn_gate.weight" || f == "ffn_up.weight") {
@@ -1346,22 +1440,35 @@ int nl_finalize(nl_handle e) {
     if (e->G > 1 && !e->comm && !e->p2p.on && !(c.flags & NL_FLAG_LOCAL_GROUP))
         return e->fail(NL_ERR_STATE, "tp_size %d needs nl_comm_init or nl_p2p_import before nl_finalize", e->G);
     if (e->stage) { hipFree(e->stage); e->stage = nullptr; e->stage_cap = 0; }
-    build_plan(e);
-    HIPCK(e, hipStreamSynchronize(e->stream));
+    {
+        // fused attention block (nl_block.h): every layer must have its per-head WO slices, and the models it pays
+        // for are the ones whose per-head weights are small (see the header of nl_block.h)
+        const char *fa = getenv("NL_FUSED_ATTN");          // knob (tests, tools): 0 keeps the five-launch plan only
+        bool ok = e->G == 1 && !e->force_tp_plan && !(c.flags & NL_FLAG_LOCAL_GROUP) && !(fa && atoi(fa) == 0);
+        for (const auto &L : e->layers)
+            ok = ok && L.wo_head.ready && L.wo_head.wtype == L.qkv.wtype && (L.qkv.wtype == WT_Q8_0 || L.qkv.wtype == WT_Q4_0);
+        e->fused = ok;
+        const char *fm = getenv("NL_FUSED_MAX_POS");
+        e->fused_max_pos = fm ? atoi(fm) : 256;
+        if (e->fused) {
+            ok = c.dim % (BLK_MEMBERS * TR) == 0 && c.n_layers < 255;
+            e->fused = ok;
+        }
+        if (e->fused) {
+            HIPCK(e, dalloc(&e->parts, (size_t)e->Hs * c.dim, &e->bytes_state));
+            HIPCK(e, dalloc(&e->xchg, (size_t)e->Hs * 192, &e->bytes_state));
+            HIPCK(e, hipMemset(e->xchg, 0, (size_t)e->Hs * 192 * 8));
+            HIPCK(e, dalloc(&e->tick, (size_t)2, &e->bytes_state));
+            HIPCK(e, hipMemset(e->tick, 0, 8));
+            HIPCK(e, hipHostMalloc((void **)&e->h_status, sizeof(unsigned), hipHostMallocMapped));
+            *e->h_status = 0;
+        }
+    }
     const bool has_coll = (e->G > 1 || e->force_tp_plan) && !e->p2p.on;
     if (has_coll && !e->comm && !(c.flags & NL_FLAG_LOCAL_GROUP))
         return e->fail(NL_ERR_STATE, "collective plan needs nl_comm_init before nl_finalize");
-    if (e->use_graph && !(c.flags & NL_FLAG_LOCAL_GROUP)) {
-        int rc = capture_graph(e);
-        if (rc && has_coll) {
-            // RCCL inside a captured graph is not guaranteed on every RCCL build: fall back to eager launches
-            hipGetLastError();
-            e->graph = nullptr; e->graph_exec = nullptr;
-            if (!getenv("NL_QUIET")) fprintf(stderr, "[nanollama_hip] graph capture with RCCL failed (%s); using eager launches\n", e->err.c_str());
-        } else if (rc) {
-            return rc;
-        }
-    }
+    HIPCK(e, hipStreamSynchronize(e->stream));
+    if (int rc = build_all(e)) return rc;
     e->finalized = true;
     return NL_OK;
 }
@@ -1401,19 +1508,12 @@ int nl_set_gamma(nl_handle e, const int32_t *indices, int n, const void *values,
     float *old_val = e->gamma_val;
     e->gamma_row = new_row;
     e->gamma_val = new_val;
-    if (e->finalized) {  // the launch closures hold the old pointers: rebuild plan and graph
-        if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
-        if (e->graph_multi_exec) { hipGraphExecDestroy(e->graph_multi_exec); e->graph_multi_exec = nullptr; }
-        if (e->graph_multi) { hipGraphDestroy(e->graph_multi); e->graph_multi = nullptr; }
+    if (e->finalized) {  // the launch closures hold the old pointers: rebuild plans and graphs
         if (e->samp_graph_exec) { hipGraphExecDestroy(e->samp_graph_exec); e->samp_graph_exec = nullptr; }
         if (e->samp_graph) { hipGraphDestroy(e->samp_graph); e->samp_graph = nullptr; }
-        e->graph_steps = 1;
-        if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
-        build_plan(e);
-        if (e->use_graph && !(c.flags & NL_FLAG_LOCAL_GROUP)) {
-            int rc = capture_graph(e);
-            if (rc && (e->G > 1 || e->force_tp_plan)) { hipGetLastError(); e->graph = nullptr; e->graph_exec = nullptr; }
-            else if (rc) { e->use_graph = false; }   // the rebuilt eager plan is valid; only the graph was lost
+        if (build_all(e)) {   // the rebuilt eager plans are valid; only the graphs were lost
+            for (auto &S : e->ps) destroy_graphs(S);
+            e->use_graph = false;
         }
     }
     if (old_row) (void)hipFree(old_row);   // nothing references the old tables any more
@@ -1426,12 +1526,9 @@ int nl_destroy(nl_handle e) {
     hipSetDevice(e->dev);
     hipDeviceSynchronize();
     samp_free(e->sp);
-    if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
-    if (e->graph_multi_exec) hipGraphExecDestroy(e->graph_multi_exec);
-    if (e->graph_multi) hipGraphDestroy(e->graph_multi);
+    for (auto &S : e->ps) destroy_graphs(S);
     if (e->samp_graph_exec) hipGraphExecDestroy(e->samp_graph_exec);
     if (e->samp_graph) hipGraphDestroy(e->samp_graph);
-    if (e->graph) hipGraphDestroy(e->graph);
     for (auto &L : e->layers) {
         if (L.attn_norm) hipFree(L.attn_norm);
         if (L.ffn_norm) hipFree(L.ffn_norm);
@@ -1457,10 +1554,11 @@ int nl_destroy(nl_handle e) {
         if (e->p2p.epoch) (void)hipFree(e->p2p.epoch);
     }
     void *bufs[] = {e->embd_raw, e->output_norm, e->rope_cos, e->rope_sin, e->x[0], e->x[1], e->qbuf, e->part_o,
-                    e->part_ml, e->hb, e->ar, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result, e->amax_val,
+                    e->part_ml, e->hb, e->ar, e->parts, e->xchg, e->tick, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result, e->amax_val,
                     e->amax_idx};
     for (void *b : bufs) if (b) hipFree(b);
     if (e->h_ctl) hipHostFree(e->h_ctl);
+    if (e->h_status) hipHostFree(e->h_status);
     if (e->h_ctl_ring) hipHostFree(e->h_ctl_ring);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     if (e->ev0) hipEventDestroy(e->ev0);
@@ -1487,7 +1585,7 @@ int nl_forward(nl_handle e, int stream, int token, int pos, float *logits_out) {
     HIPCK(e, hipSetDevice(e->dev));
     if ((rc = note_positions(e, stream, pos, 1))) return rc;
     if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
-    if ((rc = launch_step(e))) return rc;
+    if ((rc = launch_step(e, pos))) return rc;
     if (logits_out)
         HIPCK(e, hipMemcpyAsync(logits_out, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCK(e, hipStreamSynchronize(e->stream));
@@ -1502,7 +1600,7 @@ int nl_forward_argmax(nl_handle e, int stream, int token, int pos, int *next_id)
     HIPCK(e, hipSetDevice(e->dev));
     if ((rc = note_positions(e, stream, pos, 1))) return rc;
     if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
-    if ((rc = launch_step(e))) return rc;
+    if ((rc = launch_step(e, pos))) return rc;
     HIPCK(e, hipMemcpyAsync(next_id, e->result, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCK(e, hipStreamSynchronize(e->stream));
     if (int prc = p2p_check(e)) return prc;
@@ -1519,10 +1617,13 @@ int nl_decode_greedy(nl_handle e, int stream, int token, int pos, int n_steps, i
     if ((rc = note_positions(e, stream, pos, n))) return rc;
     if ((rc = set_ctl(e, token, pos, 1, stream))) return rc;
     int i = 0;
-    if (e->graph_multi_exec)
-        for (; i + e->graph_steps <= n; i += e->graph_steps) HIPCK(e, hipGraphLaunch(e->graph_multi_exec, e->stream));
+    for (; i + e->graph_steps <= n && e->graph_steps > 1; i += e->graph_steps) {
+        nl_engine::PlanSet &S = pick_plan(e, pos + i + e->graph_steps - 1);   // highest position of these steps
+        if (!S.multi_exec) break;
+        HIPCK(e, hipGraphLaunch(S.multi_exec, e->stream));
+    }
     for (; i < n; i++)
-        if ((rc = launch_step(e))) return rc;
+        if ((rc = launch_step(e, pos + i))) return rc;
     if (n > 0) HIPCK(e, hipMemcpyAsync(ids_out, e->ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCK(e, hipStreamSynchronize(e->stream));
     if (int prc = p2p_check(e)) return prc;
@@ -1627,7 +1728,7 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
     if (*n_recent > 0) HIPCK(e, hipMemcpyAsync(s.recent, recent, (size_t)*n_recent * 4, hipMemcpyHostToDevice, e->stream));
     HIPCK(e, hipMemcpyAsync(s.recent_n, n_recent, 4, hipMemcpyHostToDevice, e->stream));
     int i = 0;
-    if (e->graph_multi_exec && !e->samp_graph_failed && n >= e->graph_steps) {
+    if (e->ps[0].multi_exec && !e->samp_graph_failed && n >= e->graph_steps) {
         // {sampler kernels, plan} x graph_steps as one graph (its kernel arguments include the sampling parameters:
         // re-captured when they change)
         if (!e->samp_graph_exec || memcmp(&e->samp_graph_params, p, sizeof(*p)) != 0) {
@@ -1637,7 +1738,7 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
             int rc2 = NL_OK;
             for (int k = 0; cs == hipSuccess && k < e->graph_steps && !rc2; k++) {
                 if (launch_sample(s, e->logits, e->cfg.vocab, *p, e->ctl, e->ids, e->stream) != hipSuccess) rc2 = NL_ERR_HIP;
-                else rc2 = run_plan_eager(e);
+                else rc2 = run_plan_eager(e, e->ps[0]);
             }
             hipGraph_t g = nullptr;
             if (cs == hipSuccess) cs = hipStreamEndCapture(e->stream, &g);
@@ -1656,7 +1757,7 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
     }
     for (; i < n; i++) {
         HIPCK(e, launch_sample(s, e->logits, e->cfg.vocab, *p, e->ctl, e->ids, e->stream));
-        if ((rc = launch_step(e))) return rc;
+        if ((rc = launch_step(e, pos + i))) return rc;
     }
     HIPCK(e, hipMemcpyAsync(ids_out, e->ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCK(e, hipMemcpyAsync(n_recent, s.recent_n, 4, hipMemcpyDeviceToHost, e->stream));
@@ -1736,7 +1837,7 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
             int *c = e->h_ctl_ring + (size_t)i * CTL_WORDS;
             c[CTL_TOKEN] = tokens[i]; c[CTL_POS] = pos0 + i; c[CTL_CHAIN] = 0; c[CTL_STEP] = 0; c[CTL_STREAM] = stream;
             HIPCK(e, hipMemcpyAsync(e->ctl, c, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, e->stream));
-            if ((rc = launch_step(e))) return rc;
+            if ((rc = launch_step(e, pos0 + i))) return rc;
         }
     }
     if (last_logits_out)
@@ -1784,7 +1885,7 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
         int *c = e->h_ctl_ring + (size_t)i * CTL_WORDS;
         c[CTL_TOKEN] = tokens[i]; c[CTL_POS] = pos[i]; c[CTL_CHAIN] = 0; c[CTL_STEP] = 0; c[CTL_STREAM] = streams[i];
         HIPCK(e, hipMemcpyAsync(e->ctl, c, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, e->stream));
-        if ((rc = launch_step(e))) return rc;
+        if ((rc = launch_step(e, pos[i]))) return rc;
         if (logits_out)
             HIPCK(e, hipMemcpyAsync(logits_out + (size_t)i * e->cfg.vocab, e->logits, (size_t)e->cfg.vocab * 4,
                                     hipMemcpyDeviceToHost, e->stream));
@@ -1830,9 +1931,10 @@ int nl_profile_forward(nl_handle e, int stream, int token, int pos, int iters, f
     for (int k = 0; k < NL_NUM_KINDS; k++) { ms_out[k] = 0.f; calls_out[k] = 0; }
     if ((rc = note_positions(e, stream, pos, 1))) return rc;
     if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
-    if ((rc = run_plan_eager(e))) return rc;
+    const nl_engine::PlanSet &S = pick_plan(e, pos);   // the plan a step at this position runs
+    if ((rc = run_plan_eager(e, S))) return rc;
     HIPCK(e, hipStreamSynchronize(e->stream));
-    for (const Op &op : e->plan) {
+    for (const Op &op : S.ops) {
         HIPCK(e, hipEventRecord(e->ev0, e->stream));
         for (int it = 0; it < iters; it++) {
             hipError_t s = op.fn(e->stream);
@@ -1898,6 +2000,15 @@ int nl_debug_stamps(nl_handle e, int kind, long long *out /* 16 waves x 8 */) {
         GemvParams P = base_params(e, L.down);
         P.x = e->hb; P.out = e->x[1]; P.resid = e->x[1]; P.dbg = d;
         s = launch_gemv_t<PRO_PLAIN, EPI_RESID>(L.down.wtype, P, e->stream);
+    } else if (kind == K_ATTNBLOCK && e->fused) {
+        // layer 0's block launch as the plan holds it, with phase stamps (position / stream as ctl has them)
+        for (const Op &op : e->ps[1].ops)
+            if (op.kind == K_ATTNBLOCK) {
+                e->dbg_block = d;
+                s = op.fn(e->stream);
+                e->dbg_block = nullptr;
+                break;
+            }
     }
     (void)c;
     if (s != hipSuccess) { hipFree(d); return e->fail(NL_ERR_HIP, "debug launch: %s", hipGetErrorString(s)); }
@@ -2044,7 +2155,7 @@ int nl_group_forward(nl_handle *hs, int n, int stream, int token, int pos, float
             return e0->fail(NL_ERR_INVALID, "nl_group_forward: shard %d is not rank %d of a local group of %d", r, r, n);
         int rc = check_step_args(hs[r], stream, token, pos);
         if (rc) return rc;
-        if (hs[r]->plan.size() != e0->plan.size()) return e0->fail(NL_ERR_STATE, "shards disagree on the launch plan");
+        if (hs[r]->ps[0].ops.size() != e0->ps[0].ops.size()) return e0->fail(NL_ERR_STATE, "shards disagree on the launch plan");
         if (hs[r]->dev != e0->dev) return e0->fail(NL_ERR_UNSUPPORTED, "local group across devices is not implemented");
     }
     HIPCK(e0, hipSetDevice(e0->dev));
@@ -2056,15 +2167,15 @@ int nl_group_forward(nl_handle *hs, int n, int stream, int token, int pos, float
         e->h_ctl[CTL_STEP] = 0; e->h_ctl[CTL_STREAM] = stream;
         HIPCK(e0, hipMemcpyAsync(e->ctl, e->h_ctl, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
     }
-    for (size_t i = 0; i < e0->plan.size(); i++) {
+    for (size_t i = 0; i < e0->ps[0].ops.size(); i++) {
         for (int r = 0; r < n; r++) {
-            hipError_t s = hs[r]->plan[i].fn(st);
-            if (s != hipSuccess) return e0->fail(NL_ERR_HIP, "group launch %s: %s", kKindNames[e0->plan[i].kind], hipGetErrorString(s));
+            hipError_t s = hs[r]->ps[0].ops[i].fn(st);
+            if (s != hipSuccess) return e0->fail(NL_ERR_HIP, "group launch %s: %s", kKindNames[e0->ps[0].ops[i].kind], hipGetErrorString(s));
         }
-        const Op &op = e0->plan[i];
+        const Op &op = e0->ps[0].ops[i];
         if (op.coll == 1) {
             PtrList8 pl{};
-            for (int r = 0; r < n; r++) pl.p[r] = hs[r]->plan[i].buf;
+            for (int r = 0; r < n; r++) pl.p[r] = hs[r]->ps[0].ops[i].buf;
             int cnt = (int)op.count;
             hipLaunchKernelGGL(local_allreduce_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, pl, n, cnt);
             HIPCK(e0, hipGetLastError());
@@ -2072,8 +2183,8 @@ int nl_group_forward(nl_handle *hs, int n, int stream, int token, int pos, float
             for (int src = 0; src < n; src++)
                 for (int dst = 0; dst < n; dst++)
                     if (src != dst)
-                        HIPCK(e0, hipMemcpyAsync(hs[dst]->plan[i].buf + (size_t)src * op.count,
-                                                 hs[src]->plan[i].buf + (size_t)src * op.count, op.count * 4,
+                        HIPCK(e0, hipMemcpyAsync(hs[dst]->ps[0].ops[i].buf + (size_t)src * op.count,
+                                                 hs[src]->ps[0].ops[i].buf + (size_t)src * op.count, op.count * 4,
                                                  hipMemcpyDeviceToDevice, st));
         }
     }

@@ -35,7 +35,8 @@ constexpr int CTL_TOKEN = 0, CTL_POS = 1, CTL_CHAIN = 2, CTL_STEP = 3, CTL_STREA
 // int8, same fp16 d); Q6_K to WT_Q6_K = int8 (6-bit value - 32) with four int8 sub-scales per 64 columns;
 // Q4_K keeps its nibbles with an 8-byte {d, dmin, sc0, m0, sc1, m1} entry per 64 columns.
 enum { WT_F32 = 0, WT_F16 = 1, WT_Q4_0 = 2, WT_Q5_0 = 6, WT_Q8_0 = 8, WT_Q4_K = 12, WT_Q6_K = 14 };
-enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_ATTN = 2 };
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_ATTN = 2, PRO_NORM_PARTS = 3 };
+constexpr int MAX_PARTS = 12;     // PRO_NORM_PARTS: partial vectors added to x (one per attention head, nl_block.h)
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3, EPI_P2P = 4 };
 enum { ROWMAP_IDENT = 0, ROWMAP_HEADPERM = 1 };
 
@@ -433,6 +434,9 @@ struct GemvParams {
     int p2p_n;
     unsigned p2p_seam;
     float *peer_out[8];
+    // PRO_NORM_PARTS: x + sum_p parts[p][.] is the input (fixed order p = 0..nparts-1); block 0 stores it to x_out
+    const float *parts;
+    int nparts;
 };
 
 // ---- cross-lane helpers on DPP (hipcc lowers __shfl_xor to ds_bpermute: ~100+ cycles a hop) ----
@@ -509,7 +513,7 @@ __device__ __forceinline__ float4 load_x4(const GemvParams &P, int gcol, unsigne
         return make_float4(v.x * il, v.y * il, v.z * il, v.w * il);
     }
     float4 v = *reinterpret_cast<const float4 *>((P.x + gcol) + lcol);
-    if (PRO == PRO_NORM) g = *reinterpret_cast<const float4 *>((P.normw + gcol) + lcol);
+    if (PRO == PRO_NORM || PRO == PRO_NORM_PARTS) g = *reinterpret_cast<const float4 *>((P.normw + gcol) + lcol);
     // optional addend (gamma row / tensor-parallel residual): always LOADED (from x itself when absent: same
     // cache line, the launcher resolves
     // the pointer so there is no select here for hipcc to turn back into a branch) and handed back; the caller adds it when it consumes x, after every load of the round is out
@@ -605,6 +609,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     auto round = [&](auto nf_tag, int g0) {
         constexpr int NFR = decltype(nf_tag)::value;
         float4 xv[NFR], gv[NFR], av[NFR];
+        float4 pv[NFR][PRO == PRO_NORM_PARTS ? MAX_PARTS : 1];
         uint4 cw[NFR][CPP];
         uint2 sw[NFR];
         bool lv[NFR], inb[NFR];
@@ -613,6 +618,12 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
             const int gcol = (g0 + f * P.kw) * (KL * PAIR);
             inb[f] = gcol + lane * 4 < P.cols;
             xv[f] = load_x4<PRO>(P, gcol, inb[f] ? (unsigned)lane * 4u : 0u, gv[f], av[f], ns);
+            if (PRO == PRO_NORM_PARTS) {
+                // all MAX_PARTS loads are issued (clamped part index: no branch around a load), surplus ones are masked at the add
+#pragma unroll
+                for (int p = 0; p < MAX_PARTS; p++)
+                    pv[f][p] = *reinterpret_cast<const float4 *>((P.parts + (size_t)min(p, P.nparts - 1) * P.cols + gcol) + (inb[f] ? (unsigned)lane * 4u : 0u));
+            }
         }
 #pragma unroll
         for (int f = 0; f < NFR; f++) {
@@ -625,9 +636,17 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
         for (int f = 0; f < NFR; f++) {
             const int g = g0 + f * P.kw;
             float4 xa = xv[f];
-            if (PRO != PRO_ATTN && P.add) { xa.x += av[f].x; xa.y += av[f].y; xa.z += av[f].z; xa.w += av[f].w; }
+            if (PRO != PRO_ATTN && PRO != PRO_NORM_PARTS && P.add) { xa.x += av[f].x; xa.y += av[f].y; xa.z += av[f].z; xa.w += av[f].w; }
+            if (PRO == PRO_NORM_PARTS) {
+#pragma unroll
+                for (int p = 0; p < MAX_PARTS; p++) {
+                    const bool on = p < P.nparts;
+                    xa.x += on ? pv[f][p].x : 0.f; xa.y += on ? pv[f][p].y : 0.f;
+                    xa.z += on ? pv[f][p].z : 0.f; xa.w += on ? pv[f][p].w : 0.f;
+                }
+            }
             if (!inb[f]) xa = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (PRO == PRO_NORM) {
+            if (PRO == PRO_NORM || PRO == PRO_NORM_PARTS) {
                 // RMSNormInto go/quant.go:597-607.  inv = 1/sqrt(mean(x^2)+eps) multiplies the GEMV OUTPUT
                 // (out = inv * sum_j w_ij (x_j g_j)), so its float64 reduction is off the critical path.
                 if (tin == 0 && msel == 0) {
@@ -657,7 +676,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     // the 4 pair-lanes of a row form a quad
     acc0 = quad_sum(acc0);
     if (k == 0) red[wave * TR + r] = acc0;
-    if (PRO == PRO_NORM && tin == 0 && msel == 0) {
+    if ((PRO == PRO_NORM || PRO == PRO_NORM_PARTS) && tin == 0 && msel == 0) {
         ss = wave_sum_f64(ss);
         if (lane == 0) dred[kw] = ss;
     }
@@ -674,7 +693,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
             v += red[(e_tin * wpt + j) * TR + rr];
             if (EPI == EPI_SWIGLU) v1 += red[(e_tin * wpt + P.kw + j) * TR + rr];
         }
-    if (PRO == PRO_NORM) {
+    if (PRO == PRO_NORM || PRO == PRO_NORM_PARTS) {
         double tot = 0.0;
         for (int w = 0; w < P.kw; w++) tot += dred[w];
         float inv = (float)(1.0 / sqrt(tot / (double)P.cols + (double)P.eps));
@@ -1162,6 +1181,7 @@ __global__ void __launch_bounds__(1024) argmax_embed_kernel(ArgmaxParams P, Embe
             P.ctl[CTL_TOKEN] = idx;
             P.ctl[CTL_POS] = P.ctl[CTL_POS] + 1;
         }
+        if (E.epoch) *E.epoch = *E.epoch + 1;   // this embedding opens the next Forward
     }
     __syncthreads();
     const int token = tok;

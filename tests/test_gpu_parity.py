@@ -972,3 +972,67 @@ def test_sampling_paths_are_well_formed(hip):
     eng.generate_ids([1, 5, 6], GenParams(max_tokens=20, temperature=0.5))
     assert eng.last_tokens == 8
     dev.close()
+
+
+# ---- fused attention block (nanollama_amd/csrc/nl_block.h): small models, short contexts -------------------------
+
+def _kinds(dev, pos):
+    return {k: c for k, (ms, c) in dev.profile_forward(5, pos, iters=1).items() if c}
+
+
+@pytest.mark.parametrize("wtype", ["q8_0", "q4_0"])
+@pytest.mark.parametrize("variant", ["mha", "gqa", "qknorm_conj_bias"])
+def test_fused_attention_block_matches_oracle(hip, orc, tmp_path, monkeypatch, wtype, variant):
+    # one launch per layer for RMSNorm + Q/K/V + RoPE + KV store + attention + WO (go/model.go:517-594) against the
+    # CPU oracle, teacher-forced across the 128-position pass boundary (NL_FUSED_MAX_POS lifted so the block runs at
+    # every position), for MHA, a GQA group of 2 and the optional QK-norm / conjugate RoPE / bias branches
+    shape = {"mha": synth.ModelShape("fb_mha", 3, 192, 3, 3, 1024, seq_len=160),
+             "gqa": synth.ModelShape("fb_gqa", 2, 256, 4, 2, 512, seq_len=160, interm=512),
+             "qknorm_conj_bias": synth.ModelShape("fb_var", 2, 256, 4, 2, 512, seq_len=160, interm=512, qk_norm=True,
+                                                  rope_conjugate=True, attn_bias=True)}[variant]
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, wtype, 61)
+    g = gguf.load_gguf(str(p))
+    monkeypatch.setenv("NL_FUSED_MAX_POS", "4096")
+    dev = hip.load_llama_model(g)
+    monkeypatch.setenv("NL_FUSED_ATTN", "0")
+    plain = hip.load_llama_model(g)
+    ref = orc.OracleModel(g)
+    toks = synth.prompt_ids(150, shape.vocab, seed=21)
+    worst = gap = 0.0
+    for pos, t in enumerate(toks):
+        dev.forward(t, pos)
+        plain.forward(t, pos)
+        want = ref.forward(t, pos)
+        worst = max(worst, float(np.abs(dev.state.logits - want).max()) / max(1.0, float(want.std())))
+        gap = max(gap, float(np.abs(dev.state.logits - plain.state.logits).max()))
+    print(f"\nfused block {variant}/{wtype}: max|gpu-oracle|={worst:.2e}, max|fused-unfused|={gap:.2e}")
+    assert worst <= LOGIT_TOL
+    k = _kinds(dev, 20)
+    assert k.get("attn_block") == shape.n_layer and "qkv_rope" not in k and "wo_resid" not in k, k
+    assert "attn_block" not in _kinds(plain, 20)
+    # the K/V rows the block stored are the ones the five-launch plan stores
+    n = shape.n_layer * shape.n_kv_head * shape.seq_len * 64
+    for which in ("k_cache", "v_cache"):
+        a, b = dev.debug_read(which, n).reshape(-1, shape.seq_len, 64), plain.debug_read(which, n).reshape(-1, shape.seq_len, 64)
+        assert np.abs(a[:, :149] - b[:, :149]).max() <= 2e-5
+    dev.close(); plain.close(); ref.close()
+
+
+def test_greedy_chain_switches_from_the_fused_plan_to_the_split_attention_plan(hip, orc, tmp_path):
+    # the block serves positions below NL_FUSED_MAX_POS (default 256); a chained greedy run that crosses it keeps
+    # producing the oracle's ids (16-step graphs of either plan, single steps at the seam)
+    shape = synth.ModelShape("fb_switch", 2, 192, 3, 3, 1024, seq_len=320)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 71)
+    g = gguf.load_gguf(str(p))
+    dev = hip.load_llama_model(g)
+    ref = orc.OracleModel(g)
+    prompt = synth.prompt_ids(200, shape.vocab, seed=3)
+    want, _ = ref.generate_greedy(prompt, 100)
+    dev.prefill(prompt)
+    first = int(np.argmax(dev.state.logits))
+    got = [first] + dev.decode_greedy(first, len(prompt), 99)
+    assert got == want
+    assert "attn_block" in _kinds(dev, 100) and "attn_block" not in _kinds(dev, 300)
+    dev.close(); ref.close()
