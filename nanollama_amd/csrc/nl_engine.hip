@@ -14,6 +14,7 @@
 #include "nl_sample.h"
 #include "nl_p2p.h"
 #include "nl_block.h"
+#include "nl_group.h"
 
 #include <dlfcn.h>
 #include <algorithm>
@@ -198,6 +199,8 @@ struct nl_engine {
         hipGraphExec_t multi_exec = nullptr;  // (one inter-graph gap per graph_steps tokens instead of per token)
     } ps[2];
     bool fused = false;           // ps[1] exists
+    int fused_mode = 0;           // 1: whole attention half per layer (nl_block.h); 2: projection + attention (nl_group.h)
+    int grp_tpm = 1;              // mode 2: 16-row tiles per workgroup
     int fused_max_pos = 0;        // ps[1] serves steps whose position is below this
     float *parts = nullptr;       // [Hs][D] per-head WO partials of the fused block
     unsigned long long *xchg = nullptr;   // [Hs][192] granules exchanged inside a head's cluster
@@ -342,12 +345,20 @@ void choose_geometry(const nl_engine *e, const PackedMat &m, int &tw, int &kw, i
     if (tw > m.ntiles) tw = m.ntiles;
 }
 
-template <int PRO, int EPI>
+template <int PRO, int EPI, int NP = 1>
 hipError_t launch_gemv_t(int wtype, GemvParams P, hipStream_t st) {
     P.add_src = P.add ? P.add : P.x;   // PRO_ATTN kernels never read it
     const int nwaves = P.tw * P.kw * (EPI == EPI_SWIGLU ? 2 : 1);
     const size_t lds = (size_t)nwaves * XS_WAVE * 4 + (size_t)nwaves * TR * 4 + (size_t)nwaves * 8;
     const dim3 grid((P.ntiles + P.tw - 1) / P.tw), block(nwaves * 64);
+    if constexpr (PRO == PRO_NORM_PARTS) {   // consumer of the fused attention block: Q8_0 / Q4_0 models only
+        switch (wtype) {
+        case WT_Q8_0: hipLaunchKernelGGL((gemv_kernel<WT_Q8_0, PRO, EPI, NP>), grid, block, lds, st, P); break;
+        case WT_Q4_0: hipLaunchKernelGGL((gemv_kernel<WT_Q4_0, PRO, EPI, NP>), grid, block, lds, st, P); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    } else {
     switch (wtype) {
     case WT_Q8_0: hipLaunchKernelGGL((gemv_kernel<WT_Q8_0, PRO, EPI>), grid, block, lds, st, P); break;
     case WT_Q4_0: hipLaunchKernelGGL((gemv_kernel<WT_Q4_0, PRO, EPI>), grid, block, lds, st, P); break;
@@ -358,6 +369,7 @@ hipError_t launch_gemv_t(int wtype, GemvParams P, hipStream_t st) {
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+    }
 }
 
 GemvParams base_params(const nl_engine *e, const PackedMat &m, int mats = 1) {
@@ -436,7 +448,11 @@ hipError_t launch_gemv_dyn(int wt, int pro, int epi, const GemvParams &P, hipStr
     if (pro == PRO_PLAIN && epi == EPI_RESID) return launch_gemv_t<PRO_PLAIN, EPI_RESID>(wt, P, st);
     if (pro == PRO_PLAIN && epi == EPI_STORE) return launch_gemv_t<PRO_PLAIN, EPI_STORE>(wt, P, st);
     if (pro == PRO_NORM && epi == EPI_STORE) return launch_gemv_t<PRO_NORM, EPI_STORE>(wt, P, st);
-    if (pro == PRO_NORM_PARTS && epi == EPI_SWIGLU) return launch_gemv_t<PRO_NORM_PARTS, EPI_SWIGLU>(wt, P, st);
+    if (pro == PRO_NORM_PARTS && epi == EPI_SWIGLU) {   // exactly as many part loads as heads, for the common head counts
+        if (P.nparts <= 4) return launch_gemv_t<PRO_NORM_PARTS, EPI_SWIGLU, 4>(wt, P, st);
+        if (P.nparts <= 9) return launch_gemv_t<PRO_NORM_PARTS, EPI_SWIGLU, 9>(wt, P, st);
+        return launch_gemv_t<PRO_NORM_PARTS, EPI_SWIGLU, MAX_PARTS>(wt, P, st);
+    }
     if (pro == PRO_ATTN && epi == EPI_P2P) return launch_gemv_t<PRO_ATTN, EPI_P2P>(wt, P, st);
     if (pro == PRO_PLAIN && epi == EPI_P2P) return launch_gemv_t<PRO_PLAIN, EPI_P2P>(wt, P, st);
     return hipErrorInvalidValue;
@@ -506,7 +522,7 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         float *kc = e->kcache + (long long)l * e->kv_layer_stride;
         float *vc = e->vcache + (long long)l * e->kv_layer_stride;
         bool parts_pending = false;
-        if (fused) {
+        if (fused && e->fused_mode == 1) {
             // the whole attention half as one launch per layer (nl_block.h); its H partial vectors are added to the
             // residual stream by the gate/up prologue below
             BlockParams B{};
@@ -527,6 +543,31 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
                                    return hipGetLastError();
                                }});
             parts_pending = true;
+        } else {
+        if (fused && e->fused_mode == 2) {
+            // projection + RoPE + KV store + attention as one launch (nl_group.h); WO below consumes its partials
+            GroupParams B{};
+            B.qkv_q = L.qkv.q; B.qkv_s = L.qkv.s;
+            B.D = c.dim; B.npairs = L.qkv.npairs; B.n_q_heads = e->Hs; B.n_kv_heads = e->KVs; B.seq_len = c.seq_len;
+            B.rope_conj = c.rope_conjugate; B.qk_norm = c.qk_norm; B.single_stream = c.max_streams == 1 ? 1 : 0;
+            B.tpm = e->grp_tpm; B.members = (e->gqa + 2) * 4 / e->grp_tpm;
+            B.x = e->x[cur]; B.normw = L.attn_norm; B.eps = c.rms_eps; B.scale = (float)(1.0 / std::sqrt((double)e->hd));
+            B.rope_cos = e->rope_cos; B.rope_sin = e->rope_sin; B.kcache = kc; B.vcache = vc;
+            B.kv_stream_stride = e->kv_stream_stride; B.ctl = e->ctl;
+            B.bias_q = L.bq; B.bias_k = L.bk; B.bias_v = L.bv;
+            B.part_o = e->part_o; B.part_ml = e->part_ml; B.nsplit_max = e->nsplit_max;
+            B.xchg = e->xchg; B.tick = p2p ? e->p2p.epoch : e->tick; B.layer_tag = (unsigned)(l + 1);
+            B.status = e->tick + 1; B.host_status = e->h_status;
+            const int wt = L.qkv.wtype, grid = grp_grid(e->KVs, B.members);
+            const int ngroups = (L.qkv.npairs + KL - 1) / KL, nf = (ngroups + 16 / e->grp_tpm - 1) / (16 / e->grp_tpm);
+            plan.push_back({K_ATTNBLOCK, 0, nullptr, 0, [B, wt, grid, nf](hipStream_t st) {
+                                   const size_t lds = grp_lds_bytes();
+                                   if (wt == WT_Q8_0 && nf == 1) hipLaunchKernelGGL((qkv_attn_kernel<WT_Q8_0, 1>), dim3(grid), dim3(GRP_THREADS), lds, st, B);
+                                   else if (wt == WT_Q8_0) hipLaunchKernelGGL((qkv_attn_kernel<WT_Q8_0, 2>), dim3(grid), dim3(GRP_THREADS), lds, st, B);
+                                   else if (nf == 1) hipLaunchKernelGGL((qkv_attn_kernel<WT_Q4_0, 1>), dim3(grid), dim3(GRP_THREADS), lds, st, B);
+                                   else hipLaunchKernelGGL((qkv_attn_kernel<WT_Q4_0, 2>), dim3(grid), dim3(GRP_THREADS), lds, st, B);
+                                   return hipGetLastError();
+                               }});
         } else {
         {   // RMSNorm + Q,K,V GEMV + RoPE + KV store   (go/model.go:517-554)
             GemvParams P = base_params(e, L.qkv);
@@ -557,6 +598,7 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
             plan.push_back({K_ATTN, 0, nullptr, 0,
                                [hd, gqa, P, grid](hipStream_t st) { return launch_attn(hd, gqa, P, grid, st); }});
         }
+        }   // five-launch projection / attention
         {   // WO + residual (go/model.go:590-594); the prologue merges the attention splits
             GemvParams P = base_params(e, L.wo);
             P.part_o = e->part_o; P.part_ml = e->part_ml;
@@ -1443,21 +1485,33 @@ int nl_finalize(nl_handle e) {
     {
         // fused attention block (nl_block.h): every layer must have its per-head WO slices, and the models it pays
         // for are the ones whose per-head weights are small (see the header of nl_block.h)
-        const char *fa = getenv("NL_FUSED_ATTN");          // knob (tests, tools): 0 keeps the five-launch plan only
-        bool ok = e->G == 1 && !e->force_tp_plan && !(c.flags & NL_FLAG_LOCAL_GROUP) && !(fa && atoi(fa) == 0);
-        for (const auto &L : e->layers)
-            ok = ok && L.wo_head.ready && L.wo_head.wtype == L.qkv.wtype && (L.qkv.wtype == WT_Q8_0 || L.qkv.wtype == WT_Q4_0);
-        e->fused = ok;
+        const char *fa = getenv("NL_FUSED_ATTN");          // knob (tests, tools): 0 keeps the five-launch plan only, 2 forces mode 2
+        const int want = fa ? atoi(fa) : -1;
+        const bool base_ok = !(c.flags & NL_FLAG_LOCAL_GROUP) && want != 0 && e->hd == 64;
+        bool ok1 = base_ok && want != 2 && e->G == 1 && !e->force_tp_plan && c.dim % (BLK_MEMBERS * TR) == 0 && c.n_layers < 255;
+        // (an RCCL plan carries the all-reduced partial into the next projection's prologue, which the fused launch lacks)
+        bool ok2 = base_ok && c.n_layers < 255 && ((e->G == 1 && !e->force_tp_plan) || e->p2p.on);
+        for (const auto &L : e->layers) {
+            ok1 = ok1 && L.wo_head.ready && L.wo_head.wtype == L.qkv.wtype && (L.qkv.wtype == WT_Q8_0 || L.qkv.wtype == WT_Q4_0);
+            ok2 = ok2 && (L.qkv.wtype == WT_Q8_0 || L.qkv.wtype == WT_Q4_0);
+        }
+        if (ok2 && !ok1) {
+            // tiles per workgroup: as few as keeps every workgroup of the launch resident at once (one per compute unit)
+            const int NT = (e->gqa + 2) * 4, ngroups = ((c.dim + PAIR - 1) / PAIR + KL - 1) / KL;
+            int tpm = 1;
+            while (tpm <= 4 && e->KVs * NT / tpm > 224) tpm *= 2;
+            ok2 = tpm <= 4 && NT % tpm == 0 && NT / tpm >= e->gqa && ngroups <= 2 * (16 / tpm);
+            e->grp_tpm = tpm;
+        }
+        e->fused_mode = ok1 ? 1 : ok2 ? 2 : 0;
+        e->fused = e->fused_mode != 0;
         const char *fm = getenv("NL_FUSED_MAX_POS");
         e->fused_max_pos = fm ? atoi(fm) : 256;
         if (e->fused) {
-            ok = c.dim % (BLK_MEMBERS * TR) == 0 && c.n_layers < 255;
-            e->fused = ok;
-        }
-        if (e->fused) {
-            HIPCK(e, dalloc(&e->parts, (size_t)e->Hs * c.dim, &e->bytes_state));
-            HIPCK(e, dalloc(&e->xchg, (size_t)e->Hs * 192, &e->bytes_state));
-            HIPCK(e, hipMemset(e->xchg, 0, (size_t)e->Hs * 192 * 8));
+            if (e->fused_mode == 1) HIPCK(e, dalloc(&e->parts, (size_t)e->Hs * c.dim, &e->bytes_state));
+            const size_t nx = e->fused_mode == 1 ? (size_t)e->Hs * 192 : (size_t)e->KVs * (e->gqa + 2) * 64;
+            HIPCK(e, dalloc(&e->xchg, nx, &e->bytes_state));
+            HIPCK(e, hipMemset(e->xchg, 0, nx * 8));
             HIPCK(e, dalloc(&e->tick, (size_t)2, &e->bytes_state));
             HIPCK(e, hipMemset(e->tick, 0, 8));
             HIPCK(e, hipHostMalloc((void **)&e->h_status, sizeof(unsigned), hipHostMallocMapped));

@@ -542,7 +542,7 @@ __device__ __forceinline__ void load_pair(const uint8_t *q, const uint32_t *s, l
 //   issue {x slice, norm weights, weight chunks, scales} together  ->  one memory latency
 //   x*g -> wave-private LDS (no workgroup barrier) -> 128 cvt + 128 fma per lane (8 chains)
 //   quad DPP adds -> LDS -> ONE workgroup barrier -> epilogue (inputs prefetched at entry).
-template <int WT, int PRO, int EPI>
+template <int WT, int PRO, int EPI, int NP = 1>   // NP: partial vectors fetched per x element (PRO_NORM_PARTS)
 __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CPP = WTraits<WT>::CPP;
@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     auto round = [&](auto nf_tag, int g0) {
         constexpr int NFR = decltype(nf_tag)::value;
         float4 xv[NFR], gv[NFR], av[NFR];
-        float4 pv[NFR][PRO == PRO_NORM_PARTS ? MAX_PARTS : 1];
+        float4 pv[NFR][NP];
         uint4 cw[NFR][CPP];
         uint2 sw[NFR];
         bool lv[NFR], inb[NFR];
@@ -619,9 +619,9 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
             inb[f] = gcol + lane * 4 < P.cols;
             xv[f] = load_x4<PRO>(P, gcol, inb[f] ? (unsigned)lane * 4u : 0u, gv[f], av[f], ns);
             if (PRO == PRO_NORM_PARTS) {
-                // all MAX_PARTS loads are issued (clamped part index: no branch around a load), surplus ones are masked at the add
+                // all NP loads are issued (clamped part index: no branch around a load), surplus ones are masked at the add
 #pragma unroll
-                for (int p = 0; p < MAX_PARTS; p++)
+                for (int p = 0; p < NP; p++)
                     pv[f][p] = *reinterpret_cast<const float4 *>((P.parts + (size_t)min(p, P.nparts - 1) * P.cols + gcol) + (inb[f] ? (unsigned)lane * 4u : 0u));
             }
         }
@@ -639,7 +639,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
             if (PRO != PRO_ATTN && PRO != PRO_NORM_PARTS && P.add) { xa.x += av[f].x; xa.y += av[f].y; xa.z += av[f].z; xa.w += av[f].w; }
             if (PRO == PRO_NORM_PARTS) {
 #pragma unroll
-                for (int p = 0; p < MAX_PARTS; p++) {
+                for (int p = 0; p < NP; p++) {
                     const bool on = p < P.nparts;
                     xa.x += on ? pv[f][p].x : 0.f; xa.y += on ? pv[f][p].y : 0.f;
                     xa.z += on ? pv[f][p].z : 0.f; xa.w += on ? pv[f][p].w : 0.f;

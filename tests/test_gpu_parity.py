@@ -1036,3 +1036,48 @@ def test_greedy_chain_switches_from_the_fused_plan_to_the_split_attention_plan(h
     assert got == want
     assert "attn_block" in _kinds(dev, 100) and "attn_block" not in _kinds(dev, 300)
     dev.close(); ref.close()
+
+
+@pytest.mark.parametrize("variant,wtype", [("g4", "q4_0"), ("g4", "q8_0"), ("g8", "q4_0"), ("mha16", "q4_0"),
+                                           ("g4_two_tiles", "q4_0"), ("g4_qknorm_conj_bias", "q8_0")])
+def test_fused_projection_attention_launch_matches_oracle(hip, orc, tmp_path, monkeypatch, variant, wtype):
+    # nl_group.h: Q/K/V + RoPE + KV store + attention as one launch for models too wide for the per-head block
+    # (clusters of workgroups per kv group, granule exchange, G attention workgroups), against the oracle across the
+    # 128-position pass boundary; "g4_two_tiles" is wide enough that a workgroup holds two tiles and a wavefront two
+    # column groups (the 7.9B tier's geometry)
+    shape = {"g4": synth.ModelShape("fg_g4", 2, 1024, 16, 4, 512, seq_len=160, interm=1024),
+             "g8": synth.ModelShape("fg_g8", 2, 1024, 16, 2, 512, seq_len=160, interm=1024),
+             "mha16": synth.ModelShape("fg_mha", 2, 1024, 16, 16, 512, seq_len=160, interm=1024),
+             "g4_two_tiles": synth.ModelShape("fg_wide", 2, 2560, 40, 10, 512, seq_len=160, interm=1024),
+             "g4_qknorm_conj_bias": synth.ModelShape("fg_var", 2, 1024, 16, 4, 512, seq_len=160, interm=1024, qk_norm=True,
+                                                     rope_conjugate=True, attn_bias=True)}[variant]
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, wtype, 63, mode="qrand")
+    g = gguf.load_gguf(str(p))
+    monkeypatch.setenv("NL_FUSED_MAX_POS", "4096")
+    dev = hip.load_llama_model(g)
+    monkeypatch.setenv("NL_FUSED_ATTN", "0")
+    plain = hip.load_llama_model(g)
+    ref = orc.OracleModel(g)
+    orc.set_threads(min(16, os.cpu_count() or 1))
+    toks = synth.prompt_ids(140, shape.vocab, seed=23)
+    worst = gap = 0.0
+    for pos, t in enumerate(toks):
+        dev.forward(t, pos)
+        plain.forward(t, pos)
+        want = ref.forward(t, pos)
+        worst = max(worst, float(np.abs(dev.state.logits - want).max()) / max(1.0, float(want.std())))
+        gap = max(gap, float(np.abs(dev.state.logits - plain.state.logits).max()))
+    orc.set_threads(1)
+    print(f"\nfused projection+attention {variant}/{wtype}: max|gpu-oracle|={worst:.2e}, max|fused-unfused|={gap:.2e}")
+    assert worst <= LOGIT_TOL
+    k = _kinds(dev, 20)
+    assert k.get("attn_block") == shape.n_layer and "qkv_rope" not in k and "attention" not in k and k.get("wo_resid") == shape.n_layer, k
+    assert "attn_block" not in _kinds(plain, 20)      # (both engines now hold the probe's row 20)
+    n = shape.n_layer * shape.n_kv_head * shape.seq_len * 64
+    for which in ("k_cache", "v_cache"):
+        a, b = dev.debug_read(which, n).reshape(-1, shape.seq_len, 64), plain.debug_read(which, n).reshape(-1, shape.seq_len, 64)
+        assert np.abs(a[:, :139] - b[:, :139]).max() <= 2e-5
+    first = int(np.argmax(dev.state.logits))
+    assert dev.decode_greedy(first, 140, 16) == plain.decode_greedy(first, 140, 16)
+    dev.close(); plain.close(); ref.close()
