@@ -1,0 +1,12 @@
+//go:build !hip
+
+// hip_stub.go -- the pure-Go build: no device backend, the hooks of model_hip.patch are dead code.
+package main
+
+const hipEnabled = false
+
+type hipBackend struct{}
+
+func loadHIP(gguf *GGUFFile, cfg *LlamaConfig, device int) (*hipBackend, error) { return nil, nil }
+func (m *LlamaModel) forwardHIP(token, pos int)                                 {}
+func (m *LlamaModel) resetHIP()                                                 {}

@@ -9,7 +9,8 @@ import textwrap
 import numpy as np
 import pytest
 
-from nanollama_amd import gguf, quant, synth, tp
+from nanollama_amd import gguf, quant, synth
+import tp_plan as tp
 from oracle import oracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

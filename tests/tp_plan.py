@@ -1,5 +1,7 @@
-"""Tensor-parallel shard plan -- the host-side statement of the slicing that
-nl_upload_tensor applies on the device (nanollama_amd/csrc/nl_engine.hip, matrix_upload call sites).
+"""TEST INFRASTRUCTURE: the tensor-parallel shard plan restated on the host, so the CPU tests can
+check with the oracle's GEMVs that such slices reproduce the full products.  The product slices on the device
+(nl_upload_tensor -> matrix_upload call sites in nanollama_amd/csrc/nl_engine.hip); its results are checked on the GPU
+against the single-GPU engine and the oracle (tests/test_gpu_parity.py, tests/test_gpu_p2p.py).
 
   attn_q / attn_k / attn_v : rows of this rank's heads (GQA groups stay local)
   attn_output              : COLUMNS of this rank's heads   -> partial [D], all-reduce(sum)
@@ -16,7 +18,7 @@ from typing import Dict, Tuple
 
 import numpy as np
 
-from .gguf import ggml_block_elements, ggml_block_size
+from nanollama_amd.gguf import ggml_block_elements, ggml_block_size
 
 
 @dataclass(frozen=True)
