@@ -133,7 +133,7 @@ NL_API int nl_sample_decode(nl_handle h, int stream, int pos, int n_steps, const
 
 /* Prompt prefill (go/main.go:160-166 feeds the prompt token-at-a-time through Forward): runs
  * tokens[0..n) at positions pos0..pos0+n-1 of `stream` back to back on the device with no host
- * round trip; last_logits_out (may be NULL) receives the logits after the last token.  Q4_0 / Q8_0
+ * round trip; last_logits_out (may be NULL) receives the logits after the last token.  Q4_0 / Q8_0 / Q5_0 / F16
  * models take the multi-token matrix-core path (up to 2048 tokens per step): the KV
  * cache and logits agree with n nl_forward calls to the stated logit tolerance (1e-4, summation order
  * and an fp16 hi+lo activation split differ), greedy continuations are identical; other formats run
@@ -175,7 +175,7 @@ NL_API int nl_debug_stamps(nl_handle h, int kind, long long *out /* 128 */);
 NL_API int nl_op_matmul(int device, uint32_t ggml_type, const void *w, uint64_t nbytes, const float *x, float *out,
                         int rows, int cols);
 /* The same product for n_tokens input vectors at once through the MFMA path (x: [n_tokens][cols],
- * out: [n_tokens][rows], host pointers); Q4_0 / Q8_0. */
+ * out: [n_tokens][rows], host pointers); Q4_0 / Q8_0 / Q5_0 / F16. */
 NL_API int nl_op_matmul_batch(int device, uint32_t ggml_type, const void *w, uint64_t nbytes, const float *x,
                                float *out, int rows, int cols, int n_tokens);
 /* RMSNormInto (go/quant.go:597-607). */

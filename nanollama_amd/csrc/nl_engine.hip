@@ -876,6 +876,7 @@ hipError_t launch_qgemm_swiglu(int wtype, QGemmParams P, hipStream_t st) {
     switch (wtype) {
     case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0, QG_FUSED_WAVES, 2, QG_EPI_SWIGLU>), grid, dim3(QG_FUSED_WAVES * 64), 0, st, P); break;
     case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0, QG_FUSED_WAVES, 2, QG_EPI_SWIGLU>), grid, dim3(QG_FUSED_WAVES * 64), 0, st, P); break;
+    case WT_F16: hipLaunchKernelGGL((qgemm_kernel<WT_F16, QG_FUSED_WAVES, 2, QG_EPI_SWIGLU>), grid, dim3(QG_FUSED_WAVES * 64), 0, st, P); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -895,6 +896,7 @@ hipError_t launch_qgemm_rope(int wtype, QGemmParams P, hipStream_t st) {
     switch (wtype) {
     case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0, QG_WAVES, 1, QG_EPI_ROPE>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
     case WT_Q8_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q8_0, QG_WAVES, 1, QG_EPI_ROPE>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
+    case WT_F16: hipLaunchKernelGGL((qgemm_kernel<WT_F16, QG_WAVES, 1, QG_EPI_ROPE>), grid, dim3(QG_WAVES * 64), 0, st, P); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -935,13 +937,15 @@ hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_bu
     dim3 grid(row_groups * mats, tok_tiles, ks);
     // a step of <= 16 / 32 tokens fetches and multiplies only the first one / two 16-token tiles of its group
     const int nt = tok_tiles > 1 || P.n_tokens > 32 ? 4 : P.n_tokens > 16 ? 2 : 1;
-    if (wtype != WT_Q4_0 && wtype != WT_Q8_0) return hipErrorInvalidValue;
+    if (wtype != WT_Q4_0 && wtype != WT_Q8_0 && wtype != WT_F16) return hipErrorInvalidValue;
     if (waves == 4) {
         if (wtype == WT_Q4_0) launch_qgemm_nt<WT_Q4_0, 4>(nt, grid, st, P);
-        else launch_qgemm_nt<WT_Q8_0, 4>(nt, grid, st, P);
+        else if (wtype == WT_Q8_0) launch_qgemm_nt<WT_Q8_0, 4>(nt, grid, st, P);
+        else launch_qgemm_nt<WT_F16, 4>(nt, grid, st, P);
     } else {
         if (wtype == WT_Q4_0) launch_qgemm_nt<WT_Q4_0, QG_WAVES>(nt, grid, st, P);
-        else launch_qgemm_nt<WT_Q8_0, QG_WAVES>(nt, grid, st, P);
+        else if (wtype == WT_Q8_0) launch_qgemm_nt<WT_Q8_0, QG_WAVES>(nt, grid, st, P);
+        else launch_qgemm_nt<WT_F16, QG_WAVES>(nt, grid, st, P);
     }
     hipError_t s = hipGetLastError();
     if (ks_out) { *ks_out = ks; return s; }     // the consumer kernel adds the slabs (GemmOut, nl_batch.h)
@@ -962,7 +966,7 @@ const int NL_BATCH_MIN = getenv("NL_BATCH_MIN") ? atoi(getenv("NL_BATCH_MIN")) :
 
 bool batch_supported(const nl_engine *e) {
     if (e->G != 1 || e->force_tp_plan) return false;
-    auto ok = [](const PackedMat &m) { return m.wtype == WT_Q4_0 || m.wtype == WT_Q8_0; };
+    auto ok = [](const PackedMat &m) { return m.wtype == WT_Q4_0 || m.wtype == WT_Q8_0 || m.wtype == WT_F16; };
     for (const auto &L : e->layers)
         if (!ok(L.qkv) || !ok(L.wo) || !ok(L.gate) || !ok(L.up) || !ok(L.down)) return false;
     return ok(e->lm_head) && !getenv("NL_NO_BATCH_PATH");
@@ -2124,7 +2128,7 @@ int nl_op_matmul(int device, uint32_t type, const void *w, uint64_t nbytes, cons
 int nl_op_matmul_batch(int device, uint32_t type, const void *w, uint64_t nbytes, const float *x, float *out,
                        int rows, int cols, int n_tokens) {
     if (!w || !x || !out || rows <= 0 || cols <= 0 || cols % 32 || n_tokens <= 0) return NL_ERR_INVALID;
-    if (device_type((int)type) != WT_Q4_0 && device_type((int)type) != WT_Q8_0) return NL_ERR_UNSUPPORTED;
+    if (device_type((int)type) != WT_Q4_0 && device_type((int)type) != WT_Q8_0 && type != WT_F16) return NL_ERR_UNSUPPORTED;
     if (raw_bytes(type, (uint64_t)rows * cols) != nbytes) return NL_ERR_INVALID;
     if (hipSetDevice(device) != hipSuccess) return NL_ERR_HIP;
     nl_engine tmp;

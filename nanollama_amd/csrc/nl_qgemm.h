@@ -148,6 +148,18 @@ template <> struct WFrag<WT_Q8_0> {
     }
 };
 
+template <> struct WFrag<WT_F16> {
+    typedef uint4 raw_t;
+    // F16 weights (go/quant.go:527-563) are their own exact fp16 operand: no quants, no scale.  A pair is 8 chunks of 8
+    // halves; block 2p+h = chunks 4h..4h+3, and lane (row i, slot group w) reads chunk 4h+w whole:
+    //   q + ((tile*npairs + g*KL)*8*TR + ((4h + w)*TR + i)*gsz + k)*16
+    static constexpr int CPP = 8;
+    static __device__ __forceinline__ unsigned lane_off(int i, int w, int gsz) { return (unsigned)((w * TR + i) * gsz) * 16u; }
+    static __device__ __forceinline__ unsigned blk_off(int odd, int k, int gsz) { return (unsigned)(odd * 4 * TR * gsz + k) * 16u; }
+    static __device__ __forceinline__ raw_t zero() { return make_uint4(0u, 0u, 0u, 0u); }
+    static __device__ __forceinline__ half8_t expand(raw_t u) { return __builtin_bit_cast(half8_t, u); }
+};
+
 // the scale word of (tile, pair, row i) holds both blocks' fp16 d: s[(tile*npairs + g*KL)*TR + i*gsz + k]; scale_of() picks one
 __device__ __forceinline__ float scale_of(uint32_t word, int blk) { return h2f_bits((word >> (16 * (blk & 1))) & 0xffff); }
 
@@ -301,7 +313,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
 #pragma unroll
             for (int pp = 0; pp < QG_KC / 2; pp++) {
                 const int blk = min(b0 + 2 * pp, nblocks - 1);
-                wd[rt][pp] = *reinterpret_cast<const uint32_t *>(Ws + ((gs + (unsigned)((blk >> 1) & 3) * 4u) + ls));
+                if constexpr (WTraits<WT>::SCALED) wd[rt][pp] = *reinterpret_cast<const uint32_t *>(Ws + ((gs + (unsigned)((blk >> 1) & 3) * 4u) + ls));
+                else wd[rt][pp] = 0u;
             }
         }
     };
@@ -330,8 +343,26 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
                 wf[rt] = WFrag<WT>::expand(wq[rt][b]);
-                const float d = scale_of(wd[rt][b >> 1], b);
+                const float d = WTraits<WT>::SCALED ? scale_of(wd[rt][b >> 1], b) : 1.0f;
                 dsc[rt] = b < nb ? d : 0.f;
+            }
+            if constexpr (!WTraits<WT>::SCALED) {
+                // no per-block scale: the products accumulate straight into the output accumulators (a block past the end
+                // of K was clamped to a valid one by the prefetch: its weight operand is zeroed instead of its scale)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+                    if (b >= nb) wf[rt] = __builtin_bit_cast(half8_t, make_uint4(0u, 0u, 0u, 0u));
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++)
+                        acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[t], wf[rt], acc[rt][t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++)
+                        acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], wf[rt], acc[rt][t], 0, 0, 0);
+                continue;
             }
             f32x4_t z[RT][NT];
 #pragma unroll

@@ -546,7 +546,7 @@ def test_fused_gemm_epilogues_on_golden_models(hip):
     assert r.returncode == 0 and "fused ok" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("tag", ["tiny_q8_0", "tiny_mha_q4_0", "tiny_qknorm_q8_0"])
+@pytest.mark.parametrize("tag", ["tiny_q8_0", "tiny_mha_q4_0", "tiny_qknorm_q8_0", "tiny_f16"])
 @pytest.mark.parametrize("n", [3, 5, 7])
 def test_short_prefill_matches_golden(hip, tag, n):
     # 3-7 tokens: the multi-token step with the per-token attention kernel, which (all positions < 128) normalises
@@ -757,7 +757,7 @@ def test_64_concurrent_streams_match_oracle(hip, orc, tmp_path):
     dev.close()
 
 
-@pytest.mark.parametrize("wtype", ["q4_0", "q8_0"])
+@pytest.mark.parametrize("wtype", ["q4_0", "q8_0", "f16"])
 @pytest.mark.parametrize("rows,cols,ntok", [(128, 256, 64), (576, 576, 5), (1536, 576, 64), (192, 768, 17),
                                              (100, 96, 3), (4096, 4096, 64), (2304, 1536, 130),
                                              # the one / two / four 16-token-tile variants at their boundaries
@@ -1081,3 +1081,42 @@ def test_fused_projection_attention_launch_matches_oracle(hip, orc, tmp_path, mo
     first = int(np.argmax(dev.state.logits))
     assert dev.decode_greedy(first, 140, 16) == plain.decode_greedy(first, 140, 16)
     dev.close(); plain.close(); ref.close()
+
+
+def test_f16_prompt_prefill_runs_on_the_matrix_cores(hip, orc, tmp_path):
+    # F16 files (BASELINE.json configs[0]'s format, go/quant.go:527-563) take the multi-token MFMA path too: the
+    # fp16 weights are their own exact operand, no scale step; a prompt long enough for the fused RoPE and SwiGLU
+    # epilogues and for two attention splits, checked against the oracle and against token-at-a-time decode
+    shape = synth.ModelShape("f16_prefill", 2, 256, 4, 2, 1024, seq_len=256, interm=512)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "f16", 83)
+    g = gguf.load_gguf(str(p))
+    toks = synth.prompt_ids(150, shape.vocab, seed=4)
+    ref = orc.OracleModel(g)
+    for pos, t in enumerate(toks):
+        want = ref.forward(t, pos)
+    dev = hip.load_llama_model(g)
+    dev.prefill(toks)
+    scale = max(1.0, float(want.std()))
+    d = float(np.abs(dev.state.logits - want).max())
+    print(f"\nf16 prefill 150 tokens: max|gpu-oracle|={d:.2e}")
+    assert d <= LOGIT_TOL * scale
+    step = hip.load_llama_model(g)
+    for pos, t in enumerate(toks):
+        step.forward(t, pos)
+    n = shape.n_layer * shape.n_kv_head * shape.seq_len * 64
+    for which in ("k_cache", "v_cache"):
+        a, b = dev.debug_read(which, n).reshape(-1, shape.seq_len, 64), step.debug_read(which, n).reshape(-1, shape.seq_len, 64)
+        assert np.abs(a[:, :150] - b[:, :150]).max() <= 2e-5
+    nxt = int(np.argmax(want))
+    assert dev.decode_greedy(nxt, 150, 12) == step.decode_greedy(nxt, 150, 12)
+    # 64 concurrent F16 decode streams through the same GEMM
+    many = hip.load_llama_model(g, max_streams=8)
+    ids, lg = many.forward_batch(list(range(8)), toks[:8], [0] * 8, want_logits=True)
+    solo = hip.load_llama_model(g)
+    for i in range(8):
+        solo.reset()
+        solo.forward(toks[i], 0)
+        assert np.abs(lg[i] - solo.state.logits).max() <= LOGIT_TOL * scale
+    for m in (dev, step, many, solo, ref):
+        m.close()
