@@ -929,7 +929,15 @@ hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_bu
     int ks = 1;
     if (part_buf && P.ldo == P.rows) {
         static const int ks_cap = getenv("NL_KS_CAP") ? atoi(getenv("NL_KS_CAP")) : 16;   // developer knob (tools/)
-        while (row_groups * mats * tok_tiles * ks < 128 && ks * 2 <= nchunks && ks < ks_cap) ks *= 2;
+        static const int min_wg = getenv("NL_QG_MIN_WG") ? atoi(getenv("NL_QG_MIN_WG")) : 128;
+        static const int max_chunks = getenv("NL_QG_MAX_CHUNKS") ? atoi(getenv("NL_QG_MAX_CHUNKS")) : 6;   // goldie x 64 streams: 2.06 -> 1.94 ms per step (tools/sweep_qg_split.sh)
+        static const int max_wg = getenv("NL_QG_MAX_WG") ? atoi(getenv("NL_QG_MAX_WG")) : 1024;
+        // split K until the grid fills the chip; a decode batch (one token tile) keeps splitting while a workgroup would
+        // still walk more than max_chunks 128-column chunks one after the other (each is a dependent memory round trip)
+        while (ks * 2 <= nchunks && ks < ks_cap &&
+               (row_groups * mats * tok_tiles * ks < min_wg ||
+                (tok_tiles == 1 && (nchunks + ks - 1) / ks > max_chunks && row_groups * mats * ks * 2 <= max_wg)))
+            ks *= 2;
         while (ks > 1 && (size_t)ks * P.n_tokens * P.ldo > part_cap) ks /= 2;
     }
     P.ksplit = ks;
