@@ -92,7 +92,9 @@ def kernel_bytes(shape, wtype, pos, tp=1):
         "embed": d * bpe + d * 4,
         "qkv_rope": (hq + 2 * kv) * d * bpe + 2 * d * 4 + (hq + 2 * kv) * 4,
         "attention": (pos + 1) * kv * 2 * 4 + hq * 4 * 2,
-        "attn_block": (hq + 2 * kv) * d * bpe + d * hq * bpe + 2 * d * 4 + (pos + 1) * kv * 2 * 4,
+        # fused launches: small tiers run norm + QKV + attention + WO in one (nl_block.h); wide tiers QKV + attention (nl_group.h)
+        "attn_block": (hq + 2 * kv) * d * bpe + (d * hq * bpe if shape.n_head <= 12 and d <= 1024 else 0) + 2 * d * 4
+                      + (pos + 1) * kv * 2 * 4,
         "wo_resid": d * hq * bpe + hq * 4 + 2 * d * 4,
         "gate_up_swiglu": 2 * i * d * bpe + 2 * d * 4 + i * 4,
         "down_resid": d * i * bpe + i * 4 + 2 * d * 4,

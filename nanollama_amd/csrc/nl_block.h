@@ -95,12 +95,20 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     uint2 sw;
     const int gg = min(grp, ngroups - 1), gs = min(KL, P.npairs - gg * KL);
     const bool lv = grp < ngroups && k < gs;
-    // x and the norm weights of this wavefront's own 256 columns (one float4 per lane), then its weights
+    // x and the norm weights of this wavefront's own 256 columns (one float4 per lane), then its weights.  A wavefront
+    // whose column group does not exist (D = 576: three groups, four wavefronts per tile) skips the loads as a whole
+    // (wave-uniform branch: no lane waits on a partial load) and contributes zeros.
     const int xcol = gg * (KL * PAIR) + lane * 4;
     const bool xin = xcol < D;
-    const float4 xv = *reinterpret_cast<const float4 *>(P.x + (xin ? xcol : 0));
-    const float4 gv = *reinterpret_cast<const float4 *>(P.normw + (xin ? xcol : 0));
-    load_pair<WT>(P.qkv_q, P.qkv_s, tp0, gg, gs, r, min(k, gs - 1), cw, sw);
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), gv = xv;
+#pragma unroll
+    for (int j = 0; j < CPP; j++) cw[j] = make_uint4(0u, 0u, 0u, 0u);
+    sw = make_uint2(0u, 0u);
+    if (grp < ngroups) {
+        xv = *reinterpret_cast<const float4 *>(P.x + (xin ? xcol : 0));
+        gv = *reinterpret_cast<const float4 *>(P.normw + (xin ? xcol : 0));
+        load_pair<WT>(P.qkv_q, P.qkv_s, tp0, gg, gs, r, min(k, gs - 1), cw, sw);
+    }
     // the first 128 cache rows of this kv head (rows >= pos hold stale finite data and are masked / replaced below)
     const int c4 = tid % R4, tg = tid / R4;
     float4 kreg[NV], vreg[NV];

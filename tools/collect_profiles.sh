@@ -7,9 +7,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 bash scripts_gpu_run.sh prof
 bash tools/prof_prefill.sh > gpurun_out/prof_pf_head.txt 2>&1
 bash tools/prof_batch.sh > gpurun_out/prof_b_head.txt 2>&1
-bash tools/prof_sampling.sh > gpurun_out/prof_s_head.txt 2>&1
 bash tools/pmc_run.sh nano:q8_0 nano_q8_0 > /dev/null 2>&1
 bash tools/pmc_run.sh big:q4_0 big_q4_0 > /dev/null 2>&1
-bash tools/pmc_qgemm.sh 2047 0 6 6 > gpurun_out/pmc_qgemm_big_gate_2047.txt 2>&1
-bash tools/pmc_kernel.sh attn_tile16 tools/prof_prefill.py > gpurun_out/pmc_attn_tile16.txt 2>&1
+bash tools/pmc_kernel.sh qgemm_kernel tools/prof_batch.py > gpurun_out/pmc_qgemm_goldie_b64.txt 2>&1
 ls gpurun_out
