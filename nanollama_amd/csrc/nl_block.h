@@ -151,8 +151,22 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
         xa.x *= gv.x; xa.y *= gv.y; xa.z *= gv.z; xa.w *= gv.w;
         *reinterpret_cast<float4 *>(xw + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
     }
+    // sum of squares: 16-lane rows on DPP, four partials per q wavefront.  x arrives long before the weights do, so the
+    // reduction, its barrier and the float64 sqrt / divide of inv happen inside the weight latency, not in the epilogue.
+    ss += dpp_f64<DPP_QUAD_XOR1>(ss);
+    ss += dpp_f64<DPP_QUAD_XOR2>(ss);
+    ss += dpp_f64<DPP_HALF_MIRROR>(ss);
+    ss += dpp_f64<DPP_ROW_MIRROR>(ss);
+    if (sect == 0 && (lane & 15) == 0) dred[grp * 4 + (lane >> 4)] = ss;
     BLK_STAMP(1);
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    float inv = 0.f;
+    if (tid < 48) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) tot += dred[w];
+        inv = (float)(1.0 / sqrt(tot / (double)D + (double)P.eps));
+    }
     BLK_STAMP(2);
 
     // ---- this member's q, k and v tile: each wavefront one 256-column group of one tile ----
@@ -161,12 +175,6 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     BLK_STAMP(16);
     acc = quad_sum(acc);
     if (k == 0) red[wave * TR + r] = acc;
-    // sum of squares: 16-lane rows on DPP, four partials per q wavefront; the epilogue threads add the 16 partials
-    ss += dpp_f64<DPP_QUAD_XOR1>(ss);
-    ss += dpp_f64<DPP_QUAD_XOR2>(ss);
-    ss += dpp_f64<DPP_HALF_MIRROR>(ss);
-    ss += dpp_f64<DPP_ROW_MIRROR>(ss);
-    if (sect == 0 && (lane & 15) == 0) dred[grp * 4 + (lane >> 4)] = ss;
     BLK_STAMP(3);
     __syncthreads();
     BLK_STAMP(4);
@@ -180,10 +188,6 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
 
     // ---- scale, bias, RoPE (go/model.go:449-477); publish the 48 values to the other members ----
     if (tid < 48) {
-        double tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < 16; w++) tot += dred[w];
-        const float inv = (float)(1.0 / sqrt(tot / (double)D + (double)P.eps));
         const float *rt = red + e_sect * 4 * TR;   // the tile's four column-group partials, fixed order
         const float dotv = ((rt[e_rr] + rt[TR + e_rr]) + rt[2 * TR + e_rr]) + rt[3 * TR + e_rr];
         const float dotp = ((rt[e_rr ^ 8] + rt[TR + (e_rr ^ 8)]) + rt[2 * TR + (e_rr ^ 8)]) + rt[3 * TR + (e_rr ^ 8)];

@@ -902,12 +902,12 @@ hipError_t launch_qgemm_rope(int wtype, QGemmParams P, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <int WT, int WAVES>
+template <int WT, int WAVES, int RT = QG_RT>
 void launch_qgemm_nt(int nt, dim3 grid, hipStream_t st, const QGemmParams &P) {
     switch (nt) {
-    case 1: hipLaunchKernelGGL((qgemm_kernel<WT, WAVES, QG_RT, QG_EPI_PLAIN, 1>), grid, dim3(WAVES * 64), 0, st, P); break;
-    case 2: hipLaunchKernelGGL((qgemm_kernel<WT, WAVES, QG_RT, QG_EPI_PLAIN, 2>), grid, dim3(WAVES * 64), 0, st, P); break;
-    default: hipLaunchKernelGGL((qgemm_kernel<WT, WAVES, QG_RT, QG_EPI_PLAIN, 4>), grid, dim3(WAVES * 64), 0, st, P); break;
+    case 1: hipLaunchKernelGGL((qgemm_kernel<WT, WAVES, RT, QG_EPI_PLAIN, 1>), grid, dim3(WAVES * 64), 0, st, P); break;
+    case 2: hipLaunchKernelGGL((qgemm_kernel<WT, WAVES, RT, QG_EPI_PLAIN, 2>), grid, dim3(WAVES * 64), 0, st, P); break;
+    default: hipLaunchKernelGGL((qgemm_kernel<WT, WAVES, RT, QG_EPI_PLAIN, 4>), grid, dim3(WAVES * 64), 0, st, P); break;
     }
 }
 
@@ -921,10 +921,15 @@ hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_bu
     // twice the workgroups and half the split-K for the small-N decode batches (goldie shapes at 16-128 tokens:
     // -4...-18 % per launch, tools/qgemm_variants.sh); then split K until ~128 workgroups exist.
     static const int force_waves = getenv("NL_QG_FORCE_WAVES") ? atoi(getenv("NL_QG_FORCE_WAVES")) : 0;   // developer knob
-    int waves = QG_WAVES;
+    int waves = QG_WAVES, rt = QG_RT;
     if (((P.ntiles + QG_WAVES - 1) / QG_WAVES) * mats * tok_tiles < 128) waves = 4;
     if (force_waves == 4 || force_waves == 8) waves = force_waves;
-    const int row_groups = (P.ntiles + waves * QG_RT - 1) / (waves * QG_RT);
+    // decode batches (one 64-token tile): a workgroup's ingest is dominated by the activation fragments (256 B per
+    // column against 72 B of Q4_0 weights for a 128-row workgroup), so tall workgroups -- 8 wavefronts x 2 tiles = 256
+    // rows -- with a deep K split move the least data per launch
+    static const int dec_geom = getenv("NL_QG_DEC_GEOM") ? atoi(getenv("NL_QG_DEC_GEOM")) : 0;   // developer knob: 82 = 8 waves x 2 tiles
+    if (tok_tiles == 1 && part_buf && P.ldo == P.rows && dec_geom == 82 && QG_RT == 1) { waves = 8; rt = 2; }
+    const int row_groups = (P.ntiles + waves * rt - 1) / (waves * rt);
     P.row_groups = row_groups;
     int ks = 1;
     if (part_buf && P.ldo == P.rows) {
@@ -946,7 +951,11 @@ hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_bu
     // a step of <= 16 / 32 tokens fetches and multiplies only the first one / two 16-token tiles of its group
     const int nt = tok_tiles > 1 || P.n_tokens > 32 ? 4 : P.n_tokens > 16 ? 2 : 1;
     if (wtype != WT_Q4_0 && wtype != WT_Q8_0 && wtype != WT_F16) return hipErrorInvalidValue;
-    if (waves == 4) {
+    if (rt == 2 && waves == 8) {
+        if (wtype == WT_Q4_0) launch_qgemm_nt<WT_Q4_0, 8, 2>(nt, grid, st, P);
+        else if (wtype == WT_Q8_0) launch_qgemm_nt<WT_Q8_0, 8, 2>(nt, grid, st, P);
+        else launch_qgemm_nt<WT_F16, 8, 2>(nt, grid, st, P);
+    } else if (waves == 4) {
         if (wtype == WT_Q4_0) launch_qgemm_nt<WT_Q4_0, 4>(nt, grid, st, P);
         else if (wtype == WT_Q8_0) launch_qgemm_nt<WT_Q8_0, 4>(nt, grid, st, P);
         else launch_qgemm_nt<WT_F16, 4>(nt, grid, st, P);
