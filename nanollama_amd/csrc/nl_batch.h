@@ -848,15 +848,17 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
         }
 #pragma unroll
         for (int nt = 0; nt < NTO; nt++) {
-            const half8_t vh = *reinterpret_cast<const half8_t *>(VTh + (NTO * j + nt) * VS + 32 * mm + 8 * kq);
-            const half8_t vl = *reinterpret_cast<const half8_t *>(VTl + (NTO * j + nt) * VS + 32 * mm + 8 * kq);
+            // B rows nt*16 + j: consecutive V^T rows across the 16 lanes of a read group are 272 B = 4 banks apart, i.e.
+            // conflict-free (rows NTO*j + nt put lanes j, j+4, j+8, j+12 on the same banks: a 4-way conflict per read)
+            const half8_t vh = *reinterpret_cast<const half8_t *>(VTh + (nt * 16 + j) * VS + 32 * mm + 8 * kq);
+            const half8_t vl = *reinterpret_cast<const half8_t *>(VTl + (nt * 16 + j) * VS + 32 * mm + 8 * kq);
             o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, o[nt], 0, 0, 0);
             o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, o[nt], 0, 0, 0);
             o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, o[nt], 0, 0, 0);
         }
     }
 
-    // O tile: this lane holds rows 4*kq+r, columns d = NTO*j .. NTO*j+NTO-1
+    // O tile: this lane holds rows 4*kq+r, columns d = nt*16 + j (the 16 lanes of a row write 64 contiguous bytes per nt)
     constexpr float unscale = 1.0f / 1024.0f;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -864,10 +866,9 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
         if (nv[vh] == 0) continue;
         const int item = i0 + vh / G, h = kvh * G + vh % G;
         const long long slot = (long long)item * P.part_item_stride + (long long)h * P.nsplit_max + split;
-        float *po = P.part_o + slot * HD + NTO * j;
-        if constexpr (NTO == 4)
-            *reinterpret_cast<float4 *>(po) = make_float4(o[0][r] * unscale, o[1][r] * unscale, o[2][r] * unscale, o[3][r] * unscale);
-        else *reinterpret_cast<float2 *>(po) = make_float2(o[0][r] * unscale, o[1][r] * unscale);
+        float *po = P.part_o + slot * HD + j;
+#pragma unroll
+        for (int nt = 0; nt < NTO; nt++) po[nt * 16] = o[nt][r] * unscale;
     }
     if (kq == 0 && nvj > 0) {
         const int vh = w * 16 + j, item = i0 + vh / G, h = kvh * G + vh % G;

@@ -212,9 +212,9 @@ struct nl_engine {
     ArgmaxParams plan_argmax{};
     P2PArgmaxParams plan_p2p_argmax{};
     // sampled chained decode: {sampler, plan} x graph_steps, captured per sampling-parameter set
-    hipGraph_t samp_graph = nullptr;
-    hipGraphExec_t samp_graph_exec = nullptr;
-    nl_sample_params samp_graph_params{};
+    hipGraph_t samp_graph[2] = {nullptr, nullptr};          // per launch plan (ps[0] / ps[1])
+    hipGraphExec_t samp_graph_exec[2] = {nullptr, nullptr};
+    nl_sample_params samp_graph_params[2]{};
     bool samp_graph_failed = false;
     bool use_graph = true;
     void *comm = nullptr;
@@ -758,6 +758,13 @@ int capture_graph(nl_engine *e, nl_engine::PlanSet &S) {
         e->graph_steps = steps;
     }
     return NL_OK;
+}
+
+void destroy_samp_graphs(nl_engine *e) {
+    for (int k = 0; k < 2; k++) {
+        if (e->samp_graph_exec[k]) { (void)hipGraphExecDestroy(e->samp_graph_exec[k]); e->samp_graph_exec[k] = nullptr; }
+        if (e->samp_graph[k]) { (void)hipGraphDestroy(e->samp_graph[k]); e->samp_graph[k] = nullptr; }
+    }
 }
 
 // the plan that serves a step (or a run of steps) whose highest position is pos_last
@@ -1584,8 +1591,7 @@ int nl_set_gamma(nl_handle e, const int32_t *indices, int n, const void *values,
     e->gamma_row = new_row;
     e->gamma_val = new_val;
     if (e->finalized) {  // the launch closures hold the old pointers: rebuild plans and graphs
-        if (e->samp_graph_exec) { hipGraphExecDestroy(e->samp_graph_exec); e->samp_graph_exec = nullptr; }
-        if (e->samp_graph) { hipGraphDestroy(e->samp_graph); e->samp_graph = nullptr; }
+        destroy_samp_graphs(e);
         if (build_all(e)) {   // the rebuilt eager plans are valid; only the graphs were lost
             for (auto &S : e->ps) destroy_graphs(S);
             e->use_graph = false;
@@ -1602,8 +1608,7 @@ int nl_destroy(nl_handle e) {
     hipDeviceSynchronize();
     samp_free(e->sp);
     for (auto &S : e->ps) destroy_graphs(S);
-    if (e->samp_graph_exec) hipGraphExecDestroy(e->samp_graph_exec);
-    if (e->samp_graph) hipGraphDestroy(e->samp_graph);
+    destroy_samp_graphs(e);
     for (auto &L : e->layers) {
         if (L.attn_norm) hipFree(L.attn_norm);
         if (L.ffn_norm) hipFree(L.ffn_norm);
@@ -1786,8 +1791,7 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
     if (n <= 0) return NL_OK;
     if (!e->sp_ready || e->sp_uniforms_cap < n) {
         HIPCK(e, hipStreamSynchronize(e->stream));
-        if (e->samp_graph_exec) { hipGraphExecDestroy(e->samp_graph_exec); e->samp_graph_exec = nullptr; }   // holds the old scratch pointers
-        if (e->samp_graph) { hipGraphDestroy(e->samp_graph); e->samp_graph = nullptr; }
+        destroy_samp_graphs(e);   // they hold the old scratch pointers
         samp_free(e->sp);
         e->sp_ready = false;
         e->sp_uniforms_cap = std::max(n, e->cfg.seq_len);
@@ -1803,32 +1807,34 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
     if (*n_recent > 0) HIPCK(e, hipMemcpyAsync(s.recent, recent, (size_t)*n_recent * 4, hipMemcpyHostToDevice, e->stream));
     HIPCK(e, hipMemcpyAsync(s.recent_n, n_recent, 4, hipMemcpyHostToDevice, e->stream));
     int i = 0;
-    if (e->ps[0].multi_exec && !e->samp_graph_failed && n >= e->graph_steps) {
-        // {sampler kernels, plan} x graph_steps as one graph (its kernel arguments include the sampling parameters:
-        // re-captured when they change)
-        if (!e->samp_graph_exec || memcmp(&e->samp_graph_params, p, sizeof(*p)) != 0) {
-            if (e->samp_graph_exec) { hipGraphExecDestroy(e->samp_graph_exec); e->samp_graph_exec = nullptr; }
-            if (e->samp_graph) { hipGraphDestroy(e->samp_graph); e->samp_graph = nullptr; }
+    while (e->ps[0].multi_exec && !e->samp_graph_failed && i + e->graph_steps <= n) {
+        // {sampler kernels, plan} x graph_steps as one graph per launch plan (its kernel arguments include the sampling
+        // parameters: re-captured when they change); the plan is chosen by the highest position of the 16 steps
+        const int k = (e->fused && pos + i + e->graph_steps - 1 < e->fused_max_pos) ? 1 : 0;
+        if (!e->samp_graph_exec[k] || memcmp(&e->samp_graph_params[k], p, sizeof(*p)) != 0) {
+            if (e->samp_graph_exec[k]) { hipGraphExecDestroy(e->samp_graph_exec[k]); e->samp_graph_exec[k] = nullptr; }
+            if (e->samp_graph[k]) { hipGraphDestroy(e->samp_graph[k]); e->samp_graph[k] = nullptr; }
             hipError_t cs = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
             int rc2 = NL_OK;
-            for (int k = 0; cs == hipSuccess && k < e->graph_steps && !rc2; k++) {
+            for (int q = 0; cs == hipSuccess && q < e->graph_steps && !rc2; q++) {
                 if (launch_sample(s, e->logits, e->cfg.vocab, *p, e->ctl, e->ids, e->stream) != hipSuccess) rc2 = NL_ERR_HIP;
-                else rc2 = run_plan_eager(e, e->ps[0]);
+                else rc2 = run_plan_eager(e, e->ps[k]);
             }
             hipGraph_t g = nullptr;
             if (cs == hipSuccess) cs = hipStreamEndCapture(e->stream, &g);
-            if (cs == hipSuccess && !rc2 && g && hipGraphInstantiate(&e->samp_graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
-                e->samp_graph = g;
-                e->samp_graph_params = *p;
+            if (cs == hipSuccess && !rc2 && g && hipGraphInstantiate(&e->samp_graph_exec[k], g, nullptr, nullptr, 0) == hipSuccess) {
+                e->samp_graph[k] = g;
+                e->samp_graph_params[k] = *p;
             } else {
                 if (g) hipGraphDestroy(g);
                 (void)hipGetLastError();
-                e->samp_graph_exec = nullptr;
+                e->samp_graph_exec[k] = nullptr;
                 e->samp_graph_failed = true;      // (e.g. a library call that cannot be captured): eager launches below
+                break;
             }
         }
-        if (e->samp_graph_exec)
-            for (; i + e->graph_steps <= n; i += e->graph_steps) HIPCK(e, hipGraphLaunch(e->samp_graph_exec, e->stream));
+        HIPCK(e, hipGraphLaunch(e->samp_graph_exec[k], e->stream));
+        i += e->graph_steps;
     }
     for (; i < n; i++) {
         HIPCK(e, launch_sample(s, e->logits, e->cfg.vocab, *p, e->ctl, e->ids, e->stream));

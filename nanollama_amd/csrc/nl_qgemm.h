@@ -346,6 +346,30 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
                 const float d = WTraits<WT>::SCALED ? scale_of(wd[rt][b >> 1], b) : 1.0f;
                 dsc[rt] = b < nb ? d : 0.f;
             }
+#ifdef NL_QG_SCALEW
+            if constexpr (WTraits<WT>::SCALED) {
+                // Scale folded into the weight operand: w = d * q as fp16 hi + lo (d is fp16, q a small integer: the product
+                // has <= 19 significant bits, so hi = round(d*q) and lo = fma(d, q, -hi) split it exactly; d is taken x 2^8
+                // -- undone once after the K loop -- so that lo stays a normal fp16 number).  Three MFMAs per block
+                // (hi*hi + hi*lo + lo*hi, the lo*lo term is 2^-22 relative) accumulate straight into the output
+                // accumulators: no per-block f32 FMAs, no accumulator read-back between blocks.
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    const uint32_t word = wd[rt][b >> 1];
+                    const _Float16 dh = (b < nb) ? (_Float16)(256.0f * h2f_bits((word >> (16 * (b & 1))) & 0xffff)) : (_Float16)0.0f;
+                    const half8_t dv = {dh, dh, dh, dh, dh, dh, dh, dh};
+                    const half8_t hi = wf[rt] * dv;
+                    const half8_t lo = __builtin_elementwise_fma(wf[rt], dv, -hi);
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[t], hi, acc[rt][t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], lo, acc[rt][t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], hi, acc[rt][t], 0, 0, 0);
+                }
+                continue;
+            }
+#endif
             if constexpr (!WTraits<WT>::SCALED) {
                 // no per-block scale: the products accumulate straight into the output accumulators (a block past the end
                 // of K was clamped to a valid one by the prefetch: its weight operand is zeroed instead of its scale)
@@ -403,6 +427,14 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
         body(chunk, 1, wqb, wdb, wqa, wda);
         chunk += P.ksplit;
     }
+#ifdef NL_QG_SCALEW
+    if constexpr (WTraits<WT>::SCALED) {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[rt][t] = acc[rt][t] * (1.0f / 256.0f);
+    }
+#endif
     if constexpr (FUSED) {
         // h = SiLU(gate) * up (go/quant.go:629-631, go/model.go:604-606) for this wavefront's 16 rows x 64 tokens,
         // transposed through LDS (the fragment buffers are idle after the loop's last barrier) into the fp16 hi/lo
