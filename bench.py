@@ -95,6 +95,7 @@ def kernel_bytes(shape, wtype, pos, tp=1):
         # fused launches: small tiers run norm + QKV + attention + WO in one (nl_block.h); wide tiers QKV + attention (nl_group.h)
         "attn_block": (hq + 2 * kv) * d * bpe + (d * hq * bpe if shape.n_head <= 12 and d <= 1024 else 0) + 2 * d * 4
                       + (pos + 1) * kv * 2 * 4,
+        "ffn_block": 3 * i * d * bpe + 2 * d * 4,       # gate + up + down in one launch (nl_block.h), small tiers
         "wo_resid": d * hq * bpe + hq * 4 + 2 * d * 4,
         "gate_up_swiglu": 2 * i * d * bpe + 2 * d * 4 + i * 4,
         "down_resid": d * i * bpe + i * 4 + 2 * d * 4,

@@ -156,7 +156,7 @@ NL_API int nl_timer_stop(nl_handle h, float *ms);
  * launch, each replayed `iters` times).  kinds: see nl_kernel_kind_name.  ms_out/calls_out have NL_NUM_KINDS
  * entries.  Measurement only: the replays leave x, the logits and the K/V rows at `pos` in a state no Forward
  * produces, so the stream's positions >= pos count as unwritten afterwards (re-run them before decoding on). */
-#define NL_NUM_KINDS 10
+#define NL_NUM_KINDS 11
 NL_API const char *nl_kernel_kind_name(int kind);
 NL_API int nl_profile_forward(nl_handle h, int stream, int token, int pos, int iters, float *ms_out, int *calls_out);
 /* Device bytes held by the handle (weights, KV, state). */

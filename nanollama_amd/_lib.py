@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NL_LIB_PATH") or os.path.join(_HERE, "libnanollama_hip.so")  # NL_LIB_PATH: A/B builds (tools/)
-NL_NUM_KINDS = 10
+NL_NUM_KINDS = 11
 NL_COMM_ID_BYTES = 128
 NL_P2P_HANDLE_BYTES = 64
 NL_FLAG_NO_GRAPH = 1

@@ -45,6 +45,9 @@ struct BlockParams {
     const int *ctl;
     const float *bias_q, *bias_k, *bias_v, *bias_out;
     float *parts;                // [H][D]: head h's share of WO * attention output (+ bias_out in head 0)
+    const float *parts_in;       // optional [nparts_in][D]: the previous layer's feed-forward partials, added to x first
+    int nparts_in;
+    float *x_out;                // with parts_in: x + sum parts_in, stored by head 0 / member 0
     unsigned long long *xchg;    // [H][192] granules: the head's q | k | v of this position
     const unsigned *tick;        // forward counter (advanced by the embedding launch): tag = tick << 8 | layer + 1
     unsigned layer_tag;
@@ -55,19 +58,19 @@ struct BlockParams {
 
 __host__ __device__ constexpr int blk_xs_floats(int D) { return (D / PAIR) * XS_PAIR; }
 __host__ __device__ constexpr size_t blk_lds_bytes(int D) {
-    return sizeof(float) * (size_t)(12 * XS_WAVE + 12 * TR + 4 * 64 + 8 + ATT_CH + 32 * 66 + 2 * 32 * 64) + 16 * sizeof(double);
+    return sizeof(float) * (size_t)(4 * XS_WAVE + 12 * TR + 4 * 64 + 8 + ATT_CH + 32 * 66 + 2 * 32 * 64) + 16 * sizeof(double);
 }
 inline int blk_grid(int heads) { return ((heads + 7) / 8) * 32; }   // block b: head (b/32)*8 + b%8, member (b/8)%4
 
-template <int WT>
+template <int WT, int NPIN>
 __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) {
     constexpr int HD = 64, CPP = WTraits<WT>::CPP, R4 = HD / 4, NGR = BLK_KV_THREADS / R4, NV = ATT_CH / NGR, NW = BLK_THREADS / 64;
     const int h = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7), jm = (blockIdx.x >> 3) & 3;
     if (h >= P.n_q_heads) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *dred = reinterpret_cast<double *>(smem);                 // [16]
-    float *xs = reinterpret_cast<float *>(dred + 16);                // [12][XS_WAVE]: x * g of each wavefront's group
-    float *red = xs + NW * XS_WAVE;                                  // [12][16]
+    float *xs = reinterpret_cast<float *>(dred + 16);                // [4][XS_WAVE]: x * g per 256-column group
+    float *red = xs + 4 * XS_WAVE;                                   // [12][16]
     float *qs = red + NW * TR;                                        // [64]
     float *kcur = qs + 64, *vcur = kcur + 64;                        // this position's K / V row
     float *on = vcur + 64;                                           // [64] normalised attention output
@@ -104,9 +107,17 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
 #pragma unroll
     for (int j = 0; j < CPP; j++) cw[j] = make_uint4(0u, 0u, 0u, 0u);
     sw = make_uint2(0u, 0u);
+    float4 pv[NPIN > 0 ? NPIN : 1];
+#pragma unroll
+    for (int p = 0; p < (NPIN > 0 ? NPIN : 1); p++) pv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (grp < ngroups) {
-        xv = *reinterpret_cast<const float4 *>(P.x + (xin ? xcol : 0));
-        gv = *reinterpret_cast<const float4 *>(P.normw + (xin ? xcol : 0));
+        if (sect == 0) {   // the q wavefronts stage x for the whole workgroup: one read of x (+ partials) per workgroup, not three
+            xv = *reinterpret_cast<const float4 *>(P.x + (xin ? xcol : 0));
+            gv = *reinterpret_cast<const float4 *>(P.normw + (xin ? xcol : 0));
+#pragma unroll
+            for (int p = 0; p < NPIN; p++)
+                pv[p] = *reinterpret_cast<const float4 *>(P.parts_in + (size_t)min(p, P.nparts_in - 1) * D + (xin ? xcol : 0));
+        }
         load_pair<WT>(P.qkv_q, P.qkv_s, tp0, gg, gs, r, min(k, gs - 1), cw, sw);
     }
     // the first 128 cache rows of this kv head (rows >= pos hold stale finite data and are masked / replaced below)
@@ -123,11 +134,15 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
             vreg[kk] = V4[row * R4 + c4];
         }
     }
-    // epilogue inputs of the projection rows (threads 0..47: one row each)
-    const int e_sect = tid >> 4, e_rr = tid & 15;
+    // epilogue inputs of the projection rows: 48 threads of the last wavefront (it holds no cache rows and stages nothing),
+    // one row each
+    constexpr int ET0 = BLK_THREADS - 64;
+    const int et = tid - ET0;
+    const bool e_thr = (unsigned)et < 48u;
+    const int e_sect = (et >> 4) & 3, e_rr = et & 15;
     const int e_i = jm * 8 + (e_rr & 7), e_e = e_i + (e_rr >> 3) * (HD / 2);
     float e_cos = 0.f, e_sin = 0.f, e_b = 0.f, e_bp = 0.f;
-    if (tid < 48) {
+    if (e_thr) {
         e_cos = P.rope_cos[pos * (HD / 2) + e_i];
         e_sin = P.rope_sin[pos * (HD / 2) + e_i];
         if (P.bias_q) {   // addBias before RoPE, go/model.go:525-527
@@ -140,14 +155,19 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     BLK_STAMP(15);
     // ---- RMSNorm (go/quant.go:597-607): x * g into this wavefront's own LDS slice (no workgroup barrier before the
     //      dot products); float64 sum of squares from the q wavefronts, which cover every column once ----
-    float *xw = xs + wave * XS_WAVE;
+    float *xw = xs + grp * XS_WAVE;      // shared by the three wavefronts of a column group
     double ss = 0.0;
-    {
-        float4 xa = xin ? xv : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (sect == 0 && grp < ngroups) {
-            ss = fma((double)xa.x, (double)xa.x, ss); ss = fma((double)xa.y, (double)xa.y, ss);
-            ss = fma((double)xa.z, (double)xa.z, ss); ss = fma((double)xa.w, (double)xa.w, ss);
+    if (sect == 0) {
+        float4 xa = xv;
+#pragma unroll
+        for (int p = 0; p < NPIN; p++) {   // the previous layer's feed-forward partials, fixed order
+            const bool on = p < P.nparts_in;
+            xa.x += on ? pv[p].x : 0.f; xa.y += on ? pv[p].y : 0.f; xa.z += on ? pv[p].z : 0.f; xa.w += on ? pv[p].w : 0.f;
         }
+        if (!xin || grp >= ngroups) xa = make_float4(0.f, 0.f, 0.f, 0.f);
+        ss = fma((double)xa.x, (double)xa.x, ss); ss = fma((double)xa.y, (double)xa.y, ss);
+        ss = fma((double)xa.z, (double)xa.z, ss); ss = fma((double)xa.w, (double)xa.w, ss);
+        if (NPIN > 0 && h == 0 && jm == 0 && xin && grp < ngroups) *reinterpret_cast<float4 *>(P.x_out + xcol) = xa;   // the updated residual stream
         xa.x *= gv.x; xa.y *= gv.y; xa.z *= gv.z; xa.w *= gv.w;
         *reinterpret_cast<float4 *>(xw + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
     }
@@ -161,7 +181,7 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     BLK_STAMP(1);
     __syncthreads();
     float inv = 0.f;
-    if (tid < 48) {
+    if (e_thr) {
         double tot = 0.0;
 #pragma unroll
         for (int w = 0; w < 16; w++) tot += dred[w];
@@ -187,7 +207,7 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     load_pair<WT>(P.wo_q, P.wo_s, (long long)h * wo_tiles + (wrow >> 4), 0, 1, wrow & 15, 0, wc, wsc);
 
     // ---- scale, bias, RoPE (go/model.go:449-477); publish the 48 values to the other members ----
-    if (tid < 48) {
+    if (e_thr) {
         const float *rt = red + e_sect * 4 * TR;   // the tile's four column-group partials, fixed order
         const float dotv = ((rt[e_rr] + rt[TR + e_rr]) + rt[2 * TR + e_rr]) + rt[3 * TR + e_rr];
         const float dotp = ((rt[e_rr ^ 8] + rt[TR + (e_rr ^ 8)]) + rt[2 * TR + (e_rr ^ 8)]) + rt[3 * TR + (e_rr ^ 8)];
@@ -327,6 +347,181 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     }
     BLK_STAMP(11);
 #undef BLK_STAMP
+}
+
+
+// ====================================================================================================================
+// The feed-forward half of a layer (go/model.go:597-612) as ONE launch, same idea: gate / up and down are all-to-all
+// over the hidden width I only because down reads every h.  Cut I into slices of 256 columns: a cluster of eight
+// workgroups (blocks b, b+8, ..., b+56: one XCD) owns a slice -- each member projects 32 gate and 32 up rows of it
+// (four 16-row tiles x up to four 256-column groups = 16 wavefronts), applies SiLU(gate) * up, the members exchange
+// their 32 values of h through tagged granules (256 per cluster), and each member multiplies its eighth of the rows of
+// W_down restricted to the slice's 256 columns (a second packed copy of W_down, sliced by column) -- a partial [D / 8]
+// vector per member, one partial [D] vector per slice.  The I / 256 partial vectors are added to the residual stream
+// by the next consumer's prologue (the next layer's attention block, or the LM head), like the attention block's.
+// nano: gate/up 4.3 us + down 3.3 us as two launches -> one launch.
+
+constexpr int FFN_THREADS = 1024;    // 16 wavefronts: {gate tile 0, gate tile 1, up tile 0, up tile 1} x 4 column groups
+constexpr int FFN_MEMBERS = 8;
+constexpr int FFN_SLICE = 256;       // hidden columns per cluster
+constexpr int FFN_MAX_PARTS = 8;     // partial vectors a consumer adds: I <= 2048
+
+struct FfnParams {
+    const uint8_t *gate_q, *up_q;    // packed gate / up [I rows x D]
+    const uint32_t *gate_s, *up_s;
+    const uint8_t *dn_q;             // W_down sliced by 256 columns: [I / 256][D / 16 tiles][4 pairs]
+    const uint32_t *dn_s;
+    int D, I, npairs;                // npairs of gate / up rows (D / 64)
+    const float *x, *normw;          // residual stream and ffn_norm
+    const float *parts_in;           // [nparts_in][D] partial vectors to add to x first (the attention block's)
+    int nparts_in;
+    float *x_out;                    // x + sum parts_in, stored by cluster 0 / member 0 (the residual the consumer adds to)
+    float eps;
+    float *parts_out;                // [I / 256][D]
+    unsigned long long *xchg;        // [I] granules
+    const unsigned *tick;
+    unsigned layer_tag;
+    unsigned *status, *host_status;
+    long long *dbg;                  // optional phase stamps of block 0 (nl_debug_stamps)
+};
+
+__host__ __device__ constexpr size_t ffn_lds_bytes() {
+    return sizeof(float) * (size_t)(4 * XS_WAVE + 16 * TR + KL * XS_PAIR) + 16 * sizeof(double);
+}
+inline int ffn_grid(int clusters) { return ((clusters + 7) / 8) * 64; }   // block b: cluster (b/64)*8 + b%8, member (b/8)%8
+
+template <int WT, int NPIN>
+__global__ void __launch_bounds__(FFN_THREADS) ffn_block_kernel(FfnParams P) {
+    constexpr int CPP = WTraits<WT>::CPP, NW = FFN_THREADS / 64;
+    const int cl = (blockIdx.x >> 6) * 8 + (blockIdx.x & 7), mem = (blockIdx.x >> 3) & 7;
+    if (cl * FFN_SLICE >= P.I) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *dred = reinterpret_cast<double *>(smem);                 // [16]
+    float *xs = reinterpret_cast<float *>(dred + 16);                // [4][XS_WAVE]: x * g per 256-column group
+    float *red = xs + 4 * XS_WAVE;                                   // [16][16]
+    float *hs = red + NW * TR;                                       // [4][XS_PAIR] h of this slice, padded pairs
+
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane >> 2, k = lane & 3, D = P.D;
+    const int tsel = wave >> 2, grp = wave & 3;      // 0,1: gate tiles; 2,3: up tiles of the same 32 rows
+    const int ngroups = (P.npairs + KL - 1) / KL;
+    const unsigned tag = (__hip_atomic_load(P.tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 8) | P.layer_tag;
+    const int tile = (cl * FFN_SLICE + mem * 32) / TR + (tsel & 1);
+    const uint8_t *const Wq = tsel < 2 ? P.gate_q : P.up_q;
+    const uint32_t *const Ws = tsel < 2 ? P.gate_s : P.up_s;
+#define FFN_STAMP(i) do { if (P.dbg && blockIdx.x == 0 && tid == 0) P.dbg[i] = clock64(); } while (0)
+    FFN_STAMP(0);
+
+    // ---- loads: x + the predecessor's partial vectors + norm weights of this wavefront's 256 columns, then its weights ----
+    const int gg = min(grp, ngroups - 1), gs = min(KL, P.npairs - gg * KL);
+    const bool lv = grp < ngroups && k < gs;
+    const int xcol = gg * (KL * PAIR) + lane * 4;
+    const bool xin = xcol < D;
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), gv = xv, pv[NPIN];
+    uint4 cw[CPP];
+    uint2 sw = make_uint2(0u, 0u);
+#pragma unroll
+    for (int j = 0; j < CPP; j++) cw[j] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int p = 0; p < NPIN; p++) pv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (grp < ngroups) {
+        if (tsel == 0) {   // the wavefronts of tile 0 stage x for the whole workgroup (one read of x + partials, not four)
+            xv = *reinterpret_cast<const float4 *>(P.x + (xin ? xcol : 0));
+            gv = *reinterpret_cast<const float4 *>(P.normw + (xin ? xcol : 0));
+#pragma unroll
+            for (int p = 0; p < NPIN; p++)
+                pv[p] = *reinterpret_cast<const float4 *>(P.parts_in + (size_t)min(p, P.nparts_in - 1) * D + (xin ? xcol : 0));
+        }
+        load_pair<WT>(Wq, Ws, (long long)tile * P.npairs, gg, gs, r, min(k, gs - 1), cw, sw);
+    }
+
+    FFN_STAMP(1);
+    // ---- residual + RMSNorm scaling into wave-private LDS; sum of squares from the wavefronts of tile 0 ----
+    float *xw = xs + grp * XS_WAVE;      // shared by the four wavefronts of a column group
+    double ss = 0.0;
+    if (tsel == 0) {
+        float4 xa = xv;
+#pragma unroll
+        for (int p = 0; p < NPIN; p++) {
+            const bool on = p < P.nparts_in;
+            xa.x += on ? pv[p].x : 0.f; xa.y += on ? pv[p].y : 0.f; xa.z += on ? pv[p].z : 0.f; xa.w += on ? pv[p].w : 0.f;
+        }
+        if (!xin || grp >= ngroups) xa = make_float4(0.f, 0.f, 0.f, 0.f);
+        ss = fma((double)xa.x, (double)xa.x, ss); ss = fma((double)xa.y, (double)xa.y, ss);
+        ss = fma((double)xa.z, (double)xa.z, ss); ss = fma((double)xa.w, (double)xa.w, ss);
+        if (cl == 0 && mem == 0 && xin && grp < ngroups) *reinterpret_cast<float4 *>(P.x_out + xcol) = xa;   // the updated residual stream
+        xa.x *= gv.x; xa.y *= gv.y; xa.z *= gv.z; xa.w *= gv.w;
+        *reinterpret_cast<float4 *>(xw + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
+    }
+    ss += dpp_f64<DPP_QUAD_XOR1>(ss);
+    ss += dpp_f64<DPP_QUAD_XOR2>(ss);
+    ss += dpp_f64<DPP_HALF_MIRROR>(ss);
+    ss += dpp_f64<DPP_ROW_MIRROR>(ss);
+    if (tsel == 0 && (lane & 15) == 0) dred[grp * 4 + (lane >> 4)] = ss;
+    FFN_STAMP(2);
+    __syncthreads();
+    FFN_STAMP(3);
+    // epilogue threads: 32 lanes of the last wavefront (idle during the dot products unless D has four column groups)
+    constexpr int ET0 = FFN_THREADS - 64;
+    const int et = tid - ET0;
+    const bool e_thr = (unsigned)et < 32u;
+    float inv = 0.f;
+    if (e_thr) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) tot += dred[w];
+        inv = (float)(1.0 / sqrt(tot / (double)D + (double)P.eps));
+    }
+    float acc = PairDot<WT>::run(cw, sw, xw + k * XS_PAIR, 0.f);
+    acc = lv ? acc : 0.f;
+    acc = quad_sum(acc);
+    if (k == 0) red[wave * TR + r] = acc;
+    FFN_STAMP(4);
+    __syncthreads();
+    FFN_STAMP(5);
+
+    // this member's rows of the slice's W_down columns stream in while the exchange runs: lane = (row, pair of the slice)
+    const int dn_rows = D / FFN_MEMBERS, dn_tiles = D / TR;
+    const int drow = mem * dn_rows + min(tid >> 2, dn_rows - 1), dpair = tid & 3;
+    uint4 dc[CPP];
+    uint2 dsc;
+    load_pair<WT>(P.dn_q, P.dn_s, ((long long)cl * dn_tiles + (drow >> 4)) * KL, 0, KL, drow & 15, dpair, dc, dsc);
+
+    // ---- h = SiLU(gate) * up (go/quant.go:629-631, go/model.go:604-606) for this member's 32 rows; publish ----
+    if (e_thr) {
+        const int t16 = et >> 4, rr = et & 15;
+        const float *rg = red + (t16 * 4) * TR, *ru = red + ((2 + t16) * 4) * TR;
+        const float g = (((rg[rr] + rg[TR + rr]) + rg[2 * TR + rr]) + rg[3 * TR + rr]) * inv;
+        const float u = (((ru[rr] + ru[TR + rr]) + ru[2 * TR + rr]) + ru[3 * TR + rr]) * inv;
+        const float ex = (float)exp((double)(-g));
+        const float h = (g / (1.0f + ex)) * u;
+        __hip_atomic_store(P.xchg + (size_t)cl * FFN_SLICE + mem * 32 + et, ((unsigned long long)tag << 32) | __float_as_uint(h),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    FFN_STAMP(6);
+    if (tid < FFN_SLICE) {
+        const bool dead = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        unsigned long long gq;
+        for (int spins = 0;; spins++) {
+            gq = __hip_atomic_load(P.xchg + (size_t)cl * FFN_SLICE + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((unsigned)(gq >> 32) == tag)) break;
+            if (dead || spins > 400000) { if (lane == 0) { atomicOr(P.status, 16u); *P.host_status = 16u; } break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        hs[(tid >> 6) * XS_PAIR + (tid & 63)] = __uint_as_float((unsigned)gq);
+    }
+    FFN_STAMP(7);
+    __syncthreads();
+    FFN_STAMP(8);
+
+    // ---- this member's rows of W_down over the slice's 256 columns (go/model.go:609-612): a partial [D / 8] vector ----
+    if (tid < dn_rows * 4) {
+        float v = PairDot<WT>::run(dc, dsc, hs + dpair * XS_PAIR, 0.f);
+        v = quad_sum(v);     // the four pairs of a row sit in one quad
+        if (dpair == 0) P.parts_out[(size_t)cl * D + drow] = v;
+    }
+    FFN_STAMP(9);
+#undef FFN_STAMP
 }
 
 }  // namespace nl

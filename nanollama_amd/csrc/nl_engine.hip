@@ -36,9 +36,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Kind { K_EMBED = 0, K_QKV, K_ATTN, K_WO, K_GATEUP, K_DOWN, K_LMHEAD, K_ARGMAX, K_ALLREDUCE, K_ATTNBLOCK };
+enum Kind { K_EMBED = 0, K_QKV, K_ATTN, K_WO, K_GATEUP, K_DOWN, K_LMHEAD, K_ARGMAX, K_ALLREDUCE, K_ATTNBLOCK, K_FFNBLOCK };
 const char *kKindNames[NL_NUM_KINDS] = {"embed", "qkv_rope", "attention", "wo_resid", "gate_up_swiglu",
-                                        "down_resid", "lm_head", "argmax", "allreduce", "attn_block"};
+                                        "down_resid", "lm_head", "argmax", "allreduce", "attn_block", "ffn_block"};
 
 struct PackedMat {
     uint8_t *q = nullptr;
@@ -133,6 +133,7 @@ struct nl_engine {
     struct Layer {
         PackedMat qkv, wo, gate, up, down;
         PackedMat wo_head;   // per-head 64-column slices of WO for the fused attention block (nl_block.h); small models only
+        PackedMat dn_slice;  // W_down sliced by 256 columns for the fused feed-forward block (nl_block.h)
         float *attn_norm = nullptr, *ffn_norm = nullptr;
         float *bq = nullptr, *bk = nullptr, *bv = nullptr, *bo = nullptr;  // optional biases (this rank's slice)
         bool have_q = false, have_k = false, have_v = false;
@@ -201,6 +202,9 @@ struct nl_engine {
     bool fused = false;           // ps[1] exists
     int fused_mode = 0;           // 1: whole attention half per layer (nl_block.h); 2: projection + attention (nl_group.h)
     int grp_tpm = 1;              // mode 2: 16-row tiles per workgroup
+    bool ffn_fused = false;       // mode 1: the feed-forward half is one launch too (ffn_block_kernel)
+    float *parts_ffn = nullptr;   // [I / 256][D] per-slice W_down partials
+    unsigned long long *xchg_ffn = nullptr;   // [I] granules
     int fused_max_pos = 0;        // ps[1] serves steps whose position is below this
     float *parts = nullptr;       // [Hs][D] per-head WO partials of the fused block
     unsigned long long *xchg = nullptr;   // [Hs][192] granules exchanged inside a head's cluster
@@ -474,10 +478,118 @@ void link_prefetch(std::vector<Op> &plan) {
     }
 }
 
+template <int WT>
+hipError_t launch_attn_block(const BlockParams &B, int npin, int grid, size_t lds, hipStream_t st) {
+    if (npin == 0) hipLaunchKernelGGL((attn_block_kernel<WT, 0>), dim3(grid), dim3(BLK_THREADS), lds, st, B);
+    else if (npin <= 2) hipLaunchKernelGGL((attn_block_kernel<WT, 2>), dim3(grid), dim3(BLK_THREADS), lds, st, B);
+    else if (npin <= 6) hipLaunchKernelGGL((attn_block_kernel<WT, 6>), dim3(grid), dim3(BLK_THREADS), lds, st, B);
+    else hipLaunchKernelGGL((attn_block_kernel<WT, FFN_MAX_PARTS>), dim3(grid), dim3(BLK_THREADS), lds, st, B);
+    return hipGetLastError();
+}
+template <int WT>
+hipError_t launch_ffn_block(const FfnParams &F, int grid, hipStream_t st) {
+    const size_t lds = ffn_lds_bytes();
+    if (F.nparts_in <= 4) hipLaunchKernelGGL((ffn_block_kernel<WT, 4>), dim3(grid), dim3(FFN_THREADS), lds, st, F);
+    else if (F.nparts_in <= 9) hipLaunchKernelGGL((ffn_block_kernel<WT, 9>), dim3(grid), dim3(FFN_THREADS), lds, st, F);
+    else hipLaunchKernelGGL((ffn_block_kernel<WT, BLK_MAX_PARTS>), dim3(grid), dim3(FFN_THREADS), lds, st, F);
+    return hipGetLastError();
+}
+
+BlockParams attn_block_params(nl_engine *e, int l, const float *x_in) {
+    const nl_config &c = e->cfg;
+    nl_engine::Layer &L = e->layers[l];
+    BlockParams B{};
+    B.qkv_q = L.qkv.q; B.qkv_s = L.qkv.s; B.wo_q = L.wo_head.q; B.wo_s = L.wo_head.s;
+    B.D = c.dim; B.npairs = L.qkv.npairs; B.n_q_heads = e->Hs; B.n_kv_heads = e->KVs; B.seq_len = c.seq_len;
+    B.rope_conj = c.rope_conjugate; B.qk_norm = c.qk_norm; B.single_stream = c.max_streams == 1 ? 1 : 0;
+    B.x = x_in; B.normw = L.attn_norm; B.eps = c.rms_eps; B.scale = (float)(1.0 / std::sqrt((double)e->hd));
+    B.rope_cos = e->rope_cos; B.rope_sin = e->rope_sin;
+    B.kcache = e->kcache + (long long)l * e->kv_layer_stride; B.vcache = e->vcache + (long long)l * e->kv_layer_stride;
+    B.kv_stream_stride = e->kv_stream_stride; B.ctl = e->ctl;
+    B.bias_q = L.bq; B.bias_k = L.bk; B.bias_v = L.bv; B.bias_out = L.bo; B.parts = e->parts;
+    B.xchg = e->xchg; B.tick = e->tick; B.layer_tag = (unsigned)(l + 1); B.status = e->tick + 1; B.host_status = e->h_status;
+    return B;
+}
+
+// Small models at short contexts, both halves of a layer fused (nl_block.h): embed -> { attn_block -> ffn_block } x L ->
+// lm_head -> argmax, 2 launches per layer.  Each block adds its predecessor's partial vectors to the residual stream in
+// its prologue (one designated workgroup stores the sum): the feed-forward block reads x[0] and writes x[1], the
+// attention block of the next layer reads x[1] and writes x[0]; the embedding row lands in x[0].
+void build_plan_blocks(nl_engine *e, std::vector<Op> &plan) {
+    plan.clear();
+    const nl_config &c = e->cfg;
+    const int nslices = e->Is / FFN_SLICE;
+    {
+        EmbedParams P{e->embd_raw, e->embd_type, c.dim, e->ctl, e->x[0], e->gamma_row, e->gamma_val, e->tick};
+        e->plan_embed = P;
+        plan.push_back({K_EMBED, 0, nullptr, 0, [P](hipStream_t st) {
+                               hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, P);
+                               return hipGetLastError();
+                           }});
+    }
+    for (int l = 0; l < c.n_layers; l++) {
+        nl_engine::Layer &L = e->layers[l];
+        {
+            BlockParams B = attn_block_params(e, l, l == 0 ? e->x[0] : e->x[1]);
+            if (l > 0) { B.parts_in = e->parts_ffn; B.nparts_in = nslices; B.x_out = e->x[0]; }
+            const int wt = L.qkv.wtype, grid = blk_grid(e->Hs), npin = l > 0 ? nslices : 0;
+            const size_t lds = blk_lds_bytes(c.dim);
+            plan.push_back({K_ATTNBLOCK, 0, nullptr, 0, [B, wt, grid, lds, npin, e](hipStream_t st) mutable {
+                                   B.dbg = e->dbg_block;      // nl_debug_stamps only
+                                   return wt == WT_Q8_0 ? launch_attn_block<WT_Q8_0>(B, npin, grid, lds, st)
+                                                        : launch_attn_block<WT_Q4_0>(B, npin, grid, lds, st);
+                               }});
+        }
+        if (l == c.n_layers - 1) {
+            // last layer: gate/up and down as the two GEMV launches, so that the residual stream is complete in memory and
+            // the LM head (2000 tiles, each re-reading its input) does not have to add partial vectors per tile
+            GemvParams P = base_params(e, L.gate, 2);
+            P.q1 = L.up.q; P.s1 = L.up.s;
+            P.x = e->x[0]; P.normw = L.ffn_norm; P.out = e->hb;
+            P.parts = e->parts; P.nparts = e->Hs; P.x_out = e->x[1];
+            push_gemv(plan, K_GATEUP, 0, nullptr, 0, L.gate.wtype, PRO_NORM_PARTS, EPI_SWIGLU, P);
+            GemvParams Q = base_params(e, L.down);
+            Q.x = e->hb; Q.out = e->x[1]; Q.resid = e->x[1];
+            push_gemv(plan, K_DOWN, 0, nullptr, 0, L.down.wtype, PRO_PLAIN, EPI_RESID, Q);
+        } else {
+            FfnParams F{};
+            F.gate_q = L.gate.q; F.gate_s = L.gate.s; F.up_q = L.up.q; F.up_s = L.up.s; F.dn_q = L.dn_slice.q; F.dn_s = L.dn_slice.s;
+            F.D = c.dim; F.I = e->Is; F.npairs = L.gate.npairs;
+            F.x = e->x[0]; F.normw = L.ffn_norm; F.parts_in = e->parts; F.nparts_in = e->Hs; F.x_out = e->x[1]; F.eps = c.rms_eps;
+            F.parts_out = e->parts_ffn; F.xchg = e->xchg_ffn; F.tick = e->tick; F.layer_tag = (unsigned)(l + 1);
+            F.status = e->tick + 1; F.host_status = e->h_status;
+            const int wt = L.gate.wtype, grid = ffn_grid(nslices);
+            plan.push_back({K_FFNBLOCK, 0, nullptr, 0, [F, wt, grid, e](hipStream_t st) mutable {
+                                   F.dbg = e->dbg_block;      // nl_debug_stamps only
+                                   return wt == WT_Q8_0 ? launch_ffn_block<WT_Q8_0>(F, grid, st) : launch_ffn_block<WT_Q4_0>(F, grid, st);
+                               }});
+        }
+    }
+    int lm_blocks, lm_spb;
+    {   // final RMSNorm + LM head (go/model.go:616-619)
+        GemvParams P = base_params(e, e->lm_head);
+        P.x = e->x[1]; P.normw = e->output_norm;
+        P.out = e->logits; P.amax_val = e->amax_val; P.amax_idx = e->amax_idx;
+        lm_blocks = (P.ntiles + P.tw - 1) / P.tw;
+        lm_spb = (P.tw * TR + 63) / 64;
+        push_gemv(plan, K_LMHEAD, 0, e->logits, (size_t)e->Vs, e->lm_head.wtype, PRO_NORM, EPI_STORE, P);
+    }
+    {
+        ArgmaxParams P{e->logits, c.vocab, e->amax_val, e->amax_idx, lm_blocks * lm_spb, e->ctl, e->ids, e->result};
+        e->plan_argmax = P;
+        plan.push_back({K_ARGMAX, 0, nullptr, 0, [P](hipStream_t st) {
+                               hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, P);
+                               return hipGetLastError();
+                           }});
+    }
+    link_prefetch(plan);
+}
+
 // Build the per-token launch plan: the device-side restatement of Forward
 // (go/model.go:490-620).  token / pos / stream are read from e->ctl by the
 // kernels, so one captured graph serves every step.
 void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
+    if (fused && e->fused_mode == 1 && e->ffn_fused) { build_plan_blocks(e, plan); return; }
     plan.clear();
     const nl_config &c = e->cfg;
     const bool p2p = e->p2p.on;
@@ -525,22 +637,13 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         if (fused && e->fused_mode == 1) {
             // the whole attention half as one launch per layer (nl_block.h); its H partial vectors are added to the
             // residual stream by the gate/up prologue below
-            BlockParams B{};
-            B.qkv_q = L.qkv.q; B.qkv_s = L.qkv.s; B.wo_q = L.wo_head.q; B.wo_s = L.wo_head.s;
-            B.D = c.dim; B.npairs = L.qkv.npairs; B.n_q_heads = e->Hs; B.n_kv_heads = e->KVs; B.seq_len = c.seq_len;
-            B.rope_conj = c.rope_conjugate; B.qk_norm = c.qk_norm; B.single_stream = c.max_streams == 1 ? 1 : 0;
-            B.x = e->x[cur]; B.normw = L.attn_norm; B.eps = c.rms_eps; B.scale = (float)(1.0 / std::sqrt((double)e->hd));
-            B.rope_cos = e->rope_cos; B.rope_sin = e->rope_sin; B.kcache = kc; B.vcache = vc;
-            B.kv_stream_stride = e->kv_stream_stride; B.ctl = e->ctl;
-            B.bias_q = L.bq; B.bias_k = L.bk; B.bias_v = L.bv; B.bias_out = L.bo; B.parts = e->parts;
-            B.xchg = e->xchg; B.tick = e->tick; B.layer_tag = (unsigned)(l + 1); B.status = e->tick + 1; B.host_status = e->h_status;
+            BlockParams B = attn_block_params(e, l, e->x[cur]);
             const int wt = L.qkv.wtype, grid = blk_grid(e->Hs);
             const size_t lds = blk_lds_bytes(c.dim);
             plan.push_back({K_ATTNBLOCK, 0, nullptr, 0, [B, wt, grid, lds, e](hipStream_t st) mutable {
                                    B.dbg = e->dbg_block;      // nl_debug_stamps only
-                                   if (wt == WT_Q8_0) hipLaunchKernelGGL(attn_block_kernel<WT_Q8_0>, dim3(grid), dim3(BLK_THREADS), lds, st, B);
-                                   else hipLaunchKernelGGL(attn_block_kernel<WT_Q4_0>, dim3(grid), dim3(BLK_THREADS), lds, st, B);
-                                   return hipGetLastError();
+                                   return wt == WT_Q8_0 ? launch_attn_block<WT_Q8_0>(B, 0, grid, lds, st)
+                                                        : launch_attn_block<WT_Q4_0>(B, 0, grid, lds, st);
                                }});
             parts_pending = true;
         } else {
@@ -1405,6 +1508,19 @@ int nl_upload_tensor(nl_handle e, const char *name, uint32_t type, const void *d
     if (f == "ffn_down.weight") {
         int rc = matrix_upload(L.down, D, c.interm, 0, D, e->rank * e->Is, e->Is, 0, (D + TR - 1) / TR, ROWMAP_IDENT, true);
         if (!rc) L.down.ready = true;
+        // small models also keep W_down sliced by 256 columns for the fused feed-forward block (nl_block.h): slice c =
+        // D/16 tiles of four pairs each.  The raw tensor is still in the staging buffer.
+        const int dt = device_type((int)type);
+        if (!rc && e->G == 1 && hd == 64 && D % PAIR == 0 && D <= BLK_MAXG * KL * PAIR && D % (FFN_MEMBERS * 2) == 0 && e->Hs <= BLK_MAX_PARTS &&
+            c.interm % FFN_SLICE == 0 && c.interm / FFN_SLICE <= FFN_MAX_PARTS && (dt == WT_Q8_0 || dt == WT_Q4_0) && !L.dn_slice.ready) {
+            PackedMat &m = L.dn_slice;
+            const int ns = c.interm / FFN_SLICE;
+            HIPCK(e, alloc_packed(e, m, (int)type, ns * (D / TR), D, FFN_SLICE));
+            for (int sc = 0; sc < ns; sc++)
+                HIPCK(e, repack(e, m, e->stage, (int)type, c.interm, 0, D, sc * FFN_SLICE, FFN_SLICE, sc * (D / TR), D / TR, ROWMAP_IDENT));
+            HIPCK(e, hipStreamSynchronize(e->stream));
+            m.ready = true;
+        }
         return rc;
     }
     if (f == "attn_q.bias" || f == "attn_k.bias" || f == "attn_v.bias" || f == "attn_output.bias") {
@@ -1535,6 +1651,18 @@ int nl_finalize(nl_handle e) {
         e->fused = e->fused_mode != 0;
         const char *fm = getenv("NL_FUSED_MAX_POS");
         e->fused_max_pos = fm ? atoi(fm) : 256;
+        {
+            const char *ff = getenv("NL_FUSED_FFN");   // knob (tests, tools): 0 keeps gate/up and down as two launches
+            bool okf = e->fused_mode == 1 && !(ff && atoi(ff) == 0);
+            for (const auto &L : e->layers)
+                okf = okf && L.dn_slice.ready && L.dn_slice.wtype == L.qkv.wtype && L.gate.wtype == L.qkv.wtype && L.up.wtype == L.qkv.wtype;
+            e->ffn_fused = okf;
+        }
+        if (e->ffn_fused) {
+            HIPCK(e, dalloc(&e->parts_ffn, (size_t)(e->Is / FFN_SLICE) * c.dim, &e->bytes_state));
+            HIPCK(e, dalloc(&e->xchg_ffn, (size_t)e->Is, &e->bytes_state));
+            HIPCK(e, hipMemset(e->xchg_ffn, 0, (size_t)e->Is * 8));
+        }
         if (e->fused) {
             if (e->fused_mode == 1) HIPCK(e, dalloc(&e->parts, (size_t)e->Hs * c.dim, &e->bytes_state));
             const size_t nx = e->fused_mode == 1 ? (size_t)e->Hs * 192 : (size_t)e->KVs * (e->gqa + 2) * 64;
@@ -1634,7 +1762,7 @@ int nl_destroy(nl_handle e) {
         if (e->p2p.epoch) (void)hipFree(e->p2p.epoch);
     }
     void *bufs[] = {e->embd_raw, e->output_norm, e->rope_cos, e->rope_sin, e->x[0], e->x[1], e->qbuf, e->part_o,
-                    e->part_ml, e->hb, e->ar, e->parts, e->xchg, e->tick, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result, e->amax_val,
+                    e->part_ml, e->hb, e->ar, e->parts, e->xchg, e->tick, e->parts_ffn, e->xchg_ffn, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result, e->amax_val,
                     e->amax_idx};
     for (void *b : bufs) if (b) hipFree(b);
     if (e->h_ctl) hipHostFree(e->h_ctl);
@@ -2081,6 +2209,14 @@ int nl_debug_stamps(nl_handle e, int kind, long long *out /* 16 waves x 8 */) {
         GemvParams P = base_params(e, L.down);
         P.x = e->hb; P.out = e->x[1]; P.resid = e->x[1]; P.dbg = d;
         s = launch_gemv_t<PRO_PLAIN, EPI_RESID>(L.down.wtype, P, e->stream);
+    } else if (kind == K_FFNBLOCK && e->fused && e->ffn_fused) {
+        for (const Op &op : e->ps[1].ops)
+            if (op.kind == K_FFNBLOCK) {
+                e->dbg_block = d;
+                s = op.fn(e->stream);
+                e->dbg_block = nullptr;
+                break;
+            }
     } else if (kind == K_ATTNBLOCK && e->fused) {
         // layer 0's block launch as the plan holds it, with phase stamps (position / stream as ctl has them)
         for (const Op &op : e->ps[1].ops)

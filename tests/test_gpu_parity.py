@@ -980,9 +980,10 @@ def _kinds(dev, pos):
     return {k: c for k, (ms, c) in dev.profile_forward(5, pos, iters=1).items() if c}
 
 
+@pytest.mark.parametrize("ffn", ["ffn_block", "gate_up+down"])
 @pytest.mark.parametrize("wtype", ["q8_0", "q4_0"])
 @pytest.mark.parametrize("variant", ["mha", "gqa", "qknorm_conj_bias"])
-def test_fused_attention_block_matches_oracle(hip, orc, tmp_path, monkeypatch, wtype, variant):
+def test_fused_attention_block_matches_oracle(hip, orc, tmp_path, monkeypatch, wtype, variant, ffn):
     # one launch per layer for RMSNorm + Q/K/V + RoPE + KV store + attention + WO (go/model.go:517-594) against the
     # CPU oracle, teacher-forced across the 128-position pass boundary (NL_FUSED_MAX_POS lifted so the block runs at
     # every position), for MHA, a GQA group of 2 and the optional QK-norm / conjugate RoPE / bias branches
@@ -994,6 +995,9 @@ def test_fused_attention_block_matches_oracle(hip, orc, tmp_path, monkeypatch, w
     synth.generate_gguf(str(p), shape, wtype, 61)
     g = gguf.load_gguf(str(p))
     monkeypatch.setenv("NL_FUSED_MAX_POS", "4096")
+    # ffn_block: the feed-forward half is one launch as well (gate/up rows, SiLU * up, exchange, W_down column slice per
+    # cluster of eight workgroups); the other case keeps gate/up and down as the two GEMV launches
+    monkeypatch.setenv("NL_FUSED_FFN", "1" if ffn == "ffn_block" else "0")
     dev = hip.load_llama_model(g)
     monkeypatch.setenv("NL_FUSED_ATTN", "0")
     plain = hip.load_llama_model(g)
@@ -1010,6 +1014,10 @@ def test_fused_attention_block_matches_oracle(hip, orc, tmp_path, monkeypatch, w
     assert worst <= LOGIT_TOL
     k = _kinds(dev, 20)
     assert k.get("attn_block") == shape.n_layer and "qkv_rope" not in k and "wo_resid" not in k, k
+    if ffn == "ffn_block":   # (the last layer keeps the two GEMV launches so that the LM head reads a complete residual stream)
+        assert k.get("ffn_block") == shape.n_layer - 1 and k.get("gate_up_swiglu") == 1 and k.get("down_resid") == 1, k
+    else:
+        assert "ffn_block" not in k and k.get("gate_up_swiglu") == shape.n_layer, k
     assert "attn_block" not in _kinds(plain, 20)
     # the K/V rows the block stored are the ones the five-launch plan stores
     n = shape.n_layer * shape.n_kv_head * shape.seq_len * 64

@@ -24,3 +24,13 @@ for rep in range(4):
         out.append(f"{names[k]}:+{st[k] - prev}")
         prev = st[k]
     print(f"total {st[11] - st[0]} cycles | " + " ".join(out))
+fn = {1: "loads issued", 2: "x staged+ss", 3: "barrier1", 4: "inv+dots+quad", 5: "barrier2", 6: "silu+publish", 7: "gathered", 8: "barrier3", 9: "down+store"}
+for rep in range(3):
+    buf = (C.c_longlong * 128)()
+    _lib.check(dev._h, L.nl_debug_stamps(dev._h, 10, buf))
+    st = list(buf)
+    prev, out = st[0], []
+    for k in range(1, 10):
+        out.append(f"{fn[k]}:+{st[k] - prev}")
+        prev = st[k]
+    print(f"ffn_block total {st[9] - st[0]} cycles | " + " ".join(out))
