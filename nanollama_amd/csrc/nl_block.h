@@ -200,11 +200,12 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     BLK_STAMP(4);
 
     // this member's quarter of the head's WO slice streams in while the exchange and the attention run
+    // (lane = (row, block of the head's pair): two lanes per row, each 32 of the 64 columns)
     const int wo_rows = D / BLK_MEMBERS, wo_tiles = D / TR;
-    const int wrow = jm * wo_rows + min(tid, wo_rows - 1);
-    uint4 wc[CPP];
-    uint2 wsc;
-    load_pair<WT>(P.wo_q, P.wo_s, (long long)h * wo_tiles + (wrow >> 4), 0, 1, wrow & 15, 0, wc, wsc);
+    const int wrow = jm * wo_rows + min(tid >> 1, wo_rows - 1), wblk = tid & 1;
+    uint4 wc[CPP / 2];
+    uint32_t wd16;
+    load_block<WT>(P.wo_q, P.wo_s, (long long)h * wo_tiles + (wrow >> 4), 0, 1, wrow & 15, 0, wblk, wc, wd16);
 
     // ---- scale, bias, RoPE (go/model.go:449-477); publish the 48 values to the other members ----
     if (e_thr) {
@@ -285,65 +286,64 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
         }
         __syncthreads();
         if (ch == 0) BLK_STAMP(13);
-        if (wave < 2) {
-            // Softmax pieces (go/quant.go:610-626: max-subtract, f32(exp(f64)), f32 sum) per 64-position half; the halves
-            // are merged below like position splits, so no wavefront waits for the other one's maximum
-            const int row = wave * 64 + lane;
-            const float s0 = row < n ? sc[row] : -INFINITY;
-            const float m = wave_max_f32(s0);
-            const float p0 = row < n ? (float)exp((double)(s0 - m)) : 0.f;
-            if (row < n) sc[row] = p0;
-            const float l = wave_sum_f32(p0);
-            if (lane == 0) { chunk[(2 * ch + wave) * 66] = m; chunk[(2 * ch + wave) * 66 + 1] = l; }
+        if (wave == 0) {   // Softmax go/quant.go:610-626 over the pass: max-subtract, f32(exp(f64)), f32 sum
+            const float s0 = lane < n ? sc[lane] : -INFINITY;
+            const float s1 = lane + 64 < n ? sc[lane + 64] : -INFINITY;
+            const float m = wave_max_f32(fmaxf(s0, s1));
+            const float p0 = lane < n ? (float)exp((double)(s0 - m)) : 0.f;
+            float p1 = 0.f;
+            if (n > 64) p1 = lane + 64 < n ? (float)exp((double)(s1 - m)) : 0.f;   // (wave-uniform: short passes skip the second exp)
+            if (lane < n) sc[lane] = p0;
+            if (lane + 64 < n) sc[lane + 64] = p1;
+            const float l = wave_sum_f32(p0 + p1);
+            if (lane == 0) { chunk[ch * 66] = m; chunk[ch * 66 + 1] = l; }
         }
         __syncthreads();
         if (ch == 0) BLK_STAMP(14);
         if (tid < BLK_KV_THREADS) {
-            // rows tg, tg + 32 belong to the first half, tg + 64, tg + 96 to the second
-            float4 o[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int kk = 0; kk < NV; kk++) {
                 const int row = tg + kk * NGR;
                 const float pw = row < n ? sc[row] : 0.f;   // (a masked row's V may be stale but is finite)
-                float4 &a = o[kk >> 1];
-                a.x = fmaf(pw, vreg[kk].x, a.x); a.y = fmaf(pw, vreg[kk].y, a.y);
-                a.z = fmaf(pw, vreg[kk].z, a.z); a.w = fmaf(pw, vreg[kk].w, a.w);
+                o.x = fmaf(pw, vreg[kk].x, o.x); o.y = fmaf(pw, vreg[kk].y, o.y);
+                o.z = fmaf(pw, vreg[kk].z, o.z); o.w = fmaf(pw, vreg[kk].w, o.w);
             }
-            *reinterpret_cast<float4 *>(ored + tg * HD + c4 * 4) = o[0];
-            *reinterpret_cast<float4 *>(ored + (NGR + tg) * HD + c4 * 4) = o[1];
+            *reinterpret_cast<float4 *>(ored + tg * HD + c4 * 4) = o;
         }
         __syncthreads();
-        if (tid < 2 * HD) {
-            const int half = tid >> 6, dd = tid & 63;
+        if (tid < HD) {
             float s = 0.f;
 #pragma unroll 8
-            for (int kk = 0; kk < NGR; kk++) s += ored[(half * NGR + kk) * HD + dd];
-            chunk[(2 * ch + half) * 66 + 2 + dd] = s;
+            for (int kk = 0; kk < NGR; kk++) s += ored[kk * HD + tid];
+            chunk[ch * 66 + 2 + tid] = s;
         }
-        __syncthreads();   // sc / ored are rewritten by the next pass
+        if (ch + 1 < nch) __syncthreads();   // sc / ored are rewritten by the next pass
     }
     BLK_STAMP(9);
-    if (tid < HD && pos < 64) on[tid] = chunk[2 + tid] * (1.0f / chunk[1]);   // one half pass: plain normalisation
-    else if (tid < HD) {   // merge the half passes by the rule of the five-launch plan's WO prologue (load_x4<PRO_ATTN>)
-        const int np = 2 * nch;
-        float M = chunk[0];
-        for (int c = 1; c < np; c++) M = fmaxf(M, chunk[c * 66]);
-        float v = 0.f, L = 0.f;
-        for (int c = 0; c < np; c++) {
-            const float w = (float)exp((double)(chunk[c * 66] - M));   // an empty half has max -inf: weight 0
-            L += w * chunk[c * 66 + 1];
-            v += w * chunk[c * 66 + 2 + tid];
+    if (tid < HD) {   // merge the passes exactly as the WO prologue of the five-launch plan does (load_x4<PRO_ATTN>)
+        if (nch == 1) on[tid] = chunk[2 + tid] * (1.0f / chunk[1]);
+        else {
+            float M = chunk[0];
+            for (int c = 1; c < nch; c++) M = fmaxf(M, chunk[c * 66]);
+            float v = 0.f, L = 0.f;
+            for (int c = 0; c < nch; c++) {
+                const float w = (float)exp((double)(chunk[c * 66] - M));
+                L += w * chunk[c * 66 + 1];
+                v += w * chunk[c * 66 + 2 + tid];
+            }
+            on[tid] = v * (1.0f / L);
         }
-        on[tid] = v * (1.0f / L);
     }
     __syncthreads();
     BLK_STAMP(10);
 
     // ---- this member's rows of the head's 64 columns of WO (go/model.go:590): partial [D/4], added by the consumer ----
-    if (tid < wo_rows) {
-        float v = PairDot<WT>::run(wc, wsc, on, 0.f);
+    if (tid < wo_rows * 2) {
+        float v = BlockDot<WT>::run(wc, wd16, on + wblk * 32);
+        v += dpp_f32<DPP_QUAD_XOR1>(v);     // the two blocks of a row sit in adjacent lanes
         if (P.bias_out && h == 0) v += P.bias_out[wrow];
-        P.parts[(long long)h * D + wrow] = v;
+        if (wblk == 0) P.parts[(long long)h * D + wrow] = v;
     }
     BLK_STAMP(11);
 #undef BLK_STAMP
@@ -481,11 +481,12 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_block_kernel(FfnParams P) {
     FFN_STAMP(5);
 
     // this member's rows of the slice's W_down columns stream in while the exchange runs: lane = (row, pair of the slice)
+    // (lane = (row, pair of the slice, block of the pair): eight lanes per row, each 32 of the 256 columns)
     const int dn_rows = D / FFN_MEMBERS, dn_tiles = D / TR;
-    const int drow = mem * dn_rows + min(tid >> 2, dn_rows - 1), dpair = tid & 3;
-    uint4 dc[CPP];
-    uint2 dsc;
-    load_pair<WT>(P.dn_q, P.dn_s, ((long long)cl * dn_tiles + (drow >> 4)) * KL, 0, KL, drow & 15, dpair, dc, dsc);
+    const int drow = mem * dn_rows + min(tid >> 3, dn_rows - 1), dpair = (tid >> 1) & 3, dblk = tid & 1;
+    uint4 dc[CPP / 2];
+    uint32_t dd16;
+    load_block<WT>(P.dn_q, P.dn_s, ((long long)cl * dn_tiles + (drow >> 4)) * KL, 0, KL, drow & 15, dpair, dblk, dc, dd16);
 
     // ---- h = SiLU(gate) * up (go/quant.go:629-631, go/model.go:604-606) for this member's 32 rows; publish ----
     if (e_thr) {
@@ -515,10 +516,11 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_block_kernel(FfnParams P) {
     FFN_STAMP(8);
 
     // ---- this member's rows of W_down over the slice's 256 columns (go/model.go:609-612): a partial [D / 8] vector ----
-    if (tid < dn_rows * 4) {
-        float v = PairDot<WT>::run(dc, dsc, hs + dpair * XS_PAIR, 0.f);
-        v = quad_sum(v);     // the four pairs of a row sit in one quad
-        if (dpair == 0) P.parts_out[(size_t)cl * D + drow] = v;
+    if (tid < dn_rows * 8) {
+        float v = BlockDot<WT>::run(dc, dd16, hs + dpair * XS_PAIR + dblk * 32);
+        v = quad_sum(v);                        // lanes 8i .. 8i+7 hold a row: two quads
+        v += dpp_f32<DPP_HALF_MIRROR>(v);       // (lane 7 - i of the 8: the other quad's sum)
+        if ((tid & 7) == 0) P.parts_out[(size_t)cl * D + drow] = v;
     }
     FFN_STAMP(9);
 #undef FFN_STAMP

@@ -306,6 +306,42 @@ template <> struct PairDot<WT_Q4_0> {
     }
 };
 
+// One 32-element block of a pair (the fused block kernels split a pair's two blocks over two lanes): chunks c[0 .. CPP/2),
+// this block's fp16 scale, the block's 32 inputs.  Same arithmetic per block as PairDot.
+template <int WT> struct BlockDot;
+template <> struct BlockDot<WT_Q8_0> {
+    static __device__ __forceinline__ float run(const uint4 *c, uint32_t d16, const float *xp) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(xp);
+        Acc4 s{0.f, 0.f, 0.f, 0.f};
+        const uint4 lo = c[0], hi = c[1];
+        dot4_i8(lo.x, x4[0], s); dot4_i8(lo.y, x4[1], s); dot4_i8(lo.z, x4[2], s); dot4_i8(lo.w, x4[3], s);
+        dot4_i8(hi.x, x4[4], s); dot4_i8(hi.y, x4[5], s); dot4_i8(hi.z, x4[6], s); dot4_i8(hi.w, x4[7], s);
+        return ((s.a + s.b) + (s.c + s.d)) * h2f_bits(d16);
+    }
+};
+template <> struct BlockDot<WT_Q4_0> {
+    static __device__ __forceinline__ float run(const uint4 *c, uint32_t d16, const float *xp) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(xp);
+        Acc4 s{0.f, 0.f, 0.f, 0.f};
+        const uint4 q = c[0];
+        dot_q4_word(q.x, x4[0], x4[4], s); dot_q4_word(q.y, x4[1], x4[5], s);
+        dot_q4_word(q.z, x4[2], x4[6], s); dot_q4_word(q.w, x4[3], x4[7], s);
+        return ((s.a + s.b) + (s.c + s.d)) * h2f_bits(d16);
+    }
+};
+// chunks and scale of block `blk` (0 / 1) of pair k in a tile: the block-level counterpart of load_pair
+template <int WT>
+__device__ __forceinline__ void load_block(const uint8_t *q, const uint32_t *s, long long tile_pair0, int g, int gsz, int r, int k,
+                                           int blk, uint4 *c, uint32_t &d16) {
+    constexpr int CPP = WTraits<WT>::CPP, CPB = CPP / 2;
+    const uint4 *qb = reinterpret_cast<const uint4 *>(q) + (tile_pair0 * (CPP * TR) + (long long)g * (KL * CPP * TR));
+    const unsigned off = __umul24((unsigned)r, (unsigned)gsz) + (unsigned)k;
+#pragma unroll
+    for (int j = 0; j < CPB; j++) c[j] = (qb + (blk * CPB + j) * TR * gsz)[off];
+    const long long sb = tile_pair0 * TR + (long long)g * (KL * TR);
+    d16 = ((s + sb)[off] >> (16 * blk)) & 0xffffu;
+}
+
 template <> struct PairDot<WT_F16> {
     static __device__ __forceinline__ float run(const uint4 *c, uint2, const float *xp, float acc) {
         const float4 *x4 = reinterpret_cast<const float4 *>(xp);
