@@ -492,6 +492,15 @@ constexpr int DPP_QUAD_XOR2 = 0x4E;   // quad_perm [2,3,0,1]
 constexpr int DPP_HALF_MIRROR = 0x141;
 constexpr int DPP_ROW_MIRROR = 0x140;
 
+// row_bcast15 / row_bcast31 (gfx9): lane 15 of each row of 16 into the next row / lane 31 into rows 2-3; rows outside the
+// row mask receive 0.  With the four in-row steps they make a full-wave reduction without ds_bpermute (the result is in
+// lane 63 and is broadcast through an SGPR).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_bcast_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWMASK, 0xF, false));
+}
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
 // sum over the 4 lanes of each quad, result in every lane of the quad
 __device__ __forceinline__ float quad_sum(float v) {
     v += dpp_f32<DPP_QUAD_XOR1>(v);
@@ -937,19 +946,23 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     v = fmaxf(v, dpp_f32<DPP_QUAD_XOR1>(v));
     v = fmaxf(v, dpp_f32<DPP_QUAD_XOR2>(v));
     v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v));
-    v = fmaxf(v, dpp_f32<DPP_ROW_MIRROR>(v));
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
+    v = fmaxf(v, dpp_f32<DPP_ROW_MIRROR>(v));      // every lane: max of its row of 16
+    // rows outside the mask receive 0 from the broadcast: take the max only where the broadcast applies
+    const int lane = (int)(threadIdx.x & 63);
+    const float b15 = dpp_bcast_f32<DPP_ROW_BCAST15, 0xA>(v);
+    v = (lane & 16) ? fmaxf(v, b15) : v;           // rows 1, 3: max with rows 0, 2
+    const float b31 = dpp_bcast_f32<DPP_ROW_BCAST31, 0xC>(v);
+    v = (lane & 32) ? fmaxf(v, b31) : v;           // rows 2, 3: max with row 1 (= rows 0-1)
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_sum_f32(float v) {
     v += dpp_f32<DPP_QUAD_XOR1>(v);
     v += dpp_f32<DPP_QUAD_XOR2>(v);
     v += dpp_f32<DPP_HALF_MIRROR>(v);
-    v += dpp_f32<DPP_ROW_MIRROR>(v);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    v += dpp_f32<DPP_ROW_MIRROR>(v);               // every lane: sum of its row of 16
+    v += dpp_bcast_f32<DPP_ROW_BCAST15, 0xA>(v);   // rows 1, 3 += rows 0, 2
+    v += dpp_bcast_f32<DPP_ROW_BCAST31, 0xC>(v);   // rows 2, 3 += row 1 (= rows 0-1): lane 63 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 template <int HD, int G, bool FIN = false>
