@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     }
     // the first 128 cache rows of this kv head (rows >= pos hold stale finite data and are masked / replaced below)
     const int c4 = tid % R4, tg = tid / R4;
-    float4 kreg[NV], vreg[NV];
+    float4 kreg[NV], vreg[NV], kregn[NV];
     const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + (long long)kvh * P.seq_len * HD);
     const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + (long long)kvh * P.seq_len * HD);
     if (tid < BLK_KV_THREADS) {
@@ -257,13 +257,19 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     for (int ch = 0; ch < nch; ch++) {
         const int t0 = ch * ATT_CH, n = min(ATT_CH, pos + 1 - t0);
         if (tid < BLK_KV_THREADS) {
+            // K of the next pass and V of this pass are requested now: V is not needed before the P*V phase (two barriers
+            // away) and the next K rows arrive during this pass, so a later pass costs its arithmetic, not a memory round trip
             if (ch > 0) {
 #pragma unroll
                 for (int kk = 0; kk < NV; kk++) {
-                    const int row = min(tg + kk * NGR, n - 1);
-                    kreg[kk] = K4[(long long)(t0 + row) * R4 + c4];
-                    vreg[kk] = V4[(long long)(t0 + row) * R4 + c4];
+                    kreg[kk] = kregn[kk];
+                    vreg[kk] = V4[(long long)(t0 + min(tg + kk * NGR, n - 1)) * R4 + c4];
                 }
+            }
+            if (ch + 1 < nch) {
+                const int n1 = min(ATT_CH, pos + 1 - t0 - ATT_CH);
+#pragma unroll
+                for (int kk = 0; kk < NV; kk++) kregn[kk] = K4[(long long)(t0 + ATT_CH + min(tg + kk * NGR, n1 - 1)) * R4 + c4];
             }
             // scores: this thread holds 4 of the 64 dims of 4 cache rows; the 16 lanes of a row sum on DPP (no LDS staging)
             const float4 q4 = *reinterpret_cast<const float4 *>(qs + c4 * 4);

@@ -544,15 +544,37 @@ __device__ __forceinline__ float4 load_x4(const GemvParams &P, int gcol, unsigne
             float il = 1.0f / l0;
             return make_float4(o0.x * il, o0.y * il, o0.z * il, o0.w * il);
         }
+        // Long contexts (this plan serves positions >= 256 and the models the fused launches do not cover): the (max, sum)
+        // pairs and partial rows of EIGHT splits are fetched per memory round trip (clamped split index, surplus ones get
+        // weight 0 -- a runtime "for c < ns: load" loop is ns dependent round trips), and the merge weights
+        // exp(m_c - M) use the f32 exponential: they are this engine's own construct (the reference has no splits), and
+        // sixteen float64 exps per lane in every wavefront of the launch cost more than the GEMV itself at pos 2047.
+        const float2 *ml2 = reinterpret_cast<const float2 *>(ml);
         float M = m0;
-        for (int c = 1; c < ns; c++) M = fmaxf(M, ml[2 * c]);
+        for (int c0 = 0; c0 < ns; c0 += 8) {
+            float2 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) t[j] = ml2[min(c0 + j, ns - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; j++) M = fmaxf(M, t[j].x);
+        }
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         float L = 0.f;
-        for (int c = 0; c < ns; c++) {
-            float w = (float)exp((double)(ml[2 * c] - M));
-            float4 o = *reinterpret_cast<const float4 *>(po + (long long)c * hd);
-            L += w * ml[2 * c + 1];
-            v.x += w * o.x; v.y += w * o.y; v.z += w * o.z; v.w += w * o.w;
+        for (int c0 = 0; c0 < ns; c0 += 8) {
+            float2 t[8];
+            float4 o[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int c = min(c0 + j, ns - 1);
+                t[j] = ml2[c];
+                o[j] = *reinterpret_cast<const float4 *>(po + (long long)c * hd);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float w = c0 + j < ns ? __expf(t[j].x - M) : 0.f;
+                L += w * t[j].y;
+                v.x += w * o[j].x; v.y += w * o[j].y; v.z += w * o[j].z; v.w += w * o[j].w;
+            }
         }
         float il = 1.0f / L;
         return make_float4(v.x * il, v.y * il, v.z * il, v.w * il);
