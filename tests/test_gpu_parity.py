@@ -1128,3 +1128,27 @@ def test_f16_prompt_prefill_runs_on_the_matrix_cores(hip, orc, tmp_path):
         assert np.abs(lg[i] - solo.state.logits).max() <= LOGIT_TOL * scale
     for m in (dev, step, many, solo, ref):
         m.close()
+
+
+@pytest.mark.parametrize("shape", [synth.ModelShape("fb_streams", 2, 192, 3, 3, 1024, seq_len=96),
+                                   synth.ModelShape("fg_streams", 2, 1024, 16, 4, 512, seq_len=96, interm=1024)])
+def test_fused_launches_keep_streams_independent(hip, tmp_path, shape):
+    # the fused attention launches address the KV cache of the stream named in the control block (several decode
+    # streams per engine): two interleaved sequences must not see each other, bitwise, in both fused forms
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 91, mode="qrand")
+    g = gguf.load_gguf(str(p))
+    dev = hip.load_llama_model(g, max_streams=2)
+    assert "attn_block" in _kinds(dev, 3)
+    dev.reset(0); dev.reset(1)
+    a, b = synth.prompt_ids(20, shape.vocab, seed=1), synth.prompt_ids(20, shape.vocab, seed=2)
+    la = []
+    for pos in range(20):
+        dev.forward(a[pos], pos, stream=0)
+        la.append(dev.state.logits.copy())
+        dev.forward(b[pos], pos, stream=1)
+    solo = hip.load_llama_model(g)
+    for pos in range(20):
+        solo.forward(a[pos], pos)
+        assert la[pos].tobytes() == solo.state.logits.tobytes(), pos
+    dev.close(); solo.close()
