@@ -10,6 +10,7 @@
 #include "../../include/nanollama_hip.h"
 #include "nl_kernels.h"
 #include "nl_qgemm.h"
+#include "nl_qgemm2.h"
 #include "nl_batch.h"
 #include "nl_sample.h"
 #include "nl_p2p.h"
@@ -971,6 +972,22 @@ hipError_t launch_xsplit(int wtype, const float *x, int ldx, int cols, int n_tok
     return hipGetLastError();
 }
 
+// Long token runs over Q4_0 weights take the weights-through-LDS kernel (nl_qgemm2.h: 1.2-1.5x qgemm_kernel from 128
+// tokens up, tools/qgemm2_bench.hip; Q8_0's 32-byte rows cost more to expand and stay on qgemm_kernel).  Workgroups of
+// 64 rows: x 256 tokens (two token tiles per wavefront) when that still gives every compute unit two of them, else x 64.
+bool qgemm2_ok(int wtype, int n_tokens) {
+    static const int min_n = getenv("NL_QG2_MIN_TOKENS") ? atoi(getenv("NL_QG2_MIN_TOKENS")) : 128;   // knob (tests, tools): a huge value disables
+    return wtype == WT_Q4_0 && n_tokens >= min_n;
+}
+template <int EPI>
+hipError_t launch_qgemm2(const QGemmParams &P, int row_blocks, hipStream_t st) {
+    if ((long long)row_blocks * ((P.n_tokens + 255) / 256) >= 512)
+        hipLaunchKernelGGL((qgemm2_kernel<WT_Q4_0, 4, 2, 8, EPI>), dim3(row_blocks, (P.n_tokens + 255) / 256, 1), dim3(512), 0, st, P);
+    else
+        hipLaunchKernelGGL((qgemm2_kernel<WT_Q4_0, 4, 1, 4, EPI>), dim3(row_blocks, (P.n_tokens + 63) / 64, 1), dim3(256), 0, st, P);
+    return hipGetLastError();
+}
+
 // gate || up with the SwiGLU epilogue (nl_qgemm.h): 4 wavefronts x (gate tile, up tile) per workgroup, no split-K.
 // Worth it only when the unsplit grid fills the chip; the caller falls back to the plain launch + bswiglu otherwise.
 constexpr int QG_FUSED_WAVES = 4;
@@ -982,6 +999,7 @@ bool qgemm_swiglu_fits(int ntiles, int n_tokens) {
 hipError_t launch_qgemm_swiglu(int wtype, QGemmParams P, hipStream_t st) {
     P.nt16 = ((P.n_tokens + 63) / 64) * 4;
     P.ksplit = 1;
+    if (qgemm2_ok(wtype, P.n_tokens)) return launch_qgemm2<QG_EPI_SWIGLU>(P, (P.ntiles + 1) / 2, st);
     const dim3 grid((P.ntiles + QG_FUSED_WAVES - 1) / QG_FUSED_WAVES, (P.n_tokens + QG_TOK - 1) / QG_TOK, 1);
     switch (wtype) {
     case WT_Q4_0: hipLaunchKernelGGL((qgemm_kernel<WT_Q4_0, QG_FUSED_WAVES, 2, QG_EPI_SWIGLU>), grid, dim3(QG_FUSED_WAVES * 64), 0, st, P); break;
@@ -1001,6 +1019,7 @@ bool qgemm_rope_fits(int ntiles, int n_tokens) {
 hipError_t launch_qgemm_rope(int wtype, QGemmParams P, hipStream_t st) {
     P.nt16 = ((P.n_tokens + 63) / 64) * 4;
     P.ksplit = 1;
+    if (qgemm2_ok(wtype, P.n_tokens)) return launch_qgemm2<QG_EPI_ROPE>(P, (P.ntiles + 3) / 4, st);
     P.row_groups = (P.ntiles + QG_WAVES - 1) / QG_WAVES;
     const dim3 grid(P.row_groups, (P.n_tokens + QG_TOK - 1) / QG_TOK, 1);
     switch (wtype) {
@@ -1027,6 +1046,12 @@ hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_bu
     const int tok_tiles = (P.n_tokens + QG_TOK - 1) / QG_TOK;
     const int nchunks = (P.cols / 32 + QG_KC - 1) / QG_KC;
     const int mats = P.q1 ? 2 : 1;
+    if (qgemm2_ok(wtype, P.n_tokens) && mats == 1 && ((P.ntiles + 3) / 4) * tok_tiles >= 128) {   // unsplit grid fills the chip
+        P.ksplit = 1;
+        P.part = nullptr;
+        if (ks_out) *ks_out = 1;
+        return launch_qgemm2<QG_EPI_PLAIN>(P, (P.ntiles + 3) / 4, st);
+    }
     // Workgroup height: 128 rows (8 wavefronts) when that alone fills the chip, else 64 rows (4 wavefronts) --
     // twice the workgroups and half the split-K for the small-N decode batches (goldie shapes at 16-128 tokens:
     // -4...-18 % per launch, tools/qgemm_variants.sh); then split K until ~128 workgroups exist.

@@ -15,7 +15,13 @@
 
 namespace nl {
 
-constexpr int QG2_ROWS = 128, QG2_TOK = 128, QG2_WAVES = 8, QG2_RT = QG2_ROWS / TR;
+#ifdef QG2_STAMPS
+__device__ long long g_qg2_stamps[4096];
+#define QG2_STAMP(i) do { if (blockIdx.x == QG2_STAMPS && blockIdx.y == 1 && blockIdx.z == 0 && tid == 64) g_qg2_stamps[(i)] = clock64(); } while (0)
+#else
+#define QG2_STAMP(i) do { } while (0)
+#endif
+
 
 // raw quant bytes of one (row, block): Q4_0 16 bytes, Q8_0 32 bytes
 template <int WT> struct RowBlock;
@@ -49,120 +55,280 @@ template <> struct RowBlock<WT_Q8_0> {
 };
 
 // Plain epilogue (out / resid / bias, or split-K partial slabs), as qgemm_kernel's.
-template <int WT>
-__global__ void __launch_bounds__(QG2_WAVES * 64, 2) qgemm2_kernel(QGemmParams P) {
-    __shared__ __attribute__((aligned(16))) uint4 wfrag[2][QG_KC][QG2_RT][64];   // [buffer][block][row tile][lane] fp16 x 8
-    __shared__ float wsc[2][QG_KC][QG2_ROWS];                                     // block scales
+// RT: 16-row tiles per workgroup (8 or 4); NTW: 16-token tiles per wavefront (every weight fragment read from LDS feeds
+// 2 * NTW MFMAs); WAVES: wavefronts per workgroup, so a workgroup covers RT * 16 rows x WAVES * NTW * 16 tokens.
+// The weight fragment is the MFMA's A operand: D[weight row = (lane>>4)*4 + j][token = lane & 15], so a lane owns four
+// consecutive rows of one token -- the block scales arrive as one float4 from LDS and the result leaves as float4 stores.
+// EPI as qgemm_kernel's: QG_EPI_SWIGLU (RT = 4: two gate tiles and the same two tiles of up; h leaves as the down
+// projection's fragments), QG_EPI_ROPE (the matrix is a layer's packed Q|K|V: bias, RoPE, KV store).
+template <int WT, int RT, int NTW, int WAVES, int EPI = QG_EPI_PLAIN>
+__global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_kernel(QGemmParams P) {
+    static_assert(EPI != QG_EPI_SWIGLU || RT == 4, "the fused gate/up workgroup is 2 + 2 row tiles");
+    constexpr int ROWS = RT * TR, NTHR = WAVES * 64, ITEMS = ROWS * QG_KC, IPT = (ITEMS + NTHR - 1) / NTHR;
+    __shared__ __attribute__((aligned(16))) uint4 wfrag[2][QG_KC][RT][64];   // [buffer][block][row tile][lane] fp16 x 8
+    __shared__ __attribute__((aligned(16))) float wsc[2][QG_KC][ROWS];       // block scales
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int li = lane & 15;
+    const int li = lane & 15, lq = lane >> 4;
     const int nblocks = P.cols / 32, nchunks = (nblocks + QG_KC - 1) / QG_KC;
-    const int row0 = blockIdx.x * QG2_ROWS, tile0 = row0 / TR;
-    const int ttile = blockIdx.y * (QG2_TOK / 16) + wave;            // this wavefront's 16-token tile
-    const bool tlive = ttile * 16 < P.n_tokens;
+    constexpr bool FUSED = EPI == QG_EPI_SWIGLU;
+    const int tile0 = FUSED ? blockIdx.x * 2 : blockIdx.x * RT, row0 = tile0 * TR;   // FUSED: of gate and of up
+    const int ttile0 = (blockIdx.y * WAVES + wave) * NTW;            // this wavefront's first 16-token tile
 
-    // staging item of this thread: (row s_row of the workgroup, block s_blk of the chunk)
-    const int s_row = tid & (QG2_ROWS - 1), s_blk = tid >> 7, s_rt = s_row >> 4, s_i = s_row & 15;
-    const int s_tile = min(tile0 + s_rt, P.ntiles - 1);
-    auto stage_load = [&](int chunk, RowBlock<WT> &rb, uint32_t &sw) {
-        const int blk = min(chunk * QG_KC + s_blk, nblocks - 1);
-        const int g = blk >> 3, gsz = min(KL, P.npairs - g * KL);
-        const unsigned gp = (unsigned)(s_tile * P.npairs + g * KL);
-        rb = RowBlock<WT>::load(P.q, gp, gsz, s_i, blk);
-        sw = P.s[(size_t)gp * TR + (size_t)s_i * gsz + ((blk >> 1) & 3)];
-    };
-    auto stage_store = [&](int chunk, int buf, const RowBlock<WT> &rb, uint32_t sw) {
-        const int blk = chunk * QG_KC + s_blk;
+    // staging items of this thread: (row of the workgroup, block of the chunk), item = tid + k * NTHR
+    auto item_live = [&](int k) { return ITEMS % NTHR == 0 || tid + k * NTHR < ITEMS; };
+    auto stage_load = [&](int chunk, RowBlock<WT> (&rb)[IPT], uint32_t (&sw)[IPT]) {
 #pragma unroll
-        for (int w = 0; w < 4; w++) wfrag[buf][s_blk][s_rt][w * 16 + s_i] = __builtin_bit_cast(uint4, rb.frag(w));
-        wsc[buf][s_blk][s_row] = blk < nblocks ? scale_of(sw, blk) : 0.f;   // a block past the end of K contributes nothing
+        for (int k = 0; k < IPT; k++) {
+            const int it = min(tid + k * NTHR, ITEMS - 1), s_row = it % ROWS, s_blk = it / ROWS, s_i = s_row & 15;
+            const int s_rt = s_row >> 4;
+            const int s_tile = min(tile0 + (FUSED ? s_rt & 1 : s_rt), P.ntiles - 1);
+            const uint8_t *const Wq = FUSED && s_rt >= 2 ? P.q1 : P.q;
+            const uint32_t *const Ws = FUSED && s_rt >= 2 ? P.s1 : P.s;
+            const int blk = min(chunk * QG_KC + s_blk, nblocks - 1);
+            const int g = blk >> 3, gsz = min(KL, P.npairs - g * KL);
+            const unsigned gp = (unsigned)(s_tile * P.npairs + g * KL);
+            rb[k] = RowBlock<WT>::load(Wq, gp, gsz, s_i, blk);
+            sw[k] = Ws[(size_t)gp * TR + (size_t)s_i * gsz + ((blk >> 1) & 3)];
+        }
     };
-    // activation fragments of this wavefront's token tile: [block][tile][hi/lo][lane] x 16 B
-    const uint4 *const xbase = P.xf + ((size_t)min(ttile, P.nt16 - 1) * 2) * QG_FRAG + lane;
-    const size_t xblock = (size_t)P.nt16 * 2 * QG_FRAG;
-    auto xload = [&](int chunk, uint4 (&xh)[QG_KC], uint4 (&xl)[QG_KC]) {
+    // one quarter of the expansion (fragment w of every item; the scale with fragment 0): spread over the chunk's four blocks
+    auto stage_store_part = [&](int chunk, int buf, int w, const RowBlock<WT> (&rb)[IPT], const uint32_t (&sw)[IPT]) {
 #pragma unroll
-        for (int b = 0; b < QG_KC; b++) {
-            const int blk = min(chunk * QG_KC + b, nblocks - 1);
-            xh[b] = xbase[(size_t)blk * xblock];
-            xl[b] = xbase[(size_t)blk * xblock + QG_FRAG];
+        for (int k = 0; k < IPT; k++) {
+            if (!item_live(k)) continue;
+            const int it = tid + k * NTHR, s_row = it % ROWS, s_blk = it / ROWS, s_i = s_row & 15, s_rt = s_row >> 4;
+            wfrag[buf][s_blk][s_rt][w * 16 + s_i] = __builtin_bit_cast(uint4, rb[k].frag(w));
+            if (w == 0) wsc[buf][s_blk][s_row] = chunk * QG_KC + s_blk < nblocks ? scale_of(sw[k], chunk * QG_KC + s_blk) : 0.f;   // a block past the end of K contributes nothing
+        }
+    };
+    // activation fragments of this wavefront's token tiles: [block][tile][hi/lo][lane] x 16 B.  Addresses are "kernel
+    // argument + unsigned 32-bit offset" with the block part wave-uniform (scalar base, saddr loads: no 64-bit VGPR math)
+    const char *const xsrc = reinterpret_cast<const char *>(P.xf);
+    unsigned xlane[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) xlane[t] = ((unsigned)min(ttile0 + t, P.nt16 - 1) * 2u * QG_FRAG + (unsigned)lane) * 16u;
+    const unsigned xblock = (unsigned)P.nt16 * 2u * QG_FRAG * 16u;
+    auto xload1 = [&](int blk, uint4 (&h)[NTW], uint4 (&l)[NTW]) {
+        const unsigned uo = (unsigned)min(blk, nblocks - 1) * xblock;
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
+            h[t] = *reinterpret_cast<const uint4 *>(xsrc + (uo + xlane[t]));
+            l[t] = *reinterpret_cast<const uint4 *>(xsrc + (uo + xlane[t]) + QG_FRAG * 16);
         }
     };
 
-    f32x4_t acc[QG2_RT];
+    f32x4_t acc[RT][NTW];
 #pragma unroll
-    for (int rt = 0; rt < QG2_RT; rt++) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int t = 0; t < NTW; t++) acc[rt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    constexpr int RG = NTW == 1 ? 4 : 2;   // row tiles per MFMA group: RG * NTW = 4 independent accumulator chains
+    constexpr int NG = RT / RG;            // groups per block
+    static_assert((QG_KC * NG) % 2 == 0, "weight fragment ping-pong");
     int chunk = blockIdx.z;
-    RowBlock<WT> rb;
-    uint32_t sw = 0;
-    uint4 xh[QG_KC], xl[QG_KC], xhn[QG_KC], xln[QG_KC];
+    RowBlock<WT> rb[IPT], rbn[IPT];        // raw weights of the next chunk (being expanded) and of the one after (in flight)
+    uint32_t sw[IPT], swn[IPT];
+    uint4 xh[2][NTW], xl[2][NTW];          // ping-pong: block b of a chunk sits in [b & 1] (QG_KC is even)
+    uint4 wf[2][RG];                       // ping-pong: group idx of a chunk sits in [idx & 1]
     if (chunk < nchunks) {
         stage_load(chunk, rb, sw);
-        xload(chunk, xh, xl);
-        stage_store(chunk, 0, rb, sw);
+        xload1(chunk * QG_KC, xh[0], xl[0]);
+#pragma unroll
+        for (int w = 0; w < 4; w++) stage_store_part(chunk, 0, w, rb, sw);
+        stage_load(chunk + P.ksplit < nchunks ? chunk + P.ksplit : chunk, rb, sw);
     }
     __syncthreads();
     int buf = 0;
+    [[maybe_unused]] int it_ = 0;
+    QG2_STAMP(0);
     while (chunk < nchunks) {
-        const int nxt = chunk + P.ksplit;
+        const int nxt = chunk + P.ksplit, nxt2 = nxt + P.ksplit;
         const bool more = nxt < nchunks;
-        // the next chunk's raw weights and activation fragments travel while this chunk is on the matrix cores
-        stage_load(more ? nxt : chunk, rb, sw);
-        xload(more ? nxt : chunk, xhn, xln);
+        // raw weights two chunks ahead (one HBM round trip is longer than a chunk of MFMAs); the activation fragments are
+        // requested one block ahead (an L2 round trip)
+        stage_load(nxt2 < nchunks ? nxt2 : chunk, rbn, swn);
+#pragma unroll
+        for (int q = 0; q < RG; q++) wf[0][q] = wfrag[buf][0][q][lane];
+        QG2_STAMP(1 + it_ * 8);
 #pragma unroll
         for (int b = 0; b < QG_KC; b++) {
-            const half8_t ah = __builtin_bit_cast(half8_t, xh[b]), al = __builtin_bit_cast(half8_t, xl[b]);
-            // four row tiles at a time: the lo-part MFMAs of all four, then the hi-part MFMAs -- each dependent pair is four
-            // issues apart, so no MFMA waits for its predecessor's accumulator
-            f32x4_t z[QG2_RT];
+            xload1(b + 1 < QG_KC ? chunk * QG_KC + b + 1 : (more ? nxt : chunk) * QG_KC, xh[(b + 1) & 1], xl[(b + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);   // the request stays HERE: a block ahead of its use
 #pragma unroll
-            for (int r0 = 0; r0 < QG2_RT; r0 += 4) {
-                half8_t wf[4];
+            for (int g = 0; g < NG; g++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int idx = b * NG + g, r0 = g * RG;
+                // the next group's weight fragments leave LDS while this group is on the matrix cores
+                if (idx + 1 < QG_KC * NG) {
+                    const int b1 = (idx + 1) / NG, g1 = (idx + 1) % NG;
 #pragma unroll
-                for (int q = 0; q < 4; q++) wf[q] = __builtin_bit_cast(half8_t, wfrag[buf][b][r0 + q][lane]);
+                    for (int q = 0; q < RG; q++) wf[(idx + 1) & 1][q] = wfrag[buf][b1][g1 * RG + q][lane];
+                }
+                f32x4_t z[RG][NTW];
+                // the lo-part MFMAs of the group, then the hi-part MFMAs: each dependent pair is four issues apart, so no
+                // MFMA waits for its predecessor's accumulator
 #pragma unroll
-                for (int q = 0; q < 4; q++) z[r0 + q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wf[q], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                for (int q = 0; q < RG; q++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) z[r0 + q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wf[q], z[r0 + q], 0, 0, 0);
+                    for (int t = 0; t < NTW; t++)
+                        z[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, wf[idx & 1][q]), __builtin_bit_cast(half8_t, xl[b & 1][t]),
+                                                                        (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < RG; q++)
+#pragma unroll
+                    for (int t = 0; t < NTW; t++)
+                        z[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, wf[idx & 1][q]), __builtin_bit_cast(half8_t, xh[b & 1][t]), z[q][t], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < RG; q++) {   // acc += z * d, two rows per instruction (v_pk_fma_f32: same roundings as fmaf)
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const float4 d = *reinterpret_cast<const float4 *>(&wsc[buf][b][(r0 + q) * TR + lq * 4]);
+                    const f2 d01 = {d.x, d.y}, d23 = {d.z, d.w};
+#pragma unroll
+                    for (int t = 0; t < NTW; t++) {
+                        const f2 lo = __builtin_elementwise_fma((f2){z[q][t][0], z[q][t][1]}, d01, (f2){acc[r0 + q][t][0], acc[r0 + q][t][1]});
+                        const f2 hi = __builtin_elementwise_fma((f2){z[q][t][2], z[q][t][3]}, d23, (f2){acc[r0 + q][t][2], acc[r0 + q][t][3]});
+                        acc[r0 + q][t] = (f32x4_t){lo[0], lo[1], hi[0], hi[1]};
+                    }
+                }
+                // Pin the updated accumulators here: instruction selection otherwise sinks every "* d" FMA of the chunk
+                // below its 64 MFMAs and keeps 128 result registers live (occupancy 2 instead of 4).
+#pragma unroll
+                for (int q = 0; q < RG; q++)
+#pragma unroll
+                    for (int t = 0; t < NTW; t++) asm volatile("" : "+v"(acc[r0 + q][t]));
+                if (g == NG - 1 && more) stage_store_part(nxt, buf ^ 1, b, rb, sw);   // the other buffer: nobody reads it during this chunk
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int rt = 0; rt < QG2_RT; rt++) {
-                const float d = wsc[buf][b][rt * TR + li];
-                acc[rt][0] = fmaf(z[rt][0], d, acc[rt][0]);
-                acc[rt][1] = fmaf(z[rt][1], d, acc[rt][1]);
-                acc[rt][2] = fmaf(z[rt][2], d, acc[rt][2]);
-                acc[rt][3] = fmaf(z[rt][3], d, acc[rt][3]);
-            }
+            QG2_STAMP(2 + it_ * 8 + b);
         }
-        if (more) stage_store(nxt, buf ^ 1, rb, sw);     // the other buffer: nobody reads it during this chunk
+        QG2_STAMP(6 + it_ * 8);
         __syncthreads();
+        QG2_STAMP(7 + it_ * 8);
+        it_++;
 #pragma unroll
-        for (int b = 0; b < QG_KC; b++) { xh[b] = xhn[b]; xl[b] = xln[b]; }
+        for (int k = 0; k < IPT; k++) { rb[k] = rbn[k]; sw[k] = swn[k]; }
         buf ^= 1;
         chunk = nxt;
     }
 
-    // D[token = (lane>>4)*4 + j][weight row = lane & 15] per row tile
-    if (!tlive) return;
+    QG2_STAMP(1 + it_ * 8);
+    if constexpr (EPI == QG_EPI_SWIGLU) {
+        // h = SiLU(gate) * up (go/quant.go:629-631, go/model.go:604-606).  A lane holds rows 4*lq..+3 of both 16-row tiles of
+        // one token, i.e. the float4 groups lq and 4 + lq of the workgroup's 32-row block of h: for a Q4_0 consumer those
+        // are exactly the two groups of k-slot group w = lq (slot_offsets), for a linear consumer neighbouring lq pairs
+        // swap one group.  The fragments go straight from registers to the store: no f32 gate / up / h in memory.
+        const int hblk = blockIdx.x;
+        if (hblk * 32 >= P.rows) return;
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
+            const int n = (ttile0 + t) * 16 + li;
+            float hv[2][4];
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float gv = acc[r][t][j], uv = acc[r + 2][t][j];
+                    const float ex = (float)exp((double)(-gv));
+                    hv[r][j] = (gv / (1.0f + ex)) * uv;
+                }
+            float v[8];
+            int w;
+            if (P.out_q4) {
+                w = lq;
+                slots_from(1, make_float4(hv[0][0], hv[0][1], hv[0][2], hv[0][3]), make_float4(hv[1][0], hv[1][1], hv[1][2], hv[1][3]), v);
+            } else {
+                // groups 2w, 2w+1 make k-slot group w: even lq keeps tile 0's group and takes its odd neighbour's, odd lq the reverse
+                float got[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) got[j] = __shfl_xor((lq & 1) ? hv[0][j] : hv[1][j], 16);
+                w = (lq & 1) ? 2 + (lq >> 1) : (lq >> 1);
+                const float4 a = (lq & 1) ? make_float4(got[0], got[1], got[2], got[3]) : make_float4(hv[0][0], hv[0][1], hv[0][2], hv[0][3]);
+                const float4 b = (lq & 1) ? make_float4(hv[1][0], hv[1][1], hv[1][2], hv[1][3]) : make_float4(got[0], got[1], got[2], got[3]);
+                slots_from(0, a, b, v);
+            }
+            if (n < P.n_tokens) store_frag(P.xf_out, P.nt16, n, hblk, w, v);
+        }
+        return;
+    }
+    if constexpr (EPI == QG_EPI_ROPE) {
+        // RoPE (go/model.go:449-477) + attention biases (:525-527) + KV store (:552-554) on the accumulators: tile rows 0-7
+        // hold element i, rows 8-15 element i + hd/2 of one head (ROWMAP_HEADPERM), so a value's rotation partner sits in
+        // lane ^ 32 (rows 4*lq + j <-> 4*(lq ^ 2) + j, same token).
+        const QGemmParams::Rope &R = P.rope;
+        const int hd = R.head_dim, half = hd >> 1, tph = hd / 16, nq = R.n_q_heads * hd;
+        int pos[NTW], strm[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
+            const int nn = min((ttile0 + t) * 16 + li, P.n_tokens - 1);
+            pos[t] = R.pos[nn];
+            strm[t] = R.stream[nn];
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const int tile = min(tile0 + rt, P.ntiles - 1);   // (a tile past the end: computed, never stored)
+            const int head = tile / tph, i0 = (tile % tph) * 8 + 4 * (lq & 1), e0 = i0 + (lq >> 1) * half;
+            const bool is_q = head < R.n_q_heads, is_k = !is_q && head < R.n_q_heads + R.n_kv_heads;
+            const int kvh = head - R.n_q_heads - (is_k ? 0 : R.n_kv_heads);
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (R.bias_q) bv = *reinterpret_cast<const float4 *>((is_q ? R.bias_q + head * hd : is_k ? R.bias_k + kvh * hd : R.bias_v + kvh * hd) + e0);
+            const float bj[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int t = 0; t < NTW; t++) {
+                const int n = (ttile0 + t) * 16 + li;
+                const float4 c4 = *reinterpret_cast<const float4 *>(R.cos + pos[t] * half + i0), s4 = *reinterpret_cast<const float4 *>(R.sin + pos[t] * half + i0);
+                const float cj[4] = {c4.x, c4.y, c4.z, c4.w}, sj[4] = {s4.x, s4.y, s4.z, s4.w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float v = acc[rt][t][j] + bj[j];
+                    const float partner = __shfl_xor(v, 32);
+                    float outv = v;
+                    if (is_q || is_k) {
+                        const float x0 = lq < 2 ? v : partner, x1 = lq < 2 ? partner : v;
+                        if (!R.conj) outv = lq < 2 ? (x0 * cj[j] - x1 * sj[j]) : (x0 * sj[j] + x1 * cj[j]);
+                        else outv = lq < 2 ? (x0 * cj[j] + x1 * sj[j]) : (-x0 * sj[j] + x1 * cj[j]);
+                    }
+                    o[j] = outv;
+                }
+                if (n >= P.n_tokens || tile0 + rt >= P.ntiles) continue;
+                float *dstp = is_q ? R.q + ((long long)n * nq + head * hd + e0)
+                                   : (is_k ? R.kcache : R.vcache) + ((long long)strm[t] * R.kv_stream_stride + ((long long)kvh * R.seq_len + pos[t]) * hd + e0);
+                *reinterpret_cast<float4 *>(dstp) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        return;
+    }
     const bool split = P.ksplit > 1;
     float *const dst = split ? P.part + (long long)blockIdx.z * P.n_tokens * P.ldo : P.out;
     const float *const resid = split ? nullptr : P.resid, *const bias = split ? nullptr : P.bias;
-    const int tok0 = ttile * 16 + (lane >> 4) * 4;
+    const bool vec = (P.ldo & 3) == 0;     // rows of four land on 16-byte boundaries
 #pragma unroll
-    for (int rt = 0; rt < QG2_RT; rt++) {
-        const int row = row0 + rt * TR + li;
-        if (tile0 + rt >= P.ntiles || row >= P.rows) continue;
-        const float bv = bias ? bias[row] : 0.f;
+    for (int t = 0; t < NTW; t++) {
+        const int n = (ttile0 + t) * 16 + li;
+        if (n >= P.n_tokens) continue;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int n = tok0 + j;
-            if (n >= P.n_tokens) continue;
+        for (int rt = 0; rt < RT; rt++) {
+            const int row = row0 + rt * TR + lq * 4;
+            if (tile0 + rt >= P.ntiles || row >= P.rows) continue;
             const size_t off = (size_t)n * P.ldo + row;
-            float v = acc[rt][j] + bv;
-            if (resid) v += resid[off];
-            dst[off] = v;
+            if (vec && row + 3 < P.rows) {
+                float4 v = make_float4(acc[rt][t][0], acc[rt][t][1], acc[rt][t][2], acc[rt][t][3]);
+                if (bias) { const float4 bv = *reinterpret_cast<const float4 *>(bias + row); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+                if (resid) { const float4 rv = *reinterpret_cast<const float4 *>(resid + off); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                *reinterpret_cast<float4 *>(dst + off) = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (row + j >= P.rows) continue;
+                    float v = acc[rt][t][j] + (bias ? bias[row + j] : 0.f);
+                    if (resid) v += resid[off + j];
+                    dst[off + j] = v;
+                }
+            }
         }
     }
+    QG2_STAMP(2 + it_ * 8);
 }
 
 }  // namespace nl

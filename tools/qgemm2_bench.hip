@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <cmath>
 #include <vector>
 #include <algorithm>
@@ -18,6 +19,7 @@ __global__ void fill_u32(uint32_t *p, size_t n, uint32_t seed, uint32_t andm, ui
     }
 }
 
+static const char *g_only = nullptr;   // argv[3]: run only the shapes whose name contains this
 template <int WT>
 int run(int N, int iters) {
     constexpr int CPP = WFrag<WT>::CPP;
@@ -27,6 +29,7 @@ int run(int N, int iters) {
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (auto &sh : shapes) {
+        if (g_only && !strstr(sh.name, g_only)) continue;
         const int ntiles = sh.rows / 16, npairs = sh.cols / 64;
         const size_t qbytes = (size_t)ntiles * npairs * CPP * TR * 16, swords = (size_t)ntiles * npairs * TR;
         const int copies = (int)std::max<size_t>(2, ((size_t)600 << 20) / qbytes);
@@ -41,8 +44,8 @@ int run(int N, int iters) {
         QGemmParams P{};
         P.rows = sh.rows; P.cols = sh.cols; P.npairs = npairs; P.ntiles = ntiles; P.xf = xf; P.nt16 = tok_tiles * 4;
         P.n_tokens = N; P.ldo = sh.rows; P.ksplit = 1;
-        const dim3 g1((ntiles + QG_WAVES - 1) / QG_WAVES, tok_tiles, 1), g2((sh.rows + QG2_ROWS - 1) / QG2_ROWS, (N + QG2_TOK - 1) / QG2_TOK, 1);
-        float ms1 = 0, ms2 = 0;
+        const dim3 g1((ntiles + QG_WAVES - 1) / QG_WAVES, tok_tiles, 1);
+        float ms1 = 0;
         for (int rep = 0; rep < 2; rep++) {
             CK(hipEventRecord(a, st));
             for (int i = 0; i < iters; i++) {
@@ -50,22 +53,53 @@ int run(int N, int iters) {
                 hipLaunchKernelGGL((qgemm_kernel<WT, QG_WAVES, 1, QG_EPI_PLAIN>), g1, dim3(QG_WAVES * 64), 0, st, P);
             }
             CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms1, a, b));
-            CK(hipEventRecord(a, st));
-            for (int i = 0; i < iters; i++) {
-                P.q = q + (size_t)(i % copies) * qbytes; P.s = s + (size_t)(i % copies) * swords; P.out = out2;
-                hipLaunchKernelGGL((qgemm2_kernel<WT>), g2, dim3(QG2_WAVES * 64), 0, st, P);
-            }
-            CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms2, a, b));
         }
-        CK(hipGetLastError());
-        // both ran the same last weight copy: compare
-        std::vector<float> h1((size_t)N * sh.rows), h2((size_t)N * sh.rows);
-        CK(hipMemcpy(h1.data(), out, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), out2, h2.size() * 4, hipMemcpyDeviceToHost));
-        double worst = 0, mag = 0;
-        for (size_t i = 0; i < h1.size(); i++) { worst = std::max(worst, (double)std::fabs(h1[i] - h2[i])); mag = std::max(mag, (double)std::fabs(h1[i])); }
         const double fl = 2.0 * sh.rows * sh.cols * N;
-        printf("%-12s %5dx%-5d N=%-4d  qgemm %8.2f us %6.1f TF | qgemm2 %8.2f us %6.1f TF  (x%.2f)  max|diff| %.2e of %.2e\n", sh.name, sh.rows, sh.cols, N,
-               ms1 * 1e3 / iters, fl / (ms1 * 1e3 / iters) * 1e-6, ms2 * 1e3 / iters, fl / (ms2 * 1e3 / iters) * 1e-6, ms1 / ms2, worst, mag);
+        printf("%-12s %5dx%-5d N=%-4d  qgemm %8.2f us %6.1f TF |", sh.name, sh.rows, sh.cols, N, ms1 * 1e3 / iters, fl / (ms1 * 1e3 / iters) * 1e-6);
+        std::vector<float> h1((size_t)N * sh.rows), h2((size_t)N * sh.rows);
+        CK(hipMemcpy(h1.data(), out, h1.size() * 4, hipMemcpyDeviceToHost));
+        auto variant = [&](const char *tag, auto kern, int RT, int NTW, int WAVES) {
+            const dim3 g2((sh.rows + RT * 16 - 1) / (RT * 16), (N + WAVES * NTW * 16 - 1) / (WAVES * NTW * 16), 1);
+            float ms2 = 0;
+            for (int rep = 0; rep < 2; rep++) {
+                CK(hipEventRecord(a, st));
+                for (int i = 0; i < iters; i++) {
+                    P.q = q + (size_t)(i % copies) * qbytes; P.s = s + (size_t)(i % copies) * swords; P.out = out2;
+                    hipLaunchKernelGGL(kern, g2, dim3(WAVES * 64), 0, st, P);
+                }
+                CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms2, a, b));
+            }
+            CK(hipGetLastError());
+            CK(hipMemcpy(h2.data(), out2, h2.size() * 4, hipMemcpyDeviceToHost));
+            double worst = 0;
+            for (size_t i = 0; i < h1.size(); i++) worst = std::max(worst, (double)std::fabs(h1[i] - h2[i]));
+            printf(" %s %7.2f us x%.2f%s |", tag, ms2 * 1e3 / iters, ms1 / ms2, worst == 0 ? "" : " DIFF");
+        };
+#ifdef QG2_STAMPS
+        variant("4/2/8", qgemm2_kernel<WT, 4, 2, 8>, 4, 2, 8);
+#else
+        variant("8/1/8", qgemm2_kernel<WT, 8, 1, 8>, 8, 1, 8);
+        variant("4/1/4", qgemm2_kernel<WT, 4, 1, 4>, 4, 1, 4);
+        variant("2/2/8", qgemm2_kernel<WT, 2, 2, 8>, 2, 2, 8);
+        variant("4/2/8", qgemm2_kernel<WT, 4, 2, 8>, 4, 2, 8);
+        variant("4/2/4", qgemm2_kernel<WT, 4, 2, 4>, 4, 2, 4);
+        variant("4/1/8", qgemm2_kernel<WT, 4, 1, 8>, 4, 1, 8);
+#endif
+        printf("\n");
+#ifdef QG2_STAMPS
+        {   // phase stamps of one wavefront of the LAST variant run above (cycles since its first stamp)
+            std::vector<long long> st_(4096);
+            CK(hipMemcpyFromSymbol(st_.data(), HIP_SYMBOL(g_qg2_stamps), 4096 * 8));
+            const int nch = (sh.cols / 32 + 3) / 4;
+            printf("   stamps: start 0");
+            for (int c = 0; c < nch; c++) {
+                printf("\n   chunk %2d: loads issued %6lld | blocks", c, st_[1 + c * 8] - st_[0]);
+                for (int b2 = 0; b2 < 4; b2++) printf(" %6lld", st_[2 + c * 8 + b2] - st_[0]);
+                printf(" | staged %6lld | barrier %6lld", st_[6 + c * 8] - st_[0], st_[7 + c * 8] - st_[0]);
+            }
+            printf("\n   epilogue start %6lld end %6lld\n", st_[1 + nch * 8] - st_[0], st_[2 + nch * 8] - st_[0]);
+        }
+#endif
         CK(hipFree(q)); CK(hipFree(s)); CK(hipFree(xf)); CK(hipFree(out)); CK(hipFree(out2));
     }
     return 0;
@@ -73,7 +107,8 @@ int run(int N, int iters) {
 
 int main(int argc, char **argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 2047, iters = argc > 2 ? atoi(argv[2]) : 50;
+    if (argc > 3) g_only = argv[3];
     printf("== Q4_0\n"); run<WT_Q4_0>(N, iters);
-    printf("== Q8_0\n"); run<WT_Q8_0>(N, iters);
+    if (!(argc > 4 && atoi(argv[4]) == 4)) { printf("== Q8_0\n"); run<WT_Q8_0>(N, iters); }
     return 0;
 }
