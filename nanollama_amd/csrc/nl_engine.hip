@@ -976,7 +976,8 @@ hipError_t launch_xsplit(int wtype, const float *x, int ldx, int cols, int n_tok
 // tokens up, tools/qgemm2_bench.hip; Q8_0's 32-byte rows cost more to expand and stay on qgemm_kernel).  Workgroups of
 // 64 rows: x 256 tokens (two token tiles per wavefront) when that still gives every compute unit two of them, else x 64.
 bool qgemm2_ok(int wtype, int n_tokens) {
-    static const int min_n = getenv("NL_QG2_MIN_TOKENS") ? atoi(getenv("NL_QG2_MIN_TOKENS")) : 128;   // knob (tests, tools): a huge value disables
+    const char *knob = getenv("NL_QG2_MIN_TOKENS");   // knob (tests, tools; read per launch so a test can flip it): a huge value disables
+    const int min_n = knob ? atoi(knob) : 128;
     return wtype == WT_Q4_0 && n_tokens >= min_n;
 }
 template <int EPI>

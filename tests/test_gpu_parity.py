@@ -627,6 +627,40 @@ def test_prefill_attention_tiles_every_gqa_ratio(hip, orc, tmp_path, heads, kv, 
     dev.close()
 
 
+@pytest.mark.parametrize("dim,heads,kv,hd,interm,n", [(160, 5, 5, 32, 224, 200), (192, 3, 1, 64, 352, 131), (256, 4, 1, 64, 96, 300)])
+def test_q4_prompt_gemm_through_lds_matches_the_per_wavefront_kernel(hip, orc, tmp_path, monkeypatch, dim, heads, kv, hd, interm, n):
+    # Q4_0 prompts of >= 128 tokens take qgemm2_kernel (weights expanded once per workgroup into LDS, nl_qgemm2.h) with
+    # its own plain / SwiGLU / RoPE epilogues.  Shapes whose K is not a multiple of the 128-column chunk, whose row count
+    # is not a multiple of the 64-row workgroup and whose token count leaves a ragged last tile: bit-identical logits,
+    # KV rows and ids to qgemm_kernel (same arithmetic per output, NL_QG2_MIN_TOKENS disables the new kernel), and
+    # within tolerance of the oracle.
+    shape = replace(synth.TIERS["tiny"], name=f"q4_{dim}_{interm}", dim=dim, n_head=heads, n_kv_head=kv, seq_len=320,
+                    interm=interm, n_layer=2)
+    p = tmp_path / "g.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", 17)
+    g = gguf.load_gguf(str(p))
+    toks = synth.prompt_ids(n, shape.vocab, seed=4)
+    ref = orc.OracleModel(g)
+    for pos, t in enumerate(toks):
+        want = ref.forward(t, pos)
+    outs = []
+    for knob in (None, "1000000"):
+        if knob is None:
+            monkeypatch.delenv("NL_QG2_MIN_TOKENS", raising=False)
+        else:
+            monkeypatch.setenv("NL_QG2_MIN_TOKENS", knob)
+        dev = hip.load_llama_model(g)
+        dev.prefill(toks)
+        logits = dev.state.logits.copy()
+        ids = dev.decode_greedy(int(np.argmax(logits)), n, 4)
+        outs.append((logits, ids))
+        dev.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
+    err = float(np.abs(outs[0][0] - want).max())
+    assert err <= LOGIT_TOL * max(1.0, float(want.std()))
+
+
 def test_mini_full_size_long_prefill_matches_oracle(hip, orc, tmp_path):
     # BASELINE.json configs[2] at its own shape (mini, 173M, Q4_0): a 1920-token prompt through the matrix-core
     # path in ONE step vs the CPU oracle fed token by token (1920 prompt positions for parity), then a
