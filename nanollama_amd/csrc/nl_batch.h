@@ -670,6 +670,12 @@ __global__ void __launch_bounds__(QT * G * 4, 2) attn_tile_kernel(AttnParams P, 
 //   * p is scaled by 2^10 before its split (exact; keeps p down to 3e-11 above the fp16 underflow) and the
 //     output by 2^-10; max / sum are taken from the unscaled f32 values.
 // Partials (max, sum, sum p*v) leave in the decode kernel's layout, so battn_merge_kernel is shared.
+#ifdef NL_ATT_STAMPS
+__device__ long long g_att_stamps[64];
+#define ATT_STAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 3 && blockIdx.z == NL_ATT_STAMPS && threadIdx.x == 64) g_att_stamps[(i)] = clock64(); } while (0)
+#else
+#define ATT_STAMP(i) do { } while (0)
+#endif
 template <int HD, int G, int QT>
 __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16_kernel(AttnParams P, int n_items) {
     constexpr int VH = QT * G;               // rows (token, query head) per workgroup
@@ -688,15 +694,21 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
     const int kvh = blockIdx.x, split = blockIdx.y, i0 = blockIdx.z * QT, tid = threadIdx.x;
     const int t0 = split * ATT_CH;
     int maxpos = -1, minpos = 0x7fffffff;
-    for (int i = 0; i < QT; i++) {
-        const int pp = i0 + i < n_items ? P.bpos[i0 + i] : -1;
-        maxpos = max(maxpos, pp);
-        minpos = min(minpos, pp);
+    if (P.pos_base_valid) {   // a prompt: consecutive positions, nothing to read
+        minpos = P.pos_base + i0;
+        maxpos = P.pos_base + min(i0 + QT, n_items) - 1;
+    } else {
+        for (int i = 0; i < QT; i++) {
+            const int pp = i0 + i < n_items ? P.bpos[i0 + i] : -1;
+            maxpos = max(maxpos, pp);
+            minpos = min(minpos, pp);
+        }
     }
     if (t0 > maxpos) return;
     const int nrows = min(ATT_CH, maxpos + 1 - t0);
     const bool full = minpos >= t0 + ATT_CH - 1;   // every row of the tile sees every key of this split
     const int lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+    ATT_STAMP(0);
 
     // B operand of S^T: row w*16+j, head_dim elements 32*ks + 8*kq .. +7, as hi / lo halves
     half8_t qh[NKS], ql[NKS];
@@ -715,7 +727,7 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
             }
         }
     }
-    const long long soff = (long long)P.bstream[i0] * P.kv_stream_stride;
+    const long long soff = P.single_stream ? 0 : (long long)P.bstream[i0] * P.kv_stream_stride;
     const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
     const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
     // staging: thread (key pair rp, float4 column c4) owns keys 2rp, 2rp+1 (clamped loads, zero beyond nrows so
@@ -732,6 +744,10 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
             vreg[it][h] = V4[row * R4 + c4];
         }
     }
+    // (hipcc otherwise sinks the second half of these loads below the first half's LDS stores: two dependent memory
+    // round trips per workgroup instead of one)
+    __builtin_amdgcn_sched_barrier(0);
+    ATT_STAMP(1);
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         const int i = tid + it * NTH, rp = i / R4, c4 = i % R4;
@@ -760,11 +776,14 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
             *reinterpret_cast<h2_t *>(VTl + (c4 * 4 + e) * VS + pos) = h2_t{l0, l1};
         }
     }
+    ATT_STAMP(2);
     if (tid < VH) {
         const int item = i0 + tid / G;
         nv[tid] = item < n_items ? min(ATT_CH, max(0, P.bpos[item] + 1 - t0)) : 0;
     }
+    ATT_STAMP(3);
     __syncthreads();
+    ATT_STAMP(4);
 
     // ---- S^T = K q^T: 8 key tiles x 16 rows; lane (j, kq) ends up with row j's scores for keys 16*mt + 4*kq + r
     v4f acc[8];
@@ -786,6 +805,7 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
         for (int mt = 0; mt < 8; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt], qh[ks], acc[mt], 0, 0, 0);
     }
 
+    ATT_STAMP(5);
     // ---- softmax pieces of row j: 32 keys in this lane, the rest in lanes j+16, j+32, j+48.  Splits below the
     //      tile's diagonal see all 128 keys in every row (uniform test): no per-element masks there.
     //      p = exp2((s - m) * log2 e) on v_exp_f32 (~1 ulp; the argument's rounding adds |s - m| * 6e-8 relative,
@@ -833,6 +853,7 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
 
+    ATT_STAMP(6);
     // ---- O = P V: A = P (this lane's own accumulators, key tiles 2m and 2m+1), B = V^T rows from LDS ----
     v4f o[NTO];
 #pragma unroll
@@ -858,6 +879,7 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
         }
     }
 
+    ATT_STAMP(7);
     // O tile: this lane holds rows 4*kq+r, columns d = nt*16 + j (the 16 lanes of a row write 64 contiguous bytes per nt)
     constexpr float unscale = 1.0f / 1024.0f;
 #pragma unroll
@@ -876,6 +898,7 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
         P.part_ml[slot * 2] = m;
         P.part_ml[slot * 2 + 1] = l;
     }
+    ATT_STAMP(8);
 }
 
 // query tokens per workgroup of the fp16 tile kernel: 128 (token, head) rows = 8 wavefronts share one staged K/V

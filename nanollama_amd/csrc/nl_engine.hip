@@ -1213,6 +1213,8 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
     static const bool no_tile = getenv("NL_NO_ATTN_TILE") != nullptr, no_fin = getenv("NL_NO_ATTN_FIN") != nullptr;   // developer knobs
     int nsplit = 1;
     for (int i = 0; i < n; i++) nsplit = std::max(nsplit, b.h_meta[b.cap + i] / ATT_CH + 1);
+    bool consecutive = true;   // positions pos0, pos0 + 1, ...: a prompt
+    for (int i = 1; i < n && consecutive; i++) consecutive = b.h_meta[b.cap + i] == b.h_meta[b.cap] + i;
     nsplit = std::min(nsplit, e->nsplit_max);
     GemmOut pend{nullptr, nullptr, 1, 0, nullptr};   // GEMM output not yet folded into the residual stream
     auto norm = [&](const float *w, const PackedMat &next, int item0, int cnt) {
@@ -1259,8 +1261,12 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
             bool merged = false;
             if (one_stream && n >= 8 && attn_tile_supported(e->gqa) && !no_tile) {
                 // prefill: the step's tokens share a stream -> K/V split staged once per tile of tokens, fp16 MFMA with hi/lo-split operands (attn_tile16_kernel)
-                LCK(hd == 64 ? launch_attn_tile_hd<64>(e->gqa, P, n, e->KVs, nsplit, st)
-                             : launch_attn_tile_hd<32>(e->gqa, P, n, e->KVs, nsplit, st));
+                AttnParams T = P;
+                T.single_stream = c.max_streams == 1 ? 1 : 0;
+                T.pos_base_valid = consecutive ? 1 : 0;   // (a prompt: the kernel derives its key range without reading bpos)
+                T.pos_base = b.h_meta[b.cap];
+                LCK(hd == 64 ? launch_attn_tile_hd<64>(e->gqa, T, n, e->KVs, nsplit, st)
+                             : launch_attn_tile_hd<32>(e->gqa, T, n, e->KVs, nsplit, st));
             } else if (nsplit == 1 && !no_fin) {
                 // every position < 128: one split per row, the attention kernel normalises and writes the fragments
                 P.fin_xf = b.xfrag; P.fin_nt16 = nt16; P.fin_q4 = L.wo.wtype == WT_Q4_0 ? 1 : 0;
@@ -1343,6 +1349,13 @@ int nl_abi_version(void) { return 1; }
 #define NL_GIT_HEAD "unknown"
 #endif
 const char *nl_build_info(void) { return "src=" NL_SRC_SHA " git=" NL_GIT_HEAD; }
+
+#ifdef NL_ATT_STAMPS
+// developer build only (tools/att_stamps.sh): phase stamps of one workgroup of the prompt attention kernel
+__attribute__((visibility("default"))) int nl_debug_att_stamps(long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nl::g_att_stamps), 64 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int nl_device_count(void) {
     int n = 0;

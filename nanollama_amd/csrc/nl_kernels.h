@@ -952,6 +952,9 @@ struct AttnParams {
     // as the WO GEMM's fp16 hi/lo fragments and battn_merge_kernel is not launched
     uint4 *fin_xf;
     int fin_nt16, fin_q4;
+    // attn_tile16_kernel: the step's positions are pos_base + item (a prompt) when pos_base_valid -- the workgroup then
+    // knows its key range without reading bpos, and its K / V requests leave at entry
+    int pos_base_valid, pos_base;
 };
 
 template <int HD, int G>
