@@ -303,6 +303,38 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
     float *const dst = split ? P.part + (long long)blockIdx.z * P.n_tokens * P.ldo : P.out;
     const float *const resid = split ? nullptr : P.resid, *const bias = split ? nullptr : P.bias;
     const bool vec = (P.ldo & 3) == 0;     // rows of four land on 16-byte boundaries
+    if (vec && tile0 + RT <= P.ntiles && row0 + RT * TR <= P.rows) {
+        // whole row tiles (every workgroup but a ragged last one): the residual / bias operands of the tile are requested
+        // first with clamped token indices -- ONE branch around all the loads, one memory latency -- then added and stored
+        float4 rv[NTW][RT], bv[RT];
+        size_t off[NTW][RT];
+#pragma unroll
+        for (int t = 0; t < NTW; t++)
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++)
+                off[t][rt] = (size_t)min((ttile0 + t) * 16 + li, P.n_tokens - 1) * P.ldo + (row0 + rt * TR + lq * 4);
+        if (resid) {
+#pragma unroll
+            for (int t = 0; t < NTW; t++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) rv[t][rt] = *reinterpret_cast<const float4 *>(resid + off[t][rt]);
+        }
+        if (bias) {
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) bv[rt] = *reinterpret_cast<const float4 *>(bias + row0 + rt * TR + lq * 4);
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; t++)
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                float4 v = make_float4(acc[rt][t][0], acc[rt][t][1], acc[rt][t][2], acc[rt][t][3]);
+                if (bias) { v.x += bv[rt].x; v.y += bv[rt].y; v.z += bv[rt].z; v.w += bv[rt].w; }
+                if (resid) { v.x += rv[t][rt].x; v.y += rv[t][rt].y; v.z += rv[t][rt].z; v.w += rv[t][rt].w; }
+                if ((ttile0 + t) * 16 + li < P.n_tokens) *reinterpret_cast<float4 *>(dst + off[t][rt]) = v;
+            }
+        QG2_STAMP(2 + it_ * 8);
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < NTW; t++) {
         const int n = (ttile0 + t) * 16 + li;
