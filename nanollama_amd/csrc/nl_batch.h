@@ -329,6 +329,7 @@ struct BMergeParams {
     int heads, nsplit_max, head_dim;
     uint4 *xf;   // attention output [N][heads*hd] as MFMA fragments for the WO GEMM
     int nt16, q4;
+    int fast_exp;   // split weights on v_exp_f32 (prompts: their partials come from attn_tile16_kernel's v_exp_f32 already)
 };
 
 // online-softmax merge of the position splits (same arithmetic and summation order as the decode GEMV's
@@ -356,7 +357,9 @@ __global__ void battn_merge_kernel(BMergeParams P, int n_items) {
 #pragma unroll
         for (int c = 0; c < MAXS; c++) {
             wt[c] = 0.f;
-            if (c < ns) wt[c] = (float)exp((double)(mlv[c].x - M));
+            // (the float64 exp of go/quant.go:619 is ~150 VALU instructions, redone by the 8 threads of a head: 12 of this
+            //  kernel's 16 us on a 2047-token prompt)
+            if (c < ns) wt[c] = P.fast_exp ? __builtin_amdgcn_exp2f((mlv[c].x - M) * 1.44269504088896340736f) : (float)exp((double)(mlv[c].x - M));
             L += wt[c] * mlv[c].y;
         }
         const float scale = 1.0f / L;

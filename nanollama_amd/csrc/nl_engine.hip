@@ -1277,7 +1277,8 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
                 LCK(launch_attn(hd, e->gqa, P, dim3(e->KVs, nsplit, n), st));
             }
             if (!merged) {
-            BMergeParams M{b.part_o, b.part_ml, b.pos, e->Hs, e->nsplit_max, hd, b.xfrag, nt16, L.wo.wtype == WT_Q4_0 ? 1 : 0};
+            const bool tile16 = one_stream && n >= 8 && attn_tile_supported(e->gqa) && !no_tile;
+            BMergeParams M{b.part_o, b.part_ml, b.pos, e->Hs, e->nsplit_max, hd, b.xfrag, nt16, L.wo.wtype == WT_Q4_0 ? 1 : 0, tile16 ? 1 : 0};
             {
                 const long long units = (long long)n * e->Hs * hd / 8;
                 hipLaunchKernelGGL(battn_merge_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, M, n);
