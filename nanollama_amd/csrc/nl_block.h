@@ -65,6 +65,10 @@ inline int blk_grid(int heads) { return ((heads + 7) / 8) * 32; }   // block b: 
 template <int WT, int NPIN>
 __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) {
     constexpr int HD = 64, CPP = WTraits<WT>::CPP, R4 = HD / 4, NGR = BLK_KV_THREADS / R4, NV = ATT_CH / NGR, NW = BLK_THREADS / 64;
+    NL_KARGS8(P.qkv_q, P.qkv_s, P.wo_q, P.wo_s, P.x, P.normw, P.kcache, P.vcache);
+    NL_KARGS8(P.ctl, P.parts, P.parts_in, P.x_out, P.xchg, P.tick, P.rope_cos, P.rope_sin);
+    NL_KARGS8(P.D, P.npairs, P.n_q_heads, P.n_kv_heads, P.seq_len, P.nparts_in, P.layer_tag, P.single_stream);
+    NL_KARGS8(P.dbg, P.host_status, P.status, P.bias_q, P.bias_out, P.eps, P.scale, P.kv_stream_stride);
     const int h = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7), jm = (blockIdx.x >> 3) & 3;
     if (h >= P.n_q_heads) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -87,8 +91,8 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     BLK_STAMP(0);
 
     // ---- every load of the launch that does not depend on a result is issued here ----
-    const int pos = P.ctl[CTL_POS];
-    const long long soff = P.single_stream ? 0 : (long long)P.ctl[CTL_STREAM] * P.kv_stream_stride;
+    const int pos = sload_i32(P.ctl + CTL_POS);
+    const long long soff = P.single_stream ? 0 : (long long)sload_i32(P.ctl + CTL_STREAM) * P.kv_stream_stride;
     const unsigned tag = (__hip_atomic_load(P.tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 8) | P.layer_tag;
     const int sect = wave >> 2, grp = wave & 3;   // 0 q, 1 k, 2 v; this wavefront's 256-column group
     const int tile = (sect == 0 ? h : sect == 1 ? P.n_q_heads + kvh : P.n_q_heads + P.n_kv_heads + kvh) * 4 + jm;
@@ -103,20 +107,23 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     // (wave-uniform branch: no lane waits on a partial load) and contributes zeros.
     const int xcol = gg * (KL * PAIR) + lane * 4;
     const bool xin = xcol < D;
-    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), gv = xv;
+    // (values of a wavefront that skips the loads below are never consumed unmasked: x / partials only by the staging
+    //  wavefronts that load them, a missing column group's dot product is replaced by 0)
+    float4 xv, gv;
+    undef_regs(xv); undef_regs(gv);
 #pragma unroll
-    for (int j = 0; j < CPP; j++) cw[j] = make_uint4(0u, 0u, 0u, 0u);
-    sw = make_uint2(0u, 0u);
+    for (int j = 0; j < CPP; j++) undef_regs(cw[j]);
+    undef_regs(sw);
     float4 pv[NPIN > 0 ? NPIN : 1];
 #pragma unroll
-    for (int p = 0; p < (NPIN > 0 ? NPIN : 1); p++) pv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < (NPIN > 0 ? NPIN : 1); p++) undef_regs(pv[p]);
     if (grp < ngroups) {
         if (sect == 0) {   // the q wavefronts stage x for the whole workgroup: one read of x (+ partials) per workgroup, not three
-            xv = *reinterpret_cast<const float4 *>(P.x + (xin ? xcol : 0));
-            gv = *reinterpret_cast<const float4 *>(P.normw + (xin ? xcol : 0));
+            const unsigned xo = (unsigned)(xin ? xcol : 0) * 4u;
+            xv = ld_off<float4>(P.x, xo);
+            gv = ld_off<float4>(P.normw, xo);
 #pragma unroll
-            for (int p = 0; p < NPIN; p++)
-                pv[p] = *reinterpret_cast<const float4 *>(P.parts_in + (size_t)min(p, P.nparts_in - 1) * D + (xin ? xcol : 0));
+            for (int p = 0; p < NPIN; p++) pv[p] = ld_off<float4>(P.parts_in, (unsigned)(min(p, P.nparts_in - 1) * D) * 4u + xo);
         }
         load_pair<WT>(P.qkv_q, P.qkv_s, tp0, gg, gs, r, min(k, gs - 1), cw, sw);
     }
@@ -129,9 +136,9 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
         const int lim = min(ATT_CH, P.seq_len);
 #pragma unroll
         for (int kk = 0; kk < NV; kk++) {
-            const int row = min(tg + kk * NGR, lim - 1);
-            kreg[kk] = K4[row * R4 + c4];
-            vreg[kk] = V4[row * R4 + c4];
+            const unsigned ro = (unsigned)(min(tg + kk * NGR, lim - 1) * R4 + c4) * 16u;
+            kreg[kk] = ld_off<float4>(K4, ro);
+            vreg[kk] = ld_off<float4>(V4, ro);
         }
     }
     // epilogue inputs of the projection rows: 48 threads of the last wavefront (it holds no cache rows and stages nothing),
@@ -399,6 +406,10 @@ inline int ffn_grid(int clusters) { return ((clusters + 7) / 8) * 64; }   // blo
 template <int WT, int NPIN>
 __global__ void __launch_bounds__(FFN_THREADS) ffn_block_kernel(FfnParams P) {
     constexpr int CPP = WTraits<WT>::CPP, NW = FFN_THREADS / 64;
+    NL_KARGS8(P.gate_q, P.up_q, P.gate_s, P.up_s, P.dn_q, P.dn_s, P.x, P.normw);
+    NL_KARGS8(P.parts_in, P.x_out, P.parts_out, P.xchg, P.tick, P.status, P.D, P.I);
+    NL_KARGS4(P.npairs, P.nparts_in, P.layer_tag, P.eps);
+    NL_KARGS2(P.dbg, P.host_status);
     const int cl = (blockIdx.x >> 6) * 8 + (blockIdx.x & 7), mem = (blockIdx.x >> 3) & 7;
     if (cl * FFN_SLICE >= P.I) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -423,20 +434,21 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_block_kernel(FfnParams P) {
     const bool lv = grp < ngroups && k < gs;
     const int xcol = gg * (KL * PAIR) + lane * 4;
     const bool xin = xcol < D;
-    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), gv = xv, pv[NPIN];
+    float4 xv, gv, pv[NPIN];     // (see attn_block_kernel: unfilled values are never consumed unmasked)
     uint4 cw[CPP];
-    uint2 sw = make_uint2(0u, 0u);
+    uint2 sw;
+    undef_regs(xv); undef_regs(gv); undef_regs(sw);
 #pragma unroll
-    for (int j = 0; j < CPP; j++) cw[j] = make_uint4(0u, 0u, 0u, 0u);
+    for (int j = 0; j < CPP; j++) undef_regs(cw[j]);
 #pragma unroll
-    for (int p = 0; p < NPIN; p++) pv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < NPIN; p++) undef_regs(pv[p]);
     if (grp < ngroups) {
         if (tsel == 0) {   // the wavefronts of tile 0 stage x for the whole workgroup (one read of x + partials, not four)
-            xv = *reinterpret_cast<const float4 *>(P.x + (xin ? xcol : 0));
-            gv = *reinterpret_cast<const float4 *>(P.normw + (xin ? xcol : 0));
+            const unsigned xo = (unsigned)(xin ? xcol : 0) * 4u;
+            xv = ld_off<float4>(P.x, xo);
+            gv = ld_off<float4>(P.normw, xo);
 #pragma unroll
-            for (int p = 0; p < NPIN; p++)
-                pv[p] = *reinterpret_cast<const float4 *>(P.parts_in + (size_t)min(p, P.nparts_in - 1) * D + (xin ? xcol : 0));
+            for (int p = 0; p < NPIN; p++) pv[p] = ld_off<float4>(P.parts_in, (unsigned)(min(p, P.nparts_in - 1) * D) * 4u + xo);
         }
         load_pair<WT>(Wq, Ws, (long long)tile * P.npairs, gg, gs, r, min(k, gs - 1), cw, sw);
     }

@@ -31,6 +31,31 @@ constexpr int ATT_CH = 128;      // positions per attention split
 constexpr int ATT_THREADS = 256;
 constexpr int CTL_TOKEN = 0, CTL_POS = 1, CTL_CHAIN = 2, CTL_STEP = 3, CTL_STREAM = 4, CTL_WORDS = 8;
 
+// A word written by an EARLIER launch (ctl / epoch counters) read through the scalar cache: s_load_dword, counted on
+// lgkmcnt.  A vector load of a wave-uniform value is followed by v_readfirstlane, i.e. by an immediate
+// `s_waitcnt vmcnt(0)` -- a whole memory round trip in front of every load the kernel issues after it.  (The scalar
+// cache is invalidated at every dispatch, like the vector L1.)
+__device__ __forceinline__ int sload_i32(const int *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) int *>(reinterpret_cast<unsigned long long>(p));
+}
+// All kernel arguments a launch reads, requested as ONE batch of s_load: hipcc otherwise fetches each field right before
+// its first use with a wait behind it -- four or five dependent scalar-cache round trips before the first weight load.
+// "Defined, value irrelevant": registers that only a conditional load fills and whose unfilled use is masked later.  An
+// explicit zero costs a v_mov per register per wavefront (81 of them in front of the first load of the attention block).
+__device__ __forceinline__ void undef_regs(float4 &v) { asm volatile("" : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w)); }
+__device__ __forceinline__ void undef_regs(uint4 &v) { asm volatile("" : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w)); }
+__device__ __forceinline__ void undef_regs(uint2 &v) { asm volatile("" : "=v"(v.x), "=v"(v.y)); }
+// load at "uniform base + unsigned 32-bit byte offset": the base stays in SGPRs and the load takes the saddr form (a signed
+// index costs a 64-bit VALU add per load)
+template <typename T>
+__device__ __forceinline__ T ld_off(const void *base, unsigned byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+#define NL_KARGS2(a, b) asm volatile("" :: "s"(a), "s"(b))
+#define NL_KARGS4(a, b, c, d) asm volatile("" :: "s"(a), "s"(b), "s"(c), "s"(d))
+#define NL_KARGS8(a, b, c, d, e, f, g, h) asm volatile("" :: "s"(a), "s"(b), "s"(c), "s"(d), "s"(e), "s"(f), "s"(g), "s"(h))
+
+
 // ggml ids (go/gguf.go:43-57).  Device layouts: Q5_0 is expanded to the Q8_0 layout at upload (5-bit value - 16 as
 // int8, same fp16 d); Q6_K to WT_Q6_K = int8 (6-bit value - 32) with four int8 sub-scales per 64 columns;
 // Q4_K keeps its nibbles with an 8-byte {d, dmin, sc0, m0, sc1, m1} entry per 64 columns.
