@@ -46,6 +46,10 @@ inline int grp_grid(int clusters, int members) { return ((clusters + 7) / 8) * m
 template <int WT, int NF>
 __global__ void __launch_bounds__(GRP_THREADS) qkv_attn_kernel(GroupParams P) {
     constexpr int HD = 64, CPP = WTraits<WT>::CPP, R4 = HD / 4, NGR = GRP_KV_THREADS / R4, NV = ATT_CH / NGR, NW = GRP_THREADS / 64;
+    NL_KARGS8(P.qkv_q, P.qkv_s, P.x, P.normw, P.rope_cos, P.rope_sin, P.kcache, P.vcache);   // one batch of s_load (nl_kernels.h)
+    NL_KARGS8(P.ctl, P.bias_q, P.part_o, P.part_ml, P.xchg, P.tick, P.status, P.host_status);
+    NL_KARGS8(P.D, P.npairs, P.n_q_heads, P.n_kv_heads, P.seq_len, P.single_stream, P.tpm, P.members);
+    NL_KARGS8(P.eps, P.scale, P.kv_stream_stride, P.nsplit_max, P.layer_tag, P.rope_conj, P.qk_norm, P.bias_k);
     const int M = P.members;
     const int cl = (blockIdx.x / (8 * M)) * 8 + (blockIdx.x & 7), mem = (blockIdx.x >> 3) % M;
     if (cl >= P.n_kv_heads) return;
@@ -75,8 +79,8 @@ __global__ void __launch_bounds__(GRP_THREADS) qkv_attn_kernel(GroupParams P) {
     const int tile = tile_of(mem * P.tpm + slot, w_sect, w_hq, w_j);
 
     // ---- loads that depend on nothing ----
-    const int pos = P.ctl[CTL_POS];
-    const long long soff = P.single_stream ? 0 : (long long)P.ctl[CTL_STREAM] * P.kv_stream_stride;
+    const int pos = sload_i32(P.ctl + CTL_POS);       // (scalar cache: no vector wait in front of the weight requests)
+    const long long soff = P.single_stream ? 0 : (long long)sload_i32(P.ctl + CTL_STREAM) * P.kv_stream_stride;
     const unsigned tag = (__hip_atomic_load(P.tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 8) | P.layer_tag;
     const long long tp0 = (long long)tile * P.npairs;
     const int ngroups = (P.npairs + KL - 1) / KL;
@@ -91,8 +95,8 @@ __global__ void __launch_bounds__(GRP_THREADS) qkv_attn_kernel(GroupParams P) {
         lv[f] = g < ngroups && k < gs;
         const int xcol = gg * (KL * PAIR) + lane * 4;
         xin[f] = xcol < D;
-        xv[f] = *reinterpret_cast<const float4 *>(P.x + (xin[f] ? xcol : 0));
-        gv[f] = *reinterpret_cast<const float4 *>(P.normw + (xin[f] ? xcol : 0));
+        xv[f] = ld_off<float4>(P.x, (unsigned)(xin[f] ? xcol : 0) * 4u);
+        gv[f] = ld_off<float4>(P.normw, (unsigned)(xin[f] ? xcol : 0) * 4u);
         load_pair<WT>(P.qkv_q, P.qkv_s, tp0, gg, gs, r, min(k, gs - 1), cw[f], sw[f]);
     }
     const bool attn_member = mem < G;    // this workgroup runs the attention of query head cl * G + mem
@@ -104,9 +108,9 @@ __global__ void __launch_bounds__(GRP_THREADS) qkv_attn_kernel(GroupParams P) {
         const int lim = min(ATT_CH, P.seq_len);
 #pragma unroll
         for (int kk = 0; kk < NV; kk++) {
-            const int row = min(tg + kk * NGR, lim - 1);
-            kreg[kk] = K4[row * R4 + c4];
-            vreg[kk] = V4[row * R4 + c4];
+            const unsigned ro = (unsigned)(min(tg + kk * NGR, lim - 1) * R4 + c4) * 16u;
+            kreg[kk] = ld_off<float4>(K4, ro);
+            vreg[kk] = ld_off<float4>(V4, ro);
         }
     }
     // epilogue inputs (threads 0 .. tpm * 16 - 1: one projection row each)
