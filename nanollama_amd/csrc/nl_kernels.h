@@ -1245,6 +1245,10 @@ __global__ void __launch_bounds__(1024) argmax_embed_kernel(ArgmaxParams P, Embe
     __shared__ int bi[16];
     __shared__ int tok;
     const int tid = threadIdx.x;
+    // the decode-state words this launch updates were written by the previous step's launch: requested now, through the
+    // scalar cache, so that after the reduction only stores remain (they were four dependent round trips of thread 0)
+    const int c_chain = sload_i32(P.ctl + CTL_CHAIN), c_step = sload_i32(P.ctl + CTL_STEP), c_pos = sload_i32(P.ctl + CTL_POS);
+    const int c_epoch = E.epoch ? sload_i32(reinterpret_cast<const int *>(E.epoch)) : 0;
     float best = -INFINITY;
     int idx = 0x7fffffff;
     if (P.part_val) {
@@ -1273,14 +1277,13 @@ __global__ void __launch_bounds__(1024) argmax_embed_kernel(ArgmaxParams P, Embe
         if (idx == 0x7fffffff) idx = 0;  // all-NaN logits: the reference's loop never leaves index 0
         tok = idx;
         *P.result = idx;
-        if (P.ctl[CTL_CHAIN]) {
-            int step = P.ctl[CTL_STEP];
-            P.ids[step] = idx;
-            P.ctl[CTL_STEP] = step + 1;
+        if (c_chain) {
+            P.ids[c_step] = idx;
+            P.ctl[CTL_STEP] = c_step + 1;
             P.ctl[CTL_TOKEN] = idx;
-            P.ctl[CTL_POS] = P.ctl[CTL_POS] + 1;
+            P.ctl[CTL_POS] = c_pos + 1;
         }
-        if (E.epoch) *E.epoch = *E.epoch + 1;   // this embedding opens the next Forward
+        if (E.epoch) *E.epoch = (unsigned)c_epoch + 1u;   // this embedding opens the next Forward
     }
     __syncthreads();
     const int token = tok;
