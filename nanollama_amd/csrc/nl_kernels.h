@@ -674,7 +674,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     }
     if (EPI == EPI_QKV) {
         if (e_act) {
-            e_pos = P.ctl[CTL_POS];
+            e_pos = sload_i32(P.ctl + CTL_POS);   // (scalar cache: the weight requests below do not queue behind a vector wait)
             const int half = P.head_dim >> 1, tph = P.head_dim / 16;
             const int i = (e_tile % tph) * 8 + (e_rr & 7);
             e_cos = P.rope_cos[e_pos * half + i];
@@ -682,9 +682,9 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
         }
     }
     unsigned e_tag = 0;
-    if (EPI == EPI_P2P) e_tag = (*P.p2p_epoch << 8) | P.p2p_seam;
+    if (EPI == EPI_P2P) e_tag = ((unsigned)sload_i32(reinterpret_cast<const int *>(P.p2p_epoch)) << 8) | P.p2p_seam;
     int ns = 1;
-    if (PRO == PRO_ATTN) ns = P.ctl[CTL_POS] / ATT_CH + 1;
+    if (PRO == PRO_ATTN) ns = sload_i32(P.ctl + CTL_POS) / ATT_CH + 1;
 
     float acc0 = 0.f;
     double ss = 0.0;
@@ -817,7 +817,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
         if (head < P.n_q_heads) {
             P.qbuf[head * hd + e] = outv;
         } else {
-            const long long soff = (long long)P.ctl[CTL_STREAM] * P.kv_stream_stride;
+            const long long soff = (long long)sload_i32(P.ctl + CTL_STREAM) * P.kv_stream_stride;
             if (head < P.n_q_heads + P.n_kv_heads) {
                 int kvh = head - P.n_q_heads;
                 P.kcache[soff + ((long long)kvh * P.seq_len + pos) * hd + e] = outv;
@@ -940,7 +940,7 @@ __device__ __forceinline__ float embed_value(const uint8_t *table, int wtype, in
 
 __global__ void embed_kernel(EmbedParams P) {
     if (P.epoch && threadIdx.x == 0) *P.epoch = *P.epoch + 1;
-    const int token = P.ctl[CTL_TOKEN];
+    const int token = sload_i32(P.ctl + CTL_TOKEN);
     const int gr = P.gamma_row ? P.gamma_row[token] : -1;
     // four elements per lane and round, their byte loads issued together (clamped index, masked store): one memory
     // latency per round instead of one per element
@@ -1055,13 +1055,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
                 vreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        pos = P.ctl[CTL_POS];
+        pos = sload_i32(P.ctl + CTL_POS);
         n = min(ATT_CH, pos + 1);
     } else {
-        pos = P.bpos ? P.bpos[item] : P.ctl[CTL_POS];
+        pos = P.bpos ? P.bpos[item] : sload_i32(P.ctl + CTL_POS);   // (ctl through the scalar cache: no vector wait before the K / V requests)
         if (t0 > pos) return;
         n = min(ATT_CH, pos + 1 - t0);
-        const long long soff = (long long)(P.bstream ? P.bstream[item] : P.ctl[CTL_STREAM]) * P.kv_stream_stride;
+        const long long soff = (long long)(P.bstream ? P.bstream[item] : sload_i32(P.ctl + CTL_STREAM)) * P.kv_stream_stride;
         const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
         const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
 #pragma unroll
