@@ -108,7 +108,7 @@ struct BEmbedParams {
 };
 
 __global__ void bembed_kernel(BEmbedParams P) {
-    const int token = P.tokens[blockIdx.x];
+    const int token = sload_i32(P.tokens + blockIdx.x);   // (per-workgroup words of the step's metadata: scalar cache, no vector wait)
     float *x = P.x + (long long)blockIdx.x * P.dim;
     const int gr = P.gamma_row ? P.gamma_row[token] : -1;
     for (int i = threadIdx.x; i < P.dim; i += blockDim.x) {
@@ -248,7 +248,7 @@ struct BRopeParams {
 __global__ void brope_kv_kernel(BRopeParams P) {
     extern __shared__ float vals[];  // [R] in natural (head, element) order after RoPE
     const int item = blockIdx.x, hd = P.head_dim, half = hd >> 1, tph = hd / 16;
-    const int pos = P.pos[item];
+    const int pos = sload_i32(P.pos + item);
     const long long src0 = (long long)item * P.R;
     for (int rho = threadIdx.x; rho < P.R; rho += blockDim.x) {
         const int tile = rho / TR, r = rho % TR;
@@ -286,7 +286,7 @@ __global__ void brope_kv_kernel(BRopeParams P) {
         }
         __syncthreads();
     }
-    const long long soff = (long long)P.stream[item] * P.kv_stream_stride;
+    const long long soff = (long long)sload_i32(P.stream + item) * P.kv_stream_stride;
     const int nq = P.n_q_heads * hd, nk = P.n_kv_heads * hd;
     for (int i = threadIdx.x; i < P.R; i += blockDim.x) {
         float v = vals[i];
@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
             }
         }
     }
-    const long long soff = P.single_stream ? 0 : (long long)P.bstream[i0] * P.kv_stream_stride;
+    const long long soff = P.single_stream ? 0 : (long long)sload_i32(P.bstream + i0) * P.kv_stream_stride;
     const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
     const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
     // staging: thread (key pair rp, float4 column c4) owns keys 2rp, 2rp+1 (clamped loads, zero beyond nrows so

@@ -1058,10 +1058,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
         pos = sload_i32(P.ctl + CTL_POS);
         n = min(ATT_CH, pos + 1);
     } else {
-        pos = P.bpos ? P.bpos[item] : sload_i32(P.ctl + CTL_POS);   // (ctl through the scalar cache: no vector wait before the K / V requests)
+        pos = sload_i32(P.bpos ? P.bpos + item : P.ctl + CTL_POS);   // (ctl through the scalar cache: no vector wait before the K / V requests)
         if (t0 > pos) return;
         n = min(ATT_CH, pos + 1 - t0);
-        const long long soff = (long long)(P.bstream ? P.bstream[item] : sload_i32(P.ctl + CTL_STREAM)) * P.kv_stream_stride;
+        const long long soff = (long long)sload_i32(P.bstream ? P.bstream + item : P.ctl + CTL_STREAM) * P.kv_stream_stride;
         const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
         const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
 #pragma unroll
