@@ -645,6 +645,14 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
 
     // the wavefront index as an SGPR value: tile, matrix and group bases become scalar arithmetic + a 32-bit lane offset
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // the arguments every variant reads, requested as one batch (the parameter block spans eight cache lines; fetched
+    // field by field they were three dependent scalar round trips)
+    NL_KARGS8(P.q0, P.q1, P.s0, P.s1, P.x, P.add_src, P.normw, P.out);
+    NL_KARGS8(P.rows, P.cols, P.npairs, P.ntiles, P.tw, P.kw, P.eps, P.dbg);
+    if (PRO == PRO_ATTN) NL_KARGS4(P.part_o, P.part_ml, P.nsplit_max, P.ctl);
+    if (PRO == PRO_NORM_PARTS) NL_KARGS2(P.parts, P.nparts);
+    if (EPI == EPI_RESID) NL_KARGS2(P.resid, P.bias_out);
+    if (EPI == EPI_STORE) NL_KARGS4(P.amax_val, P.amax_idx, P.bias_out, P.x_out);
 #define NL_STAMP(k) do { if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + (k)] = clock64(); } while (0)
     NL_STAMP(0);
     const int r = lane >> 2, k = lane & 3;
