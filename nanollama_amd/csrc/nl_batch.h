@@ -136,6 +136,8 @@ struct BNormParams {
 // from the sum of squares to the fragment store: one trip to memory per row, 16-byte loads.
 template <int UPT>
 __global__ void __launch_bounds__(256) bnorm_kernel(BNormParams P) {
+    NL_KARGS8(P.x, P.w, P.xf, P.pend.part, P.pend.bias, P.dim, P.item0, P.pend.ks);   // one batch of s_load (nl_kernels.h)
+    NL_KARGS4(P.eps, P.nt16, P.q4, P.pend.zstride);
     __shared__ double dred[4];
     const int item = P.item0 + blockIdx.x, n = P.dim, nu = n / 8;
     float *xr = P.x + (long long)item * n;
@@ -246,6 +248,9 @@ struct BRopeParams {
 
 // RoPE (go/model.go:449-477) + optional QK-norm (:542-549) + KV store (:552-554) for one token per workgroup
 __global__ void brope_kv_kernel(BRopeParams P) {
+    NL_KARGS8(P.qkv.val, P.qkv.part, P.qkv.bias, P.pos, P.stream, P.rope_cos, P.rope_sin, P.q);   // one batch of s_load
+    NL_KARGS8(P.kcache, P.vcache, P.bias_q, P.kv_stream_stride, P.R, P.head_dim, P.n_q_heads, P.n_kv_heads);
+    NL_KARGS8(P.seq_len, P.rope_conj, P.qk_norm, P.eps, P.qkv.ks, P.qkv.zstride, P.bias_k, P.bias_v);
     extern __shared__ float vals[];  // [R] in natural (head, element) order after RoPE
     const int item = blockIdx.x, hd = P.head_dim, half = hd >> 1, tph = hd / 16;
     const int pos = sload_i32(P.pos + item);
@@ -337,6 +342,7 @@ struct BMergeParams {
 // partial rows of four splits at a time are fetched with clamped indices before anything consumes them
 // (a runtime-bounded "for c < ns: load" loop is ns dependent round trips); splits past ns get weight 0.
 __global__ void battn_merge_kernel(BMergeParams P, int n_items) {
+    NL_KARGS8(P.part_o, P.part_ml, P.pos, P.xf, P.heads, P.nsplit_max, P.head_dim, P.nt16);   // one batch of s_load
     constexpr int MAXS = 16;                         // seq_len <= 2048 (go/model.go:145-148) => at most 16 splits
     const int hd = P.head_dim, upi = P.heads * hd / 8;
     const long long total = (long long)n_items * upi;
@@ -403,6 +409,8 @@ struct BSwigluParams {
 };
 
 __global__ void bswiglu_kernel(BSwigluParams P) {
+    NL_KARGS8(P.g.val, P.g.part, P.u.val, P.u.part, P.xf, P.interm, P.n_tokens, P.g.ks);   // one batch of s_load
+    NL_KARGS4(P.g.zstride, P.u.zstride, P.nt16, P.q4);
     const int upt = P.interm / 8;                     // units per token
     const long long total = (long long)P.n_tokens * upt;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {

@@ -247,6 +247,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
     static_assert(EPI != QG_EPI_SWIGLU || (RT == 2 && NT == 4), "the fused epilogue pairs a gate tile with its up tile");
     static_assert(EPI != QG_EPI_ROPE || (RT == 1 && NT == 4), "one Q|K|V tile per wavefront: rotation partners are rows r and r^8 of a tile");
     static_assert(NT == 1 || NT == 2 || NT == 4, "16-token tiles of the 64-token group this workgroup computes");
+    NL_KARGS8(P.q, P.s, P.xf, P.out, P.resid, P.bias, P.part, P.q1);   // one batch of s_load (nl_kernels.h)
+    NL_KARGS8(P.rows, P.cols, P.npairs, P.ntiles, P.nt16, P.n_tokens, P.ldo, P.ksplit);
+    NL_KARGS4(P.s1, P.out1, P.part1, P.row_groups);
     typedef typename WFrag<WT>::raw_t raw_t;
     // fragment buffers: [buffer][block in chunk][token tile < NT][hi/lo][lane] x 16 bytes.  NT < 4 (decode batches
     // and prompts of <= 16 / 32 tokens): only the first NT tiles of the group are fetched and multiplied.
