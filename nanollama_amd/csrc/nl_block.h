@@ -37,6 +37,7 @@ struct BlockParams {
     const uint8_t *wo_q;         // per-head WO slices: [H][D/16 tiles][1 pair]
     const uint32_t *wo_s;
     int D, npairs, n_q_heads, n_kv_heads, seq_len, rope_conj, qk_norm, single_stream;
+    unsigned gqa, gqa_inv;       // query heads per kv head and udiv_inv of it (head -> kv head without a division)
     const float *x, *normw;
     float eps, scale;
     const float *rope_cos, *rope_sin;
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     float *chunk = sc + ATT_CH;                                      // [32][66]: (m, l, o[64]) per 64-position half pass
     float *ored = chunk + 32 * 66;                                   // [2][32][64]
 
-    const int G = P.n_q_heads / P.n_kv_heads, kvh = h / G;
+    const int G = (int)P.gqa, kvh = (int)udiv_by((unsigned)h, P.gqa, P.gqa_inv);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane >> 2, k = lane & 3;
     const int D = P.D;

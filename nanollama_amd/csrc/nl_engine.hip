@@ -353,6 +353,7 @@ void choose_geometry(const nl_engine *e, const PackedMat &m, int &tw, int &kw, i
 template <int PRO, int EPI, int NP = 1>
 hipError_t launch_gemv_t(int wtype, GemvParams P, hipStream_t st) {
     P.add_src = P.add ? P.add : P.x;   // PRO_ATTN kernels never read it
+    P.kw_inv = udiv_inv((unsigned)P.kw); P.kw2_inv = udiv_inv(2u * (unsigned)P.kw);
     const int nwaves = P.tw * P.kw * (EPI == EPI_SWIGLU ? 2 : 1);
     const size_t lds = (size_t)nwaves * XS_WAVE * 4 + (size_t)nwaves * TR * 4 + (size_t)nwaves * 8;
     const dim3 grid((P.ntiles + P.tw - 1) / P.tw), block(nwaves * 64);
@@ -503,6 +504,7 @@ BlockParams attn_block_params(nl_engine *e, int l, const float *x_in) {
     B.qkv_q = L.qkv.q; B.qkv_s = L.qkv.s; B.wo_q = L.wo_head.q; B.wo_s = L.wo_head.s;
     B.D = c.dim; B.npairs = L.qkv.npairs; B.n_q_heads = e->Hs; B.n_kv_heads = e->KVs; B.seq_len = c.seq_len;
     B.rope_conj = c.rope_conjugate; B.qk_norm = c.qk_norm; B.single_stream = c.max_streams == 1 ? 1 : 0;
+    B.gqa = (unsigned)(e->Hs / e->KVs); B.gqa_inv = udiv_inv(B.gqa);
     B.x = x_in; B.normw = L.attn_norm; B.eps = c.rms_eps; B.scale = (float)(1.0 / std::sqrt((double)e->hd));
     B.rope_cos = e->rope_cos; B.rope_sin = e->rope_sin;
     B.kcache = e->kcache + (long long)l * e->kv_layer_stride; B.vcache = e->vcache + (long long)l * e->kv_layer_stride;

@@ -51,6 +51,11 @@ template <typename T>
 __device__ __forceinline__ T ld_off(const void *base, unsigned byte_off) {
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
 }
+// n / d for a runtime divisor known on the host: inv = ceil(2^32 / d) (udiv_inv), q = mulhi(n, inv), exact while
+// n < 2^32 / d.  hipcc's generic 32-bit division is ~35 instructions with a v_rcp in a dependent chain, in front of the
+// first load of a launch that derives its tile from a wavefront or workgroup index.
+__host__ __device__ inline unsigned udiv_inv(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+__device__ __forceinline__ unsigned udiv_by(unsigned n, unsigned d, unsigned inv) { return d <= 1 ? n : __umulhi(n, inv); }
 #define NL_KARGS2(a, b) asm volatile("" :: "s"(a), "s"(b))
 #define NL_KARGS4(a, b, c, d) asm volatile("" :: "s"(a), "s"(b), "s"(c), "s"(d))
 #define NL_KARGS8(a, b, c, d, e, f, g, h) asm volatile("" :: "s"(a), "s"(b), "s"(c), "s"(d), "s"(e), "s"(f), "s"(g), "s"(h))
@@ -459,6 +464,7 @@ struct GemvParams {
     const uint8_t *q0, *q1;
     const uint32_t *s0, *s1;
     int rows, cols, npairs, ntiles, tw, kw;
+    unsigned kw_inv, kw2_inv;   // udiv_inv(kw), udiv_inv(2 * kw): wavefront -> tile slot without a division (launch_gemv_t)
     // prologue: input vector
     const float *x;      // PRO_PLAIN / PRO_NORM input [cols]
     const float *add;    // optional addend (tensor-parallel: all-reduced partial of the previous block)
@@ -658,8 +664,8 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     const int r = lane >> 2, k = lane & 3;
     // EPI_SWIGLU: a tile slot is served by 2*kw wavefronts, the first kw on the gate matrix, the rest on up
     const int wpt = EPI == EPI_SWIGLU ? 2 * P.kw : P.kw;
-    const int tin = wave / wpt;
-    const int msel = EPI == EPI_SWIGLU ? (wave - tin * wpt) / P.kw : 0;
+    const int tin = (int)udiv_by((unsigned)wave, (unsigned)wpt, EPI == EPI_SWIGLU ? P.kw2_inv : P.kw_inv);
+    const int msel = EPI == EPI_SWIGLU ? (int)udiv_by((unsigned)(wave - tin * wpt), (unsigned)P.kw, P.kw_inv) : 0;
     const int kw = (wave - tin * wpt) - msel * P.kw;
     const uint8_t *const Wq = msel ? P.q1 : P.q0;
     const uint32_t *const Ws = msel ? P.s1 : P.s0;
