@@ -657,6 +657,8 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
             B.D = c.dim; B.npairs = L.qkv.npairs; B.n_q_heads = e->Hs; B.n_kv_heads = e->KVs; B.seq_len = c.seq_len;
             B.rope_conj = c.rope_conjugate; B.qk_norm = c.qk_norm; B.single_stream = c.max_streams == 1 ? 1 : 0;
             B.tpm = e->grp_tpm; B.members = (e->gqa + 2) * 4 / e->grp_tpm;
+            B.gqa = (unsigned)e->gqa; B.wpt = (unsigned)((GRP_THREADS / 64) / e->grp_tpm); B.wpt_inv = udiv_inv(B.wpt);
+            B.m8_inv = udiv_inv(8u * (unsigned)B.members); B.m_inv = udiv_inv((unsigned)B.members);
             B.x = e->x[cur]; B.normw = L.attn_norm; B.eps = c.rms_eps; B.scale = (float)(1.0 / std::sqrt((double)e->hd));
             B.rope_cos = e->rope_cos; B.rope_sin = e->rope_sin; B.kcache = kc; B.vcache = vc;
             B.kv_stream_stride = e->kv_stream_stride; B.ctl = e->ctl;

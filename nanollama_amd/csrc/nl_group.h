@@ -22,6 +22,7 @@ struct GroupParams {
     const uint32_t *qkv_s;
     int D, npairs, n_q_heads, n_kv_heads, seq_len, rope_conj, qk_norm, single_stream;
     int tpm, members;            // 16-row tiles per workgroup; workgroups per kv group = (G + 2) * 4 / tpm
+    unsigned gqa, wpt, wpt_inv, m8_inv, m_inv;   // G, wavefronts per tile, udiv_inv of wpt / 8 * members / members (host: no divisions at entry)
     const float *x, *normw;
     float eps, scale;
     const float *rope_cos, *rope_sin;
@@ -51,7 +52,8 @@ __global__ void __launch_bounds__(GRP_THREADS) qkv_attn_kernel(GroupParams P) {
     NL_KARGS8(P.D, P.npairs, P.n_q_heads, P.n_kv_heads, P.seq_len, P.single_stream, P.tpm, P.members);
     NL_KARGS8(P.eps, P.scale, P.kv_stream_stride, P.nsplit_max, P.layer_tag, P.rope_conj, P.qk_norm, P.bias_k);
     const int M = P.members;
-    const int cl = (blockIdx.x / (8 * M)) * 8 + (blockIdx.x & 7), mem = (blockIdx.x >> 3) % M;
+    const int b8 = (int)(blockIdx.x >> 3);
+    const int cl = (int)udiv_by(blockIdx.x, 8u * (unsigned)M, P.m8_inv) * 8 + (blockIdx.x & 7), mem = b8 - (int)udiv_by((unsigned)b8, (unsigned)M, P.m_inv) * M;
     if (cl >= P.n_kv_heads) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *dred = reinterpret_cast<double *>(smem);                 // [16]
@@ -63,11 +65,11 @@ __global__ void __launch_bounds__(GRP_THREADS) qkv_attn_kernel(GroupParams P) {
     float *sc = ml + 8;                                              // [128]
     float *ored = sc + ATT_CH;                                       // [32][64]
 
-    const int G = P.n_q_heads / P.n_kv_heads, D = P.D;
+    const int G = (int)P.gqa, D = P.D;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane >> 2, k = lane & 3;
-    const int wpt = NW / P.tpm;                    // wavefronts per tile
-    const int slot = wave / wpt, cs = wave % wpt;  // tile of this workgroup, column share
+    const int wpt = (int)P.wpt;                    // wavefronts per tile (NW / tpm)
+    const int slot = (int)udiv_by((unsigned)wave, P.wpt, P.wpt_inv), cs = wave - slot * wpt;  // tile of this workgroup, column share
     // tile u of the group: q heads first (4 tiles each), then k, then v
     auto tile_of = [&](int u, int &sect, int &hq, int &j) {
         j = u & 3;
