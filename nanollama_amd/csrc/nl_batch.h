@@ -77,6 +77,32 @@ __device__ __forceinline__ void gemm_out_at4x2(const GemmOut &g, long long ia, i
     }
 }
 
+// gate and up of the same two float4 groups: the slabs of BOTH matrices are requested before either is summed (four
+// slabs of each per round trip), same additions in the same order as gemm_out_at4x2 per matrix
+__device__ __forceinline__ void gemm_out_pair4x2(const GemmOut &g, const GemmOut &u, long long ia, long long ib,
+                                                 float4 &ga, float4 &gb, float4 &ua, float4 &ub) {
+    ga = make_float4(0.f, 0.f, 0.f, 0.f); gb = ga; ua = ga; ub = ga;
+    for (int z0 = 0; z0 < g.ks; z0 += 4) {
+        float4 pga[4], pgb[4], pua[4], pub[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const long long zo = (long long)min(z0 + k, g.ks - 1) * g.zstride;
+            pga[k] = *reinterpret_cast<const float4 *>(g.part + zo + ia);
+            pgb[k] = *reinterpret_cast<const float4 *>(g.part + zo + ib);
+            pua[k] = *reinterpret_cast<const float4 *>(u.part + zo + ia);
+            pub[k] = *reinterpret_cast<const float4 *>(u.part + zo + ib);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool on = z0 + k < g.ks;
+            ga.x += on ? pga[k].x : 0.f; ga.y += on ? pga[k].y : 0.f; ga.z += on ? pga[k].z : 0.f; ga.w += on ? pga[k].w : 0.f;
+            gb.x += on ? pgb[k].x : 0.f; gb.y += on ? pgb[k].y : 0.f; gb.z += on ? pgb[k].z : 0.f; gb.w += on ? pgb[k].w : 0.f;
+            ua.x += on ? pua[k].x : 0.f; ua.y += on ? pua[k].y : 0.f; ua.z += on ? pua[k].z : 0.f; ua.w += on ? pua[k].w : 0.f;
+            ub.x += on ? pub[k].x : 0.f; ub.y += on ? pub[k].y : 0.f; ub.z += on ? pub[k].z : 0.f; ub.w += on ? pub[k].w : 0.f;
+        }
+    }
+}
+
 // four consecutive columns (idx, col multiples of 4): same arithmetic per element as gemm_out_at
 __device__ __forceinline__ float4 gemm_out_at4(const GemmOut &g, long long idx, int col) {
     if (g.ks <= 1) return *reinterpret_cast<const float4 *>(g.val + idx);
@@ -153,6 +179,12 @@ __global__ void __launch_bounds__(256) bnorm_kernel(BNormParams P) {
         xa[k] = *reinterpret_cast<const float4 *>(xr + ca[k]);
         xb[k] = *reinterpret_cast<const float4 *>(xr + cb[k]);
     }
+    float4 wa[UPT], wb[UPT];     // (requested with x: not behind the slab round trip of the fold)
+#pragma unroll
+    for (int k = 0; k < UPT; k++) {
+        wa[k] = *reinterpret_cast<const float4 *>(P.w + ca[k]);
+        wb[k] = *reinterpret_cast<const float4 *>(P.w + cb[k]);
+    }
     if (fold) {
 #pragma unroll
         for (int k = 0; k < UPT; k++) {
@@ -165,12 +197,6 @@ __global__ void __launch_bounds__(256) bnorm_kernel(BNormParams P) {
                 *reinterpret_cast<float4 *>(xr + cb[k]) = xb[k];
             }
         }
-    }
-    float4 wa[UPT], wb[UPT];
-#pragma unroll
-    for (int k = 0; k < UPT; k++) {
-        wa[k] = *reinterpret_cast<const float4 *>(P.w + ca[k]);
-        wb[k] = *reinterpret_cast<const float4 *>(P.w + cb[k]);
     }
     double ss = 0.0;
 #pragma unroll
@@ -252,13 +278,16 @@ __global__ void brope_kv_kernel(BRopeParams P) {
     NL_KARGS8(P.kcache, P.vcache, P.bias_q, P.kv_stream_stride, P.R, P.head_dim, P.n_q_heads, P.n_kv_heads);
     NL_KARGS8(P.seq_len, P.rope_conj, P.qk_norm, P.eps, P.qkv.ks, P.qkv.zstride, P.bias_k, P.bias_v);
     extern __shared__ float vals[];  // [R] in natural (head, element) order after RoPE
-    const int item = blockIdx.x, hd = P.head_dim, half = hd >> 1, tph = hd / 16;
+    const int item = blockIdx.x, hd = P.head_dim, half = hd >> 1;
+    const int hsh = hd == 64 ? 6 : 5, tsh = hsh - 4;     // head_dim is 32 or 64 (nl_create): shifts, not runtime divisions
     const int pos = sload_i32(P.pos + item);
     const long long src0 = (long long)item * P.R;
     for (int rho = threadIdx.x; rho < P.R; rho += blockDim.x) {
         const int tile = rho / TR, r = rho % TR;
-        const int head = tile / tph, j = tile % tph;
+        const int head = tile >> tsh, j = tile & ((1 << tsh) - 1);
         const int i = j * 8 + (r & 7), e = i + (r >> 3) * half;
+        // the rotation's cos / sin leave with the slab requests (V rows load them too and ignore them): one round trip
+        const float rc = P.rope_cos[pos * half + i], rs = P.rope_sin[pos * half + i];
         float v, partner;
         gemm_out_at2(P.qkv, src0 + rho, rho, src0 + (rho ^ 8), rho ^ 8, v, partner);
         float outv = v;
@@ -271,7 +300,7 @@ __global__ void brope_kv_kernel(BRopeParams P) {
             outv = v;
         }
         if (head < P.n_q_heads + P.n_kv_heads) {
-            float c = P.rope_cos[pos * half + i], s = P.rope_sin[pos * half + i];
+            const float c = rc, s = rs;
             float x0 = (r < 8) ? v : partner, x1 = (r < 8) ? partner : v;
             if (!P.rope_conj) outv = (r < 8) ? (x0 * c - x1 * s) : (x0 * s + x1 * c);
             else outv = (r < 8) ? (x0 * c + x1 * s) : (-x0 * s + x1 * c);
@@ -298,10 +327,10 @@ __global__ void brope_kv_kernel(BRopeParams P) {
         if (i < nq) {
             P.q[(long long)item * nq + i] = v;
         } else if (i < nq + nk) {
-            int kvh = (i - nq) / hd, e = (i - nq) % hd;
+            int kvh = (i - nq) >> hsh, e = (i - nq) & (hd - 1);
             P.kcache[soff + ((long long)kvh * P.seq_len + pos) * hd + e] = v;
         } else {
-            int kvh = (i - nq - nk) / hd, e = (i - nq - nk) % hd;
+            int kvh = (i - nq - nk) >> hsh, e = (i - nq - nk) & (hd - 1);
             P.vcache[soff + ((long long)kvh * P.seq_len + pos) * hd + e] = v;
         }
     }
@@ -423,6 +452,8 @@ __global__ void bswiglu_kernel(BSwigluParams P) {
         if (P.g.ks <= 1 && P.u.ks <= 1) {   // one branch around all four loads: they are in flight together
             ga = *reinterpret_cast<const float4 *>(P.g.val + row + ca); gb = *reinterpret_cast<const float4 *>(P.g.val + row + cb);
             ua = *reinterpret_cast<const float4 *>(P.u.val + row + ca); ub = *reinterpret_cast<const float4 *>(P.u.val + row + cb);
+        } else if (P.g.ks == P.u.ks && P.g.ks > 1 && !P.g.bias && !P.u.bias && P.g.zstride == P.u.zstride) {
+            gemm_out_pair4x2(P.g, P.u, row + ca, row + cb, ga, gb, ua, ub);   // (the gate || up launch: same split for both)
         } else {
             gemm_out_at4x2(P.g, row + ca, ca, row + cb, cb, ga, gb);
             gemm_out_at4x2(P.u, row + ca, ca, row + cb, cb, ua, ub);
