@@ -1,15 +1,20 @@
-// nl_qgemm2.h -- the multi-token GEMM for LONG token runs (prompt prefill): weights through LDS, activations in registers.
+// nl_qgemm2.h -- the multi-token GEMM for LONG token runs (prompt prefill, Q4_0): weights through LDS, activations in registers.
 //
 // qgemm_kernel (nl_qgemm.h) gives every wavefront its own 16 weight rows and shares the activation fragments of 64 tokens
 // through LDS: per 32-column block a wavefront issues 8 ds_read_b128 for 8 MFMAs, expands its weight fragment itself
 // and spends 16 VALU FMAs on the block scale -- LDS reads, VALU and MFMA issue are co-limited (measured: MFMA pipe
 // 29 % busy at 2047 tokens, and neither a 3-MFMA scaled-weight form nor two row tiles per wavefront helped).
-// Here the roles are swapped.  A workgroup owns 128 weight rows x 128 tokens; its 512 threads expand the 128 x 128-column
-// chunk of weights ONCE into fp16 MFMA fragments in LDS (one (row, block) item per thread), every wavefront owns one
-// 16-token tile whose hi / lo activation fragments it loads straight from the fragment store into registers, and per
-// block it multiplies them against all 8 row tiles: 8 ds_read_b128 now feed 16 MFMAs, the weight expansion costs 1/8 of
-// the VALU work per MFMA, and the 32 scale FMAs ride under 256 cycles of MFMA issue.
-// Same arithmetic per output as qgemm_kernel: exact integer quants in fp16, x = hi + lo, f32 block sums, * d in f32.
+// Here the roles are swapped.  A workgroup owns RT (4) 16-row tiles of weights and WAVES * NTW 16-token tiles; all its
+// threads expand the RT*16 x 128-column chunk of weights ONCE into fp16 MFMA fragments in LDS (one (row, block) item per
+// thread, a quarter of the expansion after each of the chunk's four blocks, raw quants requested two chunks ahead), every
+// wavefront owns NTW token tiles whose hi / lo activation fragments it loads straight from the fragment store into
+// registers one block ahead, and per block it multiplies them against all RT row tiles: RT ds_read_b128 feed
+// 2 * RT * NTW MFMAs.  The weight fragment is the MFMA's A operand, so a lane owns four consecutive rows of one token:
+// block scales arrive as one ds_read_b128, `acc += z * d` is two v_pk_fma_f32, results leave as float4 stores.
+// The written order is pinned (sched_barrier + an empty asm on the accumulators): hipcc otherwise sinks every "* d" FMA
+// of a chunk below its 64 MFMAs (128 live result registers, occupancy 2) and the activation prefetch next to its use.
+// Same arithmetic per output as qgemm_kernel (exact integer quants in fp16, x = hi + lo, f32 block sums, * d in f32):
+// outputs are bit-identical between the two kernels (tests/test_gpu_parity.py, tools/qgemm2_bench.hip).  DESIGN.md 4.2b.
 #pragma once
 #include "nl_qgemm.h"
 
