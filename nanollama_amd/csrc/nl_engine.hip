@@ -1694,7 +1694,9 @@ int nl_finalize(nl_handle e) {
         e->fused_mode = ok1 ? 1 : ok2 ? 2 : 0;
         e->fused = e->fused_mode != 0;
         const char *fm = getenv("NL_FUSED_MAX_POS");
-        e->fused_max_pos = fm ? atoi(fm) : 384;   // tools/fused_limit.py: the fused plans win up to ~450 (nano), ~600 (mini), ~350 (big) positions
+        // tools/fused_limit.py: the per-head blocks (mode 1) win up to ~500 (nano) / ~600 (mini) positions, the projection +
+        // attention launch of the wide tiers (mode 2) up to ~390 (big)
+        e->fused_max_pos = fm ? atoi(fm) : e->fused_mode == 1 ? 512 : 384;
         {
             const char *ff = getenv("NL_FUSED_FFN");   // knob (tests, tools): 0 keeps gate/up and down as two launches
             bool okf = e->fused_mode == 1 && !(ff && atoi(ff) == 0);

@@ -1062,21 +1062,21 @@ def test_fused_attention_block_matches_oracle(hip, orc, tmp_path, monkeypatch, w
 
 
 def test_greedy_chain_switches_from_the_fused_plan_to_the_split_attention_plan(hip, orc, tmp_path):
-    # the block serves positions below NL_FUSED_MAX_POS (default 384); a chained greedy run that crosses it keeps
-    # producing the oracle's ids (16-step graphs of either plan, single steps at the seam)
-    shape = synth.ModelShape("fb_switch", 2, 192, 3, 3, 1024, seq_len=480)
+    # the block serves positions below NL_FUSED_MAX_POS (default 512 for the per-head blocks); a chained greedy run that
+    # crosses it keeps producing the oracle's ids (16-step graphs of either plan, single steps at the seam)
+    shape = synth.ModelShape("fb_switch", 2, 192, 3, 3, 1024, seq_len=608)
     p = tmp_path / "m.gguf"
     synth.generate_gguf(str(p), shape, "q8_0", 71)
     g = gguf.load_gguf(str(p))
     dev = hip.load_llama_model(g)
     ref = orc.OracleModel(g)
-    prompt = synth.prompt_ids(330, shape.vocab, seed=3)
+    prompt = synth.prompt_ids(458, shape.vocab, seed=3)
     want, _ = ref.generate_greedy(prompt, 100)
     dev.prefill(prompt)
     first = int(np.argmax(dev.state.logits))
     got = [first] + dev.decode_greedy(first, len(prompt), 99)
     assert got == want
-    assert "attn_block" in _kinds(dev, 100) and "attn_block" not in _kinds(dev, 450)
+    assert "attn_block" in _kinds(dev, 100) and "attn_block" not in _kinds(dev, 580)
     dev.close(); ref.close()
 
 
