@@ -117,9 +117,10 @@ def ensure_gguf(shape, wtype, mode, rank=0):
     return path
 
 
-def cpu_baseline(path, prompt, budget_s=20.0):
+def cpu_baseline(path, prompt, budget_s=20.0, min_tokens=1, max_tokens=SEGMENT):
     """The Go engine's algorithm (C restatement, oracle/) timed on this box's
-    host cores on a bounded sample of the same workload.  Reported, not optimised against."""
+    host cores on a bounded sample of the same workload (timer after the prompt, go/main.go:171,222-226).
+    Reported, not optimised against."""
     from nanollama_amd import gguf
     from oracle import oracle
     ncpu = os.cpu_count() or 1
@@ -142,7 +143,7 @@ def cpu_baseline(path, prompt, budget_s=20.0):
             best, cores = dt, c
     oracle.set_threads(cores)
     n, t0 = 0, time.perf_counter()
-    while n < SEGMENT and (time.perf_counter() - t0) < budget_s:   # timer after prefill, go/main.go:171
+    while n < max_tokens and (n < min_tokens or (time.perf_counter() - t0) < budget_s):   # timer after prefill, go/main.go:171
         m.forward(nxt, pos)
         nxt = oracle.argmax(m.logits())
         pos += 1
@@ -227,7 +228,7 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
 
     # per-launch device time: every launch of the plan replayed 20x back to back between HIP events on the
     # engine's stream (nl_profile_forward), at a mid-run position
-    ppos = min(profile_pos, shape.seq_len - 1)
+    ppos = min(profile_pos if profile_pos is not None else pos0 + (min(SEGMENT, steps) - 1) // 2, shape.seq_len - 1)
     prof = dev.profile_forward(first, ppos, iters=20)
     kb = kernel_bytes(shape, wtype, ppos, tp=world)
     kernels = {}
@@ -237,10 +238,19 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
             kernels[kind] = {"launches": calls, "us_per_launch": round(per * 1e3, 3),
                              "GBps": round(kb[kind] / (per * 1e-3) / 1e9, 1)}
     traffic, traffic_file = measured_traffic(tier, wtype) if world == 1 else (None, None)
-    # dominant kernel = the kind that moves the most algorithmic bytes per step (stable from run to run; for the
-    # launch-bound nano tier the per-layer kinds have near-equal time shares and a time ranking flips)
-    dom = max((k for k in kernels if k not in ("argmax", "allreduce")), key=lambda k: kb[k] * prof[k][1])
-    dom_gbs = kernels[dom]["GBps"]
+    # dominant kernel = the kind with the largest TIME share of the step (launches x time per launch; ties broken by
+    # name); the kind that moves the most algorithmic bytes per step is reported beside it as roofline_by_bytes
+    cand = sorted(k for k in kernels if k not in ("argmax", "allreduce"))
+    dom = max(cand, key=lambda k: (prof[k][0], k))          # prof[k][0] = sum over the kind's launches of ms per launch
+    dom_bytes = max(cand, key=lambda k: (kb[k] * prof[k][1], k))
+    step_ms_profiled = sum(prof[k][0] for k in kernels)
+
+    def roof(kind):
+        return {"bound": "hbm", "kernel": kind, "achieved": kernels[kind]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(kernels[kind]["GBps"] / HBM_PEAK_GBS, 4), "traffic": (traffic or {}).get(kind),
+                "traffic_source": traffic_file, "bytes_per_launch": int(kb[kind]),
+                "us_per_launch": kernels[kind]["us_per_launch"], "launches_per_step": kernels[kind]["launches"],
+                "time_share_of_step": round(prof[kind][0] / step_ms_profiled, 3), "profiled_at_pos": ppos}
     mean_pos = pos0 + (min(SEGMENT, steps) - 1) / 2.0
     step_bytes = synth.weight_bytes_per_token(shape, wtype) + synth.kv_bytes_per_token(shape, int(mean_pos))
     step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
@@ -252,10 +262,8 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
         "replicas": replicas, "tp": world, "p2p": p2p,
         "step_bytes": int(step_bytes), "hbm_frac_whole_step": step_gbs / (HBM_PEAK_GBS * max(world, 1)),
         "kernels": kernels, "last_ids": ids[-4:], "head_ids": head_ids, "prefill_logits": prefill_logits,
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": (traffic or {}).get(dom),
-                     "traffic_source": traffic_file,
-                     "bytes_per_launch": int(kb[dom]), "us_per_launch": kernels[dom]["us_per_launch"]},
+        "roofline": roof(dom), "roofline_by_bytes": roof(dom_bytes),
+        "segment": min(SEGMENT, steps), "pos_first": pos0, "pos_last": pos0 + min(SEGMENT, steps) - 1,
     }
     if keep is not None:
         keep.append(dev)
@@ -304,12 +312,17 @@ def side_configs(model):
     streams = list(range(ns))
     for p in range(pos0):
         ids, _ = dev.forward_batch(streams, ids, [p] * ns)
+    dev.synchronize()
+    dev.timer_start()              # HIP events on the engine's stream around the same loop the wall clock brackets
     t0 = time.perf_counter()
     for k in range(steps):
         ids, _ = dev.forward_batch(streams, ids, [pos0 + k] * ns)
     dt = time.perf_counter() - t0
+    ev_ms = dev.timer_stop()
     step_bytes = synth.weight_bytes_per_token(shape, "q4_0") + ns * synth.kv_bytes_per_token(shape, pos0 + steps // 2)
     out["goldie_q4_0_64_streams"] = {"tokens_per_s_aggregate": round(ns * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+                                     "device_ms_per_step": round(ev_ms / steps, 3), "steps": steps,
+                                     "positions": f"{pos0}..{pos0 + steps - 1}", "launch": "one nl_forward_batch call per step (host loop; ids read back every step)",
                                      "hbm_frac": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
     dev.close()
     # -- nano at the reference's DEFAULT generation settings (go/main.go:29-34: temp 0.8, top-p 0.9, repetition
@@ -331,15 +344,20 @@ def side_configs(model):
     return out
 
 
-def workload_text(shape, tier, wtype):
-    return (f"{tier} ({shape.matrix_params() / 1e6:.0f}M matrix params) {wtype.upper()} GGUF, "
-            f"{PROMPT_LEN}-token prompt + {SEGMENT}-token greedy decode segments, 1 stream")
+def workload_text(shape, tier, wtype, r, steps):
+    """What the timed region ran: `steps` chained greedy decode steps as segments that each restart behind the prompt."""
+    seg = r["segment"]
+    nseg = (steps + seg - 1) // seg
+    return (f"{tier} ({shape.matrix_params() / 1e6:.0f}M matrix params) {wtype.upper()} GGUF, {PROMPT_LEN}-token prompt, then "
+            f"{steps} timed greedy decode steps = {nseg} segment{'s' if nseg > 1 else ''} of {seg} tokens at positions "
+            f"{r['pos_first']}..{r['pos_last']}, 1 stream")
 
 
 def summary(r, keys=("kernels",)):
     out = {"value": round(r["tok_s"], 2), "unit": "tokens/s", "ms_per_step": round(r["ms_per_step"], 5),
            "ms_per_step_min": round(r["ms_per_step_min"], 5), "ms_per_step_max": round(r["ms_per_step_max"], 5),
-           "hbm_frac_whole_step": round(r["hbm_frac_whole_step"], 4), "roofline": r["roofline"]}
+           "hbm_frac_whole_step": round(r["hbm_frac_whole_step"], 4), "roofline": r["roofline"],
+           "roofline_by_bytes": r["roofline_by_bytes"]}
     for k in keys:
         out[k] = r[k]
     return out
@@ -355,7 +373,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the side measurements")
     ap.add_argument("--comm", default=None, choices=("p2p", "rccl"), help="N > 1: force the all-reduce transport")
     ap.add_argument("--rccl-worker", default=None, help=argparse.SUPPRESS)
-    ap.add_argument("--profile-pos", type=int, default=PROMPT_LEN + SEGMENT // 2)
+    ap.add_argument("--profile-pos", type=int, default=None, help="position of the per-launch profile (default: the mean timed position)")
     args = ap.parse_args()
     n = args.gpus
     if n < 1:
@@ -410,7 +428,7 @@ def main():
         out = dict(common, metric=f"decode tokens/sec, {tier} {wtype.upper()} single-stream greedy"
                    + (f", tensor-parallel over {world} GPUs" if world > 1 else ""),
                    scaling="strong" if world > 1 else "weak",
-                   config={"workload": workload_text(shape, tier, wtype), "parallelism": f"tp{world}" if world > 1 else "single-gpu",
+                   config={"workload": workload_text(shape, tier, wtype, r, args.steps), "parallelism": f"tp{world}" if world > 1 else "single-gpu",
                            "allreduce": (args.comm or "p2p") if world > 1 else None},
                    device_ms_per_step=round(r["device_ms_per_step"], 5), algorithmic_bytes_per_step=r["step_bytes"],
                    last_ids=r["last_ids"], **summary(r))
@@ -424,7 +442,7 @@ def main():
         shape = synth.TIERS[tier]
         r = run_workload(tier, wtype, rdv, args.steps, args.warmup, args.profile_pos, model, tp=False)
         out = dict(common, metric=f"decode tokens/sec, {tier} {wtype.upper()} single-stream greedy", scaling="weak",
-                   config={"workload": workload_text(shape, tier, wtype) + " per GPU", "parallelism": "single-gpu",
+                   config={"workload": workload_text(shape, tier, wtype, r, args.steps) + " per GPU", "parallelism": "single-gpu",
                            "weights": f"{wtype} blocks dequantised in-register, f32 activations and KV cache"},
                    device_ms_per_step=round(r["device_ms_per_step"], 5), algorithmic_bytes_per_step=r["step_bytes"],
                    last_ids=r["last_ids"], **summary(r))
@@ -434,7 +452,10 @@ def main():
             # BASELINE.json's metric also names big Q4_0 @ 1 GPU: the 1-GPU point of the tensor-parallel curve
             try:
                 b = run_workload("big", "q4_0", rdv, 96, 16, args.profile_pos, model)
-                out["secondary"] = dict(workload="big (7.9B) Q4_0 single-stream greedy decode, 1 GPU", **summary(b))
+                out["secondary"] = dict(workload=workload_text(synth.TIERS["big"], "big", "q4_0", b, 96) + ", 1 GPU", **summary(b))
+                if not args.no_cpu_baseline:
+                    # north_star tabulates both tiers next to the CPU engine; SURVEY 8(d) allows a shortened run for big
+                    out["secondary"]["cpu_baseline"] = cpu_baseline(b["path"], b["prompt"], budget_s=12.0, min_tokens=4, max_tokens=16)
             except Exception as exc:  # the headline result must survive a failure of the side measurement
                 out["secondary"] = {"error": repr(exc)}
             try:
@@ -506,7 +527,7 @@ def main():
             raise SystemExit(1)
         out = dict(common, metric=f"decode tokens/sec, big Q4_0 single-stream greedy, tensor-parallel over {n} GPUs",
                    scaling="strong",
-                   config={"workload": workload_text(shape, "big", "q4_0"), "parallelism": f"tp{n}", "allreduce": transport,
+                   config={"workload": workload_text(shape, "big", "q4_0", tp_res, args.steps), "parallelism": f"tp{n}", "allreduce": transport,
                            "weights": "q4_0 blocks dequantised in-register, f32 activations and KV cache, rows/columns sharded per rank"},
                    algorithmic_bytes_per_step=tp_res["step_bytes"], last_ids=tp_res["last_ids"],
                    **summary(tp_res))

@@ -10,7 +10,8 @@
 //     recomputed by every head of the group: the work is latency, not bytes) -> bias, RoPE -> the members exchange
 //     their 3 x 16 values through 8-byte {tag, value} granules (the only cross-workgroup step: 192 values per head,
 //     cdna_hip_programming.md G16 form R2; cluster members are the blocks b, b+8, b+16, b+24, which the dispatcher
-//     places on one XCD) -> QK-norm -> KV store (first head of the group) -> every member runs the head's softmax
+//     happens to place on one XCD -- observed, used for speed only, never relied on) -> QK-norm -> KV store (first
+//     head of the group) -> every member runs the head's softmax
 //     attention over the cache (the cache rows come from L2) -> each member multiplies ITS quarter of the head's
 //     64-column WO slice, a partial [D/4] vector.
 // The H partial vectors are added to the residual stream by the consuming gate/up GEMV (PRO_NORM_PARTS, fixed head
@@ -52,8 +53,10 @@ struct BlockParams {
     unsigned long long *xchg;    // [H][192] granules: the head's q | k | v of this position
     const unsigned *tick;        // forward counter (advanced by the embedding launch): tag = tick << 8 | layer + 1
     unsigned layer_tag;
-    unsigned *status;            // set non-zero if an exchange poll gave up (never expected: members are co-resident)
+    unsigned *status;            // set non-zero if an exchange poll gave up: HIP promises nothing about co-residence, so the
+                                 // host then redoes the step on the general plan and retires the fused one (nl_engine.hip)
     unsigned *host_status;       // the same flag in host-visible memory (read by the host without a copy)
+    int spin_limit;              // polls before a wavefront gives up (NL_FUSED_SPIN_LIMIT; a test forces 0)
     long long *dbg;              // optional phase stamps (wall_clock64, 100 MHz... s_memtime shader clock) of block 0
 };
 
@@ -70,6 +73,7 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     NL_KARGS8(P.ctl, P.parts, P.parts_in, P.x_out, P.xchg, P.tick, P.rope_cos, P.rope_sin);
     NL_KARGS8(P.D, P.npairs, P.n_q_heads, P.n_kv_heads, P.seq_len, P.nparts_in, P.layer_tag, P.single_stream);
     NL_KARGS8(P.dbg, P.host_status, P.status, P.bias_q, P.bias_out, P.eps, P.scale, P.kv_stream_stride);
+    NL_KARGS2(P.spin_limit, P.gqa);
     const int h = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7), jm = (blockIdx.x >> 3) & 3;
     if (h >= P.n_q_heads) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -238,7 +242,7 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
         for (int spins = 0;; spins++) {
             gq = __hip_atomic_load(P.xchg + (size_t)h * 192 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all((unsigned)(gq >> 32) == tag)) break;
-            if (dead || spins > 400000) { if (lane == 0) { atomicOr(P.status, 4u); *P.host_status = 4u; } break; }
+            if (dead || spins >= P.spin_limit) { if (lane == 0) { atomicOr(P.status, 4u); *P.host_status = 4u; } break; }
             __builtin_amdgcn_s_sleep(1);
         }
         qs[tid] = __uint_as_float((unsigned)gq);   // qs | kcur | vcur are contiguous
@@ -367,7 +371,7 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
 // ====================================================================================================================
 // The feed-forward half of a layer (go/model.go:597-612) as ONE launch, same idea: gate / up and down are all-to-all
 // over the hidden width I only because down reads every h.  Cut I into slices of 256 columns: a cluster of eight
-// workgroups (blocks b, b+8, ..., b+56: one XCD) owns a slice -- each member projects 32 gate and 32 up rows of it
+// workgroups (blocks b, b+8, ..., b+56: one XCD as observed, for speed only) owns a slice -- each member projects 32 gate and 32 up rows of it
 // (four 16-row tiles x up to four 256-column groups = 16 wavefronts), applies SiLU(gate) * up, the members exchange
 // their 32 values of h through tagged granules (256 per cluster), and each member multiplies its eighth of the rows of
 // W_down restricted to the slice's 256 columns (a second packed copy of W_down, sliced by column) -- a partial [D / 8]
@@ -396,6 +400,7 @@ struct FfnParams {
     const unsigned *tick;
     unsigned layer_tag;
     unsigned *status, *host_status;
+    int spin_limit;                  // polls before a wavefront gives up (see BlockParams)
     long long *dbg;                  // optional phase stamps of block 0 (nl_debug_stamps)
 };
 
@@ -410,7 +415,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_block_kernel(FfnParams P) {
     NL_KARGS8(P.gate_q, P.up_q, P.gate_s, P.up_s, P.dn_q, P.dn_s, P.x, P.normw);
     NL_KARGS8(P.parts_in, P.x_out, P.parts_out, P.xchg, P.tick, P.status, P.D, P.I);
     NL_KARGS4(P.npairs, P.nparts_in, P.layer_tag, P.eps);
-    NL_KARGS2(P.dbg, P.host_status);
+    NL_KARGS4(P.dbg, P.host_status, P.spin_limit, P.nparts_in);
     const int cl = (blockIdx.x >> 6) * 8 + (blockIdx.x & 7), mem = (blockIdx.x >> 3) & 7;
     if (cl * FFN_SLICE >= P.I) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -525,7 +530,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_block_kernel(FfnParams P) {
         for (int spins = 0;; spins++) {
             gq = __hip_atomic_load(P.xchg + (size_t)cl * FFN_SLICE + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all((unsigned)(gq >> 32) == tag)) break;
-            if (dead || spins > 400000) { if (lane == 0) { atomicOr(P.status, 16u); *P.host_status = 16u; } break; }
+            if (dead || spins >= P.spin_limit) { if (lane == 0) { atomicOr(P.status, 16u); *P.host_status = 16u; } break; }
             __builtin_amdgcn_s_sleep(1);
         }
         hs[(tid >> 6) * XS_PAIR + (tid & 63)] = __uint_as_float((unsigned)gq);

@@ -189,6 +189,7 @@ struct nl_engine {
     // on-device sampling (nl_sample_decode): scratch for one vocabulary, allocated on first use
     SampScratch sp;
     bool sp_ready = false;
+    float *samp_keep = nullptr;   // logits as nl_sample_decode found them (restart point of a redo on the general plan)
     int sp_uniforms_cap = 0;
 
     // A launch plan with its captured graphs.  ps[0]: five launches per layer, any context length.  ps[1] (small
@@ -212,6 +213,9 @@ struct nl_engine {
     unsigned *tick = nullptr;     // {forward counter, status} device words of the fused block
     long long *dbg_block = nullptr;
     unsigned *h_status = nullptr; // pinned, device-visible: non-zero after an in-kernel exchange gave up
+    int spin_limit = 400000;      // polls before a cluster exchange gives up (NL_FUSED_SPIN_LIMIT)
+    int num_cus = 256;            // compute units of the device: a fused launch must fit on them all at once
+    bool fused_retired = false;   // an exchange timed out once: the handle stays on the general plan
     int graph_steps = 1;
     EmbedParams plan_embed{};    // kept for the fused argmax + embed launch of the multi-step graph
     ArgmaxParams plan_argmax{};
@@ -510,7 +514,7 @@ BlockParams attn_block_params(nl_engine *e, int l, const float *x_in) {
     B.kcache = e->kcache + (long long)l * e->kv_layer_stride; B.vcache = e->vcache + (long long)l * e->kv_layer_stride;
     B.kv_stream_stride = e->kv_stream_stride; B.ctl = e->ctl;
     B.bias_q = L.bq; B.bias_k = L.bk; B.bias_v = L.bv; B.bias_out = L.bo; B.parts = e->parts;
-    B.xchg = e->xchg; B.tick = e->tick; B.layer_tag = (unsigned)(l + 1); B.status = e->tick + 1; B.host_status = e->h_status;
+    B.xchg = e->xchg; B.tick = e->tick; B.layer_tag = (unsigned)(l + 1); B.status = e->tick + 1; B.host_status = e->h_status; B.spin_limit = e->spin_limit;
     return B;
 }
 
@@ -560,7 +564,7 @@ void build_plan_blocks(nl_engine *e, std::vector<Op> &plan) {
             F.D = c.dim; F.I = e->Is; F.npairs = L.gate.npairs;
             F.x = e->x[0]; F.normw = L.ffn_norm; F.parts_in = e->parts; F.nparts_in = e->Hs; F.x_out = e->x[1]; F.eps = c.rms_eps;
             F.parts_out = e->parts_ffn; F.xchg = e->xchg_ffn; F.tick = e->tick; F.layer_tag = (unsigned)(l + 1);
-            F.status = e->tick + 1; F.host_status = e->h_status;
+            F.status = e->tick + 1; F.host_status = e->h_status; F.spin_limit = e->spin_limit;
             const int wt = L.gate.wtype, grid = ffn_grid(nslices);
             plan.push_back({K_FFNBLOCK, 0, nullptr, 0, [F, wt, grid, e](hipStream_t st) mutable {
                                    F.dbg = e->dbg_block;      // nl_debug_stamps only
@@ -665,7 +669,7 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
             B.bias_q = L.bq; B.bias_k = L.bk; B.bias_v = L.bv;
             B.part_o = e->part_o; B.part_ml = e->part_ml; B.nsplit_max = e->nsplit_max;
             B.xchg = e->xchg; B.tick = p2p ? e->p2p.epoch : e->tick; B.layer_tag = (unsigned)(l + 1);
-            B.status = e->tick + 1; B.host_status = e->h_status;
+            B.status = e->tick + 1; B.host_status = e->h_status; B.spin_limit = e->spin_limit;
             const int wt = L.qkv.wtype, grid = grp_grid(e->KVs, B.members);
             const int ngroups = (L.qkv.npairs + KL - 1) / KL, nf = (ngroups + 16 / e->grp_tpm - 1) / (16 / e->grp_tpm);
             plan.push_back({K_ATTNBLOCK, 0, nullptr, 0, [B, wt, grid, nf](hipStream_t st) {
@@ -946,13 +950,32 @@ int note_positions(nl_engine *e, int stream, int pos, int n, hipStream_t st = nu
 
 // after a synchronize: did any poll of the push all-reduce give up?
 int p2p_check(nl_engine *e) {
-    if (e->h_status && *e->h_status)
-        return e->fail(NL_ERR_HIP, "fused attention block: a cluster exchange timed out (status %u)", *e->h_status);
     if (!e->p2p.on) return NL_OK;
     unsigned st = 0;
     HIPCK(e, hipMemcpy(&st, e->p2p.status, sizeof st, hipMemcpyDeviceToHost));
     if (st) return e->fail(NL_ERR_COMM, "push all-reduce timed out waiting for a peer (status %u): a rank is missing or stalled", st);
     return NL_OK;
+}
+
+// After a synchronize: did a cluster exchange of a fused launch (nl_block.h, nl_group.h) give up?  HIP promises nothing
+// about which workgroups of a launch are resident together, so on a GPU shared with another tenant a member can wait
+// for a peer that has not been dispatched.  Forward cannot fail in the reference (go/model.go:490): the flag is
+// cleared, the fused plan is retired for this handle, and the caller redoes its whole call on the general plan (every
+// buffer a step writes -- residual stream, K/V rows of its positions, logits, ids -- is rewritten by the redo).
+// nl_last_error carries a one-time note while the call returns NL_OK.
+bool take_fused_timeout(nl_engine *e) {
+    if (!e->h_status || !*e->h_status) return false;
+    const unsigned st = *e->h_status;
+    *e->h_status = 0;
+    (void)hipMemsetAsync(e->tick + 1, 0, sizeof(unsigned), e->stream);
+    (void)hipStreamSynchronize(e->stream);
+    e->fused = false;
+    e->fused_retired = true;
+    destroy_samp_graphs(e);
+    e->fail(NL_OK, "warning: a fused-launch cluster exchange timed out (status %u); the step was redone on the general plan, "
+                   "which this handle keeps from now on", st);
+    if (!getenv("NL_QUIET")) fprintf(stderr, "[nanollama_hip] %s\n", e->err.c_str());
+    return true;
 }
 
 struct Slot { int layer; std::string field; };
@@ -1673,6 +1696,11 @@ int nl_finalize(nl_handle e) {
     {
         // fused attention block (nl_block.h): every layer must have its per-head WO slices, and the models it pays
         // for are the ones whose per-head weights are small (see the header of nl_block.h)
+        {
+            hipDeviceProp_t prop{};
+            if (hipGetDeviceProperties(&prop, e->dev) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
+            if (const char *sl = getenv("NL_FUSED_SPIN_LIMIT")) e->spin_limit = atoi(sl);   // knob (tests): 0 makes every exchange give up
+        }
         const char *fa = getenv("NL_FUSED_ATTN");          // knob (tests, tools): 0 keeps the five-launch plan only, 2 forces mode 2
         const int want = fa ? atoi(fa) : -1;
         const bool base_ok = !(c.flags & NL_FLAG_LOCAL_GROUP) && want != 0 && e->hd == 64;
@@ -1687,10 +1715,14 @@ int nl_finalize(nl_handle e) {
             // tiles per workgroup: as few as keeps every workgroup of the launch resident at once (one per compute unit)
             const int NT = (e->gqa + 2) * 4, ngroups = ((c.dim + PAIR - 1) / PAIR + KL - 1) / KL;
             int tpm = 1;
-            while (tpm <= 4 && e->KVs * NT / tpm > 224) tpm *= 2;
+            const int cu_budget = e->num_cus - e->num_cus / 8;   // every workgroup of the launch resident at once, with a margin
+            while (tpm <= 4 && e->KVs * NT / tpm > cu_budget) tpm *= 2;
             ok2 = tpm <= 4 && NT % tpm == 0 && NT / tpm >= e->gqa && ngroups <= 2 * (16 / tpm);
             e->grp_tpm = tpm;
         }
+        // mode 1 launches one 768-thread workgroup per (head, member) and one per (slice, member): they only make progress
+        // together, so both grids must fit on the device's compute units at once
+        if (ok1 && (blk_grid(e->Hs) > e->num_cus || ffn_grid(e->Is / FFN_SLICE) > e->num_cus)) ok1 = false;
         e->fused_mode = ok1 ? 1 : ok2 ? 2 : 0;
         e->fused = e->fused_mode != 0;
         const char *fm = getenv("NL_FUSED_MAX_POS");
@@ -1801,14 +1833,14 @@ int nl_destroy(nl_handle e) {
         if (b.h_meta) hipHostFree(b.h_meta);
     }
     if (e->p2p.area) {
-        e->logits = nullptr;   // lives inside the receive area
+        if (e->p2p.on) e->logits = nullptr;   // lives inside the receive area (an export that was never imported allocated its own)
         for (int r = 0; r < 8; r++)
             if (e->p2p.opened[r]) (void)hipIpcCloseMemHandle(e->p2p.peer[r]);
         (void)hipFree(e->p2p.area);
         if (e->p2p.epoch) (void)hipFree(e->p2p.epoch);
     }
     void *bufs[] = {e->embd_raw, e->output_norm, e->rope_cos, e->rope_sin, e->x[0], e->x[1], e->qbuf, e->part_o,
-                    e->part_ml, e->hb, e->ar, e->parts, e->xchg, e->tick, e->parts_ffn, e->xchg_ffn, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result, e->amax_val,
+                    e->part_ml, e->hb, e->ar, e->parts, e->xchg, e->tick, e->parts_ffn, e->xchg_ffn, e->samp_keep, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result, e->amax_val,
                     e->amax_idx};
     for (void *b : bufs) if (b) hipFree(b);
     if (e->h_ctl) hipHostFree(e->h_ctl);
@@ -1837,12 +1869,16 @@ int nl_forward(nl_handle e, int stream, int token, int pos, float *logits_out) {
     int rc = check_step_args(e, stream, token, pos);
     if (rc) return rc;
     HIPCK(e, hipSetDevice(e->dev));
-    if ((rc = note_positions(e, stream, pos, 1))) return rc;
-    if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
-    if ((rc = launch_step(e, pos))) return rc;
-    if (logits_out)
-        HIPCK(e, hipMemcpyAsync(logits_out, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCK(e, hipStreamSynchronize(e->stream));
+    for (int attempt = 0;; attempt++) {
+        if ((rc = note_positions(e, stream, pos, 1))) return rc;
+        if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
+        if ((rc = launch_step(e, pos))) return rc;
+        if (logits_out)
+            HIPCK(e, hipMemcpyAsync(logits_out, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCK(e, hipStreamSynchronize(e->stream));
+        if (attempt == 0 && take_fused_timeout(e)) continue;   // redo on the general plan
+        break;
+    }
     if (int prc = p2p_check(e)) return prc;
     return NL_OK;
 }
@@ -1852,11 +1888,15 @@ int nl_forward_argmax(nl_handle e, int stream, int token, int pos, int *next_id)
     int rc = check_step_args(e, stream, token, pos);
     if (rc) return rc;
     HIPCK(e, hipSetDevice(e->dev));
-    if ((rc = note_positions(e, stream, pos, 1))) return rc;
-    if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
-    if ((rc = launch_step(e, pos))) return rc;
-    HIPCK(e, hipMemcpyAsync(next_id, e->result, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIPCK(e, hipStreamSynchronize(e->stream));
+    for (int attempt = 0;; attempt++) {
+        if ((rc = note_positions(e, stream, pos, 1))) return rc;
+        if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
+        if ((rc = launch_step(e, pos))) return rc;
+        HIPCK(e, hipMemcpyAsync(next_id, e->result, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCK(e, hipStreamSynchronize(e->stream));
+        if (attempt == 0 && take_fused_timeout(e)) continue;   // redo on the general plan
+        break;
+    }
     if (int prc = p2p_check(e)) return prc;
     return NL_OK;
 }
@@ -1868,18 +1908,22 @@ int nl_decode_greedy(nl_handle e, int stream, int token, int pos, int n_steps, i
     HIPCK(e, hipSetDevice(e->dev));
     int n = std::min(n_steps, e->cfg.seq_len - pos);
     n = std::min(n, e->ids_cap);
-    if ((rc = note_positions(e, stream, pos, n))) return rc;
-    if ((rc = set_ctl(e, token, pos, 1, stream))) return rc;
-    int i = 0;
-    for (; i + e->graph_steps <= n && e->graph_steps > 1; i += e->graph_steps) {
-        nl_engine::PlanSet &S = pick_plan(e, pos + i + e->graph_steps - 1);   // highest position of these steps
-        if (!S.multi_exec) break;
-        HIPCK(e, hipGraphLaunch(S.multi_exec, e->stream));
+    for (int attempt = 0;; attempt++) {
+        if ((rc = note_positions(e, stream, pos, n))) return rc;
+        if ((rc = set_ctl(e, token, pos, 1, stream))) return rc;
+        int i = 0;
+        for (; i + e->graph_steps <= n && e->graph_steps > 1; i += e->graph_steps) {
+            nl_engine::PlanSet &S = pick_plan(e, pos + i + e->graph_steps - 1);   // highest position of these steps
+            if (!S.multi_exec) break;
+            HIPCK(e, hipGraphLaunch(S.multi_exec, e->stream));
+        }
+        for (; i < n; i++)
+            if ((rc = launch_step(e, pos + i))) return rc;
+        if (n > 0) HIPCK(e, hipMemcpyAsync(ids_out, e->ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCK(e, hipStreamSynchronize(e->stream));
+        if (attempt == 0 && take_fused_timeout(e)) continue;   // the whole chain again, on the general plan
+        break;
     }
-    for (; i < n; i++)
-        if ((rc = launch_step(e, pos + i))) return rc;
-    if (n > 0) HIPCK(e, hipMemcpyAsync(ids_out, e->ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIPCK(e, hipStreamSynchronize(e->stream));
     if (int prc = p2p_check(e)) return prc;
     if (n_done) *n_done = n;
     return NL_OK;
@@ -1972,51 +2016,64 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
         HIPCK(e, samp_alloc(e->sp, e->cfg.vocab, e->sp_uniforms_cap));
         e->sp_ready = true;
     }
-    if ((rc = note_positions(e, stream, pos, n))) return rc;
     const SampScratch &s = e->sp;
-    // ctl: the select kernel writes token = sampled id and pos + 1; the forward that follows runs unchained
-    // (its argmax does not advance the state).  ctl.pos is primed to pos - 1 so the first increment lands on pos.
-    if ((rc = set_ctl(e, 0, pos - 1, 0, stream))) return rc;
-    HIPCK(e, hipMemcpyAsync(s.uniforms, uniforms, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
-    if (*n_recent > 0) HIPCK(e, hipMemcpyAsync(s.recent, recent, (size_t)*n_recent * 4, hipMemcpyHostToDevice, e->stream));
-    HIPCK(e, hipMemcpyAsync(s.recent_n, n_recent, 4, hipMemcpyHostToDevice, e->stream));
-    int i = 0;
-    while (e->ps[0].multi_exec && !e->samp_graph_failed && i + e->graph_steps <= n) {
-        // {sampler kernels, plan} x graph_steps as one graph per launch plan (its kernel arguments include the sampling
-        // parameters: re-captured when they change); the plan is chosen by the highest position of the 16 steps
-        const int k = (e->fused && pos + i + e->graph_steps - 1 < e->fused_max_pos) ? 1 : 0;
-        if (!e->samp_graph_exec[k] || memcmp(&e->samp_graph_params[k], p, sizeof(*p)) != 0) {
-            if (e->samp_graph_exec[k]) { hipGraphExecDestroy(e->samp_graph_exec[k]); e->samp_graph_exec[k] = nullptr; }
-            if (e->samp_graph[k]) { hipGraphDestroy(e->samp_graph[k]); e->samp_graph[k] = nullptr; }
-            hipError_t cs = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
-            int rc2 = NL_OK;
-            for (int q = 0; cs == hipSuccess && q < e->graph_steps && !rc2; q++) {
-                if (launch_sample(s, e->logits, e->cfg.vocab, *p, e->ctl, e->ids, e->stream) != hipSuccess) rc2 = NL_ERR_HIP;
-                else rc2 = run_plan_eager(e, e->ps[k]);
+    const int n_recent_in = *n_recent;
+    if (e->fused) {   // a redo after a fused-launch timeout restarts from the logits this call found (take_fused_timeout)
+        if (!e->samp_keep) HIPCK(e, dalloc(&e->samp_keep, (size_t)e->cfg.vocab, &e->bytes_state));
+        HIPCK(e, hipMemcpyAsync(e->samp_keep, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToDevice, e->stream));
+    }
+    for (int attempt = 0;; attempt++) {
+        if ((rc = note_positions(e, stream, pos, n))) return rc;
+        // ctl: the select kernel writes token = sampled id and pos + 1; the forward that follows runs unchained
+        // (its argmax does not advance the state).  ctl.pos is primed to pos - 1 so the first increment lands on pos.
+        if ((rc = set_ctl(e, 0, pos - 1, 0, stream))) return rc;
+        HIPCK(e, hipMemcpyAsync(s.uniforms, uniforms, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+        if (n_recent_in > 0) HIPCK(e, hipMemcpyAsync(s.recent, recent, (size_t)n_recent_in * 4, hipMemcpyHostToDevice, e->stream));
+        *n_recent = n_recent_in;
+        HIPCK(e, hipMemcpyAsync(s.recent_n, n_recent, 4, hipMemcpyHostToDevice, e->stream));
+        int i = 0;
+        while (e->ps[0].multi_exec && !e->samp_graph_failed && i + e->graph_steps <= n) {
+            // {sampler kernels, plan} x graph_steps as one graph per launch plan (its kernel arguments include the sampling
+            // parameters: re-captured when they change); the plan is chosen by the highest position of the 16 steps
+            const int k = (e->fused && pos + i + e->graph_steps - 1 < e->fused_max_pos) ? 1 : 0;
+            if (!e->samp_graph_exec[k] || memcmp(&e->samp_graph_params[k], p, sizeof(*p)) != 0) {
+                if (e->samp_graph_exec[k]) { hipGraphExecDestroy(e->samp_graph_exec[k]); e->samp_graph_exec[k] = nullptr; }
+                if (e->samp_graph[k]) { hipGraphDestroy(e->samp_graph[k]); e->samp_graph[k] = nullptr; }
+                hipError_t cs = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+                int rc2 = NL_OK;
+                for (int q = 0; cs == hipSuccess && q < e->graph_steps && !rc2; q++) {
+                    if (launch_sample(s, e->logits, e->cfg.vocab, *p, e->ctl, e->ids, e->stream) != hipSuccess) rc2 = NL_ERR_HIP;
+                    else rc2 = run_plan_eager(e, e->ps[k]);
+                }
+                hipGraph_t g = nullptr;
+                if (cs == hipSuccess) cs = hipStreamEndCapture(e->stream, &g);
+                if (cs == hipSuccess && !rc2 && g && hipGraphInstantiate(&e->samp_graph_exec[k], g, nullptr, nullptr, 0) == hipSuccess) {
+                    e->samp_graph[k] = g;
+                    e->samp_graph_params[k] = *p;
+                } else {
+                    if (g) hipGraphDestroy(g);
+                    (void)hipGetLastError();
+                    e->samp_graph_exec[k] = nullptr;
+                    e->samp_graph_failed = true;      // (e.g. a library call that cannot be captured): eager launches below
+                    break;
+                }
             }
-            hipGraph_t g = nullptr;
-            if (cs == hipSuccess) cs = hipStreamEndCapture(e->stream, &g);
-            if (cs == hipSuccess && !rc2 && g && hipGraphInstantiate(&e->samp_graph_exec[k], g, nullptr, nullptr, 0) == hipSuccess) {
-                e->samp_graph[k] = g;
-                e->samp_graph_params[k] = *p;
-            } else {
-                if (g) hipGraphDestroy(g);
-                (void)hipGetLastError();
-                e->samp_graph_exec[k] = nullptr;
-                e->samp_graph_failed = true;      // (e.g. a library call that cannot be captured): eager launches below
-                break;
-            }
+            HIPCK(e, hipGraphLaunch(e->samp_graph_exec[k], e->stream));
+            i += e->graph_steps;
         }
-        HIPCK(e, hipGraphLaunch(e->samp_graph_exec[k], e->stream));
-        i += e->graph_steps;
+        for (; i < n; i++) {
+            HIPCK(e, launch_sample(s, e->logits, e->cfg.vocab, *p, e->ctl, e->ids, e->stream));
+            if ((rc = launch_step(e, pos + i))) return rc;
+        }
+        HIPCK(e, hipMemcpyAsync(ids_out, e->ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCK(e, hipMemcpyAsync(n_recent, s.recent_n, 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCK(e, hipStreamSynchronize(e->stream));
+        if (attempt == 0 && take_fused_timeout(e)) {
+            HIPCK(e, hipMemcpyAsync(e->logits, e->samp_keep, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToDevice, e->stream));
+            continue;
+        }
+        break;
     }
-    for (; i < n; i++) {
-        HIPCK(e, launch_sample(s, e->logits, e->cfg.vocab, *p, e->ctl, e->ids, e->stream));
-        if ((rc = launch_step(e, pos + i))) return rc;
-    }
-    HIPCK(e, hipMemcpyAsync(ids_out, e->ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIPCK(e, hipMemcpyAsync(n_recent, s.recent_n, 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCK(e, hipStreamSynchronize(e->stream));
     if (int prc = p2p_check(e)) return prc;
     if (*n_recent > 0) HIPCK(e, hipMemcpy(recent, s.recent, (size_t)*n_recent * 4, hipMemcpyDeviceToHost));
     return NL_OK;
@@ -2088,11 +2145,16 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
             }
         }
     } else {
-        for (int i = 0; i < n; i++) {
-            int *c = e->h_ctl_ring + (size_t)i * CTL_WORDS;
-            c[CTL_TOKEN] = tokens[i]; c[CTL_POS] = pos0 + i; c[CTL_CHAIN] = 0; c[CTL_STEP] = 0; c[CTL_STREAM] = stream;
-            HIPCK(e, hipMemcpyAsync(e->ctl, c, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, e->stream));
-            if ((rc = launch_step(e, pos0 + i))) return rc;
+        for (int attempt = 0;; attempt++) {
+            for (int i = 0; i < n; i++) {
+                int *c = e->h_ctl_ring + (size_t)i * CTL_WORDS;
+                c[CTL_TOKEN] = tokens[i]; c[CTL_POS] = pos0 + i; c[CTL_CHAIN] = 0; c[CTL_STEP] = 0; c[CTL_STREAM] = stream;
+                HIPCK(e, hipMemcpyAsync(e->ctl, c, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, e->stream));
+                if ((rc = launch_step(e, pos0 + i))) return rc;
+            }
+            HIPCK(e, hipStreamSynchronize(e->stream));
+            if (attempt == 0 && take_fused_timeout(e)) continue;   // the prompt again, on the general plan
+            break;
         }
     }
     if (last_logits_out)
@@ -2136,17 +2198,21 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
         HIPCK(e, hipStreamSynchronize(e->stream));
         return NL_OK;
     }
-    for (int i = 0; i < n; i++) {
-        int *c = e->h_ctl_ring + (size_t)i * CTL_WORDS;
-        c[CTL_TOKEN] = tokens[i]; c[CTL_POS] = pos[i]; c[CTL_CHAIN] = 0; c[CTL_STEP] = 0; c[CTL_STREAM] = streams[i];
-        HIPCK(e, hipMemcpyAsync(e->ctl, c, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, e->stream));
-        if ((rc = launch_step(e, pos[i]))) return rc;
-        if (logits_out)
-            HIPCK(e, hipMemcpyAsync(logits_out + (size_t)i * e->cfg.vocab, e->logits, (size_t)e->cfg.vocab * 4,
-                                    hipMemcpyDeviceToHost, e->stream));
-        if (next_ids) HIPCK(e, hipMemcpyAsync(next_ids + i, e->result, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    for (int attempt = 0;; attempt++) {
+        for (int i = 0; i < n; i++) {
+            int *c = e->h_ctl_ring + (size_t)i * CTL_WORDS;
+            c[CTL_TOKEN] = tokens[i]; c[CTL_POS] = pos[i]; c[CTL_CHAIN] = 0; c[CTL_STEP] = 0; c[CTL_STREAM] = streams[i];
+            HIPCK(e, hipMemcpyAsync(e->ctl, c, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, e->stream));
+            if ((rc = launch_step(e, pos[i]))) return rc;
+            if (logits_out)
+                HIPCK(e, hipMemcpyAsync(logits_out + (size_t)i * e->cfg.vocab, e->logits, (size_t)e->cfg.vocab * 4,
+                                        hipMemcpyDeviceToHost, e->stream));
+            if (next_ids) HIPCK(e, hipMemcpyAsync(next_ids + i, e->result, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        }
+        HIPCK(e, hipStreamSynchronize(e->stream));
+        if (attempt == 0 && take_fused_timeout(e)) continue;   // every stream's step again, on the general plan
+        break;
     }
-    HIPCK(e, hipStreamSynchronize(e->stream));
     return NL_OK;
 }
 
@@ -2186,9 +2252,15 @@ int nl_profile_forward(nl_handle e, int stream, int token, int pos, int iters, f
     for (int k = 0; k < NL_NUM_KINDS; k++) { ms_out[k] = 0.f; calls_out[k] = 0; }
     if ((rc = note_positions(e, stream, pos, 1))) return rc;
     if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
-    const nl_engine::PlanSet &S = pick_plan(e, pos);   // the plan a step at this position runs
-    if ((rc = run_plan_eager(e, S))) return rc;
+    const nl_engine::PlanSet *Sp = &pick_plan(e, pos);   // the plan a step at this position runs
+    if ((rc = run_plan_eager(e, *Sp))) return rc;
     HIPCK(e, hipStreamSynchronize(e->stream));
+    if (take_fused_timeout(e)) {
+        Sp = &pick_plan(e, pos);
+        if ((rc = run_plan_eager(e, *Sp))) return rc;
+        HIPCK(e, hipStreamSynchronize(e->stream));
+    }
+    const nl_engine::PlanSet &S = *Sp;
     for (const Op &op : S.ops) {
         HIPCK(e, hipEventRecord(e->ev0, e->stream));
         for (int it = 0; it < iters; it++) {
@@ -2499,10 +2571,20 @@ int nl_p2p_export(nl_handle e, void *handle_out) {
         p.off_amax = (ar + 255) & ~(size_t)255;
         p.off_logits = (p.off_amax + (size_t)e->G * 2 * sizeof(u64) + 255) & ~(size_t)255;
         p.bytes = p.off_logits + (size_t)e->cfg.vocab * 4;
-        // written by the peers while this device reads it: uncached, so no L2 line of this device can shadow a push
-        hipError_t s = getenv("NL_P2P_CACHED") ? hipErrorNotSupported : hipExtMallocWithFlags(&p.area, p.bytes, hipDeviceMallocUncached);
-        p.uncached = s == hipSuccess;
-        if (s != hipSuccess) { (void)hipGetLastError(); HIPCK(e, hipMalloc(&p.area, p.bytes)); }
+        // Written by the peers while this device reads it: the area must be UNCACHED, so that no L2 line of this device
+        // can shadow a push (remote xGMI writes do not probe the local L2).  The tagged granules would survive a cached
+        // area -- their polls time out -- but the logits all-gather stores plain floats: a stale line would be read
+        // silently.  So there is no cached fallback: without an uncached, exportable allocation the push path is
+        // refused and the caller (bench.py, load_llama_model) falls back to RCCL.  NL_P2P_CACHED=1 is a test knob for
+        // ranks that share ONE device (one L2, nothing to shadow); it is rejected across devices at import.
+        const bool test_cached = getenv("NL_P2P_CACHED") != nullptr;
+        hipError_t s = test_cached ? hipMalloc(&p.area, p.bytes) : hipExtMallocWithFlags(&p.area, p.bytes, hipDeviceMallocUncached);
+        if (s != hipSuccess) {
+            (void)hipGetLastError();
+            p.area = nullptr;
+            return e->fail(NL_ERR_UNSUPPORTED, "push all-reduce needs an uncached receive area (hipExtMallocWithFlags: %s); use RCCL", hipGetErrorString(s));
+        }
+        p.uncached = !test_cached;
         HIPCK(e, hipMemset(p.area, 0, p.bytes));
         HIPCK(e, hipMalloc((void **)&p.epoch, 2 * sizeof(unsigned)));
         HIPCK(e, hipMemset(p.epoch, 0, 2 * sizeof(unsigned)));
@@ -2513,16 +2595,10 @@ int nl_p2p_export(nl_handle e, void *handle_out) {
     }
     hipIpcMemHandle_t h;
     hipError_t s = hipIpcGetMemHandle(&h, p.area);
-    if (s != hipSuccess && p.uncached) {
-        // this runtime cannot export an uncached allocation: fall back to a plain one
+    if (s != hipSuccess) {
         (void)hipGetLastError();
-        (void)hipFree(p.area);
-        p.area = nullptr; p.uncached = false;
-        HIPCK(e, hipMalloc(&p.area, p.bytes));
-        HIPCK(e, hipMemset(p.area, 0, p.bytes));
-        s = hipIpcGetMemHandle(&h, p.area);
+        return e->fail(NL_ERR_UNSUPPORTED, "push all-reduce: the uncached receive area cannot be exported (hipIpcGetMemHandle: %s); use RCCL", hipGetErrorString(s));
     }
-    if (s != hipSuccess) return e->fail(NL_ERR_COMM, "hipIpcGetMemHandle: %s", hipGetErrorString(s));
     static_assert(sizeof(hipIpcMemHandle_t) == NL_P2P_HANDLE_BYTES, "handle size");
     memcpy(handle_out, &h, NL_P2P_HANDLE_BYTES);
     return NL_OK;
@@ -2541,6 +2617,12 @@ int nl_p2p_import(nl_handle e, const void *handles) {
         hipError_t s = hipIpcOpenMemHandle(&p.peer[r], h, hipIpcMemLazyEnablePeerAccess);
         if (s != hipSuccess) return e->fail(NL_ERR_COMM, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(s));
         p.opened[r] = true;
+        if (!p.uncached) {   // NL_P2P_CACHED test knob: only sound while every rank shares this device's L2
+            hipPointerAttribute_t at{};
+            if (hipPointerGetAttributes(&at, p.peer[r]) == hipSuccess && at.device != e->dev)
+                return e->fail(NL_ERR_UNSUPPORTED, "NL_P2P_CACHED is a one-device test knob: rank %d lives on device %d", r, at.device);
+            (void)hipGetLastError();
+        }
     }
     p.on = true;
     return NL_OK;

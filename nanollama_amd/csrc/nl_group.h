@@ -3,7 +3,7 @@
 // go/model.go:517-587.  A head's weights are far too many bytes for a few compute units here (7.9B tier: 885 KB per
 // kv group), so the projection keeps its chip-wide spread -- one or two 16-row tiles per workgroup, 16 wavefronts
 // splitting the columns -- and only the tiny attention step is pulled in: the workgroups that hold the tiles of one kv
-// group form a cluster (blocks with equal index mod 8: one XCD), publish their rows as 8-byte {tag, value} granules
+// group form a cluster (blocks with equal index mod 8: one XCD as observed -- speed only; a poll that gives up makes the host redo the step on the general plan), publish their rows as 8-byte {tag, value} granules
 // (cdna_hip_programming.md G16 form R2), and G of them -- one per query head of the group -- gather q, k, v and run the
 // softmax attention, writing the same (max, sum, sum p*v) partials the stand-alone attention launch writes; the WO
 // GEMV's prologue consumes them unchanged.  This removes one of the five dependent launches per layer (~6.5 us of pure
@@ -36,12 +36,13 @@ struct GroupParams {
     const unsigned *tick;
     unsigned layer_tag;
     unsigned *status, *host_status;
+    int spin_limit;              // polls before a wavefront gives up (see BlockParams, nl_block.h)
 };
 
 __host__ __device__ constexpr size_t grp_lds_bytes() {
     return sizeof(float) * (size_t)(16 * XS_WAVE + 16 * TR + 3 * 64 + 8 + ATT_CH + 32 * 64) + 16 * sizeof(double);
 }
-// block b: cluster (b / (8 * members)) * 8 + b % 8, member (b / 8) % members  (cluster members share b % 8, i.e. an XCD)
+// block b: cluster (b / (8 * members)) * 8 + b % 8, member (b / 8) % members  (cluster members share b % 8: an XCD as observed, not a contract)
 inline int grp_grid(int clusters, int members) { return ((clusters + 7) / 8) * members * 8; }
 
 template <int WT, int NF>
@@ -51,6 +52,7 @@ __global__ void __launch_bounds__(GRP_THREADS) qkv_attn_kernel(GroupParams P) {
     NL_KARGS8(P.ctl, P.bias_q, P.part_o, P.part_ml, P.xchg, P.tick, P.status, P.host_status);
     NL_KARGS8(P.D, P.npairs, P.n_q_heads, P.n_kv_heads, P.seq_len, P.single_stream, P.tpm, P.members);
     NL_KARGS8(P.eps, P.scale, P.kv_stream_stride, P.nsplit_max, P.layer_tag, P.rope_conj, P.qk_norm, P.bias_k);
+    NL_KARGS2(P.spin_limit, P.gqa);
     const int M = P.members;
     const int b8 = (int)(blockIdx.x >> 3);
     const int cl = (int)udiv_by(blockIdx.x, 8u * (unsigned)M, P.m8_inv) * 8 + (blockIdx.x & 7), mem = b8 - (int)udiv_by((unsigned)b8, (unsigned)M, P.m_inv) * M;
@@ -186,7 +188,7 @@ __global__ void __launch_bounds__(GRP_THREADS) qkv_attn_kernel(GroupParams P) {
         for (int spins = 0;; spins++) {
             gq = __hip_atomic_load(P.xchg + (size_t)cl * gvec + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all((unsigned)(gq >> 32) == tag)) break;
-            if (dead || spins > 400000) { if (lane == 0) { atomicOr(P.status, 8u); *P.host_status = 8u; } break; }
+            if (dead || spins >= P.spin_limit) { if (lane == 0) { atomicOr(P.status, 8u); *P.host_status = 8u; } break; }
             __builtin_amdgcn_s_sleep(1);
         }
         qs[tid] = __uint_as_float((unsigned)gq);   // qs | kcur | vcur are contiguous

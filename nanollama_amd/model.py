@@ -161,6 +161,11 @@ class LlamaModel:
         _lib.check(self._h, _lib.lib().nl_p2p_info(self._h, C.byref(on), C.byref(unc)))
         return {"push_allreduce": bool(on.value), "uncached_receive_area": bool(unc.value)}
 
+    def last_error(self) -> str:
+        """nl_last_error: the message of the last failed call -- or the one-time note of a call that succeeded after
+        retiring the fused launch plan (a cluster exchange timed out and the step was redone on the general plan)."""
+        return (_lib.lib().nl_last_error(self._h) or b"").decode()
+
     def debug_read(self, which: str, n: int, stream: int = 0) -> np.ndarray:
         out = np.zeros(n, dtype=np.float32)
         got = _lib.lib().nl_debug_read(self._h, which.encode(), stream, out.ctypes.data_as(C.POINTER(C.c_float)), n)

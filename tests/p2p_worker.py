@@ -35,11 +35,19 @@ def main():
     again = dev.decode_greedy(first, n_tok, n_greedy)          # replay from the same prefix: identical
     dev.prefill(toks[:5])                                       # token-at-a-time plan under tensor parallelism
     pre = dev.state.logits.copy()
+    sampled = []
+    n_samp = int(os.environ.get("NL_P2P_SAMPLED", "0"))
+    if n_samp:
+        # the sampled loop reads the GATHERED logits on every rank (the LM-head slices the peers pushed): same uniforms,
+        # so every rank must pick the same ids -- a stale slice on one rank would show up here
+        us = np.random.default_rng(5).random(n_samp, dtype=np.float32)
+        sampled, _ = dev.sample_decode(5, n_samp, 0.8, 0.9, 50, 1.15, 16, us, [])
     rdv.barrier()
     if rdv.rank == 0:
-        np.savez(out, logits=np.stack(logits), ids=np.array(ids), again=np.array(again), pre=pre, toks=np.array(toks))
+        np.savez(out, logits=np.stack(logits), ids=np.array(ids), again=np.array(again), pre=pre, toks=np.array(toks),
+                 sampled=np.array(sampled, np.int32))
     # every rank must hold the same gathered logits and ids: compare through the star
-    mine = np.stack(logits).tobytes() + np.array(ids, np.int32).tobytes()
+    mine = np.stack(logits).tobytes() + np.array(ids, np.int32).tobytes() + np.array(sampled, np.int32).tobytes()
     parts = rdv.allgather_bytes(mine)
     assert all(p == parts[0] for p in parts), "ranks disagree on the gathered logits / greedy ids"
     dev.close()

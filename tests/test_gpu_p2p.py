@@ -17,12 +17,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 LOGIT_TOL = 1e-4
 
 
-def run_ranks(n, path, out, n_tok, n_greedy, extra_env=None, timeout=150):
+def run_ranks(n, path, out, n_tok, n_greedy, extra_env=None, timeout=150, one_device=True):
     port = 29000 + (os.getpid() * 11 + n * 37) % 2000
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), NL_BENCH_ONE_DEVICE="1", NL_P2P_TIMEOUT_MS="5000", **(extra_env or {}))
+                   MASTER_PORT=str(port), NL_P2P_TIMEOUT_MS="5000", **(extra_env or {}))
+        if one_device:
+            env["NL_BENCH_ONE_DEVICE"] = "1"
+        else:
+            env.pop("NL_BENCH_ONE_DEVICE", None)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), path, out, str(n_tok),
                                        str(n_greedy)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
@@ -83,13 +87,14 @@ def test_push_allreduce_with_4_and_8_ranks(tmp_path, n, dim, heads, kv, interm):
     synth.generate_gguf(p, shape, "q4_0", 51, mode="qrand")
     from nanollama_amd import model
     out = str(tmp_path / "r0.npz")
-    run_ranks(n, p, out, n_tok=6, n_greedy=20, timeout=240, extra_env={"NL_FUSED_ATTN": "0"})
+    run_ranks(n, p, out, n_tok=6, n_greedy=20, timeout=240, extra_env={"NL_FUSED_ATTN": "0", "NL_P2P_SAMPLED": "20"})
     got = np.load(out)
     g = gguf.load_gguf(p)
     grp = model.LocalTPGroup(g, n)
     for pos, t in enumerate(int(t) for t in got["toks"]):
         assert grp.forward(t, pos).tobytes() == got["logits"][pos].tobytes()
     assert got["ids"].tobytes() == got["again"].tobytes()
+    assert len(got["sampled"]) == 20     # sampled decode from the gathered logits: every rank picked the same ids (worker)
     # the same ranks with the fused projection + attention launch (nl_group.h) in their plans: summation order
     # differs from the five-launch plan, so this one is held to the logit tolerance and to identical greedy ids
     out2 = str(tmp_path / "r0_fused.npz")
@@ -97,6 +102,29 @@ def test_push_allreduce_with_4_and_8_ranks(tmp_path, n, dim, heads, kv, interm):
     fused = np.load(out2)
     assert np.abs(fused["logits"] - got["logits"]).max() <= LOGIT_TOL * max(1.0, float(got["logits"].std()))
     assert fused["ids"].tobytes() == got["ids"].tobytes() and fused["ids"].tobytes() == fused["again"].tobytes()
+    grp.close()
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_push_allreduce_across_devices(tmp_path, n):
+    # One rank per GPU: the only test in which a granule crosses xGMI.  Skipped on boxes with fewer devices (the
+    # 1-GPU test pool) -- until it has run green on a multi-GPU node the cross-device wire counts as UNVERIFIED
+    #  and bench.py keeps its 1-GPU logit / greedy-id self-check and the RCCL fallback.
+    from nanollama_amd import _lib, model
+    if _lib.lib().nl_device_count() < n:
+        pytest.skip(f"needs {n} devices")
+    shape = synth.ModelShape("p2p_xgmi_probe", 4, 1024, 16, 8, 8192, seq_len=96, interm=2048)
+    p = str(tmp_path / "m.gguf")
+    synth.generate_gguf(p, shape, "q4_0", 53, mode="qrand")
+    out = str(tmp_path / "r0.npz")
+    run_ranks(n, p, out, n_tok=8, n_greedy=48, timeout=300, extra_env={"NL_FUSED_ATTN": "0", "NL_P2P_SAMPLED": "24"}, one_device=False)
+    got = np.load(out)
+    g = gguf.load_gguf(p)
+    grp = model.LocalTPGroup(g, n)
+    for pos, t in enumerate(int(t) for t in got["toks"]):
+        assert grp.forward(t, pos).tobytes() == got["logits"][pos].tobytes(), f"pos {pos}: ranks != in-process group"
+    assert got["ids"].tobytes() == got["again"].tobytes()
+    assert len(got["sampled"]) == 24          # (the worker asserts that every rank sampled the same ids from the gathered logits)
     grp.close()
 
 

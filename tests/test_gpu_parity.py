@@ -8,12 +8,15 @@ Tolerances (stated once, used everywhere below):
   * greedy token ids: identical, on inputs whose top-1/top-2 margin is >> LOGIT_TOL
 """
 import os
+import sys
 from dataclasses import replace
 
 import numpy as np
 import pytest
 
 from nanollama_amd import gguf, synth
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -75,6 +78,53 @@ def test_gemv_edge_values(hip, orc):
         assert np.all(np.abs(got - want) <= 2e-5 * (1 + np.abs(want)))
         zero = hip.op_matmul(raw, t, np.zeros(cols, np.float32), rows, cols)
         assert np.all(zero == 0)
+
+
+def test_gemv_inf_and_nan_scales_follow_the_reference(hip, orc):
+    # go/gguf.go:603-636: the fp16 -> f32 table keeps inf and NaN, and MatMulQ8_0 / MatMulQ4_0 (go/quant.go:74-94,
+    # :149-165) multiply the block dot by that scale: a row with a +inf block is +inf, with +inf and -inf blocks NaN,
+    # with a NaN scale NaN, and 0 * inf (an all-zero x under an inf scale) NaN.  The special blocks hold only
+    # positive quants and x is positive, so the sign of each block dot does not depend on the summation order.
+    rows, cols = 32, 256
+    rng = np.random.Generator(np.random.PCG64(17))
+    x = (np.abs(rng.standard_normal(cols)) + 0.25).astype(np.float32)
+    special = {0: [(2, 0x7C00)], 1: [(2, 0xFC00)], 2: [(1, 0x7C00), (5, 0xFC00)], 3: [(7, 0x7E00)], 4: [(0, 0xFE01)],
+               5: [(3, 0x7C00), (4, 0x7C00)], 17: [(6, 0x7C00)], 31: [(0, 0xFC00), (7, 0x7E00)]}
+    for t, bsz in ((gguf.GGML_Q8_0, 34), (gguf.GGML_Q4_0, 18)):
+        raw = rng.integers(0, 256, size=(rows, cols // 32, bsz), dtype=np.uint8)
+        raw[:, :, 0:2] = np.frombuffer(np.float16(rng.uniform(0.01, 0.2, size=(rows, cols // 32))).tobytes(), np.uint8).reshape(rows, cols // 32, 2)
+        for r, blocks in special.items():
+            for b, bits in blocks:
+                raw[r, b, 0], raw[r, b, 1] = bits & 0xFF, bits >> 8
+                raw[r, b, 2:] = rng.integers(1, 128, size=bsz - 2) if t == gguf.GGML_Q8_0 else (rng.integers(9, 16, size=bsz - 2) * 17)
+        flat = raw.reshape(-1)
+        for xv in (x, np.where(np.arange(cols) // 32 == 2, 0, x).astype(np.float32)):   # second: block 2 of x all zero -> 0 * inf
+            want = orc.matmul(flat, t, xv, rows, cols)
+            assert np.isinf(want[0]) or np.isnan(want[0])
+            for got in (hip.op_matmul(flat, t, xv, rows, cols),
+                        hip.op_matmul_batch(flat, t, np.stack([xv, xv * 2, xv]), rows, cols)[0]):
+                assert np.array_equal(np.isnan(got), np.isnan(want)), (t, np.flatnonzero(np.isnan(got) != np.isnan(want)))
+                inf = np.isinf(want)
+                assert np.array_equal(got[inf], want[inf])                      # same infinities, same signs
+                fin = np.isfinite(want)
+                assert np.all(np.abs(got[fin] - want[fin]) <= 2e-5 * (1 + np.abs(want[fin])))
+
+
+@pytest.mark.parametrize("kind", ["q4_k", "q6_k"])
+def test_gemv_reproduces_the_hand_built_kquant_super_blocks(hip, kind):
+    # first-principles KAT (tests/kquant_kat.py; go/quant.go:171-396): exact binary fractions everywhere, so the device's
+    # dot products with one-hot and small-integer x are exact in any summation order
+    from test_oracle_kquants import _kat_matrix
+    t = gguf.GGML_Q4_K if kind == "q4_k" else gguf.GGML_Q6_K
+    raw, want = _kat_matrix(kind)
+    probes = [((np.arange(512) * 7) % 5 - 2).astype(np.float32), np.ones(512, np.float32)]
+    for k in (0, 1, 31, 32, 63, 64, 100, 127, 128, 191, 255, 256, 300, 511):
+        e = np.zeros(512, np.float32)
+        e[k] = 1.0
+        probes.append(e)
+    for x in probes:
+        exact = (want.astype(np.float64) @ x.astype(np.float64)).astype(np.float32)
+        assert np.array_equal(hip.op_matmul(raw, t, x, 2, 512), exact)
 
 
 def test_gemv_rejects_unsupported_type(hip):
@@ -791,6 +841,58 @@ def test_64_concurrent_streams_match_oracle(hip, orc, tmp_path):
     dev.close()
 
 
+def test_goldie_full_shape_64_streams_match_oracle(hip, orc, tmp_path):
+    # BASELINE.json configs[3] at its OWN shape: goldie (841M: 28 layers, D 1536, 24 heads / 6 kv heads -> G = 4,
+    # FFN 4096, vocabulary 48000) Q4_0 with 64 decode streams stepped together -- the batched GQA attention
+    # instantiation and the split-K GEMM grids bench.py's goldie line launches (go/model.go:510-612, one layer,
+    # batched).  Three streams are checked against their own oracle run: stream 5 at positions 0.., stream 40 a
+    # few positions in, stream 63 walking 122..129 -- steps 0-5 have every row below position 128 (one attention
+    # split, the attention kernel writes the WO fragments itself), steps 6-7 cross the 128-position split.
+    shape = synth.TIERS["goldie"]
+    p = os.path.join(os.environ.get("NL_BENCH_DIR", "/tmp"), "nl_bench_goldie_q4_0_qrand.gguf")   # bench.py's file when present
+    if not os.path.exists(p):
+        synth.generate_gguf(p + ".tmp", shape, "q4_0", mode="qrand")
+        os.replace(p + ".tmp", p)
+    g = gguf.load_gguf(p)
+    assert (g.meta.num_layers, g.meta.embed_dim, g.meta.num_heads, g.meta.num_kv_heads, g.meta.interm_size,
+            g.meta.vocab_size) == (28, 1536, 24, 6, 4096, 48000)
+    ns, nsteps = 64, 8
+    rng = np.random.Generator(np.random.PCG64(64))
+    start = [int(v) for v in rng.integers(0, 24, size=ns)]   # ragged: every stream at its own position
+    check = {5: 0, 40: 7, 63: 122}
+    for s, p0 in check.items():
+        start[s] = p0
+    seqs = [[int(t) for t in rng.integers(3, shape.vocab, size=start[s] + nsteps)] for s in range(ns)]
+    orc.set_threads(min(32, os.cpu_count() or 1))
+    wants = {}
+    for s in check:
+        ref = orc.OracleModel(g)
+        for pos, t in enumerate(seqs[s]):
+            lg = ref.forward(t, pos)
+            if pos >= start[s]:
+                wants[(s, pos - start[s])] = lg.copy()
+        ref.close()
+    orc.set_threads(1)
+    dev = hip.load_llama_model(g, max_streams=ns)
+    for s in range(ns):
+        if start[s]:
+            dev.prefill(seqs[s][:start[s]], stream=s, want_logits=False)
+    worst, scale = 0.0, 1.0
+    for k in range(nsteps):
+        ids, lg = dev.forward_batch(list(range(ns)), [seqs[s][start[s] + k] for s in range(ns)],
+                                    [start[s] + k for s in range(ns)], want_logits=True)
+        for s in check:
+            want = wants[(s, k)]
+            scale = max(scale, float(want.std()))
+            worst = max(worst, float(np.abs(lg[s] - want).max()))
+            top2 = np.partition(want, -2)[-2:]
+            if float(top2[1] - top2[0]) > 10 * LOGIT_TOL * scale:   # (a tie inside the tolerance may go either way)
+                assert ids[s] == int(orc.argmax(want)), (s, k)
+    print(f"\ngoldie x 64 streams: max|gpu-oracle|={worst:.2e} (logit std {scale:.2f})")
+    assert worst <= LOGIT_TOL * scale
+    dev.close()
+
+
 @pytest.mark.parametrize("wtype", ["q4_0", "q8_0", "f16"])
 @pytest.mark.parametrize("rows,cols,ntok", [(128, 256, 64), (576, 576, 5), (1536, 576, 64), (192, 768, 17),
                                              (100, 96, 3), (4096, 4096, 64), (2304, 1536, 130),
@@ -1059,6 +1161,83 @@ def test_fused_attention_block_matches_oracle(hip, orc, tmp_path, monkeypatch, w
         a, b = dev.debug_read(which, n).reshape(-1, shape.seq_len, 64), plain.debug_read(which, n).reshape(-1, shape.seq_len, 64)
         assert np.abs(a[:, :149] - b[:, :149]).max() <= 2e-5
     dev.close(); plain.close(); ref.close()
+
+
+@pytest.mark.parametrize("case", ["small_tier_blocks", "wide_tier_projection_attention"])
+def test_fused_plan_timeout_falls_back_to_the_general_plan(hip, orc, tmp_path, monkeypatch, case):
+    # HIP promises nothing about which workgroups of a launch are resident together; on a shared GPU a cluster member can
+    # wait for a peer that was never dispatched.  NL_FUSED_SPIN_LIMIT=0 makes every exchange poll give up at once: the
+    # call must still succeed (Forward cannot fail in the reference, go/model.go:490) with the oracle's logits -- the
+    # step is redone on the general plan -- the handle must stay on the general plan afterwards, and nl_last_error
+    # carries the one-time note.  Covered for every entry point that steps the plan.
+    if case == "small_tier_blocks":
+        shape = synth.ModelShape("fb_fallback", 3, 192, 3, 3, 1024, seq_len=96)
+    else:
+        shape = synth.ModelShape("fb_fallback_wide", 2, 2048, 32, 8, 1024, seq_len=96, interm=1024)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", 67, mode="qrand" if case != "small_tier_blocks" else "float")
+    g = gguf.load_gguf(str(p))
+    ref = orc.OracleModel(g)
+    toks = synth.prompt_ids(12, shape.vocab, seed=3)
+    wants = [ref.forward(t, pos).copy() for pos, t in enumerate(toks)]
+    ref_ids, _ = ref.generate_greedy(toks, 20)
+    probe = hip.load_llama_model(g)
+    assert "attn_block" in _kinds(probe, 4)                      # the fused plan is what normally serves this model
+    probe.close()
+    monkeypatch.setenv("NL_FUSED_SPIN_LIMIT", "0")
+    monkeypatch.setenv("NL_QUIET", "1")
+
+    def fresh():
+        dev = hip.load_llama_model(g)
+        assert dev.last_error() == ""
+        return dev
+
+    def retired(dev):
+        assert "timed out" in dev.last_error() and "general plan" in dev.last_error()
+        assert "attn_block" not in _kinds(dev, 4) and "ffn_block" not in _kinds(dev, 4)
+
+    tol = lambda w: LOGIT_TOL * max(1.0, float(w.std()))
+    dev = fresh()                                                # nl_forward
+    for pos, t in enumerate(toks):
+        dev.forward(t, pos)
+        assert np.abs(dev.state.logits - wants[pos]).max() <= tol(wants[pos]), pos
+    retired(dev)
+    dev.close()
+    dev = fresh()                                                # nl_prefill, two tokens: the single-token plan
+    dev.prefill(toks[:2])
+    assert np.abs(dev.state.logits - wants[1]).max() <= tol(wants[1])
+    retired(dev)
+    dev.close()
+    dev = fresh()                                                # nl_forward_batch below the batch threshold
+    ids, lg = dev.forward_batch([0], [toks[0]], [0], want_logits=True)
+    assert np.abs(lg[0] - wants[0]).max() <= tol(wants[0]) and ids[0] == int(np.argmax(wants[0]))
+    retired(dev)
+    dev.close()
+    dev = fresh()                                                # nl_forward_argmax
+    assert dev.forward_argmax(toks[0], 0) == int(np.argmax(wants[0]))
+    retired(dev)
+    dev.close()
+    dev = fresh()                                                # nl_decode_greedy: the chained 16-step graph hits the timeout
+    dev.prefill(toks)                                            # (12 tokens: the multi-token path, no fused launch yet)
+    assert dev.last_error() == ""
+    first = int(np.argmax(dev.state.logits))
+    assert [first] + dev.decode_greedy(first, len(toks), 19) == ref_ids
+    retired(dev)
+    dev.close()
+    # nl_sample_decode: same uniforms as a handle that ran the general plan from the start -> identical ids and window
+    us = np.random.default_rng(9).random(24, dtype=np.float32)
+    dev = fresh()
+    dev.prefill(toks)
+    got = dev.sample_decode(len(toks), 24, 0.9, 0.9, 50, 1.15, 8, us, [3, 4])
+    retired(dev)
+    dev.close()
+    monkeypatch.delenv("NL_FUSED_SPIN_LIMIT")
+    monkeypatch.setenv("NL_FUSED_ATTN", "0")
+    plain = hip.load_llama_model(g)
+    plain.prefill(toks)
+    assert plain.sample_decode(len(toks), 24, 0.9, 0.9, 50, 1.15, 8, us, [3, 4]) == got
+    assert plain.last_error() == ""
+    plain.close(); ref.close()
 
 
 def test_greedy_chain_switches_from_the_fused_plan_to_the_split_attention_plan(hip, orc, tmp_path):

@@ -7,6 +7,7 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import sampling_kat as kat  # noqa: E402
 import sampling_mirror as sm  # noqa: E402
 from nanollama_amd import gguf  # noqa: E402
 
@@ -31,8 +32,31 @@ def _case(rng, V):
     return lg, window, recent, float(rng.random(dtype=np.float32))
 
 
+def test_device_answers_the_first_principles_kat(hip):
+    # hand-computed picks (tests/sampling_kat.py: eight logits, every pick >= 9e-3 from a cdf boundary); the literal-Go
+    # mirror answers the same table in tests/test_sampling_kat.py
+    lg = np.array(kat.LOGITS, np.float32)
+    for temp, top_p, u, want in kat.TOP_P:
+        pick, after, rec = hip.op_sample(lg, temp, top_p, 50, 1.0, 4, u, [7])
+        assert pick == want, (temp, top_p, u, pick)
+        assert np.array_equal(after, lg) and rec == [7, want]        # penalty 1.0 leaves the logits alone
+    for temp, k, u, want in kat.TOP_K:
+        assert hip.op_sample(lg, temp, 1.0, k, 1.0, 0, u, [])[0] == want, (temp, k, u)
+    tie = np.array(kat.TIE_LOGITS, np.float32)
+    for temp, k, u, want in kat.TIE_TOP_K:
+        assert hip.op_sample(tie, temp, 1.0, k, 1.0, 0, u, [])[0] == want, (temp, k, u)
+    pick, after, rec = hip.op_sample(lg, 0.0, 0.9, 50, kat.PENALTY, 8, 0.5, kat.RECENT)
+    assert after.tolist() == kat.LOGITS_AFTER_PENALTY
+    assert pick == 6 and rec == kat.RECENT + [6]                      # argmax of the penalised logits: id 6 (1.5)
+
+
 @pytest.mark.parametrize("V", [512, 4096, 32000, 96000])
-def test_top_p_matches_the_mirrors(hip, V):
+def test_top_p_matches_the_go_chain(hip, V):
+    # Primary oracle: the literal Go chain (sampling_mirror.go_top_p -- float32 throughout, one left-to-right sum).  The
+    # device adds the V terms in fixed chunks instead, so a draw whose r (or the top-p cut) lies within float32 rounding
+    # of a cumulative-probability boundary may land on the neighbouring candidate; device_top_p -- the same algorithm
+    # in the device's summation order -- is consulted ONLY to show that a disagreement is such a boundary case
+    # (margin < 5e-4 relative) and that the device did what its summation order implies.
     rng = np.random.default_rng(V)
     go_mismatch = 0
     trials = 24 if V <= 32000 else 8
@@ -42,12 +66,11 @@ def test_top_p_matches_the_mirrors(hip, V):
         pick, lg_after, rec_after = hip.op_sample(lg, temp, top_p, 50, pen, window, u, recent)
         want_lg = sm.apply_penalty(lg, recent, pen, V)
         assert np.array_equal(lg_after, want_lg)                       # in-place penalty, bit for bit
-        want, margin = sm.device_top_p(want_lg, temp, top_p, u)
-        assert pick == want, (V, temp, top_p, u, margin)               # same summation order: exact
         assert rec_after == sm.push_recent(recent, pick, window)
-        if pick != sm.go_top_p(want_lg, temp, top_p, u):               # Go's single float32 chain
+        if pick != sm.go_top_p(want_lg, temp, top_p, u):
             go_mismatch += 1
-            assert margin < 5e-4, margin                               # only ever on a cdf boundary
+            explained, margin = sm.device_top_p(want_lg, temp, top_p, u)
+            assert margin < 5e-4 and pick == explained, (V, temp, top_p, u, margin)
     assert go_mismatch <= max(2, trials // 8)
 
 

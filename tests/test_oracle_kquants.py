@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import oracle as orc  # noqa: E402
 
 GGML_Q5_0, GGML_Q4_K, GGML_Q6_K = 6, 12, 14
@@ -112,3 +113,31 @@ def test_oracle_block_decoder_matches_published_format(kind, gtype, per, npfn):
         flipped = raw.copy()
         flipped[pos] ^= 0x5A
         assert not np.array_equal(orc.dequant(flipped, gtype, nblk * per), got.reshape(-1))
+
+
+def _kat_matrix(kind):
+    """rows x 512 matrix from the hand-built super block (tests/kquant_kat.py): row 0 = [B, B x 4], row 1 = [B x 4, B]
+    (x 4: the same bytes with d -- and dmin -- four times larger).  Returns (raw bytes, expected[2][512])."""
+    import kquant_kat as kat
+    raw, exp = kat.q4_k_block() if kind == "q4_k" else kat.q6_k_block()
+    raw = bytearray(raw)
+    big = bytearray(raw)
+    import struct
+    if kind == "q4_k":
+        big[0:2] = struct.pack("<e", 2.0); big[2:4] = struct.pack("<e", 1.0)
+    else:
+        big[208:210] = struct.pack("<e", 1.0)
+    e1, e4 = np.array(exp, np.float32), np.array(exp, np.float32) * np.float32(4)
+    return (np.frombuffer(bytes(raw + big + big + raw), np.uint8).copy(),
+            np.stack([np.concatenate([e1, e4]), np.concatenate([e4, e1])]))
+
+
+@pytest.mark.parametrize("kind,gtype", [("q4_k", GGML_Q4_K), ("q6_k", GGML_Q6_K)])
+def test_oracle_reproduces_the_hand_built_super_blocks_exactly(kind, gtype):
+    # first-principles KAT (no reference vectors exist for these formats): every expected value is an exact binary
+    # fraction, so dequantisation AND any-order dot products with small-integer x must match bit for bit
+    raw, want = _kat_matrix(kind)
+    got = orc.dequant(raw, gtype, 2 * 512).reshape(2, 512)
+    assert np.array_equal(got, want)
+    x = ((np.arange(512) * 7) % 5 - 2).astype(np.float32)
+    assert np.array_equal(orc.matmul(raw, gtype, x, 2, 512), (want.astype(np.float64) @ x.astype(np.float64)).astype(np.float32))
