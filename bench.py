@@ -171,7 +171,7 @@ def measured_traffic(tier, wtype):
     return None, None
 
 
-def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, comm=None, keep=None):
+def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, comm=None, keep=None, shard_of=None):
     """Load the tier's random-weight GGUF, run `warmup` + REPEATS x `steps` chained greedy decode steps, profile the
     launches.  tp=True: the ranks of rdv form one tensor-parallel engine (comm = "p2p" push all-reduce or "rccl");
     tp=False: every rank is an independent replica (no data-path collective).  Timing = max over ranks."""
@@ -180,17 +180,21 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
     rank, local_rank = rdv.rank, rdv.local_rank
     replicas = 1 if tp else rdv.world
     world = rdv.world if tp else 1
+    if shard_of:          # rank 0's shard of a shard_of-rank tensor-parallel group, alone on this GPU (nl_p2p_loopback)
+        world = shard_of
     shape = synth.TIERS[tier]
     mode = "qrand" if tier in ("big", "goldie") else "float"
     path = ensure_gguf(shape, wtype, mode, rank)
     rdv.barrier()
     g = gguf.load_gguf(path)
     kw = {}
-    if world > 1 and comm == "p2p":
+    if shard_of:
+        kw["p2p_loopback"] = True
+    elif world > 1 and comm == "p2p":
         kw["p2p_allgather"] = rdv.allgather_bytes
     elif world > 1 or os.environ.get("NL_FORCE_TP_PLAN"):
         kw["comm_id"] = rdv.broadcast_bytes(model.comm_unique_id)
-    dev = model.load_llama_model(g, device=local_rank, tp_rank=rank if world > 1 else 0, tp_size=world, **kw)
+    dev = model.load_llama_model(g, device=local_rank, tp_rank=0 if shard_of else (rank if world > 1 else 0), tp_size=world, **kw)
     prompt = synth.prompt_ids(PROMPT_LEN, shape.vocab)
     rdv.barrier()
     dev.prefill(prompt)
@@ -230,7 +234,7 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
     # engine's stream (nl_profile_forward), at a mid-run position
     ppos = min(profile_pos if profile_pos is not None else pos0 + (min(SEGMENT, steps) - 1) // 2, shape.seq_len - 1)
     prof = dev.profile_forward(first, ppos, iters=20)
-    kb = kernel_bytes(shape, wtype, ppos, tp=world)
+    kb = kernel_bytes(shape, wtype, ppos, tp=shard_of or world)
     kernels = {}
     for kind, (ms, calls) in prof.items():
         if calls:
@@ -238,6 +242,8 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
             kernels[kind] = {"launches": calls, "us_per_launch": round(per * 1e3, 3),
                              "GBps": round(kb[kind] / (per * 1e-3) / 1e9, 1)}
     traffic, traffic_file = measured_traffic(tier, wtype) if world == 1 else (None, None)
+    if shard_of:
+        world = 1        # (one GPU did the work: fractions below are against ONE device's peak, bytes are the shard's)
     # dominant kernel = the kind with the largest TIME share of the step (launches x time per launch; ties broken by
     # name); the kind that moves the most algorithmic bytes per step is reported beside it as roofline_by_bytes
     cand = sorted(k for k in kernels if k not in ("argmax", "allreduce"))
@@ -252,9 +258,9 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
                 "us_per_launch": kernels[kind]["us_per_launch"], "launches_per_step": kernels[kind]["launches"],
                 "time_share_of_step": round(prof[kind][0] / step_ms_profiled, 3), "profiled_at_pos": ppos}
     mean_pos = pos0 + (min(SEGMENT, steps) - 1) / 2.0
-    step_bytes = synth.weight_bytes_per_token(shape, wtype) + synth.kv_bytes_per_token(shape, int(mean_pos))
+    step_bytes = (synth.weight_bytes_per_token(shape, wtype) + synth.kv_bytes_per_token(shape, int(mean_pos))) / (shard_of or 1)
     step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
-    p2p = dev.p2p_info() if world > 1 else None
+    p2p = dev.p2p_info() if (world > 1 or shard_of) else None
     res = {
         "tier": tier, "wtype": wtype, "path": path, "prompt": prompt,
         "tok_s": replicas * steps / (wall_ms / 1e3), "ms_per_step": ms_per_step, "device_ms_per_step": evs[med] / steps,
@@ -344,6 +350,34 @@ def side_configs(model):
     return out
 
 
+def shard_probe(model, rdv, ns=(2, 4, 8), seam_us=2.0, steps=96, warmup=16, base=None):
+    """per-rank step time of big Q4_0 at tp_size N with NO contention -- rank 0's shard alone on
+    this GPU with the real tensor-parallel plan (grids, granule stores into its own receive slots, polls;
+    nl_p2p_loopback), only the xGMI hop missing.  predicted = per-rank time + 2 L seams x an ASSUMED wire latency
+    (seam_us per seam: no xGMI figure has been measured by this repo) -- a prediction, labelled as such."""
+    from nanollama_amd import synth
+    shape = synth.TIERS["big"]
+    out = {"workload": "big (7.9B) Q4_0: rank 0's shard of a tensor-parallel group of N, alone on one idle GPU "
+                       "(nl_p2p_loopback: real plan, grids, granule stores and polls; no xGMI hop; logits are not a model's)",
+           "assumed_seam_us": seam_us, "seams_per_step": 2 * shape.n_layer, "per_rank": {}, "predicted_scaling": {}}
+    for n in ns:
+        try:
+            r = run_workload("big", "q4_0", rdv, steps, warmup, None, model, tp=False, shard_of=n)
+        except Exception as exc:
+            out["per_rank"][str(n)] = {"error": repr(exc)}
+            continue
+        kern = {k: {"launches": v["launches"], "us_per_launch": v["us_per_launch"]} for k, v in r["kernels"].items()}
+        out["per_rank"][str(n)] = {"ms_per_step": round(r["ms_per_step"], 5), "launches_per_step": sum(v["launches"] for v in kern.values()),
+                                   "shard_bytes_per_step": r["step_bytes"], "hbm_frac_of_one_gpu": round(r["hbm_frac_whole_step"], 4),
+                                   "kernels": kern}
+        pred_ms = r["ms_per_step"] + out["seams_per_step"] * seam_us * 1e-3
+        out["predicted_scaling"][str(n)] = {"predicted_ms_per_step": round(pred_ms, 4), "predicted_tokens_per_s": round(1e3 / pred_ms, 1)}
+        if base:
+            out["predicted_scaling"][str(n)]["predicted_speedup_vs_1gpu"] = round(base / pred_ms, 2)
+    out["label"] = "PREDICTION from one GPU: no store has crossed xGMI in this measurement"
+    return out
+
+
 def workload_text(shape, tier, wtype, r, steps):
     """What the timed region ran: `steps` chained greedy decode steps as segments that each restart behind the prompt."""
     seg = r["segment"]
@@ -372,6 +406,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the side measurements")
     ap.add_argument("--comm", default=None, choices=("p2p", "rccl"), help="N > 1: force the all-reduce transport")
+    ap.add_argument("--shard-of", type=int, default=None, choices=(2, 4, 8),
+                    help="one GPU: time rank 0's shard of big Q4_0 at tp_size N alone (loopback slots) and print that line only")
+    ap.add_argument("--seam-us", type=float, default=2.0, help="assumed xGMI latency per all-reduce seam for the predicted-scaling table")
+    ap.add_argument("--no-shard-probe", action="store_true", help="N = 1: skip the tensor-parallel shard-only probe of big")
     ap.add_argument("--rccl-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--profile-pos", type=int, default=None, help="position of the per-launch profile (default: the mean timed position)")
     args = ap.parse_args()
@@ -420,6 +458,15 @@ def main():
         rdv.close()
         return
 
+    if args.shard_of:
+        if n != 1:
+            raise SystemExit("--shard-of runs on one GPU")
+        out = dict(common, metric=f"per-rank decode step, big Q4_0 shard 0 of {args.shard_of} (loopback)", scaling="strong",
+                   **shard_probe(model, rdv, ns=(args.shard_of,), seam_us=args.seam_us, steps=args.steps, warmup=args.warmup))
+        print(json.dumps(out))
+        rdv.close()
+        return
+
     if args.workload:
         tier, wtype = args.workload.split(":")
         shape = synth.TIERS[tier]
@@ -462,6 +509,12 @@ def main():
                 out["other_configs"] = side_configs(model)
             except Exception as exc:
                 out["other_configs"] = {"error": repr(exc)}
+            if not args.no_shard_probe:
+                try:
+                    base = out["secondary"].get("ms_per_step") if isinstance(out.get("secondary"), dict) else None
+                    out["tensor_parallel_shard_probe"] = shard_probe(model, rdv, seam_us=args.seam_us, base=base)
+                except Exception as exc:
+                    out["tensor_parallel_shard_probe"] = {"error": repr(exc)}
         print(json.dumps(out))
         rdv.close()
         return

@@ -207,6 +207,11 @@ NL_API int nl_comm_init(nl_handle h, const void *id /* NL_COMM_ID_BYTES */);
 NL_API int nl_p2p_export(nl_handle h, void *handle_out /* NL_P2P_HANDLE_BYTES */);
 NL_API int nl_p2p_import(nl_handle h, const void *handles /* tp_size x NL_P2P_HANDLE_BYTES, rank order */);
 NL_API int nl_p2p_info(nl_handle h, int *enabled, int *uncached_area);
+/* Measurement only (bench.py --shard-of N): this rank alone on an idle GPU with the tensor-parallel launch plan of a
+ * tp_size-rank group; the rank writes its partial into all tp_size receive slots of its own area, so grids, granule
+ * stores and polls are the real ones and only the xGMI hop is missing.  Timings are real, logits are not a model's.
+ * Before nl_finalize, instead of nl_p2p_export / nl_p2p_import.  No reference counterpart (the Go engine is one process). */
+NL_API int nl_p2p_loopback(nl_handle h);
 
 /* In-process tensor-parallel group: `n` handles created with tp_size = n, tp_rank = 0..n-1 and
  * NL_FLAG_LOCAL_GROUP (all on devices this process can reach; the same device is allowed).  Steps

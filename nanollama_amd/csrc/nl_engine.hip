@@ -233,6 +233,7 @@ struct nl_engine {
         void *area = nullptr;     // this rank's receive area (uncached, exported over hipIpc)
         size_t bytes = 0;
         bool uncached = false;
+        bool loopback = false;    // nl_p2p_loopback: every "peer" is this rank's own area (one rank alone, timing only)
         void *peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // rank r's area mapped here
         bool opened[8] = {false, false, false, false, false, false, false, false};
         unsigned *epoch = nullptr, *status = nullptr;   // device words: forward counter, poll-timeout flags
@@ -604,27 +605,18 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
     int cur = 0;
     int lm_blocks = 0, lm_spb = 1;
     const float *pending = nullptr;  // all-reduced partial still to be added to the residual stream
-    // push seams (nl_p2p.h): the partial leaves the producing GEMV as granules into every rank's receive slots,
-    // a small kernel adds the G slots into the residual stream.  Slots alternate by seam parity.
+    // push seams (nl_p2p.h): the partial leaves the producing GEMV as granules into every rank's receive slots and the
+    // same launch finishes the all-reduce (each row's owner lane adds the G granules of its row to the residual stream,
+    // EPI_P2P).  Slots alternate by seam parity.  Loopback (nl_p2p_loopback: one rank alone, timing only): the rank
+    // writes its partial into ALL G rank-slots of its own area, so grids, stores and polls are the real ones.
     const size_t slot_bytes = (size_t)c.dim * sizeof(u64);
-    auto p2p_producer = [&](GemvParams &P, int seam) {
+    auto p2p_producer = [&](GemvParams &P, int seam, float *x) {
         for (int r = 0; r < e->G; r++)
-            P.p2p_dst[r] = reinterpret_cast<u64 *>((char *)e->p2p.peer[r] + ((size_t)(seam & 1) * e->G + e->rank) * slot_bytes);
+            P.p2p_dst[r] = reinterpret_cast<u64 *>((char *)e->p2p.peer[r] + ((size_t)(seam & 1) * e->G + (e->p2p.loopback ? r : e->rank)) * slot_bytes);
+        P.p2p_slots = reinterpret_cast<const u64 *>((char *)e->p2p.area + (size_t)(seam & 1) * e->G * slot_bytes);
         P.p2p_n = e->G; P.p2p_epoch = e->p2p.epoch; P.p2p_seam = (unsigned)(seam + 1);
-    };
-    auto p2p_reduce = [&](int seam, float *x) {
-        P2PReduceParams R{reinterpret_cast<const u64 *>((char *)e->p2p.area + (size_t)(seam & 1) * e->G * slot_bytes), c.dim,
-                          (unsigned)(seam + 1), e->p2p.epoch, x, e->p2p.status, e->p2p.timeout_ticks};
-        const int G = e->G, blocks = (c.dim + 255) / 256;
-        plan.push_back({K_ALLREDUCE, 0, nullptr, 0, [R, G, blocks](hipStream_t st) {
-                               switch (G) {
-                               case 2: hipLaunchKernelGGL(p2p_reduce_kernel<2>, dim3(blocks), dim3(256), 0, st, R); break;
-                               case 4: hipLaunchKernelGGL(p2p_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, R); break;
-                               case 8: hipLaunchKernelGGL(p2p_reduce_kernel<8>, dim3(blocks), dim3(256), 0, st, R); break;
-                               default: return hipErrorInvalidValue;
-                               }
-                               return hipGetLastError();
-                           }});
+        P.p2p_status = e->p2p.status; P.p2p_timeout = e->p2p.timeout_ticks;
+        P.out = x; P.resid = x;
     };
     int seam = 0;
 
@@ -717,9 +709,8 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
             P.bias_out = L.bo;
             int wt = L.wo.wtype;
             if (p2p) {
-                p2p_producer(P, seam);
+                p2p_producer(P, seam++, e->x[cur]);
                 push_gemv(plan, K_WO, 0, nullptr, 0, wt, PRO_ATTN, EPI_P2P, P);
-                p2p_reduce(seam++, e->x[cur]);
             } else if (!tp) {
                 P.out = e->x[cur]; P.resid = e->x[cur];
                 push_gemv(plan, K_WO, 0, nullptr, 0, wt, PRO_ATTN, EPI_RESID, P);
@@ -750,9 +741,8 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
             P.x = e->hb;
             int wt = L.down.wtype;
             if (p2p) {
-                p2p_producer(P, seam);
+                p2p_producer(P, seam++, e->x[cur]);
                 push_gemv(plan, K_DOWN, 0, nullptr, 0, wt, PRO_PLAIN, EPI_P2P, P);
-                p2p_reduce(seam++, e->x[cur]);
             } else if (!tp) {
                 P.out = e->x[cur]; P.resid = e->x[cur];
                 push_gemv(plan, K_DOWN, 0, nullptr, 0, wt, PRO_PLAIN, EPI_RESID, P);
@@ -771,8 +761,8 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         if (!tp) { P.amax_val = e->amax_val; P.amax_idx = e->amax_idx; }
         if (p2p)   // the logits all-gather: this rank's slice also lands in every peer's gathered buffer
             for (int r = 0; r < e->G; r++)
-                if (r != e->rank)
-                    P.peer_out[r] = reinterpret_cast<float *>((char *)e->p2p.peer[r] + e->p2p.off_logits) + (size_t)e->rank * e->Vs;
+                if (r != e->rank)   // (loopback: the slice fills every other rank's place in this rank's own buffer)
+                    P.peer_out[r] = reinterpret_cast<float *>((char *)e->p2p.peer[r] + e->p2p.off_logits) + (size_t)(e->p2p.loopback ? r : e->rank) * e->Vs;
         int wt = e->lm_head.wtype;
         lm_blocks = (P.ntiles + P.tw - 1) / P.tw;
         lm_spb = (P.tw * TR + 63) / 64;
@@ -782,7 +772,7 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         P2PArgmaxParams P{};
         P.A = ArgmaxParams{e->logits, c.vocab, e->amax_val, e->amax_idx, lm_blocks * lm_spb, e->ctl, e->ids, e->result};
         for (int r = 0; r < e->G; r++)
-            P.dst[r] = reinterpret_cast<u64 *>((char *)e->p2p.peer[r] + e->p2p.off_amax) + 2 * e->rank;
+            P.dst[r] = reinterpret_cast<u64 *>((char *)e->p2p.peer[r] + e->p2p.off_amax) + 2 * (e->p2p.loopback ? r : e->rank);
         P.slots = reinterpret_cast<const u64 *>((char *)e->p2p.area + e->p2p.off_amax);
         P.G = e->G; P.row0 = e->rank * e->Vs; P.seam = 255u;
         P.epoch = e->p2p.epoch; P.status = e->p2p.status; P.timeout_ticks = e->p2p.timeout_ticks;
@@ -2625,6 +2615,22 @@ int nl_p2p_import(nl_handle e, const void *handles) {
         }
     }
     p.on = true;
+    return NL_OK;
+}
+
+int nl_p2p_loopback(nl_handle e) {
+    // Measurement mode: ONE rank of a tensor-parallel group on an otherwise idle GPU.  The launch plan, grids, granule
+    // stores and polls are the tensor-parallel ones; every "peer" is this rank's own receive area and the rank writes
+    // its partial into all G rank-slots itself, so only the xGMI hop is missing.  The residual stream then holds
+    // G x this rank's partial sums: timings are real, logits are NOT a model's.
+    if (!e) return NL_ERR_INVALID;
+    if (e->finalized) return e->fail(NL_ERR_STATE, "nl_p2p_loopback after nl_finalize");
+    unsigned char h[NL_P2P_HANDLE_BYTES];
+    int rc = nl_p2p_export(e, h);            // allocates the (uncached) area exactly as a real rank does
+    if (rc) return rc;
+    for (int r = 0; r < e->G; r++) e->p2p.peer[r] = e->p2p.area;
+    e->p2p.loopback = true;
+    e->p2p.on = true;
     return NL_OK;
 }
 

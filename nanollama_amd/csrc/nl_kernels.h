@@ -493,11 +493,17 @@ struct GemvParams {
     // EPI_RESID / EPI_STORE add bias_out[row]
     const float *bias_q, *bias_k, *bias_v, *bias_out;
     long long *dbg;  // optional phase timestamps (clock64) written by workgroup 0, lane 0 of each wave
-    // tensor-parallel push (nl_p2p.h).  EPI_P2P: out[row] leaves as a tagged granule into the receive slot of every
-    // rank (p2p_dst[r] = rank r's slot for THIS rank's partial).  EPI_STORE with peer_out: the logits slice is also
+    // tensor-parallel push (nl_p2p.h).  EPI_P2P: this rank's partial of out[row] leaves as a tagged granule into the
+    // receive slot of every rank (p2p_dst[r] = rank r's slot for THIS rank's partial); the SAME lane then waits for the
+    // p2p_n granules the ranks pushed for its row (p2p_slots: this rank's receive slots of the seam, [G][rows]) and
+    // stores out[row] = resid[row] + sum over ranks in rank order -- the all-reduce is finished by the row's owner
+    // inside the producing launch, there is no reduce launch.  EPI_STORE with peer_out: the logits slice is also
     // written into every peer's gathered logits buffer.
     unsigned long long *p2p_dst[8];
+    const unsigned long long *p2p_slots;
     const unsigned *p2p_epoch;
+    unsigned *p2p_status;       // set non-zero when a poll gave up (host: NL_ERR_COMM)
+    long long p2p_timeout;      // wall_clock64 ticks (100 MHz)
     int p2p_n;
     unsigned p2p_seam;
     float *peer_out[8];
@@ -658,6 +664,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     if (PRO == PRO_ATTN) NL_KARGS4(P.part_o, P.part_ml, P.nsplit_max, P.ctl);
     if (PRO == PRO_NORM_PARTS) NL_KARGS2(P.parts, P.nparts);
     if (EPI == EPI_RESID) NL_KARGS2(P.resid, P.bias_out);
+    if (EPI == EPI_P2P) NL_KARGS8(P.resid, P.bias_out, P.p2p_slots, P.p2p_epoch, P.p2p_status, P.p2p_timeout, P.p2p_n, P.p2p_seam);
     if (EPI == EPI_STORE) NL_KARGS4(P.amax_val, P.amax_idx, P.bias_out, P.x_out);
 #define NL_STAMP(k) do { if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + (k)] = clock64(); } while (0)
     NL_STAMP(0);
@@ -683,7 +690,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     const bool e_act = t < nact && e_tile < P.ntiles;
     float e_resid = 0.f, e_cos = 0.f, e_sin = 0.f;
     int e_pos = 0;
-    if (EPI == EPI_RESID) {
+    if (EPI == EPI_RESID || EPI == EPI_P2P) {
         if (e_act && e_tile * TR + e_rr < P.rows) e_resid = P.resid[e_tile * TR + e_rr];
     }
     if (EPI == EPI_QKV) {
@@ -851,6 +858,28 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
 #pragma unroll
         for (int pr = 0; pr < 8; pr++)
             if (pr < P.p2p_n) __hip_atomic_store(P.p2p_dst[pr] + row, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // ... and the all-reduce is finished here, by the row's owner: wait for the granule every rank pushed for this
+        // row (the peers run the same launch at the same time, so the wait is the wire's latency while the other
+        // workgroups of this launch still stream their weights), add them in rank order (deterministic; bitwise what
+        // the in-process shard group computes) and store the new residual.  Bounded: a missing rank sets the status word.
+        const bool dead = __hip_atomic_load(P.p2p_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        unsigned long long g[8];
+        const long long t0 = wall_clock64();
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int pr = 0; pr < 8; pr++)
+                g[pr] = __hip_atomic_load(P.p2p_slots + (size_t)min(pr, P.p2p_n - 1) * P.rows + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+            for (int pr = 0; pr < 8; pr++) ok &= (unsigned)(g[pr] >> 32) == e_tag;
+            if (ok) break;
+            if (dead || wall_clock64() - t0 > P.p2p_timeout) { atomicOr(P.p2p_status, 1u); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int pr = 0; pr < 8; pr++) sum += pr < P.p2p_n ? __uint_as_float((unsigned)g[pr]) : 0.f;   // fixed rank order
+        P.out[row] = e_resid + sum;
         return;
     }
     if (EPI == EPI_STORE) {

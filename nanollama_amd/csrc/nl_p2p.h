@@ -4,7 +4,9 @@
 // rank holds only a partial [D] vector.  The 16 KiB all-reduce that completes it is latency, not bandwidth:
 // 80 of them per token for the 7.9B tier.  Instead of a ring, every rank PUSHES its partial straight into a
 // receive slot in every peer's memory (xGMI is point to point: one hop) and each rank sums the G slots itself
-// in fixed rank order (deterministic, and bitwise what the in-process group of nl_group_forward computes).
+// in fixed rank order (deterministic, and bitwise what the in-process group of nl_group_forward computes).  The
+// sum is done by the lane that produced the row, in the tail of the producing GEMV (EPI_P2P, nl_kernels.h): the
+// peers run the same launch at the same time, so the wait is the wire's latency, and no reduce launch exists.
 //
 // Transport: 8-byte granules {tag, float bits}, each written by ONE system-scope store and polled with
 // system-scope loads -- the data is its own flag, so no fence or separate flag orders anything
@@ -25,45 +27,6 @@ __device__ __forceinline__ u64 granule_load(const u64 *p) {
 }
 __device__ __forceinline__ void granule_store(u64 *p, unsigned tag, unsigned bits) {
     __hip_atomic_store(p, ((u64)tag << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-struct P2PReduceParams {
-    const u64 *slots;      // this rank's receive slots of the seam: [G][D] granules
-    int D;
-    unsigned seam;         // low 8 bits of the tag (seam index + 1, never 0)
-    const unsigned *epoch; // forward counter of this device
-    float *x;              // residual stream [D], updated in place: x += sum_r partial_r
-    unsigned *status;      // set non-zero when a poll gave up
-    long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
-};
-
-// x[i] += sum over ranks (rank order) of the partial each rank pushed for this seam.
-template <int G>
-__global__ void __launch_bounds__(256) p2p_reduce_kernel(P2PReduceParams P) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int ii = min(i, P.D - 1);
-    const unsigned tag = (__hip_atomic_load(P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 8) | P.seam;
-    const float xv = P.x[ii];
-    const bool dead = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    u64 g[G];
-    const long long t0 = wall_clock64();
-    for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int r = 0; r < G; r++) g[r] = granule_load(P.slots + (size_t)r * P.D + ii);
-#pragma unroll
-        for (int r = 0; r < G; r++) ok &= (unsigned)(g[r] >> 32) == tag;
-        if (__all(ok)) break;
-        if (dead || wall_clock64() - t0 > P.timeout_ticks) {
-            if ((threadIdx.x & 63) == 0) atomicOr(P.status, 1u);
-            break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < G; r++) s += __uint_as_float((unsigned)g[r]);   // fixed rank order
-    if (i < P.D) P.x[i] = xv + s;
 }
 
 struct P2PArgmaxParams {

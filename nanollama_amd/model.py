@@ -187,7 +187,7 @@ class LlamaModel:
 
 def load_llama_model(gguf: GGUFFile, device: int = 0, max_streams: int = 1, tp_rank: int = 0, tp_size: int = 1,
                      comm_id: Optional[bytes] = None, flags: int = 0, verbose: bool = False,
-                     p2p_allgather=None) -> LlamaModel:
+                     p2p_allgather=None, p2p_loopback: bool = False) -> LlamaModel:
     """LoadLlamaModel go/model.go:121-174: config from GGUF metadata, every
     tensor handed to the device library, state allocated there.
 
@@ -212,7 +212,10 @@ def load_llama_model(gguf: GGUFFile, device: int = 0, max_streams: int = 1, tp_r
     if rc != 0:
         raise _lib.NlError(rc, (L.nl_last_error(None) or b"").decode())
     try:
-        if tp_size > 1 and p2p_allgather is not None and not (flags & _lib.NL_FLAG_LOCAL_GROUP):
+        if tp_size > 1 and p2p_loopback:
+            # measurement only (bench.py --shard-of): this rank alone, tensor-parallel plan, own area in place of the peers'
+            _lib.check(h, L.nl_p2p_loopback(h))
+        elif tp_size > 1 and p2p_allgather is not None and not (flags & _lib.NL_FLAG_LOCAL_GROUP):
             mine = C.create_string_buffer(_lib.NL_P2P_HANDLE_BYTES)
             _lib.check(h, L.nl_p2p_export(h, mine))
             handles = p2p_allgather(mine.raw)
