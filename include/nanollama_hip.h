@@ -180,6 +180,9 @@ NL_API int nl_op_matmul_batch(int device, uint32_t ggml_type, const void *w, uin
                                float *out, int rows, int cols, int n_tokens);
 /* RMSNormInto (go/quant.go:597-607). */
 NL_API int nl_op_rmsnorm(int device, const float *x, const float *w, float eps, float *out, int n);
+/* float32(math.Exp(float64(x))) of Softmax and SiLU (go/quant.go:619, :629-631) as the forward kernels compute it
+ * (short-chain float64 exponential, nl_kernels.h exp_f64_as_f32), element-wise on host arrays. */
+NL_API int nl_op_exp(int device, const float *x, float *out, int n);
 
 /* Sampling operator on host logits: one decision of sampleTopP / sampleTopK / argmax (go/main.go:294-408)
  * after the in-place repetition penalty (:177-187), on the device.  logits (in/out: the penalty is applied in

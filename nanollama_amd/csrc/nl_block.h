@@ -308,9 +308,9 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
             const float s0 = lane < n ? sc[lane] : -INFINITY;
             const float s1 = lane + 64 < n ? sc[lane + 64] : -INFINITY;
             const float m = wave_max_f32(fmaxf(s0, s1));
-            const float p0 = lane < n ? (float)exp((double)(s0 - m)) : 0.f;
+            const float p0 = lane < n ? exp_f64_as_f32(s0 - m) : 0.f;
             float p1 = 0.f;
-            if (n > 64) p1 = lane + 64 < n ? (float)exp((double)(s1 - m)) : 0.f;   // (wave-uniform: short passes skip the second exp)
+            if (n > 64) p1 = lane + 64 < n ? exp_f64_as_f32(s1 - m) : 0.f;   // (wave-uniform: short passes skip the second exp)
             if (lane < n) sc[lane] = p0;
             if (lane + 64 < n) sc[lane + 64] = p1;
             const float l = wave_sum_f32(p0 + p1);
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
             for (int c = 1; c < nch; c++) M = fmaxf(M, chunk[c * 66]);
             float v = 0.f, L = 0.f;
             for (int c = 0; c < nch; c++) {
-                const float w = (float)exp((double)(chunk[c * 66] - M));
+                const float w = exp_f64_as_f32(chunk[c * 66] - M);
                 L += w * chunk[c * 66 + 1];
                 v += w * chunk[c * 66 + 2 + tid];
             }
@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_block_kernel(FfnParams P) {
         const float *rg = red + (t16 * 4) * TR, *ru = red + ((2 + t16) * 4) * TR;
         const float g = (((rg[rr] + rg[TR + rr]) + rg[2 * TR + rr]) + rg[3 * TR + rr]) * inv;
         const float u = (((ru[rr] + ru[TR + rr]) + ru[2 * TR + rr]) + ru[3 * TR + rr]) * inv;
-        const float ex = (float)exp((double)(-g));
+        const float ex = exp_f64_as_f32(-g);
         const float h = (g / (1.0f + ex)) * u;
         __hip_atomic_store(P.xchg + (size_t)cl * FFN_SLICE + mem * 32 + et, ((unsigned long long)tag << 32) | __float_as_uint(h),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

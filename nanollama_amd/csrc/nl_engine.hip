@@ -464,6 +464,11 @@ hipError_t launch_gemv_dyn(int wt, int pro, int epi, const GemvParams &P, hipStr
         if (P.nparts <= 9) return launch_gemv_t<PRO_NORM_PARTS, EPI_SWIGLU, 9>(wt, P, st);
         return launch_gemv_t<PRO_NORM_PARTS, EPI_SWIGLU, MAX_PARTS>(wt, P, st);
     }
+    if (pro == PRO_NORM_PARTS && epi == EPI_STORE) {   // the LM head behind a fused feed-forward block
+        if (P.nparts <= 4) return launch_gemv_t<PRO_NORM_PARTS, EPI_STORE, 4>(wt, P, st);
+        if (P.nparts <= 6) return launch_gemv_t<PRO_NORM_PARTS, EPI_STORE, 6>(wt, P, st);
+        return launch_gemv_t<PRO_NORM_PARTS, EPI_STORE, FFN_MAX_PARTS>(wt, P, st);
+    }
     if (pro == PRO_ATTN && epi == EPI_P2P) return launch_gemv_t<PRO_ATTN, EPI_P2P>(wt, P, st);
     if (pro == PRO_PLAIN && epi == EPI_P2P) return launch_gemv_t<PRO_PLAIN, EPI_P2P>(wt, P, st);
     return hipErrorInvalidValue;
@@ -548,18 +553,7 @@ void build_plan_blocks(nl_engine *e, std::vector<Op> &plan) {
                                                         : launch_attn_block<WT_Q4_0>(B, npin, grid, lds, st);
                                }});
         }
-        if (l == c.n_layers - 1) {
-            // last layer: gate/up and down as the two GEMV launches, so that the residual stream is complete in memory and
-            // the LM head (2000 tiles, each re-reading its input) does not have to add partial vectors per tile
-            GemvParams P = base_params(e, L.gate, 2);
-            P.q1 = L.up.q; P.s1 = L.up.s;
-            P.x = e->x[0]; P.normw = L.ffn_norm; P.out = e->hb;
-            P.parts = e->parts; P.nparts = e->Hs; P.x_out = e->x[1];
-            push_gemv(plan, K_GATEUP, 0, nullptr, 0, L.gate.wtype, PRO_NORM_PARTS, EPI_SWIGLU, P);
-            GemvParams Q = base_params(e, L.down);
-            Q.x = e->hb; Q.out = e->x[1]; Q.resid = e->x[1];
-            push_gemv(plan, K_DOWN, 0, nullptr, 0, L.down.wtype, PRO_PLAIN, EPI_RESID, Q);
-        } else {
+        {
             FfnParams F{};
             F.gate_q = L.gate.q; F.gate_s = L.gate.s; F.up_q = L.up.q; F.up_s = L.up.s; F.dn_q = L.dn_slice.q; F.dn_s = L.dn_slice.s;
             F.D = c.dim; F.I = e->Is; F.npairs = L.gate.npairs;
@@ -574,13 +568,15 @@ void build_plan_blocks(nl_engine *e, std::vector<Op> &plan) {
         }
     }
     int lm_blocks, lm_spb;
-    {   // final RMSNorm + LM head (go/model.go:616-619)
+    {   // final RMSNorm + LM head (go/model.go:616-619); its prologue adds the last feed-forward block's partial vectors
+        // (I / 256 of them, a few KB per workgroup from L2) like every other consumer of a block: 2 L + 3 launches per token
         GemvParams P = base_params(e, e->lm_head);
         P.x = e->x[1]; P.normw = e->output_norm;
+        P.parts = e->parts_ffn; P.nparts = nslices;
         P.out = e->logits; P.amax_val = e->amax_val; P.amax_idx = e->amax_idx;
         lm_blocks = (P.ntiles + P.tw - 1) / P.tw;
         lm_spb = (P.tw * TR + 63) / 64;
-        push_gemv(plan, K_LMHEAD, 0, e->logits, (size_t)e->Vs, e->lm_head.wtype, PRO_NORM, EPI_STORE, P);
+        push_gemv(plan, K_LMHEAD, 0, e->logits, (size_t)e->Vs, e->lm_head.wtype, PRO_NORM_PARTS, EPI_STORE, P);
     }
     {
         ArgmaxParams P{e->logits, c.vocab, e->amax_val, e->amax_idx, lm_blocks * lm_spb, e->ctl, e->ids, e->result};
@@ -1724,7 +1720,8 @@ int nl_finalize(nl_handle e) {
             bool okf = e->fused_mode == 1 && !(ff && atoi(ff) == 0);
             for (const auto &L : e->layers)
                 okf = okf && L.dn_slice.ready && L.dn_slice.wtype == L.qkv.wtype && L.gate.wtype == L.qkv.wtype && L.up.wtype == L.qkv.wtype;
-            e->ffn_fused = okf;
+            // (the LM head behind the last feed-forward block adds its partial vectors: PRO_NORM_PARTS exists for Q8_0 / Q4_0)
+            e->ffn_fused = okf && (e->lm_head.wtype == WT_Q8_0 || e->lm_head.wtype == WT_Q4_0);
         }
         if (e->ffn_fused) {
             HIPCK(e, dalloc(&e->parts_ffn, (size_t)(e->Is / FFN_SLICE) * c.dim, &e->bytes_state));
@@ -2463,6 +2460,30 @@ int nl_op_rmsnorm(int device, const float *x, const float *w, float eps, float *
         hipLaunchKernelGGL(rmsnorm_op_kernel, dim3(1), dim3(256), 0, 0, d, d + n, eps, d + 2 * n, n);
         if (hipGetLastError() != hipSuccess) break;
         if (hipMemcpy(out, d + 2 * n, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = NL_OK;
+    } while (0);
+    hipFree(d);
+    return rc;
+}
+
+namespace {
+__global__ void exp_op_kernel(const float *x, float *out, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = exp_f64_as_f32(x[i]);
+}
+}  // namespace
+
+// float32(exp(float64(x))) as the forward kernels compute it (exp_f64_as_f32, nl_kernels.h): parity tests only.
+int nl_op_exp(int device, const float *x, float *out, int n) {
+    if (!x || !out || n <= 0) return NL_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return NL_ERR_HIP;
+    float *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)n * 8) != hipSuccess) return NL_ERR_HIP;
+    int rc = NL_ERR_HIP;
+    do {
+        if (hipMemcpy(d, x, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) break;
+        hipLaunchKernelGGL(exp_op_kernel, dim3(1024), dim3(256), 0, 0, d, d + n, n);
+        if (hipGetLastError() != hipSuccess) break;
+        if (hipMemcpy(out, d + n, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
         rc = NL_OK;
     } while (0);
     hipFree(d);

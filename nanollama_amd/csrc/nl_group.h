@@ -249,8 +249,8 @@ __global__ void __launch_bounds__(GRP_THREADS) qkv_attn_kernel(GroupParams P) {
             const float s0 = lane < n ? sc[lane] : -INFINITY;
             const float s1 = lane + 64 < n ? sc[lane + 64] : -INFINITY;
             const float m = wave_max_f32(fmaxf(s0, s1));
-            const float p0 = lane < n ? (float)exp((double)(s0 - m)) : 0.f;
-            const float p1 = lane + 64 < n ? (float)exp((double)(s1 - m)) : 0.f;
+            const float p0 = lane < n ? exp_f64_as_f32(s0 - m) : 0.f;
+            const float p1 = lane + 64 < n ? exp_f64_as_f32(s1 - m) : 0.f;
             if (lane < n) sc[lane] = p0;
             if (lane + 64 < n) sc[lane + 64] = p1;
             const float l = wave_sum_f32(p0 + p1);

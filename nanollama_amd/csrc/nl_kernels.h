@@ -84,6 +84,30 @@ __device__ __forceinline__ float h2f_bits(uint32_t h) {
     return __half2float(__ushort_as_half((unsigned short)h));
 }
 
+// float32(exp(float64(x))) -- the exponential of the reference's Softmax and SiLU (go/quant.go:619, :629-631) -- with a
+// short dependent chain.  The library exp is ~150 instructions, most of them dependent; in the fused block launches one
+// wavefront computes the softmax of a head while eleven wait for it, so its chain is launch time.  Cody-Waite
+// reduction (k = rint(x log2 e), r = x - k ln2 in two exact steps), degree-13 Taylor polynomial in Estrin form (|r| <=
+// 0.347: truncation 4e-18), v_ldexp_f64.  <= 2 ulp in float64, i.e. the float32 result differs from the library's only
+// when the exact value lies within 2^-51 of a float32 rounding boundary (never in 4e6 test arguments,
+// tests/test_gpu_parity.py::test_fast_exp_matches_float64_exp).  NaN in, NaN out; -inf and x < -745 give 0, x > 709 inf.
+__device__ __forceinline__ float exp_f64_as_f32(float xf) {
+    const double x = fmin(fmax((double)xf, -750.0), 710.0);
+    const double k = rint(x * 1.44269504088896338700e+00);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+    const double a0 = 1.0 + r;
+    const double a1 = fma(r, 1.0 / 6, 1.0 / 2), a2 = fma(r, 1.0 / 120, 1.0 / 24), a3 = fma(r, 1.0 / 5040, 1.0 / 720);
+    const double a4 = fma(r, 1.0 / 362880, 1.0 / 40320), a5 = fma(r, 1.0 / 39916800, 1.0 / 3628800);
+    const double a6 = fma(r, 1.0 / 6227020800.0, 1.0 / 479001600);
+    const double b0 = fma(a1, r2, a0), b1 = fma(a3, r2, a2), b2 = fma(a5, r2, a4);
+    const double d0 = fma(b1, r4, b0), d1 = fma(a6, r4, b2);
+    const double p = fma(d1, r8, d0);
+    const float res = (float)ldexp(p, (int)k);
+    return xf == xf ? res : xf;
+}
+
 // ---------------------------------------------------------------- repack ---
 
 struct RepackParams {
@@ -914,7 +938,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
         P.out[row] = e_resid + v;
     } else if (EPI == EPI_SWIGLU) {
         // SiLU go/quant.go:629-631: x / (1 + f32(exp(f64(-x)))), then * up (go/model.go:604-606)
-        float ex = (float)exp((double)(-v));
+        float ex = exp_f64_as_f32(-v);
         P.out[row] = (v / (1.0f + ex)) * v1;
     }
     NL_STAMP(7);
@@ -1152,8 +1176,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
         float s0 = lane < n ? sc[g * ATT_CH + lane] : -INFINITY;
         float s1 = lane + 64 < n ? sc[g * ATT_CH + lane + 64] : -INFINITY;
         float m = wave_max_f32(fmaxf(s0, s1));
-        float p0 = lane < n ? (float)exp((double)(s0 - m)) : 0.f;       // go/quant.go:619
-        float p1 = lane + 64 < n ? (float)exp((double)(s1 - m)) : 0.f;
+        float p0 = lane < n ? exp_f64_as_f32(s0 - m) : 0.f;       // go/quant.go:619
+        float p1 = lane + 64 < n ? exp_f64_as_f32(s1 - m) : 0.f;
         if (lane < n) sc[g * ATT_CH + lane] = p0;
         if (lane + 64 < n) sc[g * ATT_CH + lane + 64] = p1;
         float l = wave_sum_f32(p0 + p1);

@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float gv = acc[0][t][j], uv = acc[1][t][j];
-                const float ex = (float)exp((double)(-gv));
+                const float ex = exp_f64_as_f32(-gv);
                 hb[(t * 16 + lw * 4 + j) * HS + wave * TR + li] = (gv / (1.0f + ex)) * uv;
             }
         __syncthreads();

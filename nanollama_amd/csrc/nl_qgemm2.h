@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const float gv = acc[r][t][j], uv = acc[r + 2][t][j];
-                    const float ex = (float)exp((double)(-gv));
+                    const float ex = exp_f64_as_f32(-gv);
                     hv[r][j] = (gv / (1.0f + ex)) * uv;
                 }
             float v[8];

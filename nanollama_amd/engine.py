@@ -79,7 +79,12 @@ class Engine:
         return int(order[hit[0]]) if len(hit) else int(order[0])
 
     def generate_ids(self, tokens: List[int], p: GenParams, on_token=None) -> List[int]:
-        """Engine.Generate go/main.go:152-230 on token ids (Encode/Decode stay with the tokenizer)."""
+        """Engine.Generate go/main.go:152-230 on token ids (Encode/Decode stay with the tokenizer).
+
+        on_token(id) is called for every generated non-EOS id; a truthy return value ends the generation after that
+        token -- the text layer uses it for the reference's 8192-byte output cap (`len(output) < 8192` in the loop
+        condition, go/main.go:173): no further token is sampled, the generator, the recent window and the token
+        counter stop where the Go loop's would."""
         m, cfg = self.model, self.model.config
         m.reset()
         # prefill, go/main.go:160-166: the Go loop forwards token after token and stops once pos reaches SeqLen-1;
@@ -108,9 +113,10 @@ class Engine:
                     if t == self.eos_id:
                         break
             if on_token:
-                for t in out:
-                    if t != self.eos_id:
-                        on_token(t)
+                for k, t in enumerate(out):
+                    if t != self.eos_id and on_token(t):
+                        del out[k + 1:]               # the loop condition fails before the next sample
+                        break
             recent = out[-self.rep_window:] if self.rep_window > 0 else []
         elif device_sampling:
             # the same loop with penalty, sampling and the recent window on the device (nl_sample_decode): no
@@ -124,7 +130,7 @@ class Engine:
                                                   self.rep_window, us, recent)
                 used, stop = len(ids), False
                 for i, t in enumerate(ids):
-                    if t == self.eos_id:
+                    if t == self.eos_id or (on_token and on_token(t)):   # EOS, or the output cap was reached with this piece
                         used, stop = i + 1, True
                         break
                 if used < k and p.temperature > 0:      # leave the generator where the per-token loop would be
@@ -138,10 +144,6 @@ class Engine:
                 else:
                     recent = new_recent
                 out.extend(ids[:used])
-                if on_token:
-                    for t in ids[:used]:
-                        if t != self.eos_id:
-                            on_token(t)
                 pos += used
                 remaining -= used
                 if stop or len(ids) < k:
@@ -164,11 +166,10 @@ class Engine:
                 out.append(nxt)
                 if nxt == self.eos_id:
                     break
-                if on_token:
-                    on_token(nxt)
+                capped = bool(on_token(nxt)) if on_token else False
                 m.forward(nxt, pos)
                 pos += 1
-                if pos >= cfg.seq_len:
+                if pos >= cfg.seq_len or capped:      # (capped: `len(output) < 8192` fails at the top of the next iteration)
                     break
         elapsed = time.perf_counter() - start
         # the reference counts len(recentTokens), capped by --rep-window (go/main.go:198-200,223)

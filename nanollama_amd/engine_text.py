@@ -23,16 +23,15 @@ class TextEngine:
         dec = codecs.getincrementaldecoder("utf-8")(errors="replace")
         out = bytearray()
 
-        def on_token(t: int):
+        def on_token(t: int) -> bool:
             # the reference loop runs while len(output) < 8192 (go/main.go:173): the piece that crosses the cap is
-            # the last one emitted
-            if len(out) >= 8192:
-                return
+            # the last one emitted, and returning True stops the id-level loop right there (no further sample)
             piece = self.tokenizer.decode_token_bytes(t)
             out.extend(piece)
             if stream is not None:
                 stream.write(dec.decode(piece))
                 stream.flush()
+            return len(out) >= 8192
 
         self.ids.generate_ids(tokens, p, on_token=on_token)
         if stream is not None:

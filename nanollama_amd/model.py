@@ -325,6 +325,17 @@ def op_sample(logits: np.ndarray, temperature: float, top_p: float, top_k: int, 
     return picked.value, lg, [int(rec[i]) for i in range(nrec.value)]
 
 
+def op_exp(x: np.ndarray, device: int = 0) -> np.ndarray:
+    """float32(exp(float64(x))) as the forward kernels compute it (go/quant.go:619, :629-631)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros_like(x)
+    fp = C.POINTER(C.c_float)
+    rc = _lib.lib().nl_op_exp(device, x.ctypes.data_as(fp), out.ctypes.data_as(fp), x.size)
+    if rc != 0:
+        raise _lib.NlError(rc, "nl_op_exp")
+    return out
+
+
 def op_rmsnorm(x: np.ndarray, w: np.ndarray, eps: float, device: int = 0) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.float32)
     w = np.ascontiguousarray(w, dtype=np.float32)

@@ -144,6 +144,24 @@ def test_rmsnorm_matches_oracle(hip, orc):
         assert np.abs(got - want).max() <= 1e-6 * (1 + np.abs(want).max())
 
 
+def test_fast_exp_matches_float64_exp(hip):
+    # Softmax / SiLU use float32(math.Exp(float64(x))) (go/quant.go:619, :629-631); the kernels compute it with a
+    # short-chain float64 exponential (exp_f64_as_f32): bit-identical float32 results over the ranges the forward
+    # pass feeds it (scores minus their maximum, minus the gate), denormal / overflow / NaN / infinity edges included
+    rng = np.random.Generator(np.random.PCG64(41))
+    x = np.concatenate([
+        (-np.abs(rng.standard_normal(1_500_000)) * rng.choice([0.1, 1.0, 8.0, 40.0], 1_500_000)).astype(np.float32),
+        (rng.standard_normal(1_500_000) * rng.choice([0.5, 4.0, 30.0], 1_500_000)).astype(np.float32),
+        rng.uniform(-110.0, 90.0, 1_000_000).astype(np.float32),
+        np.array([0.0, -0.0, 1.0, -1.0, -87.3, -88.0, -103.9, -104.0, -745.0, -746.0, -1e4, 88.7, 88.8, 709.0, 710.0, 1e4,
+                  np.inf, -np.inf, np.nan, 1e-30, -1e-30, 0.6931472, -0.6931472, 0.34657359, -0.34657359], np.float32)])
+    got = hip.op_exp(x)
+    with np.errstate(over="ignore", under="ignore"):
+        want = np.exp(x.astype(np.float64)).astype(np.float32)
+    same = (got == want) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), (int((~same).sum()), x[~same][:5], got[~same][:5], want[~same][:5])
+
+
 def _run_teacher_forced(hip, orc, path, tokens):
     g = gguf.load_gguf(path)
     dev = hip.load_llama_model(g)
@@ -371,7 +389,8 @@ def test_full_size_tiers_match_oracle(hip, orc, tmp_path, tier, wtype, ntok):
 def test_big_full_shape_matches_oracle(hip, orc, tmp_path):
     # BASELINE.json configs[4] at its own shape (nanollama/llama.py:50: 40 layers, D 4096, 64 heads / 16 kv heads,
     # FFN 11008, vocabulary 96000 -- 7.9B parameters, Q4_0): two teacher-forced tokens against the CPU oracle, on one
-    # GPU and as two tensor-parallel shards (the slicing and the partial sums of the 8-GPU plan, stepped in-process).
+    # GPU and as 2, 4 and 8 tensor-parallel shards (the slicing and the partial sums of the multi-GPU plans, stepped
+    # in-process on the one GPU).
     shape = synth.TIERS["big"]
     p = os.path.join(os.environ.get("NL_BENCH_DIR", "/tmp"), "nl_bench_big_q4_0_qrand.gguf")   # bench.py's file when present
     if not os.path.exists(p):
@@ -394,13 +413,15 @@ def test_big_full_shape_matches_oracle(hip, orc, tmp_path):
         assert d <= LOGIT_TOL * scale
         assert int(np.argmax(dev.state.logits)) == int(orc.argmax(wants[pos]))
     dev.close()
-    grp = hip.LocalTPGroup(g, 2)
-    for pos, t in enumerate(toks):
-        lg = grp.forward(t, pos)
-        d = float(np.abs(lg - wants[pos]).max())
-        print(f"big/q4_0 tp2 pos {pos}: max|tp-oracle|={d:.2e}")
-        assert d <= LOGIT_TOL * max(1.0, float(wants[pos].std()))
-    grp.close()
+    for n in (2, 4, 8):      # the shardings of the 1/2/4/8-GPU curve, full shape (8: 8 q heads + 2 kv heads, 1376 FFN rows per rank)
+        grp = hip.LocalTPGroup(g, n)
+        for pos, t in enumerate(toks):
+            lg = grp.forward(t, pos)
+            d = float(np.abs(lg - wants[pos]).max())
+            print(f"big/q4_0 tp{n} pos {pos}: max|tp-oracle|={d:.2e}")
+            assert d <= LOGIT_TOL * max(1.0, float(wants[pos].std()))
+            assert int(np.argmax(lg)) == int(orc.argmax(wants[pos]))
+        grp.close()
 
 
 def test_nano_full_size_long_greedy_run_matches_oracle(hip, orc, tmp_path):
