@@ -178,6 +178,7 @@ struct nl_engine {
         int cap = 0, lm_cap = 0;
         uint4 *xfrag = nullptr;  // fp16 hi/lo activation fragments of the GEMM being run
         uint4 *xfrag2 = nullptr; // second store: output of the fused gate/up/SwiGLU GEMM, input of down
+        double *ssq = nullptr;   // [cap][dim / 64] sums of squares of the residual rows (RMSNorm folded around the prompt GEMMs)
         float *kpart = nullptr, *kpart2 = nullptr;  // split-K partial sums (second buffer: up, alive beside gate)
         size_t kpart_cap = 0;    // floats, each
         float *x = nullptr, *qkv = nullptr, *q = nullptr, *g = nullptr, *u = nullptr, *logits = nullptr,
@@ -464,11 +465,6 @@ hipError_t launch_gemv_dyn(int wt, int pro, int epi, const GemvParams &P, hipStr
         if (P.nparts <= 9) return launch_gemv_t<PRO_NORM_PARTS, EPI_SWIGLU, 9>(wt, P, st);
         return launch_gemv_t<PRO_NORM_PARTS, EPI_SWIGLU, MAX_PARTS>(wt, P, st);
     }
-    if (pro == PRO_NORM_PARTS && epi == EPI_STORE) {   // the LM head behind a fused feed-forward block
-        if (P.nparts <= 4) return launch_gemv_t<PRO_NORM_PARTS, EPI_STORE, 4>(wt, P, st);
-        if (P.nparts <= 6) return launch_gemv_t<PRO_NORM_PARTS, EPI_STORE, 6>(wt, P, st);
-        return launch_gemv_t<PRO_NORM_PARTS, EPI_STORE, FFN_MAX_PARTS>(wt, P, st);
-    }
     if (pro == PRO_ATTN && epi == EPI_P2P) return launch_gemv_t<PRO_ATTN, EPI_P2P>(wt, P, st);
     if (pro == PRO_PLAIN && epi == EPI_P2P) return launch_gemv_t<PRO_PLAIN, EPI_P2P>(wt, P, st);
     return hipErrorInvalidValue;
@@ -553,7 +549,20 @@ void build_plan_blocks(nl_engine *e, std::vector<Op> &plan) {
                                                         : launch_attn_block<WT_Q4_0>(B, npin, grid, lds, st);
                                }});
         }
-        {
+        if (l == c.n_layers - 1) {
+            // last layer: gate/up and down as the two GEMV launches, so that the residual stream is complete in memory.
+            // (Measured: the feed-forward block here too, with the LM head adding the I / 256 partial vectors in its
+            // prologue -- 28 launches instead of 30 -- costs the LM head what it saves: its ~1000 workgroups each re-read
+            // seven vectors from L2, 6.5 -> 8.6 us, nano 5440 -> 5424 tok/s.)
+            GemvParams P = base_params(e, L.gate, 2);
+            P.q1 = L.up.q; P.s1 = L.up.s;
+            P.x = e->x[0]; P.normw = L.ffn_norm; P.out = e->hb;
+            P.parts = e->parts; P.nparts = e->Hs; P.x_out = e->x[1];
+            push_gemv(plan, K_GATEUP, 0, nullptr, 0, L.gate.wtype, PRO_NORM_PARTS, EPI_SWIGLU, P);
+            GemvParams Q = base_params(e, L.down);
+            Q.x = e->hb; Q.out = e->x[1]; Q.resid = e->x[1];
+            push_gemv(plan, K_DOWN, 0, nullptr, 0, L.down.wtype, PRO_PLAIN, EPI_RESID, Q);
+        } else {
             FfnParams F{};
             F.gate_q = L.gate.q; F.gate_s = L.gate.s; F.up_q = L.up.q; F.up_s = L.up.s; F.dn_q = L.dn_slice.q; F.dn_s = L.dn_slice.s;
             F.D = c.dim; F.I = e->Is; F.npairs = L.gate.npairs;
@@ -568,15 +577,13 @@ void build_plan_blocks(nl_engine *e, std::vector<Op> &plan) {
         }
     }
     int lm_blocks, lm_spb;
-    {   // final RMSNorm + LM head (go/model.go:616-619); its prologue adds the last feed-forward block's partial vectors
-        // (I / 256 of them, a few KB per workgroup from L2) like every other consumer of a block: 2 L + 3 launches per token
+    {   // final RMSNorm + LM head (go/model.go:616-619)
         GemvParams P = base_params(e, e->lm_head);
         P.x = e->x[1]; P.normw = e->output_norm;
-        P.parts = e->parts_ffn; P.nparts = nslices;
         P.out = e->logits; P.amax_val = e->amax_val; P.amax_idx = e->amax_idx;
         lm_blocks = (P.ntiles + P.tw - 1) / P.tw;
         lm_spb = (P.tw * TR + 63) / 64;
-        push_gemv(plan, K_LMHEAD, 0, e->logits, (size_t)e->Vs, e->lm_head.wtype, PRO_NORM_PARTS, EPI_STORE, P);
+        push_gemv(plan, K_LMHEAD, 0, e->logits, (size_t)e->Vs, e->lm_head.wtype, PRO_NORM, EPI_STORE, P);
     }
     {
         ArgmaxParams P{e->logits, c.vocab, e->amax_val, e->amax_idx, lm_blocks * lm_spb, e->ctl, e->ids, e->result};
@@ -993,6 +1000,10 @@ bool qgemm2_ok(int wtype, int n_tokens) {
     const int min_n = knob ? atoi(knob) : 128;
     return wtype == WT_Q4_0 && n_tokens >= min_n;
 }
+// the plain GEMM of a long Q4_0 token run whose unsplit 64-row x 64-token grid fills the chip: qgemm2_kernel, no split-K
+bool qgemm2_plain_unsplit(int wtype, int ntiles, int n_tokens) {
+    return qgemm2_ok(wtype, n_tokens) && ((ntiles + 3) / 4) * ((n_tokens + QG_TOK - 1) / QG_TOK) >= 128;
+}
 template <int EPI>
 hipError_t launch_qgemm2(const QGemmParams &P, int row_blocks, hipStream_t st) {
     if ((long long)row_blocks * ((P.n_tokens + 255) / 256) >= 512)
@@ -1060,12 +1071,13 @@ hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_bu
     const int tok_tiles = (P.n_tokens + QG_TOK - 1) / QG_TOK;
     const int nchunks = (P.cols / 32 + QG_KC - 1) / QG_KC;
     const int mats = P.q1 ? 2 : 1;
-    if (qgemm2_ok(wtype, P.n_tokens) && mats == 1 && ((P.ntiles + 3) / 4) * tok_tiles >= 128) {   // unsplit grid fills the chip
+    if (qgemm2_plain_unsplit(wtype, P.ntiles, P.n_tokens) && mats == 1) {   // unsplit grid fills the chip
         P.ksplit = 1;
         P.part = nullptr;
         if (ks_out) *ks_out = 1;
         return launch_qgemm2<QG_EPI_PLAIN>(P, (P.ntiles + 3) / 4, st);
     }
+    if (P.nrm_out.w) return hipErrorInvalidValue;   // (the folded norm's producer epilogue exists in qgemm2_kernel only: host logic error)
     // Workgroup height: 128 rows (8 wavefronts) when that alone fills the chip, else 64 rows (4 wavefronts) --
     // twice the workgroups and half the split-K for the small-N decode batches (goldie shapes at 16-128 tokens:
     // -4...-18 % per launch, tools/qgemm_variants.sh); then split K until ~128 workgroups exist.
@@ -1165,11 +1177,12 @@ int batch_alloc(nl_engine *e) {
         float *raw = nullptr;
         HIPCK(e, dalloc(&raw, nx * 4, &e->bytes_state));
         b.xfrag = reinterpret_cast<uint4 *>(raw);
-        const size_t nx2 = xfrag_uint4(e->Is, (int)n);   // SiLU(gate) * up, written by the fused gate/up GEMM
+        const size_t nx2 = xfrag_uint4(std::max(e->Is, c.dim), (int)n);   // SiLU(gate) * up, written by the fused gate/up GEMM (or the folded norm's fragments)
         raw = nullptr;
         HIPCK(e, dalloc(&raw, nx2 * 4, &e->bytes_state));
         b.xfrag2 = reinterpret_cast<uint4 *>(raw);
     }
+    HIPCK(e, dalloc(&b.ssq, n * (size_t)((c.dim + 63) / 64), &e->bytes_state));
     b.kpart_cap = (size_t)16 * QG_TOK * std::max<size_t>(std::max<size_t>(R, c.dim), e->Is);
     HIPCK(e, dalloc(&b.kpart, b.kpart_cap, &e->bytes_state));
     HIPCK(e, dalloc(&b.kpart2, b.kpart_cap, &e->bytes_state));
@@ -1187,9 +1200,11 @@ int batch_alloc(nl_engine *e) {
 // GEMM of the multi-token step: input = the fragment store the producing kernel just filled; output = `out`
 // (with resid / bias applied) when it ran unsplit, else split-K slabs in `part` for the consumer to add.
 hipError_t qg(nl_engine *e, const PackedMat &m, int n, float *out, int ldo, const float *resid, hipStream_t st,
-              GemmOut *res, float *part, const float *bias = nullptr, const uint4 *xf = nullptr) {
+              GemmOut *res, float *part, const float *bias = nullptr, const uint4 *xf = nullptr,
+              const QGemmParams::NormOut *nout = nullptr) {
     QGemmParams P{};
     P.bias = bias;
+    if (nout) P.nrm_out = *nout;
     P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
     P.xf = xf ? xf : e->bt.xfrag; P.n_tokens = n; P.out = out; P.ldo = ldo; P.resid = resid;
     int ks = 1;
@@ -1230,6 +1245,22 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
     for (int i = 1; i < n && consecutive; i++) consecutive = b.h_meta[b.cap + i] == b.h_meta[b.cap] + i;
     nsplit = std::min(nsplit, e->nsplit_max);
     GemmOut pend{nullptr, nullptr, 1, 0, nullptr};   // GEMM output not yet folded into the residual stream
+    // RMSNorm folded around the GEMMs (QGemmParams::NormOut / NormIn): when WO and down run unsplit on qgemm2_kernel and
+    // their consumers are the fused-epilogue GEMMs of the same kernel -- a Q4_0 prompt -- the producing GEMM writes the
+    // next GEMM's fragments and per-block sums of squares itself and the two bnorm launches per layer disappear (mini,
+    // 2047 tokens: 2 x 8.7 us of 187 us per layer).  Fragment stores then alternate: the consumer of a producing GEMM
+    // reads xfrag2, everything else xfrag.
+    const char *fk = getenv("NL_FOLD_NORM");   // knob (tests, tools; read per step so a test can flip it): 0 keeps the bnorm launches
+    const bool fold_knob = !(fk && atoi(fk) == 0);
+    bool fold = fold_knob && !c.qk_norm && D % 64 == 0 && c.n_layers > 0;
+    for (int l = 0; l < c.n_layers && fold; l++) {
+        const nl_engine::Layer &L = e->layers[l];
+        fold = qgemm2_plain_unsplit(L.wo.wtype, L.wo.ntiles, n) && qgemm2_plain_unsplit(L.down.wtype, L.down.ntiles, n) &&
+               L.wo.ntiles % 4 == 0 && L.down.ntiles % 4 == 0 &&
+               qgemm2_ok(L.qkv.wtype, n) && qgemm_rope_fits(L.qkv.ntiles, n) &&
+               L.up.wtype == L.gate.wtype && qgemm2_ok(L.gate.wtype, n) && qgemm_swiglu_fits(L.gate.ntiles, n);
+    }
+    const QGemmParams::NormIn nin_on{b.ssq, D / 64, D, c.rms_eps}, nin_off{nullptr, 0, 0, 0.f};
     auto norm = [&](const float *w, const PackedMat &next, int item0, int cnt) {
         BNormParams P{b.x, pend, w, c.rms_eps, D, item0, b.xfrag, ((cnt + 63) / 64) * 4, next.wtype == WT_Q4_0 ? 1 : 0};
         const int nu = D / 8;
@@ -1244,13 +1275,15 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
         nl_engine::Layer &L = e->layers[l];
         float *kc = e->kcache + (long long)l * e->kv_layer_stride;
         float *vc = e->vcache + (long long)l * e->kv_layer_stride;
-        LCK(norm(L.attn_norm, L.qkv, 0, n));
+        const bool folded_in = fold && l > 0;      // the previous layer's down GEMM wrote this layer's Q|K|V input
+        if (!folded_in) LCK(norm(L.attn_norm, L.qkv, 0, n));
         if (!c.qk_norm && qgemm_rope_fits(L.qkv.ntiles, n)) {
             // Q|K|V, RoPE, biases and the KV store in ONE launch (QK-norm needs whole heads: unfused path)
             QGemmParams P{};
             const PackedMat &m = L.qkv;
             P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
-            P.xf = b.xfrag; P.n_tokens = n; P.ldo = (int)R;
+            P.xf = folded_in ? b.xfrag2 : b.xfrag; P.nrm_in = folded_in ? nin_on : nin_off;
+            P.n_tokens = n; P.ldo = (int)R;
             P.rope = QGemmParams::Rope{b.pos, b.stream, e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride,
                                        L.bq, L.bk, L.bv, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate};
             LCK(launch_qgemm_rope(m.wtype, P, st));
@@ -1299,8 +1332,13 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
             }
             LCK(hipGetLastError());
         }
-        LCK(qg(e, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo));
-        LCK(norm(L.ffn_norm, L.gate, 0, n));
+        if (fold) {
+            const QGemmParams::NormOut nout{L.ffn_norm, b.xfrag2, b.ssq, L.gate.wtype == WT_Q4_0 ? 1 : 0};
+            LCK(qg(e, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo, nullptr, &nout));
+        } else {
+            LCK(qg(e, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo));
+            LCK(norm(L.ffn_norm, L.gate, 0, n));
+        }
         if (L.up.wtype != L.gate.wtype)   // (a mixed-type file: the fragment k-slot order differs per type)
             return e->fail(NL_ERR_UNSUPPORTED, "gate and up projections of different quantisation types");
         const uint4 *down_in = b.xfrag;
@@ -1310,11 +1348,12 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
             QGemmParams P{};
             const PackedMat &m = L.gate;
             P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
-            P.xf = b.xfrag; P.n_tokens = n; P.ldo = e->Is;
+            P.xf = fold ? b.xfrag2 : b.xfrag; P.nrm_in = fold ? nin_on : nin_off;
+            P.n_tokens = n; P.ldo = e->Is;
             P.q1 = L.up.q; P.s1 = L.up.s;
-            P.xf_out = b.xfrag2; P.out_q4 = L.down.wtype == WT_Q4_0 ? 1 : 0;
+            P.xf_out = fold ? b.xfrag : b.xfrag2; P.out_q4 = L.down.wtype == WT_Q4_0 ? 1 : 0;
             LCK(launch_qgemm_swiglu(m.wtype, P, st));
-            down_in = b.xfrag2;
+            down_in = P.xf_out;
         } else {
             GemmOut gate, up;
             {   // gate and up in ONE launch: same input fragments, twice the workgroups, half the split-K
@@ -1333,7 +1372,13 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
             hipLaunchKernelGGL(bswiglu_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 4096)), dim3(256), 0, st, P);
             LCK(hipGetLastError());
         }
-        LCK(qg(e, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in));
+        if (fold && l + 1 < c.n_layers) {
+            const nl_engine::Layer &Ln = e->layers[l + 1];
+            const QGemmParams::NormOut nout{Ln.attn_norm, b.xfrag2, b.ssq, Ln.qkv.wtype == WT_Q4_0 ? 1 : 0};
+            LCK(qg(e, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in, &nout));
+        } else {
+            LCK(qg(e, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in));
+        }
     }
     if (lm_mode) {
         // logits rows [0, cnt) of bt.logits / ids [0, cnt): all tokens (mode 1, n <= lm_cap) or just the last (mode 2)
@@ -1720,8 +1765,7 @@ int nl_finalize(nl_handle e) {
             bool okf = e->fused_mode == 1 && !(ff && atoi(ff) == 0);
             for (const auto &L : e->layers)
                 okf = okf && L.dn_slice.ready && L.dn_slice.wtype == L.qkv.wtype && L.gate.wtype == L.qkv.wtype && L.up.wtype == L.qkv.wtype;
-            // (the LM head behind the last feed-forward block adds its partial vectors: PRO_NORM_PARTS exists for Q8_0 / Q4_0)
-            e->ffn_fused = okf && (e->lm_head.wtype == WT_Q8_0 || e->lm_head.wtype == WT_Q4_0);
+            e->ffn_fused = okf;
         }
         if (e->ffn_fused) {
             HIPCK(e, dalloc(&e->parts_ffn, (size_t)(e->Is / FFN_SLICE) * c.dim, &e->bytes_state));
@@ -1815,7 +1859,7 @@ int nl_destroy(nl_handle e) {
     {
         nl_engine::Batch &b = e->bt;
         void *bb[] = {b.x, b.qkv, b.q, b.g, b.u, b.logits, b.part_o, b.part_ml, b.tok /* | pos | stream */, b.ids, b.kpart, b.kpart2,
-                      b.xfrag, b.xfrag2};
+                      b.xfrag, b.xfrag2, b.ssq};
         for (void *p : bb) if (p) hipFree(p);
         if (b.h_meta) hipHostFree(b.h_meta);
     }

@@ -72,6 +72,24 @@ struct QGemmParams {
         const float *bias_q, *bias_k, *bias_v;
         int head_dim, n_q_heads, n_kv_heads, seq_len, conj;
     } rope;
+    // RMSNorm (go/quant.go:597-607) folded around the GEMMs of a prompt (nl_qgemm2.h).  A producer -- WO or down with
+    // the plain epilogue, unsplit, so its lanes hold finished rows of the new residual stream -- also emits those rows
+    // as the NEXT GEMM's fragments, multiplied by that GEMM's norm weights but not yet by 1 / rms, plus one float64
+    // sum of squares per (token, 64-row block).  The consumer (Q|K|V with the RoPE epilogue, gate || up with the
+    // SwiGLU epilogue) adds a token's partial sums in block order and scales its OUTPUT by inv, exactly as the decode
+    // GEMV does (nl_kernels.h: out = inv * sum_j w_ij (x_j g_j)).  No bnorm launch, no second pass over x.
+    struct NormOut {
+        const float *w;      // [rows] norm weights of the consuming GEMM; nullptr = not folded
+        uint4 *xf;           // fragment store the consumer reads
+        double *ssq;         // [n_tokens][rows / 64]
+        int q4;              // k-slot order of the consumer's weight type
+    } nrm_out;
+    struct NormIn {
+        const double *ssq;   // nullptr = the input fragments are already normalised
+        int nrb;             // partial sums per token (dim / 64)
+        int dim;
+        float eps;
+    } nrm_in;
 };
 
 inline size_t xfrag_uint4(int cols, int n_tokens) {   // uint4 elements of a fragment store

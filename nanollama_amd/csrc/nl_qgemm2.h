@@ -218,6 +218,32 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
     }
 
     QG2_STAMP(1 + it_ * 8);
+    // folded RMSNorm, consumer side: inv of this lane's tokens from the producer's per-block sums of squares (block order:
+    // deterministic), applied to the accumulators before bias / RoPE / SiLU -- the decode GEMV's "scale the output" form
+    [[maybe_unused]] float inv[NTW];
+    if constexpr (EPI != QG_EPI_PLAIN) {
+#pragma unroll
+        for (int t = 0; t < NTW; t++) inv[t] = 1.0f;
+        if (P.nrm_in.ssq) {
+#pragma unroll
+            for (int t = 0; t < NTW; t++) {
+                const double *sp = P.nrm_in.ssq + (size_t)min((ttile0 + t) * 16 + li, P.n_tokens - 1) * P.nrm_in.nrb;
+                double tot = 0.0;
+                for (int r0 = 0; r0 < P.nrm_in.nrb; r0 += 8) {    // eight partial sums per memory round trip (clamped, masked)
+                    double v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v[k] = sp[min(r0 + k, P.nrm_in.nrb - 1)];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) tot += r0 + k < P.nrm_in.nrb ? v[k] : 0.0;
+                }
+                inv[t] = (float)(1.0 / sqrt(tot / (double)P.nrm_in.dim + (double)P.nrm_in.eps));
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                for (int t = 0; t < NTW; t++) acc[rt][t] = acc[rt][t] * inv[t];
+        }
+    }
     if constexpr (EPI == QG_EPI_SWIGLU) {
         // h = SiLU(gate) * up (go/quant.go:629-631, go/model.go:604-606).  A lane holds rows 4*lq..+3 of both 16-row tiles of
         // one token, i.e. the float4 groups lq and 4 + lq of the workgroup's 32-row block of h: for a Q4_0 consumer those
@@ -336,7 +362,57 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
                 if (bias) { v.x += bv[rt].x; v.y += bv[rt].y; v.z += bv[rt].z; v.w += bv[rt].w; }
                 if (resid) { v.x += rv[t][rt].x; v.y += rv[t][rt].y; v.z += rv[t][rt].z; v.w += rv[t][rt].w; }
                 if ((ttile0 + t) * 16 + li < P.n_tokens) *reinterpret_cast<float4 *>(dst + off[t][rt]) = v;
+                acc[rt][t] = (f32x4_t){v.x, v.y, v.z, v.w};
             }
+        if constexpr (RT % 2 == 0) {
+            if (P.nrm_out.w && !split) {
+                // folded RMSNorm, producer side (QGemmParams::NormOut): acc now holds rows row0 + 16 rt + 4 lq .. + 3 of the new
+                // residual stream for token (ttile0 + t) * 16 + li.  Sum of squares of the workgroup's 64 rows per token
+                // (float64, fixed order: a lane's 16 values, then the four lanes of a token), and x * g as the consumer's
+                // fragments -- tiles 2b and 2b + 1 are one 32-column block, and for a Q4_0 consumer the two float4 groups of
+                // k-slot group lq are exactly this lane's (as in the SwiGLU epilogue above).
+                float4 gw[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) gw[rt] = *reinterpret_cast<const float4 *>(P.nrm_out.w + row0 + rt * TR + lq * 4);
+#pragma unroll
+                for (int t = 0; t < NTW; t++) {
+                    const int n = (ttile0 + t) * 16 + li;
+                    double ss = 0.0;
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) ss = fma((double)acc[rt][t][j], (double)acc[rt][t][j], ss);
+                    ss += __shfl_xor(ss, 16);
+                    ss += __shfl_xor(ss, 32);
+                    if (lq == 0 && n < P.n_tokens) P.nrm_out.ssq[(size_t)n * (P.rows / 64) + blockIdx.x * (RT / 4)] = ss;
+#pragma unroll
+                    for (int b = 0; b < RT / 2; b++) {
+                        float y[2][4];
+#pragma unroll
+                        for (int r = 0; r < 2; r++) {
+                            const float4 g = gw[2 * b + r];
+                            y[r][0] = acc[2 * b + r][t][0] * g.x; y[r][1] = acc[2 * b + r][t][1] * g.y;
+                            y[r][2] = acc[2 * b + r][t][2] * g.z; y[r][3] = acc[2 * b + r][t][3] * g.w;
+                        }
+                        float v[8];
+                        int w;
+                        if (P.nrm_out.q4) {
+                            w = lq;
+                            slots_from(1, make_float4(y[0][0], y[0][1], y[0][2], y[0][3]), make_float4(y[1][0], y[1][1], y[1][2], y[1][3]), v);
+                        } else {
+                            float got[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) got[j] = __shfl_xor((lq & 1) ? y[0][j] : y[1][j], 16);
+                            w = (lq & 1) ? 2 + (lq >> 1) : (lq >> 1);
+                            const float4 a = (lq & 1) ? make_float4(got[0], got[1], got[2], got[3]) : make_float4(y[0][0], y[0][1], y[0][2], y[0][3]);
+                            const float4 bb = (lq & 1) ? make_float4(y[1][0], y[1][1], y[1][2], y[1][3]) : make_float4(got[0], got[1], got[2], got[3]);
+                            slots_from(0, a, bb, v);
+                        }
+                        if (n < P.n_tokens) store_frag(P.nrm_out.xf, P.nt16, n, row0 / 32 + b, w, v);
+                    }
+                }
+            }
+        }
         QG2_STAMP(2 + it_ * 8);
         return;
     }

@@ -715,6 +715,7 @@ def test_q4_prompt_gemm_through_lds_matches_the_per_wavefront_kernel(hip, orc, t
     for pos, t in enumerate(toks):
         want = ref.forward(t, pos)
     outs = []
+    monkeypatch.setenv("NL_FOLD_NORM", "0")     # (the folded RMSNorm scales the consumer's output instead of its input: own test below)
     for knob in (None, "1000000"):
         if knob is None:
             monkeypatch.delenv("NL_QG2_MIN_TOKENS", raising=False)
@@ -730,6 +731,49 @@ def test_q4_prompt_gemm_through_lds_matches_the_per_wavefront_kernel(hip, orc, t
     assert outs[0][1] == outs[1][1]
     err = float(np.abs(outs[0][0] - want).max())
     assert err <= LOGIT_TOL * max(1.0, float(want.std()))
+
+
+@pytest.mark.parametrize("wt_variant", ["q4_0", "q4_0_bias_conj"])
+def test_prompt_with_rmsnorm_folded_into_the_gemms_matches_oracle(hip, orc, tmp_path, monkeypatch, wt_variant):
+    # Long Q4_0 prompts run without bnorm launches: the WO / down GEMM epilogues emit the next GEMM's fragments (x * g) and
+    # per-64-row sums of squares, the consuming GEMM scales its output by inv (go/quant.go:597-607 restated as the decode
+    # GEMV restates it).  1100 tokens of a 3-layer D = 512 GQA model (every GEMM grid >= 128 workgroups, the folding
+    # condition): logits and the next greedy ids against the oracle, and against the same prompt with NL_FOLD_NORM=0
+    # (close, but not bit-identical -- which also shows that the folded path is the one that ran).
+    shape = synth.ModelShape("fold_probe", 3, 512, 8, 4, 1024, seq_len=1200, interm=1536,
+                             rope_conjugate=wt_variant != "q4_0", attn_bias=wt_variant != "q4_0")
+    p = tmp_path / "f.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", 29)
+    g = gguf.load_gguf(str(p))
+    n = 1100
+    toks = synth.prompt_ids(n, shape.vocab, seed=6)
+    ref = orc.OracleModel(g)
+    orc.set_threads(min(16, os.cpu_count() or 1))
+    for pos, t in enumerate(toks):
+        want = ref.forward(t, pos).copy()
+    ref_ids = []
+    tok = int(orc.argmax(want))
+    for k in range(4):
+        ref_ids.append(tok)
+        tok = int(orc.argmax(ref.forward(tok, n + k)))
+    orc.set_threads(1)
+    outs = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("NL_FOLD_NORM", knob)
+        dev = hip.load_llama_model(g)
+        dev.prefill(toks)
+        logits = dev.state.logits.copy()
+        first = int(np.argmax(logits))
+        outs[knob] = (logits, [first] + dev.decode_greedy(first, n, 3))
+        dev.close()
+    scale = max(1.0, float(want.std()))
+    for knob, (logits, ids) in outs.items():
+        err = float(np.abs(logits - want).max())
+        print(f"\nfolded norm {wt_variant} NL_FOLD_NORM={knob}: max|gpu-oracle|={err:.2e} (logit std {scale:.2f})")
+        assert err <= LOGIT_TOL * scale
+        assert ids == ref_ids
+    assert not np.array_equal(outs["1"][0], outs["0"][0])
+    ref.close()
 
 
 def test_mini_full_size_long_prefill_matches_oracle(hip, orc, tmp_path):
