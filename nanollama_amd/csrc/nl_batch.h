@@ -6,16 +6,7 @@
 
 namespace nl {
 
-// A multi-token GEMM result as its consumer sees it: final values, or -- when the GEMM ran split-K -- the ks
-// partial-sum slabs, which the consumer adds in ascending z order (then bias), exactly as qgemm_sum_kernel does.
-// Folding the reduction into the consumer removes one launch per GEMM from the batched-decode step.
-struct GemmOut {
-    const float *val;     // [N][ld], used when ks <= 1 (bias / residual already applied by the GEMM epilogue)
-    const float *part;    // [ks][N][ld]
-    int ks;
-    long long zstride;    // N * ld
-    const float *bias;    // optional [ld], applied after the partials when ks > 1
-};
+// (struct GemmOut: nl_kernels.h, beside AttnParams)
 
 __device__ __forceinline__ float gemm_out_at(const GemmOut &g, long long idx, int col) {
     if (g.ks <= 1) return g.val[idx];
@@ -49,6 +40,43 @@ __device__ __forceinline__ void gemm_out_at2(const GemmOut &g, long long ia, int
         for (int k = 0; k < 8; k++) { a += z0 + k < g.ks ? pa[k] : 0.f; b += z0 + k < g.ks ? pb[k] : 0.f; }
     }
     if (g.bias) { a += g.bias[ca]; b += g.bias[cb]; }
+}
+
+// RoPE prologue of attn_kernel<HD, G, FIN> (decode batches whose Q|K|V GEMM ran split-K): the rows of this workgroup's
+// kv group -- G query heads, one K and one V head of one token -- are summed from the GEMM's slabs, biased, rotated
+// (go/model.go:449-477, :525-527) and handed to the attention through LDS; the K / V rows also go to the cache
+// (go/model.go:552-554).  What brope_kv_kernel does per token, done per (token, kv head) by the consumer: one launch less
+// per layer.  Element e of a head sits at packed row (head * hd/16 + (e % half) / 8) * 16 + (e % half) % 8 + 8 * (e / half)
+// (ROWMAP_HEADPERM), its rotation partner at that row ^ 8.
+template <int HD, int G>
+__device__ void attn_rope_prologue(const AttnParams &P, int kvh, int item, int pos, long long soff, float *qs, float *krow, float *vcur) {
+    constexpr int half = HD / 2, tph = HD / 16;
+    const AttnParams::Rope &R = P.rp;
+    const long long src0 = (long long)item * R.R;
+    for (int i = threadIdx.x; i < (G + 2) * HD; i += ATT_THREADS) {
+        const int hs = i / HD, e = i % HD, ih = e % half, hi = e / half;
+        const int head = hs < G ? kvh * G + hs : hs == G ? R.n_q_heads + kvh : R.n_q_heads + P.n_kv_heads + kvh;
+        const int rho = (head * tph + ih / 8) * 16 + (ih % 8) + 8 * hi;
+        const float rc = R.cos[pos * half + ih], rs = R.sin[pos * half + ih];   // (requested with the slabs: one round trip)
+        float v, partner;
+        gemm_out_at2(R.qkv, src0 + rho, rho, src0 + (rho ^ 8), rho ^ 8, v, partner);
+        if (R.bias_q) {
+            const float *bp = hs < G ? R.bias_q + (kvh * G + hs) * HD : hs == G ? R.bias_k + kvh * HD : R.bias_v + kvh * HD;
+            v += bp[e];
+            partner += bp[e ^ half];
+        }
+        float outv = v;
+        if (hs <= G) {
+            const float x0 = hi == 0 ? v : partner, x1 = hi == 0 ? partner : v;
+            if (!R.conj) outv = hi == 0 ? (x0 * rc - x1 * rs) : (x0 * rs + x1 * rc);
+            else outv = hi == 0 ? (x0 * rc + x1 * rs) : (-x0 * rs + x1 * rc);
+        }
+        if (hs < G) qs[hs * HD + e] = outv;
+        else {
+            (hs == G ? krow : vcur)[e] = outv;
+            (hs == G ? R.kcache_w : R.vcache_w)[soff + ((long long)kvh * P.seq_len + pos) * HD + e] = outv;
+        }
+    }
 }
 
 // two float4 groups at once (the a / b halves of an 8-slot unit), slabs fetched eight at a time for both

@@ -1058,6 +1058,16 @@ hipError_t launch_qgemm_rope(int wtype, QGemmParams P, hipStream_t st) {
 
 template <int WT, int WAVES, int RT = QG_RT>
 void launch_qgemm_nt(int nt, dim3 grid, hipStream_t st, const QGemmParams &P) {
+    // one 64-token tile (decode batches, short prompts) in 64-row workgroups: fragments staged through registers (RSTAGE)
+    static const bool rstage_knob = !(getenv("NL_QG_RSTAGE") && atoi(getenv("NL_QG_RSTAGE")) == 0);   // developer knob (tools/)
+    if (WAVES == 4 && RT == 1 && grid.y == 1 && rstage_knob) {
+        switch (nt) {
+        case 1: hipLaunchKernelGGL((qgemm_kernel<WT, 4, 1, QG_EPI_PLAIN, 1, true>), grid, dim3(256), 0, st, P); break;
+        case 2: hipLaunchKernelGGL((qgemm_kernel<WT, 4, 1, QG_EPI_PLAIN, 2, true>), grid, dim3(256), 0, st, P); break;
+        default: hipLaunchKernelGGL((qgemm_kernel<WT, 4, 1, QG_EPI_PLAIN, 4, true>), grid, dim3(256), 0, st, P); break;
+        }
+        return;
+    }
     switch (nt) {
     case 1: hipLaunchKernelGGL((qgemm_kernel<WT, WAVES, RT, QG_EPI_PLAIN, 1>), grid, dim3(WAVES * 64), 0, st, P); break;
     case 2: hipLaunchKernelGGL((qgemm_kernel<WT, WAVES, RT, QG_EPI_PLAIN, 2>), grid, dim3(WAVES * 64), 0, st, P); break;
@@ -1244,6 +1254,10 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
     bool consecutive = true;   // positions pos0, pos0 + 1, ...: a prompt
     for (int i = 1; i < n && consecutive; i++) consecutive = b.h_meta[b.cap + i] == b.h_meta[b.cap] + i;
     nsplit = std::min(nsplit, e->nsplit_max);
+    const bool tile_attn = one_stream && n >= 8 && attn_tile_supported(e->gqa) && !no_tile;   // prompts: attn_tile16_kernel
+    const bool fin_attn = !tile_attn && nsplit == 1 && !no_fin;                                 // one split: attn_kernel<..., FIN>
+    const char *rk = getenv("NL_ROPE_IN_ATTN");    // knob (tests, tools; read per step): 0 keeps the brope_kv launch
+    const bool rope_attn_knob = !(rk && atoi(rk) == 0);
     GemmOut pend{nullptr, nullptr, 1, 0, nullptr};   // GEMM output not yet folded into the residual stream
     // RMSNorm folded around the GEMMs (QGemmParams::NormOut / NormIn): when WO and down run unsplit on qgemm2_kernel and
     // their consumers are the fused-epilogue GEMMs of the same kernel -- a Q4_0 prompt -- the producing GEMM writes the
@@ -1275,6 +1289,8 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
         nl_engine::Layer &L = e->layers[l];
         float *kc = e->kcache + (long long)l * e->kv_layer_stride;
         float *vc = e->vcache + (long long)l * e->kv_layer_stride;
+        GemmOut qkv_out{nullptr, nullptr, 1, 0, nullptr};
+        bool rope_in_attn = false;
         const bool folded_in = fold && l > 0;      // the previous layer's down GEMM wrote this layer's Q|K|V input
         if (!folded_in) LCK(norm(L.attn_norm, L.qkv, 0, n));
         if (!c.qk_norm && qgemm_rope_fits(L.qkv.ntiles, n)) {
@@ -1288,9 +1304,13 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
                                        L.bq, L.bk, L.bv, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate};
             LCK(launch_qgemm_rope(m.wtype, P, st));
         } else {
-            GemmOut qkv;
-            LCK(qg(e, L.qkv, n, b.qkv, R, nullptr, st, &qkv, b.kpart));
-            {
+            LCK(qg(e, L.qkv, n, b.qkv, R, nullptr, st, &qkv_out, b.kpart));
+            // decode batches (every token its own stream: no token of the step attends over another's K / V row) below
+            // position 128 (one attention split, the FIN kernel), no QK-norm: the attention launch rotates and stores its
+            // own q / k / v rows (attn_rope_prologue) -- no brope_kv launch
+            rope_in_attn = fin_attn && !one_stream && !c.qk_norm && rope_attn_knob;
+            if (!rope_in_attn) {
+                const GemmOut &qkv = qkv_out;
                 BRopeParams P{qkv, R, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate, c.qk_norm, c.rms_eps, b.pos, b.stream,
                               e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride, L.bq, L.bk, L.bv};
                 // few tokens (decode batches): one element per thread where the row fits, so the per-element chain (slabs ->
@@ -1313,9 +1333,11 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
                 T.pos_base = b.h_meta[b.cap];
                 LCK(hd == 64 ? launch_attn_tile_hd<64>(e->gqa, T, n, e->KVs, nsplit, st)
                              : launch_attn_tile_hd<32>(e->gqa, T, n, e->KVs, nsplit, st));
-            } else if (nsplit == 1 && !no_fin) {
+            } else if (fin_attn) {
                 // every position < 128: one split per row, the attention kernel normalises and writes the fragments
                 P.fin_xf = b.xfrag; P.fin_nt16 = nt16; P.fin_q4 = L.wo.wtype == WT_Q4_0 ? 1 : 0;
+                if (rope_in_attn)
+                    P.rp = AttnParams::Rope{1, qkv_out, (int)R, e->Hs, c.rope_conjugate, e->rope_cos, e->rope_sin, L.bq, L.bk, L.bv, kc, vc};
                 LCK(hd == 64 ? launch_attn_fin_hd<64>(e->gqa, P, dim3(e->KVs, 1, n), st)
                              : launch_attn_fin_hd<32>(e->gqa, P, dim3(e->KVs, 1, n), st));
                 merged = true;

@@ -1027,6 +1027,17 @@ __global__ void embed_kernel(EmbedParams P) {
 
 // ------------------------------------------------------------- attention ---
 
+// A multi-token GEMM result as its consumer sees it (nl_batch.h): final values, or -- when the GEMM ran split-K -- the ks
+// partial-sum slabs, which the consumer adds in ascending z order (then bias), exactly as qgemm_sum_kernel does.
+// Folding the reduction into the consumer removes one launch per GEMM from the batched-decode step.
+struct GemmOut {
+    const float *val;     // [N][ld], used when ks <= 1 (bias / residual already applied by the GEMM epilogue)
+    const float *part;    // [ks][N][ld]
+    int ks;
+    long long zstride;    // N * ld
+    const float *bias;    // optional [ld], applied after the partials when ks > 1
+};
+
 struct AttnParams {
     const float *qbuf;             // [n_q_heads][hd], RoPE applied
     const float *kcache, *vcache;  // this layer, stream 0: [kv][seq][hd]
@@ -1047,10 +1058,22 @@ struct AttnParams {
     // attn_tile16_kernel: the step's positions are pos_base + item (a prompt) when pos_base_valid -- the workgroup then
     // knows its key range without reading bpos, and its K / V requests leave at entry
     int pos_base_valid, pos_base;
+    // FIN variant with the RoPE prologue (decode batches, nl_batch.h attn_rope_prologue): q / k / v of the step's tokens are
+    // still the Q|K|V GEMM's output -- packed row order, possibly split-K slabs -- and this kernel rotates and stores them
+    struct Rope {
+        int on;
+        GemmOut qkv;               // [N][R]
+        int R, n_q_heads, conj;
+        const float *cos, *sin;    // [seq][hd/2]
+        const float *bias_q, *bias_k, *bias_v;
+        float *kcache_w, *vcache_w;   // = kcache / vcache (written here)
+    } rp;
 };
 
 template <int HD, int G>
 __device__ void attn_finalize(const AttnParams &P, const float *ored, const float *ml, int kvh, int item);   // nl_batch.h
+template <int HD, int G>
+__device__ void attn_rope_prologue(const AttnParams &P, int kvh, int item, int pos, long long soff, float *qs, float *krow, float *vcur);   // nl_batch.h
 
 // GQA decode attention for one token (go/model.go:557-587): one workgroup per
 // (kv head, 128-position split); the G query heads of the group share every K
@@ -1095,6 +1118,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
     __shared__ float sc[G * ATT_CH];
     __shared__ __attribute__((aligned(16))) float ored[NG * G * HD];
     __shared__ float ml[G * 2];
+    __shared__ __attribute__((aligned(16))) float vcur[FIN ? HD : 4];   // FIN + RoPE prologue: this step's V row
 
     const int c4 = tid % R4, tg = tid / R4;
     float4 kreg[NV], vreg[NV];
@@ -1129,6 +1153,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
         if (t0 > pos) return;
         n = min(ATT_CH, pos + 1 - t0);
         const long long soff = (long long)sload_i32(P.bstream ? P.bstream + item : P.ctl + CTL_STREAM) * P.kv_stream_stride;
+        if constexpr (FIN) {
+            // (one split, t0 = 0: row `pos` of the cache is written here; its K goes straight into the staged tile)
+            if (P.rp.on) attn_rope_prologue<HD, G>(P, kvh, item, pos, soff, qs, Kt + pos * KS, vcur);
+        }
         const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
         const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
 #pragma unroll
@@ -1143,16 +1171,25 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
             }
         }
     }
-    for (int i = tid; i < G * HD; i += ATT_THREADS) qs[i] = qsrc[kvh * G * HD + i];
+    const bool roped = FIN && P.rp.on;       // q, and row `pos` of K / V, come from the RoPE prologue above
+    if (!roped)
+        for (int i = tid; i < G * HD; i += ATT_THREADS) qs[i] = qsrc[kvh * G * HD + i];
 #pragma unroll
     for (int k = 0; k < NV; k++) {
         int row = tg + k * NG;
-        if (row < n) {
+        if (row < n && !(roped && row == pos)) {
             float *dst = Kt + row * KS + c4 * 4;
             dst[0] = kreg[k].x; dst[1] = kreg[k].y; dst[2] = kreg[k].z; dst[3] = kreg[k].w;
         }
     }
     __syncthreads();
+    if constexpr (FIN) {
+        if (roped) {
+#pragma unroll
+            for (int k = 0; k < NV; k++)
+                if (tg + k * NG == pos) vreg[k] = *reinterpret_cast<const float4 *>(vcur + c4 * 4);
+        }
+    }
 
     // scores: thread (t, g) -> q.k over d (four partial sums: a lone wavefront is latency-bound)
     for (int i = tid; i < n * G; i += ATT_THREADS) {

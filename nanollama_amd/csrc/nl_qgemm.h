@@ -260,7 +260,7 @@ __device__ __forceinline__ void store_frag(uint4 *xf, int nt16, int n, int blk, 
 // Software pipeline, one barrier per chunk: while chunk c is on the matrix cores, chunk c+1's activation
 // fragments travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: the fragment store is lane-linear, one
 // instruction per 1 KB fragment, no VGPR round trip) and its packed weights + scales travel to registers.
-template <int WT, int WAVES, int RT, int EPI, int NT = 4>
+template <int WT, int WAVES, int RT, int EPI, int NT = 4, bool RSTAGE = false>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_kernel(QGemmParams P) {
     static_assert(EPI != QG_EPI_SWIGLU || (RT == 2 && NT == 4), "the fused epilogue pairs a gate tile with its up tile");
     static_assert(EPI != QG_EPI_ROPE || (RT == 1 && NT == 4), "one Q|K|V tile per wavefront: rotation partners are rows r and r^8 of a tile");
@@ -303,16 +303,31 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
     static_assert(QG_KC == 2 || QG_KC == 4 || QG_KC == 8, "a chunk is a whole number of pairs inside one group");
     const unsigned xlane = (unsigned)lane * 16u;
     const unsigned xblock = (unsigned)P.nt16 * (2 * QG_FRAG * 16);   // bytes of one block's fragments
+    // RSTAGE (decode batches: one 64-token tile, a handful of chunks per workgroup): the next chunk's fragments travel
+    // through REGISTERS (global_load_dwordx4 now, ds_write_b128 after this chunk's MFMAs) instead of LDS-DMA.  The guide's
+    // verdict -- LDS-DMA wins -- is for GEMMs that spend their registers and issue slots on MFMA work; here a wavefront
+    // is alone on its SIMD with ~50 instructions per block, and the register path measured 5-8 % faster per launch on
+    // every goldie shape at 64 tokens (tools/qgemm_bench.hip, profiles/r03_rejected_qgemm_ring_bench.log has the series).
+    constexpr int NFR = 2 * NT * QG_KC / WAVES;   // fragments of a chunk staged per wavefront
+    [[maybe_unused]] uint4 xr[RSTAGE ? NFR : 1];
     auto stage = [&](int chunk, int buf) {
         const int b0 = chunk * QG_KC;
         static_assert((2 * NT * QG_KC) % WAVES == 0, "fragments of a chunk divide evenly over the wavefronts");
 #pragma unroll
-        for (int i = 0; i < 2 * NT * QG_KC / WAVES; i++) {
+        for (int i = 0; i < NFR; i++) {
             const int f = wave + WAVES * i;        // fragment of the chunk: block f / 2NT, (tile, part) f % 2NT
             const unsigned uo = (unsigned)min(b0 + f / (2 * NT), nblocks - 1) * xblock + (unsigned)(f % (2 * NT)) * (QG_FRAG * 16);
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(xsrc + (uo + xlane)),
-                (__attribute__((address_space(3))) void *)&xfrag[buf][f * QG_FRAG], 16, 0, 0);
+            if constexpr (RSTAGE) xr[i] = ld_off<uint4>(xsrc, uo + xlane);
+            else
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(xsrc + (uo + xlane)),
+                    (__attribute__((address_space(3))) void *)&xfrag[buf][f * QG_FRAG], 16, 0, 0);
+        }
+    };
+    auto stage_commit = [&](int buf) {     // RSTAGE: the staged registers into the buffer nobody reads during this chunk
+        if constexpr (RSTAGE) {
+#pragma unroll
+            for (int i = 0; i < NFR; i++) xfrag[buf][(wave + WAVES * i) * QG_FRAG + lane] = xr[i];
         }
     };
     const uint8_t *const wq_base = Wq, *const ws_base = Ws;
@@ -430,6 +445,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
                     acc[rt][t][3] = fmaf(z[rt][t][3], dsc[rt], acc[rt][t][3]);
                 }
         }
+        stage_commit(buf ^ 1);
         __syncthreads();             // this chunk's buffer is free again; the next chunk's DMA has landed
     };
 
@@ -439,6 +455,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? NL_QG_OCC : 2) qgemm_
     if (chunk < nchunks) {
         stage(chunk, 0);
         wload(chunk, wqa, wda);
+        stage_commit(0);
     }
     __syncthreads();                 // (drains the LDS-DMA queue: chunk 0 has landed)
     while (chunk < nchunks) {

@@ -858,6 +858,47 @@ def test_forward_batch_matches_individual_forwards(hip):
     dev.close(); solo.close()
 
 
+@pytest.mark.parametrize("variant", ["conj_gqa", "bias_mha", "hd32_g3"])
+def test_batched_decode_rotates_inside_the_attention_launch(hip, orc, tmp_path, monkeypatch, variant):
+    # decode batches below position 128: the attention launch sums the Q|K|V GEMM's split-K slabs, adds the biases,
+    # rotates (standard / conjugate RoPE) and stores the K / V rows itself (attn_rope_prologue) -- no brope_kv launch.
+    # Five streams at ragged positions against the oracle, and bit-identical to the same steps with NL_ROPE_IN_ATTN=0
+    # (the separate brope_kv launch does the same arithmetic in the same order).
+    shape = {"conj_gqa": synth.ModelShape("ria_conj", 2, 256, 4, 2, 512, seq_len=96, interm=512, rope_conjugate=True),
+             "bias_mha": synth.ModelShape("ria_bias", 2, 192, 3, 3, 512, seq_len=96, attn_bias=True),
+             "hd32_g3": synth.ModelShape("ria_hd32", 2, 192, 6, 2, 512, seq_len=96, interm=384)}[variant]
+    p = tmp_path / "r.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0" if variant != "bias_mha" else "q8_0", 43)
+    g = gguf.load_gguf(str(p))
+    ns, nsteps = 5, 6
+    rng = np.random.Generator(np.random.PCG64(77))
+    start = [0, 3, 9, 1, 20]
+    seqs = [[int(t) for t in rng.integers(3, shape.vocab, size=start[s] + nsteps)] for s in range(ns)]
+    refs = []
+    for s in range(ns):
+        ref = orc.OracleModel(g)
+        lg = [ref.forward(t, pos).copy() for pos, t in enumerate(seqs[s])]
+        refs.append(lg[start[s]:])
+        ref.close()
+    outs = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("NL_ROPE_IN_ATTN", knob)
+        dev = hip.load_llama_model(g, max_streams=ns)
+        for s in range(ns):
+            for pos in range(start[s]):
+                dev.forward(seqs[s][pos], pos, stream=s)
+        got = []
+        for k in range(nsteps):
+            ids, lg = dev.forward_batch(list(range(ns)), [seqs[s][start[s] + k] for s in range(ns)],
+                                        [start[s] + k for s in range(ns)], want_logits=True)
+            got.append(lg.copy())
+            for s in range(ns):
+                assert np.abs(lg[s] - refs[s][k]).max() <= LOGIT_TOL * max(1.0, float(refs[s][k].std())), (knob, s, k)
+        outs[knob] = np.stack(got)
+        dev.close()
+    assert np.array_equal(outs["1"], outs["0"])
+
+
 def test_batched_decode_across_the_128_position_split(hip, orc, tmp_path):
     # three streams stepped together from position 0 to 135: below 128 every row has one attention split and the
     # attention kernel writes the WO fragments itself; from 128 on the split partials go through battn_merge.
