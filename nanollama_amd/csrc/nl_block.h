@@ -132,18 +132,25 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
         }
         load_pair<WT>(P.qkv_q, P.qkv_s, tp0, gg, gs, r, min(k, gs - 1), cw, sw);
     }
-    // the first 128 cache rows of this kv head (rows >= pos hold stale finite data and are masked / replaced below)
-    const int c4 = tid % R4, tg = tid / R4;
+    // The first 128 cache rows of this kv head (rows >= pos hold stale finite data and are masked / replaced below).
+    // Each of the eight cache wavefronts owns 16 consecutive positions of a pass.  K: lane (row kr = lane / 4, quarter
+    // kq = lane % 4) holds 16 of the row's 64 dims -- a score is 16 in-lane FMAs and two quad adds, no LDS.  V: lane (row
+    // group vg = lane / 16, float4 column vc = lane % 16) holds float4 vc of rows vg, vg + 4, vg + 8, vg + 12 -- P*V is
+    // four FMAs per component and two cross-row adds.  The wavefront reduces its 16 positions to one (max, sum, sum p*v)
+    // partial by itself; eight partials per pass meet in LDS behind ONE barrier (was: scores | softmax | P*V | 32-way
+    // reduction, four barriers per pass).
+    static_assert(NV == 4 && BLK_KV_THREADS == 512 && HD == 64, "eight cache wavefronts x 16 positions, 16 floats per lane");
+    const int kr = lane >> 2, kq = lane & 3, vg = lane >> 4, vc = lane & 15;
     float4 kreg[NV], vreg[NV], kregn[NV];
     const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + (long long)kvh * P.seq_len * HD);
     const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + (long long)kvh * P.seq_len * HD);
     if (tid < BLK_KV_THREADS) {
         const int lim = min(ATT_CH, P.seq_len);
+        const unsigned krow = (unsigned)min(wave * 16 + kr, lim - 1) * R4 + (unsigned)kq * 4u;
 #pragma unroll
         for (int kk = 0; kk < NV; kk++) {
-            const unsigned ro = (unsigned)(min(tg + kk * NGR, lim - 1) * R4 + c4) * 16u;
-            kreg[kk] = ld_off<float4>(K4, ro);
-            vreg[kk] = ld_off<float4>(V4, ro);
+            kreg[kk] = ld_off<float4>(K4, (krow + kk) * 16u);
+            vreg[kk] = ld_off<float4>(V4, (unsigned)(min(wave * 16 + vg + 4 * kk, lim - 1) * R4 + vc) * 16u);
         }
     }
     // epilogue inputs of the projection rows: 48 threads of the last wavefront (it holds no cache rows and stages nothing),
@@ -266,77 +273,73 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     BLK_STAMP(8);
     // ---- GQA attention over positions 0..pos (go/model.go:557-587), 128 positions per pass ----
     const int nch = pos / ATT_CH + 1;
+    float *wpart = ored;                     // [8][68]: a cache wavefront's (max, sum, -, -, sum p*v[64]) of the pass
     for (int ch = 0; ch < nch; ch++) {
         const int t0 = ch * ATT_CH, n = min(ATT_CH, pos + 1 - t0);
         if (tid < BLK_KV_THREADS) {
-            // K of the next pass and V of this pass are requested now: V is not needed before the P*V phase (two barriers
-            // away) and the next K rows arrive during this pass, so a later pass costs its arithmetic, not a memory round trip
+            // K of the next pass and V of this pass are requested now: the next K rows arrive during this pass, so a later
+            // pass costs its arithmetic, not a memory round trip
             if (ch > 0) {
 #pragma unroll
                 for (int kk = 0; kk < NV; kk++) {
                     kreg[kk] = kregn[kk];
-                    vreg[kk] = V4[(long long)(t0 + min(tg + kk * NGR, n - 1)) * R4 + c4];
+                    vreg[kk] = V4[(long long)(t0 + min(wave * 16 + vg + 4 * kk, n - 1)) * R4 + vc];
                 }
             }
             if (ch + 1 < nch) {
                 const int n1 = min(ATT_CH, pos + 1 - t0 - ATT_CH);
 #pragma unroll
-                for (int kk = 0; kk < NV; kk++) kregn[kk] = K4[(long long)(t0 + ATT_CH + min(tg + kk * NGR, n1 - 1)) * R4 + c4];
+                for (int kk = 0; kk < NV; kk++) kregn[kk] = K4[(long long)(t0 + ATT_CH + min(wave * 16 + kr, n1 - 1)) * R4 + kq * 4 + kk];
             }
-            // scores: this thread holds 4 of the 64 dims of 4 cache rows; the 16 lanes of a row sum on DPP (no LDS staging)
-            const float4 q4 = *reinterpret_cast<const float4 *>(qs + c4 * 4);
-            const float4 kc4 = *reinterpret_cast<const float4 *>(kcur + c4 * 4), vc4 = *reinterpret_cast<const float4 *>(vcur + c4 * 4);
+            // scores: 16 dims in the lane, the row's four quarters summed on DPP (valid in every lane of the quad)
+            const int krow = wave * 16 + kr;
+            const bool kcurrow = t0 + krow == pos;   // the row this launch produced: not in memory yet for this workgroup
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
             for (int kk = 0; kk < NV; kk++) {
-                const int row = tg + kk * NGR;
-                const bool cur = t0 + row == pos;   // the row this launch produced: not in memory yet for this workgroup
-                kreg[kk].x = cur ? kc4.x : kreg[kk].x; kreg[kk].y = cur ? kc4.y : kreg[kk].y;
-                kreg[kk].z = cur ? kc4.z : kreg[kk].z; kreg[kk].w = cur ? kc4.w : kreg[kk].w;
-                vreg[kk].x = cur ? vc4.x : vreg[kk].x; vreg[kk].y = cur ? vc4.y : vreg[kk].y;
-                vreg[kk].z = cur ? vc4.z : vreg[kk].z; vreg[kk].w = cur ? vc4.w : vreg[kk].w;
-                float d = fmaf(q4.w, kreg[kk].w, fmaf(q4.z, kreg[kk].z, fmaf(q4.y, kreg[kk].y, q4.x * kreg[kk].x)));
-                d += dpp_f32<DPP_QUAD_XOR1>(d);
-                d += dpp_f32<DPP_QUAD_XOR2>(d);
-                d += dpp_f32<DPP_HALF_MIRROR>(d);
-                d += dpp_f32<DPP_ROW_MIRROR>(d);
-                if (c4 == 0 && row < n) sc[row] = d * P.scale;
+                const float4 q4 = *reinterpret_cast<const float4 *>(qs + kq * 16 + kk * 4);
+                const float4 kc4 = *reinterpret_cast<const float4 *>(kcur + kq * 16 + kk * 4);
+                const float4 k4 = kcurrow ? kc4 : kreg[kk];
+                d0 = fmaf(q4.x, k4.x, d0); d1 = fmaf(q4.y, k4.y, d1); d2 = fmaf(q4.z, k4.z, d2); d3 = fmaf(q4.w, k4.w, d3);
             }
+            const float sv = krow < n ? quad_sum((d0 + d1) + (d2 + d3)) * P.scale : -INFINITY;
+            // this wavefront's 16 positions: Softmax pieces go/quant.go:610-626 (max-subtract, f32(exp(f64)), f32 sum)
+            const float mw = wave_max_f32(sv);
+            const float p = krow < n ? exp_f64_as_f32(sv - (mw == -INFINITY ? 0.f : mw)) : 0.f;
+            const float lw = wave_sum_f32(kq == 0 ? p : 0.f);
+            // P*V: the probabilities of rows vg + 4 kk come from the lanes that hold those rows' scores
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 vc4 = *reinterpret_cast<const float4 *>(vcur + vc * 4);
+#pragma unroll
+            for (int kk = 0; kk < NV; kk++) {
+                const float pw = __shfl(p, (vg + 4 * kk) * 4);
+                const bool vcurrow = t0 + wave * 16 + vg + 4 * kk == pos;
+                const float4 v4 = vcurrow ? vc4 : vreg[kk];       // (a masked row's V may be stale but is finite, and its p is 0)
+                o.x = fmaf(pw, v4.x, o.x); o.y = fmaf(pw, v4.y, o.y); o.z = fmaf(pw, v4.z, o.z); o.w = fmaf(pw, v4.w, o.w);
+            }
+            o.x += __shfl_xor(o.x, 16); o.y += __shfl_xor(o.y, 16); o.z += __shfl_xor(o.z, 16); o.w += __shfl_xor(o.w, 16);
+            o.x += __shfl_xor(o.x, 32); o.y += __shfl_xor(o.y, 32); o.z += __shfl_xor(o.z, 32); o.w += __shfl_xor(o.w, 32);
+            if (lane < 16) *reinterpret_cast<float4 *>(wpart + wave * 68 + 4 + vc * 4) = o;
+            if (lane == 0) { wpart[wave * 68] = mw; wpart[wave * 68 + 1] = lw; }
         }
         __syncthreads();
         if (ch == 0) BLK_STAMP(13);
-        if (wave == 0) {   // Softmax go/quant.go:610-626 over the pass: max-subtract, f32(exp(f64)), f32 sum
-            const float s0 = lane < n ? sc[lane] : -INFINITY;
-            const float s1 = lane + 64 < n ? sc[lane + 64] : -INFINITY;
-            const float m = wave_max_f32(fmaxf(s0, s1));
-            const float p0 = lane < n ? exp_f64_as_f32(s0 - m) : 0.f;
-            float p1 = 0.f;
-            if (n > 64) p1 = lane + 64 < n ? exp_f64_as_f32(s1 - m) : 0.f;   // (wave-uniform: short passes skip the second exp)
-            if (lane < n) sc[lane] = p0;
-            if (lane + 64 < n) sc[lane + 64] = p1;
-            const float l = wave_sum_f32(p0 + p1);
-            if (lane == 0) { chunk[ch * 66] = m; chunk[ch * 66 + 1] = l; }
-        }
-        __syncthreads();
-        if (ch == 0) BLK_STAMP(14);
-        if (tid < BLK_KV_THREADS) {
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wave == 0) {
+            // the eight partials of the pass, merged like position splits (fixed order).  The weights exp(m_w - M) are this
+            // engine's own construct -- the reference has one softmax over all positions -- and use the f32 exponential, as
+            // the split merge of the five-launch plan does (load_x4<PRO_ATTN>): (M, L, o[64]) of the pass
+            const float mw = lane < 8 ? wpart[min(lane, 7) * 68] : -INFINITY;
+            const float M = wave_max_f32(mw);
+            const float wgt = lane < 8 ? __expf(mw - M) : 0.f;             // (an empty wavefront: exp(-inf) = 0)
+            const float L = wave_sum_f32(lane < 8 ? wgt * wpart[min(lane, 7) * 68 + 1] : 0.f);
+            float ov = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < NV; kk++) {
-                const int row = tg + kk * NGR;
-                const float pw = row < n ? sc[row] : 0.f;   // (a masked row's V may be stale but is finite)
-                o.x = fmaf(pw, vreg[kk].x, o.x); o.y = fmaf(pw, vreg[kk].y, o.y);
-                o.z = fmaf(pw, vreg[kk].z, o.z); o.w = fmaf(pw, vreg[kk].w, o.w);
-            }
-            *reinterpret_cast<float4 *>(ored + tg * HD + c4 * 4) = o;
+            for (int w = 0; w < 8; w++) ov = fmaf(__shfl(wgt, w), wpart[w * 68 + 4 + lane], ov);
+            chunk[ch * 66 + 2 + lane] = ov;
+            if (lane == 0) { chunk[ch * 66] = M; chunk[ch * 66 + 1] = L; }
         }
-        __syncthreads();
-        if (tid < HD) {
-            float s = 0.f;
-#pragma unroll 8
-            for (int kk = 0; kk < NGR; kk++) s += ored[kk * HD + tid];
-            chunk[ch * 66 + 2 + tid] = s;
-        }
-        if (ch + 1 < nch) __syncthreads();   // sc / ored are rewritten by the next pass
+        if (ch == 0) BLK_STAMP(14);
+        if (ch + 1 < nch) __syncthreads();   // wpart is rewritten by the next pass
     }
     BLK_STAMP(9);
     if (tid < HD) {   // merge the passes exactly as the WO prologue of the five-launch plan does (load_x4<PRO_ATTN>)

@@ -12,7 +12,7 @@ for pos, t in enumerate(synth.prompt_ids(72, synth.TIERS[tier].vocab)):
 L = _lib.lib()
 L.nl_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]
 names = {15: "loads issued", 16: "dots", 1: "x staged", 2: "barrier1", 3: "quad+ss", 4: "barrier2", 5: "published", 6: "gathered", 7: "barrier3", 8: "kv stored",
-         13: "scores+bar", 14: "softmax+bar", 9: "PV+reduce", 10: "merged+bar", 11: "wo done"}
+         13: "scores+softmax+PV per wavefront+bar", 14: "pass merge (wave 0)", 9: "loop end", 10: "merged+bar", 11: "wo done"}
 order = [15, 1, 2, 16, 3, 4, 5, 6, 7, 8, 13, 14, 9, 10, 11]
 for rep in range(4):
     buf = (C.c_longlong * 128)()
