@@ -13,6 +13,7 @@ import os
 import socket
 import struct
 import time
+import zlib
 from typing import Callable, List, Optional
 
 _MAGIC = b"NLRDV1"
@@ -41,8 +42,18 @@ def _recv(sock: socket.socket) -> bytes:
     return buf
 
 
+class RendezvousDesync(RuntimeError):
+    """A peer is at a different collective than this rank (one rank left the common control flow, e.g. after an
+    exception): every message carries (operation, sequence number, tag) and a mismatch fails fast on both sides
+    instead of pairing the wrong replies or waiting for the socket timeout."""
+
+
+_OP_BCAST, _OP_GATHER, _OP_MAX = 1, 2, 3
+
+
 class Rendezvous:
     def __init__(self, timeout_s: float = 300.0):
+        self._seq = 0
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -66,6 +77,7 @@ class Rendezvous:
         r.rank, r.world = 0, 1
         r.local_rank = 0 if os.environ.get("NL_BENCH_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
         r._peers, r._root, r._listener = [], None, None
+        r._seq = 0
         return r
 
     # ---- wiring ----
@@ -132,54 +144,70 @@ class Rendezvous:
         raise TimeoutError("rendezvous: could not reach rank 0")
 
     # ---- collectives over the star ----
-    def broadcast_bytes(self, make: Callable[[], bytes]) -> bytes:
+    # every message = header (operation, sequence number of the collective on the sending rank, crc32 of the caller's
+    # tag) + payload; the receiver checks the header against its own position (RendezvousDesync)
+    def _hdr(self, op: int, tag: str) -> bytes:
+        return struct.pack("<BII", op, self._seq, zlib.crc32(tag.encode()))
+
+    def _check(self, msg: bytes, op: int, tag: str) -> bytes:
+        want = self._hdr(op, tag)
+        if msg[:len(want)] != want:
+            got = struct.unpack("<BII", msg[:9]) if len(msg) >= 9 else ()
+            raise RendezvousDesync(f"rank {self.rank}: peer is at {got}, this rank at (op {op}, seq {self._seq}, tag {tag!r})")
+        return msg[len(want):]
+
+    def broadcast_bytes(self, make: Callable[[], bytes], tag: str = "") -> bytes:
         """Rank 0 calls make(); every rank returns the same bytes."""
         if self.world == 1:
             return make()
-        if self.rank == 0:
-            data = make()
-            for p in self._peers:
-                _send(p, data)
-            return data
-        return _recv(self._root)
+        try:
+            if self.rank == 0:
+                data = make()
+                for p in self._peers:
+                    _send(p, self._hdr(_OP_BCAST, tag) + data)
+                return data
+            return self._check(_recv(self._root), _OP_BCAST, tag)
+        finally:
+            self._seq += 1
 
-    def allgather_bytes(self, mine: bytes) -> List[bytes]:
+    def allgather_bytes(self, mine: bytes, tag: str = "") -> List[bytes]:
         """Every rank contributes a byte string; every rank returns the rank-ordered list."""
         if self.world == 1:
             return [mine]
-        if self.rank == 0:
-            parts = [mine] + [_recv(p) for p in self._peers]
-            blob = b"".join(struct.pack("<I", len(x)) + x for x in parts)
-            for p in self._peers:
-                _send(p, blob)
+        try:
+            if self.rank == 0:
+                parts = [mine] + [self._check(_recv(p), _OP_GATHER, tag) for p in self._peers]
+                blob = b"".join(struct.pack("<I", len(x)) + x for x in parts)
+                for p in self._peers:
+                    _send(p, self._hdr(_OP_GATHER, tag) + blob)
+                return parts
+            _send(self._root, self._hdr(_OP_GATHER, tag) + mine)
+            blob, parts, off = self._check(_recv(self._root), _OP_GATHER, tag), [], 0
+            while off < len(blob):
+                n = struct.unpack_from("<I", blob, off)[0]
+                parts.append(blob[off + 4:off + 4 + n])
+                off += 4 + n
             return parts
-        _send(self._root, mine)
-        blob, parts, off = _recv(self._root), [], 0
-        while off < len(blob):
-            n = struct.unpack_from("<I", blob, off)[0]
-            parts.append(blob[off + 4:off + 4 + n])
-            off += 4 + n
-        return parts
+        finally:
+            self._seq += 1
 
-    def _gather_floats(self, value: float) -> List[float]:
-        vals = [value]
-        for p in self._peers:
-            vals.append(struct.unpack("<d", _recv(p))[0])
-        return vals
+    def barrier(self, tag: str = "barrier") -> None:
+        self.max_over_ranks(0.0, tag)
 
-    def barrier(self) -> None:
-        self.max_over_ranks(0.0)
-
-    def max_over_ranks(self, value: float) -> float:
+    def max_over_ranks(self, value: float, tag: str = "") -> float:
         if self.world == 1:
             return value
-        if self.rank == 0:
-            m = max(self._gather_floats(value))
-            for p in self._peers:
-                _send(p, struct.pack("<d", m))
-            return m
-        _send(self._root, struct.pack("<d", value))
-        return struct.unpack("<d", _recv(self._root))[0]
+        try:
+            if self.rank == 0:
+                vals = [value] + [struct.unpack("<d", self._check(_recv(p), _OP_MAX, tag))[0] for p in self._peers]
+                m = max(vals)
+                for p in self._peers:
+                    _send(p, self._hdr(_OP_MAX, tag) + struct.pack("<d", m))
+                return m
+            _send(self._root, self._hdr(_OP_MAX, tag) + struct.pack("<d", value))
+            return struct.unpack("<d", self._check(_recv(self._root), _OP_MAX, tag))[0]
+        finally:
+            self._seq += 1
 
     def close(self) -> None:
         for s in self._peers + [x for x in (self._root, self._listener) if x is not None]:

@@ -90,3 +90,34 @@ def test_world_size_2_rendezvous(tmp_path):
             break
     assert out.returncode == 0, out.stderr[-2000:]
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+def test_a_rank_that_leaves_the_common_flow_is_detected(tmp_path):
+    # rank 1 "fails" inside a phase and goes straight to the vote the ranks take afterwards, while rank 0 is still at
+    # the phase's barrier: the messages carry (operation, sequence, tag), so both sides raise RendezvousDesync at once
+    # instead of pairing the vote with the barrier (or waiting for the socket timeout)
+    script = tmp_path / "d.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        from nanollama_amd.dist import Rendezvous, RendezvousDesync
+        r = Rendezvous(timeout_s=30.0)
+        r.barrier("start")
+        try:
+            if r.rank == 0:
+                r.barrier("phase:after-load")
+            else:
+                r.max_over_ranks(1.0, tag="vote:p2p")
+            print("rank", r.rank, "NOT DETECTED")
+        except (RendezvousDesync, ConnectionError) as exc:
+            print("rank", r.rank, "detected", type(exc).__name__)
+        r.close()
+    """))
+    port = 29000 + (os.getpid() * 3 + 977) % 2000
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert "rank 0 detected RendezvousDesync" in outs[0][0], outs[0]
+    assert "detected" in outs[1][0], outs[1]          # (rank 1 sees the desync reply, or rank 0 closing the socket first)
