@@ -1355,7 +1355,7 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
             LCK(hipGetLastError());
         }
         if (fold) {
-            const QGemmParams::NormOut nout{L.ffn_norm, b.xfrag2, b.ssq, L.gate.wtype == WT_Q4_0 ? 1 : 0};
+            const QGemmParams::NormOut nout{L.ffn_norm, b.xfrag2, b.ssq};
             LCK(qg(e, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo, nullptr, &nout));
         } else {
             LCK(qg(e, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo));
@@ -1396,7 +1396,7 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
         }
         if (fold && l + 1 < c.n_layers) {
             const nl_engine::Layer &Ln = e->layers[l + 1];
-            const QGemmParams::NormOut nout{Ln.attn_norm, b.xfrag2, b.ssq, Ln.qkv.wtype == WT_Q4_0 ? 1 : 0};
+            const QGemmParams::NormOut nout{Ln.attn_norm, b.xfrag2, b.ssq};
             LCK(qg(e, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in, &nout));
         } else {
             LCK(qg(e, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in));

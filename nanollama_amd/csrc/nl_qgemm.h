@@ -82,8 +82,7 @@ struct QGemmParams {
         const float *w;      // [rows] norm weights of the consuming GEMM; nullptr = not folded
         uint4 *xf;           // fragment store the consumer reads
         double *ssq;         // [n_tokens][rows / 64]
-        int q4;              // k-slot order of the consumer's weight type
-    } nrm_out;
+    } nrm_out;               // (the consumer is a Q4_0 GEMM of nl_qgemm2.h: Q4_0 k-slot order)
     struct NormIn {
         const double *ssq;   // nullptr = the input fragments are already normalised
         int nrb;             // partial sums per token (dim / 64)

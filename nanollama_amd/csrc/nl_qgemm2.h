@@ -394,20 +394,10 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
                             y[r][0] = acc[2 * b + r][t][0] * g.x; y[r][1] = acc[2 * b + r][t][1] * g.y;
                             y[r][2] = acc[2 * b + r][t][2] * g.z; y[r][3] = acc[2 * b + r][t][3] * g.w;
                         }
+                        // (the consumer is a qgemm2 GEMM, i.e. Q4_0: k-slot group lq = this lane's float4 groups of the two tiles)
                         float v[8];
-                        int w;
-                        if (P.nrm_out.q4) {
-                            w = lq;
-                            slots_from(1, make_float4(y[0][0], y[0][1], y[0][2], y[0][3]), make_float4(y[1][0], y[1][1], y[1][2], y[1][3]), v);
-                        } else {
-                            float got[4];
-#pragma unroll
-                            for (int j = 0; j < 4; j++) got[j] = __shfl_xor((lq & 1) ? y[0][j] : y[1][j], 16);
-                            w = (lq & 1) ? 2 + (lq >> 1) : (lq >> 1);
-                            const float4 a = (lq & 1) ? make_float4(got[0], got[1], got[2], got[3]) : make_float4(y[0][0], y[0][1], y[0][2], y[0][3]);
-                            const float4 bb = (lq & 1) ? make_float4(y[1][0], y[1][1], y[1][2], y[1][3]) : make_float4(got[0], got[1], got[2], got[3]);
-                            slots_from(0, a, bb, v);
-                        }
+                        const int w = lq;
+                        slots_from(1, make_float4(y[0][0], y[0][1], y[0][2], y[0][3]), make_float4(y[1][0], y[1][1], y[1][2], y[1][3]), v);
                         if (n < P.n_tokens) store_frag(P.nrm_out.xf, P.nt16, n, row0 / 32 + b, w, v);
                     }
                 }
