@@ -388,6 +388,7 @@ __device__ void attn_finalize(const AttnParams &P, const float *ored, const floa
 struct BMergeParams {
     const float *part_o, *part_ml;  // [N][heads][nsplit_max][hd] / [..][2]
     const int *pos;
+    const int *nparts;   // partials per item when attn_tile16_kernel folded runs of chunks (null: one per 128 positions)
     int heads, nsplit_max, head_dim;
     uint4 *xf;   // attention output [N][heads*hd] as MFMA fragments for the WO GEMM
     int nt16, q4;
@@ -405,7 +406,7 @@ __global__ void battn_merge_kernel(BMergeParams P, int n_items) {
     const long long total = (long long)n_items * upi;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int item = (int)(idx / upi), u = (int)(idx - (long long)item * upi);
-        const int ns = min(P.pos[item] / ATT_CH + 1, MAXS);
+        const int ns = min(P.nparts ? P.nparts[item] : P.pos[item] / ATT_CH + 1, MAXS);
         const long long pbase = (long long)item * P.heads * P.nsplit_max;
         const int blk = u >> 2, w = u & 3;
         const int h = blk * 32 / hd;                 // a 32-column block never straddles heads (hd = 32 or 64)
@@ -749,28 +750,147 @@ __global__ void __launch_bounds__(QT * G * 4, 2) attn_tile_kernel(AttnParams P, 
 //     output by 2^-10; max / sum are taken from the unscaled f32 values.
 // Partials (max, sum, sum p*v) leave in the decode kernel's layout, so battn_merge_kernel is shared.
 #ifdef NL_ATT_STAMPS
+// developer build (tools/att_stamps.sh): phase stamps of one workgroup + a census of every workgroup of the last launch
+// (entry / exit on the 100 MHz wall clock, HW_ID and XCC_ID registers)
 __device__ long long g_att_stamps[64];
-#define ATT_STAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 3 && blockIdx.z == NL_ATT_STAMPS && threadIdx.x == 64) g_att_stamps[(i)] = clock64(); } while (0)
+__device__ long long g_att_census[4 * 8192];
+#define ATT_STAMP(i) do { \
+    if (kvh == 1 && c_first == 0 && i0 == NL_ATT_STAMPS * QT && threadIdx.x == 64 && (i) < 64) g_att_stamps[(i)] = clock64(); \
+    if (((i) == 0 || (i) == 8) && threadIdx.x == 0) { \
+        const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; \
+        if (wg_ < 8192) { \
+            g_att_census[4 * wg_ + ((i) ? 1 : 0)] = wall_clock64(); \
+            if ((i) == 0) { g_att_census[4 * wg_ + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+                            g_att_census[4 * wg_ + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) | ((long long)__builtin_amdgcn_s_getreg(6 | (0 << 6) | (31 << 11)) << 8); } \
+        } } } while (0)
 #else
 #define ATT_STAMP(i) do { } while (0)
 #endif
-template <int HD, int G, int QT>
+// LDS image of one 128-key chunk of one kv head, in halves: Kh | Kl [key][HD], then VTh | VTl [d][128].  Rows are not
+// padded; the 16-byte segments of a row are XOR-swizzled so that the kernel's ds_read_b128 are conflict-free.  A wave64
+// ds_read_b128 is serviced in four groups of 16 lanes -- {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32
+// (MI355X_MICROARCH.md, LDS) -- i.e. with lane = j + 16*kq every group holds each j once, half of them with segment s and
+// half with s ^ 1; the padded layouts of round 2 (rows of HD + 8 / 128 + 8 halves) put 7 of those 16 lanes on a busy
+// bank and every read took 8 LDS cycles instead of 4 (SQ_LDS_BANK_CONFLICT = 4 per ds_read_b128, measured).
+template <int HD> struct Kv16Image {
+    static constexpr int KS = HD;                   // K row: HD halves = HD/8 segments
+    static constexpr int VS = ATT_CH;               // V^T row: 128 halves = 16 segments = one 256-byte bank row
+    static constexpr int K_HALVES = 2 * ATT_CH * KS, V_HALVES = 2 * HD * VS;
+    static constexpr int K_BYTES = K_HALVES * 2, V_BYTES = V_HALVES * 2, BYTES = K_BYTES + V_BYTES;
+    static_assert(K_BYTES % 1024 == 0 && V_BYTES % 1024 == 0, "whole 1 KB LDS-DMA instructions");
+    // offset (halves) of segment `seg` (8 halves) of K row `row`: HD = 64: two rows per bank row, rows r and r + 2 differ
+    // by one segment; HD = 32: four rows per bank row
+    static __device__ __forceinline__ int k_off(int row, int seg) {
+        const int sw = HD == 64 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3);
+        return row * KS + ((seg ^ sw) << 3);
+    }
+    // offset (halves) of segment `seg` (8 key positions) of V^T row d
+    static __device__ __forceinline__ int v_off(int d, int seg) { return d * VS + ((seg ^ (d & 15)) << 3); }
+};
+
+// f32 cache rows of one chunk -> the image (split_hi_lo, V transposed with the key -> position map of the kernel below).
+// Thread (key pair rp, float4 column c4) owns keys 2rp, 2rp+1 (clamped loads, zero beyond nrows so that masked
+// probabilities meet finite values); all loads are issued before the first LDS store.
+template <int HD, int NTH>
+__device__ __forceinline__ void kv16_stage(const float4 *K4, const float4 *V4, int nrows, int tid,
+                                           _Float16 *Kh, _Float16 *Kl, _Float16 *VTh, _Float16 *VTl, bool sync_before_store) {
+    typedef Kv16Image<HD> Img;
+    constexpr int R4 = HD / 4;
+    constexpr int NIT = (ATT_CH / 2 * R4 + NTH - 1) / NTH;
+    float4 kreg[NIT][2], vreg[NIT][2];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int i = min(tid + it * NTH, ATT_CH / 2 * R4 - 1), rp = i / R4, c4 = i % R4;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int row = min(2 * rp + h, nrows - 1);
+            kreg[it][h] = K4[row * R4 + c4];
+            vreg[it][h] = V4[row * R4 + c4];
+        }
+    }
+    // (hipcc otherwise sinks the second half of these loads below the first half's LDS stores: two dependent memory
+    // round trips per chunk instead of one)
+    __builtin_amdgcn_sched_barrier(0);
+    if (sync_before_store) __syncthreads();            // every wavefront is done with the previous chunk's K / V^T
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int i = tid + it * NTH, rp = i / R4, c4 = i % R4;
+        if (i >= ATT_CH / 2 * R4) continue;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const bool live = 2 * rp + h < nrows;
+            const float kv[4] = {kreg[it][h].x, kreg[it][h].y, kreg[it][h].z, kreg[it][h].w};
+            _Float16 hh[4], ll[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) split_hi_lo(live ? kv[e] : 0.f, hh[e], ll[e]);
+            typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+            const int ko = Img::k_off(2 * rp + h, c4 >> 1) + (c4 & 1) * 4;
+            *reinterpret_cast<h4_t *>(Kh + ko) = h4_t{hh[0], hh[1], hh[2], hh[3]};
+            *reinterpret_cast<h4_t *>(Kl + ko) = h4_t{ll[0], ll[1], ll[2], ll[3]};
+        }
+        // V^T: keys 2rp, 2rp+1 sit side by side at position 32m + 8kg + 4h + e (e even)
+        const int r = 2 * rp, pos = (r & ~31) + 8 * ((r >> 2) & 3) + 4 * ((r >> 4) & 1) + (r & 3);
+        const float v0[4] = {vreg[it][0].x, vreg[it][0].y, vreg[it][0].z, vreg[it][0].w};
+        const float v1[4] = {vreg[it][1].x, vreg[it][1].y, vreg[it][1].z, vreg[it][1].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            _Float16 h0, l0, h1, l1;
+            split_hi_lo(r < nrows ? v0[e] : 0.f, h0, l0);
+            split_hi_lo(r + 1 < nrows ? v1[e] : 0.f, h1, l1);
+            const int vo = Img::v_off(c4 * 4 + e, pos >> 3) + (pos & 7);
+            *reinterpret_cast<h2_t *>(VTh + vo) = h2_t{h0, h1};
+            *reinterpret_cast<h2_t *>(VTl + vo) = h2_t{l0, l1};
+        }
+    }
+}
+
+// prompts of many query tiles: every chunk is converted ONCE per layer (a tile-kernel workgroup converting its own chunks
+// repeats the work of every other tile that reads them -- ~34x at 2047 tokens -- and the conversion was ~half of a
+// workgroup's life).  grid (kv head, chunk); the image leaves LDS with coalesced 16-byte stores.
+struct Kv16BuildParams {
+    const float *kcache, *vcache;   // this layer, the prompt's stream: [kv][seq][hd]
+    uint4 *kv16;                    // [kv][nsplit_max] images
+    int seq_len, nsplit_max, n_keys;
+};
+template <int HD>
+__global__ void __launch_bounds__(512) kv16_build_kernel(Kv16BuildParams P) {
+    typedef Kv16Image<HD> Img;
+    __shared__ __attribute__((aligned(16))) _Float16 img[Img::K_HALVES + Img::V_HALVES];
+    const int kvh = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x, t0 = chunk * ATT_CH;
+    const int nrows = min(ATT_CH, P.n_keys - t0);
+    const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + ((long long)kvh * P.seq_len + t0) * HD);
+    const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + ((long long)kvh * P.seq_len + t0) * HD);
+    kv16_stage<HD, 512>(K4, V4, nrows, tid, img, img + ATT_CH * Img::KS, img + Img::K_HALVES, img + Img::K_HALVES + HD * Img::VS, false);
+    __syncthreads();
+    uint4 *dst = P.kv16 + ((long long)kvh * P.nsplit_max + chunk) * (Img::BYTES / 16);
+    const uint4 *src = reinterpret_cast<const uint4 *>(img);
+    for (int i = tid; i < Img::BYTES / 16; i += 512) dst[i] = src[i];
+}
+
+template <int HD, int G, int QT, bool SHADOW>
 __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16_kernel(AttnParams P, int n_items) {
     constexpr int VH = QT * G;               // rows (token, query head) per workgroup
     static_assert(VH % 16 == 0 && VH <= 256, "16 rows per wavefront");
-    constexpr int NTH = VH * 4;
-    constexpr int KS = HD + 8;               // K row stride (halves): 144 B rows
-    constexpr int VS = ATT_CH + 8;           // V^T row stride (halves): 272 B rows, 16-byte aligned
+    constexpr int NTH = VH * 4, NW = NTH / 64;
+    typedef Kv16Image<HD> Img;
+    constexpr int KS = Img::KS, VS = Img::VS;
     constexpr int NKS = HD / 32;             // 32-wide reduction steps of q.k
     constexpr int NTO = HD / 16;             // output column tiles
-    constexpr int R4 = HD / 4;
     static_assert(ATT_CH == 128, "key position map below assumes 4 groups of 32 keys");
-    __shared__ __attribute__((aligned(16))) _Float16 Kh[ATT_CH * KS], Kl[ATT_CH * KS];
-    __shared__ __attribute__((aligned(16))) _Float16 VTh[HD * VS], VTl[HD * VS];
-    __shared__ int nv[VH];
+    __shared__ __attribute__((aligned(16))) _Float16 Kimg[Img::K_HALVES], Vimg[Img::V_HALVES];
+    _Float16 *const Kh = Kimg, *const Kl = Kimg + ATT_CH * KS, *const VTh = Vimg, *const VTl = Vimg + HD * VS;
+    __shared__ int npos[VH];                 // keys visible to each row: its position + 1 (0: no such item)
 
-    const int kvh = blockIdx.x, split = blockIdx.y, i0 = blockIdx.z * QT, tid = threadIdx.x;
-    const int t0 = split * ATT_CH;
+    // a workgroup = one query tile x a RUN of consecutive 128-key chunks, folded with the online softmax in registers;
+    // its (max, sum, sum p*v) leaves as partial `slot` of the tile's items.  Prompts come with the host's list of runs
+    // (AttnParams::live_map: tile << 16 | slot << 12 | first chunk << 6 | chunks); without it the grid is
+    // (kv head, chunk, tile) with one chunk per workgroup.
+    const int kvh = blockIdx.x, tid = threadIdx.x;
+    const int code = P.live_map ? sload_i32(P.live_map + blockIdx.y) : 0;
+    const int i0 = (P.live_map ? (code >> 16) : (int)blockIdx.z) * QT;
+    const int split = P.live_map ? ((code >> 12) & 15) : (int)blockIdx.y;           // partial slot
+    const int c_first = P.live_map ? ((code >> 6) & 63) : (int)blockIdx.y;
+    int c_count = P.live_map ? (code & 63) : 1;
     int maxpos = -1, minpos = 0x7fffffff;
     if (P.pos_base_valid) {   // a prompt: consecutive positions, nothing to read
         minpos = P.pos_base + i0;
@@ -782,11 +902,23 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
             minpos = min(minpos, pp);
         }
     }
-    if (t0 > maxpos) return;
-    const int nrows = min(ATT_CH, maxpos + 1 - t0);
-    const bool full = minpos >= t0 + ATT_CH - 1;   // every row of the tile sees every key of this split
+    if (c_first * ATT_CH > maxpos) return;
+    c_count = min(c_count, maxpos / ATT_CH + 1 - c_first);
     const int lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
     ATT_STAMP(0);
+    // SHADOW: a chunk's image, built by kv16_build_kernel, goes straight into LDS (global_load_lds_dwordx4: 1 KB per
+    // instruction, 64 per chunk); the first chunk's leaves before anything else is fetched
+    [[maybe_unused]] auto dma_chunk = [&](int chunk) {
+        const char *src = reinterpret_cast<const char *>(P.kv16) + ((long long)kvh * P.nsplit_max + chunk) * Img::BYTES + lane * 16;
+        const int wv = __builtin_amdgcn_readfirstlane(w);
+        for (int i = wv; i < Img::K_BYTES / 1024; i += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * 1024),
+                                             (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(Kimg) + i * 1024), 16, 0, 0);
+        for (int i = wv; i < Img::V_BYTES / 1024; i += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + Img::K_BYTES + i * 1024),
+                                             (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(Vimg) + i * 1024), 16, 0, 0);
+    };
+    if constexpr (SHADOW) dma_chunk(c_first);
 
     // B operand of S^T: row w*16+j, head_dim elements 32*ks + 8*kq .. +7, as hi / lo halves
     half8_t qh[NKS], ql[NKS];
@@ -805,176 +937,172 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
             }
         }
     }
-    const long long soff = P.single_stream ? 0 : (long long)sload_i32(P.bstream + i0) * P.kv_stream_stride;
-    const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
-    const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
-    // staging: thread (key pair rp, float4 column c4) owns keys 2rp, 2rp+1 (clamped loads, zero beyond nrows so
-    // that masked probabilities meet finite values); all loads are issued before the first LDS store
-    constexpr int NIT = (ATT_CH / 2 * R4 + NTH - 1) / NTH;
-    float4 kreg[NIT][2], vreg[NIT][2];
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const int i = min(tid + it * NTH, ATT_CH / 2 * R4 - 1), rp = i / R4, c4 = i % R4;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int row = min(2 * rp + h, nrows - 1);
-            kreg[it][h] = K4[row * R4 + c4];
-            vreg[it][h] = V4[row * R4 + c4];
-        }
-    }
-    // (hipcc otherwise sinks the second half of these loads below the first half's LDS stores: two dependent memory
-    // round trips per workgroup instead of one)
-    __builtin_amdgcn_sched_barrier(0);
-    ATT_STAMP(1);
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const int i = tid + it * NTH, rp = i / R4, c4 = i % R4;
-        if (i >= ATT_CH / 2 * R4) continue;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const bool live = 2 * rp + h < nrows;
-            const float kv[4] = {kreg[it][h].x, kreg[it][h].y, kreg[it][h].z, kreg[it][h].w};
-            _Float16 hh[4], ll[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) split_hi_lo(live ? kv[e] : 0.f, hh[e], ll[e]);
-            typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
-            *reinterpret_cast<h4_t *>(Kh + (2 * rp + h) * KS + c4 * 4) = h4_t{hh[0], hh[1], hh[2], hh[3]};
-            *reinterpret_cast<h4_t *>(Kl + (2 * rp + h) * KS + c4 * 4) = h4_t{ll[0], ll[1], ll[2], ll[3]};
-        }
-        // V^T: keys 2rp, 2rp+1 sit side by side at position 32m + 8kg + 4h + e (e even)
-        const int r = 2 * rp, pos = (r & ~31) + 8 * ((r >> 2) & 3) + 4 * ((r >> 4) & 1) + (r & 3);
-        const float v0[4] = {vreg[it][0].x, vreg[it][0].y, vreg[it][0].z, vreg[it][0].w};
-        const float v1[4] = {vreg[it][1].x, vreg[it][1].y, vreg[it][1].z, vreg[it][1].w};
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            _Float16 h0, l0, h1, l1;
-            split_hi_lo(r < nrows ? v0[e] : 0.f, h0, l0);
-            split_hi_lo(r + 1 < nrows ? v1[e] : 0.f, h1, l1);
-            *reinterpret_cast<h2_t *>(VTh + (c4 * 4 + e) * VS + pos) = h2_t{h0, h1};
-            *reinterpret_cast<h2_t *>(VTl + (c4 * 4 + e) * VS + pos) = h2_t{l0, l1};
-        }
-    }
-    ATT_STAMP(2);
     if (tid < VH) {
         const int item = i0 + tid / G;
-        nv[tid] = item < n_items ? min(ATT_CH, max(0, P.bpos[item] + 1 - t0)) : 0;
+        npos[tid] = item < n_items ? P.bpos[item] + 1 : 0;
     }
-    ATT_STAMP(3);
-    __syncthreads();
-    ATT_STAMP(4);
-
-    // ---- S^T = K q^T: 8 key tiles x 16 rows; lane (j, kq) ends up with row j's scores for keys 16*mt + 4*kq + r
-    v4f acc[8];
-#pragma unroll
-    for (int mt = 0; mt < 8; mt++) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < NKS; ks++) {
-        half8_t kh[8], kl[8];
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++) {
-            kh[mt] = *reinterpret_cast<const half8_t *>(Kh + (mt * 16 + j) * KS + 32 * ks + 8 * kq);
-            kl[mt] = *reinterpret_cast<const half8_t *>(Kl + (mt * 16 + j) * KS + 32 * ks + 8 * kq);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[mt], qh[ks], acc[mt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt], ql[ks], acc[mt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt], qh[ks], acc[mt], 0, 0, 0);
-    }
-
-    ATT_STAMP(5);
-    // ---- softmax pieces of row j: 32 keys in this lane, the rest in lanes j+16, j+32, j+48.  Splits below the
-    //      tile's diagonal see all 128 keys in every row (uniform test): no per-element masks there.
-    //      p = exp2((s - m) * log2 e) on v_exp_f32 (~1 ulp; the argument's rounding adds |s - m| * 6e-8 relative,
-    //      i.e. < 1e-6 wherever p matters) ----
-    const int nvj = nv[w * 16 + j];
-    constexpr float LOG2E = 1.44269504088896340736f;
-    float m = -INFINITY, l = 0.f;
-    if (full) {
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                acc[mt][r] *= P.scale;
-                m = fmaxf(m, acc[mt][r]);
-            }
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                acc[mt][r] = __builtin_amdgcn_exp2f((acc[mt][r] - m) * LOG2E);
-                l += acc[mt][r];
-            }
-    } else {
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float sv = mt * 16 + 4 * kq + r < nvj ? acc[mt][r] * P.scale : -INFINITY;
-                acc[mt][r] = sv;
-                m = fmaxf(m, sv);
-            }
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float pv = mt * 16 + 4 * kq + r < nvj ? __builtin_amdgcn_exp2f((acc[mt][r] - m) * LOG2E) : 0.f;
-                acc[mt][r] = pv;
-                l += pv;
-            }
-    }
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-
-    ATT_STAMP(6);
-    // ---- O = P V: A = P (this lane's own accumulators, key tiles 2m and 2m+1), B = V^T rows from LDS ----
-    v4f o[NTO];
+    const long long soff = P.single_stream ? 0 : (long long)sload_i32(P.bstream + i0) * P.kv_stream_stride;
+    constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const float c2 = P.scale * LOG2E;
+    float m = -INFINITY, l = 0.f;            // running max (log2 domain) / sum * 2^10 of row j (the same value in its four kq lanes)
+    v4f o[NTO];                              // running sum p*v * 2^10: rows 4*kq+r, columns nt*16 + j
 #pragma unroll
     for (int nt = 0; nt < NTO; nt++) o[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mm = 0; mm < 4; mm++) {
-        half8_t ph, pl;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            _Float16 h, lo;
-            split_hi_lo(acc[2 * mm + (e >> 2)][e & 3] * 1024.0f, h, lo);
-            ph[e] = h; pl[e] = lo;
+
+#pragma unroll 1
+    for (int c = 0; c < c_count; c++) {
+        const int t0 = (c_first + c) * ATT_CH;
+        const int nrows = min(ATT_CH, maxpos + 1 - t0);
+        const bool full = minpos >= t0 + ATT_CH - 1;   // every row of the tile sees every key of this chunk
+        if constexpr (SHADOW) {
+            if (c > 0) {
+                __syncthreads();                       // every wavefront is done with the previous chunk's K / V^T
+                dma_chunk(c_first + c);
+            }
+            ATT_STAMP(10 * c + 1);
+        } else {
+            const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
+            const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
+            kv16_stage<HD, NTH>(K4, V4, nrows, tid, Kh, Kl, VTh, VTl, c > 0);
         }
+        ATT_STAMP(10 * c + 3);
+        __syncthreads();
+        ATT_STAMP(10 * c + 4);
+
+        // ---- S^T = K q^T: 8 key tiles x 16 rows; lane (j, kq) ends up with row j's scores for keys 16*mt + 4*kq + r
+        v4f acc[8];
 #pragma unroll
-        for (int nt = 0; nt < NTO; nt++) {
-            // B rows nt*16 + j: consecutive V^T rows across the 16 lanes of a read group are 272 B = 4 banks apart, i.e.
-            // conflict-free (rows NTO*j + nt put lanes j, j+4, j+8, j+12 on the same banks: a 4-way conflict per read)
-            const half8_t vh = *reinterpret_cast<const half8_t *>(VTh + (nt * 16 + j) * VS + 32 * mm + 8 * kq);
-            const half8_t vl = *reinterpret_cast<const half8_t *>(VTl + (nt * 16 + j) * VS + 32 * mm + 8 * kq);
-            o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, o[nt], 0, 0, 0);
-            o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, o[nt], 0, 0, 0);
-            o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, o[nt], 0, 0, 0);
+        for (int mt = 0; mt < 8; mt++) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ks++) {
+#pragma unroll
+            for (int mh = 0; mh < 8; mh += 4) {        // four key tiles at a time: 32 operand registers live, not 64
+                half8_t kh[4], kl[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+                    const int ko = Img::k_off((mh + mt) * 16 + j, 4 * ks + kq);
+                    kh[mt] = *reinterpret_cast<const half8_t *>(Kh + ko);
+                    kl[mt] = *reinterpret_cast<const half8_t *>(Kl + ko);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) acc[mh + mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[mt], qh[ks], acc[mh + mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) acc[mh + mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt], ql[ks], acc[mh + mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) acc[mh + mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt], qh[ks], acc[mh + mt], 0, 0, 0);
+            }
         }
+
+        ATT_STAMP(10 * c + 5);
+        // ---- online softmax of row j: 32 keys of this chunk in this lane, the rest in lanes j+16, j+32, j+48.  Chunks
+        //      below the tile's diagonal see all 128 keys in every row (uniform test): no per-element masks there.
+        //      The vector pipe is this kernel's busiest (SQ_INSTS_VALU x 4 cycles ~ 40 % of the launch, all of it on the
+        //      critical path of the longest runs), so everything is kept in the log2 domain and two elements per
+        //      instruction (v_pk_mul_f32 / v_pk_add_f32): t = s * (scale * log2 e); p * 2^10 = exp2(t + (10 - max)) on
+        //      v_exp_f32 (~1 ulp; the two roundings of the argument add < 1.5e-6 relative for |t| < 32); max and sum
+        //      leave in natural units (max * ln 2, sum * 2^-10) ----
+        //      (two separate instruction streams: with the masked variant merely branched around, hipcc hoists its 32
+        //      compares into the common path)
+        float alpha;
+        auto softmax = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            [[maybe_unused]] const int nvj = FULL ? ATT_CH : min(ATT_CH, max(0, npos[w * 16 + j] - t0));
+            float mc = -INFINITY;
+#pragma unroll
+            for (int mt = 0; mt < 8; mt++) {
+                if constexpr (FULL) {
+                    acc[mt] = acc[mt] * c2;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[mt][r] = mt * 16 + 4 * kq + r < nvj ? acc[mt][r] * c2 : -INFINITY;
+                }
+                mc = fmaxf(fmaxf(mc, fmaxf(acc[mt][0], acc[mt][1])), fmaxf(acc[mt][2], acc[mt][3]));
+            }
+            mc = fmaxf(mc, __shfl_xor(mc, 16));
+            mc = fmaxf(mc, __shfl_xor(mc, 32));
+            const float mn = fmaxf(m, mc);
+            // weight of what has been accumulated so far (nothing yet, or a row with no visible key so far: 0)
+            alpha = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m - mn);
+            const float nb = 10.0f - mn;
+            v2f ls = {0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < 8; mt++) {
+                if constexpr (FULL) {
+                    const v4f t = acc[mt] + nb;
+                    acc[mt] = (v4f){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]), __builtin_amdgcn_exp2f(t[3])};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[mt][r] = mt * 16 + 4 * kq + r < nvj ? __builtin_amdgcn_exp2f(acc[mt][r] + nb) : 0.f;
+                }
+                ls += acc[mt].lo;
+                ls += acc[mt].hi;
+            }
+            float lc = ls[0] + ls[1];
+            lc += __shfl_xor(lc, 16);
+            lc += __shfl_xor(lc, 32);
+            l = l * alpha + lc;
+            m = mn;
+        };
+        if (full) softmax(std::true_type{});
+        else softmax(std::false_type{});
+        if (c > 0) {   // (uniform) the rows this lane accumulates, 4*kq + r, take their weights from lanes j = 4*kq + r
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float ar = __shfl(alpha, 4 * kq + r);
+#pragma unroll
+                for (int nt = 0; nt < NTO; nt++) o[nt][r] *= ar;
+            }
+        }
+
+        ATT_STAMP(10 * c + 6);
+        // ---- O += P V: A = P (this lane's own accumulators, key tiles 2m and 2m+1), B = V^T rows from LDS ----
+#pragma unroll
+        for (int mm = 0; mm < 4; mm++) {
+            // p * 2^10 = hi + lo: hi = the leading 11 bits (a mask, exact in fp16 down to its subnormals), lo = the rest
+            half8_t ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const v4f &a4 = acc[2 * mm + (e >> 2)];
+                const float p0 = a4[e & 2], p1 = a4[(e & 2) + 1];
+                const float h0 = __uint_as_float(__float_as_uint(p0) & 0xFFFFE000u), h1 = __uint_as_float(__float_as_uint(p1) & 0xFFFFE000u);
+                const v2f lf = (v2f){p0, p1} - (v2f){h0, h1};
+                ph[e] = (_Float16)h0; ph[e + 1] = (_Float16)h1;
+                pl[e] = (_Float16)lf[0]; pl[e + 1] = (_Float16)lf[1];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTO; nt++) {
+                // B rows nt*16 + j, key segment 4*mm + kq (Kv16Image: swizzled, conflict-free)
+                const int vo = Img::v_off(nt * 16 + j, 4 * mm + kq);
+                const half8_t vh = *reinterpret_cast<const half8_t *>(VTh + vo);
+                const half8_t vl = *reinterpret_cast<const half8_t *>(VTl + vo);
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, o[nt], 0, 0, 0);
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, o[nt], 0, 0, 0);
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, o[nt], 0, 0, 0);
+            }
+        }
+        ATT_STAMP(10 * c + 7);
     }
 
-    ATT_STAMP(7);
-    // O tile: this lane holds rows 4*kq+r, columns d = nt*16 + j (the 16 lanes of a row write 64 contiguous bytes per nt)
+    // O tile: this lane holds rows 4*kq+r, columns d = nt*16 + j (the 16 lanes of a row write 64 contiguous bytes per nt);
+    // rows that see no key of this run leave no partial (the merge does not count this slot for them)
     constexpr float unscale = 1.0f / 1024.0f;
+    const int t_first = c_first * ATT_CH;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int vh = w * 16 + 4 * kq + r;
-        if (nv[vh] == 0) continue;
+        if (npos[vh] <= t_first) continue;
         const int item = i0 + vh / G, h = kvh * G + vh % G;
         const long long slot = (long long)item * P.part_item_stride + (long long)h * P.nsplit_max + split;
         float *po = P.part_o + slot * HD + j;
 #pragma unroll
         for (int nt = 0; nt < NTO; nt++) po[nt * 16] = o[nt][r] * unscale;
     }
-    if (kq == 0 && nvj > 0) {
+    if (kq == 0 && npos[w * 16 + j] > t_first) {
         const int vh = w * 16 + j, item = i0 + vh / G, h = kvh * G + vh % G;
         const long long slot = (long long)item * P.part_item_stride + (long long)h * P.nsplit_max + split;
-        P.part_ml[slot * 2] = m;
-        P.part_ml[slot * 2 + 1] = l;
+        P.part_ml[slot * 2] = m * LN2;
+        P.part_ml[slot * 2 + 1] = l * unscale;
     }
     ATT_STAMP(8);
 }

@@ -184,7 +184,8 @@ struct nl_engine {
         float *x = nullptr, *qkv = nullptr, *q = nullptr, *g = nullptr, *u = nullptr, *logits = nullptr,
               *part_o = nullptr, *part_ml = nullptr;
         int *tok = nullptr, *pos = nullptr, *stream = nullptr, *ids = nullptr;
-        int *h_meta = nullptr;  // pinned [3][cap]
+        int *h_meta = nullptr;  // pinned [5][cap]: token | position | stream | attention workgroup list | partials per token
+        uint4 *kv16 = nullptr;  // one layer's K / V^T of a prompt's stream as fp16 hi / lo LDS images (nl_batch.h Kv16Image)
     } bt;
 
     // on-device sampling (nl_sample_decode): scratch for one vocabulary, allocated on first use
@@ -435,9 +436,12 @@ void launch_attn_tile_g(const AttnParams &P, int n, int kvs, int nsplit, hipStre
     if (f32_tile) hipLaunchKernelGGL((attn_tile_kernel<HD, G, QT>), dim3(kvs, nsplit, (n + QT - 1) / QT), dim3(QT * G * 4), 0, st, P, n);
     else {
         constexpr int QT16 = AttnTile16QT<G>::value;
-        hipLaunchKernelGGL((attn_tile16_kernel<HD, G, QT16>), dim3(kvs, nsplit, (n + QT16 - 1) / QT16), dim3(QT16 * G * 4), 0, st, P, n);
+        if (P.live_map && P.kv16) hipLaunchKernelGGL((attn_tile16_kernel<HD, G, QT16, true>), dim3(kvs, nsplit /* = listed workgroups */, 1), dim3(QT16 * G * 4), 0, st, P, n);
+        else if (P.live_map) hipLaunchKernelGGL((attn_tile16_kernel<HD, G, QT16, false>), dim3(kvs, nsplit /* = listed workgroups */, 1), dim3(QT16 * G * 4), 0, st, P, n);
+        else hipLaunchKernelGGL((attn_tile16_kernel<HD, G, QT16, false>), dim3(kvs, nsplit, (n + QT16 - 1) / QT16), dim3(QT16 * G * 4), 0, st, P, n);
     }
 }
+inline int attn_tile16_qt(int gqa) { return NL_ATT16_MUL * (gqa == 1 ? 64 : gqa == 2 ? 32 : gqa == 8 ? 8 : 16); }   // = AttnTile16QT<G>::value
 inline bool attn_tile_supported(int gqa) { return gqa == 1 || gqa == 2 || gqa == 3 || gqa == 4 || gqa == 8; }
 template <int HD>
 hipError_t launch_attn_tile_hd(int gqa, const AttnParams &P, int n, int kvs, int nsplit, hipStream_t st) {
@@ -1198,11 +1202,15 @@ int batch_alloc(nl_engine *e) {
     HIPCK(e, dalloc(&b.kpart2, b.kpart_cap, &e->bytes_state));
     HIPCK(e, dalloc(&b.part_o, n * e->Hs * e->nsplit_max * e->hd, &e->bytes_state));
     HIPCK(e, dalloc(&b.part_ml, n * e->Hs * e->nsplit_max * 2, &e->bytes_state));
-    HIPCK(e, dalloc(&b.tok, 3 * n, &e->bytes_state));   // token | pos | stream, the layout of h_meta: one upload per step
+    HIPCK(e, dalloc(&b.tok, 5 * n, &e->bytes_state));   // token | pos | stream | attention workgroup list | partials per token, the layout of h_meta: one upload per step
     b.pos = b.tok + n;
     b.stream = b.tok + 2 * n;
     HIPCK(e, dalloc(&b.ids, n, &e->bytes_state));
-    HIPCK(e, hipHostMalloc((void **)&b.h_meta, 3 * n * sizeof(int), hipHostMallocDefault));
+    {   // one layer's K / V^T as fp16 hi / lo LDS images (Kv16Image), rebuilt per layer of a prompt step
+        const size_t img = e->hd == 64 ? Kv16Image<64>::BYTES : Kv16Image<32>::BYTES;
+        HIPCK(e, dalloc(&b.kv16, (size_t)e->KVs * e->nsplit_max * img / 16, &e->bytes_state));
+    }
+    HIPCK(e, hipHostMalloc((void **)&b.h_meta, 5 * n * sizeof(int), hipHostMallocDefault));
     b.ready = true;
     return NL_OK;
 }
@@ -1239,7 +1247,35 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
     hipStream_t st = e->stream;
     const int D = c.dim, hd = e->hd, HQ = e->Hs * hd, R = (e->Hs + 2 * e->KVs) * hd;
 #define LCK(expr) do { hipError_t s_ = (expr); if (s_ != hipSuccess) return e->fail(NL_ERR_HIP, "batched step: %s: %s", #expr, hipGetErrorString(s_)); } while (0)
-    LCK(hipMemcpyAsync(b.tok, b.h_meta, (size_t)3 * b.cap * 4, hipMemcpyHostToDevice, st));
+    // prompts (consecutive positions of one stream): the workgroups of the causal attention launch, each a query tile and a
+    // run of consecutive 128-key chunks under the diagonal (AttnParams::live_map), and how many partials every token gets.
+    // Run length: the shortest that lets every workgroup be resident at once (2 per CU); tiles are cut into equal runs.
+    int n_live = 0;
+    {
+        bool cons = one_stream && n >= 8 && attn_tile_supported(e->gqa) && !getenv("NL_ATTN_F32") && !getenv("NL_NO_ATTN_TILE");
+        for (int i = 1; i < n && cons; i++) cons = b.h_meta[b.cap + i] == b.h_meta[b.cap] + i;
+        const int qt = attn_tile16_qt(e->gqa), ntile = (n + qt - 1) / qt, p0 = b.h_meta[b.cap];
+        if (cons && (long long)ntile * e->nsplit_max <= b.cap && ntile <= 32768) {
+            auto chunks_of = [&](int z) { return std::min((p0 + std::min((z + 1) * qt, n) - 1) / ATT_CH + 1, e->nsplit_max); };
+            static const int run_knob = getenv("NL_ATT_RUN") ? atoi(getenv("NL_ATT_RUN")) : 0;   // developer knob: fixed run length
+            int run = run_knob > 0 ? run_knob : 1;
+            for (; run_knob <= 0 && run < e->nsplit_max; run++) {
+                long long wgs = 0;
+                for (int z = 0; z < ntile; z++) wgs += (chunks_of(z) + run - 1) / run;
+                if (wgs * e->KVs <= 2LL * e->num_cus) break;
+            }
+            int *map = b.h_meta + 3 * b.cap, *nparts = b.h_meta + 4 * b.cap;
+            for (int z = ntile - 1; z >= 0; z--) {   // the long tiles first
+                const int cz = chunks_of(z), nrun = (cz + run - 1) / run, len = (cz + nrun - 1) / nrun;
+                for (int k = 0; k * len < cz; k++) map[n_live++] = (z << 16) | (k << 12) | ((k * len) << 6) | std::min(len, cz - k * len);
+                for (int i = z * qt; i < std::min((z + 1) * qt, n); i++) nparts[i] = ((p0 + i) / ATT_CH) / len + 1;
+            }
+        }
+    }
+    // ... whose chunks are split into fp16 halves once per layer (kv16_build_kernel) when several query tiles read them
+    static const int kv16_min = getenv("NL_KV16_MIN_TOKENS") ? atoi(getenv("NL_KV16_MIN_TOKENS")) : 256;
+    const bool kv16_on = n_live > 0 && n >= kv16_min && b.kv16 != nullptr;
+    LCK(hipMemcpyAsync(b.tok, b.h_meta, (size_t)5 * b.cap * 4, hipMemcpyHostToDevice, st));
     {
         BEmbedParams P{e->embd_raw, e->embd_type, D, b.tok, b.x, e->gamma_row, e->gamma_val};
         hipLaunchKernelGGL(bembed_kernel, dim3(n), dim3(256), 0, st, P);
@@ -1331,8 +1367,19 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
                 T.single_stream = c.max_streams == 1 ? 1 : 0;
                 T.pos_base_valid = consecutive ? 1 : 0;   // (a prompt: the kernel derives its key range without reading bpos)
                 T.pos_base = b.h_meta[b.cap];
-                LCK(hd == 64 ? launch_attn_tile_hd<64>(e->gqa, T, n, e->KVs, nsplit, st)
-                             : launch_attn_tile_hd<32>(e->gqa, T, n, e->KVs, nsplit, st));
+                T.live_map = n_live > 0 ? b.tok + 3 * b.cap : nullptr;
+                if (n_live > 0 && kv16_on) {
+                    // every chunk the prompt can see, split into fp16 halves once for all the tiles that read it
+                    const long long so = T.single_stream ? 0 : (long long)b.h_meta[2 * b.cap] * e->kv_stream_stride;
+                    const int n_keys = b.h_meta[b.cap] + n;
+                    Kv16BuildParams KB{kc + so, vc + so, b.kv16, c.seq_len, e->nsplit_max, n_keys};
+                    const dim3 kg(e->KVs, (n_keys + ATT_CH - 1) / ATT_CH);
+                    if (hd == 64) hipLaunchKernelGGL(kv16_build_kernel<64>, kg, dim3(512), 0, st, KB);
+                    else hipLaunchKernelGGL(kv16_build_kernel<32>, kg, dim3(512), 0, st, KB);
+                    T.kv16 = b.kv16;
+                }
+                LCK(hd == 64 ? launch_attn_tile_hd<64>(e->gqa, T, n, e->KVs, n_live > 0 ? n_live : nsplit, st)
+                             : launch_attn_tile_hd<32>(e->gqa, T, n, e->KVs, n_live > 0 ? n_live : nsplit, st));
             } else if (fin_attn) {
                 // every position < 128: one split per row, the attention kernel normalises and writes the fragments
                 P.fin_xf = b.xfrag; P.fin_nt16 = nt16; P.fin_q4 = L.wo.wtype == WT_Q4_0 ? 1 : 0;
@@ -1346,7 +1393,7 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
             }
             if (!merged) {
             const bool tile16 = one_stream && n >= 8 && attn_tile_supported(e->gqa) && !no_tile;
-            BMergeParams M{b.part_o, b.part_ml, b.pos, e->Hs, e->nsplit_max, hd, b.xfrag, nt16, L.wo.wtype == WT_Q4_0 ? 1 : 0, tile16 ? 1 : 0};
+            BMergeParams M{b.part_o, b.part_ml, b.pos, tile16 && n_live > 0 ? b.tok + 4 * b.cap : nullptr, e->Hs, e->nsplit_max, hd, b.xfrag, nt16, L.wo.wtype == WT_Q4_0 ? 1 : 0, tile16 ? 1 : 0};
             {
                 const long long units = (long long)n * e->Hs * hd / 8;
                 hipLaunchKernelGGL(battn_merge_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, M, n);
@@ -1435,6 +1482,9 @@ const char *nl_build_info(void) { return "src=" NL_SRC_SHA " git=" NL_GIT_HEAD; 
 // developer build only (tools/att_stamps.sh): phase stamps of one workgroup of the prompt attention kernel
 __attribute__((visibility("default"))) int nl_debug_att_stamps(long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nl::g_att_stamps), 64 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+__attribute__((visibility("default"))) int nl_debug_att_census(long long *out) {   // 4 x 8192 values
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nl::g_att_census), 4 * 8192 * sizeof(long long)) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -1881,7 +1931,7 @@ int nl_destroy(nl_handle e) {
     {
         nl_engine::Batch &b = e->bt;
         void *bb[] = {b.x, b.qkv, b.q, b.g, b.u, b.logits, b.part_o, b.part_ml, b.tok /* | pos | stream */, b.ids, b.kpart, b.kpart2,
-                      b.xfrag, b.xfrag2, b.ssq};
+                      b.xfrag, b.xfrag2, b.ssq, b.kv16};
         for (void *p : bb) if (p) hipFree(p);
         if (b.h_meta) hipHostFree(b.h_meta);
     }
