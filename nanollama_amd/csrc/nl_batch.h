@@ -738,24 +738,31 @@ __global__ void __launch_bounds__(QT * G * 4, 2) attn_tile_kernel(AttnParams P, 
 // 256 of them (8192 SIMD cycles) per wavefront.  Here every f32 operand is split x = hi + lo into two fp16 values
 // (split_hi_lo, ~2^-22 relative; the lo x lo term is dropped) and each product becomes three
 // v_mfma_f32_16x16x32_f16 (hi*hi + lo*hi + hi*lo, f32 accumulation): 96 MFMAs of 16 cycles per wavefront.
-//   * K is split while it is staged: Kh / Kl[key][hd] fp16, natural layout (A operand of S^T = K q^T: a lane
-//     reads 8 consecutive head_dim elements of its key with one ds_read_b128).
-//   * V is split AND transposed while it is staged: VTh / VTl[d][key position] -- the 16-bit MFMA wants a lane
-//     to hold 8 reduction indices (keys) of one output column d.  Two adjacent keys are packed per ds_write_b32.
-//     The key -> position map inside each 32-key group puts the 8 keys a lane owns side by side
-//     (key = 32m + 16h + 4kg + e  ->  position 32m + 8kg + 4h + e), which is exactly how the S^T accumulators
-//     leave P in registers (lane (row, kg) holds keys 16*mt + 4kg + e of key tile mt): P is converted in place,
-//     never moved, and V^T is read with one ds_read_b128 per operand.
-//   * p is scaled by 2^10 before its split (exact; keeps p down to 3e-11 above the fp16 underflow) and the
-//     output by 2^-10; max / sum are taken from the unscaled f32 values.
-// Partials (max, sum, sum p*v) leave in the decode kernel's layout, so battn_merge_kernel is shared.
+//   * K is split into Kh / Kl[key][hd] fp16 (A operand of S^T = K q^T: a lane reads 8 consecutive head_dim
+//     elements of its key with one ds_read_b128).
+//   * V is split AND transposed: VTh / VTl[d][key position] -- the 16-bit MFMA wants a lane to hold 8 reduction
+//     indices (keys) of one head_dim element d.  The key -> position map inside each 32-key group puts the 8 keys a
+//     lane owns side by side (key = 32m + 16h + 4kg + e  ->  position 32m + 8kg + 4h + e), which is exactly how the
+//     S^T accumulators leave P in registers (lane (row, kg) holds keys 16*mt + 4kg + e of key tile mt): P is converted
+//     in place, never moved, and V^T is read with one ds_read_b128 per operand.
+//   * Both are XOR-swizzled 16-byte segments of unpadded rows (Kv16Image): conflict-free under ds_read_b128's lane groups.
+//   * A workgroup folds a RUN of chunks with the online softmax in registers: log2 domain, two elements per instruction;
+//     p * 2^10 = hi (a mask) + lo, the running output as O^T = V^T P^T so that a query row stays in one lane column.
+//   * From 256 tokens on (SHADOW) the images are built once per layer by kv16_build_kernel and a workgroup takes 256 rows.
+// Partials (max, sum, sum p*v) leave in the decode kernel's layout, one per run, so battn_merge_kernel is shared.
+// Measured (mini, 2047 tokens, per layer): 52 us attention + 15 us merge at the start of round 3 (one chunk per
+// workgroup, every workgroup converting its chunk) -> 31 + 6 (images) + 7 us.  What is left: the matrix, vector and LDS
+// pipes of a SIMD take turns -- all the wavefronts between two chunk barriers are in the same phase -- at ~38 % MFMA
+// busy (profiles/r03_prompt_attention.txt has the stamps, the census and the SQ counters of every step).
 #ifdef NL_ATT_STAMPS
 // developer build (tools/att_stamps.sh): phase stamps of one workgroup + a census of every workgroup of the last launch
 // (entry / exit on the 100 MHz wall clock, HW_ID and XCC_ID registers)
 __device__ long long g_att_stamps[64];
 __device__ long long g_att_census[4 * 8192];
+__device__ long long g_att_timeline[512 * 64];   // the same stamps of every workgroup (linear id < 512), wall clock
 #define ATT_STAMP(i) do { \
     if (kvh == 1 && c_first == 0 && i0 == NL_ATT_STAMPS * QT && threadIdx.x == 64 && (i) < 64) g_att_stamps[(i)] = clock64(); \
+    if (threadIdx.x == 64 && (i) < 64 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 512) g_att_timeline[blockIdx.x * 64 + (i)] = clock64(); \
     if (((i) == 0 || (i) == 8) && threadIdx.x == 0) { \
         const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; \
         if (wg_ < 8192) { \
@@ -867,6 +874,23 @@ __global__ void __launch_bounds__(512) kv16_build_kernel(Kv16BuildParams P) {
     for (int i = tid; i < Img::BYTES / 16; i += 512) dst[i] = src[i];
 }
 
+// max / sum over the four lanes j, j + 16, j + 32, j + 48 (one per row of 16), result in all four: gfx950's
+// v_permlane16_swap (odd rows of the first operand <-> even rows of the second) and v_permlane32_swap (upper half <->
+// lower half) are vector-pipe instructions -- __shfl_xor(v, 16 / 32) is a ds_bpermute round trip each, and a wavefront
+// of the kernel below had eight of them in a row per chunk.
+__device__ __forceinline__ float rows4_max(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows4_sum(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 template <int HD, int G, int QT, bool SHADOW>
 __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16_kernel(AttnParams P, int n_items) {
     constexpr int VH = QT * G;               // rows (token, query head) per workgroup
@@ -877,17 +901,18 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
     constexpr int NKS = HD / 32;             // 32-wide reduction steps of q.k
     constexpr int NTO = HD / 16;             // output column tiles
     static_assert(ATT_CH == 128, "key position map below assumes 4 groups of 32 keys");
-    __shared__ __attribute__((aligned(16))) _Float16 Kimg[Img::K_HALVES], Vimg[Img::V_HALVES];
-    _Float16 *const Kh = Kimg, *const Kl = Kimg + ATT_CH * KS, *const VTh = Vimg, *const VTl = Vimg + HD * VS;
+    constexpr int NBUF = SHADOW ? 2 : 1;     // SHADOW: the next chunk's images travel while this chunk is multiplied
+    __shared__ __attribute__((aligned(16))) _Float16 Kimg[NBUF][Img::K_HALVES], Vimg[NBUF][Img::V_HALVES];
     __shared__ int npos[VH];                 // keys visible to each row: its position + 1 (0: no such item)
 
     // a workgroup = one query tile x a RUN of consecutive 128-key chunks, folded with the online softmax in registers;
     // its (max, sum, sum p*v) leaves as partial `slot` of the tile's items.  Prompts come with the host's list of runs
-    // (AttnParams::live_map: tile << 16 | slot << 12 | first chunk << 6 | chunks); without it the grid is
-    // (kv head, chunk, tile) with one chunk per workgroup.
-    const int kvh = blockIdx.x, tid = threadIdx.x;
-    const int code = P.live_map ? sload_i32(P.live_map + blockIdx.y) : 0;
-    const int i0 = (P.live_map ? (code >> 16) : (int)blockIdx.z) * QT;
+    // (AttnParams::live_map, one entry per blockIdx.x: kv head << 24 | tile << 16 | slot << 12 | first chunk << 6 | chunks);
+    // without it the grid is (kv head, chunk, tile) with one chunk per workgroup.
+    const int tid = threadIdx.x;
+    const int code = P.live_map ? sload_i32(P.live_map + blockIdx.x) : 0;
+    const int kvh = P.live_map ? (int)((unsigned)code >> 24) : (int)blockIdx.x;
+    const int i0 = (P.live_map ? ((code >> 16) & 255) : (int)blockIdx.z) * QT;
     const int split = P.live_map ? ((code >> 12) & 15) : (int)blockIdx.y;           // partial slot
     const int c_first = P.live_map ? ((code >> 6) & 63) : (int)blockIdx.y;
     int c_count = P.live_map ? (code & 63) : 1;
@@ -906,19 +931,31 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
     c_count = min(c_count, maxpos / ATT_CH + 1 - c_first);
     const int lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
     ATT_STAMP(0);
-    // SHADOW: a chunk's image, built by kv16_build_kernel, goes straight into LDS (global_load_lds_dwordx4: 1 KB per
-    // instruction, 64 per chunk); the first chunk's leaves before anything else is fetched
-    [[maybe_unused]] auto dma_chunk = [&](int chunk) {
-        const char *src = reinterpret_cast<const char *>(P.kv16) + ((long long)kvh * P.nsplit_max + chunk) * Img::BYTES + lane * 16;
+    // SHADOW: a chunk's images, built by kv16_build_kernel, go straight into LDS (global_load_lds_dwordx4: 1 KB per
+    // instruction, 64 per chunk) one chunk ahead of the arithmetic.  What bounds this kernel is the rate at which a CU
+    // pulls those images out of the L2 -- 11-13 B/clk (MI355X_MICROARCH.md, the prologue-burst row; measured here as
+    // ~5k cycles per 64 KB chunk however the requests were placed) against ~3k cycles of MFMA work per 128 rows -- so a
+    // workgroup takes 256 rows (16 wavefronts, one workgroup per CU) per staged chunk and double-buffers the images.
+    // The DMA is issued from inline asm (cdna_hip_programming.md 5.7): hipcc counts a builtin LDS-DMA and drains it
+    // (vmcnt(0)) in front of the next LDS read it cannot prove disjoint, i.e. right away; these it does not see, and the
+    // one wait per chunk is written out.  Source = scalar base + one VGPR of lane offsets: a per-lane 64-bit address kept
+    // across the loop is spilled by hipcc and reloaded from scratch behind every barrier.
+    [[maybe_unused]] auto dma_chunk = [&](int chunk, int buf) {
+        const char *sbase = reinterpret_cast<const char *>(P.kv16) + ((long long)kvh * P.nsplit_max + chunk) * Img::BYTES;
         const int wv = __builtin_amdgcn_readfirstlane(w);
-        for (int i = wv; i < Img::K_BYTES / 1024; i += NW)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * 1024),
-                                             (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(Kimg) + i * 1024), 16, 0, 0);
-        for (int i = wv; i < Img::V_BYTES / 1024; i += NW)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + Img::K_BYTES + i * 1024),
-                                             (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(Vimg) + i * 1024), 16, 0, 0);
+        const unsigned kdst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&Kimg[buf][0]);
+        const unsigned vdst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&Vimg[buf][0]);
+        const unsigned voff = (unsigned)lane * 16u;
+        constexpr int NPK = Img::K_BYTES / 1024, NPV = Img::V_BYTES / 1024;
+        for (int i = wv; i < NPK + NPV; i += NW) {
+            unsigned keep;
+            const unsigned dst = i < NPK ? kdst + i * 1024 : vdst + (i - NPK) * 1024;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(dst), "s"(sbase + i * 1024) : "memory");
+        }
     };
-    if constexpr (SHADOW) dma_chunk(c_first);
+    [[maybe_unused]] auto dma_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    if constexpr (SHADOW) dma_chunk(c_first, 0);
 
     // B operand of S^T: row w*16+j, head_dim elements 32*ks + 8*kq .. +7, as hi / lo halves
     half8_t qh[NKS], ql[NKS];
@@ -946,7 +983,7 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
     typedef float v2f __attribute__((ext_vector_type(2)));
     const float c2 = P.scale * LOG2E;
     float m = -INFINITY, l = 0.f;            // running max (log2 domain) / sum * 2^10 of row j (the same value in its four kq lanes)
-    v4f o[NTO];                              // running sum p*v * 2^10: rows 4*kq+r, columns nt*16 + j
+    v4f o[NTO];                              // running sum p*v * 2^10 of row j: head_dim elements nt*16 + 4*kq + r
 #pragma unroll
     for (int nt = 0; nt < NTO; nt++) o[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
@@ -955,11 +992,9 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
         const int t0 = (c_first + c) * ATT_CH;
         const int nrows = min(ATT_CH, maxpos + 1 - t0);
         const bool full = minpos >= t0 + ATT_CH - 1;   // every row of the tile sees every key of this chunk
+        _Float16 *const Kh = Kimg[c & (NBUF - 1)], *const Kl = Kh + ATT_CH * KS, *const VTh = Vimg[c & (NBUF - 1)], *const VTl = VTh + HD * VS;
         if constexpr (SHADOW) {
-            if (c > 0) {
-                __syncthreads();                       // every wavefront is done with the previous chunk's K / V^T
-                dma_chunk(c_first + c);
-            }
+            dma_landed();                              // this wavefront's pieces of the chunk (issued a chunk ago)
             ATT_STAMP(10 * c + 1);
         } else {
             const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
@@ -967,7 +1002,10 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
             kv16_stage<HD, NTH>(K4, V4, nrows, tid, Kh, Kl, VTh, VTl, c > 0);
         }
         ATT_STAMP(10 * c + 3);
-        __syncthreads();
+        __syncthreads();                               // the chunk is in LDS; every wavefront is past the previous chunk
+        if constexpr (SHADOW) {
+            if (c + 1 < c_count) dma_chunk(c_first + c + 1, (c + 1) & 1);
+        }
         ATT_STAMP(10 * c + 4);
 
         // ---- S^T = K q^T: 8 key tiles x 16 rows; lane (j, kq) ends up with row j's scores for keys 16*mt + 4*kq + r
@@ -1019,8 +1057,7 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
                 }
                 mc = fmaxf(fmaxf(mc, fmaxf(acc[mt][0], acc[mt][1])), fmaxf(acc[mt][2], acc[mt][3]));
             }
-            mc = fmaxf(mc, __shfl_xor(mc, 16));
-            mc = fmaxf(mc, __shfl_xor(mc, 32));
+            mc = rows4_max(mc);
             const float mn = fmaxf(m, mc);
             // weight of what has been accumulated so far (nothing yet, or a row with no visible key so far: 0)
             alpha = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m - mn);
@@ -1038,25 +1075,21 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
                 ls += acc[mt].lo;
                 ls += acc[mt].hi;
             }
-            float lc = ls[0] + ls[1];
-            lc += __shfl_xor(lc, 16);
-            lc += __shfl_xor(lc, 32);
+            const float lc = rows4_sum(ls[0] + ls[1]);
             l = l * alpha + lc;
             m = mn;
         };
         if (full) softmax(std::true_type{});
         else softmax(std::false_type{});
-        if (c > 0) {   // (uniform) the rows this lane accumulates, 4*kq + r, take their weights from lanes j = 4*kq + r
+        if (c > 0) {   // (uniform)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float ar = __shfl(alpha, 4 * kq + r);
-#pragma unroll
-                for (int nt = 0; nt < NTO; nt++) o[nt][r] *= ar;
-            }
+            for (int nt = 0; nt < NTO; nt++) o[nt] = o[nt] * alpha;
         }
 
         ATT_STAMP(10 * c + 6);
-        // ---- O += P V: A = P (this lane's own accumulators, key tiles 2m and 2m+1), B = V^T rows from LDS ----
+        // ---- O^T += V^T P^T: A = V^T rows from LDS, B = P^T (this lane's own accumulators, key tiles 2m and 2m+1).  The
+        //      transposed product keeps query row j in lane column j, where S^T left its max and sum: the running output is
+        //      rescaled in place, and a lane ends up with four consecutive head_dim elements of its row ----
 #pragma unroll
         for (int mm = 0; mm < 4; mm++) {
             // p * 2^10 = hi + lo: hi = the leading 11 bits (a mask, exact in fp16 down to its subnormals), lo = the rest
@@ -1076,27 +1109,27 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
                 const int vo = Img::v_off(nt * 16 + j, 4 * mm + kq);
                 const half8_t vh = *reinterpret_cast<const half8_t *>(VTh + vo);
                 const half8_t vl = *reinterpret_cast<const half8_t *>(VTl + vo);
-                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, o[nt], 0, 0, 0);
-                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, o[nt], 0, 0, 0);
-                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, o[nt], 0, 0, 0);
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, o[nt], 0, 0, 0);
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o[nt], 0, 0, 0);
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o[nt], 0, 0, 0);
             }
         }
         ATT_STAMP(10 * c + 7);
     }
 
-    // O tile: this lane holds rows 4*kq+r, columns d = nt*16 + j (the 16 lanes of a row write 64 contiguous bytes per nt);
-    // rows that see no key of this run leave no partial (the merge does not count this slot for them)
+    // O^T tile: this lane holds row j's head_dim elements nt*16 + 4*kq .. +3 (the four lanes of a row write 64 contiguous
+    // bytes per nt); rows that see no key of this run leave no partial (the merge does not count this slot for them)
     constexpr float unscale = 1.0f / 1024.0f;
     const int t_first = c_first * ATT_CH;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int vh = w * 16 + 4 * kq + r;
-        if (npos[vh] <= t_first) continue;
-        const int item = i0 + vh / G, h = kvh * G + vh % G;
+    if (npos[w * 16 + j] > t_first) {
+        const int vh = w * 16 + j, item = i0 + vh / G, h = kvh * G + vh % G;
         const long long slot = (long long)item * P.part_item_stride + (long long)h * P.nsplit_max + split;
-        float *po = P.part_o + slot * HD + j;
+        float *po = P.part_o + slot * HD + 4 * kq;
 #pragma unroll
-        for (int nt = 0; nt < NTO; nt++) po[nt * 16] = o[nt][r] * unscale;
+        for (int nt = 0; nt < NTO; nt++) {
+            const v4f ov = o[nt] * unscale;
+            *reinterpret_cast<float4 *>(po + nt * 16) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        }
     }
     if (kq == 0 && npos[w * 16 + j] > t_first) {
         const int vh = w * 16 + j, item = i0 + vh / G, h = kvh * G + vh % G;
@@ -1113,6 +1146,8 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
 #define NL_ATT16_MUL 2
 #endif
 template <int G> struct AttnTile16QT { static constexpr int value = NL_ATT16_MUL * (G == 1 ? 64 : G == 2 ? 32 : G == 8 ? 8 : 16); };
+// ... and 256 rows = 16 wavefronts, one workgroup per CU, when the chunks come as prebuilt images (SHADOW, see the kernel)
+template <int G> struct AttnTile16ShadowQT { static constexpr int value = 2 * AttnTile16QT<G>::value; };
 template <int G> struct AttnTileQT { static constexpr int value = G == 1 ? 64 : G == 2 ? 32 : G == 8 ? 8 : 16; };
 
 }  // namespace nl

@@ -436,8 +436,8 @@ void launch_attn_tile_g(const AttnParams &P, int n, int kvs, int nsplit, hipStre
     if (f32_tile) hipLaunchKernelGGL((attn_tile_kernel<HD, G, QT>), dim3(kvs, nsplit, (n + QT - 1) / QT), dim3(QT * G * 4), 0, st, P, n);
     else {
         constexpr int QT16 = AttnTile16QT<G>::value;
-        if (P.live_map && P.kv16) hipLaunchKernelGGL((attn_tile16_kernel<HD, G, QT16, true>), dim3(kvs, nsplit /* = listed workgroups */, 1), dim3(QT16 * G * 4), 0, st, P, n);
-        else if (P.live_map) hipLaunchKernelGGL((attn_tile16_kernel<HD, G, QT16, false>), dim3(kvs, nsplit /* = listed workgroups */, 1), dim3(QT16 * G * 4), 0, st, P, n);
+        if (P.live_map && P.kv16) hipLaunchKernelGGL((attn_tile16_kernel<HD, G, AttnTile16ShadowQT<G>::value, true>), dim3(nsplit /* = listed workgroups */), dim3(AttnTile16ShadowQT<G>::value * G * 4), 0, st, P, n);
+        else if (P.live_map) hipLaunchKernelGGL((attn_tile16_kernel<HD, G, QT16, false>), dim3(nsplit /* = listed workgroups */), dim3(QT16 * G * 4), 0, st, P, n);
         else hipLaunchKernelGGL((attn_tile16_kernel<HD, G, QT16, false>), dim3(kvs, nsplit, (n + QT16 - 1) / QT16), dim3(QT16 * G * 4), 0, st, P, n);
     }
 }
@@ -1250,31 +1250,45 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
     // prompts (consecutive positions of one stream): the workgroups of the causal attention launch, each a query tile and a
     // run of consecutive 128-key chunks under the diagonal (AttnParams::live_map), and how many partials every token gets.
     // Run length: the shortest that lets every workgroup be resident at once (2 per CU); tiles are cut into equal runs.
+    // Prompts of several query tiles (n >= NL_KV16_MIN_TOKENS): the chunks are split into fp16 halves once per layer
+    // (kv16_build_kernel) and a workgroup takes twice the rows, one workgroup per CU (AttnTile16ShadowQT).
     int n_live = 0;
+    bool kv16_on = false;
     {
         bool cons = one_stream && n >= 8 && attn_tile_supported(e->gqa) && !getenv("NL_ATTN_F32") && !getenv("NL_NO_ATTN_TILE");
         for (int i = 1; i < n && cons; i++) cons = b.h_meta[b.cap + i] == b.h_meta[b.cap] + i;
-        const int qt = attn_tile16_qt(e->gqa), ntile = (n + qt - 1) / qt, p0 = b.h_meta[b.cap];
-        if (cons && (long long)ntile * e->nsplit_max <= b.cap && ntile <= 32768) {
+        const int kv16_min = getenv("NL_KV16_MIN_TOKENS") ? atoi(getenv("NL_KV16_MIN_TOKENS")) : 256;   // (read per step: a test lowers it)
+        kv16_on = cons && n >= kv16_min && b.kv16 != nullptr;
+        const int qt = attn_tile16_qt(e->gqa) * (kv16_on ? 2 : 1), ntile = (n + qt - 1) / qt, p0 = b.h_meta[b.cap];
+        const long long slots = (long long)e->num_cus * (kv16_on ? 1 : 2);   // workgroups resident at once
+        if (cons && ntile <= 256 && e->KVs <= 255) {
             auto chunks_of = [&](int z) { return std::min((p0 + std::min((z + 1) * qt, n) - 1) / ATT_CH + 1, e->nsplit_max); };
             static const int run_knob = getenv("NL_ATT_RUN") ? atoi(getenv("NL_ATT_RUN")) : 0;   // developer knob: fixed run length
             int run = run_knob > 0 ? run_knob : 1;
             for (; run_knob <= 0 && run < e->nsplit_max; run++) {
                 long long wgs = 0;
                 for (int z = 0; z < ntile; z++) wgs += (chunks_of(z) + run - 1) / run;
-                if (wgs * e->KVs <= 2LL * e->num_cus) break;
+                if (wgs * e->KVs <= slots) break;
             }
             int *map = b.h_meta + 3 * b.cap, *nparts = b.h_meta + 4 * b.cap;
-            for (int z = ntile - 1; z >= 0; z--) {   // the long tiles first
+            std::vector<int> wg;
+            for (int z = ntile - 1; z >= 0; z--) {
                 const int cz = chunks_of(z), nrun = (cz + run - 1) / run, len = (cz + nrun - 1) / nrun;
-                for (int k = 0; k * len < cz; k++) map[n_live++] = (z << 16) | (k << 12) | ((k * len) << 6) | std::min(len, cz - k * len);
+                for (int k = 0; k * len < cz; k++)
+                    for (int kv = 0; kv < e->KVs; kv++)
+                        wg.push_back((int)((unsigned)kv << 24) | (z << 16) | (k << 12) | ((k * len) << 6) | std::min(len, cz - k * len));
                 for (int i = z * qt; i < std::min((z + 1) * qt, n); i++) nparts[i] = ((p0 + i) / ATT_CH) / len + 1;
             }
+            if ((int)wg.size() <= b.cap) {
+                // the longest runs first; with two workgroups per CU, i and i + #CUs share one (tools/att_stamps.py census):
+                // the entries past the first #CUs follow shortest first, so every CU's pair does about the same work
+                std::stable_sort(wg.begin(), wg.end(), [](int a, int c2) { return (a & 63) > (c2 & 63); });
+                if (!kv16_on && (int)wg.size() > e->num_cus) std::reverse(wg.begin() + e->num_cus, wg.end());
+                for (int v : wg) map[n_live++] = v;
+            }
         }
+        kv16_on = kv16_on && n_live > 0;
     }
-    // ... whose chunks are split into fp16 halves once per layer (kv16_build_kernel) when several query tiles read them
-    static const int kv16_min = getenv("NL_KV16_MIN_TOKENS") ? atoi(getenv("NL_KV16_MIN_TOKENS")) : 256;
-    const bool kv16_on = n_live > 0 && n >= kv16_min && b.kv16 != nullptr;
     LCK(hipMemcpyAsync(b.tok, b.h_meta, (size_t)5 * b.cap * 4, hipMemcpyHostToDevice, st));
     {
         BEmbedParams P{e->embd_raw, e->embd_type, D, b.tok, b.x, e->gamma_row, e->gamma_val};
@@ -1482,6 +1496,9 @@ const char *nl_build_info(void) { return "src=" NL_SRC_SHA " git=" NL_GIT_HEAD; 
 // developer build only (tools/att_stamps.sh): phase stamps of one workgroup of the prompt attention kernel
 __attribute__((visibility("default"))) int nl_debug_att_stamps(long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nl::g_att_stamps), 64 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+__attribute__((visibility("default"))) int nl_debug_att_timeline(long long *out) {   // 512 x 64 values
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nl::g_att_timeline), 512 * 64 * sizeof(long long)) == hipSuccess ? 0 : -1;
 }
 __attribute__((visibility("default"))) int nl_debug_att_census(long long *out) {   // 4 x 8192 values
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nl::g_att_census), 4 * 8192 * sizeof(long long)) == hipSuccess ? 0 : -1;

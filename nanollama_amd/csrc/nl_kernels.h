@@ -1058,10 +1058,11 @@ struct AttnParams {
     // attn_tile16_kernel: the step's positions are pos_base + item (a prompt) when pos_base_valid -- the workgroup then
     // knows its key range without reading bpos, and its K / V requests leave at entry
     int pos_base_valid, pos_base;
-    // ... and the launch is COMPACT then: blockIdx.y indexes the host-built list of workgroups, each a query tile and a run
-    // of consecutive 128-key chunks under the causal diagonal (tile << 16 | partial slot << 12 | first chunk << 6 | chunks)
-    // instead of a tiles x chunks grid half of whose workgroups -- the ones above the diagonal -- are dispatched, given
-    // 72 KB of LDS and exit
+    // ... and the launch is COMPACT then: blockIdx.x indexes the host-built list of workgroups, each a kv head, a query tile
+    // and a run of consecutive 128-key chunks under the causal diagonal (kv head << 24 | tile << 16 | partial slot << 12 |
+    // first chunk << 6 | chunks) instead of a tiles x chunks grid half of whose workgroups -- the ones above the diagonal --
+    // are dispatched, given LDS and exit.  The list is ordered so that the two workgroups of a CU (i and i + #CUs, measured)
+    // are a long run and a short one.
     const int *live_map;
     // ... and K / V^T arrive already split into fp16 hi / lo halves and laid out as the workgroup's LDS image, one image per
     // (kv head, 128-key chunk), built once per layer by kv16_build_kernel (null: every workgroup converts its own chunks)

@@ -698,6 +698,36 @@ def test_prefill_attention_tiles_every_gqa_ratio(hip, orc, tmp_path, heads, kv, 
     dev.close()
 
 
+@pytest.mark.parametrize("kv16_min", [16, 1 << 30])
+@pytest.mark.parametrize("heads,kv,hd", [(4, 1, 64), (6, 2, 32), (8, 1, 32), (2, 2, 64)])
+def test_prefill_attention_chunk_runs_with_and_without_prebuilt_images(hip, orc, tmp_path, monkeypatch, heads, kv, hd, kv16_min):
+    # Prompts: a workgroup of attn_tile16_kernel folds a RUN of 128-key chunks with an online softmax.  From 256 tokens on
+    # the chunks arrive as fp16 hi/lo LDS images built once per layer (kv16_build_kernel) and fetched by LDS-DMA into a
+    # double buffer, 256 rows per workgroup; below, every workgroup converts its own chunks (128 rows).  Both variants,
+    # forced by NL_KV16_MIN_TOKENS, on a 700-token prompt in three calls (ragged tiles, pos0 > 0, runs of several chunks,
+    # rows that see no key of a run's first chunk) against the oracle.
+    monkeypatch.setenv("NL_KV16_MIN_TOKENS", str(kv16_min))
+    shape = replace(synth.TIERS["tiny"], name=f"r{heads}_{kv}_{hd}", dim=heads * hd, n_head=heads, n_kv_head=kv,
+                    seq_len=768, interm=128, n_layer=2)
+    p = tmp_path / "g.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 57)
+    g = gguf.load_gguf(str(p))
+    dev = hip.load_llama_model(g)
+    ref = orc.OracleModel(g)
+    toks = synth.prompt_ids(700, shape.vocab, seed=13)
+    for pos, t in enumerate(toks):
+        want = ref.forward(t, pos)
+    dev.prefill(toks[:45], want_logits=False)
+    dev.prefill(toks[45:391], pos0=45, want_logits=False)
+    dev.prefill(toks[391:], pos0=391)
+    err = float(np.abs(dev.state.logits - want).max())
+    print(f"\nheads={heads} kv={kv} hd={hd} images from {kv16_min} tokens: max|gpu-oracle|={err:.2e}")
+    assert err <= LOGIT_TOL * max(1.0, float(want.std()))
+    nxt = int(np.argmax(want))
+    assert dev.decode_greedy(nxt, len(toks), 3)[0] == int(np.argmax(ref.forward(nxt, len(toks))))
+    dev.close()
+
+
 @pytest.mark.parametrize("dim,heads,kv,hd,interm,n", [(160, 5, 5, 32, 224, 200), (192, 3, 1, 64, 352, 131), (256, 4, 1, 64, 96, 300)])
 def test_q4_prompt_gemm_through_lds_matches_the_per_wavefront_kernel(hip, orc, tmp_path, monkeypatch, dim, heads, kv, hd, interm, n):
     # Q4_0 prompts of >= 128 tokens take qgemm2_kernel (weights expanded once per workgroup into LDS, nl_qgemm2.h) with

@@ -17,7 +17,7 @@ L.nl_debug_att_stamps.argtypes = [C.POINTER(C.c_longlong)]
 print("rc", L.nl_debug_att_stamps(out))
 t0 = out[0]
 print(f"entry +0; exit +{out[8] - t0}")
-names = {1: "chunk requested (DMA issued / loads issued)", 3: "chunk in LDS (own part)", 4: "after barrier", 5: "S^T issued", 6: "softmax done", 7: "PV issued"}
+names = {1: "chunk landed (own pieces)", 3: "-", 4: "barrier, next chunk requested", 5: "S^T issued", 6: "softmax done", 7: "PV issued"}
 prev = t0
 for c in range(6):
     if out[10 * c + 4] == 0 and c > 0: break
@@ -58,4 +58,34 @@ if L.nl_debug_att_census(cen) == 0:
         for _, d in ev:
             k += d; peak = max(peak, k)
     print(f"  peak workgroups resident on one CU (first 64 CUs): {peak}")
+    lo_half = ids_all = np.nonzero(np.array(cen[:], dtype=np.int64).reshape(8192, 4)[:, 1] > 0)[0]
+    for name, m in (("first #CUs workgroups", lo_half < 256), ("the rest", lo_half >= 256)):
+        if m.any(): print(f"  {name}: {int(m.sum())}, lifetime us min/median/max {life[m].min():.2f}/{np.median(life[m]):.2f}/{life[m].max():.2f}, start us median {np.median((t_in[m] - base) / 100.0):.2f}, end us median {np.median((t_out[m] - base) / 100.0):.2f}")
+    order = np.argsort(-life)[:8]
+    print("  longest-lived workgroups (linear id, start us, lifetime us):", [(int(lo_half[i]), round(float((t_in[i] - base) / 100.0), 1), round(float(life[i]), 1)) for i in order])
+    ids = np.nonzero(np.array(cen[:], dtype=np.int64).reshape(8192, 4)[:, 1] > 0)[0]
+    byc = {}
+    for wg, c_ in zip(ids.tolist(), cu.tolist()):
+        byc.setdefault(c_, []).append(wg)
+    diffs = [b_ - a_ for a_, b_ in (sorted(v_)[:2] for v_ in byc.values() if len(v_) >= 2)]
+    print("  linear ids of the workgroups sharing a CU (first 12 CUs):", [sorted(v_) for v_ in list(byc.values())[:12]])
+    print("  id distance between the two workgroups of a CU: ", {d: diffs.count(d) for d in sorted(set(diffs))})
+# the two workgroups of one CU side by side (ids i and i + 256), shader clock relative to the earlier entry
+tl = (C.c_longlong * (512 * 64))()
+L.nl_debug_att_timeline.argtypes = [C.POINTER(C.c_longlong)]
+if L.nl_debug_att_timeline(tl) == 0:
+    t = np.array(tl[:], dtype=np.int64).reshape(512, 64)
+    nch = lambda w: sum(1 for c in range(6) if t[w, 10 * c + 7] > 0)
+    pairs = [(i, i + 256) for i in range(224) if t[i, 0] and t[i + 256, 0]] or [(i, i) for i in range(256) if t[i, 0]]
+    pairs.sort(key=lambda p_: -(nch(p_[0]) + nch(p_[1])))
+    for a_, b_ in pairs[:1] + pairs[-1:]:
+        z = min(t[a_, 0], t[b_, 0])
+        ev = []
+        for w in (a_, b_):
+            for c in range(6):
+                for k, nm in ((1, "chunk landed (own pieces)"), (4, "barrier, next chunk requested"), (5, "S^T issued"), (6, "softmax done"), (7, "PV issued")):
+                    if t[w, 10 * c + k]: ev.append((int(t[w, 10 * c + k] - z), w, f"chunk {c} {nm}"))
+            ev.append((int(t[w, 8] - z), w, "exit"))
+        print(f"CU pair {a_} ({nch(a_)} chunks) / {b_} ({nch(b_)} chunks):")
+        for tt, w, nm in sorted(ev): print(f"   {tt:7d}  {'A' if w == a_ else '        B'} {nm}")
 dev.close()
