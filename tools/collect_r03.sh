@@ -22,6 +22,8 @@ for t in nano_q8_0 big_q4_0; do for c in FETCH_SIZE WRITE_SIZE; do cp gpurun_out
 bash tools/r3_stamps.sh > /dev/null 2>&1
 cp gpurun_out/r3_nano_block_stamps.txt $O/r03_nano_q8_0_block_phase_stamps.txt; cp gpurun_out/r3_nano_attn_block_counters.txt $O/r03_nano_q8_0_attn_block_sq_counters.txt; cp gpurun_out/r3_nano_ffn_block_counters.txt $O/r03_nano_q8_0_ffn_block_sq_counters.txt
 bash tools/r3_goldie_counters.sh > /dev/null 2>&1; cp gpurun_out/r3_goldie_counters.txt $O/r03_goldie_q4_0_batch64_qgemm_bnorm_counters.txt
+# prompt attention (mini, 2047 tokens): per-chunk stamps of one workgroup, census of every workgroup, SQ / TCC counters
+(bash tools/att_stamps.sh 20; bash tools/pmc_kernel.sh "attn_tile16_kernel<64, 4, 64, true>" tools/prof_prefill.py) > $O/r03_mini_q4_0_prompt_attention_stamps_counters.txt 2>&1
 # tensor parallelism: the shard-only probe and the N > 1 control flow with two ranks on the one GPU
 (timeout 600 python bench.py --shard-of 8 --steps 96 --warmup 16 2>/dev/null | tail -1) > $O/r03_bench_shard_of_8.json.log
 bash tools/tp2_flow.sh > $O/tp2_flow_head.txt 2>&1; grep '^{' gpurun_out/tp2.log | tail -1 > $O/r03_bench_tp2_one_device.json.log
