@@ -8,7 +8,7 @@ restated as HIP kernels) plus the greedy argmax, chained on the device.
 
   N = 1 : headline = BASELINE.json configs[1], nano (89M) Q8_0 single-stream greedy decode;
           "secondary" = big (7.9B) Q4_0 on the one GPU (the 1-GPU point of configs[4]);
-          "other_configs" = mini prefill, goldie x 64 streams.
+          "other_configs" = mini prefill, goldie prefill, goldie x 64 streams.
   N > 1 : headline = BASELINE.json configs[4], big (7.9B) Q4_0 tensor-parallel over the N GPUs,
           one process per GPU, strong scaling ("scaling": "strong"): the two per-layer all-reduces are the
           push all-reduce over xGMI (nl_p2p_*), RCCL when that cannot be set up.  "secondary" = N independent
@@ -312,9 +312,24 @@ def side_configs(model):
                                      "mfma_peak_frac_f16_dense": round(gemm_flop / dt / 2.5e15, 5),
                                      "decode_step_ms_at_pos_2047": round(dt1 * 1e3, 3)}
     dev.close()
-    # -- goldie: 64 streams
+    # -- goldie: the same prompt step at 841M parameters (what the MFMA path does with longer rows), then 64 streams
     shape = synth.TIERS["goldie"]
     g = gguf.load_gguf(ensure_gguf(shape, "q4_0", "qrand"))
+    dev = model.load_llama_model(g)
+    toks = synth.prompt_ids(2047, shape.vocab)
+    dev.prefill(toks)
+    dev.synchronize()
+    dt = 1e9
+    for _ in range(3):
+        dev.reset()
+        t0 = time.perf_counter()
+        dev.prefill(toks)
+        dt = min(dt, time.perf_counter() - t0)
+    gemm_flop = 2.0 * shape.matrix_params() * 2047 - 2.0 * shape.vocab * shape.dim * 2046
+    out["goldie_q4_0_prefill_2047"] = {"prefill_tokens_per_s": round(2047 / dt, 1), "prefill_ms": round(dt * 1e3, 2),
+                                       "gemm_TFLOPs_algorithmic": round(gemm_flop / dt / 1e12, 2),
+                                       "mfma_peak_frac_f16_dense": round(gemm_flop / dt / 2.5e15, 5)}
+    dev.close()
     ns, steps, pos0 = 64, 32, 8
     dev = model.load_llama_model(g, max_streams=ns)
     rng = np.random.Generator(np.random.PCG64(3))
