@@ -1263,7 +1263,7 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
         const long long slots = (long long)e->num_cus * (kv16_on ? 1 : 2);   // workgroups resident at once
         if (cons && ntile <= 256 && e->KVs <= 255) {
             auto chunks_of = [&](int z) { return std::min((p0 + std::min((z + 1) * qt, n) - 1) / ATT_CH + 1, e->nsplit_max); };
-            static const int run_knob = getenv("NL_ATT_RUN") ? atoi(getenv("NL_ATT_RUN")) : 0;   // developer knob: fixed run length
+            const int run_knob = getenv("NL_ATT_RUN") ? atoi(getenv("NL_ATT_RUN")) : 0;   // developer knob: fixed run length (read per step: a test sets it)
             int run = run_knob > 0 ? run_knob : 1;
             for (; run_knob <= 0 && run < e->nsplit_max; run++) {
                 long long wgs = 0;

@@ -728,6 +728,26 @@ def test_prefill_attention_chunk_runs_with_and_without_prebuilt_images(hip, orc,
     dev.close()
 
 
+def test_prefill_attention_more_workgroups_than_the_chip_holds(hip, orc, tmp_path, monkeypatch):
+    # 32 kv heads x 3 tiles x one-chunk runs (NL_ATT_RUN=1) = 384 listed workgroups at one per CU: a second round of
+    # dispatches, partial slots up to 5, G = 1 (256 tokens per tile).
+    monkeypatch.setenv("NL_ATT_RUN", "1")
+    shape = replace(synth.TIERS["tiny"], name="kv32", dim=1024, n_head=32, n_kv_head=32, seq_len=768, interm=64, n_layer=2)
+    p = tmp_path / "g.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 91)
+    g = gguf.load_gguf(str(p))
+    dev = hip.load_llama_model(g)
+    ref = orc.OracleModel(g)
+    toks = synth.prompt_ids(700, shape.vocab, seed=21)
+    for pos, t in enumerate(toks):
+        want = ref.forward(t, pos)
+    dev.prefill(toks)
+    err = float(np.abs(dev.state.logits - want).max())
+    print(f"\n32 kv heads, 384 attention workgroups: max|gpu-oracle|={err:.2e}")
+    assert err <= LOGIT_TOL * max(1.0, float(want.std()))
+    dev.close()
+
+
 @pytest.mark.parametrize("dim,heads,kv,hd,interm,n", [(160, 5, 5, 32, 224, 200), (192, 3, 1, 64, 352, 131), (256, 4, 1, 64, 96, 300)])
 def test_q4_prompt_gemm_through_lds_matches_the_per_wavefront_kernel(hip, orc, tmp_path, monkeypatch, dim, heads, kv, hd, interm, n):
     # Q4_0 prompts of >= 128 tokens take qgemm2_kernel (weights expanded once per workgroup into LDS, nl_qgemm2.h) with
