@@ -1162,10 +1162,6 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
         if (t0 > pos) return;
         n = min(ATT_CH, pos + 1 - t0);
         const long long soff = (long long)sload_i32(P.bstream ? P.bstream + item : P.ctl + CTL_STREAM) * P.kv_stream_stride;
-        if constexpr (FIN) {
-            // (one split, t0 = 0: row `pos` of the cache is written here; its K goes straight into the staged tile)
-            if (P.rp.on) attn_rope_prologue<HD, G>(P, kvh, item, pos, soff, qs, Kt + pos * KS, vcur);
-        }
         const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
         const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + ((long long)kvh * P.seq_len + t0) * HD);
 #pragma unroll
@@ -1177,6 +1173,16 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
             } else {
                 kreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 vreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if constexpr (FIN) {
+            // (one split, t0 = 0: row `pos` of the cache is written here; its K goes straight into the staged tile.  AFTER the
+            // cache rows have been requested: the prologue stores into the cache, so placed first it kept the requests
+            // behind its own slab round trip -- two round trips per launch instead of one.  What the requests above
+            // return for row `pos` is discarded below.)
+            if (P.rp.on) {
+                __builtin_amdgcn_sched_barrier(0);
+                attn_rope_prologue<HD, G>(P, kvh, item, pos, soff, qs, Kt + pos * KS, vcur);
             }
         }
     }
