@@ -49,11 +49,11 @@ __device__ __forceinline__ void gemm_out_at2(const GemmOut &g, long long ia, int
 // per layer.  Element e of a head sits at packed row (head * hd/16 + (e % half) / 8) * 16 + (e % half) % 8 + 8 * (e / half)
 // (ROWMAP_HEADPERM), its rotation partner at that row ^ 8.
 template <int HD, int G>
-__device__ void attn_rope_prologue(const AttnParams &P, int kvh, int item, int pos, long long soff, float *qs, float *krow, float *vcur) {
+__device__ void attn_rope_prologue(const AttnParams &P, int kvh, int item, int pos, long long soff, float *qs, float *krow, float *vcur, bool kv_part) {
     constexpr int half = HD / 2, tph = HD / 16;
     const AttnParams::Rope &R = P.rp;
     const long long src0 = (long long)item * R.R;
-    for (int i = threadIdx.x; i < (G + 2) * HD; i += ATT_THREADS) {
+    for (int i = threadIdx.x; i < (kv_part ? G + 2 : G) * HD; i += ATT_THREADS) {
         const int hs = i / HD, e = i % HD, ih = e % half, hi = e / half;
         const int head = hs < G ? kvh * G + hs : hs == G ? R.n_q_heads + kvh : R.n_q_heads + P.n_kv_heads + kvh;
         const int rho = (head * tph + ih / 8) * 16 + (ih % 8) + 8 * hi;

@@ -423,7 +423,22 @@ hipError_t launch_attn_fin_hd(int gqa, AttnParams P, dim3 grid, hipStream_t st) 
     return hipGetLastError();
 }
 
+// several position splits per token with the RoPE prologue (decode batches at positions >= 128, AttnParams::rp)
+template <int HD>
+hipError_t launch_attn_rope_hd(int gqa, AttnParams P, dim3 grid, hipStream_t st) {
+    switch (gqa) {
+    case 1: hipLaunchKernelGGL((attn_kernel<HD, 1, false, true>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    case 2: hipLaunchKernelGGL((attn_kernel<HD, 2, false, true>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    case 3: hipLaunchKernelGGL((attn_kernel<HD, 3, false, true>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    case 4: hipLaunchKernelGGL((attn_kernel<HD, 4, false, true>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    case 8: hipLaunchKernelGGL((attn_kernel<HD, 8, false, true>), grid, dim3(ATT_THREADS), 0, st, P); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_attn(int hd, int gqa, AttnParams P, dim3 grid, hipStream_t st) {
+    if (P.rp.on) return hd == 64 ? launch_attn_rope_hd<64>(gqa, P, grid, st) : hd == 32 ? launch_attn_rope_hd<32>(gqa, P, grid, st) : hipErrorInvalidValue;
     if (hd == 64) return launch_attn_hd<64>(gqa, P, grid, st);
     if (hd == 32) return launch_attn_hd<32>(gqa, P, grid, st);
     return hipErrorInvalidValue;
@@ -1355,10 +1370,12 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
             LCK(launch_qgemm_rope(m.wtype, P, st));
         } else {
             LCK(qg(e, L.qkv, n, b.qkv, R, nullptr, st, &qkv_out, b.kpart));
-            // decode batches (every token its own stream: no token of the step attends over another's K / V row) below
-            // position 128 (one attention split, the FIN kernel), no QK-norm: the attention launch rotates and stores its
-            // own q / k / v rows (attn_rope_prologue) -- no brope_kv launch
-            rope_in_attn = fin_attn && !one_stream && !c.qk_norm && rope_attn_knob;
+            // decode batches (every token its own stream: no token of the step attends over another's K / V row), no QK-norm:
+            // the attention launch rotates and stores its own q / k / v rows (attn_rope_prologue) -- no brope_kv launch.
+            // Below position 128 that is the one-split FIN kernel; with two splits per token every split rotates q and the
+            // last one k / v.  Beyond that the repeated q work of every split costs more than the launch it saves (goldie x
+            // 64 streams: positions 130..145 2.03 -> 1.92 ms per step, 300.. 2.19 -> 2.19, 1000.. 2.85 -> 2.95).
+            rope_in_attn = !tile_attn && nsplit <= 2 && !one_stream && !c.qk_norm && rope_attn_knob;
             if (!rope_in_attn) {
                 const GemmOut &qkv = qkv_out;
                 BRopeParams P{qkv, R, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate, c.qk_norm, c.rms_eps, b.pos, b.stream,
@@ -1403,6 +1420,8 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
                              : launch_attn_fin_hd<32>(e->gqa, P, dim3(e->KVs, 1, n), st));
                 merged = true;
             } else {
+                if (rope_in_attn)
+                    P.rp = AttnParams::Rope{1, qkv_out, (int)R, e->Hs, c.rope_conjugate, e->rope_cos, e->rope_sin, L.bq, L.bk, L.bv, kc, vc};
                 LCK(launch_attn(hd, e->gqa, P, dim3(e->KVs, nsplit, n), st));
             }
             if (!merged) {

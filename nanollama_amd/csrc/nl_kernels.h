@@ -1082,7 +1082,7 @@ struct AttnParams {
 template <int HD, int G>
 __device__ void attn_finalize(const AttnParams &P, const float *ored, const float *ml, int kvh, int item);   // nl_batch.h
 template <int HD, int G>
-__device__ void attn_rope_prologue(const AttnParams &P, int kvh, int item, int pos, long long soff, float *qs, float *krow, float *vcur);   // nl_batch.h
+__device__ void attn_rope_prologue(const AttnParams &P, int kvh, int item, int pos, long long soff, float *qs, float *krow, float *vcur, bool kv_part);   // nl_batch.h
 
 // GQA decode attention for one token (go/model.go:557-587): one workgroup per
 // (kv head, 128-position split); the G query heads of the group share every K
@@ -1114,7 +1114,7 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-template <int HD, int G, bool FIN = false>
+template <int HD, int G, bool FIN = false, bool ROPE = FIN>   // ROPE: the instantiation carries the RoPE prologue (AttnParams::rp)
 __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
     const int split = blockIdx.y, t0 = split * ATT_CH;
     const int kvh = blockIdx.x, tid = threadIdx.x;
@@ -1127,7 +1127,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
     __shared__ float sc[G * ATT_CH];
     __shared__ __attribute__((aligned(16))) float ored[NG * G * HD];
     __shared__ float ml[G * 2];
-    __shared__ __attribute__((aligned(16))) float vcur[FIN ? HD : 4];   // FIN + RoPE prologue: this step's V row
+    __shared__ __attribute__((aligned(16))) float vcur[ROPE ? HD : 4];  // RoPE prologue: this step's V row
 
     const int c4 = tid % R4, tg = tid / R4;
     float4 kreg[NV], vreg[NV];
@@ -1175,34 +1175,35 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
                 vreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        if constexpr (FIN) {
-            // (one split, t0 = 0: row `pos` of the cache is written here; its K goes straight into the staged tile.  AFTER the
-            // cache rows have been requested: the prologue stores into the cache, so placed first it kept the requests
-            // behind its own slab round trip -- two round trips per launch instead of one.  What the requests above
-            // return for row `pos` is discarded below.)
+        if constexpr (ROPE) {
+            // (every split rotates its own copy of q; the split that holds `pos` -- the last one -- also rotates k, writes
+            // row `pos` of the cache and puts its K straight into the staged tile.  AFTER the cache rows have been requested:
+            // the prologue stores into the cache, so placed first it kept the requests behind its own slab round trip -- two
+            // round trips per launch instead of one.  What the requests above return for row `pos` is discarded below.)
             if (P.rp.on) {
                 __builtin_amdgcn_sched_barrier(0);
-                attn_rope_prologue<HD, G>(P, kvh, item, pos, soff, qs, Kt + pos * KS, vcur);
+                attn_rope_prologue<HD, G>(P, kvh, item, pos, soff, qs, Kt + (pos - t0) * KS, vcur, pos - t0 < ATT_CH);
             }
         }
     }
-    const bool roped = FIN && P.rp.on;       // q, and row `pos` of K / V, come from the RoPE prologue above
+    const bool roped = ROPE && P.rp.on;      // q comes from the RoPE prologue above ...
+    const int own = roped && pos - t0 < ATT_CH ? pos - t0 : -1;   // ... and so does this staged row of K / V (the step's own position)
     if (!roped)
         for (int i = tid; i < G * HD; i += ATT_THREADS) qs[i] = qsrc[kvh * G * HD + i];
 #pragma unroll
     for (int k = 0; k < NV; k++) {
         int row = tg + k * NG;
-        if (row < n && !(roped && row == pos)) {
+        if (row < n && row != own) {
             float *dst = Kt + row * KS + c4 * 4;
             dst[0] = kreg[k].x; dst[1] = kreg[k].y; dst[2] = kreg[k].z; dst[3] = kreg[k].w;
         }
     }
     __syncthreads();
-    if constexpr (FIN) {
-        if (roped) {
+    if constexpr (ROPE) {
+        if (own >= 0) {
 #pragma unroll
             for (int k = 0; k < NV; k++)
-                if (tg + k * NG == pos) vreg[k] = *reinterpret_cast<const float4 *>(vcur + c4 * 4);
+                if (tg + k * NG == own) vreg[k] = *reinterpret_cast<const float4 *>(vcur + c4 * 4);
         }
     }
 

@@ -949,6 +949,46 @@ def test_batched_decode_rotates_inside_the_attention_launch(hip, orc, tmp_path, 
     assert np.array_equal(outs["1"], outs["0"])
 
 
+@pytest.mark.parametrize("variant", ["conj_gqa", "bias_mha"])
+def test_batched_decode_rotates_inside_the_split_attention_launch(hip, orc, tmp_path, monkeypatch, variant):
+    # decode batches at positions >= 128 (several 128-key splits per token): every split's workgroup rotates its own copy
+    # of q, the split that holds the step's position also rotates k, stores the K / V rows and stages its own K -- still no
+    # brope_kv launch.  Four streams at ragged positions that cross the 128- and 256-key boundaries during the run, against
+    # the oracle and bit-identical to the same steps with NL_ROPE_IN_ATTN=0.
+    shape = {"conj_gqa": synth.ModelShape("rsa_conj", 2, 256, 4, 2, 512, seq_len=320, interm=256, rope_conjugate=True),
+             "bias_mha": synth.ModelShape("rsa_bias", 2, 192, 3, 3, 512, seq_len=320, interm=256, attn_bias=True)}[variant]
+    p = tmp_path / "r.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0" if variant != "bias_mha" else "q8_0", 47)
+    g = gguf.load_gguf(str(p))
+    ns, nsteps = 4, 5
+    rng = np.random.Generator(np.random.PCG64(78))
+    start = [125, 127, 254, 300]
+    seqs = [[int(t) for t in rng.integers(3, shape.vocab, size=start[s] + nsteps)] for s in range(ns)]
+    refs = []
+    for s in range(ns):
+        ref = orc.OracleModel(g)
+        lg = [ref.forward(t, pos).copy() for pos, t in enumerate(seqs[s])]
+        refs.append(lg[start[s]:])
+        ref.close()
+    outs = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("NL_ROPE_IN_ATTN", knob)
+        dev = hip.load_llama_model(g, max_streams=ns)
+        for s in range(ns):
+            dev.prefill(seqs[s][:start[s]], stream=s, want_logits=False)
+        got = []
+        for k in range(nsteps):
+            ids, lg = dev.forward_batch(list(range(ns)), [seqs[s][start[s] + k] for s in range(ns)],
+                                        [start[s] + k for s in range(ns)], want_logits=True)
+            got.append(lg.copy())
+            for s in range(ns):
+                assert np.abs(lg[s] - refs[s][k]).max() <= LOGIT_TOL * max(1.0, float(refs[s][k].std())), (knob, s, k)
+                assert ids[s] == int(np.argmax(refs[s][k]))
+        outs[knob] = np.stack(got)
+        dev.close()
+    assert np.array_equal(outs["1"], outs["0"])
+
+
 def test_batched_decode_across_the_128_position_split(hip, orc, tmp_path):
     # three streams stepped together from position 0 to 135: below 128 every row has one attention split and the
     # attention kernel writes the WO fragments itself; from 128 on the split partials go through battn_merge.
