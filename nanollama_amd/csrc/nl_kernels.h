@@ -1118,14 +1118,21 @@ template <int HD, int G, bool FIN = false, bool ROPE = FIN>   // ROPE: the insta
 __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
     const int split = blockIdx.y, t0 = split * ATT_CH;
     const int kvh = blockIdx.x, tid = threadIdx.x;
-    constexpr int KS = HD + 1;               // padded row stride: conflict-free column walks
+    constexpr int KS = HD + 4;               // padded row stride, 16-byte aligned: a lane reads its key's row as float4s and
+                                             // consecutive rows sit one 16-byte slot apart (conflict-free ds_read_b128)
+    static_assert(ATT_THREADS == 2 * ATT_CH, "scores: thread = (key row, half of the group's heads)");
     constexpr int R4 = HD / 4;               // float4 per row
     constexpr int NG = ATT_THREADS / R4;     // row groups
     constexpr int NV = ATT_CH / NG;          // rows per thread
-    __shared__ float Kt[ATT_CH * KS];
-    __shared__ float qs[G * HD];
+    // the per-row-group partial outputs (ored, written after the last read of the staged K) reuse K's storage when they fit:
+    // 52 -> 37 KB of LDS for HD = 64, G = 4, i.e. four workgroups per CU instead of three -- at long contexts this kernel
+    // is bound by the bytes it keeps in flight (goldie x 64 streams at position 1000: 2048 workgroups of 64 KB per layer)
+    constexpr bool ORED_IN_K = NG * G * HD <= ATT_CH * KS;
+    __shared__ __attribute__((aligned(16))) float Kt[ATT_CH * KS];
+    __shared__ __attribute__((aligned(16))) float qs[G * HD];
     __shared__ float sc[G * ATT_CH];
-    __shared__ __attribute__((aligned(16))) float ored[NG * G * HD];
+    __shared__ __attribute__((aligned(16))) float ored_own[ORED_IN_K ? 4 : NG * G * HD];
+    float *const ored = ORED_IN_K ? Kt : ored_own;
     __shared__ float ml[G * 2];
     __shared__ __attribute__((aligned(16))) float vcur[ROPE ? HD : 4];  // RoPE prologue: this step's V row
 
@@ -1194,8 +1201,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
     for (int k = 0; k < NV; k++) {
         int row = tg + k * NG;
         if (row < n && row != own) {
-            float *dst = Kt + row * KS + c4 * 4;
-            dst[0] = kreg[k].x; dst[1] = kreg[k].y; dst[2] = kreg[k].z; dst[3] = kreg[k].w;
+            *reinterpret_cast<float4 *>(Kt + row * KS + c4 * 4) = kreg[k];
         }
     }
     __syncthreads();
@@ -1207,19 +1213,37 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
         }
     }
 
-    // scores: thread (t, g) -> q.k over d (four partial sums: a lone wavefront is latency-bound)
-    for (int i = tid; i < n * G; i += ATT_THREADS) {
-        int t = i % n, g = i / n;
-        const float *kr = Kt + t * KS, *qr = qs + g * HD;
-        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    // scores: thread (key row t, half gp of the group's heads) -> q.k over d.  The row is read once, as float4s, for all the
+    // heads of the half; q is a broadcast read.  Per (t, g): four partial sums over d = 0, 4, 8, ... / 1, 5, ... / ..., the
+    // order the one-float-at-a-time loop of rounds 1-2 used (256 ds_read_b32 per thread against 48 ds_read_b128 now).
+    {
+        constexpr int GH = (G + 1) / 2;
+        const int t = tid & (ATT_CH - 1), gp = tid >> 7;
+        if (t < n) {
+            float d[GH][4];
 #pragma unroll
-        for (int d = 0; d < HD; d += 4) {
-            d0 = fmaf(qr[d], kr[d], d0);
-            d1 = fmaf(qr[d + 1], kr[d + 1], d1);
-            d2 = fmaf(qr[d + 2], kr[d + 2], d2);
-            d3 = fmaf(qr[d + 3], kr[d + 3], d3);
+            for (int gi = 0; gi < GH; gi++) d[gi][0] = d[gi][1] = d[gi][2] = d[gi][3] = 0.f;
+#pragma unroll
+            for (int dd = 0; dd < HD; dd += 4) {
+                const float4 kv = *reinterpret_cast<const float4 *>(Kt + t * KS + dd);
+#pragma unroll
+                for (int gi = 0; gi < GH; gi++) {
+                    const int g = gp * GH + gi;
+                    if (g < G) {
+                        const float4 qv = *reinterpret_cast<const float4 *>(qs + g * HD + dd);
+                        d[gi][0] = fmaf(qv.x, kv.x, d[gi][0]);
+                        d[gi][1] = fmaf(qv.y, kv.y, d[gi][1]);
+                        d[gi][2] = fmaf(qv.z, kv.z, d[gi][2]);
+                        d[gi][3] = fmaf(qv.w, kv.w, d[gi][3]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int gi = 0; gi < GH; gi++) {
+                const int g = gp * GH + gi;
+                if (g < G) sc[g * ATT_CH + t] = ((d[gi][0] + d[gi][1]) + (d[gi][2] + d[gi][3])) * P.scale;
+            }
         }
-        sc[g * ATT_CH + t] = ((d0 + d1) + (d2 + d3)) * P.scale;
     }
     __syncthreads();
 

@@ -989,6 +989,38 @@ def test_batched_decode_rotates_inside_the_split_attention_launch(hip, orc, tmp_
     assert np.array_equal(outs["1"], outs["0"])
 
 
+@pytest.mark.parametrize("heads,kv", [(4, 4), (8, 4)])
+def test_batched_decode_at_long_contexts(hip, orc, tmp_path, heads, kv):
+    # 64 streams at ragged positions around 400-520 (four / five 128-key splits per token, streams 0 and 1 cross into a
+    # fifth split during the run): split attention + brope_kv + battn_merge; three streams against the oracle.
+    shape = synth.ModelShape(f"lc_{heads}_{kv}", 2, heads * 64, heads, kv, 512, seq_len=640, interm=128)
+    p = tmp_path / "l.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 53)
+    g = gguf.load_gguf(str(p))
+    ns, nsteps = 64, 3
+    rng = np.random.Generator(np.random.PCG64(79))
+    start = [int(x) for x in rng.integers(390, 520, size=ns)]
+    start[0], start[1] = 510, 511
+    seqs = [[int(t) for t in rng.integers(3, shape.vocab, size=start[s] + nsteps)] for s in range(ns)]
+    check = [0, 1, 37]
+    refs = {}
+    for s in check:
+        ref = orc.OracleModel(g)
+        lg = [ref.forward(t, pos).copy() for pos, t in enumerate(seqs[s])]
+        refs[s] = lg[start[s]:]
+        ref.close()
+    dev = hip.load_llama_model(g, max_streams=ns)
+    for s in range(ns):
+        dev.prefill(seqs[s][:start[s]], stream=s, want_logits=False)
+    for k in range(nsteps):
+        ids, lg = dev.forward_batch(list(range(ns)), [seqs[s][start[s] + k] for s in range(ns)],
+                                    [start[s] + k for s in range(ns)], want_logits=True)
+        for s in check:
+            assert np.abs(lg[s] - refs[s][k]).max() <= LOGIT_TOL * max(1.0, float(refs[s][k].std())), (s, k)
+            assert ids[s] == int(np.argmax(refs[s][k]))
+    dev.close()
+
+
 def test_batched_decode_across_the_128_position_split(hip, orc, tmp_path):
     # three streams stepped together from position 0 to 135: below 128 every row has one attention split and the
     # attention kernel writes the WO fragments itself; from 128 on the split partials go through battn_merge.
