@@ -349,6 +349,19 @@ def side_configs(model):
                                      "device_ms_per_step": round(ev_ms / steps, 3), "steps": steps,
                                      "positions": f"{pos0}..{pos0 + steps - 1}", "launch": "one nl_forward_batch call per step (host loop; ids read back every step)",
                                      "hbm_frac": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
+    # ... and the same batch deep in its context (the K / V rows below are whatever the cache holds: timing only)
+    lpos, lsteps = 1000, 16
+    for p in range(lpos - 4, lpos):
+        ids, _ = dev.forward_batch(streams, ids, [p] * ns)
+    dev.synchronize()
+    t0 = time.perf_counter()
+    for k in range(lsteps):
+        ids, _ = dev.forward_batch(streams, ids, [lpos + k] * ns)
+    dt = time.perf_counter() - t0
+    step_bytes = synth.weight_bytes_per_token(shape, "q4_0") + ns * synth.kv_bytes_per_token(shape, lpos + lsteps // 2)
+    out["goldie_q4_0_64_streams"]["at_position_1000"] = {"tokens_per_s_aggregate": round(ns * lsteps / dt, 1), "ms_per_step": round(dt / lsteps * 1e3, 3),
+                                                          "positions": f"{lpos}..{lpos + lsteps - 1}",
+                                                          "hbm_frac": round(step_bytes / (dt / lsteps) / 1e9 / HBM_PEAK_GBS, 4)}
     dev.close()
     # -- nano at the reference's DEFAULT generation settings (go/main.go:29-34: temp 0.8, top-p 0.9, repetition
     #    penalty 1.15 over 64 tokens): sampling loop on the device vs logits read back and sampled on the host
