@@ -51,25 +51,39 @@ __device__ __forceinline__ void gemm_out_at2(const GemmOut &g, long long ia, int
 template <int HD, int G>
 __device__ void attn_rope_prologue(const AttnParams &P, int kvh, int item, int pos, long long soff, float *qs, float *krow, float *vcur, bool kv_part) {
     constexpr int half = HD / 2, tph = HD / 16;
+    constexpr int NIT = ((G + 2) * HD + ATT_THREADS - 1) / ATT_THREADS;   // elements per thread
     const AttnParams::Rope &R = P.rp;
     const long long src0 = (long long)item * R.R;
-    for (int i = threadIdx.x; i < (kv_part ? G + 2 : G) * HD; i += ATT_THREADS) {
+    const int count = (kv_part ? G + 2 : G) * HD;
+    // Every element's operands are requested before any is used: the stores below may alias the loads of a later element as
+    // far as hipcc can tell, so written as one loop the second element's round trip started after the first one's stores
+    // (stamps: 7-8k of this launch's 15k cycles were entry -> prologue done).  Same arithmetic in the same order.
+    float v[NIT], partner[NIT], rc[NIT], rs[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        if (it * ATT_THREADS >= count) { v[it] = partner[it] = rc[it] = rs[it] = 0.f; continue; }   // (uniform: a q-only split has fewer elements)
+        const int i = min((int)threadIdx.x + it * ATT_THREADS, count - 1);
         const int hs = i / HD, e = i % HD, ih = e % half, hi = e / half;
         const int head = hs < G ? kvh * G + hs : hs == G ? R.n_q_heads + kvh : R.n_q_heads + P.n_kv_heads + kvh;
         const int rho = (head * tph + ih / 8) * 16 + (ih % 8) + 8 * hi;
-        const float rc = R.cos[pos * half + ih], rs = R.sin[pos * half + ih];   // (requested with the slabs: one round trip)
-        float v, partner;
-        gemm_out_at2(R.qkv, src0 + rho, rho, src0 + (rho ^ 8), rho ^ 8, v, partner);
+        rc[it] = R.cos[pos * half + ih]; rs[it] = R.sin[pos * half + ih];
+        gemm_out_at2(R.qkv, src0 + rho, rho, src0 + (rho ^ 8), rho ^ 8, v[it], partner[it]);
         if (R.bias_q) {
             const float *bp = hs < G ? R.bias_q + (kvh * G + hs) * HD : hs == G ? R.bias_k + kvh * HD : R.bias_v + kvh * HD;
-            v += bp[e];
-            partner += bp[e ^ half];
+            v[it] += bp[e];
+            partner[it] += bp[e ^ half];
         }
-        float outv = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int i = (int)threadIdx.x + it * ATT_THREADS;
+        if (i >= count) continue;
+        const int hs = i / HD, e = i % HD, hi = e / half;
+        float outv = v[it];
         if (hs <= G) {
-            const float x0 = hi == 0 ? v : partner, x1 = hi == 0 ? partner : v;
-            if (!R.conj) outv = hi == 0 ? (x0 * rc - x1 * rs) : (x0 * rs + x1 * rc);
-            else outv = hi == 0 ? (x0 * rc + x1 * rs) : (-x0 * rs + x1 * rc);
+            const float x0 = hi == 0 ? v[it] : partner[it], x1 = hi == 0 ? partner[it] : v[it];
+            if (!R.conj) outv = hi == 0 ? (x0 * rc[it] - x1 * rs[it]) : (x0 * rs[it] + x1 * rc[it]);
+            else outv = hi == 0 ? (x0 * rc[it] + x1 * rs[it]) : (-x0 * rs[it] + x1 * rc[it]);
         }
         if (hs < G) qs[hs * HD + e] = outv;
         else {

@@ -1511,6 +1511,11 @@ int nl_abi_version(void) { return 1; }
 #endif
 const char *nl_build_info(void) { return "src=" NL_SRC_SHA " git=" NL_GIT_HEAD; }
 
+#ifdef NL_ATTN_STAMPS
+__attribute__((visibility("default"))) int nl_debug_attn_stamps(long long *out) {   // developer build only: 16 values
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nl::g_attn_stamps), 16 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef NL_ATT_STAMPS
 // developer build only (tools/att_stamps.sh): phase stamps of one workgroup of the prompt attention kernel
 __attribute__((visibility("default"))) int nl_debug_att_stamps(long long *out) {

@@ -1114,8 +1114,15 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+#ifdef NL_ATTN_STAMPS
+__device__ long long g_attn_stamps[16];   // developer build (-DNL_ATTN_STAMPS): phase stamps of workgroup (0, 0, item 5), thread 64
+#define ATTN_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 5 && threadIdx.x == 64) g_attn_stamps[(i)] = clock64(); } while (0)
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#endif
 template <int HD, int G, bool FIN = false, bool ROPE = FIN>   // ROPE: the instantiation carries the RoPE prologue (AttnParams::rp)
 __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
+    ATTN_STAMP(0);
     const int split = blockIdx.y, t0 = split * ATT_CH;
     const int kvh = blockIdx.x, tid = threadIdx.x;
     constexpr int KS = HD + 4;               // padded row stride, 16-byte aligned: a lane reads its key's row as float4s and
@@ -1193,6 +1200,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
             }
         }
     }
+    ATTN_STAMP(1);
     const bool roped = ROPE && P.rp.on;      // q comes from the RoPE prologue above ...
     const int own = roped && pos - t0 < ATT_CH ? pos - t0 : -1;   // ... and so does this staged row of K / V (the step's own position)
     if (!roped)
@@ -1213,6 +1221,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
         }
     }
 
+    ATTN_STAMP(2);
     // scores: thread (key row t, half gp of the group's heads) -> q.k over d.  The row is read once, as float4s, for all the
     // heads of the half; q is a broadcast read.  Per (t, g): four partial sums over d = 0, 4, 8, ... / 1, 5, ... / ..., the
     // order the one-float-at-a-time loop of rounds 1-2 used (256 ds_read_b32 per thread against 48 ds_read_b128 now).
@@ -1223,20 +1232,27 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
             float d[GH][4];
 #pragma unroll
             for (int gi = 0; gi < GH; gi++) d[gi][0] = d[gi][1] = d[gi][2] = d[gi][3] = 0.f;
+            // (sixteen dims per round of LDS reads: one-float4-at-a-time left a dependent LDS round trip per step, 3.8k of a
+            // decode-batch launch's 15k cycles)
+#pragma unroll 1
+            for (int d0 = 0; d0 < HD; d0 += 16) {      // (not unrolled: hipcc otherwise hoists every round's reads -- 230+ registers)
+                float4 kv[4], qv[GH][4];
 #pragma unroll
-            for (int dd = 0; dd < HD; dd += 4) {
-                const float4 kv = *reinterpret_cast<const float4 *>(Kt + t * KS + dd);
+                for (int u = 0; u < 4; u++) kv[u] = *reinterpret_cast<const float4 *>(Kt + t * KS + d0 + 4 * u);
 #pragma unroll
-                for (int gi = 0; gi < GH; gi++) {
-                    const int g = gp * GH + gi;
-                    if (g < G) {
-                        const float4 qv = *reinterpret_cast<const float4 *>(qs + g * HD + dd);
-                        d[gi][0] = fmaf(qv.x, kv.x, d[gi][0]);
-                        d[gi][1] = fmaf(qv.y, kv.y, d[gi][1]);
-                        d[gi][2] = fmaf(qv.z, kv.z, d[gi][2]);
-                        d[gi][3] = fmaf(qv.w, kv.w, d[gi][3]);
+                for (int gi = 0; gi < GH; gi++)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) qv[gi][u] = *reinterpret_cast<const float4 *>(qs + min(gp * GH + gi, G - 1) * HD + d0 + 4 * u);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int gi = 0; gi < GH; gi++) {
+                        d[gi][0] = fmaf(qv[gi][u].x, kv[u].x, d[gi][0]);
+                        d[gi][1] = fmaf(qv[gi][u].y, kv[u].y, d[gi][1]);
+                        d[gi][2] = fmaf(qv[gi][u].z, kv[u].z, d[gi][2]);
+                        d[gi][3] = fmaf(qv[gi][u].w, kv[u].w, d[gi][3]);
                     }
-                }
             }
 #pragma unroll
             for (int gi = 0; gi < GH; gi++) {
@@ -1247,6 +1263,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
     }
     __syncthreads();
 
+    ATTN_STAMP(3);
     // softmax pieces per head: wave w handles heads w, w+4, ...
     const int wave = tid >> 6, lane = tid & 63;
     for (int g = wave; g < G; g += ATT_THREADS / 64) {
@@ -1262,6 +1279,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
     }
     __syncthreads();
 
+    ATTN_STAMP(4);
     // P*V from the V rows already in registers
     float4 o[G];
 #pragma unroll
@@ -1283,8 +1301,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_kernel(AttnParams P) {
 #pragma unroll
     for (int g = 0; g < G; g++) *reinterpret_cast<float4 *>(ored + (tg * G + g) * HD + c4 * 4) = o[g];
     __syncthreads();
+    ATTN_STAMP(5);
     if constexpr (FIN) {
         attn_finalize<HD, G>(P, ored, ml, kvh, item);
+        ATTN_STAMP(6);
         return;
     }
     for (int i = tid; i < G * HD; i += ATT_THREADS) {
