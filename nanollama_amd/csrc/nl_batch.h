@@ -413,9 +413,10 @@ struct BMergeParams {
 // PRO_ATTN prologue); one thread per 8 k-slots of the output row.  The (max, sum) pairs of all splits and the
 // partial rows of four splits at a time are fetched with clamped indices before anything consumes them
 // (a runtime-bounded "for c < ns: load" loop is ns dependent round trips); splits past ns get weight 0.
+template <int MAXS>   // most partials an item can have: 16 (seq_len <= 2048, go/model.go:145-148, one per 128 keys), or 4 when the
+                      // prompt attention kernel folded runs of chunks (12 of the 16 (max, sum) loads and weights were masked work)
 __global__ void battn_merge_kernel(BMergeParams P, int n_items) {
     NL_KARGS8(P.part_o, P.part_ml, P.pos, P.xf, P.heads, P.nsplit_max, P.head_dim, P.nt16);   // one batch of s_load
-    constexpr int MAXS = 16;                         // seq_len <= 2048 (go/model.go:145-148) => at most 16 splits
     const int hd = P.head_dim, upi = P.heads * hd / 8;
     const long long total = (long long)n_items * upi;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {

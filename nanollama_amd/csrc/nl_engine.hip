@@ -1267,7 +1267,7 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
     // Run length: the shortest that lets every workgroup be resident at once (2 per CU); tiles are cut into equal runs.
     // Prompts of several query tiles (n >= NL_KV16_MIN_TOKENS): the chunks are split into fp16 halves once per layer
     // (kv16_build_kernel) and a workgroup takes twice the rows, one workgroup per CU (AttnTile16ShadowQT).
-    int n_live = 0;
+    int n_live = 0, max_nparts = 0;
     bool kv16_on = false;
     {
         bool cons = one_stream && n >= 8 && attn_tile_supported(e->gqa) && !getenv("NL_ATTN_F32") && !getenv("NL_NO_ATTN_TILE");
@@ -1293,6 +1293,7 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
                     for (int kv = 0; kv < e->KVs; kv++)
                         wg.push_back((int)((unsigned)kv << 24) | (z << 16) | (k << 12) | ((k * len) << 6) | std::min(len, cz - k * len));
                 for (int i = z * qt; i < std::min((z + 1) * qt, n); i++) nparts[i] = ((p0 + i) / ATT_CH) / len + 1;
+                max_nparts = std::max(max_nparts, nrun);
             }
             if ((int)wg.size() <= b.cap) {
                 // the longest runs first; with two workgroups per CU, i and i + #CUs share one (tools/att_stamps.py census):
@@ -1429,7 +1430,8 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
             BMergeParams M{b.part_o, b.part_ml, b.pos, tile16 && n_live > 0 ? b.tok + 4 * b.cap : nullptr, e->Hs, e->nsplit_max, hd, b.xfrag, nt16, L.wo.wtype == WT_Q4_0 ? 1 : 0, tile16 ? 1 : 0};
             {
                 const long long units = (long long)n * e->Hs * hd / 8;
-                hipLaunchKernelGGL(battn_merge_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, M, n);
+                if (M.nparts && max_nparts <= 4) hipLaunchKernelGGL(battn_merge_kernel<4>, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, M, n);
+                else hipLaunchKernelGGL(battn_merge_kernel<16>, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, M, n);
             }
             }
             LCK(hipGetLastError());
