@@ -1,0 +1,60 @@
+"""Developer tool (GPU): a few minutes of continuous work on the three multi-launch paths, checking that results stay
+identical run after run and that the fused plan never had to be retired (nl_last_error stays empty).
+   gpurun -- python3 tools/soak.py [seconds per path]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from nanollama_amd import gguf, model, synth
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bench_modes as b
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
+
+# 1. nano greedy decode: the same 448-token continuation over and over (fused two-launch plan, chained graphs)
+g = b.gen("nano", "q8_0")
+dev = model.load_llama_model(g)
+prompt = synth.prompt_ids(16, g.meta.vocab_size)
+ref_ids, runs, toks = None, 0, 0
+t0 = time.time()
+while time.time() - t0 < budget:
+    dev.reset(); dev.prefill(prompt)
+    ids = dev.decode_greedy(int(np.argmax(dev.state.logits)), len(prompt), 448)
+    ref_ids = ref_ids or ids
+    assert ids == ref_ids, f"nano greedy run {runs} differs"
+    runs += 1; toks += len(ids)
+print(f"nano greedy: {runs} runs, {toks} tokens in {time.time() - t0:.1f} s, identical ids every run; last_error: {dev.last_error()!r}", flush=True)
+dev.close()
+
+# 2. goldie x 64 streams: steps from position 0 to 255, repeated (FIN, two-split and general attention paths)
+g = b.gen("goldie", "q4_0")
+ns = 64
+dev = model.load_llama_model(g, max_streams=ns)
+rng = np.random.Generator(np.random.PCG64(5))
+first = [int(t) for t in rng.integers(3, g.meta.vocab_size, size=ns)]
+ref_last, runs, steps = None, 0, 0
+t0 = time.time()
+while time.time() - t0 < budget:
+    for s in range(ns): dev.reset(s)
+    ids = list(first)
+    for p in range(160):
+        ids, _ = dev.forward_batch(list(range(ns)), ids, [p] * ns)
+    ref_last = ref_last or list(ids)
+    assert list(ids) == ref_last, f"goldie batch run {runs} differs"
+    runs += 1; steps += 160
+print(f"goldie x 64: {runs} runs, {steps} steps in {time.time() - t0:.1f} s, identical ids every run; last_error: {dev.last_error()!r}", flush=True)
+dev.close()
+
+# 3. mini 2047-token prefill, repeated (runs of chunks, images, merge)
+g = b.gen("mini", "q4_0")
+dev = model.load_llama_model(g)
+toks_in = synth.prompt_ids(2047, g.meta.vocab_size)
+ref_lg, runs = None, 0
+t0 = time.time()
+while time.time() - t0 < budget:
+    dev.reset(); dev.prefill(toks_in)
+    lg = dev.state.logits.copy()
+    if ref_lg is None: ref_lg = lg
+    assert np.array_equal(lg, ref_lg), f"mini prefill run {runs} differs"
+    runs += 1
+print(f"mini prefill 2047: {runs} runs in {time.time() - t0:.1f} s, bit-identical logits every run; last_error: {dev.last_error()!r}", flush=True)
+dev.close()
