@@ -80,7 +80,7 @@ def launch_ranks(n, argv, timeout_s=None):
 
 # ------------------------------------------------------------------ measurement ---
 
-def kernel_bytes(shape, wtype, pos, tp=1):
+def kernel_bytes(shape, wtype, pos, tp=1, wo_in_block=None):
     """Algorithmic HBM bytes per LAUNCH of each kernel kind:
     every weight byte once + the vectors the kernel must read/write."""
     from nanollama_amd import gguf, synth
@@ -93,8 +93,9 @@ def kernel_bytes(shape, wtype, pos, tp=1):
         "qkv_rope": (hq + 2 * kv) * d * bpe + 2 * d * 4 + (hq + 2 * kv) * 4,
         "attention": (pos + 1) * kv * 2 * 4 + hq * 4 * 2,
         # fused launches: small tiers run norm + QKV + attention + WO in one (nl_block.h); wide tiers QKV + attention (nl_group.h)
-        "attn_block": (hq + 2 * kv) * d * bpe + (d * hq * bpe if shape.n_head <= 12 and d <= 1024 else 0) + 2 * d * 4
-                      + (pos + 1) * kv * 2 * 4,
+        # (wo_in_block: the plan has no separate WO launch -- small tiers, and a tensor-parallel rank's two-launch layers, nl_tp.h)
+        "attn_block": (hq + 2 * kv) * d * bpe + (d * hq * bpe if (wo_in_block if wo_in_block is not None else (shape.n_head <= 12 and d <= 1024)) else 0)
+                      + 2 * d * 4 + (pos + 1) * kv * 2 * 4,
         "ffn_block": 3 * i * d * bpe + 2 * d * 4,       # gate + up + down in one launch (nl_block.h), small tiers
         "wo_resid": d * hq * bpe + hq * 4 + 2 * d * 4,
         "gate_up_swiglu": 2 * i * d * bpe + 2 * d * 4 + i * 4,
@@ -235,7 +236,8 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
         # engine's stream (nl_profile_forward), at a mid-run position
         ppos = min(profile_pos if profile_pos is not None else pos0 + (min(SEGMENT, steps) - 1) // 2, shape.seq_len - 1)
         prof = dev.profile_forward(first, ppos, iters=20)
-        kb = kernel_bytes(shape, wtype, ppos, tp=shard_of or world)
+        wo_in_block = bool(prof.get("attn_block", (0, 0))[1]) and not prof.get("wo_resid", (0, 0))[1]
+        kb = kernel_bytes(shape, wtype, ppos, tp=shard_of or world, wo_in_block=wo_in_block)
         kernels = {}
         for kind, (ms, calls) in prof.items():
             if calls:
@@ -266,7 +268,7 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
             "tier": tier, "wtype": wtype, "path": path, "prompt": prompt,
             "tok_s": replicas * steps / (wall_ms / 1e3), "ms_per_step": ms_per_step, "device_ms_per_step": evs[med] / steps,
             "ms_per_step_min": min(walls) / steps, "ms_per_step_max": max(walls) / steps,
-            "replicas": replicas, "tp": world, "p2p": p2p,
+            "replicas": replicas, "tp": world, "p2p": p2p, "plan": dev.plan_info(),
             "step_bytes": int(step_bytes), "hbm_frac_whole_step": step_gbs / (HBM_PEAK_GBS * max(world, 1)),
             "kernels": kernels, "last_ids": ids[-4:], "head_ids": head_ids, "prefill_logits": prefill_logits,
             "roofline": roof(dom), "roofline_by_bytes": roof(dom_bytes),
@@ -400,6 +402,7 @@ def shard_probe(model, rdv, ns=(2, 4, 8), seam_us=2.0, steps=96, warmup=16, base
             continue
         kern = {k: {"launches": v["launches"], "us_per_launch": v["us_per_launch"]} for k, v in r["kernels"].items()}
         out["per_rank"][str(n)] = {"ms_per_step": round(r["ms_per_step"], 5), "launches_per_step": sum(v["launches"] for v in kern.values()),
+                                   "plan": r["plan"],
                                    "shard_bytes_per_step": r["step_bytes"], "hbm_frac_of_one_gpu": round(r["hbm_frac_whole_step"], 4),
                                    "kernels": kern}
         pred_ms = r["ms_per_step"] + out["seams_per_step"] * seam_us * 1e-3

@@ -62,6 +62,7 @@ typedef struct {
 
 #define NL_FLAG_NO_GRAPH 1 /* launch kernels eagerly instead of replaying a hipGraph */
 #define NL_FLAG_LOCAL_GROUP 2 /* tp_size > 1 shards living in ONE process, stepped by nl_group_forward */
+#define NL_FLAG_GROUP_FUSED 4 /* with NL_FLAG_LOCAL_GROUP: short contexts step the two-launches-per-layer plan of a push-group rank */
 
 /* Library / device probes (no handle, no device work for nl_abi_version). */
 NL_API int nl_abi_version(void);
@@ -159,6 +160,12 @@ NL_API int nl_timer_stop(nl_handle h, float *ms);
 #define NL_NUM_KINDS 11
 NL_API const char *nl_kernel_kind_name(int kind);
 NL_API int nl_profile_forward(nl_handle h, int stream, int token, int pos, int iters, float *ms_out, int *calls_out);
+/* Which launch plans the handle holds (no reference counterpart; tests and bench.py report it).  fused_mode: 0 = only the
+ * general five-launches-per-layer plan; 1 = small tiers, attention block + feed-forward block (2 per layer); 2 = wide
+ * tiers, projection + attention fused (4 per layer); 3 = a tensor-parallel rank's layer as two launches with the push
+ * all-reduce finished in their tails.  fused_max_pos: steps below this position take the fused plan.  launches_*: kernel
+ * launches per token of the fused / general plan (0 when the plan does not exist). */
+NL_API int nl_plan_info(nl_handle h, int *fused_mode, int *fused_max_pos, int *launches_fused, int *launches_general);
 /* Device bytes held by the handle (weights, KV, state). */
 NL_API int nl_memory_usage(nl_handle h, uint64_t *weights, uint64_t *kv_cache, uint64_t *state);
 /* Read back a device state buffer for tests ("x","q","xb2","hb","logits",

@@ -16,6 +16,7 @@ NL_COMM_ID_BYTES = 128
 NL_P2P_HANDLE_BYTES = 64
 NL_FLAG_NO_GRAPH = 1
 NL_FLAG_LOCAL_GROUP = 2
+NL_FLAG_GROUP_FUSED = 4
 
 STATUS = {0: "NL_OK", -1: "NL_ERR_INVALID", -2: "NL_ERR_UNSUPPORTED", -3: "NL_ERR_HIP", -4: "NL_ERR_STATE",
           -5: "NL_ERR_MISSING", -6: "NL_ERR_COMM"}
@@ -89,7 +90,7 @@ EXPORTS = ["nl_build_info", "nl_set_gamma", "nl_abi_version", "nl_device_count",
            "nl_synchronize", "nl_timer_start", "nl_timer_stop", "nl_kernel_kind_name", "nl_profile_forward",
            "nl_memory_usage", "nl_debug_read", "nl_op_matmul", "nl_op_matmul_batch", "nl_op_rmsnorm", "nl_comm_get_unique_id",
            "nl_comm_init", "nl_group_forward", "nl_debug_stamps", "nl_sample_decode", "nl_op_sample", "nl_p2p_export",
-           "nl_p2p_import", "nl_p2p_info", "nl_p2p_loopback", "nl_op_exp"]
+           "nl_p2p_import", "nl_p2p_info", "nl_p2p_loopback", "nl_op_exp", "nl_plan_info"]
 
 
 def lib():
@@ -135,6 +136,7 @@ def lib():
     L.nl_p2p_import.argtypes = [vp, vp]
     L.nl_p2p_info.argtypes = [vp, ip, ip]
     L.nl_p2p_loopback.argtypes = [vp]
+    L.nl_plan_info.argtypes = [vp, ip, ip, ip, ip]
     L.nl_op_exp.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
     L.nl_group_forward.argtypes = [C.POINTER(vp), i32, i32, i32, i32, fp]
     L.nl_sample_decode.argtypes = [vp, i32, i32, i32, C.POINTER(NlSampleParams), fp, ip, ip, ip, ip]

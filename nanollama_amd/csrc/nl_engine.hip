@@ -16,6 +16,7 @@
 #include "nl_p2p.h"
 #include "nl_block.h"
 #include "nl_group.h"
+#include "nl_tp.h"
 
 #include <dlfcn.h>
 #include <algorithm>
@@ -106,10 +107,12 @@ constexpr int kNcclFloat = 7, kNcclSum = 0;
 
 struct Op {
     int kind;
-    int coll;  // 0 none, 1 all-reduce(sum) of buf[count], 2 all-gather into buf (count per rank)
+    int coll;  // 0 none, 1 all-reduce(sum) of buf[count], 2 all-gather into buf (count per rank),
+               // 3 (in-process group only) all-reduce(sum) of buf[count], then add_to[i] += buf[i]
     float *buf;
     size_t count;
     std::function<hipError_t(hipStream_t)> fn;
+    float *add_to = nullptr;
     // GEMV launches keep their parameters here so a later pass can point each one at its successor
     bool is_gemv = false;
     int wtype = 0, pro = 0, epi = 0;
@@ -204,7 +207,16 @@ struct nl_engine {
         hipGraphExec_t multi_exec = nullptr;  // (one inter-graph gap per graph_steps tokens instead of per token)
     } ps[2];
     bool fused = false;           // ps[1] exists
-    int fused_mode = 0;           // 1: whole attention half per layer (nl_block.h); 2: projection + attention (nl_group.h)
+    int fused_mode = 0;           // 1: whole attention half per layer (nl_block.h); 2: projection + attention (nl_group.h);
+                                  // 3: a tensor-parallel rank's layer as two launches (nl_tp.h)
+    struct TpGeom {               // mode 3 geometry, fixed at nl_finalize
+        int wo_gshift = 0;        // log2 of the 256-column groups of a WO row
+        int wo_tpw = 1;           // WO tiles per block of the attention launch's grid
+        int pair = 0, n_prod = 0, n_cons = 0, ct_shift = 1, grid = 0, nf = 1, ngc = 1, nr = 1;   // feed-forward launch
+    } tpg;
+    u32x4 *tp_xq = nullptr;       // 16-byte granules of the two-launch layer (nl_tp.h): q | k | v tiles of a kv group,
+    u32x4 *tp_xo = nullptr;       //   the heads' attention outputs,
+    u32x4 *tp_hx = nullptr;       //   g | u (or h) tiles of the feed-forward half
     int grp_tpm = 1;              // mode 2: 16-row tiles per workgroup
     bool ffn_fused = false;       // mode 1: the feed-forward half is one launch too (ffn_block_kernel)
     float *parts_ffn = nullptr;   // [I / 256][D] per-slice W_down partials
@@ -655,6 +667,84 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         float *kc = e->kcache + (long long)l * e->kv_layer_stride;
         float *vc = e->vcache + (long long)l * e->kv_layer_stride;
         bool parts_pending = false;
+        if (fused && e->fused_mode == 3) {
+            // a tensor-parallel rank's layer as two launches (nl_tp.h): both finish their all-reduce seam in the tail (push
+            // path), or leave the rank's partial in `ar` for the in-process group to sum and add (coll 3)
+            auto make_seam = [&](int sm) {
+                TpSeam S{};
+                S.rows = c.dim;
+                if (p2p) {
+                    for (int r = 0; r < e->G; r++)
+                        S.dst[r] = reinterpret_cast<u64 *>((char *)e->p2p.peer[r] + ((size_t)(sm & 1) * e->G + (e->p2p.loopback ? r : e->rank)) * slot_bytes);
+                    S.slots = reinterpret_cast<const u64 *>((char *)e->p2p.area + (size_t)(sm & 1) * e->G * slot_bytes);
+                    S.n = e->G; S.epoch = e->p2p.epoch; S.seam = (unsigned)(sm + 1);
+                    S.status = e->p2p.status; S.timeout = e->p2p.timeout_ticks;
+                } else {
+                    S.n = 0; S.partial = e->ar;
+                }
+                return S;
+            };
+            {
+                TpAttnParams Q{};
+                GroupParams &B = Q.G;
+                B.qkv_q = L.qkv.q; B.qkv_s = L.qkv.s;
+                B.D = c.dim; B.npairs = L.qkv.npairs; B.n_q_heads = e->Hs; B.n_kv_heads = e->KVs; B.seq_len = c.seq_len;
+                B.rope_conj = c.rope_conjugate; B.qk_norm = c.qk_norm; B.single_stream = c.max_streams == 1 ? 1 : 0;
+                B.tpm = e->grp_tpm; B.members = (e->gqa + 2) * 4 / e->grp_tpm;
+                B.gqa = (unsigned)e->gqa; B.wpt = (unsigned)((GRP_THREADS / 64) / e->grp_tpm); B.wpt_inv = udiv_inv(B.wpt);
+                B.m8_inv = udiv_inv(8u * (unsigned)B.members); B.m_inv = udiv_inv((unsigned)B.members);
+                B.x = e->x[cur]; B.normw = L.attn_norm; B.eps = c.rms_eps; B.scale = (float)(1.0 / std::sqrt((double)e->hd));
+                B.rope_cos = e->rope_cos; B.rope_sin = e->rope_sin; B.kcache = kc; B.vcache = vc;
+                B.kv_stream_stride = e->kv_stream_stride; B.ctl = e->ctl;
+                B.bias_q = L.bq; B.bias_k = L.bk; B.bias_v = L.bv;
+                B.nsplit_max = e->nsplit_max;
+                B.xchg = e->xchg; B.tick = p2p ? e->p2p.epoch : e->tick; B.layer_tag = (unsigned)(l + 1);
+                B.status = e->tick + 1; B.host_status = e->h_status; B.spin_limit = e->spin_limit;
+                Q.wo_q = L.wo.q; Q.wo_s = L.wo.s; Q.wo_npairs = L.wo.npairs; Q.wo_ntiles = L.wo.ntiles; Q.wo_gshift = e->tpg.wo_gshift;
+                Q.wo_tpw = e->tpg.wo_tpw;
+                Q.n_heads_local = e->Hs; Q.xq = e->tp_xq; Q.xo = e->tp_xo; Q.bias_out = L.bo; Q.x = e->x[cur];
+                Q.seam = make_seam(seam++);
+                const int wt = L.qkv.wtype, grid = grp_grid(e->KVs, B.members);
+                const int ngroups = (L.qkv.npairs + KL - 1) / KL, nf = (ngroups + 16 / e->grp_tpm - 1) / (16 / e->grp_tpm);
+                const size_t lds = tp_attn_lds_bytes(L.wo.npairs);
+                Op op{K_ATTNBLOCK, p2p ? 0 : 3, p2p ? nullptr : e->ar, (size_t)c.dim, [Q, wt, grid, nf, lds](hipStream_t st) {
+                          if (wt == WT_Q8_0 && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 1>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                          else if (wt == WT_Q8_0) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 2>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                          else if (nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 1>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                          else hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 2>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                          return hipGetLastError();
+                      }};
+                op.add_to = e->x[cur];
+                plan.push_back(op);
+            }
+            {
+                TpFfnParams F{};
+                F.gate_q = L.gate.q; F.gate_s = L.gate.s; F.up_q = L.up.q; F.up_s = L.up.s; F.dn_q = L.down.q; F.dn_s = L.down.s;
+                F.D = c.dim; F.I = e->Is; F.npairs = L.gate.npairs; F.gu_tiles = L.gate.ntiles;
+                F.dn_npairs = L.down.npairs; F.dn_ntiles = L.down.ntiles;
+                F.pair = e->tpg.pair; F.n_prod = e->tpg.n_prod; F.n_cons = e->tpg.n_cons; F.ct_shift = e->tpg.ct_shift;
+                F.normw = L.ffn_norm; F.eps = c.rms_eps; F.x = e->x[cur]; F.hx = e->tp_hx;
+                F.tick = p2p ? e->p2p.epoch : e->tick; F.layer_tag = (unsigned)(l + 1);
+                F.status = e->tick + 1; F.host_status = e->h_status; F.spin_limit = e->spin_limit;
+                F.seam = make_seam(seam++);
+                const int wt = L.gate.wtype, grid = e->tpg.grid, nf = e->tpg.nf, ngc = e->tpg.ngc, nr = e->tpg.nr;
+                const size_t lds = tp_ffn_lds_bytes(L.down.npairs);
+                Op op{K_FFNBLOCK, p2p ? 0 : 3, p2p ? nullptr : e->ar, (size_t)c.dim, [F, wt, grid, nf, ngc, nr, lds](hipStream_t st) {
+#define NL_TPF(WT_, NF_, NGC_, NR_) hipLaunchKernelGGL((tp_ffn_kernel<WT_, NF_, NGC_, NR_>), dim3(grid), dim3(TP_THREADS), lds, st, F)
+#define NL_TPF2(WT_, NF_, NGC_) do { if (nr <= 1) NL_TPF(WT_, NF_, NGC_, 1); else NL_TPF(WT_, NF_, NGC_, 2); } while (0)
+#define NL_TPF3(WT_, NF_) do { if (ngc <= 1) NL_TPF2(WT_, NF_, 1); else NL_TPF2(WT_, NF_, 2); } while (0)
+                          if (wt == WT_Q8_0) { if (nf == 1) NL_TPF3(WT_Q8_0, 1); else NL_TPF3(WT_Q8_0, 2); }
+                          else { if (nf == 1) NL_TPF3(WT_Q4_0, 1); else NL_TPF3(WT_Q4_0, 2); }
+#undef NL_TPF3
+#undef NL_TPF2
+#undef NL_TPF
+                          return hipGetLastError();
+                      }};
+                op.add_to = e->x[cur];
+                plan.push_back(op);
+            }
+            continue;
+        }
         if (fused && e->fused_mode == 1) {
             // the whole attention half as one launch per layer (nl_block.h); its H partial vectors are added to the
             // residual stream by the gate/up prologue below
@@ -794,8 +884,10 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         P2PArgmaxParams P{};
         P.A = ArgmaxParams{e->logits, c.vocab, e->amax_val, e->amax_idx, lm_blocks * lm_spb, e->ctl, e->ids, e->result};
         for (int r = 0; r < e->G; r++)
-            P.dst[r] = reinterpret_cast<u64 *>((char *)e->p2p.peer[r] + e->p2p.off_amax) + 2 * (e->p2p.loopback ? r : e->rank);
+            P.dst[r] = reinterpret_cast<u64 *>((char *)e->p2p.peer[r] + e->p2p.off_amax) + 4 * (e->p2p.loopback ? r : e->rank);
         P.slots = reinterpret_cast<const u64 *>((char *)e->p2p.area + e->p2p.off_amax);
+        // a fused-launch give-up on ANY rank travels with the pair: every rank retires its fused plan in the same call
+        if (e->tick && e->h_status) { P.fstatus = e->tick + 1; P.host_fstatus = e->h_status; }
         P.G = e->G; P.row0 = e->rank * e->Vs; P.seam = 255u;
         P.epoch = e->p2p.epoch; P.status = e->p2p.status; P.timeout_ticks = e->p2p.timeout_ticks;
         e->plan_p2p_argmax = P;
@@ -1513,6 +1605,14 @@ int nl_abi_version(void) { return 1; }
 #endif
 const char *nl_build_info(void) { return "src=" NL_SRC_SHA " git=" NL_GIT_HEAD; }
 
+#ifdef NL_TP_STAMPS
+__attribute__((visibility("default"))) int nl_debug_tp_stamps(long long *out) {   // developer build only: 8 x 16 values
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nl::g_tp_stamps), 8 * 16 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+__attribute__((visibility("default"))) int nl_debug_tp_census(long long *out) {   // 2 x 512 x 2 values
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nl::g_tp_census), 2 * 512 * 2 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef NL_ATTN_STAMPS
 __attribute__((visibility("default"))) int nl_debug_attn_stamps(long long *out) {   // developer build only: 16 values
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nl::g_attn_stamps), 16 * sizeof(long long)) == hipSuccess ? 0 : -1;
@@ -1853,28 +1953,78 @@ int nl_finalize(nl_handle e) {
         bool ok1 = base_ok && want != 2 && e->G == 1 && !e->force_tp_plan && c.dim % (BLK_MEMBERS * TR) == 0 && c.n_layers < 255;
         // (an RCCL plan carries the all-reduced partial into the next projection's prologue, which the fused launch lacks)
         bool ok2 = base_ok && c.n_layers < 255 && ((e->G == 1 && !e->force_tp_plan) || e->p2p.on);
+        // mode 3 (nl_tp.h): a tensor-parallel rank's layer as two launches -- ranks of a push group, or the shards of an
+        // in-process group that asked for it (NL_FLAG_GROUP_FUSED: the same kernels, the group adds the partials itself)
+        const bool group_fused = (c.flags & NL_FLAG_LOCAL_GROUP) && (c.flags & NL_FLAG_GROUP_FUSED);
+        const char *tf = getenv("NL_TP_FUSED");            // knob (tests, tools): 0 keeps a rank on the projection + attention plan
+        bool ok3 = want != 0 && want != 2 && !(tf && atoi(tf) == 0) && e->hd == 64 && e->G > 1 && c.n_layers < 127 &&
+                   ((e->p2p.on && !(c.flags & NL_FLAG_LOCAL_GROUP)) || group_fused);
         for (const auto &L : e->layers) {
             ok1 = ok1 && L.wo_head.ready && L.wo_head.wtype == L.qkv.wtype && (L.qkv.wtype == WT_Q8_0 || L.qkv.wtype == WT_Q4_0);
             ok2 = ok2 && (L.qkv.wtype == WT_Q8_0 || L.qkv.wtype == WT_Q4_0);
+            ok3 = ok3 && (L.qkv.wtype == WT_Q8_0 || L.qkv.wtype == WT_Q4_0) && L.wo.wtype == L.qkv.wtype &&
+                  L.gate.wtype == L.qkv.wtype && L.up.wtype == L.qkv.wtype && L.down.wtype == L.qkv.wtype;
         }
-        if (ok2 && !ok1) {
+        if ((ok2 && !ok1) || ok3) {
             // tiles per workgroup: as few as keeps every workgroup of the launch resident at once (one per compute unit)
             const int NT = (e->gqa + 2) * 4, ngroups = ((c.dim + PAIR - 1) / PAIR + KL - 1) / KL;
             int tpm = 1;
             const int cu_budget = e->num_cus - e->num_cus / 8;   // every workgroup of the launch resident at once, with a margin
             while (tpm <= 4 && e->KVs * NT / tpm > cu_budget) tpm *= 2;
-            ok2 = tpm <= 4 && NT % tpm == 0 && NT / tpm >= e->gqa && ngroups <= 2 * (16 / tpm);
+            const bool geo = tpm <= 4 && NT % tpm == 0 && NT / tpm >= e->gqa && ngroups <= 2 * (16 / tpm);
+            ok2 = ok2 && geo;
+            ok3 = ok3 && geo;
             e->grp_tpm = tpm;
+        }
+        if (ok3) {
+            nl_engine::TpGeom &t = e->tpg;
+            const nl_engine::Layer &L0 = e->layers[0];
+            // WO: EVERY block of the attention launch's grid owns tpw tiles of this rank's column slice; a row's 256-column
+            // groups (a power of two <= 16) and the block's tiles share its 16 wavefronts
+            const int wo_groups = (L0.wo.npairs + KL - 1) / KL;
+            int gshift = 0;
+            while ((1 << gshift) < wo_groups) gshift++;
+            const int agrid = grp_grid(e->KVs, (e->gqa + 2) * 4 / e->grp_tpm);
+            int tpw = 1;
+            while (tpw < 16 && (long long)agrid * tpw < L0.wo.ntiles) tpw *= 2;
+            ok3 = gshift <= 4 && (tpw << gshift) <= 16 && (long long)agrid * tpw >= L0.wo.ntiles && L0.wo.npairs <= 64;
+            t.wo_gshift = gshift;
+            t.wo_tpw = tpw;
+            ok3 = ok3 && e->Hs * 4 * GPT <= TP_THREADS;      // one attention-output granule per thread
+            // feed-forward: blocks [0, n_prod) project one gate / up tile each while that grid stays resident (one 1024-thread
+            // workgroup per compute unit), else a gate + up tile pair each; EVERY block b < ceil(D / 16) owns W_down tile b
+            const int ngroups = (L0.gate.npairs + KL - 1) / KL, dgroups = (L0.down.npairs + KL - 1) / KL;
+            const int budget = e->num_cus - e->num_cus / 16;
+            const char *pk = getenv("NL_TP_PAIR");     // developer knob (tools/, tests)
+            t.pair = pk ? (atoi(pk) != 0) : (2 * L0.gate.ntiles > budget);
+            t.n_prod = t.pair ? L0.gate.ntiles : 2 * L0.gate.ntiles;
+            // W_down: blocks [0, n_cons) own ct tiles each (every consumer gathers all of h: fewer consumers = less fabric
+            // traffic per gather, more tiles per consumer = more vector work per compute unit; 2 measured best at tp 8)
+            const char *ck = getenv("NL_TP_CT");      // developer knob (tools/)
+            int ct = ck ? atoi(ck) : (L0.down.npairs <= 24 ? 2 : 1);   // (tp 8 of the 7.9B tier: 2; tp 4: 1 -- measured, tools/r4_tp3.sh)
+            if (ct != 1 && ct != 2 && ct != 4 && ct != 8 && ct != 16) ct = 2;
+            while (ct > 1 && (dgroups + 16 / ct - 1) / (16 / ct) > 2) ct /= 2;
+            t.ct_shift = ct == 1 ? 0 : ct == 2 ? 1 : ct == 4 ? 2 : ct == 8 ? 3 : 4;
+            t.n_cons = (L0.down.ntiles + ct - 1) / ct;
+            t.grid = std::max(t.n_prod, t.n_cons);
+            t.nf = (ngroups + (t.pair ? 8 : 16) - 1) / (t.pair ? 8 : 16);
+            t.ngc = (dgroups + 16 / ct - 1) / (16 / ct);
+            t.nr = (L0.gate.ntiles * GPT + TP_THREADS - 1) / TP_THREADS;
+            ok3 = ok3 && t.ngc <= 2 && t.nf <= 2 && t.nr <= 2 && t.n_prod <= budget && L0.down.npairs <= 128;
+            for (const auto &L : e->layers)   // (every layer has the shapes of layer 0: checked, not assumed)
+                ok3 = ok3 && L.wo.npairs == L0.wo.npairs && L.gate.ntiles == L0.gate.ntiles && L.down.npairs == L0.down.npairs &&
+                      L.down.ntiles == L0.down.ntiles && L.gate.npairs == L0.gate.npairs;
         }
         // mode 1 launches one 768-thread workgroup per (head, member) and one per (slice, member): they only make progress
         // together, so both grids must fit on the device's compute units at once
         if (ok1 && (blk_grid(e->Hs) > e->num_cus || ffn_grid(e->Is / FFN_SLICE) > e->num_cus)) ok1 = false;
-        e->fused_mode = ok1 ? 1 : ok2 ? 2 : 0;
+        e->fused_mode = ok1 ? 1 : ok3 ? 3 : ok2 ? 2 : 0;
         e->fused = e->fused_mode != 0;
         const char *fm = getenv("NL_FUSED_MAX_POS");
         // tools/fused_limit.py: the per-head blocks (mode 1) win up to ~500 (nano) / ~600 (mini) positions, the projection +
         // attention launch of the wide tiers (mode 2) up to ~390 (big)
         e->fused_max_pos = fm ? atoi(fm) : e->fused_mode == 1 ? 512 : 384;
+        if (e->fused_mode == 3) e->fused_max_pos = std::min(e->fused_max_pos, TP_NCH_MAX * ATT_CH);   // passes a head takes inside the launch
         {
             const char *ff = getenv("NL_FUSED_FFN");   // knob (tests, tools): 0 keeps gate/up and down as two launches
             bool okf = e->fused_mode == 1 && !(ff && atoi(ff) == 0);
@@ -1896,6 +2046,15 @@ int nl_finalize(nl_handle e) {
             HIPCK(e, hipMemset(e->tick, 0, 8));
             HIPCK(e, hipHostMalloc((void **)&e->h_status, sizeof(unsigned), hipHostMallocMapped));
             *e->h_status = 0;
+        }
+        if (e->fused_mode == 3) {
+            const size_t nq = (size_t)e->KVs * (e->gqa + 2) * 4 * GPT, no = (size_t)e->Hs * 4 * GPT, nh = (size_t)2 * e->layers[0].gate.ntiles * GPT;
+            HIPCK(e, dalloc(&e->tp_xq, nq, &e->bytes_state));
+            HIPCK(e, hipMemset(e->tp_xq, 0, nq * sizeof(u32x4)));
+            HIPCK(e, dalloc(&e->tp_xo, no, &e->bytes_state));
+            HIPCK(e, hipMemset(e->tp_xo, 0, no * sizeof(u32x4)));
+            HIPCK(e, dalloc(&e->tp_hx, nh, &e->bytes_state));
+            HIPCK(e, hipMemset(e->tp_hx, 0, nh * sizeof(u32x4)));
         }
     }
     const bool has_coll = (e->G > 1 || e->force_tp_plan) && !e->p2p.on;
@@ -1986,7 +2145,7 @@ int nl_destroy(nl_handle e) {
         if (e->p2p.epoch) (void)hipFree(e->p2p.epoch);
     }
     void *bufs[] = {e->embd_raw, e->output_norm, e->rope_cos, e->rope_sin, e->x[0], e->x[1], e->qbuf, e->part_o,
-                    e->part_ml, e->hb, e->ar, e->parts, e->xchg, e->tick, e->parts_ffn, e->xchg_ffn, e->samp_keep, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result, e->amax_val,
+                    e->part_ml, e->hb, e->ar, e->parts, e->xchg, e->tp_xq, e->tp_xo, e->tp_hx, e->tick, e->parts_ffn, e->xchg_ffn, e->samp_keep, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result, e->amax_val,
                     e->amax_idx};
     for (void *b : bufs) if (b) hipFree(b);
     if (e->h_ctl) hipHostFree(e->h_ctl);
@@ -2427,6 +2586,16 @@ int nl_profile_forward(nl_handle e, int stream, int token, int pos, int iters, f
     return NL_OK;
 }
 
+int nl_plan_info(nl_handle e, int *fused_mode, int *fused_max_pos, int *launches_fused, int *launches_general) {
+    if (!e) return NL_ERR_INVALID;
+    if (!e->finalized) return e->fail(NL_ERR_STATE, "nl_plan_info before nl_finalize");
+    if (fused_mode) *fused_mode = e->fused ? e->fused_mode : 0;
+    if (fused_max_pos) *fused_max_pos = e->fused ? e->fused_max_pos : 0;
+    if (launches_fused) *launches_fused = e->fused ? (int)e->ps[1].ops.size() : 0;
+    if (launches_general) *launches_general = (int)e->ps[0].ops.size();
+    return NL_OK;
+}
+
 int nl_memory_usage(nl_handle e, uint64_t *w, uint64_t *kv, uint64_t *st) {
     if (!e) return NL_ERR_INVALID;
     if (w) *w = e->bytes_weights;
@@ -2660,42 +2829,72 @@ int nl_group_forward(nl_handle *hs, int n, int stream, int token, int pos, float
             return e0->fail(NL_ERR_INVALID, "nl_group_forward: shard %d is not rank %d of a local group of %d", r, r, n);
         int rc = check_step_args(hs[r], stream, token, pos);
         if (rc) return rc;
-        if (hs[r]->ps[0].ops.size() != e0->ps[0].ops.size()) return e0->fail(NL_ERR_STATE, "shards disagree on the launch plan");
         if (hs[r]->dev != e0->dev) return e0->fail(NL_ERR_UNSUPPORTED, "local group across devices is not implemented");
     }
     HIPCK(e0, hipSetDevice(e0->dev));
     hipStream_t st = e0->stream;  // one stream serialises the whole group
-    for (int r = 0; r < n; r++) {
-        nl_engine *e = hs[r];
-        if (int rc = note_positions(e, stream, pos, 1, st)) return rc;
-        e->h_ctl[CTL_TOKEN] = token; e->h_ctl[CTL_POS] = pos; e->h_ctl[CTL_CHAIN] = 0;
-        e->h_ctl[CTL_STEP] = 0; e->h_ctl[CTL_STREAM] = stream;
-        HIPCK(e0, hipMemcpyAsync(e->ctl, e->h_ctl, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
-    }
-    for (size_t i = 0; i < e0->ps[0].ops.size(); i++) {
+    for (int attempt = 0;; attempt++) {
+        // NL_FLAG_GROUP_FUSED shards step the two-launches-per-layer plan of a push-group rank (nl_tp.h) at short contexts;
+        // its launches leave every shard's partial in `ar` and the group adds them in rank order (coll 3)
+        int k = 1;
+        for (int r = 0; r < n; r++)
+            if (!(hs[r]->fused && hs[r]->fused_mode == 3 && pos < hs[r]->fused_max_pos)) k = 0;
+        for (int r = 0; r < n; r++)
+            if (hs[r]->ps[k].ops.size() != e0->ps[k].ops.size()) return e0->fail(NL_ERR_STATE, "shards disagree on the launch plan");
         for (int r = 0; r < n; r++) {
-            hipError_t s = hs[r]->ps[0].ops[i].fn(st);
-            if (s != hipSuccess) return e0->fail(NL_ERR_HIP, "group launch %s: %s", kKindNames[e0->ps[0].ops[i].kind], hipGetErrorString(s));
+            nl_engine *e = hs[r];
+            if (int rc = note_positions(e, stream, pos, 1, st)) return rc;
+            e->h_ctl[CTL_TOKEN] = token; e->h_ctl[CTL_POS] = pos; e->h_ctl[CTL_CHAIN] = 0;
+            e->h_ctl[CTL_STEP] = 0; e->h_ctl[CTL_STREAM] = stream;
+            HIPCK(e0, hipMemcpyAsync(e->ctl, e->h_ctl, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
         }
-        const Op &op = e0->ps[0].ops[i];
-        if (op.coll == 1) {
-            PtrList8 pl{};
-            for (int r = 0; r < n; r++) pl.p[r] = hs[r]->ps[0].ops[i].buf;
-            int cnt = (int)op.count;
-            hipLaunchKernelGGL(local_allreduce_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, pl, n, cnt);
-            HIPCK(e0, hipGetLastError());
-        } else if (op.coll == 2) {
-            for (int src = 0; src < n; src++)
-                for (int dst = 0; dst < n; dst++)
-                    if (src != dst)
-                        HIPCK(e0, hipMemcpyAsync(hs[dst]->ps[0].ops[i].buf + (size_t)src * op.count,
-                                                 hs[src]->ps[0].ops[i].buf + (size_t)src * op.count, op.count * 4,
-                                                 hipMemcpyDeviceToDevice, st));
+        for (size_t i = 0; i < e0->ps[k].ops.size(); i++) {
+            for (int r = 0; r < n; r++) {
+                hipError_t s = hs[r]->ps[k].ops[i].fn(st);
+                if (s != hipSuccess) return e0->fail(NL_ERR_HIP, "group launch %s: %s", kKindNames[e0->ps[k].ops[i].kind], hipGetErrorString(s));
+            }
+            const Op &op = e0->ps[k].ops[i];
+            if (op.coll == 1 || op.coll == 3) {
+                PtrList8 pl{};
+                for (int r = 0; r < n; r++) pl.p[r] = hs[r]->ps[k].ops[i].buf;
+                int cnt = (int)op.count;
+                hipLaunchKernelGGL(local_allreduce_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, pl, n, cnt);
+                HIPCK(e0, hipGetLastError());
+                if (op.coll == 3)
+                    for (int r = 0; r < n; r++) {
+                        const Op &o = hs[r]->ps[k].ops[i];
+                        hipLaunchKernelGGL(tp_add_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, o.add_to, o.buf, cnt);
+                        HIPCK(e0, hipGetLastError());
+                    }
+            } else if (op.coll == 2) {
+                for (int src = 0; src < n; src++)
+                    for (int dst = 0; dst < n; dst++)
+                        if (src != dst)
+                            HIPCK(e0, hipMemcpyAsync(hs[dst]->ps[k].ops[i].buf + (size_t)src * op.count,
+                                                     hs[src]->ps[k].ops[i].buf + (size_t)src * op.count, op.count * 4,
+                                                     hipMemcpyDeviceToDevice, st));
+            }
         }
+        if (logits_out)
+            HIPCK(e0, hipMemcpyAsync(logits_out, e0->logits, (size_t)e0->cfg.vocab * 4, hipMemcpyDeviceToHost, st));
+        HIPCK(e0, hipStreamSynchronize(st));
+        bool redo = false;
+        for (int r = 0; r < n; r++)
+            if (hs[r]->h_status && *hs[r]->h_status) redo = true;
+        if (attempt == 0 && redo) {          // a cluster exchange gave up in some shard: every shard retires the fused plan
+            for (int r = 0; r < n; r++) {
+                nl_engine *e = hs[r];
+                if (e->h_status) *e->h_status = 0;
+                if (e->tick) (void)hipMemsetAsync(e->tick + 1, 0, sizeof(unsigned), st);
+                e->fused = false;
+                e->fused_retired = true;
+            }
+            HIPCK(e0, hipStreamSynchronize(st));
+            e0->fail(NL_OK, "warning: a fused-launch cluster exchange timed out in the shard group; the step was redone on the general plan");
+            continue;
+        }
+        break;
     }
-    if (logits_out)
-        HIPCK(e0, hipMemcpyAsync(logits_out, e0->logits, (size_t)e0->cfg.vocab * 4, hipMemcpyDeviceToHost, st));
-    HIPCK(e0, hipStreamSynchronize(st));
     return NL_OK;
 }
 
@@ -2739,7 +2938,7 @@ int nl_p2p_export(nl_handle e, void *handle_out) {
     if (!p.area) {
         const size_t ar = (size_t)2 * e->G * e->cfg.dim * sizeof(u64);
         p.off_amax = (ar + 255) & ~(size_t)255;
-        p.off_logits = (p.off_amax + (size_t)e->G * 2 * sizeof(u64) + 255) & ~(size_t)255;
+        p.off_logits = (p.off_amax + (size_t)e->G * 4 * sizeof(u64) + 255) & ~(size_t)255;
         p.bytes = p.off_logits + (size_t)e->cfg.vocab * 4;
         // Written by the peers while this device reads it: the area must be UNCACHED, so that no L2 line of this device
         // can shadow a push (remote xGMI writes do not probe the local L2).  The tagged granules would survive a cached

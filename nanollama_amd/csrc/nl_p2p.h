@@ -32,8 +32,11 @@ __device__ __forceinline__ void granule_store(u64 *p, unsigned tag, unsigned bit
 struct P2PArgmaxParams {
     ArgmaxParams A;        // this rank's partial maxima from its LM-head slice (indices local to the slice)
     EmbedParams E;         // E.x != nullptr: also embed the chosen token (next step of a multi-step graph)
-    u64 *dst[8];           // peer r's argmax slots, already offset to this rank's pair
-    const u64 *slots;      // this rank's receive pairs: [G][2] granules {value, index}
+    u64 *dst[8];           // peer r's argmax slots, already offset to this rank's entry
+    const u64 *slots;      // this rank's receive entries: [G][4] granules {value, index, fused-launch status, -}
+    unsigned *fstatus;     // this rank's fused-launch status word (nl_block.h; null without a fused plan): pushed with the
+    unsigned *host_fstatus;//   pair, and set here (device word + its host-visible copy) when ANY rank reports a give-up, so
+                           //   that every rank of the group retires its fused plan and redoes the call in the same step
     int G, row0;           // row0: global vocabulary index of this rank's first row
     unsigned seam;
     unsigned *epoch;       // advanced when E.x is set (the embedded token opens the next Forward)
@@ -70,37 +73,45 @@ __global__ void __launch_bounds__(1024) p2p_argmax_kernel(P2PArgmaxParams P) {
         for (int w = 1; w < (int)(blockDim.x >> 6); w++)
             if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
         const int gidx = idx == 0x7fffffff ? 0x7fffffff : idx + P.row0;
+        const unsigned fs = P.fstatus ? __hip_atomic_load(P.fstatus, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         __threadfence_system();
         for (int r = 0; r < P.G; r++) {
             granule_store(P.dst[r], tag, __float_as_uint(best));
             granule_store(P.dst[r] + 1, tag, (unsigned)gidx);
+            granule_store(P.dst[r] + 2, tag, fs);
         }
     }
     // lanes 0..G-1 of wave 0 each wait for one rank's pair
     if (tid < 64) {
         const int r = min(tid, P.G - 1);
         const bool dead = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        u64 gv, gi;
+        u64 gv, gi, gs;
         const long long t0 = wall_clock64();
+        bool got = true;
         for (;;) {
-            gv = granule_load(P.slots + 2 * r);
-            gi = granule_load(P.slots + 2 * r + 1);
-            const bool ok = (unsigned)(gv >> 32) == tag && (unsigned)(gi >> 32) == tag;
+            gv = granule_load(P.slots + 4 * r);
+            gi = granule_load(P.slots + 4 * r + 1);
+            gs = granule_load(P.slots + 4 * r + 2);
+            const bool ok = (unsigned)(gv >> 32) == tag && (unsigned)(gi >> 32) == tag && (unsigned)(gs >> 32) == tag;
             if (__all(ok)) break;
             if (dead || wall_clock64() - t0 > P.timeout_ticks) {
                 if (tid == 0) atomicOr(P.status, 2u);
+                got = false;
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
         }
         float v = tid < P.G ? __uint_as_float((unsigned)gv) : -INFINITY;
         int vi = tid < P.G ? (int)(unsigned)gi : 0x7fffffff;
+        unsigned fst = (tid < P.G && got) ? (unsigned)gs : 0u;
 #pragma unroll
         for (int o = 4; o > 0; o >>= 1) {   // G <= 8
             float ov = __shfl_xor(v, o);
             int oi = __shfl_xor(vi, o);
             if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
+            fst |= __shfl_xor(fst, o);
         }
+        if (tid == 0 && fst && P.fstatus) { atomicOr(P.fstatus, fst); *P.host_fstatus = fst; }
         if (tid == 0) {
             if (vi == 0x7fffffff) vi = 0;   // all-NaN logits: the reference's loop never leaves index 0
             tok = vi;

@@ -1,0 +1,771 @@
+// nl_tp.h -- a tensor-parallel rank's decoder layer as TWO launches (go/model.go:517-594 and :597-612).
+//
+// A rank of a tp 4 / tp 8 group holds 12-25 MB of a 7.9B layer: 2.4-5 us of HBM time spread over the four dependent
+// launches of the wide-tier plan (projection + attention, WO, gate || up, down), each of which costs 4.5-7 us whatever it
+// streams.  The shard is a small-tier problem, so it gets the small-tier answer -- two launches per layer:
+//
+//   tp_attn_kernel   RMSNorm -> this rank's Q | K | V tiles (chip-wide spread, as nl_group.h) -> RoPE -> cluster exchange
+//                    -> GQA attention per query head -> the heads' normalised outputs published as granules -> every
+//                    workgroup multiplies its rows of this rank's WO column slice (weights requested at entry: they
+//                    stream in while the attention runs) -> push all-reduce finished by the row's owner lane.
+//   tp_ffn_kernel    PRODUCER workgroups: RMSNorm -> one gate / up tile each (or a gate + up tile pair, SwiGLU applied)
+//                    -> published as granules.  CONSUMER workgroups: request their rows of this rank's W_down column
+//                    slice at entry, gather h, multiply -> push all-reduce finished by the row's owner lane.
+//
+// Every in-launch hand-off is cdna_hip_programming.md Guideline 16 form R2 (8-byte {tag, value} granules, relaxed
+// agent-scope stores and polls, the value is its own flag); tag = (forward counter << 8) | layer, the counter advanced by
+// the embedding launch, so a replayed graph needs no per-launch argument.  Producers never wait, so the launches cannot
+// deadlock on their own; every poll is bounded and a give-up is reported like the other fused launches' (nl_block.h).
+// The all-reduce tail is the one of the GEMV's EPI_P2P (nl_kernels.h, nl_p2p.h): granules into every rank's receive slot,
+// the row's owner adds the G partials in rank order.  In an in-process shard group (NL_FLAG_LOCAL_GROUP) the tail stores
+// the rank's partial instead and nl_group_forward adds the shards' partials in the same order: bitwise the same result.
+#pragma once
+#include "nl_kernels.h"
+#include "nl_group.h"
+#include "nl_p2p.h"
+
+namespace nl {
+
+#ifdef NL_TP_STAMPS
+// developer build (tools/tp_stamps.sh): wall-clock (100 MHz) phase stamps of a few workgroups of layer NL_TP_STAMPS's launches
+__device__ long long g_tp_stamps[8][16];
+__device__ long long g_tp_census[2][512][2];     // [launch kind][block][entry, exit] of the stamped layer
+#define TP_STAMP(slot, i) do { if ((slot) >= 0 && threadIdx.x == 0) g_tp_stamps[(slot)][(i)] = wall_clock64(); } while (0)
+#define TP_CENSUS(kind, layer_tag, which) do { if ((layer_tag) == NL_TP_STAMPS && threadIdx.x == 0 && blockIdx.x < 512) g_tp_census[(kind)][blockIdx.x][(which)] = wall_clock64(); } while (0)
+#else
+#define TP_STAMP(slot, i) do { } while (0)
+#define TP_CENSUS(kind, layer_tag, which) do { } while (0)
+#endif
+
+constexpr int TP_THREADS = 1024;
+constexpr int TP_NCH_MAX = 4;        // 128-position passes a head's attention may take inside the launch (fused_max_pos <= 512)
+
+// One all-reduce seam as the tail of a launch sees it.
+struct TpSeam {
+    u64 *dst[8];            // rank r's receive slot for THIS rank's partial (seam parity applied)
+    const u64 *slots;       // this rank's receive slots of the seam: [n][rows]
+    const unsigned *epoch;  // forward counter (tag = epoch << 8 | seam)
+    unsigned *status;       // set non-zero when a poll gave up (host: NL_ERR_COMM)
+    long long timeout;      // wall_clock64 ticks
+    int n;                  // ranks; 0 = in-process group: store the partial to `partial` and return
+    unsigned seam;
+    int rows;               // D
+    float *partial;         // n == 0: [rows]
+};
+
+// out[row] = resid + sum over ranks (rank order) of the partials of `row`; this lane owns the row.
+__device__ __forceinline__ void tp_allreduce_row(const TpSeam &S, unsigned e_tag, int row, float v, float resid, float *out) {
+    if (S.n == 0) { S.partial[row] = v; return; }
+    const u64 gran = ((u64)e_tag << 32) | __float_as_uint(v);
+#pragma unroll
+    for (int pr = 0; pr < 8; pr++)
+        if (pr < S.n) __hip_atomic_store(S.dst[pr] + row, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const bool dead = __hip_atomic_load(S.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    u64 g[8];
+    const long long t0 = wall_clock64();
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int pr = 0; pr < 8; pr++)
+            g[pr] = __hip_atomic_load(S.slots + (size_t)min(pr, S.n - 1) * S.rows + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int pr = 0; pr < 8; pr++) ok &= (unsigned)(g[pr] >> 32) == e_tag;
+        if (ok) break;
+        if (dead || wall_clock64() - t0 > S.timeout) { atomicOr(S.status, 1u); break; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int pr = 0; pr < 8; pr++) sum += pr < S.n ? __uint_as_float((unsigned)g[pr]) : 0.f;   // fixed rank order
+    out[row] = resid + sum;
+}
+
+// ---- 16-byte granules {tag, v0, v1, v2}: ONE dwordx4 write-through store each (observed untorn on gfx950 like the 8-byte
+// form, cdna_hip_programming.md G16 R2; every consumer validates the tag of every granule it uses).  Measured
+// (tools/allgather_probe.hip, profiles/r04_allgather_probe.log): an all-gather of 2752 floats to 256 workgroups costs 1.77 us
+// from the last publish with these against 2.05 us with 8-byte granules and 2.6-4.5 us with flag + payload forms.
+// A TILE of 16 values (one 16-row projection tile, a quarter of a head) is six granules: granule j holds values 3j .. 3j+2.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int GPT = 6;      // granules per 16-value tile
+
+__device__ __forceinline__ void gran16_store(u32x4 *p, unsigned tag, float a, float b, float c) {
+    const u32x4 v = {tag, __float_as_uint(a), __float_as_uint(b), __float_as_uint(c)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+// the calling wavefront (all 64 lanes active) publishes ntile tiles: lane l holds value l & 15 of tile l >> 4
+__device__ __forceinline__ void gran16_publish(u32x4 *tile0, int ntile, unsigned tag, float v, int lane) {
+    const int t = lane / GPT, j = lane - t * GPT;                 // lanes 0 .. 6 ntile - 1 store one granule each
+    const int src = min(t, 3) * 16 + 3 * j;
+    const float a = __shfl(v, src), b = __shfl(v, min(src + 1, 63)), c = __shfl(v, min(src + 2, 63));
+    if (t < ntile) gran16_store(tile0 + t * GPT + j, tag, a, b, c);
+}
+__device__ __forceinline__ u32x4 gran16_load(const u32x4 *p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void gran16_load2(const u32x4 *p0, const u32x4 *p1, u32x4 &a, u32x4 &b) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(p0), "v"(p1) : "memory");
+}
+__device__ __forceinline__ void gran16_load4(const u32x4 *p0, const u32x4 *p1, const u32x4 *p2, const u32x4 *p3, u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
+
+// Every thread with gi < ng spins on granule gi until its tag matches (a wavefront leaves together); bounded.
+__device__ __forceinline__ u32x4 gran16_wait(const u32x4 *src, int gi, int ng, unsigned tag, unsigned *status, unsigned *host_status,
+                                             int spin_limit, unsigned code, bool dead) {
+    u32x4 g;
+    const int lane = threadIdx.x & 63;
+    for (int spins = 0;; spins++) {
+        g = gran16_load(src + min(gi, ng - 1));
+        if (__all(g.x == tag)) break;
+        if (dead || spins >= spin_limit) { if (lane == 0) { atomicOr(status, code); *host_status = code; } break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return g;
+}
+
+// All-gather of `ntile` 16-value tiles (and, TWO, of a second array of as many: dst = SiLU(first) * second, go/quant.go:629-631,
+// go/model.go:604-606) into LDS as padded 64-column pairs, by every thread of the workgroup.  Two stages, because a polling
+// workgroup costs the streaming ones fabric bandwidth (tp_ffn_kernel with every wavefront polling: +1 us on the producers'
+// weight fetch): ONE wavefront spins on the first granule of <= 16 tiles spread over the array while the others sit at the
+// barrier, then every granule is fetched once, a thread's loads in flight together, every tag checked -- the sampled tiles
+// being visible promises nothing about the rest, so the sweep retries.  NR: granules per thread and array.
+template <int NR, bool TWO, bool PROBE>
+__device__ __forceinline__ void tp_gather16(const u32x4 *src, const u32x4 *src2, int ntile, unsigned tag, float *dst, float *dst2, int nvals,
+                                            unsigned *status, unsigned *host_status, int spin_limit, unsigned code) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool dead = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (PROBE) {
+        if (tid < 64) {
+            const int np = min(ntile, 16), pl = lane & 15;
+            const int pt = min((pl * ntile) / np, ntile - 1);              // lanes 0-15: array one; 16-31: array two (TWO); the rest repeat
+            const u32x4 *pp = ((TWO && (lane & 16)) ? src2 : src) + (size_t)pt * GPT;
+            for (int spins = 0;; spins++) {
+                const u32x4 g = gran16_load(pp);
+                if (__all(g.x == tag)) break;
+                if (dead || spins >= spin_limit) { if (lane == 0) { atomicOr(status, code); *host_status = code; } break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+    }
+    const int ng = ntile * GPT;
+    static_assert(NR == 1 || NR == 2, "granules per thread");
+    u32x4 ga[NR], gb[NR];
+    if ((tid & ~63) < ng) {           // this wavefront holds granules
+        for (int spins = 0;; spins++) {
+            const u32x4 *p0 = src + min(tid, ng - 1), *p1 = src + min(tid + TP_THREADS, ng - 1);
+            if (TWO) {
+                const u32x4 *q0 = src2 + min(tid, ng - 1), *q1 = src2 + min(tid + TP_THREADS, ng - 1);
+                if (NR == 1 || tid + TP_THREADS >= ng + 63) gran16_load2(p0, q0, ga[0], gb[0]);
+                else gran16_load4(p0, p1, q0, q1, ga[0], ga[NR - 1], gb[0], gb[NR - 1]);
+            } else {
+                if (NR == 1 || tid + TP_THREADS >= ng + 63) ga[0] = gran16_load(p0);
+                else gran16_load2(p0, p1, ga[0], ga[NR - 1]);
+            }
+            bool ok = ga[0].x == tag && (!TWO || gb[0].x == tag);
+            if (NR == 2 && tid + TP_THREADS < ng + 63) ok = ok && ga[NR - 1].x == tag && (!TWO || gb[NR - 1].x == tag);
+            if (__all(ok)) break;
+            if (dead || spins >= spin_limit) { if (lane == 0) { atomicOr(status, code); *host_status = code; } break; }
+            __builtin_amdgcn_s_sleep(PROBE ? 1 : 3);
+        }
+#pragma unroll
+        for (int q = 0; q < NR; q++) {
+            const int gi = tid + q * TP_THREADS;
+            if (gi < ng) {
+                const int t = gi / GPT, j = gi - t * GPT;
+                const unsigned va[3] = {ga[q].y, ga[q].z, ga[q].w}, vb[3] = {gb[q].y, gb[q].z, gb[q].w};
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const int i = t * 16 + 3 * j + c;
+                    if (3 * j + c < 16 && i < nvals) {
+                        dst[(i >> 6) * XS_PAIR + (i & 63)] = __uint_as_float(va[c]);
+                        if (TWO) dst2[i] = __uint_as_float(vb[c]);
+                    }
+                }
+            }
+        }
+    }
+    if (TWO) {
+        // SiLU(g) * u (go/quant.go:629-631, go/model.go:604-606) with the float64 exponentials spread over all threads
+        __syncthreads();
+        for (int i = tid; i < nvals; i += TP_THREADS) {
+            float *d = dst + (i >> 6) * XS_PAIR + (i & 63);
+            const float g = *d;
+            *d = (g / (1.0f + exp_f64_as_f32(-g))) * dst2[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ attention half ---
+
+struct TpAttnParams {
+    GroupParams G;               // projection + attention geometry, as qkv_attn_kernel (xchg / part_o / part_ml unused)
+    const uint8_t *wo_q;         // this rank's WO column slice, packed [D / 16 tiles][Hs * 64 columns]
+    const uint32_t *wo_s;
+    int wo_npairs, wo_ntiles;
+    int wo_gshift;               // log2 of the 256-column groups of a WO row (1, 2, 4, 8 or 16 groups; host-checked)
+    int wo_tpw;                  // WO tiles per workgroup: block b owns tiles [b * tpw, b * tpw + tpw)
+    int n_heads_local;           // Hs
+    u32x4 *xq;                   // [kv groups][(G + 2) * 4 tiles][6] granules: q | k | v rows of this position, tile order
+    u32x4 *xo;                   // [Hs][4 tiles][6] granules: the heads' normalised attention outputs
+    const float *bias_out;
+    float *x;                    // residual stream, read at entry (RMSNorm input, owner rows) and rewritten by the owners
+    TpSeam seam;
+};
+
+__host__ __device__ constexpr size_t tp_attn_lds_bytes(int wo_npairs) {
+    return 16 * sizeof(double) + sizeof(float) * (size_t)(16 * XS_WAVE + 16 * TR + 3 * 64 + 8 * 68 + TP_NCH_MAX * 66 + wo_npairs * XS_PAIR + 16 * TR);
+}
+
+// One role of the launch as straight-line code: every load below is unconditional (clamped addresses, masked uses), so
+// hipcc's counted s_waitcnt in front of the first use of x is exact -- with loads behind role branches it assumes the
+// shortest path and makes the RMSNorm wait for the weights, the dots for the cache rows and the WO tiles.
+// LIVE: the block holds projection tiles; RUNNER: ... and runs the attention of one query head.
+template <int WT, int NF, bool LIVE, bool RUNNER>
+__device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, int cl, int mem) {
+    const GroupParams &P = Q.G;
+    constexpr int HD = 64, CPP = WTraits<WT>::CPP, R4 = HD / 4, NV = 4, NW = TP_THREADS / 64;
+    double *dred = reinterpret_cast<double *>(smem);                 // [16]
+    float *xs = reinterpret_cast<float *>(dred + 16);                // [16][XS_WAVE]
+    float *red = xs + NW * XS_WAVE;                                  // [16][16]
+    float *qs = red + NW * TR;                                       // [64]
+    float *kcur = qs + 64, *vcur = kcur + 64;
+    float *wpart = vcur + 64;                                        // [8][68]: a cache wavefront's (max, sum, -, -, sum p*v[64]) of the pass
+    float *chunk = wpart + 8 * 68;                                   // [TP_NCH_MAX][66]: (M, L, o[64]) per pass
+    float *ao = chunk + TP_NCH_MAX * 66;                             // [wo_npairs][XS_PAIR]: every local head's output
+    float *red2 = ao + Q.wo_npairs * XS_PAIR;                        // [16][16]
+
+    const int G = (int)P.gqa, D = P.D;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane >> 2, k = lane & 3;
+    const int wpt = (int)P.wpt;
+    const int slot = (int)udiv_by((unsigned)wave, P.wpt, P.wpt_inv), cs = wave - slot * wpt;
+    auto tile_of = [&](int u, int &sect, int &hq, int &j) {
+        j = u & 3;
+        hq = u >> 2;
+        sect = hq < G ? 0 : hq == G ? 1 : 2;
+        return (sect == 0 ? cl * G + hq : sect == 1 ? P.n_q_heads + cl : P.n_q_heads + P.n_kv_heads + cl) * 4 + j;
+    };
+#ifdef NL_TP_STAMPS
+    const int sslot = P.layer_tag != NL_TP_STAMPS ? -1 : (LIVE && cl == 0 && mem == 0) ? 0 : (LIVE && cl == 0 && mem == (int)P.gqa) ? 1
+                      : (LIVE && cl == P.n_kv_heads - 1 && mem == P.members - 1) ? 2 : blockIdx.x == 7 ? 3 : -1;
+#endif
+    TP_STAMP(sslot, 0);
+
+    // ---- every load of the role.  The forward counter and the position come through the scalar cache (written by earlier
+    //      launches): a vector load of either would put a memory round trip in front of the weight requests ----
+    const int pos = sload_i32(P.ctl + CTL_POS);
+    const long long soff = P.single_stream ? 0 : (long long)sload_i32(P.ctl + CTL_STREAM) * P.kv_stream_stride;
+    const unsigned tag = ((unsigned)sload_i32(reinterpret_cast<const int *>(P.tick)) << 8) | P.layer_tag;
+    const unsigned e_tag = Q.seam.n ? ((unsigned)sload_i32(reinterpret_cast<const int *>(Q.seam.epoch)) << 8) | Q.seam.seam : 0u;
+    const int ngroups = (P.npairs + KL - 1) / KL;
+    float4 xv[NF], gv[NF];
+    uint4 cw[NF][CPP];
+    uint2 sw[NF];
+    bool lv[NF], xin[NF];
+    if (LIVE) {
+        int w_sect, w_hq, w_j;
+        const long long tp0 = (long long)tile_of(mem * P.tpm + slot, w_sect, w_hq, w_j) * P.npairs;
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            const int g = cs + f * wpt, gg = min(g, ngroups - 1);
+            const int gs = min(KL, P.npairs - gg * KL);
+            lv[f] = g < ngroups && k < gs;
+            const int xcol = gg * (KL * PAIR) + lane * 4;
+            xin[f] = xcol < D;
+            xv[f] = ld_off<float4>(P.x, (unsigned)(xin[f] ? xcol : 0) * 4u);
+            gv[f] = ld_off<float4>(P.normw, (unsigned)(xin[f] ? xcol : 0) * 4u);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            const int g = cs + f * wpt, gg = min(g, ngroups - 1);
+            const int gs = min(KL, P.npairs - gg * KL);
+            load_pair<WT>(P.qkv_q, P.qkv_s, tp0, gg, gs, r, min(k, gs - 1), cw[f], sw[f]);
+        }
+    }
+    // epilogue inputs of the projection rows (threads 0 .. tpm * 16 - 1 use them; every thread requests a clamped copy)
+    const int e_slot = min(tid >> 4, P.tpm - 1), e_rr = tid & 15;
+    int e_sect = 0, e_hq = 0, e_j = 0;
+    const bool e_act = LIVE && tid < P.tpm * TR;
+    if (LIVE) tile_of(mem * P.tpm + e_slot, e_sect, e_hq, e_j);
+    const int e_i = e_j * 8 + (e_rr & 7), e_e = e_i + (e_rr >> 3) * (HD / 2);
+    float e_cos = 0.f, e_sin = 0.f, e_b = 0.f, e_bp = 0.f, e_bo = 0.f;
+    if (LIVE) {
+        e_cos = P.rope_cos[pos * (HD / 2) + e_i];
+        e_sin = P.rope_sin[pos * (HD / 2) + e_i];
+    }
+    if (LIVE && P.bias_q) {   // (optional tensors, last: a pointer test in front of a load costs the loads after it their exact wait)
+        const float *b = e_sect == 0 ? P.bias_q + (cl * G + e_hq) * HD : e_sect == 1 ? P.bias_k + cl * HD : P.bias_v + cl * HD;
+        e_b = b[e_e];
+        e_bp = b[e_e ^ (HD / 2)];
+    }
+    // ---- what the SECOND half of the launch reads -- this wavefront's share of WO: (tile, 256-column group) of the rows the
+    //      BLOCK owns (clamped: a wavefront or block without a share repeats a neighbour's request and masks the result), the
+    //      residual rows, the head's cache rows -- is requested by a LIVE block only after its projection dots: a wavefront
+    //      issues in order and the compute unit ingests ~11 B/clk, so requested at entry these bytes delay the projection
+    //      tile (the runner block's barrier came 1 us after its neighbours') ----
+    const int ngw = 1 << Q.wo_gshift, tpw = Q.wo_tpw;
+    const int wslot = wave >> Q.wo_gshift, wgrp = wave & (ngw - 1);
+    const int wtile = (int)blockIdx.x * tpw + wslot;
+    const bool wg_has_wo = (int)blockIdx.x * tpw < Q.wo_ntiles;
+    const int wo_ngroups = (Q.wo_npairs + KL - 1) / KL;
+    const int wgg = min(wgrp, wo_ngroups - 1), wgs = min(KL, Q.wo_npairs - wgg * KL);
+    const bool wlv = wslot < tpw && wtile < Q.wo_ntiles && wgrp < wo_ngroups && k < wgs;
+    const int w_rowt = tid >> 4, w_rr = tid & 15;            // tail: thread = (tile slot, row) of the block's WO rows
+    const int w_row = ((int)blockIdx.x * tpw + w_rowt) * TR + w_rr;
+    const bool w_act = tid < tpw * TR && (int)blockIdx.x * tpw + w_rowt < Q.wo_ntiles && w_row < D;
+    uint4 wc[CPP];
+    uint2 wsc;
+    float e_resid = 0.f;
+    const int kr = lane >> 2, kq = lane & 3, vg = lane >> 4, vc = lane & 15;
+    float4 kreg[NV], vreg[NV], kregn[NV];
+    const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + (long long)cl * P.seq_len * HD);
+    const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + (long long)cl * P.seq_len * HD);
+    auto second_half_loads = [&]() {
+        load_pair<WT>(Q.wo_q, Q.wo_s, (long long)min(wtile, Q.wo_ntiles - 1) * Q.wo_npairs, wgg, wgs, r, min(k, wgs - 1), wc, wsc);
+        e_resid = Q.x[min(w_row, D - 1)];
+        // the cache rows of this kv head, positions 0 .. min(pos, 127) (rows beyond pos repeat row pos: the same cache lines;
+        // the row AT pos is produced by this launch and replaced from LDS below).  Eight cache wavefronts x 16 consecutive
+        // positions of a pass: K as 16 of the row's 64 dims per lane (a score = 16 in-lane FMAs + two quad adds), V as float4
+        // columns of four rows per lane -- nl_block.h's attention phase.
+        if (RUNNER && wave < 8) {
+            const int lim = min(min(ATT_CH, P.seq_len), pos + 1);
+            const unsigned krow = (unsigned)min(wave * 16 + kr, lim - 1) * R4 + (unsigned)kq;
+#pragma unroll
+            for (int kk = 0; kk < NV; kk++) {
+                kreg[kk] = ld_off<float4>(K4, (krow + 4 * kk) * 16u);       // float4 kq + 4 kk of the row: a quad reads 64 contiguous bytes per instruction
+                vreg[kk] = ld_off<float4>(V4, (unsigned)(min(wave * 16 + vg + 4 * kk, lim - 1) * R4 + vc) * 16u);
+            }
+        }
+        if (Q.bias_out) e_bo = Q.bias_out[min(w_row, D - 1)];
+    };
+    if (!LIVE) second_half_loads();
+    __builtin_amdgcn_sched_barrier(0);      // (every request above leaves before anything below consumes one)
+    TP_STAMP(sslot, 1);
+
+    if (LIVE) {
+        // ---- RMSNorm scaling (go/quant.go:597-607) into wave-private LDS, dot products of this wavefront's column groups.  (An
+        //      early barrier for the sum of squares was measured and removed: in a fresh launch x takes as long to arrive as
+        //      the weights -- ~2 us for the first fetch of every compute unit at once -- so it only serialised.) ----
+        float *xw = xs + wave * XS_WAVE;
+        double ss = 0.0;
+        float acc = 0.f;
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            float4 xa = xin[f] ? xv[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (slot == 0 && cs + f * wpt < ngroups) {   // the wavefronts of tile slot 0 see every column exactly once
+                ss = fma((double)xa.x, (double)xa.x, ss); ss = fma((double)xa.y, (double)xa.y, ss);
+                ss = fma((double)xa.z, (double)xa.z, ss); ss = fma((double)xa.w, (double)xa.w, ss);
+            }
+            xa.x *= gv[f].x; xa.y *= gv[f].y; xa.z *= gv[f].z; xa.w *= gv[f].w;
+            *reinterpret_cast<float4 *>(xw + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
+            __builtin_amdgcn_wave_barrier();
+            const float a1 = PairDot<WT>::run(cw[f], sw[f], xw + k * XS_PAIR, acc);
+            acc = lv[f] ? a1 : acc;
+            __builtin_amdgcn_wave_barrier();
+        }
+        second_half_loads();
+        __builtin_amdgcn_sched_barrier(0);
+        acc = quad_sum(acc);
+        if (k == 0) red[wave * TR + r] = acc;
+        ss = wave_sum_f64(ss);
+        if (slot == 0 && lane == 0) dred[cs] = ss;
+        TP_STAMP(sslot, 2);
+        __syncthreads();
+        TP_STAMP(sslot, 3);
+        float inv = 0.f;
+        if (e_act) {
+            double tot = 0.0;
+            for (int w = 0; w < wpt; w++) tot += dred[w];
+            inv = (float)(1.0 / sqrt(tot / (double)D + (double)P.eps));
+        }
+
+        // ---- scale, bias, RoPE (go/model.go:449-477); publish this workgroup's tiles to the cluster, tile order ----
+        if (wave == 0) {
+            float outv = 0.f;
+            if (e_act) {
+                const float *rt = red + e_slot * wpt * TR;
+                float dotv = 0.f, dotp = 0.f;
+                for (int w = 0; w < wpt; w++) { dotv += rt[w * TR + e_rr]; dotp += rt[w * TR + (e_rr ^ 8)]; }   // fixed order
+                const float v = dotv * inv + e_b, partner = dotp * inv + e_bp;
+                outv = v;
+                if (e_sect < 2) {
+                    const float x0 = (e_rr < 8) ? v : partner, x1 = (e_rr < 8) ? partner : v;
+                    if (!P.rope_conj) outv = (e_rr < 8) ? (x0 * e_cos - x1 * e_sin) : (x0 * e_sin + x1 * e_cos);
+                    else outv = (e_rr < 8) ? (x0 * e_cos + x1 * e_sin) : (-x0 * e_sin + x1 * e_cos);
+                }
+            }
+            // the block's tiles mem * tpm .. are consecutive tiles of the group (q heads, then k, then v: four tiles each)
+            gran16_publish(Q.xq + ((size_t)cl * (G + 2) * 4 + (size_t)mem * P.tpm) * GPT, P.tpm, tag, outv, lane);
+        }
+        TP_STAMP(sslot, 4);
+    }
+    if (!RUNNER && !wg_has_wo) return;
+
+    if (RUNNER) {
+        // ---- the attention of query head cl * G + mem (go/model.go:557-587): gather the head's q and the group's k | v ----
+        const int h = cl * G + mem;
+        if (tid < 128) {     // 12 tiles x 6 granules on 72 threads (two wavefronts)
+            const bool dead = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            const int gi = min(tid, 12 * GPT - 1), t12 = gi / GPT, j = gi - t12 * GPT;
+            const int sect = t12 >> 2, tj = t12 & 3, hq = sect == 0 ? mem : G + sect - 1;
+            const u32x4 g = gran16_wait(Q.xq + ((size_t)cl * (G + 2) * 4 + hq * 4 + tj) * GPT + j, 0, 1, tag, P.status, P.host_status, P.spin_limit, 8u, dead);
+            if (tid < 12 * GPT) {
+                const unsigned vals[3] = {g.y, g.z, g.w};
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const int rr = 3 * j + c;       // row of the tile: rows 0-7 hold element tj * 8 + rr, rows 8-15 element 32 + tj * 8 + rr - 8
+                    if (rr < 16) qs[sect * 64 + tj * 8 + (rr & 7) + (rr >> 3) * (HD / 2)] = __uint_as_float(vals[c]);   // qs | kcur | vcur are contiguous
+                }
+            }
+        }
+        __syncthreads();
+        TP_STAMP(sslot, 5);
+        if (P.qk_norm) {   // RMSNormBare per head on q and k after RoPE, go/model.go:542-549
+            if (wave < 2) {
+                float *vec = wave == 0 ? qs : kcur;
+                const float val = vec[lane];
+                const double s2 = wave_sum_f64((double)val * (double)val);
+                const float inv = (float)(1.0 / sqrt(s2 / (double)HD + (double)P.eps));
+                vec[lane] = val * inv;
+            }
+            __syncthreads();
+        }
+        if (mem == 0 && tid < 128)   // KV store go/model.go:552-554, once per kv head
+            (tid < 64 ? P.kcache : P.vcache)[soff + ((long long)cl * P.seq_len + pos) * HD + (tid & 63)] = kcur[tid];
+
+        // ---- positions 0..pos, 128 per pass; every cache wavefront reduces its 16 positions to ONE (max, sum, sum p*v)
+        //      partial in registers, eight partials per pass meet in LDS behind one barrier (nl_block.h) ----
+        const int nch = min(pos / ATT_CH + 1, TP_NCH_MAX);
+        for (int ch = 0; ch < nch; ch++) {
+            const int t0 = ch * ATT_CH, n = min(ATT_CH, pos + 1 - t0);
+            if (wave < 8) {
+                if (ch > 0) {
+#pragma unroll
+                    for (int kk = 0; kk < NV; kk++) {
+                        kreg[kk] = kregn[kk];
+                        vreg[kk] = V4[(long long)(t0 + min(wave * 16 + vg + 4 * kk, n - 1)) * R4 + vc];
+                    }
+                }
+                if (ch + 1 < nch) {
+                    const int n1 = min(ATT_CH, pos + 1 - t0 - ATT_CH);
+#pragma unroll
+                    for (int kk = 0; kk < NV; kk++) kregn[kk] = K4[(long long)(t0 + ATT_CH + min(wave * 16 + kr, n1 - 1)) * R4 + kq + 4 * kk];
+                }
+                const int krow = wave * 16 + kr;
+                const bool kcurrow = t0 + krow == pos;   // the row this launch produced: not in memory yet for this workgroup
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < NV; kk++) {
+                    const float4 q4 = *reinterpret_cast<const float4 *>(qs + (kq + 4 * kk) * 4);
+                    const float4 kc4 = *reinterpret_cast<const float4 *>(kcur + (kq + 4 * kk) * 4);
+                    const float4 k4 = kcurrow ? kc4 : kreg[kk];
+                    d0 = fmaf(q4.x, k4.x, d0); d1 = fmaf(q4.y, k4.y, d1); d2 = fmaf(q4.z, k4.z, d2); d3 = fmaf(q4.w, k4.w, d3);
+                }
+                const float sv = krow < n ? quad_sum((d0 + d1) + (d2 + d3)) * P.scale : -INFINITY;
+                const float mw = wave_max_f32(sv);
+                const float p = krow < n ? exp_f64_as_f32(sv - (mw == -INFINITY ? 0.f : mw)) : 0.f;     // go/quant.go:619
+                const float lw = wave_sum_f32(kq == 0 ? p : 0.f);
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 vc4 = *reinterpret_cast<const float4 *>(vcur + vc * 4);
+#pragma unroll
+                for (int kk = 0; kk < NV; kk++) {
+                    const float pw = __shfl(p, (vg + 4 * kk) * 4);
+                    const bool vcurrow = t0 + wave * 16 + vg + 4 * kk == pos;
+                    const float4 v4 = vcurrow ? vc4 : vreg[kk];       // (a masked row's V may be stale but is finite, and its p is 0)
+                    o.x = fmaf(pw, v4.x, o.x); o.y = fmaf(pw, v4.y, o.y); o.z = fmaf(pw, v4.z, o.z); o.w = fmaf(pw, v4.w, o.w);
+                }
+                o.x += __shfl_xor(o.x, 16); o.y += __shfl_xor(o.y, 16); o.z += __shfl_xor(o.z, 16); o.w += __shfl_xor(o.w, 16);
+                o.x += __shfl_xor(o.x, 32); o.y += __shfl_xor(o.y, 32); o.z += __shfl_xor(o.z, 32); o.w += __shfl_xor(o.w, 32);
+                if (lane < 16) *reinterpret_cast<float4 *>(wpart + wave * 68 + 4 + vc * 4) = o;
+                if (lane == 0) { wpart[wave * 68] = mw; wpart[wave * 68 + 1] = lw; }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                // the eight partials of the pass merged like position splits (fixed order); the weights f32(exp(f64(m_w - M)))
+                const float mw = lane < 8 ? wpart[min(lane, 7) * 68] : -INFINITY;
+                const float Mx = wave_max_f32(mw);
+                const float wgt = (lane < 8 && mw != -INFINITY) ? exp_f64_as_f32(mw - Mx) : 0.f;
+                const float L = wave_sum_f32(lane < 8 ? wgt * wpart[min(lane, 7) * 68 + 1] : 0.f);
+                float ov = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; w++) ov = fmaf(__shfl(wgt, w), wpart[w * 68 + 4 + lane], ov);
+                chunk[ch * 66 + 2 + lane] = ov;
+                if (lane == 0) { chunk[ch * 66] = Mx; chunk[ch * 66 + 1] = L; }
+            }
+            if (ch + 1 < nch) __syncthreads();   // wpart is rewritten by the next pass
+        }
+        TP_STAMP(sslot, 6);
+        // merge the passes as the WO prologue of the general plan does (load_x4<PRO_ATTN>); publish the head's output
+        if (wave == 0) {
+            float outv;
+            if (nch == 1) outv = chunk[2 + lane] * (1.0f / chunk[1]);
+            else {
+                float Mx = chunk[0];
+                for (int c = 1; c < nch; c++) Mx = fmaxf(Mx, chunk[c * 66]);
+                float v = 0.f, L = 0.f;
+                for (int c = 0; c < nch; c++) {
+                    const float w = __expf(chunk[c * 66] - Mx);
+                    L += w * chunk[c * 66 + 1];
+                    v += w * chunk[c * 66 + 2 + lane];
+                }
+                outv = v * (1.0f / L);
+            }
+            gran16_publish(Q.xo + (size_t)h * 4 * GPT, 4, tag, outv, lane);
+        }
+        TP_STAMP(sslot, 7);
+        if (!wg_has_wo) return;
+    }
+
+    // ---- WO (go/model.go:590-594): gather every local head's output, this block's rows of the column slice ----
+    tp_gather16<1, false, true>(Q.xo, Q.xo, Q.n_heads_local * 4, tag, ao, ao, Q.n_heads_local * HD, P.status, P.host_status, P.spin_limit, 32u);
+    __syncthreads();
+    TP_STAMP(sslot, 8);
+    if (wslot < tpw) {
+        const float a1 = PairDot<WT>::run(wc, wsc, ao + min(wgg * KL + k, Q.wo_npairs - 1) * XS_PAIR, 0.f);
+        float a = wlv ? a1 : 0.f;
+        a = quad_sum(a);
+        if (k == 0) red2[wave * TR + r] = a;
+    }
+    __syncthreads();
+    TP_STAMP(sslot, 9);
+    if (w_act) {
+        float v = 0.f;
+        for (int g = 0; g < ngw; g++) v += red2[(w_rowt * ngw + g) * TR + w_rr];   // fixed order
+        v += e_bo;
+        tp_allreduce_row(Q.seam, e_tag, w_row, v, e_resid, Q.x);
+    }
+    TP_STAMP(sslot, 10);
+}
+
+template <int WT, int NF>
+__global__ void __launch_bounds__(TP_THREADS) tp_attn_kernel(TpAttnParams Q) {
+    const GroupParams &P = Q.G;
+    NL_KARGS8(P.qkv_q, P.qkv_s, P.x, P.normw, P.rope_cos, P.rope_sin, P.kcache, P.vcache);
+    NL_KARGS8(P.ctl, P.bias_q, Q.wo_q, Q.wo_s, Q.xq, P.tick, P.status, P.host_status);
+    NL_KARGS8(P.D, P.npairs, P.n_q_heads, P.n_kv_heads, P.seq_len, P.single_stream, P.tpm, P.members);
+    NL_KARGS8(P.eps, P.scale, P.kv_stream_stride, Q.wo_npairs, P.layer_tag, P.rope_conj, P.qk_norm, P.bias_k);
+    NL_KARGS8(P.spin_limit, P.gqa, Q.wo_ntiles, Q.wo_gshift, Q.xo, Q.x, Q.bias_out, Q.n_heads_local);
+    NL_KARGS4(Q.seam.slots, Q.seam.epoch, Q.seam.status, Q.seam.n);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = P.members;
+    const int b8 = (int)(blockIdx.x >> 3);
+    const int cl = (int)udiv_by(blockIdx.x, 8u * (unsigned)M, P.m8_inv) * 8 + (blockIdx.x & 7), mem = b8 - (int)udiv_by((unsigned)b8, (unsigned)M, P.m_inv) * M;
+    const bool live = cl < P.n_kv_heads;          // holds projection tiles; the other blocks only multiply WO rows (or exit)
+    TP_CENSUS(0, P.layer_tag, 0);
+    if (!live) {
+        if ((int)blockIdx.x * Q.wo_tpw >= Q.wo_ntiles) return;
+        tp_attn_body<WT, NF, false, false>(Q, smem, 0, 0);
+    } else if (mem < (int)P.gqa) tp_attn_body<WT, NF, true, true>(Q, smem, cl, mem);
+    else tp_attn_body<WT, NF, true, false>(Q, smem, cl, mem);
+    TP_CENSUS(0, P.layer_tag, 1);
+}
+
+// --------------------------------------------------------------------------------------------- feed-forward half ---
+
+struct TpFfnParams {
+    const uint8_t *gate_q, *up_q;     // this rank's gate / up rows, packed [I / 16 tiles][D]
+    const uint32_t *gate_s, *up_s;
+    const uint8_t *dn_q;              // this rank's W_down column slice, packed [D / 16 tiles][I columns]
+    const uint32_t *dn_s;
+    int D, I, npairs, gu_tiles;       // npairs of a gate / up row (D / 64); gu_tiles = ceil(I / 16) per matrix
+    int dn_npairs, dn_ntiles;
+    int pair;                         // 1: a producer holds gate tile t AND up tile t and publishes h; 0: one tile, publishes g or u
+    int n_prod;                       // blocks [0, n_prod) project a gate / up tile
+    int n_cons, ct_shift;             // blocks [0, n_cons) own 2^ct_shift W_down tiles each (ct * n_cons >= dn_ntiles)
+    const float *normw;
+    float eps;
+    float *x;                         // residual stream: RMSNorm input, rewritten by the row owners
+    u32x4 *hx;                        // granules: pair ? h[gu_tiles][6] : g[gu_tiles][6] | u[gu_tiles][6]
+    const unsigned *tick;
+    unsigned layer_tag;
+    unsigned *status, *host_status;
+    int spin_limit;
+    TpSeam seam;
+};
+
+__host__ __device__ constexpr size_t tp_ffn_lds_bytes(int dn_npairs) {
+    return sizeof(float) * (size_t)(16 * XS_WAVE + 16 * TR) + 16 * sizeof(double) + sizeof(float) * (size_t)(dn_npairs * XS_PAIR + dn_npairs * PAIR);
+}
+
+// NF: 256-column groups of a gate / up row per producer wavefront; NGC: groups of a W_down row per wavefront (16 wavefronts
+// share the block's one tile); NR: granules of h gathered per thread (6 * gu_tiles <= NR * 1024).  PROD: the block projects a
+// gate / up tile first -- each role straight-line code, every load unconditional (see tp_attn_body).
+template <int WT, int NF, int NGC, int NR, bool PROD>
+__device__ __forceinline__ void tp_ffn_body(const TpFfnParams &P, char *smem) {
+    constexpr int CPP = WTraits<WT>::CPP, NW = TP_THREADS / 64;
+    double *dred = reinterpret_cast<double *>(smem);                 // [16]
+    float *xs = reinterpret_cast<float *>(dred + 16);                // [16][XS_WAVE]
+    float *red = xs + NW * XS_WAVE;                                  // [16][16]
+    float *hs = red + NW * TR;                                       // [dn_npairs][XS_PAIR]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane >> 2, k = lane & 3, D = P.D;
+    const int b = (int)blockIdx.x;
+    const bool is_cons = b < P.n_cons;
+#ifdef NL_TP_STAMPS
+    const int sslot = P.layer_tag != NL_TP_STAMPS ? -1 : b == 0 ? 4 : b == P.n_prod - 1 ? 5 : b == P.n_cons / 2 ? 6 : b == P.n_cons - 1 ? 7 : -1;
+#endif
+    TP_STAMP(sslot, 0);
+    const unsigned tag = ((unsigned)sload_i32(reinterpret_cast<const int *>(P.tick)) << 8) | P.layer_tag;   // (scalar cache: no vector wait before the weight requests)
+    const unsigned e_tag = P.seam.n ? ((unsigned)sload_i32(reinterpret_cast<const int *>(P.seam.epoch)) << 8) | P.seam.seam : 0u;
+
+    // ---- producer part: one gate or up tile (16 wavefronts), or gate tile t + up tile t (8 wavefronts each) ----
+    const int wpt = P.pair ? NW / 2 : NW;
+    const int wsel = P.pair ? wave >> 3 : 0, cs = P.pair ? wave & 7 : wave;
+    const int msel = P.pair ? wsel : (b >= P.gu_tiles ? 1 : 0);
+    const int ptile = P.pair ? b : b - msel * P.gu_tiles;
+    const int ngroups = (P.npairs + KL - 1) / KL;
+    float4 xv[NF], gv[NF];
+    uint4 cw[NF][CPP];
+    uint2 sw[NF];
+    bool lv[NF], xin[NF];
+    if (PROD) {
+        const uint8_t *const Wq = msel ? P.up_q : P.gate_q;
+        const uint32_t *const Ws = msel ? P.up_s : P.gate_s;
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            const int g = cs + f * wpt, gg = min(g, ngroups - 1);
+            const int gs = min(KL, P.npairs - gg * KL);
+            lv[f] = g < ngroups && k < gs;
+            const int xcol = gg * (KL * PAIR) + lane * 4;
+            xin[f] = xcol < D;
+            xv[f] = ld_off<float4>(P.x, (unsigned)(xin[f] ? xcol : 0) * 4u);
+            gv[f] = ld_off<float4>(P.normw, (unsigned)(xin[f] ? xcol : 0) * 4u);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            const int g = cs + f * wpt, gg = min(g, ngroups - 1);
+            const int gs = min(KL, P.npairs - gg * KL);
+            load_pair<WT>(Wq, Ws, (long long)ptile * P.npairs, gg, gs, r, min(k, gs - 1), cw[f], sw[f]);
+        }
+    }
+    // ---- consumer part: W_down tiles b * ct .. (clamped), 16 / ct wavefronts per tile share its 256-column groups.  A block
+    //      that projects first requests them after its dot products (see tp_attn_body), the others at entry ----
+    const int dgroups = (P.dn_npairs + KL - 1) / KL;
+    const int ct = 1 << P.ct_shift, wptc = NW >> P.ct_shift;
+    const int dslot = wave >> (4 - P.ct_shift), dcs = wave & (wptc - 1);
+    const int dtile = b * ct + dslot;
+    uint4 dw[NGC][CPP];
+    uint2 dsw[NGC];
+    bool dlv[NGC];
+    int gsel[NGC];
+    const int o_slot = tid >> 4, o_rr = tid & 15;
+    const int o_row = (b * ct + o_slot) * TR + o_rr;
+    const bool o_act = is_cons && tid < ct * TR && b * ct + o_slot < P.dn_ntiles && o_row < D;
+    float e_resid = 0.f;
+    auto second_half_loads = [&]() {
+#pragma unroll
+        for (int j = 0; j < NGC; j++) {
+            const int g = dcs + j * wptc, gg = min(g, dgroups - 1);
+            const int gs = min(KL, P.dn_npairs - gg * KL);
+            dlv[j] = is_cons && dtile < P.dn_ntiles && g < dgroups && k < gs;
+            gsel[j] = min(gg * KL + k, P.dn_npairs - 1);
+            load_pair<WT>(P.dn_q, P.dn_s, (long long)min(dtile, P.dn_ntiles - 1) * P.dn_npairs, gg, gs, r, min(k, gs - 1), dw[j], dsw[j]);
+        }
+        e_resid = P.x[min(o_row, D - 1)];
+    };
+    if (!PROD) second_half_loads();
+    if (PROD) {
+        // RMSNorm scaling into wave-private LDS, dot products of this wavefront's column groups (one barrier: see tp_attn_body)
+        float *xw = xs + wave * XS_WAVE;
+        double ss = 0.0;
+        float acc = 0.f;
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            float4 xa = xin[f] ? xv[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (wsel == 0 && cs + f * wpt < ngroups) {   // the wavefronts of the first tile see every column exactly once
+                ss = fma((double)xa.x, (double)xa.x, ss); ss = fma((double)xa.y, (double)xa.y, ss);
+                ss = fma((double)xa.z, (double)xa.z, ss); ss = fma((double)xa.w, (double)xa.w, ss);
+            }
+            xa.x *= gv[f].x; xa.y *= gv[f].y; xa.z *= gv[f].z; xa.w *= gv[f].w;
+            *reinterpret_cast<float4 *>(xw + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
+            __builtin_amdgcn_wave_barrier();
+            const float a1 = PairDot<WT>::run(cw[f], sw[f], xw + k * XS_PAIR, acc);
+            acc = lv[f] ? a1 : acc;
+            __builtin_amdgcn_wave_barrier();
+        }
+        second_half_loads();
+        __builtin_amdgcn_sched_barrier(0);
+        acc = quad_sum(acc);
+        if (k == 0) red[wave * TR + r] = acc;
+        ss = wave_sum_f64(ss);
+        if (wsel == 0 && lane == 0) dred[cs] = ss;
+        TP_STAMP(sslot, 2);
+        __syncthreads();
+        TP_STAMP(sslot, 3);
+        float inv = 0.f;
+        if (tid < TR) {
+            double tot = 0.0;
+            for (int w = 0; w < wpt; w++) tot += dred[w];
+            inv = (float)(1.0 / sqrt(tot / (double)D + (double)P.eps));
+        }
+        if (wave == 0) {
+            float outv = 0.f;
+            if (lane < TR) {
+                float a = 0.f, bsum = 0.f;
+                for (int w = 0; w < wpt; w++) { a += red[w * TR + lane]; if (P.pair) bsum += red[(wpt + w) * TR + lane]; }   // fixed order
+                outv = a * inv;
+                if (P.pair) {   // SiLU go/quant.go:629-631, * up go/model.go:604-606
+                    const float g = outv, u = bsum * inv;
+                    outv = (g / (1.0f + exp_f64_as_f32(-g))) * u;
+                }
+            }
+            gran16_publish(P.hx + ((size_t)(P.pair ? 0 : msel * P.gu_tiles) + ptile) * GPT, 1, tag, outv, lane);
+        }
+        TP_STAMP(sslot, 4);
+    }
+    if (!is_cons) return;
+
+    // ---- gather h (pair) or g | u (SiLU(g) * u applied here) into LDS as padded pairs ----
+    for (int i = P.I + tid; i < P.dn_npairs * PAIR; i += TP_THREADS) hs[(i >> 6) * XS_PAIR + (i & 63)] = 0.f;   // ragged last pair
+    // (a block that has just published goes straight to the sweep: the weight streams it could disturb are over by then;
+    //  a block without a producer part is early and spins on a few probe granules first)
+    float *us = hs + P.dn_npairs * XS_PAIR;     // [I] raw up values (split mode)
+    if (P.pair) tp_gather16<NR, false, !PROD>(P.hx, P.hx, P.gu_tiles, tag, hs, us, P.I, P.status, P.host_status, P.spin_limit, 64u);
+    else tp_gather16<NR, true, !PROD>(P.hx, P.hx + (size_t)P.gu_tiles * GPT, P.gu_tiles, tag, hs, us, P.I, P.status, P.host_status, P.spin_limit, 64u);
+    __syncthreads();
+    TP_STAMP(sslot, 5);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < NGC; j++) {
+        const float a1 = PairDot<WT>::run(dw[j], dsw[j], hs + gsel[j] * XS_PAIR, acc);
+        acc = dlv[j] ? a1 : acc;
+    }
+    acc = quad_sum(acc);
+    if (k == 0) red[wave * TR + r] = acc;
+    __syncthreads();
+    TP_STAMP(sslot, 6);
+    if (o_act) {
+        float v = 0.f;
+        const int nwg = min(wptc, dgroups);
+        for (int w = 0; w < nwg; w++) v += red[(o_slot * wptc + w) * TR + o_rr];   // fixed order
+        tp_allreduce_row(P.seam, e_tag, o_row, v, e_resid, P.x);
+    }
+    TP_STAMP(sslot, 7);
+}
+
+template <int WT, int NF, int NGC, int NR>
+__global__ void __launch_bounds__(TP_THREADS) tp_ffn_kernel(TpFfnParams P) {
+    NL_KARGS8(P.gate_q, P.up_q, P.gate_s, P.up_s, P.dn_q, P.dn_s, P.x, P.normw);
+    NL_KARGS8(P.D, P.I, P.npairs, P.gu_tiles, P.dn_npairs, P.dn_ntiles, P.pair, P.n_prod);
+    NL_KARGS8(P.eps, P.hx, P.tick, P.layer_tag, P.status, P.host_status, P.spin_limit, P.seam.n);
+    NL_KARGS4(P.seam.slots, P.seam.epoch, P.seam.status, P.seam.seam);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    TP_CENSUS(1, P.layer_tag, 0);
+    if ((int)blockIdx.x < P.n_prod) tp_ffn_body<WT, NF, NGC, NR, true>(P, smem);
+    else if ((int)blockIdx.x < P.n_cons) tp_ffn_body<WT, NF, NGC, NR, false>(P, smem);
+    TP_CENSUS(1, P.layer_tag, 1);
+}
+
+// x[i] += sum[i]: the in-process shard group's counterpart of the owner lanes' store (nl_group_forward)
+__global__ void tp_add_kernel(float *x, const float *sum, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = x[i] + sum[i];
+}
+
+}  // namespace nl

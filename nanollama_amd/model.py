@@ -161,6 +161,12 @@ class LlamaModel:
         _lib.check(self._h, _lib.lib().nl_p2p_info(self._h, C.byref(on), C.byref(unc)))
         return {"push_allreduce": bool(on.value), "uncached_receive_area": bool(unc.value)}
 
+    def plan_info(self):
+        """nl_plan_info: which launch plans the handle holds (fused mode, its position limit, launches per token)."""
+        v = [C.c_int(0) for _ in range(4)]
+        _lib.check(self._h, _lib.lib().nl_plan_info(self._h, *[C.byref(x) for x in v]))
+        return {"fused_mode": v[0].value, "fused_max_pos": v[1].value, "launches_fused": v[2].value, "launches_general": v[3].value}
+
     def last_error(self) -> str:
         """nl_last_error: the message of the last failed call -- or the one-time note of a call that succeeded after
         retiring the fused launch plan (a cluster exchange timed out and the step was redone on the general plan)."""
@@ -257,9 +263,11 @@ class LocalTPGroup:
     arithmetic as the one-process-per-GPU RCCL path, with the all-reduce / all-gather seams done
     in-process so it can be checked on a single GPU."""
 
-    def __init__(self, gguf: GGUFFile, n: int, device: int = 0):
-        self.shards = [load_llama_model(gguf, device=device, tp_rank=r, tp_size=n, flags=_lib.NL_FLAG_LOCAL_GROUP)
-                       for r in range(n)]
+    def __init__(self, gguf: GGUFFile, n: int, device: int = 0, fused: bool = False):
+        # fused: short contexts step the two-launches-per-layer plan of a push-group rank (nl_tp.h) where the shapes allow
+        # it; the group then adds the shards' partial vectors itself, in rank order
+        flags = _lib.NL_FLAG_LOCAL_GROUP | (_lib.NL_FLAG_GROUP_FUSED if fused else 0)
+        self.shards = [load_llama_model(gguf, device=device, tp_rank=r, tp_size=n, flags=flags) for r in range(n)]
         self.n = n
         self.logits = np.zeros(self.shards[0].config.vocab_size, dtype=np.float32)
 

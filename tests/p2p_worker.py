@@ -25,6 +25,9 @@ def main():
     dev = model.load_llama_model(g, device=rdv.local_rank, tp_rank=rdv.rank, tp_size=rdv.world,
                                  p2p_allgather=rdv.allgather_bytes)
     toks = synth.prompt_ids(n_tok, g.meta.vocab_size, seed=9)
+    want_mode = os.environ.get("NL_EXPECT_FUSED_MODE")
+    if want_mode is not None:
+        assert dev.plan_info()["fused_mode"] == int(want_mode), dev.plan_info()
     rdv.barrier()
     logits = []
     for pos, t in enumerate(toks):
@@ -43,6 +46,10 @@ def main():
         us = np.random.default_rng(5).random(n_samp, dtype=np.float32)
         sampled, _ = dev.sample_decode(5, n_samp, 0.8, 0.9, 50, 1.15, 16, us, [])
     rdv.barrier()
+    if os.environ.get("NL_EXPECT_RETIRED"):      # a fused-launch give-up on ANY rank retires the plan on EVERY rank
+        assert dev.plan_info()["fused_mode"] == 0, (rdv.rank, dev.plan_info())
+    elif want_mode is not None:                  # ... and otherwise the plan the test asked for is still the one in use
+        assert dev.plan_info()["fused_mode"] == int(want_mode), (rdv.rank, dev.plan_info(), dev.last_error())
     if rdv.rank == 0:
         np.savez(out, logits=np.stack(logits), ids=np.array(ids), again=np.array(again), pre=pre, toks=np.array(toks),
                  sampled=np.array(sampled, np.int32))

@@ -17,12 +17,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 LOGIT_TOL = 1e-4
 
 
-def run_ranks(n, path, out, n_tok, n_greedy, extra_env=None, timeout=150, one_device=True):
+def run_ranks(n, path, out, n_tok, n_greedy, extra_env=None, timeout=150, one_device=True, rank_env=None):
     port = 29000 + (os.getpid() * 11 + n * 37) % 2000
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), NL_P2P_TIMEOUT_MS="5000", **(extra_env or {}))
+        env.update((rank_env or {}).get(r, {}))
         if one_device:
             env["NL_BENCH_ONE_DEVICE"] = "1"
         else:
@@ -98,10 +99,56 @@ def test_push_allreduce_with_4_and_8_ranks(tmp_path, n, dim, heads, kv, interm):
     # the same ranks with the fused projection + attention launch (nl_group.h) in their plans: summation order
     # differs from the five-launch plan, so this one is held to the logit tolerance and to identical greedy ids
     out2 = str(tmp_path / "r0_fused.npz")
-    run_ranks(n, p, out2, n_tok=6, n_greedy=20, timeout=240)
+    run_ranks(n, p, out2, n_tok=6, n_greedy=20, timeout=240, extra_env={"NL_TP_FUSED": "0"})
     fused = np.load(out2)
     assert np.abs(fused["logits"] - got["logits"]).max() <= LOGIT_TOL * max(1.0, float(got["logits"].std()))
     assert fused["ids"].tobytes() == got["ids"].tobytes() and fused["ids"].tobytes() == fused["again"].tobytes()
+    grp.close()
+
+
+@pytest.mark.parametrize("n,dim,heads,kv,interm", [(2, 1024, 16, 4, 2048), (4, 512, 8, 4, 1024), (8, 512, 8, 8, 1024)])
+def test_two_launch_layer_ranks_match_the_in_process_group(tmp_path, n, dim, heads, kv, interm):
+    # a rank's layer as TWO launches (nl_tp.h, the default plan of a push group at short contexts): the in-process group
+    # steps the same kernels and adds the partial vectors in the same rank order -- bitwise equal.  (Shapes small enough that
+    # the n rank processes' resident workgroups fit the ONE GPU they share here: every block of these launches stays
+    # resident until its rows are done, and a rank whose exchange starves would -- correctly -- retire the plan.)
+    from nanollama_amd import model
+    shape = synth.ModelShape("p2p_tp_probe", 3, dim, heads, kv, 4096, seq_len=64, interm=interm)
+    p = str(tmp_path / "m.gguf")
+    synth.generate_gguf(p, shape, "q4_0", 59, mode="qrand")
+    g = gguf.load_gguf(p)
+    out = str(tmp_path / "r0_tp.npz")
+    run_ranks(n, p, out, n_tok=6, n_greedy=20, timeout=240, extra_env={"NL_QUIET": "1", "NL_P2P_SAMPLED": "20", "NL_EXPECT_FUSED_MODE": "3"})
+    tp = np.load(out)
+    grp = model.LocalTPGroup(g, n, fused=True)
+    assert grp.shards[0].plan_info()["fused_mode"] == 3
+    plain = model.LocalTPGroup(g, n)
+    for pos, t in enumerate(int(t) for t in tp["toks"]):
+        assert grp.forward(t, pos).tobytes() == tp["logits"][pos].tobytes(), f"pos {pos}: ranks != in-process group (two-launch plan)"
+        want = plain.forward(t, pos)
+        assert np.abs(tp["logits"][pos] - want).max() <= LOGIT_TOL * max(1.0, float(want.std()))
+    assert tp["ids"].tobytes() == tp["again"].tobytes()
+    assert len(tp["sampled"]) == 20
+    grp.close(); plain.close()
+
+
+def test_a_fused_exchange_timeout_on_one_rank_retires_the_plan_on_every_rank(tmp_path):
+    # a cluster exchange of a fused launch gives up on ONE rank only (NL_FUSED_SPIN_LIMIT=0 there).  The give-up
+    # travels with the argmax exchange of the same step, so BOTH ranks retire their fused plans and redo the call from a
+    # common forward counter: the logits are the five-launch plan's, bit for bit, and nothing hangs or desynchronises.
+    from nanollama_amd import model
+    shape = synth.ModelShape("p2p_fallback_probe", 3, 1024, 16, 4, 4096, seq_len=64, interm=2048)
+    p = str(tmp_path / "m.gguf")
+    synth.generate_gguf(p, shape, "q4_0", 57, mode="qrand")
+    out = str(tmp_path / "r0.npz")
+    run_ranks(2, p, out, n_tok=6, n_greedy=20, timeout=240, extra_env={"NL_QUIET": "1", "NL_EXPECT_FUSED_MODE": "3", "NL_EXPECT_RETIRED": "1"},
+              rank_env={1: {"NL_FUSED_SPIN_LIMIT": "0"}})
+    got = np.load(out)
+    g = gguf.load_gguf(p)
+    grp = model.LocalTPGroup(g, 2)                  # five-launch plan
+    for pos, t in enumerate(int(t) for t in got["toks"]):
+        assert grp.forward(t, pos).tobytes() == got["logits"][pos].tobytes(), f"pos {pos}"
+    assert got["ids"].tobytes() == got["again"].tobytes()
     grp.close()
 
 

@@ -422,6 +422,16 @@ def test_big_full_shape_matches_oracle(hip, orc, tmp_path):
             assert d <= LOGIT_TOL * max(1.0, float(wants[pos].std()))
             assert int(np.argmax(lg)) == int(orc.argmax(wants[pos]))
         grp.close()
+    for n in (4, 8):         # ... and a rank's layer as TWO launches (nl_tp.h: the plan of a push group at tp 4 / 8), full shape
+        grp = hip.LocalTPGroup(g, n, fused=True)
+        assert grp.shards[0].plan_info()["fused_mode"] == 3, grp.shards[0].plan_info()
+        for pos, t in enumerate(toks):
+            lg = grp.forward(t, pos)
+            d = float(np.abs(lg - wants[pos]).max())
+            print(f"big/q4_0 tp{n} two-launch layers pos {pos}: max|tp-oracle|={d:.2e}")
+            assert d <= LOGIT_TOL * max(1.0, float(wants[pos].std()))
+            assert int(np.argmax(lg)) == int(orc.argmax(wants[pos]))
+        grp.close()
 
 
 def test_nano_full_size_long_greedy_run_matches_oracle(hip, orc, tmp_path):

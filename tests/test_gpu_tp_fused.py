@@ -1,0 +1,120 @@
+"""GPU tests of the two-launches-per-layer tensor-parallel plan (nanollama_amd/csrc/nl_tp.h: tp_attn_kernel,
+tp_ffn_kernel).  The kernels are exercised three ways:
+
+  * as the shards of an IN-PROCESS group (LocalTPGroup(fused=True)): the same kernels, the group adds the partial
+    vectors itself -- against the CPU oracle (stated tolerance) and the five-launch group plan, at test shapes and at
+    the full 7.9B shape (tests/test_gpu_parity.py::test_big_full_shape_matches_oracle);
+  * as rank PROCESSES sharing the box's one GPU over the push all-reduce (tests/test_gpu_p2p.py) -- bitwise against the
+    in-process group (same kernels, same summation order);
+  * alone in loopback (bench.py --shard-of N) for timing.
+Reference lines: go/model.go:517-594 (attention half), :597-612 (feed-forward half).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from nanollama_amd import gguf, synth
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4
+
+SHAPES = {
+    # name: (shape, tp sizes)
+    "gqa4": (synth.ModelShape("tpf_gqa4", 3, 1024, 16, 4, 4096, seq_len=160, interm=2048), (2, 4)),
+    "mha8": (synth.ModelShape("tpf_mha8", 3, 512, 8, 8, 4096, seq_len=160, interm=1024), (2, 8)),
+    # interm = 43 blocks of 32 per rank at tp 2 (the 7.9B tier's 1376 rows per rank at tp 8): a ragged last pair and group
+    "ragged": (synth.ModelShape("tpf_ragged", 2, 1024, 16, 4, 4096, seq_len=160, interm=2752), (2,)),
+    "qknorm_conj_bias": (synth.ModelShape("tpf_var", 2, 1024, 16, 4, 4096, seq_len=160, interm=2048, qk_norm=True,
+                                          rope_conjugate=True, attn_bias=True), (4,)),
+    # wide enough that a producer wavefront holds two column groups in pair mode (D = 4096: 16 groups)
+    "wide": (synth.ModelShape("tpf_wide", 2, 4096, 64, 16, 2048, seq_len=160, interm=4096), (4,)),
+    # 16 kv groups of 2 heads per rank at tp 2: a projection workgroup holds two tiles, a wavefront two column groups
+    "two_tiles": (synth.ModelShape("tpf_two_tiles", 2, 4096, 64, 32, 2048, seq_len=160, interm=2048), (2,)),
+}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from nanollama_amd import _lib, model
+    if _lib.lib().nl_device_count() < 1:
+        pytest.fail("no HIP device visible: the GPU tests must run on the MI355X box")
+    return model
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.mark.parametrize("pair", ["auto", "pair", "split"])
+@pytest.mark.parametrize("name,wtype", [("gqa4", "q4_0"), ("gqa4", "q8_0"), ("mha8", "q4_0"), ("ragged", "q4_0"),
+                                        ("qknorm_conj_bias", "q8_0"), ("wide", "q4_0"), ("two_tiles", "q4_0")])
+def test_two_launch_layer_in_process_group_matches_oracle(hip, orc, tmp_path, monkeypatch, name, wtype, pair):
+    shape, sizes = SHAPES[name]
+    if pair != "auto" and name not in ("gqa4", "ragged", "wide"):
+        pytest.skip("producer geometry variants are covered on three shapes")
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, wtype, 71, mode="qrand")
+    g = gguf.load_gguf(str(p))
+    if pair != "auto":
+        monkeypatch.setenv("NL_TP_PAIR", "1" if pair == "pair" else "0")
+    ref = orc.OracleModel(g)
+    orc.set_threads(min(16, os.cpu_count() or 1))
+    toks = synth.prompt_ids(140, shape.vocab, seed=29)          # crosses the 128-position pass boundary inside the launch
+    wants = [ref.forward(t, pos).copy() for pos, t in enumerate(toks)]
+    orc.set_threads(1)
+    ref.close()
+    for n in sizes:
+        fused = hip.LocalTPGroup(g, n, fused=True)
+        info = fused.shards[0].plan_info()
+        assert info["fused_mode"] == 3, info
+        assert info["launches_fused"] == 2 * shape.n_layer + 3, info       # embed + 2 per layer + LM head + argmax
+        plain = hip.LocalTPGroup(g, n)
+        worst = gap = 0.0
+        for pos, t in enumerate(toks):
+            a = fused.forward(t, pos).copy()
+            b = plain.forward(t, pos)
+            worst = max(worst, float(np.abs(a - wants[pos]).max()) / max(1.0, float(wants[pos].std())))
+            gap = max(gap, float(np.abs(a - b).max()))
+            assert int(np.argmax(a)) == int(orc.argmax(wants[pos])) or float(np.sort(wants[pos])[-1] - np.sort(wants[pos])[-2]) < 1e-3
+        print(f"\ntwo-launch layer {name}/{wtype}/{pair} tp{n}: max|gpu-oracle|={worst:.2e}, max|fused-general|={gap:.2e}")
+        assert worst <= LOGIT_TOL
+        # replay from a reset: bit-identical (fixed reduction orders, no atomics on values)
+        again = hip.LocalTPGroup(g, n, fused=True)
+        for pos, t in enumerate(toks[:20]):
+            again.forward(t, pos)
+        for s in fused.shards:
+            s.reset()
+        for pos, t in enumerate(toks[:20]):
+            lg = fused.forward(t, pos)
+        assert lg.tobytes() == again.logits.tobytes()
+        assert not fused.shards[0].last_error()         # (the fused plan was never retired)
+        fused.close(); plain.close(); again.close()
+
+
+def test_group_exchange_timeout_falls_back_to_the_general_plan(hip, orc, tmp_path, monkeypatch):
+    # every cluster exchange of the fused launches gives up at once (NL_FUSED_SPIN_LIMIT=0): the group retires the plan
+    # in every shard, redoes the step on the five-launch plan and returns the general plan's logits, bit for bit
+    shape, _ = SHAPES["gqa4"]
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", 73, mode="qrand")
+    g = gguf.load_gguf(str(p))
+    plain = hip.LocalTPGroup(g, 4)
+    monkeypatch.setenv("NL_FUSED_SPIN_LIMIT", "0")
+    monkeypatch.setenv("NL_QUIET", "1")
+    fused = hip.LocalTPGroup(g, 4, fused=True)
+    assert fused.shards[0].plan_info()["fused_mode"] == 3
+    toks = synth.prompt_ids(6, shape.vocab, seed=31)
+    for pos, t in enumerate(toks):
+        a = fused.forward(t, pos).copy()
+        b = plain.forward(t, pos)
+        assert a.tobytes() == b.tobytes(), pos
+    assert fused.shards[0].plan_info()["fused_mode"] == 0        # retired
+    assert "timed out" in fused.shards[0].last_error()
+    fused.close(); plain.close()

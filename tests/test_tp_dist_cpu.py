@@ -49,6 +49,24 @@ def test_column_and_row_slices_reproduce_the_full_gemv(wtype, n):
         assert np.concatenate(parts).tobytes() == full.tobytes()
 
 
+def _free_port_pair(start):
+    """A port p such that p (the launcher's store) and p + 23 (nanollama_amd.dist's TCP star) can both be bound now."""
+    import socket
+    for p in range(start, start + 400):
+        ok = True
+        for q in (p, p + 23):
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            try:
+                s.bind(("127.0.0.1", q))
+            except OSError:
+                ok = False
+            finally:
+                s.close()
+        if ok:
+            return p
+    return start
+
+
 def test_big_tier_divides_for_1_2_4_8_gpus():
     b = synth.TIERS["big"]
     for n in (1, 2, 4, 8):
@@ -82,7 +100,7 @@ def test_world_size_2_rendezvous(tmp_path):
     """))
     out = None
     for attempt in range(3):  # a busy rendezvous port is the only expected flake
-        port = 29000 + (os.getpid() * 7 + attempt * 131) % 2000
+        port = _free_port_pair(29000 + (os.getpid() * 7 + attempt * 131) % 2000)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                "127.0.0.1", "--master-port", str(port), str(script)]
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
