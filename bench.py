@@ -143,17 +143,103 @@ def cpu_baseline(path, prompt, budget_s=20.0, min_tokens=1, max_tokens=SEGMENT):
         if best is None or dt < best:
             best, cores = dt, c
     oracle.set_threads(cores)
+    import numpy as np
+    first = int(nxt)
+    ids, margins = [], []
     n, t0 = 0, time.perf_counter()
     while n < max_tokens and (n < min_tokens or (time.perf_counter() - t0) < budget_s):   # timer after prefill, go/main.go:171
         m.forward(nxt, pos)
-        nxt = oracle.argmax(m.logits())
+        lg = m.logits()
+        nxt = oracle.argmax(lg)
+        top2 = np.partition(lg, -2)[-2:]
+        ids.append(int(nxt))
+        margins.append(float(top2[1] - top2[0]))
         pos += 1
         n += 1
     dt = time.perf_counter() - t0
     m.close()
     return {"value": round(n / dt, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": f"{n} greedy decode tokens after an {len(prompt)}-token prefill, same GGUF, "
-                      f"C restatement of go/quant.go+go/model.go with the Go row partition on {cores} threads (best of 1..64 on a {ncpu}-cpu host)"}
+                      f"C restatement of go/quant.go+go/model.go with the Go row partition on {cores} threads (BEST OF 1..64 threads on a {ncpu}-cpu host; "
+                      f"the Go engine itself would use runtime.NumCPU() workers)",
+            "_first": first, "_ids": ids, "_margins": margins}
+
+
+ID_MARGIN = 1e-3   # a greedy id may differ from the CPU engine's only where the CPU engine's own top-1 / top-2 logit gap is below this
+
+
+def ids_check(cpu, dev_first, dev_ids):
+    """the device's greedy ids against the ids the CPU baseline generated on the same file (the same
+    prompt, the same first token): equal one for one, up to a step where the CPU engine's own top-2 margin is < ID_MARGIN
+    (after such a step the two runs are different texts and the comparison stops)."""
+    ids, margins = cpu.pop("_ids"), cpu.pop("_margins")
+    first = cpu.pop("_first")
+    n = min(len(ids), len(dev_ids))
+    if first != dev_first:
+        return {"ids_match_cpu": False, "n": 0, "note": f"first token after the prompt differs: cpu {first}, device {dev_first}"}
+    for k in range(n):
+        if ids[k] != dev_ids[k]:
+            ok = margins[k] < ID_MARGIN
+            return {"ids_match_cpu": bool(ok), "n": k, "of": n,
+                    "note": f"step {k}: cpu {ids[k]} vs device {dev_ids[k]}, cpu top-2 margin {margins[k]:.2e} "
+                            f"({'inside' if ok else 'OUTSIDE'} the {ID_MARGIN} margin; comparison stops here)"}
+    return {"ids_match_cpu": True, "n": n, "of": n}
+
+
+_DROPIN = None
+
+
+def dropin_lib():
+    """integration/c/dropin_loop.c built with gcc next to the library (C99, links libnanollama_hip.so): the per-token loops an
+    unpatched Go host runs over the cgo shim, in compiled code."""
+    global _DROPIN
+    if _DROPIN is not None:
+        return _DROPIN or None
+    import ctypes as C
+    from nanollama_amd import _lib
+    out = os.path.join(os.environ.get("NL_BENCH_DIR", "/tmp"), "libnl_dropin.so")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    try:
+        subprocess.check_call(["gcc", "-std=c99", "-D_POSIX_C_SOURCE=199309L", "-O2", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "integration", "c", "dropin_loop.c"), "-o", out, "-L", libdir,
+                               "-l:" + os.path.basename(_lib.LIB_PATH), f"-Wl,-rpath,{libdir}"], stderr=subprocess.DEVNULL)
+        L = C.CDLL(out)
+        ip, fp = C.POINTER(C.c_int), C.POINTER(C.c_float)
+        L.nl_dropin_forward_loop.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, ip, C.POINTER(C.c_double)]
+        L.nl_dropin_forward_argmax_loop.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.POINTER(C.c_double)]
+        _DROPIN = L
+    except (OSError, subprocess.CalledProcessError) as exc:
+        print(f"[bench] drop-in loop library not built ({exc!r})", file=sys.stderr)
+        _DROPIN = False
+    return _DROPIN or None
+
+
+def dropin_rates(dev, first, pos0, n, chained_ids):
+    """tok/s of the per-token loops -- nl_forward + host argmax (what integration/go/model_hip.patch gives an
+    UNMODIFIED Engine.Generate, go/main.go:173-219) and nl_forward_argmax -- next to the chained nl_decode_greedy headline."""
+    import ctypes as C
+    import numpy as np
+    L = dropin_lib()
+    if L is None:
+        return {"error": "gcc or the drop-in loop source is missing"}
+    v = dev.config.vocab_size
+    logits = np.zeros(v, dtype=np.float32)
+    ids = (C.c_int * n)()
+    sec = C.c_double(0.0)
+    out = {"loop": "integration/c/dropin_loop.c (C99, gcc -O2), one call per token", "tokens": n}
+    for key, call in (("nl_forward_plus_host_argmax_tokens_per_s",
+                       lambda: L.nl_dropin_forward_loop(dev._h, 0, first, pos0, n, logits.ctypes.data_as(C.POINTER(C.c_float)), v, ids, C.byref(sec))),
+                      ("nl_forward_argmax_tokens_per_s",
+                       lambda: L.nl_dropin_forward_argmax_loop(dev._h, 0, first, pos0, n, ids, C.byref(sec)))):
+        best = None
+        for _ in range(3):
+            rc = call()
+            if rc != 0:
+                return {"error": f"{key}: status {rc}"}
+            best = sec.value if best is None else min(best, sec.value)
+        out[key] = round(n / best, 1)
+        out[key.replace("_tokens_per_s", "_ids_equal_chained")] = [int(ids[i]) for i in range(n)] == list(chained_ids[:n])
+    return out
 
 
 def measured_traffic(tier, wtype):
@@ -172,7 +258,7 @@ def measured_traffic(tier, wtype):
     return None, None
 
 
-def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, comm=None, keep=None, shard_of=None):
+def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, comm=None, keep=None, shard_of=None, dropin=False):
     """Load the tier's random-weight GGUF, run `warmup` + REPEATS x `steps` chained greedy decode steps, profile the
     launches.  tp=True: the ranks of rdv form one tensor-parallel engine (comm = "p2p" push all-reduce or "rccl");
     tp=False: every rank is an independent replica (no data-path collective).  Timing = max over ranks."""
@@ -213,7 +299,7 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
                 done += seg
             return ids
 
-        head_ids = dev.decode_greedy(first, pos0, 32)
+        head_ids = dev.decode_greedy(first, pos0, min(SEGMENT, shape.seq_len - pos0))
         run_steps(warmup)
         walls, evs, ids = [], [], []
         for _ in range(REPEATS):
@@ -270,7 +356,8 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
             "ms_per_step_min": min(walls) / steps, "ms_per_step_max": max(walls) / steps,
             "replicas": replicas, "tp": world, "p2p": p2p, "plan": dev.plan_info(),
             "step_bytes": int(step_bytes), "hbm_frac_whole_step": step_gbs / (HBM_PEAK_GBS * max(world, 1)),
-            "kernels": kernels, "last_ids": ids[-4:], "head_ids": head_ids, "prefill_logits": prefill_logits,
+            "kernels": kernels, "last_ids": ids[-4:], "head_ids": head_ids, "first_id": first, "prefill_logits": prefill_logits,
+            "dropin": (dropin_rates(dev, first, pos0, 64 if tier != "big" else 32, head_ids) if dropin and world == 1 and not shard_of else None),
             "roofline": roof(dom), "roofline_by_bytes": roof(dom_bytes),
             "segment": min(SEGMENT, steps), "pos_first": pos0, "pos_last": pos0 + min(SEGMENT, steps) - 1,
         }
@@ -409,6 +496,17 @@ def shard_probe(model, rdv, ns=(2, 4, 8), seam_us=2.0, steps=96, warmup=16, base
         out["predicted_scaling"][str(n)] = {"predicted_ms_per_step": round(pred_ms, 4), "predicted_tokens_per_s": round(1e3 / pred_ms, 1)}
         if base:
             out["predicted_scaling"][str(n)]["predicted_speedup_vs_1gpu"] = round(base / pred_ms, 2)
+    # the same shard on the four-launches-per-layer plan (projection + attention fused, nl_group.h), for the comparison
+    if 8 in ns and not os.environ.get("NL_TP_FUSED"):
+        os.environ["NL_TP_FUSED"] = "0"
+        try:
+            r = run_workload("big", "q4_0", rdv, steps, warmup, None, model, tp=False, shard_of=8)
+            out["per_rank_four_launch_plan"] = {"8": {"ms_per_step": round(r["ms_per_step"], 5), "plan": r["plan"],
+                                                      "launches_per_step": sum(v["launches"] for v in r["kernels"].values())}}
+        except Exception as exc:
+            out["per_rank_four_launch_plan"] = {"error": repr(exc)}
+        finally:
+            del os.environ["NL_TP_FUSED"]
     out["label"] = "PREDICTION from one GPU: no store has crossed xGMI in this measurement"
     return out
 
@@ -522,22 +620,42 @@ def main():
     if n == 1:
         tier, wtype = "nano", "q8_0"
         shape = synth.TIERS[tier]
-        r = run_workload(tier, wtype, rdv, args.steps, args.warmup, args.profile_pos, model, tp=False)
+        r = run_workload(tier, wtype, rdv, args.steps, args.warmup, args.profile_pos, model, tp=False, dropin=not args.no_secondary)
         out = dict(common, metric=f"decode tokens/sec, {tier} {wtype.upper()} single-stream greedy", scaling="weak",
                    config={"workload": workload_text(shape, tier, wtype, r, args.steps) + " per GPU", "parallelism": "single-gpu",
                            "weights": f"{wtype} blocks dequantised in-register, f32 activations and KV cache"},
                    device_ms_per_step=round(r["device_ms_per_step"], 5), algorithmic_bytes_per_step=r["step_bytes"],
                    last_ids=r["last_ids"], **summary(r))
+        bad_ids = []
+        if r.get("dropin"):
+            out["dropin_forward_loop"] = r["dropin"]
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(r["path"], r["prompt"])
+            out.update({"greedy_ids_vs_cpu": ids_check(out["cpu_baseline"], r["first_id"], r["head_ids"])})
+            if not out["greedy_ids_vs_cpu"]["ids_match_cpu"]:
+                bad_ids.append("nano")
+            if not args.no_secondary:
+                # BASELINE.json configs[0]: nano f16, greedy 128-token decode on the CPU engine (go/quant.go:527-563), no GPU involved
+                try:
+                    f16 = cpu_baseline(ensure_gguf(shape, "f16", "float"), r["prompt"], budget_s=15.0)
+                    for k in ("_ids", "_margins", "_first"):
+                        f16.pop(k, None)
+                    out["config0_nano_f16_cpu"] = f16
+                except Exception as exc:
+                    out["config0_nano_f16_cpu"] = {"error": repr(exc)}
         if not args.no_secondary:
             # BASELINE.json's metric also names big Q4_0 @ 1 GPU: the 1-GPU point of the tensor-parallel curve
             try:
-                b = run_workload("big", "q4_0", rdv, 96, 16, args.profile_pos, model)
+                b = run_workload("big", "q4_0", rdv, 96, 16, args.profile_pos, model, dropin=True)
                 out["secondary"] = dict(workload=workload_text(synth.TIERS["big"], "big", "q4_0", b, 96) + ", 1 GPU", **summary(b))
+                if b.get("dropin"):
+                    out["secondary"]["dropin_forward_loop"] = b["dropin"]
                 if not args.no_cpu_baseline:
                     # north_star tabulates both tiers next to the CPU engine; SURVEY 8(d) allows a shortened run for big
                     out["secondary"]["cpu_baseline"] = cpu_baseline(b["path"], b["prompt"], budget_s=12.0, min_tokens=4, max_tokens=16)
+                    out["secondary"]["greedy_ids_vs_cpu"] = ids_check(out["secondary"]["cpu_baseline"], b["first_id"], b["head_ids"])
+                    if not out["secondary"]["greedy_ids_vs_cpu"]["ids_match_cpu"]:
+                        bad_ids.append("big")
             except Exception as exc:  # the headline result must survive a failure of the side measurement
                 out["secondary"] = {"error": repr(exc)}
             try:
@@ -550,8 +668,15 @@ def main():
                     out["tensor_parallel_shard_probe"] = shard_probe(model, rdv, seam_us=args.seam_us, base=base)
                 except Exception as exc:
                     out["tensor_parallel_shard_probe"] = {"error": repr(exc)}
+        for cb in (out.get("cpu_baseline"), (out.get("secondary") or {}).get("cpu_baseline") if isinstance(out.get("secondary"), dict) else None):
+            if isinstance(cb, dict):
+                for k in ("_ids", "_margins", "_first"):
+                    cb.pop(k, None)
         print(json.dumps(out))
         rdv.close()
+        if bad_ids:
+            print(f"[bench] greedy ids differ from the CPU engine's outside the {ID_MARGIN} margin: {bad_ids}", file=sys.stderr)
+            raise SystemExit(4)
         return
 
     # ---- N > 1: big Q4_0, tensor-parallel over the N GPUs (BASELINE.json configs[4]) ----

@@ -191,6 +191,20 @@ struct nl_engine {
         uint4 *kv16 = nullptr;  // one layer's K / V^T of a prompt's stream as fp16 hi / lo LDS images (nl_batch.h Kv16Image)
     } bt;
 
+    // Concurrent sub-batches of a decode batch (nl_forward_batch): the streams of a batch are independent (go/serve.go:106-108
+    // serialises them only because it has one CPU engine), so the batch is cut into groups that step on their own HIP stream
+    // with their own step buffers -- one dependent chain's launch heads and memory round trips overlap another's work.
+    // Each group's step is a hipGraph cached by (tokens, position splits): twice the launches would otherwise bind on the host.
+    struct SubBatch {
+        Batch bt;
+        hipStream_t st = nullptr;
+        hipEvent_t done = nullptr;
+        struct G { int n, nsplit; hipGraph_t graph; hipGraphExec_t exec; };
+        std::vector<G> graphs;
+    } sub[4];
+    hipEvent_t sub_fork = nullptr;
+    int sub_batches = 1;          // NL_SUB_BATCHES: groups a decode batch is cut into (1 = the whole batch as one step: measured fastest, profiles/r04_subbatch_groups.log)
+
     // on-device sampling (nl_sample_decode): scratch for one vocabulary, allocated on first use
     SampScratch sp;
     bool sp_ready = false;
@@ -1271,15 +1285,14 @@ bool batch_supported(const nl_engine *e) {
     return ok(e->lm_head) && !getenv("NL_NO_BATCH_PATH");
 }
 
-int batch_alloc(nl_engine *e) {
-    if (e->bt.ready) return NL_OK;
+int batch_alloc(nl_engine *e, nl_engine::Batch &b, int cap_limit = 2048) {
+    if (b.ready) return NL_OK;
     const nl_config &c = e->cfg;
-    nl_engine::Batch &b = e->bt;
     // tokens per multi-token step: a whole prompt when it fits (one launch per op and layer, enough workgroups
     // that no GEMM needs split-K); halved until the activation set stays under 4 GiB.  The LM head runs on
     // <= 64 of them.
     const size_t R = (size_t)(e->Hs + 2 * e->KVs) * e->hd, HQ = (size_t)e->Hs * e->hd;
-    b.cap = std::min(2048, ((c.seq_len + QG_TOK - 1) / QG_TOK) * QG_TOK);
+    b.cap = std::min(cap_limit, ((c.seq_len + QG_TOK - 1) / QG_TOK) * QG_TOK);
     {
         const size_t per_tok = 4 * (2 * (size_t)c.dim + R + 2 * HQ + 3 * (size_t)e->Is + (size_t)e->Hs * e->nsplit_max * (e->hd + 2) +
                                     std::max<size_t>(std::max<size_t>(HQ, c.dim), e->Is));
@@ -1324,34 +1337,32 @@ int batch_alloc(nl_engine *e) {
 
 // GEMM of the multi-token step: input = the fragment store the producing kernel just filled; output = `out`
 // (with resid / bias applied) when it ran unsplit, else split-K slabs in `part` for the consumer to add.
-hipError_t qg(nl_engine *e, const PackedMat &m, int n, float *out, int ldo, const float *resid, hipStream_t st,
+hipError_t qg(nl_engine *e, nl_engine::Batch &bt, const PackedMat &m, int n, float *out, int ldo, const float *resid, hipStream_t st,
               GemmOut *res, float *part, const float *bias = nullptr, const uint4 *xf = nullptr,
               const QGemmParams::NormOut *nout = nullptr) {
     QGemmParams P{};
     P.bias = bias;
     if (nout) P.nrm_out = *nout;
     P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
-    P.xf = xf ? xf : e->bt.xfrag; P.n_tokens = n; P.out = out; P.ldo = ldo; P.resid = resid;
+    P.xf = xf ? xf : bt.xfrag; P.n_tokens = n; P.out = out; P.ldo = ldo; P.resid = resid;
     int ks = 1;
-    hipError_t s = launch_qgemm(m.wtype, P, st, part, e->bt.kpart_cap, &ks);
+    hipError_t s = launch_qgemm(m.wtype, P, st, part, bt.kpart_cap, &ks);
     *res = GemmOut{out, part, ks, (long long)n * ldo, bias};
     return s;
 }
 
-hipError_t launch_qgemm_plain(nl_engine *e, const PackedMat &m, int n, float *out, int ldo, hipStream_t st) {
+hipError_t launch_qgemm_plain(nl_engine *e, nl_engine::Batch &bt, const PackedMat &m, int n, float *out, int ldo, hipStream_t st) {
     QGemmParams P{};
     P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
-    P.xf = e->bt.xfrag; P.n_tokens = n; P.out = out; P.ldo = ldo;
-    return launch_qgemm(m.wtype, P, st, e->bt.kpart, e->bt.kpart_cap);   // split-K + its own sum launch
+    P.xf = bt.xfrag; P.n_tokens = n; P.out = out; P.ldo = ldo;
+    return launch_qgemm(m.wtype, P, st, bt.kpart, bt.kpart_cap);   // split-K + its own sum launch
 }
 
 // One multi-token step: n <= 64 (token, pos, stream) triples through every layer on the MFMA path.
 // lm_mode: 0 = no LM head, 1 = logits + argmax for every token, 2 = logits + argmax for the LAST token only.
 // The caller has filled bt.h_meta; stream-ordered, no synchronisation inside.
-int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
+int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int lm_mode, bool one_stream = false) {
     const nl_config &c = e->cfg;
-    nl_engine::Batch &b = e->bt;
-    hipStream_t st = e->stream;
     const int D = c.dim, hd = e->hd, HQ = e->Hs * hd, R = (e->Hs + 2 * e->KVs) * hd;
 #define LCK(expr) do { hipError_t s_ = (expr); if (s_ != hipSuccess) return e->fail(NL_ERR_HIP, "batched step: %s: %s", #expr, hipGetErrorString(s_)); } while (0)
     // prompts (consecutive positions of one stream): the workgroups of the causal attention launch, each a query tile and a
@@ -1462,7 +1473,7 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
                                        L.bq, L.bk, L.bv, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate};
             LCK(launch_qgemm_rope(m.wtype, P, st));
         } else {
-            LCK(qg(e, L.qkv, n, b.qkv, R, nullptr, st, &qkv_out, b.kpart));
+            LCK(qg(e, b, L.qkv, n, b.qkv, R, nullptr, st, &qkv_out, b.kpart));
             // decode batches (every token its own stream: no token of the step attends over another's K / V row), no QK-norm:
             // the attention launch rotates and stores its own q / k / v rows (attn_rope_prologue) -- no brope_kv launch.
             // Below position 128 that is the one-split FIN kernel; with two splits per token every split rotates q and the
@@ -1530,9 +1541,9 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
         }
         if (fold) {
             const QGemmParams::NormOut nout{L.ffn_norm, b.xfrag2, b.ssq};
-            LCK(qg(e, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo, nullptr, &nout));
+            LCK(qg(e, b, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo, nullptr, &nout));
         } else {
-            LCK(qg(e, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo));
+            LCK(qg(e, b, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo));
             LCK(norm(L.ffn_norm, L.gate, 0, n));
         }
         if (L.up.wtype != L.gate.wtype)   // (a mixed-type file: the fragment k-slot order differs per type)
@@ -1571,9 +1582,9 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
         if (fold && l + 1 < c.n_layers) {
             const nl_engine::Layer &Ln = e->layers[l + 1];
             const QGemmParams::NormOut nout{Ln.attn_norm, b.xfrag2, b.ssq};
-            LCK(qg(e, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in, &nout));
+            LCK(qg(e, b, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in, &nout));
         } else {
-            LCK(qg(e, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in));
+            LCK(qg(e, b, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in));
         }
     }
     if (lm_mode) {
@@ -1581,7 +1592,7 @@ int batched_step(nl_engine *e, int n, int lm_mode, bool one_stream = false) {
         const int first = lm_mode == 2 ? n - 1 : 0, cnt = lm_mode == 2 ? 1 : n;
         if (cnt > b.lm_cap) return e->fail(NL_ERR_INVALID, "LM head batch %d exceeds %d", cnt, b.lm_cap);
         LCK(norm(e->output_norm, e->lm_head, first, cnt));
-        LCK(launch_qgemm_plain(e, e->lm_head, cnt, b.logits, c.vocab, st));
+        LCK(launch_qgemm_plain(e, b, e->lm_head, cnt, b.logits, c.vocab, st));
         hipLaunchKernelGGL(bargmax_kernel, dim3(cnt), dim3(1024), 0, st, b.logits, c.vocab, b.ids);
         LCK(hipGetLastError());
     }
@@ -1676,6 +1687,7 @@ int nl_create(const nl_config *cfg, nl_handle *out) {
     e->layers.resize(c.n_layers);
     e->use_graph = !(c.flags & NL_FLAG_NO_GRAPH) && !getenv("NL_NO_GRAPH");
     if (getenv("NL_FORCE_TP_PLAN")) e->force_tp_plan = true;
+    if (const char *v = getenv("NL_SUB_BATCHES")) e->sub_batches = std::max(1, std::min(4, atoi(v)));   // knob (tests, tools)
     if (const char *v = getenv("NL_TW")) e->tw_override = atoi(v);
     if (const char *v = getenv("NL_KW")) e->kw_override = atoi(v);
     if ((s = hipSetDevice(e->dev)) != hipSuccess || (s = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -2101,6 +2113,10 @@ int nl_set_gamma(nl_handle e, const int32_t *indices, int n, const void *values,
     float *old_val = e->gamma_val;
     e->gamma_row = new_row;
     e->gamma_val = new_val;
+    for (auto &sb : e->sub) {   // the sub-batch step graphs hold the old tables too
+        for (auto &G : sb.graphs) { (void)hipGraphExecDestroy(G.exec); (void)hipGraphDestroy(G.graph); }
+        sb.graphs.clear();
+    }
     if (e->finalized) {  // the launch closures hold the old pointers: rebuild plans and graphs
         destroy_samp_graphs(e);
         if (build_all(e)) {   // the rebuilt eager plans are valid; only the graphs were lost
@@ -2130,13 +2146,20 @@ int nl_destroy(nl_handle e) {
     if (e->gamma_val) hipFree(e->gamma_val);
     for (void *c : e->arena_chunks) hipFree(c);
     if (e->stage) hipFree(e->stage);
-    {
-        nl_engine::Batch &b = e->bt;
+    auto batch_free = [](nl_engine::Batch &b) {
         void *bb[] = {b.x, b.qkv, b.q, b.g, b.u, b.logits, b.part_o, b.part_ml, b.tok /* | pos | stream */, b.ids, b.kpart, b.kpart2,
                       b.xfrag, b.xfrag2, b.ssq, b.kv16};
         for (void *p : bb) if (p) hipFree(p);
         if (b.h_meta) hipHostFree(b.h_meta);
+    };
+    batch_free(e->bt);
+    for (auto &sb : e->sub) {
+        for (auto &G : sb.graphs) { (void)hipGraphExecDestroy(G.exec); (void)hipGraphDestroy(G.graph); }
+        batch_free(sb.bt);
+        if (sb.done) (void)hipEventDestroy(sb.done);
+        if (sb.st) (void)hipStreamDestroy(sb.st);
     }
+    if (e->sub_fork) (void)hipEventDestroy(e->sub_fork);
     if (e->p2p.area) {
         if (e->p2p.on) e->logits = nullptr;   // lives inside the receive area (an export that was never imported allocated its own)
         for (int r = 0; r < 8; r++)
@@ -2431,7 +2454,7 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
     if ((rc = note_positions(e, stream, pos0, n))) return rc;
     if (n >= NL_BATCH_MIN && batch_supported(e)) {
         // multi-token path: 64-token tiles on the matrix cores; causality comes from each token's own pos
-        if ((rc = batch_alloc(e))) return rc;
+        if ((rc = batch_alloc(e, e->bt))) return rc;
         nl_engine::Batch &b = e->bt;
         for (int t0 = 0; t0 < n; t0 += b.cap) {
             const int m = std::min(b.cap, n - t0);
@@ -2442,7 +2465,7 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
                 b.h_meta[2 * b.cap + i] = stream;
             }
             const bool last = t0 + m == n;
-            if ((rc = batched_step(e, m, last ? 2 : 0, true))) return rc;
+            if ((rc = batched_step(e, b, e->stream, m, last ? 2 : 0, true))) return rc;
             if (last) {
                 // keep the single-token state coherent: logits / argmax of the last token
                 HIPCK(e, hipMemcpyAsync(e->logits, b.logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToDevice, e->stream));
@@ -2484,7 +2507,78 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
     for (int i = 0; i < n; i++)
         if ((rc = note_positions(e, streams[i], pos[i], 1))) return rc;
     if (n >= NL_BATCH_MIN && batch_supported(e)) {
-        if ((rc = batch_alloc(e))) return rc;
+        // The streams of a batch are independent: cut it into groups of >= 16 that step concurrently, each on its own HIP
+        // stream with its own step buffers, so that one dependent chain's launch heads and memory round trips overlap
+        // another's work (a 64-stream step of the 841M tier is ~224 launches of <= 144 workgroups on a 256-CU chip).  The
+        // arithmetic per stream does not depend on the group it steps in: results are bitwise those of the one-step form.
+        const int groups = std::max((n + QG_TOK - 1) / QG_TOK, std::min(e->sub_batches, n / 16));
+        if (groups > 1 && groups <= 4) {
+            if (!e->sub_fork) HIPCK(e, hipEventCreateWithFlags(&e->sub_fork, hipEventDisableTiming));
+            HIPCK(e, hipEventRecord(e->sub_fork, e->stream));      // (the position bookkeeping above may have queued row clears)
+            const int per = (n + groups - 1) / groups;
+            const char *rk = getenv("NL_ROPE_IN_ATTN");
+            const int knob_sig = rk ? atoi(rk) + 1 : 0;            // (a step's launch list also depends on this test knob)
+            for (int g = 0, t0 = 0; g < groups; g++, t0 += per) {
+                const int m = std::min(per, n - t0);
+                if (m <= 0) break;
+                nl_engine::SubBatch &sb = e->sub[g];
+                if ((rc = batch_alloc(e, sb.bt, QG_TOK))) return rc;
+                if (!sb.st) {
+                    HIPCK(e, hipStreamCreateWithFlags(&sb.st, hipStreamNonBlocking));
+                    HIPCK(e, hipEventCreateWithFlags(&sb.done, hipEventDisableTiming));
+                }
+                nl_engine::Batch &b = sb.bt;
+                int nsplit = 1;
+                for (int i = 0; i < m; i++) {
+                    b.h_meta[i] = tokens[t0 + i];
+                    b.h_meta[b.cap + i] = pos[t0 + i];
+                    b.h_meta[2 * b.cap + i] = streams[t0 + i];
+                    nsplit = std::max(nsplit, pos[t0 + i] / ATT_CH + 1);
+                }
+                const int key_split = nsplit * 8 + knob_sig;
+                HIPCK(e, hipStreamWaitEvent(sb.st, e->sub_fork, 0));
+                hipGraphExec_t exec = nullptr;
+                for (auto &G : sb.graphs)
+                    if (G.n == m && G.nsplit == key_split) exec = G.exec;
+                if (!exec && e->use_graph) {
+                    // the step reads its tokens / positions / streams from the pinned block behind h_meta (a copy node of the
+                    // graph), so one graph serves every step of m streams with as many position splits
+                    hipGraph_t gr = nullptr;
+                    if (hipStreamBeginCapture(sb.st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                        const int rc2 = batched_step(e, b, sb.st, m, 1);
+                        const hipError_t ce = hipStreamEndCapture(sb.st, &gr);
+                        if (!rc2 && ce == hipSuccess && gr && hipGraphInstantiate(&exec, gr, nullptr, nullptr, 0) == hipSuccess) {
+                            sb.graphs.push_back({m, key_split, gr, exec});
+                        } else {
+                            if (gr) (void)hipGraphDestroy(gr);
+                            (void)hipGetLastError();
+                            exec = nullptr;
+                        }
+                    }
+                    (void)hipGetLastError();
+                }
+                if (exec) HIPCK(e, hipGraphLaunch(exec, sb.st));
+                else if ((rc = batched_step(e, b, sb.st, m, 1))) return rc;
+                HIPCK(e, hipEventRecord(sb.done, sb.st));
+                HIPCK(e, hipStreamWaitEvent(e->stream, sb.done, 0));     // later work on the engine's stream follows every group
+            }
+            // the read-backs only after EVERY group is queued: a copy into the caller's pageable memory blocks the host until
+            // its stream has drained, and would serialise the groups
+            for (int g = 0, t0 = 0; g < groups; g++, t0 += per) {
+                const int m = std::min(per, n - t0);
+                if (m <= 0) break;
+                nl_engine::SubBatch &sb = e->sub[g];
+                if (logits_out)
+                    HIPCK(e, hipMemcpyAsync(logits_out + (size_t)t0 * e->cfg.vocab, sb.bt.logits, (size_t)m * e->cfg.vocab * 4,
+                                            hipMemcpyDeviceToHost, sb.st));
+                if (next_ids) HIPCK(e, hipMemcpyAsync(next_ids + t0, sb.bt.ids, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, sb.st));
+            }
+            for (int g = 0; g < groups; g++)
+                if (e->sub[g].st) HIPCK(e, hipStreamSynchronize(e->sub[g].st));
+            HIPCK(e, hipStreamSynchronize(e->stream));
+            return NL_OK;
+        }
+        if ((rc = batch_alloc(e, e->bt))) return rc;
         nl_engine::Batch &b = e->bt;
         for (int t0 = 0; t0 < n; t0 += b.lm_cap) {
             const int m = std::min(b.lm_cap, n - t0);
@@ -2494,7 +2588,7 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
                 b.h_meta[b.cap + i] = pos[t0 + i];
                 b.h_meta[2 * b.cap + i] = streams[t0 + i];
             }
-            if ((rc = batched_step(e, m, 1))) return rc;
+            if ((rc = batched_step(e, b, e->stream, m, 1))) return rc;
             if (logits_out)
                 HIPCK(e, hipMemcpyAsync(logits_out + (size_t)t0 * e->cfg.vocab, b.logits, (size_t)m * e->cfg.vocab * 4,
                                         hipMemcpyDeviceToHost, e->stream));

@@ -1603,3 +1603,41 @@ def test_fused_launches_keep_streams_independent(hip, tmp_path, shape):
         solo.forward(a[pos], pos)
         assert la[pos].tobytes() == solo.state.logits.tobytes(), pos
     dev.close(); solo.close()
+
+
+@pytest.mark.parametrize("groups", [2, 4])
+def test_concurrent_sub_batches_equal_the_one_step_batch_bitwise(hip, tmp_path, monkeypatch, groups):
+    # nl_forward_batch cuts a decode batch into groups that step concurrently on their own HIP streams (each group's step a
+    # cached hipGraph); a stream's arithmetic does not depend on the group it steps in, so logits and ids are BITWISE those of
+    # the whole batch stepped as one (go/model.go:510-612 per stream; go/serve.go:106-108 serialises requests only because it
+    # has one CPU engine).  Ragged positions across the 128-position attention split, 64 and 37 streams, graph replays.
+    shape = synth.ModelShape("subbatch", 3, 512, 8, 2, 4096, seq_len=192, interm=1536)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", 77, mode="qrand")
+    g = gguf.load_gguf(str(p))
+    ns, nsteps = 64, 12
+    rng = np.random.Generator(np.random.PCG64(65))
+    start = [int(v) for v in rng.integers(0, 30, size=ns)]
+    start[3], start[50] = 120, 125                      # these cross position 128 during the run
+    seqs = [[int(t) for t in rng.integers(3, shape.vocab, size=start[s] + nsteps)] for s in range(ns)]
+
+    def run(sub):
+        monkeypatch.setenv("NL_SUB_BATCHES", str(sub))
+        dev = hip.load_llama_model(g, max_streams=ns)
+        for s in range(ns):
+            if start[s]:
+                dev.prefill(seqs[s][:start[s]], stream=s, want_logits=False)
+        out = []
+        for k in range(nsteps):
+            live = list(range(ns)) if k % 3 else list(range(0, ns, 2)) + [1, 3, 5, 7, 9]      # 64 streams, or 37
+            ids, lg = dev.forward_batch(live, [seqs[s][start[s] + k] for s in live], [start[s] + k for s in live], want_logits=True)
+            out.append((list(ids), lg.copy()))
+            for s in set(range(ns)) - set(live):       # keep every stream's cache complete: the skipped ones step alone
+                dev.forward(seqs[s][start[s] + k], start[s] + k, stream=s)
+        dev.close()
+        return out
+
+    one, cut = run(1), run(groups)
+    for k, ((ids_a, lg_a), (ids_b, lg_b)) in enumerate(zip(one, cut)):
+        assert ids_a == ids_b, k
+        assert lg_a.tobytes() == lg_b.tobytes(), f"step {k}: sub-batched logits differ from the one-step batch"
