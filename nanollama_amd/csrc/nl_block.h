@@ -145,7 +145,9 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
     const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + (long long)kvh * P.seq_len * HD);
     const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + (long long)kvh * P.seq_len * HD);
     if (tid < BLK_KV_THREADS) {
-        const int lim = min(ATT_CH, P.seq_len);
+        // (rows beyond pos repeat row pos -- the same cache lines: at short contexts a workgroup fetched 64 KB of cache rows
+        //  it then masked, more than its weights)
+        const int lim = min(min(ATT_CH, P.seq_len), pos + 1);
         const unsigned krow = (unsigned)min(wave * 16 + kr, lim - 1) * R4 + (unsigned)kq * 4u;
 #pragma unroll
         for (int kk = 0; kk < NV; kk++) {

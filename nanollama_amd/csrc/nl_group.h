@@ -108,15 +108,6 @@ __global__ void __launch_bounds__(GRP_THREADS) qkv_attn_kernel(GroupParams P) {
     float4 kreg[NV], vreg[NV], kregn[NV];
     const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + (long long)cl * P.seq_len * HD);
     const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + (long long)cl * P.seq_len * HD);
-    if (attn_member && tid < GRP_KV_THREADS) {
-        const int lim = min(ATT_CH, P.seq_len);
-#pragma unroll
-        for (int kk = 0; kk < NV; kk++) {
-            const unsigned ro = (unsigned)(min(tg + kk * NGR, lim - 1) * R4 + c4) * 16u;
-            kreg[kk] = ld_off<float4>(K4, ro);
-            vreg[kk] = ld_off<float4>(V4, ro);
-        }
-    }
     // epilogue inputs (threads 0 .. tpm * 16 - 1: one projection row each)
     const int e_slot = tid >> 4, e_rr = tid & 15;
     int e_sect = 0, e_hq = 0, e_j = 0;
@@ -151,6 +142,19 @@ __global__ void __launch_bounds__(GRP_THREADS) qkv_attn_kernel(GroupParams P) {
         const float a1 = PairDot<WT>::run(cw[f], sw[f], xw + k * XS_PAIR, acc);
         acc = lv[f] ? a1 : acc;
         __builtin_amdgcn_wave_barrier();
+    }
+    // The head's cache rows are requested only now, after the projection dots (round 4): a wavefront issues in order and a
+    // compute unit ingests ~11 B/clk, so requested at entry the 64 KB of rows delayed the attention blocks' projection tiles
+    // -- and with them the exchange every block of the cluster waits for.  Rows beyond pos repeat row pos (the same cache
+    // lines; they are masked below), the row AT pos comes from LDS.
+    if (attn_member && tid < GRP_KV_THREADS) {
+        const int lim = min(min(ATT_CH, P.seq_len), pos + 1);
+#pragma unroll
+        for (int kk = 0; kk < NV; kk++) {
+            const unsigned ro = (unsigned)(min(tg + kk * NGR, lim - 1) * R4 + c4) * 16u;
+            kreg[kk] = ld_off<float4>(K4, ro);
+            vreg[kk] = ld_off<float4>(V4, ro);
+        }
     }
     acc = quad_sum(acc);
     if (k == 0) red[wave * TR + r] = acc;

@@ -656,8 +656,17 @@ __device__ __forceinline__ void load_pair(const uint8_t *q, const uint32_t *s, l
     // uniform bases (tile, group) + one unsigned lane offset shared by the quant chunks and the scale entry
     const uint4 *qb = reinterpret_cast<const uint4 *>(q) + (tile_pair0 * (CPP * TR) + (long long)g * (KL * CPP * TR));
     const unsigned off = __umul24((unsigned)r, (unsigned)gsz) + (unsigned)k;
+#ifdef NL_NT_WEIGHTS   // developer build (tools/r4_big.sh): non-temporal policy on the streamed weight chunks
+#pragma unroll
+    for (int j = 0; j < CPP; j++) {
+        typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
+        const u32x4n t = __builtin_nontemporal_load(reinterpret_cast<const u32x4n *>(qb + j * TR * gsz) + off);
+        c[j] = make_uint4(t.x, t.y, t.z, t.w);
+    }
+#else
 #pragma unroll
     for (int j = 0; j < CPP; j++) c[j] = (qb + j * TR * gsz)[off];
+#endif
     const long long sb = tile_pair0 * TR + (long long)g * (KL * TR);
     if (!WTraits<WT>::SCALED) sc = make_uint2(0u, 0u);
     else if (scale_words(WT) == 2) sc = (reinterpret_cast<const uint2 *>(s) + sb)[off];
