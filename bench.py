@@ -371,6 +371,34 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
     return res
 
 
+def prefill_x1(dev, toks, dt_hilo, gemm_flop):
+    """The same prompt in the single-product precision mode (NL_PREFILL_PRECISION=fp16x1): time, and its logits
+    against the default hi + lo mode's on this device (the hi + lo mode is the one held to 1e-4 against the CPU engine)."""
+    import numpy as np
+    dev.reset()
+    dev.prefill(toks)
+    base = dev.state.logits.copy()
+    os.environ["NL_PREFILL_PRECISION"] = "fp16x1"
+    try:
+        dev.reset()
+        dev.prefill(toks)
+        dev.synchronize()
+        dt = 1e9
+        for _ in range(3):
+            dev.reset()
+            t0 = time.perf_counter()
+            dev.prefill(toks)
+            dt = min(dt, time.perf_counter() - t0)
+        lg = dev.state.logits.copy()
+    finally:
+        del os.environ["NL_PREFILL_PRECISION"]
+    scale = max(1.0, float(base.std()))
+    return {"prefill_ms": round(dt * 1e3, 2), "prefill_tokens_per_s": round(len(toks) / dt, 1), "speedup_vs_hi_lo": round(dt_hilo / dt, 3),
+            "mfma_peak_frac_f16_dense": round(gemm_flop / dt / 2.5e15, 5),
+            "max_abs_logit_diff_vs_hi_lo_over_std": round(float(np.abs(lg - base).max()) / scale, 6), "stated_tolerance_over_std": 1e-2,
+            "same_argmax": bool(int(np.argmax(lg)) == int(np.argmax(base)))}
+
+
 def side_configs(model):
     """BASELINE.json configs[2] and [3] as side results of the single-GPU run: mini Q4_0 2047-token prefill
     (MFMA multi-token path) + one decode step, and goldie Q4_0 with 64 concurrent decode streams."""
@@ -399,7 +427,9 @@ def side_configs(model):
     out["mini_q4_0_prefill_2047"] = {"prefill_tokens_per_s": round(2047 / dt, 1), "prefill_ms": round(dt * 1e3, 2),
                                      "gemm_TFLOPs_algorithmic": round(gemm_flop / dt / 1e12, 2),
                                      "mfma_peak_frac_f16_dense": round(gemm_flop / dt / 2.5e15, 5),
-                                     "decode_step_ms_at_pos_2047": round(dt1 * 1e3, 3)}
+                                     "decode_step_ms_at_pos_2047": round(dt1 * 1e3, 3),
+                                     "precision": "x = fp16 hi + fp16 lo (two MFMAs per product; logits within 1e-4 of the CPU engine)"}
+    out["mini_q4_0_prefill_2047"]["fp16x1_mode"] = prefill_x1(dev, toks, dt, gemm_flop)
     dev.close()
     # -- goldie: the same prompt step at 841M parameters (what the MFMA path does with longer rows), then 64 streams
     shape = synth.TIERS["goldie"]
@@ -418,6 +448,7 @@ def side_configs(model):
     out["goldie_q4_0_prefill_2047"] = {"prefill_tokens_per_s": round(2047 / dt, 1), "prefill_ms": round(dt * 1e3, 2),
                                        "gemm_TFLOPs_algorithmic": round(gemm_flop / dt / 1e12, 2),
                                        "mfma_peak_frac_f16_dense": round(gemm_flop / dt / 2.5e15, 5)}
+    out["goldie_q4_0_prefill_2047"]["fp16x1_mode"] = prefill_x1(dev, toks, dt, gemm_flop)
     dev.close()
     ns, steps, pos0 = 64, 32, 8
     dev = model.load_llama_model(g, max_streams=ns)

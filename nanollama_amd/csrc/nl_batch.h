@@ -1027,25 +1027,33 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
         v4f acc[8];
 #pragma unroll
         for (int mt = 0; mt < 8; mt++) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        // (two instruction streams, chosen by a uniform test: three products per term, or the fp16x1 precision mode's one)
+        auto scores = [&](auto x1_tag) {
+            constexpr bool X1 = decltype(x1_tag)::value;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ks++) {
+            for (int ks = 0; ks < NKS; ks++) {
 #pragma unroll
-            for (int mh = 0; mh < 8; mh += 4) {        // four key tiles at a time: 32 operand registers live, not 64
-                half8_t kh[4], kl[4];
+                for (int mh = 0; mh < 8; mh += 4) {        // four key tiles at a time: 32 operand registers live, not 64
+                    half8_t kh[4], kl[4];
 #pragma unroll
-                for (int mt = 0; mt < 4; mt++) {
-                    const int ko = Img::k_off((mh + mt) * 16 + j, 4 * ks + kq);
-                    kh[mt] = *reinterpret_cast<const half8_t *>(Kh + ko);
-                    kl[mt] = *reinterpret_cast<const half8_t *>(Kl + ko);
+                    for (int mt = 0; mt < 4; mt++) {
+                        const int ko = Img::k_off((mh + mt) * 16 + j, 4 * ks + kq);
+                        kh[mt] = *reinterpret_cast<const half8_t *>(Kh + ko);
+                        if (!X1) kl[mt] = *reinterpret_cast<const half8_t *>(Kl + ko);
+                    }
+                    if (!X1) {
+#pragma unroll
+                        for (int mt = 0; mt < 4; mt++) acc[mh + mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[mt], qh[ks], acc[mh + mt], 0, 0, 0);
+#pragma unroll
+                        for (int mt = 0; mt < 4; mt++) acc[mh + mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt], ql[ks], acc[mh + mt], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt++) acc[mh + mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt], qh[ks], acc[mh + mt], 0, 0, 0);
                 }
-#pragma unroll
-                for (int mt = 0; mt < 4; mt++) acc[mh + mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[mt], qh[ks], acc[mh + mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 4; mt++) acc[mh + mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt], ql[ks], acc[mh + mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 4; mt++) acc[mh + mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt], qh[ks], acc[mh + mt], 0, 0, 0);
             }
-        }
+        };
+        if (P.x1) scores(std::true_type{});
+        else scores(std::false_type{});
 
         ATT_STAMP(10 * c + 5);
         // ---- online softmax of row j: 32 keys of this chunk in this lane, the rest in lanes j+16, j+32, j+48.  Chunks
@@ -1105,30 +1113,41 @@ __global__ void __launch_bounds__(QT * G * 4, QT * G >= 128 ? 4 : 2) attn_tile16
         // ---- O^T += V^T P^T: A = V^T rows from LDS, B = P^T (this lane's own accumulators, key tiles 2m and 2m+1).  The
         //      transposed product keeps query row j in lane column j, where S^T left its max and sum: the running output is
         //      rescaled in place, and a lane ends up with four consecutive head_dim elements of its row ----
+        auto pv = [&](auto x1_tag) {
+            constexpr bool X1 = decltype(x1_tag)::value;
 #pragma unroll
-        for (int mm = 0; mm < 4; mm++) {
-            // p * 2^10 = hi + lo: hi = the leading 11 bits (a mask, exact in fp16 down to its subnormals), lo = the rest
-            half8_t ph, pl;
+            for (int mm = 0; mm < 4; mm++) {
+                // p * 2^10 = hi + lo: hi = the leading 11 bits (a mask, exact in fp16 down to its subnormals), lo = the rest
+                // (fp16x1: p rounded to fp16, no lo)
+                half8_t ph, pl;
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const v4f &a4 = acc[2 * mm + (e >> 2)];
-                const float p0 = a4[e & 2], p1 = a4[(e & 2) + 1];
-                const float h0 = __uint_as_float(__float_as_uint(p0) & 0xFFFFE000u), h1 = __uint_as_float(__float_as_uint(p1) & 0xFFFFE000u);
-                const v2f lf = (v2f){p0, p1} - (v2f){h0, h1};
-                ph[e] = (_Float16)h0; ph[e + 1] = (_Float16)h1;
-                pl[e] = (_Float16)lf[0]; pl[e + 1] = (_Float16)lf[1];
+                for (int e = 0; e < 8; e += 2) {
+                    const v4f &a4 = acc[2 * mm + (e >> 2)];
+                    const float p0 = a4[e & 2], p1 = a4[(e & 2) + 1];
+                    if (X1) { ph[e] = (_Float16)p0; ph[e + 1] = (_Float16)p1; }
+                    else {
+                        const float h0 = __uint_as_float(__float_as_uint(p0) & 0xFFFFE000u), h1 = __uint_as_float(__float_as_uint(p1) & 0xFFFFE000u);
+                        const v2f lf = (v2f){p0, p1} - (v2f){h0, h1};
+                        ph[e] = (_Float16)h0; ph[e + 1] = (_Float16)h1;
+                        pl[e] = (_Float16)lf[0]; pl[e + 1] = (_Float16)lf[1];
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NTO; nt++) {
+                    // B rows nt*16 + j, key segment 4*mm + kq (Kv16Image: swizzled, conflict-free)
+                    const int vo = Img::v_off(nt * 16 + j, 4 * mm + kq);
+                    const half8_t vh = *reinterpret_cast<const half8_t *>(VTh + vo);
+                    if (!X1) {
+                        const half8_t vl = *reinterpret_cast<const half8_t *>(VTl + vo);
+                        o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, o[nt], 0, 0, 0);
+                        o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o[nt], 0, 0, 0);
+                    }
+                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o[nt], 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int nt = 0; nt < NTO; nt++) {
-                // B rows nt*16 + j, key segment 4*mm + kq (Kv16Image: swizzled, conflict-free)
-                const int vo = Img::v_off(nt * 16 + j, 4 * mm + kq);
-                const half8_t vh = *reinterpret_cast<const half8_t *>(VTh + vo);
-                const half8_t vl = *reinterpret_cast<const half8_t *>(VTl + vo);
-                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, o[nt], 0, 0, 0);
-                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o[nt], 0, 0, 0);
-                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o[nt], 0, 0, 0);
-            }
-        }
+        };
+        if (P.x1) pv(std::true_type{});
+        else pv(std::false_type{});
         ATT_STAMP(10 * c + 7);
     }
 

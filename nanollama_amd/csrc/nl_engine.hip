@@ -1339,9 +1339,10 @@ int batch_alloc(nl_engine *e, nl_engine::Batch &b, int cap_limit = 2048) {
 // (with resid / bias applied) when it ran unsplit, else split-K slabs in `part` for the consumer to add.
 hipError_t qg(nl_engine *e, nl_engine::Batch &bt, const PackedMat &m, int n, float *out, int ldo, const float *resid, hipStream_t st,
               GemmOut *res, float *part, const float *bias = nullptr, const uint4 *xf = nullptr,
-              const QGemmParams::NormOut *nout = nullptr) {
+              const QGemmParams::NormOut *nout = nullptr, int x1 = 0) {
     QGemmParams P{};
     P.bias = bias;
+    P.x1 = x1;
     if (nout) P.nrm_out = *nout;
     P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
     P.xf = xf ? xf : bt.xfrag; P.n_tokens = n; P.out = out; P.ldo = ldo; P.resid = resid;
@@ -1443,6 +1444,12 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
                qgemm2_ok(L.qkv.wtype, n) && qgemm_rope_fits(L.qkv.ntiles, n) &&
                L.up.wtype == L.gate.wtype && qgemm2_ok(L.gate.wtype, n) && qgemm_swiglu_fits(L.gate.ntiles, n);
     }
+    // NL_PREFILL_PRECISION=fp16x1 (read per step: tests and bench.py flip it): the long-prompt GEMMs (qgemm2_kernel) and the
+    // prompt attention multiply only the fp16 hi half of every activation / probability -- half / a third of the matrix work,
+    // activations rounded to 11 bits.  The default x = hi + lo keeps float32-grade results (logit tolerance 1e-4).
+    const char *pk = getenv("NL_PREFILL_PRECISION");
+    const int x1 = pk && std::string(pk) == "fp16x1" ? 1 : 0;
+    const int x1_gemm = x1 || (pk && std::string(pk) == "fp16x1-gemm"), x1_attn = x1 || (pk && std::string(pk) == "fp16x1-attn");   // (developer: one half of the mode)
     const QGemmParams::NormIn nin_on{b.ssq, D / 64, D, c.rms_eps}, nin_off{nullptr, 0, 0, 0.f};
     auto norm = [&](const float *w, const PackedMat &next, int item0, int cnt) {
         BNormParams P{b.x, pend, w, c.rms_eps, D, item0, b.xfrag, ((cnt + 63) / 64) * 4, next.wtype == WT_Q4_0 ? 1 : 0};
@@ -1468,12 +1475,12 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
             const PackedMat &m = L.qkv;
             P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
             P.xf = folded_in ? b.xfrag2 : b.xfrag; P.nrm_in = folded_in ? nin_on : nin_off;
-            P.n_tokens = n; P.ldo = (int)R;
+            P.n_tokens = n; P.ldo = (int)R; P.x1 = x1_gemm;
             P.rope = QGemmParams::Rope{b.pos, b.stream, e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride,
                                        L.bq, L.bk, L.bv, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate};
             LCK(launch_qgemm_rope(m.wtype, P, st));
         } else {
-            LCK(qg(e, b, L.qkv, n, b.qkv, R, nullptr, st, &qkv_out, b.kpart));
+            LCK(qg(e, b, L.qkv, n, b.qkv, R, nullptr, st, &qkv_out, b.kpart, nullptr, nullptr, nullptr, x1_gemm));
             // decode batches (every token its own stream: no token of the step attends over another's K / V row), no QK-norm:
             // the attention launch rotates and stores its own q / k / v rows (attn_rope_prologue) -- no brope_kv launch.
             // Below position 128 that is the one-split FIN kernel; with two splits per token every split rotates q and the
@@ -1499,6 +1506,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
             if (one_stream && n >= 8 && attn_tile_supported(e->gqa) && !no_tile) {
                 // prefill: the step's tokens share a stream -> K/V split staged once per tile of tokens, fp16 MFMA with hi/lo-split operands (attn_tile16_kernel)
                 AttnParams T = P;
+                T.x1 = x1_attn;
                 T.single_stream = c.max_streams == 1 ? 1 : 0;
                 T.pos_base_valid = consecutive ? 1 : 0;   // (a prompt: the kernel derives its key range without reading bpos)
                 T.pos_base = b.h_meta[b.cap];
@@ -1541,9 +1549,9 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
         }
         if (fold) {
             const QGemmParams::NormOut nout{L.ffn_norm, b.xfrag2, b.ssq};
-            LCK(qg(e, b, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo, nullptr, &nout));
+            LCK(qg(e, b, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo, nullptr, &nout, x1_gemm));
         } else {
-            LCK(qg(e, b, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo));
+            LCK(qg(e, b, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo, nullptr, nullptr, x1_gemm));
             LCK(norm(L.ffn_norm, L.gate, 0, n));
         }
         if (L.up.wtype != L.gate.wtype)   // (a mixed-type file: the fragment k-slot order differs per type)
@@ -1556,7 +1564,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
             const PackedMat &m = L.gate;
             P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
             P.xf = fold ? b.xfrag2 : b.xfrag; P.nrm_in = fold ? nin_on : nin_off;
-            P.n_tokens = n; P.ldo = e->Is;
+            P.n_tokens = n; P.ldo = e->Is; P.x1 = x1_gemm;
             P.q1 = L.up.q; P.s1 = L.up.s;
             P.xf_out = fold ? b.xfrag : b.xfrag2; P.out_q4 = L.down.wtype == WT_Q4_0 ? 1 : 0;
             LCK(launch_qgemm_swiglu(m.wtype, P, st));
@@ -1567,7 +1575,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
                 QGemmParams P{};
                 const PackedMat &m = L.gate;
                 P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
-                P.xf = b.xfrag; P.n_tokens = n; P.out = b.g; P.ldo = e->Is;
+                P.xf = b.xfrag; P.n_tokens = n; P.out = b.g; P.ldo = e->Is; P.x1 = x1_gemm;
                 P.q1 = L.up.q; P.s1 = L.up.s; P.out1 = b.u; P.part1 = b.kpart2;
                 int ks = 1;
                 LCK(launch_qgemm(m.wtype, P, st, b.kpart, b.kpart_cap, &ks));
@@ -1582,9 +1590,9 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
         if (fold && l + 1 < c.n_layers) {
             const nl_engine::Layer &Ln = e->layers[l + 1];
             const QGemmParams::NormOut nout{Ln.attn_norm, b.xfrag2, b.ssq};
-            LCK(qg(e, b, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in, &nout));
+            LCK(qg(e, b, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in, &nout, x1_gemm));
         } else {
-            LCK(qg(e, b, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in));
+            LCK(qg(e, b, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in, nullptr, x1_gemm));
         }
     }
     if (lm_mode) {

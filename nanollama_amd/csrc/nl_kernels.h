@@ -1064,6 +1064,7 @@ struct AttnParams {
     // as the WO GEMM's fp16 hi/lo fragments and battn_merge_kernel is not launched
     uint4 *fin_xf;
     int fin_nt16, fin_q4;
+    int x1;   // attn_tile16_kernel: prompt precision mode fp16x1 -- one fp16 product per q.k and p.v term instead of hi*hi + lo*hi + hi*lo
     // attn_tile16_kernel: the step's positions are pos_base + item (a prompt) when pos_base_valid -- the workgroup then
     // knows its key range without reading bpos, and its K / V requests leave at entry
     int pos_base_valid, pos_base;

@@ -45,6 +45,7 @@ struct QGemmParams {
     int rows, cols, npairs, ntiles;
     const uint4 *xf;     // activation fragments
     int nt16, n_tokens;
+    int x1;              // prompt precision mode fp16x1 (qgemm2_kernel): only the hi half of every activation is multiplied
     float *out;          // [N][ldo]
     int ldo;
     const float *resid;  // optional [N][ldo]: out = resid + y

@@ -113,12 +113,14 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
 #pragma unroll
     for (int t = 0; t < NTW; t++) xlane[t] = ((unsigned)min(ttile0 + t, P.nt16 - 1) * 2u * QG_FRAG + (unsigned)lane) * 16u;
     const unsigned xblock = (unsigned)P.nt16 * 2u * QG_FRAG * 16u;
-    auto xload1 = [&](int blk, uint4 (&h)[NTW], uint4 (&l)[NTW]) {
+    // (X1: the single-product precision mode -- the lo halves are neither fetched nor multiplied)
+    auto xload1 = [&](auto x1_tag, int blk, uint4 (&h)[NTW], uint4 (&l)[NTW]) {
+        constexpr bool X1 = decltype(x1_tag)::value;
         const unsigned uo = (unsigned)min(blk, nblocks - 1) * xblock;
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
             h[t] = *reinterpret_cast<const uint4 *>(xsrc + (uo + xlane[t]));
-            l[t] = *reinterpret_cast<const uint4 *>(xsrc + (uo + xlane[t]) + QG_FRAG * 16);
+            if (!X1) l[t] = *reinterpret_cast<const uint4 *>(xsrc + (uo + xlane[t]) + QG_FRAG * 16);
         }
     };
 
@@ -136,16 +138,20 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
     uint32_t sw[IPT], swn[IPT];
     uint4 xh[2][NTW], xl[2][NTW];          // ping-pong: block b of a chunk sits in [b & 1] (QG_KC is even)
     uint4 wf[2][RG];                       // ping-pong: group idx of a chunk sits in [idx & 1]
+    int buf = 0;
+    [[maybe_unused]] int it_ = 0;
+    // The K loop exists as TWO instruction streams chosen once by a uniform test: x = hi + lo (two MFMAs per product, float32-
+    // grade results) and the fp16x1 precision mode (hi only: half the matrix work, activations rounded to 11 bits).
+    auto mainloop = [&](auto x1_tag) {
+    constexpr bool X1 = decltype(x1_tag)::value;
     if (chunk < nchunks) {
         stage_load(chunk, rb, sw);
-        xload1(chunk * QG_KC, xh[0], xl[0]);
+        xload1(x1_tag, chunk * QG_KC, xh[0], xl[0]);
 #pragma unroll
         for (int w = 0; w < 4; w++) stage_store_part(chunk, 0, w, rb, sw);
         stage_load(chunk + P.ksplit < nchunks ? chunk + P.ksplit : chunk, rb, sw);
     }
     __syncthreads();
-    int buf = 0;
-    [[maybe_unused]] int it_ = 0;
     QG2_STAMP(0);
     while (chunk < nchunks) {
         const int nxt = chunk + P.ksplit, nxt2 = nxt + P.ksplit;
@@ -158,7 +164,7 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
         QG2_STAMP(1 + it_ * 8);
 #pragma unroll
         for (int b = 0; b < QG_KC; b++) {
-            xload1(b + 1 < QG_KC ? chunk * QG_KC + b + 1 : (more ? nxt : chunk) * QG_KC, xh[(b + 1) & 1], xl[(b + 1) & 1]);
+            xload1(x1_tag, b + 1 < QG_KC ? chunk * QG_KC + b + 1 : (more ? nxt : chunk) * QG_KC, xh[(b + 1) & 1], xl[(b + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);   // the request stays HERE: a block ahead of its use
 #pragma unroll
             for (int g = 0; g < NG; g++) {
@@ -176,9 +182,11 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
 #pragma unroll
                 for (int q = 0; q < RG; q++)
 #pragma unroll
-                    for (int t = 0; t < NTW; t++)
-                        z[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, wf[idx & 1][q]), __builtin_bit_cast(half8_t, xl[b & 1][t]),
-                                                                        (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    for (int t = 0; t < NTW; t++) {
+                        if (X1) z[q][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                        else z[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, wf[idx & 1][q]), __builtin_bit_cast(half8_t, xl[b & 1][t]),
+                                                                             (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    }
 #pragma unroll
                 for (int q = 0; q < RG; q++)
 #pragma unroll
@@ -216,6 +224,9 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
         buf ^= 1;
         chunk = nxt;
     }
+    };
+    if (P.x1) mainloop(std::true_type{});
+    else mainloop(std::false_type{});
 
     QG2_STAMP(1 + it_ * 8);
     // folded RMSNorm, consumer side: inv of this lane's tokens from the producer's per-block sums of squares (block order:
