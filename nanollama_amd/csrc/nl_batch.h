@@ -198,6 +198,7 @@ struct BNormParams {
     int dim, item0;      // token of workgroup b = item0 + b; its fragment column is b
     uint4 *xf;
     int nt16, q4;
+    float *scale_out;    // [N] or nullptr: norm_prescale(inv) of the token, the pre-scale of the first folded-norm producer
 };
 
 // UPT = 8-slot units per thread (host: dim / 8 <= UPT * blockDim.x).  A thread's units stay in registers
@@ -256,6 +257,7 @@ __global__ void __launch_bounds__(256) bnorm_kernel(BNormParams P) {
     double tot = 0.0;
     for (int k = 0; k < (int)(blockDim.x >> 6); k++) tot += dred[k];
     const float inv = (float)(1.0 / sqrt(tot / (double)n + (double)P.eps));
+    if (P.scale_out && threadIdx.x == 0) P.scale_out[item] = norm_prescale(inv);
 #pragma unroll
     for (int k = 0; k < UPT; k++) {
         const int u = (int)threadIdx.x + k * (int)blockDim.x;
@@ -290,6 +292,7 @@ __global__ void __launch_bounds__(256) bnorm_generic_kernel(BNormParams P) {
     double tot = 0.0;
     for (int k = 0; k < (int)(blockDim.x >> 6); k++) tot += dred[k];
     const float inv = (float)(1.0 / sqrt(tot / (double)n + (double)P.eps));
+    if (P.scale_out && threadIdx.x == 0) P.scale_out[item] = norm_prescale(inv);
     for (int u = threadIdx.x; u < n / 8; u += blockDim.x) {
         const int blk = u >> 2, w = u & 3;
         float v[8];

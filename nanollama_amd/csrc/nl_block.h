@@ -327,12 +327,13 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
         __syncthreads();
         if (ch == 0) BLK_STAMP(13);
         if (wave == 0) {
-            // the eight partials of the pass, merged like position splits (fixed order).  The weights exp(m_w - M) are this
-            // engine's own construct -- the reference has one softmax over all positions -- and use the f32 exponential, as
-            // the split merge of the five-launch plan does (load_x4<PRO_ATTN>): (M, L, o[64]) of the pass
+            // the eight partials of the pass, merged in a fixed order.  The weights exp(m_w - M) are this engine's own
+            // construct -- the reference has one softmax over all positions -- so they use the reference's exponential,
+            // float32(exp(float64)) (go/quant.go:619): p * wgt then differs from exp(s - M) by roundings only, not by the
+            // fast exponential's error (eight lanes of one wavefront: no cost): (M, L, o[64]) of the pass
             const float mw = lane < 8 ? wpart[min(lane, 7) * 68] : -INFINITY;
             const float M = wave_max_f32(mw);
-            const float wgt = lane < 8 ? __expf(mw - M) : 0.f;             // (an empty wavefront: exp(-inf) = 0)
+            const float wgt = (lane < 8 && mw != -INFINITY) ? exp_f64_as_f32(mw - M) : 0.f;   // (an empty wavefront weighs 0)
             const float L = wave_sum_f32(lane < 8 ? wgt * wpart[min(lane, 7) * 68 + 1] : 0.f);
             float ov = 0.f;
 #pragma unroll

@@ -182,6 +182,7 @@ struct nl_engine {
         uint4 *xfrag = nullptr;  // fp16 hi/lo activation fragments of the GEMM being run
         uint4 *xfrag2 = nullptr; // second store: output of the fused gate/up/SwiGLU GEMM, input of down
         double *ssq = nullptr;   // [cap][dim / 64] sums of squares of the residual rows (RMSNorm folded around the prompt GEMMs)
+        float *nscale = nullptr; // [2][cap] per-token power-of-two pre-scales of the folded norm's fragments (norm_prescale, nl_qgemm.h)
         float *kpart = nullptr, *kpart2 = nullptr;  // split-K partial sums (second buffer: up, alive beside gate)
         size_t kpart_cap = 0;    // floats, each
         float *x = nullptr, *qkv = nullptr, *q = nullptr, *g = nullptr, *u = nullptr, *logits = nullptr,
@@ -470,10 +471,21 @@ hipError_t launch_attn(int hd, int gqa, AttnParams P, dim3 grid, hipStream_t st)
     return hipErrorInvalidValue;
 }
 
+// developer knobs of the prompt attention, read ONCE per process and in one place: the workgroup list of batched_step
+// and the launchers below must agree on which kernel runs (a list built for attn_tile16_kernel is not a grid of the f32
+// tile kernel)
+struct AttnKnobs { bool f32_tile, no_tile, no_fin; };
+static const AttnKnobs &attn_knobs() {
+    static const AttnKnobs k{getenv("NL_ATTN_F32") != nullptr,       // the f32-MFMA tile kernel
+                             getenv("NL_NO_ATTN_TILE") != nullptr,   // no tile kernel at all: attn_kernel per token
+                             getenv("NL_NO_ATTN_FIN") != nullptr};
+    return k;
+}
+
 template <int HD, int G>
 void launch_attn_tile_g(const AttnParams &P, int n, int kvs, int nsplit, hipStream_t st) {
     constexpr int QT = AttnTileQT<G>::value;
-    static const bool f32_tile = getenv("NL_ATTN_F32") != nullptr;   // developer knob: the f32-MFMA tile kernel
+    const bool f32_tile = attn_knobs().f32_tile;
     if (f32_tile) hipLaunchKernelGGL((attn_tile_kernel<HD, G, QT>), dim3(kvs, nsplit, (n + QT - 1) / QT), dim3(QT * G * 4), 0, st, P, n);
     else {
         constexpr int QT16 = AttnTile16QT<G>::value;
@@ -1317,6 +1329,7 @@ int batch_alloc(nl_engine *e, nl_engine::Batch &b, int cap_limit = 2048) {
         b.xfrag2 = reinterpret_cast<uint4 *>(raw);
     }
     HIPCK(e, dalloc(&b.ssq, n * (size_t)((c.dim + 63) / 64), &e->bytes_state));
+    HIPCK(e, dalloc(&b.nscale, 2 * n, &e->bytes_state));
     b.kpart_cap = (size_t)16 * QG_TOK * std::max<size_t>(std::max<size_t>(R, c.dim), e->Is);
     HIPCK(e, dalloc(&b.kpart, b.kpart_cap, &e->bytes_state));
     HIPCK(e, dalloc(&b.kpart2, b.kpart_cap, &e->bytes_state));
@@ -1374,7 +1387,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
     int n_live = 0, max_nparts = 0;
     bool kv16_on = false;
     {
-        bool cons = one_stream && n >= 8 && attn_tile_supported(e->gqa) && !getenv("NL_ATTN_F32") && !getenv("NL_NO_ATTN_TILE");
+        bool cons = one_stream && n >= 8 && attn_tile_supported(e->gqa) && !attn_knobs().f32_tile && !attn_knobs().no_tile;
         for (int i = 1; i < n && cons; i++) cons = b.h_meta[b.cap + i] == b.h_meta[b.cap] + i;
         const int kv16_min = getenv("NL_KV16_MIN_TOKENS") ? atoi(getenv("NL_KV16_MIN_TOKENS")) : 256;   // (read per step: a test lowers it)
         kv16_on = cons && n >= kv16_min && b.kv16 != nullptr;
@@ -1418,7 +1431,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
     const int nt16 = ((n + 63) / 64) * 4;
     // position splits any token of this step can see: the attention grids skip the rest (a decode batch at short
     // contexts would otherwise dispatch 15 empty workgroups for every live one)
-    static const bool no_tile = getenv("NL_NO_ATTN_TILE") != nullptr, no_fin = getenv("NL_NO_ATTN_FIN") != nullptr;   // developer knobs
+    const bool no_tile = attn_knobs().no_tile, no_fin = attn_knobs().no_fin;
     int nsplit = 1;
     for (int i = 0; i < n; i++) nsplit = std::max(nsplit, b.h_meta[b.cap + i] / ATT_CH + 1);
     bool consecutive = true;   // positions pos0, pos0 + 1, ...: a prompt
@@ -1450,9 +1463,13 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
     const char *pk = getenv("NL_PREFILL_PRECISION");
     const int x1 = pk && std::string(pk) == "fp16x1" ? 1 : 0;
     const int x1_gemm = x1 || (pk && std::string(pk) == "fp16x1-gemm"), x1_attn = x1 || (pk && std::string(pk) == "fp16x1-attn");   // (developer: one half of the mode)
-    const QGemmParams::NormIn nin_on{b.ssq, D / 64, D, c.rms_eps}, nin_off{nullptr, 0, 0, 0.f};
-    auto norm = [&](const float *w, const PackedMat &next, int item0, int cnt) {
-        BNormParams P{b.x, pend, w, c.rms_eps, D, item0, b.xfrag, ((cnt + 63) / 64) * 4, next.wtype == WT_Q4_0 ? 1 : 0};
+    // (pre-scales: the attention norm's consumer undoes sA and leaves sB for the WO producer; the feed-forward norm's consumer
+    //  undoes sB and leaves sA for the down producer; layer 0's unfolded attention norm leaves the first sB)
+    float *const sA = b.nscale, *const sB = b.nscale + b.cap;
+    const QGemmParams::NormIn nin_attn{b.ssq, D / 64, D, c.rms_eps, sA, sB}, nin_ffn{b.ssq, D / 64, D, c.rms_eps, sB, sA},
+                              nin_off{nullptr, 0, 0, 0.f, nullptr, nullptr};
+    auto norm = [&](const float *w, const PackedMat &next, int item0, int cnt, float *scale_out = nullptr) {
+        BNormParams P{b.x, pend, w, c.rms_eps, D, item0, b.xfrag, ((cnt + 63) / 64) * 4, next.wtype == WT_Q4_0 ? 1 : 0, scale_out};
         const int nu = D / 8;
         if (nu <= 256) hipLaunchKernelGGL(bnorm_kernel<1>, dim3(cnt), dim3(std::min(256, (nu + 63) / 64 * 64)), 0, st, P);
         else if (nu <= 512) hipLaunchKernelGGL(bnorm_kernel<2>, dim3(cnt), dim3(256), 0, st, P);
@@ -1468,13 +1485,13 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
         GemmOut qkv_out{nullptr, nullptr, 1, 0, nullptr};
         bool rope_in_attn = false;
         const bool folded_in = fold && l > 0;      // the previous layer's down GEMM wrote this layer's Q|K|V input
-        if (!folded_in) LCK(norm(L.attn_norm, L.qkv, 0, n));
+        if (!folded_in) LCK(norm(L.attn_norm, L.qkv, 0, n, fold ? sB : nullptr));
         if (!c.qk_norm && qgemm_rope_fits(L.qkv.ntiles, n)) {
             // Q|K|V, RoPE, biases and the KV store in ONE launch (QK-norm needs whole heads: unfused path)
             QGemmParams P{};
             const PackedMat &m = L.qkv;
             P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
-            P.xf = folded_in ? b.xfrag2 : b.xfrag; P.nrm_in = folded_in ? nin_on : nin_off;
+            P.xf = folded_in ? b.xfrag2 : b.xfrag; P.nrm_in = folded_in ? nin_attn : nin_off;
             P.n_tokens = n; P.ldo = (int)R; P.x1 = x1_gemm;
             P.rope = QGemmParams::Rope{b.pos, b.stream, e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride,
                                        L.bq, L.bk, L.bv, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate};
@@ -1548,7 +1565,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
             LCK(hipGetLastError());
         }
         if (fold) {
-            const QGemmParams::NormOut nout{L.ffn_norm, b.xfrag2, b.ssq};
+            const QGemmParams::NormOut nout{L.ffn_norm, b.xfrag2, b.ssq, sB};
             LCK(qg(e, b, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo, nullptr, &nout, x1_gemm));
         } else {
             LCK(qg(e, b, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo, nullptr, nullptr, x1_gemm));
@@ -1563,7 +1580,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
             QGemmParams P{};
             const PackedMat &m = L.gate;
             P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
-            P.xf = fold ? b.xfrag2 : b.xfrag; P.nrm_in = fold ? nin_on : nin_off;
+            P.xf = fold ? b.xfrag2 : b.xfrag; P.nrm_in = fold ? nin_ffn : nin_off;
             P.n_tokens = n; P.ldo = e->Is; P.x1 = x1_gemm;
             P.q1 = L.up.q; P.s1 = L.up.s;
             P.xf_out = fold ? b.xfrag : b.xfrag2; P.out_q4 = L.down.wtype == WT_Q4_0 ? 1 : 0;
@@ -1589,7 +1606,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
         }
         if (fold && l + 1 < c.n_layers) {
             const nl_engine::Layer &Ln = e->layers[l + 1];
-            const QGemmParams::NormOut nout{Ln.attn_norm, b.xfrag2, b.ssq};
+            const QGemmParams::NormOut nout{Ln.attn_norm, b.xfrag2, b.ssq, sA};
             LCK(qg(e, b, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in, &nout, x1_gemm));
         } else {
             LCK(qg(e, b, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in, nullptr, x1_gemm));
@@ -2156,7 +2173,7 @@ int nl_destroy(nl_handle e) {
     if (e->stage) hipFree(e->stage);
     auto batch_free = [](nl_engine::Batch &b) {
         void *bb[] = {b.x, b.qkv, b.q, b.g, b.u, b.logits, b.part_o, b.part_ml, b.tok /* | pos | stream */, b.ids, b.kpart, b.kpart2,
-                      b.xfrag, b.xfrag2, b.ssq, b.kv16};
+                      b.xfrag, b.xfrag2, b.ssq, b.nscale, b.kv16};
         for (void *p : bb) if (p) hipFree(p);
         if (b.h_meta) hipHostFree(b.h_meta);
     };

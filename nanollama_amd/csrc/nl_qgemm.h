@@ -83,12 +83,15 @@ struct QGemmParams {
         const float *w;      // [rows] norm weights of the consuming GEMM; nullptr = not folded
         uint4 *xf;           // fragment store the consumer reads
         double *ssq;         // [n_tokens][rows / 64]
+        const float *scale;  // [n_tokens] exact power of two the fragments are multiplied by (norm_prescale below); nullptr = 1
     } nrm_out;               // (the consumer is a Q4_0 GEMM of nl_qgemm2.h: Q4_0 k-slot order)
     struct NormIn {
         const double *ssq;   // nullptr = the input fragments are already normalised
         int nrb;             // partial sums per token (dim / 64)
         int dim;
         float eps;
+        const float *scale;  // the power of two the producer multiplied this token's fragments by (undone through inv); nullptr = 1
+        float *scale_next;   // written by the workgroups of row block 0: the pre-scale of the NEXT producer, from this inv
     } nrm_in;
 };
 
@@ -180,6 +183,17 @@ template <> struct WFrag<WT_F16> {
 
 // the scale word of (tile, pair, row i) holds both blocks' fp16 d: s[(tile*npairs + g*KL)*TR + i*gsz + k]; scale_of() picks one
 __device__ __forceinline__ float scale_of(uint32_t word, int blk) { return h2f_bits((word >> (16 * (blk & 1))) & 0xffff); }
+
+// The folded RMSNorm hands x * g to its consumer BEFORE 1 / rms is known, as fp16 hi / lo fragments.  fp16 has 5 exponent
+// bits: a residual stream of rms 1e-3 would put every lo half into the denormals (absolute 2^-25 instead of relative 2^-22)
+// and one of rms 1e5 would overflow to inf - inf.  So the producer multiplies by an EXACT power of two close to 1 / rms -- the
+// largest one not above the inv of the token's previous norm (the stream's rms moves by a small factor from one norm to the
+// next) -- and the consumer divides its inv by the same power: both are exact, so for streams that were in range anyway the
+// results are bit-identical to the unscaled form.
+__device__ __forceinline__ float norm_prescale(float inv) {
+    const unsigned e = (__float_as_uint(inv) >> 23) & 0xffu;
+    return __uint_as_float((unsigned)min(max((int)e, 127 - 100), 127 + 100) << 23);     // 2^floor(log2 inv), kept inside 2^+-100
+}
 
 // x = hi + lo, two fp16 values (~2^-22 relative).  The f32 value is pinned in a register first: when v is a
 // product the compiler otherwise derives hi TWICE -- once as cvt(f32 product) for the store, once as

@@ -97,13 +97,24 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
         }
     };
     // one quarter of the expansion (fragment w of every item; the scale with fragment 0): spread over the chunk's four blocks
-    auto stage_store_part = [&](int chunk, int buf, int w, const RowBlock<WT> (&rb)[IPT], const uint32_t (&sw)[IPT]) {
+    // (X1, the single-product precision mode: the block scale is multiplied into the fp16 weight fragment here, once per
+    //  workgroup and chunk, so the K loop is a bare MFMA chain -- no per-block "* d" on the vector pipe.  (n - 8) * d rounded to
+    //  fp16 costs 2^-12 relative per weight, the size of the mode's activation rounding.)
+    auto stage_store_part = [&](auto x1_tag, int chunk, int buf, int w, const RowBlock<WT> (&rb)[IPT], const uint32_t (&sw)[IPT]) {
+        constexpr bool X1 = decltype(x1_tag)::value;
 #pragma unroll
         for (int k = 0; k < IPT; k++) {
             if (!item_live(k)) continue;
             const int it = tid + k * NTHR, s_row = it % ROWS, s_blk = it / ROWS, s_i = s_row & 15, s_rt = s_row >> 4;
-            wfrag[buf][s_blk][s_rt][w * 16 + s_i] = __builtin_bit_cast(uint4, rb[k].frag(w));
-            if (w == 0) wsc[buf][s_blk][s_row] = chunk * QG_KC + s_blk < nblocks ? scale_of(sw[k], chunk * QG_KC + s_blk) : 0.f;   // a block past the end of K contributes nothing
+            const float d = chunk * QG_KC + s_blk < nblocks ? scale_of(sw[k], chunk * QG_KC + s_blk) : 0.f;   // a block past the end of K contributes nothing
+            half8_t f = rb[k].frag(w);
+            if (X1) {
+                const _Float16 dh = (_Float16)d;        // (d is an fp16 value: exact)
+#pragma unroll
+                for (int e = 0; e < 8; e++) f[e] = f[e] * dh;
+            }
+            wfrag[buf][s_blk][s_rt][w * 16 + s_i] = __builtin_bit_cast(uint4, f);
+            if (!X1 && w == 0) wsc[buf][s_blk][s_row] = d;
         }
     };
     // activation fragments of this wavefront's token tiles: [block][tile][hi/lo][lane] x 16 B.  Addresses are "kernel
@@ -148,7 +159,7 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
         stage_load(chunk, rb, sw);
         xload1(x1_tag, chunk * QG_KC, xh[0], xl[0]);
 #pragma unroll
-        for (int w = 0; w < 4; w++) stage_store_part(chunk, 0, w, rb, sw);
+        for (int w = 0; w < 4; w++) stage_store_part(x1_tag, chunk, 0, w, rb, sw);
         stage_load(chunk + P.ksplit < nchunks ? chunk + P.ksplit : chunk, rb, sw);
     }
     __syncthreads();
@@ -176,17 +187,24 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
 #pragma unroll
                     for (int q = 0; q < RG; q++) wf[(idx + 1) & 1][q] = wfrag[buf][b1][g1 * RG + q][lane];
                 }
+                if constexpr (X1) {
+                    // scaled weights: the products accumulate across blocks inside the MFMA accumulators
+#pragma unroll
+                    for (int q = 0; q < RG; q++)
+#pragma unroll
+                        for (int t = 0; t < NTW; t++)
+                            acc[r0 + q][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, wf[idx & 1][q]), __builtin_bit_cast(half8_t, xh[b & 1][t]),
+                                                                                  acc[r0 + q][t], 0, 0, 0);
+                } else {
                 f32x4_t z[RG][NTW];
                 // the lo-part MFMAs of the group, then the hi-part MFMAs: each dependent pair is four issues apart, so no
                 // MFMA waits for its predecessor's accumulator
 #pragma unroll
                 for (int q = 0; q < RG; q++)
 #pragma unroll
-                    for (int t = 0; t < NTW; t++) {
-                        if (X1) z[q][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                        else z[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, wf[idx & 1][q]), __builtin_bit_cast(half8_t, xl[b & 1][t]),
-                                                                             (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    }
+                    for (int t = 0; t < NTW; t++)
+                        z[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, wf[idx & 1][q]), __builtin_bit_cast(half8_t, xl[b & 1][t]),
+                                                                        (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
                 for (int q = 0; q < RG; q++)
 #pragma unroll
@@ -204,13 +222,14 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
                         acc[r0 + q][t] = (f32x4_t){lo[0], lo[1], hi[0], hi[1]};
                     }
                 }
+                }
                 // Pin the updated accumulators here: instruction selection otherwise sinks every "* d" FMA of the chunk
                 // below its 64 MFMAs and keeps 128 result registers live (occupancy 2 instead of 4).
 #pragma unroll
                 for (int q = 0; q < RG; q++)
 #pragma unroll
                     for (int t = 0; t < NTW; t++) asm volatile("" : "+v"(acc[r0 + q][t]));
-                if (g == NG - 1 && more) stage_store_part(nxt, buf ^ 1, b, rb, sw);   // the other buffer: nobody reads it during this chunk
+                if (g == NG - 1 && more) stage_store_part(x1_tag, nxt, buf ^ 1, b, rb, sw);   // the other buffer: nobody reads it during this chunk
                 __builtin_amdgcn_sched_barrier(0);
             }
             QG2_STAMP(2 + it_ * 8 + b);
@@ -248,6 +267,16 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
                     for (int k = 0; k < 8; k++) tot += r0 + k < P.nrm_in.nrb ? v[k] : 0.0;
                 }
                 inv[t] = (float)(1.0 / sqrt(tot / (double)P.nrm_in.dim + (double)P.nrm_in.eps));
+            }
+            if (P.nrm_in.scale) {     // the producer's power-of-two pre-scale (norm_prescale, nl_qgemm.h): undone exactly
+                float sc[NTW];
+#pragma unroll
+                for (int t = 0; t < NTW; t++) sc[t] = P.nrm_in.scale[min((ttile0 + t) * 16 + li, P.n_tokens - 1)];
+#pragma unroll
+                for (int t = 0; t < NTW; t++) {
+                    if (blockIdx.x == 0 && lq == 0) P.nrm_in.scale_next[min((ttile0 + t) * 16 + li, P.n_tokens - 1)] = norm_prescale(inv[t]);
+                    inv[t] *= 1.0f / sc[t];
+                }
             }
 #pragma unroll
             for (int rt = 0; rt < RT; rt++)
@@ -385,6 +414,9 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
                 float4 gw[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) gw[rt] = *reinterpret_cast<const float4 *>(P.nrm_out.w + row0 + rt * TR + lq * 4);
+                float psc[NTW];      // exact power of two near 1 / rms of the token (norm_prescale, nl_qgemm.h)
+#pragma unroll
+                for (int t = 0; t < NTW; t++) psc[t] = P.nrm_out.scale ? P.nrm_out.scale[min((ttile0 + t) * 16 + li, P.n_tokens - 1)] : 1.0f;
 #pragma unroll
                 for (int t = 0; t < NTW; t++) {
                     const int n = (ttile0 + t) * 16 + li;
@@ -402,8 +434,8 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
 #pragma unroll
                         for (int r = 0; r < 2; r++) {
                             const float4 g = gw[2 * b + r];
-                            y[r][0] = acc[2 * b + r][t][0] * g.x; y[r][1] = acc[2 * b + r][t][1] * g.y;
-                            y[r][2] = acc[2 * b + r][t][2] * g.z; y[r][3] = acc[2 * b + r][t][3] * g.w;
+                            y[r][0] = (acc[2 * b + r][t][0] * g.x) * psc[t]; y[r][1] = (acc[2 * b + r][t][1] * g.y) * psc[t];
+                            y[r][2] = (acc[2 * b + r][t][2] * g.z) * psc[t]; y[r][3] = (acc[2 * b + r][t][3] * g.w) * psc[t];
                         }
                         // (the consumer is a qgemm2 GEMM, i.e. Q4_0: k-slot group lq = this lane's float4 groups of the two tiles)
                         float v[8];

@@ -44,6 +44,7 @@ class Engine:
         self.rng = np.random.default_rng(seed)
         self.device_sampling = device_sampling   # False: read the logits back and sample on the host every token
         self.sample_chunk = sample_chunk         # tokens per nl_sample_decode call (steps after an EOS are wasted)
+        self.greedy_chunk = 64                   # tokens per nl_decode_greedy call (four 16-step graph segments)
         self.last_tok_per_s = 0.0
         self.last_tokens = 0
 
@@ -107,16 +108,20 @@ class Engine:
             nxt = argmax(m.state.logits, cfg.vocab_size)
             out.append(nxt)
             n = min(p.max_tokens - 1, cfg.seq_len - 1 - pos)
-            if nxt != self.eos_id and n > 0:
-                for t in m.decode_greedy(nxt, pos, n):
+            # decoded in chunks (whole 16-step graph segments) so that an EOS or the output cap (on_token -> True:
+            # `len(output) < 8192` fails before the next sample, go/main.go:173) ends the device work within one chunk:
+            # the timer below and the device's KV / position state stop where the Go loop stops, give or take a chunk
+            stop = nxt == self.eos_id or bool(on_token and on_token(nxt))
+            while not stop and n > 0:
+                ids = m.decode_greedy(nxt, pos, min(n, self.greedy_chunk))
+                for t in ids:
                     out.append(t)
-                    if t == self.eos_id:
+                    if t == self.eos_id or (on_token and on_token(t)):
+                        stop = True
                         break
-            if on_token:
-                for k, t in enumerate(out):
-                    if t != self.eos_id and on_token(t):
-                        del out[k + 1:]               # the loop condition fails before the next sample
-                        break
+                if not ids:
+                    break
+                nxt, pos, n = ids[-1], pos + len(ids), n - len(ids)
             recent = out[-self.rep_window:] if self.rep_window > 0 else []
         elif device_sampling:
             # the same loop with penalty, sampling and the recent window on the device (nl_sample_decode): no

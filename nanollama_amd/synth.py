@@ -184,9 +184,11 @@ def _draw_qrand(shape: ModelShape, seed: int, ckpt_name: str, tshape, kind: str,
 
 
 def generate_gguf(path: str, shape: ModelShape, wtype: str = "q8_0", seed: Optional[int] = None,
-                  mode: str = "float", keep_float: bool = False) -> Dict[str, np.ndarray]:
+                  mode: str = "float", keep_float: bool = False, stream_scale: float = 1.0) -> Dict[str, np.ndarray]:
     """Write a random-weight GGUF.  Returns {gguf_name: float32 weights} when
-    keep_float (test-sized models only)."""
+    keep_float (test-sized models only).  stream_scale (float mode): the embedding and the two projections that write the
+    residual stream (attention output, down) are multiplied by it -- a model whose residual stream lives at that magnitude
+    while everything behind an RMSNorm stays O(1)."""
     t = WTYPES[wtype]
     if seed is None:
         seed = TIER_SEED.get(shape.name, 4242)
@@ -228,6 +230,8 @@ def generate_gguf(path: str, shape: ModelShape, wtype: str = "q8_0", seed: Optio
             w.add_tensor_raw(gname, _draw_qrand(shape, seed, ckpt, tshape, kind, t), t, tshape)
             continue
         f32 = draw_float(shape, seed, ckpt, tshape, kind)
+        if stream_scale != 1.0 and (kind == "embedding" or ckpt.endswith(("attn.c_proj.weight", "ffn.down_proj.weight"))):
+            f32 = (f32 * np.float32(stream_scale)).astype(np.float32)
         w.add_tensor_raw(gname, quant.encode(f32, t), t, tshape)
         if keep_float:
             floats[gname] = f32

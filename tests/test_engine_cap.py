@@ -86,3 +86,19 @@ def test_without_a_cap_all_tokens_are_emitted():
     for mode in ("greedy", "device", "host"):
         ids, seen, last, _ = _run(mode, None, max_tokens=20)
         assert len(ids) == 20 and seen == ids and last == 6
+
+
+def test_greedy_path_stops_the_device_within_a_chunk_of_the_cap():
+    # (advisor, round 3) the greedy fast path used to run all max_tokens steps and truncate afterwards: the rate was
+    # understated and the device state ran past where the Go loop stops
+    m = FakeModel()
+    eng = Engine(m, rep_penalty=1.0, eos_id=-1, rep_window=6, seed=11)
+    eng.greedy_chunk = 16
+    seen = []
+    ids = eng.generate_ids([1, 2, 3], GenParams(max_tokens=200, temperature=0.0),
+                           on_token=lambda t: seen.append(t) or len(seen) >= 20)
+    assert len(ids) == 20 and seen == ids
+    assert m.forwards <= 19 + 16                # sample_0 from the prefill, then at most one chunk beyond the 19 kept steps
+    full = Engine(FakeModel(), rep_penalty=1.0, eos_id=-1, rep_window=6, seed=11).generate_ids(
+        [1, 2, 3], GenParams(max_tokens=200, temperature=0.0))
+    assert len(full) == 200 and full[:20] == ids

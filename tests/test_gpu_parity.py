@@ -837,6 +837,41 @@ def test_prompt_with_rmsnorm_folded_into_the_gemms_matches_oracle(hip, orc, tmp_
     ref.close()
 
 
+@pytest.mark.parametrize("stream_scale", [2.0 ** -6, 2.0 ** 15])
+def test_folded_rmsnorm_at_small_and_large_residual_magnitudes(hip, orc, tmp_path, monkeypatch, stream_scale):
+    # (advisor, round 3) the folded norm hands x * g to the consumer as fp16 hi / lo fragments BEFORE 1 / rms is known.  A
+    # residual stream of rms ~1e-2 puts every lo half into the fp16 denormals (absolute instead of relative precision; smaller
+    # still and RMSNorm's eps takes the model over), one of rms ~3e4
+    # has elements beyond 65504 (inf - inf = NaN).  The producer therefore pre-scales by an exact power of two near the
+    # token's previous 1 / rms (norm_prescale, nl_qgemm.h) and the consumer divides it out of inv: same tolerance against
+    # the oracle as at magnitude 1, and as close to the unfolded path as there.
+    shape = synth.ModelShape("fold_mag", 3, 512, 8, 4, 1024, seq_len=1200, interm=1536, tied=False)
+    p = tmp_path / "f.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", 31, stream_scale=stream_scale)
+    g = gguf.load_gguf(str(p))
+    n = 1100                                   # (every GEMM grid >= 128 workgroups: the folding condition)
+    toks = synth.prompt_ids(n, shape.vocab, seed=8)
+    ref = orc.OracleModel(g)
+    orc.set_threads(min(16, os.cpu_count() or 1))
+    for pos, t in enumerate(toks):
+        want = ref.forward(t, pos).copy()
+    orc.set_threads(1)
+    ref.close()
+    scale = max(1.0, float(want.std()))
+    outs = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("NL_FOLD_NORM", knob)
+        dev = hip.load_llama_model(g)
+        dev.prefill(toks)
+        outs[knob] = dev.state.logits.copy()
+        dev.close()
+        assert np.isfinite(outs[knob]).all(), knob
+        err = float(np.abs(outs[knob] - want).max())
+        print(f"\nfolded norm, stream x {stream_scale:g}, NL_FOLD_NORM={knob}: max|gpu-oracle|={err:.2e} (logit std {scale:.2f})")
+        assert err <= LOGIT_TOL * scale
+    assert not np.array_equal(outs["1"], outs["0"])          # (the folded path is the one that ran)
+
+
 def test_mini_full_size_long_prefill_matches_oracle(hip, orc, tmp_path, monkeypatch):
     # BASELINE.json configs[2] at its own shape (mini, 173M, Q4_0): a 1920-token prompt through the matrix-core
     # path in ONE step vs the CPU oracle fed token by token (1920 prompt positions for parity), then a
