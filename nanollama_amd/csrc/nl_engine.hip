@@ -2293,9 +2293,9 @@ hipError_t samp_alloc(SampScratch &s, int vocab, int n_uniforms) {
     if (samp_chunk(vocab) > 128) return hipErrorInvalidValue;   // vocab > 131072
     const int nblocks = (vocab + 255) / 256;
 #define SA(ptr, count) if ((rc = hipMalloc((void **)&(ptr), (size_t)(count) * 4)) != hipSuccess) return rc
-    SA(s.keys_in, vocab); SA(s.keys_out, SAMP_THREADS * samp_chunk(vocab)); SA(s.idx_in, vocab); SA(s.idx_out, vocab);
+    SA(s.keys_in, SAMP_THREADS * samp_chunk(vocab)); SA(s.keys_out, SAMP_THREADS * samp_chunk(vocab)); SA(s.idx_in, vocab); SA(s.idx_out, vocab);   // (whole lane chunks: the select kernels load past vocab and mask)
     if ((rc = hipMemset(s.keys_out, 0, (size_t)SAMP_THREADS * samp_chunk(vocab) * 4)) != hipSuccess) return rc;  // zero tail past vocab
-    SA(s.partial, nblocks); SA(s.scal, 4); SA(s.uniforms, std::max(n_uniforms, 1)); SA(s.recent, SAMP_THREADS); SA(s.recent_n, 1);
+    SA(s.partial, nblocks); SA(s.scal, 4); SA(s.pmax, nblocks); SA(s.uniforms, std::max(n_uniforms, 1)); SA(s.recent, SAMP_THREADS); SA(s.recent_n, 1);
 #undef SA
     if ((rc = rocprim::radix_sort_pairs_desc(nullptr, s.sort_tmp_bytes, s.keys_in, s.keys_out, s.idx_in, s.idx_out,
                                              (unsigned)vocab, 0, 32, (hipStream_t)0)) != hipSuccess) return rc;
@@ -2303,21 +2303,32 @@ hipError_t samp_alloc(SampScratch &s, int vocab, int n_uniforms) {
 }
 
 void samp_free(SampScratch &s) {
-    void *p[] = {s.keys_in, s.keys_out, s.idx_in, s.idx_out, s.partial, s.scal, s.uniforms, s.recent, s.recent_n, s.sort_tmp};
+    void *p[] = {s.keys_in, s.keys_out, s.idx_in, s.idx_out, s.partial, s.scal, s.pmax, s.uniforms, s.recent, s.recent_n, s.sort_tmp};
     for (void *q : p) if (q) (void)hipFree(q);
     s = SampScratch{};
 }
 
 // one sampling decision on `logits` (device); advances ctl / ids / the recent window
 hipError_t launch_sample(const SampScratch &s, float *logits, int vocab, const nl_sample_params &p, int *ctl, int *ids,
-                         hipStream_t st) {
+                         hipStream_t st, const EmbedParams *emb = nullptr) {
     SampleParams P{};
+    if (emb) { P.embed = 1; P.emb = *emb; }
     P.logits = logits; P.vocab = vocab; P.temp = p.temperature; P.top_p = p.top_p; P.top_k = std::max(p.top_k, 1);
     P.rep_penalty = p.rep_penalty; P.recent = s.recent; P.recent_n = s.recent_n; P.rep_window = p.rep_window;
     P.uniforms = s.uniforms; P.ctl = ctl; P.ids = ids;
     P.keys_in = s.keys_in; P.keys_out = s.keys_out; P.idx_in = s.idx_in; P.idx_out = s.idx_out;
-    P.partial = s.partial; P.scal = s.scal; P.nblocks = (vocab + 255) / 256;
-    hipLaunchKernelGGL(samp_penalty_kernel, dim3(1), dim3(SAMP_THREADS), 0, st, P);
+    P.partial = s.partial; P.scal = s.scal; P.pmax = s.pmax; P.nblocks = (vocab + 255) / 256;
+    // top-p up to 65536 candidates: weighted radix selection in one launch, no sort (nl_sample.h).  NL_SAMP_SORT=1 keeps the
+    // sorted path (developer A/B; read once)
+    static const bool force_sort = getenv("NL_SAMP_SORT") && atoi(getenv("NL_SAMP_SORT")) != 0;
+    P.radix = p.temperature > 0.f && p.top_p < 1.0f && samp_chunk(vocab) <= 64 && !force_sort ? 1 : 0;
+    hipLaunchKernelGGL(samp_penalty_kernel, dim3(P.nblocks), dim3(256), 0, st, P);
+    if (P.radix) {
+        hipLaunchKernelGGL(samp_prob_kernel, dim3(P.nblocks), dim3(256), 0, st, P);
+        if (samp_chunk(vocab) == 32) hipLaunchKernelGGL(samp_select_radix_kernel<32>, dim3(1), dim3(SAMP_THREADS), 0, st, P);
+        else hipLaunchKernelGGL(samp_select_radix_kernel<64>, dim3(1), dim3(SAMP_THREADS), 0, st, P);
+        return hipGetLastError();
+    }
     if (p.temperature > 0.f) {
         hipLaunchKernelGGL(samp_prob_kernel, dim3(P.nblocks), dim3(256), 0, st, P);
         size_t tmp = s.sort_tmp_bytes;
@@ -2394,9 +2405,19 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
                 if (e->samp_graph[k]) { hipGraphDestroy(e->samp_graph[k]); e->samp_graph[k] = nullptr; }
                 hipError_t cs = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
                 int rc2 = NL_OK;
+                // one GPU: the launch that picks the token also fetches its embedding row, and the plan's own embed and
+                // argmax launches (the argmax of logits nobody reads) are left out of the graph -- two launches per token
+                const bool tail = e->G == 1 && !e->p2p.on && !e->force_tp_plan && !getenv("NL_NO_SAMPLE_EMBED");
                 for (int q = 0; cs == hipSuccess && q < e->graph_steps && !rc2; q++) {
-                    if (launch_sample(s, e->logits, e->cfg.vocab, *p, e->ctl, e->ids, e->stream) != hipSuccess) rc2 = NL_ERR_HIP;
-                    else rc2 = run_plan_eager(e, e->ps[k]);
+                    if (launch_sample(s, e->logits, e->cfg.vocab, *p, e->ctl, e->ids, e->stream, tail ? &e->plan_embed : nullptr) != hipSuccess) rc2 = NL_ERR_HIP;
+                    else if (!tail) rc2 = run_plan_eager(e, e->ps[k]);
+                    else {
+                        for (const Op &op : e->ps[k].ops) {
+                            if (op.kind == K_EMBED || op.kind == K_ARGMAX) continue;
+                            const hipError_t ls = op.fn(e->stream);
+                            if (ls != hipSuccess) { rc2 = e->fail(NL_ERR_HIP, "launch %s: %s", kKindNames[op.kind], hipGetErrorString(ls)); break; }
+                        }
+                    }
                 }
                 hipGraph_t g = nullptr;
                 if (cs == hipSuccess) cs = hipStreamEndCapture(e->stream, &g);

@@ -14,6 +14,18 @@
 // the Go loop does; the top-p path adds V terms in fixed chunks (1024 contiguous chunks, each summed left to right,
 // chunk totals accumulated left to right) -- deterministic, but not the Go loop's single left-to-right chain, so a
 // u within ~1e-7 of a cdf boundary can select the neighbouring candidate.
+//
+// Round 4: top-p for vocabularies up to 65536 needs NO sort.  Both questions the Go loop asks of the sorted list -- where
+// does the cumulative probability reach top_p, and where does it reach r = u * cumsum -- are weighted rank selections, and
+// samp_select_radix_kernel answers them by radix selection on the bits of p (three histogram levels of 11 + 11 + 10 bits,
+// each bucket holding the SUM of its candidates' weights) inside one workgroup that keeps the candidates in registers.
+// Weights are exact integers, W_i = floor(p_i * 2^45), so sums do not depend on the order of addition (LDS atomics stay
+// deterministic) and every cumulative value is the exact sum of the float32 p_i (to 2^-45 each), not a float32 chain:
+//   cut  = first j (p descending, equal p by ascending id) with CDF_j >= ceil(top_p * TOTAL)
+//   pick = first j with CDF_j >= max(1, ceil(u * CDF_cut))
+// -- the Go conditions `cum >= topP` and `r <= cdf` on the unnormalised, exactly summed weights.  tests/sampling_mirror.py
+// (device_top_p) restates it with Python integers and the device is held to it exactly; against the literal Go chain the
+// picks are equal except for a u within float32 rounding of a cdf boundary, as before.
 #pragma once
 #include "nl_kernels.h"
 
@@ -35,58 +47,59 @@ struct SampleParams {
     float *keys_in, *keys_out;
     int *idx_in, *idx_out;
     float *partial;       // [nblocks of samp_prob_kernel]
-    float *scal;          // [0] = max logit after the penalty
+    float *scal;          // (spare scalars)
+    float *pmax;          // [nblocks] workgroup maxima of the penalised logits (samp_penalty_kernel)
     int nblocks;
+    int radix;            // top-p by radix selection (samp_select_radix_kernel): keys_in = p, nothing else is prepared
+    int embed;            // the select launch also writes the picked token's embedding row (emb): the next Forward then starts
+    EmbedParams emb;      //   at its first layer, as the chained greedy graph does with argmax_embed_kernel
 };
+
+// the embedding lookup that opens the next Forward (embed_kernel), by the workgroup that picked the token
+__device__ __forceinline__ void samp_embed_tail(const SampleParams &P, int token) {
+    if (!P.embed) return;
+    const EmbedParams &E = P.emb;
+    if (E.epoch && threadIdx.x == 0) *E.epoch = *E.epoch + 1;            // the forward counter, as embed_kernel advances it
+    const int gr = E.gamma_row ? E.gamma_row[token] : -1;
+    for (int i = threadIdx.x; i < E.dim; i += blockDim.x) {
+        float v = embed_value(E.table, E.wtype, E.dim, token, i);
+        if (gr >= 0) v += E.gamma_val[(long long)gr * E.dim + i];
+        E.x[i] = v;
+    }
+}
 
 // device scratch of one sampler (one vocabulary)
 struct SampScratch {
-    float *keys_in = nullptr, *keys_out = nullptr, *partial = nullptr, *scal = nullptr, *uniforms = nullptr;
+    float *keys_in = nullptr, *keys_out = nullptr, *partial = nullptr, *scal = nullptr, *pmax = nullptr, *uniforms = nullptr;
     int *idx_in = nullptr, *idx_out = nullptr, *recent = nullptr, *recent_n = nullptr;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
 };
 
-// 1 workgroup: repetition penalty, then the maximum logit
-__global__ void __launch_bounds__(SAMP_THREADS) samp_penalty_kernel(SampleParams P) {
-    __shared__ float red[SAMP_THREADS / 64];
+// vocab / 256 workgroups: repetition penalty on the workgroup's own 256 logits (every workgroup reads the window and
+// counts the occurrences of its own ids: the penalty of a token depends on its own logit and its count only, and x / p,
+// x * p keep the sign, so "once per occurrence in window order" is "count times"), then the workgroup's maximum
+__global__ void __launch_bounds__(256) samp_penalty_kernel(SampleParams P) {
+    __shared__ float red[4];
     __shared__ int win[SAMP_THREADS];
-    const int tid = threadIdx.x, n = *P.recent_n;
-    // the maximum scan's loads do not depend on the penalty: issue the first batch now
-    float m = -INFINITY;
+    const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+    const int n = sload_i32(P.recent_n);
+    float v = P.logits[min(i, P.vocab - 1)];
     if (P.rep_penalty > 1.0f && n > 0) {
-        if (tid < n) win[tid] = P.recent[tid];
+        for (int s = tid; s < n; s += 256) win[s] = P.recent[s];
         __syncthreads();
-        if (tid < n) {
-            const int tok = win[tid];
-            if (tok >= 0 && tok < P.vocab) {
-                bool first = true;
-                for (int s = 0; s < tid; s++) first = first && win[s] != tok;
-                if (first) {
-                    int count = 0;
-                    for (int s = tid; s < n; s++) count += win[s] == tok;
-                    float v = P.logits[tok];
-                    for (int c = 0; c < count; c++) v = v > 0.f ? v / P.rep_penalty : v * P.rep_penalty;
-                    P.logits[tok] = v;
-                }
-            }
+        int count = 0;
+        for (int s = 0; s < n; s++) count += win[s] == i ? 1 : 0;
+        if (count && i < P.vocab) {
+            for (int c = 0; c < count; c++) v = v > 0.f ? v / P.rep_penalty : v * P.rep_penalty;
+            P.logits[i] = v;
         }
     }
-    __syncthreads();   // (orders the penalty stores before the scan below; same workgroup)
-    for (int i0 = tid; i0 < P.vocab; i0 += 8 * SAMP_THREADS) {   // 8 independent loads per round (clamped, masked)
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = P.logits[min(i0 + k * SAMP_THREADS, P.vocab - 1)];
-#pragma unroll
-        for (int k = 0; k < 8; k++) m = i0 + k * SAMP_THREADS < P.vocab ? fmaxf(m, v[k]) : m;
-    }
+    float m = i < P.vocab ? v : -INFINITY;
     m = wave_max_f32(m);
     if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < SAMP_THREADS / 64; w++) m = fmaxf(m, red[w]);
-        P.scal[0] = m;
-    }
+    if (tid == 0) P.pmax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // sort keys: top-p mode = unnormalised probabilities (+ per-workgroup partial sums), top-k mode = the logits
@@ -95,15 +108,25 @@ __global__ void __launch_bounds__(256) samp_prob_kernel(SampleParams P) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool top_p_mode = P.top_p < 1.0f;
     float key = 0.f;
+    const float l = P.logits[min(i, P.vocab - 1)];
+    float gmax = -INFINITY;
+    if (top_p_mode) {
+        // the maximum over the workgroup maxima of samp_penalty_kernel (nblocks <= 512)
+        const float m0 = P.pmax[min((int)threadIdx.x, P.nblocks - 1)], m1 = P.pmax[min((int)threadIdx.x + 256, P.nblocks - 1)];
+        gmax = wave_max_f32(fmaxf(m0, m1));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gmax;
+        __syncthreads();
+        gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+    }
     if (i < P.vocab) {
-        const float l = P.logits[i];
-        key = top_p_mode ? (float)exp((double)((l - P.scal[0]) / P.temp)) : l;
+        key = top_p_mode ? (float)exp((double)((l - gmax) / P.temp)) : l;
         P.keys_in[i] = key;
-        P.idx_in[i] = i;
+        if (!P.radix) P.idx_in[i] = i;
     } else if (top_p_mode) {
         key = 0.f;
     }
-    if (top_p_mode) {
+    if (top_p_mode && !P.radix) {
         float s = i < P.vocab ? key : 0.f;
         s = wave_sum_f32(s);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -247,6 +270,7 @@ __global__ void __launch_bounds__(SAMP_THREADS) samp_select_kernel(SampleParams 
     }
     __syncthreads();
     pick = s_pick;
+    samp_embed_tail(P, pick);
     // recent window: append, drop the oldest when full (go/main.go:197-200)
     const int n = *P.recent_n;
     int shifted = 0;
@@ -267,6 +291,307 @@ __global__ void __launch_bounds__(SAMP_THREADS) samp_select_kernel(SampleParams 
         P.ctl[CTL_TOKEN] = pick;
         P.ctl[CTL_POS] = P.ctl[CTL_POS] + 1;
     }
+}
+
+// ---- top-p without a sort: weighted radix selection in one workgroup -----------------------------------------------
+typedef unsigned long long samp_u64;
+
+// exact ceil(f * x) for a float32 0 <= f <= 1 (f = m * 2^(e - 150), m < 2^24; m * x < 2^88)
+__device__ __forceinline__ samp_u64 samp_ceil_mul(float f, samp_u64 x) {
+    const unsigned bits = __float_as_uint(f);
+    int e = (int)((bits >> 23) & 0xffu);
+    unsigned m = bits & 0x7fffffu;
+    if (e == 0) { if (m == 0) return 0; e = 1; } else m |= 0x800000u;
+    const int s = 150 - e;                                  // >= 23 for f <= 1
+    const unsigned __int128 prod = (unsigned __int128)m * x;
+    if (s >= 100) return prod ? 1 : 0;
+    return (samp_u64)((prod + ((((unsigned __int128)1) << s) - 1)) >> s);
+}
+
+// weight of a candidate: floor(p * 2^45) (p <= 1: at most 2^45; 131072 of them stay below 2^63), from the bits of p --
+// p = m * 2^(e - 150), so the weight is m shifted by e - 105 (integer shifts: a float64 product costs ten times as much
+// on the one compute unit that runs the selection)
+__device__ __forceinline__ samp_u64 samp_weight(unsigned key) {
+    const int e = (int)((key >> 23) & 0xffu);
+    const samp_u64 m = (samp_u64)((key & 0x7fffffu) | 0x800000u);
+    const int sh = e - 105;                                  // (e = 0, zero / denormal p: far below 2^-45, weight 0)
+    return sh >= 0 ? m << (sh & 63) : (sh > -24 ? m >> ((-sh) & 63) : 0ull);
+}
+
+__device__ __forceinline__ samp_u64 samp_shfl_up_u64(samp_u64 v, int d) {
+    const unsigned lo = __shfl_up((unsigned)v, d), hi = __shfl_up((unsigned)(v >> 32), d);
+    return ((samp_u64)hi << 32) | lo;
+}
+
+// inclusive prefix sum over the 64 lanes on DPP (four in-row shifts, two cross-row broadcasts; hipcc lowers __shfl_up to
+// ds_bpermute, ~130 cycles a hop and twelve hops for a 64-bit scan)
+template <int CTRL, int ROWMASK, bool BOUND>
+__device__ __forceinline__ samp_u64 samp_dpp_u64(samp_u64 v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROWMASK, 0xF, BOUND);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROWMASK, 0xF, BOUND);
+    return ((samp_u64)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ samp_u64 samp_wave_scan_u64(samp_u64 v) {
+    v += samp_dpp_u64<0x111, 0xF, true>(v);                 // row_shr:1 (lanes shifted in from outside the row: 0)
+    v += samp_dpp_u64<0x112, 0xF, true>(v);
+    v += samp_dpp_u64<0x114, 0xF, true>(v);
+    v += samp_dpp_u64<0x118, 0xF, true>(v);
+    v += samp_dpp_u64<DPP_ROW_BCAST15, 0xA, false>(v);      // rows 1, 3 += lane 15 of rows 0, 2
+    v += samp_dpp_u64<DPP_ROW_BCAST31, 0xC, false>(v);      // rows 2, 3 += lane 31
+    return v;
+}
+
+// Descending weighted selection over the 2048 buckets of h (bucket 2047 first): the bucket in which the running sum first
+// reaches x = x_of(total) (1 <= x <= total), and what is left of x inside it.  The whole workgroup calls it; four
+// wavefronts (one per SIMD) do the work, eight buckets per lane -- the selection runs on ONE compute unit and is bound by
+// its vector issue slots, so work that a quarter of the wavefronts can do is not spread over all sixteen.  scr: 2 x 8 words
+// of LDS used alternately (par), so that no barrier is needed behind the result read.
+struct SampSel { int bucket; samp_u64 rem, x, total; };
+template <typename XF>
+__device__ __forceinline__ SampSel samp_select_bucket(const samp_u64 *h, XF x_of, samp_u64 *scr, int &par) {
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    samp_u64 *wtot = scr + par * 8, *res = scr + par * 8 + 4;
+    par ^= 1;
+    samp_u64 v[8], inc = 0;
+    if (tid < 256) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(h + 2040 - 8 * tid);      // buckets 2040 - 8 tid .. 2047 - 8 tid
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 t = src[3 - q];
+            v[2 * q] = ((samp_u64)t.w << 32) | t.z;         // descending: the higher bucket of the pair first
+            v[2 * q + 1] = ((samp_u64)t.y << 32) | t.x;
+        }
+        samp_u64 local = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) local += v[q];
+        inc = samp_wave_scan_u64(local);
+        if (ln == 63) wtot[wv] = inc;
+        inc -= local;                                        // exclusive, within the wavefront
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const samp_u64 t0 = wtot[0], t1 = wtot[1], t2 = wtot[2], t3 = wtot[3];
+        const samp_u64 total = (t0 + t1) + (t2 + t3);
+        const samp_u64 x = x_of(total);
+        samp_u64 run = inc + (wv > 0 ? t0 : 0) + (wv > 1 ? t1 : 0) + (wv > 2 ? t2 : 0);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (run < x && x <= run + v[q]) { res[0] = (samp_u64)(2047 - 8 * tid - q); res[1] = x - run; res[2] = x; res[3] = total; }
+            run += v[q];
+        }
+    }
+    __syncthreads();
+    return SampSel{(int)res[0], res[1], res[2], res[3]};
+}
+
+// 1 workgroup: C candidates per thread in registers (1024 * C >= vocab), the cut, the pick, the decode state.
+// Candidates = the entries of weight >= 1 (p >= 2^-45).  Keys are taken relative to the smallest candidate and the
+// histogram levels split the POPULATED key range [kmin, kmax] (B = its width in bits: digits of 11 / 11 / rest bits from the
+// top of B, fewer levels when B is small) -- a flat distribution whose p all share three exponents would otherwise put
+// every candidate into a handful of buckets, and LDS atomics on one address are served one at a time.  Only the first
+// level walks all candidates with their weights; a selection then copies the candidates of its level-1 bucket into an LDS
+// list (one compare per candidate) and the lower levels work on that list.
+constexpr unsigned SAMP_KEY_MIN = 82u << 23;                 // bits of 2^-45: the smallest p of weight 1
+#ifdef NL_SAMP_STAMPS   // developer build (tools/samp_probe.hip): shader-clock stamps of thread 0
+__device__ unsigned long long g_samp_stamps[32];
+#define SAMP_STAMP(i) do { if (threadIdx.x == 0) g_samp_stamps[i] = wall_clock64(); } while (0)
+#else
+#define SAMP_STAMP(i) do {} while (0)
+#endif
+constexpr int SAMP_LIST_CAP = 8192;
+template <int C>
+__global__ void __launch_bounds__(SAMP_THREADS) samp_select_radix_kernel(SampleParams P) {
+    __shared__ samp_u64 h1[2048], hw[2048];
+    __shared__ unsigned list[SAMP_LIST_CAP];
+    __shared__ samp_u64 scr[16];
+    __shared__ unsigned wcnt[SAMP_THREADS / 64], wmin[SAMP_THREADS / 64], wmax[SAMP_THREADS / 64];
+    __shared__ unsigned list_n;
+    __shared__ int s_pick;
+    const int tid = threadIdx.x, V = P.vocab, lo = tid * C;
+    const int step = P.ctl[CTL_STEP];
+    const float u = P.uniforms[step];
+    unsigned key[C];                                        // bits of p >= 0: unsigned order = float order
+    const unsigned *kin = reinterpret_cast<const unsigned *>(P.keys_in);
+    SAMP_STAMP(0);
+#pragma unroll
+    for (int k = 0; k < C; k += 4) {                        // (keys_in holds 1024 * C entries; the tail past vocab is masked)
+        const uint4 t4 = *reinterpret_cast<const uint4 *>(kin + lo + k);
+        key[k] = lo + k < V ? t4.x : 0u; key[k + 1] = lo + k + 1 < V ? t4.y : 0u;
+        key[k + 2] = lo + k + 2 < V ? t4.z : 0u; key[k + 3] = lo + k + 3 < V ? t4.w : 0u;
+    }
+    h1[tid] = 0; h1[tid + 1024] = 0;
+    if (tid == 0) s_pick = 0x7fffffff;
+    int par = 0;
+    unsigned kmin = 0xffffffffu, kmax = 0u;
+    SAMP_STAMP(1);
+#pragma unroll
+    for (int k = 0; k < C; k++) {                           // (a key below SAMP_KEY_MIN counts as SAMP_KEY_MIN: the range only widens)
+        kmin = min(kmin, max(key[k], SAMP_KEY_MIN));
+        kmax = max(kmax, key[k]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { kmin = min(kmin, (unsigned)__shfl_xor(kmin, o)); kmax = max(kmax, (unsigned)__shfl_xor(kmax, o)); }
+    if ((tid & 63) == 0) { wmin[tid >> 6] = kmin; wmax[tid >> 6] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < SAMP_THREADS / 64; w++) { kmin = min(kmin, wmin[w]); kmax = max(kmax, wmax[w]); }
+    // (the largest p is exp(0) = 1: kmax = bits of 1.0f and at least one candidate exists.  kmin >= SAMP_KEY_MIN, so
+    //  "key >= kmin" is the candidate test and d = key - kmin < 2^B <= 2^30)
+    const int B = 32 - __clz((int)(kmax - kmin));           // __clz(0) = 32: B = 0 when all candidates share one p
+    const int s1 = max(B - 11, 0), s2 = max(B - 22, 0);
+    // weight of the candidate with relative key d: floor(p 2^45) = (m 2^22) >> (127 - e), 127 - e <= 45 for candidates
+    auto weight_of = [&](unsigned k) {
+        const samp_u64 m = (samp_u64)((k & 0x7fffffu) | 0x800000u) << 22;
+        return m >> (127u - (k >> 23));
+    };
+    SAMP_STAMP(2);
+    // level 1, the only pass that weighs every candidate.  (The empty asm pins every pass to "one candidate at a time":
+    // left alone, hipcc keeps all C 64-bit weights live across the passes and spills 450 registers)
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        unsigned kk = key[k];
+        asm volatile("" : "+v"(kk));
+        if (kk >= kmin) atomicAdd(&h1[(kk - kmin) >> s1], weight_of(kk));
+    }
+    __syncthreads();
+    SAMP_STAMP(3);
+    [[maybe_unused]] int stamp_base = 4;
+    // one weighted selection: up to three levels; returns the relative key of the crossing candidates and what is left of x
+    // among them
+    auto select = [&](auto x_of, unsigned &dout, samp_u64 &rem, samp_u64 &x) {
+        const SampSel a = samp_select_bucket(h1, x_of, scr, par);
+        unsigned prefix = (unsigned)a.bucket;               // = d >> s1 of the crossing candidates
+        rem = a.rem;
+        x = a.x;
+        SAMP_STAMP(stamp_base + 0);
+        if (s1 == 0) { dout = prefix; return; }
+        // the candidates of that bucket -> list (relative keys).  (Counting first and reserving one run per thread was
+        // measured slower: the second walk over the registers costs more than the atomics it saves)
+        if (tid == 0) list_n = 0;
+        hw[tid] = 0; hw[tid + 1024] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            const unsigned d = key[k] - kmin;               // (a non-candidate wraps to >= 2^32 - 2^30: its d >> s1 is no bucket)
+            if ((d >> s1) == prefix) {
+                const unsigned at = atomicAdd(&list_n, 1u);
+                if (at < (unsigned)SAMP_LIST_CAP) list[at] = d;
+            }
+        }
+        __syncthreads();
+        SAMP_STAMP(stamp_base + 1);
+        const unsigned n = list_n;
+        const bool listed = n <= (unsigned)SAMP_LIST_CAP;   // (else: the lower levels walk the registers again)
+        auto same = [](samp_u64 r) { return [r](samp_u64) { return r; }; };
+        {
+            const unsigned mask = (1u << (s1 - s2)) - 1u;
+            if (listed) {
+                for (unsigned i = tid; i < n; i += SAMP_THREADS) { const unsigned d = list[i]; atomicAdd(&hw[(d >> s2) & mask], weight_of(d + kmin)); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < C; k++) {
+                    unsigned kk = key[k];
+                    asm volatile("" : "+v"(kk));
+                    const unsigned d = kk - kmin;
+                    if ((d >> s1) == prefix) atomicAdd(&hw[(d >> s2) & mask], weight_of(kk));
+                }
+            }
+            __syncthreads();
+            const SampSel b = samp_select_bucket(hw, same(rem), scr, par);
+            prefix = (prefix << (s1 - s2)) | (unsigned)b.bucket;
+            rem = b.rem;
+            SAMP_STAMP(stamp_base + 2);
+        }
+        if (s2 > 0) {
+            hw[tid] = 0; hw[tid + 1024] = 0;
+            __syncthreads();
+            const unsigned mask = (1u << s2) - 1u;
+            if (listed) {
+                for (unsigned i = tid; i < n; i += SAMP_THREADS) { const unsigned d = list[i]; if ((d >> s2) == prefix) atomicAdd(&hw[d & mask], weight_of(d + kmin)); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < C; k++) {
+                    unsigned kk = key[k];
+                    asm volatile("" : "+v"(kk));
+                    const unsigned d = kk - kmin;
+                    if ((d >> s2) == prefix) atomicAdd(&hw[d & mask], weight_of(kk));
+                }
+            }
+            __syncthreads();
+            const SampSel c = samp_select_bucket(hw, same(rem), scr, par);
+            prefix = (prefix << s2) | (unsigned)c.bucket;
+            rem = c.rem;
+            SAMP_STAMP(stamp_base + 3);
+        }
+        dout = prefix;
+    };
+    // ties: as many of the equal candidates as x needs (one, unless several candidates share the crossing p)
+    auto tie_rank = [](samp_u64 rem, samp_u64 w) { return rem <= w ? (samp_u64)1 : (rem + w - 1) / w; };
+    unsigned dc, dp;
+    samp_u64 rem, xcut, xr;
+    const float top_p = P.top_p;
+    select([top_p](samp_u64 total) { const samp_u64 x = samp_ceil_mul(top_p, total); return x < 1 ? (samp_u64)1 : x; }, dc, rem, xcut);
+    stamp_base = 8;
+    const samp_u64 wc = weight_of(dc + kmin);
+    const samp_u64 cum = xcut - rem + tie_rank(rem, wc) * wc;            // CDF of the cut candidate
+    select([u, cum](samp_u64) { const samp_u64 x = samp_ceil_mul(u, cum); return x < 1 ? (samp_u64)1 : x; }, dp, rem, xr);
+    SAMP_STAMP(12);
+    const unsigned rank = (unsigned)tie_rank(rem, weight_of(dp + kmin));   // 1-based among the candidates with this p, by id
+    // the rank-th candidate with relative key dp in ascending id (thread chunks are contiguous in id)
+    const unsigned kpick = dp + kmin;
+    if (rank == 1) {
+        // (the usual case: the first candidate with this p = the smallest id)
+        int first = 0x7fffffff;
+#pragma unroll
+        for (int k = C - 1; k >= 0; k--) first = key[k] == kpick ? lo + k : first;
+        if (first != 0x7fffffff) atomicMin(&s_pick, first);
+    } else {
+        unsigned cnt = 0;
+#pragma unroll
+        for (int k = 0; k < C; k++) cnt += key[k] == kpick ? 1u : 0u;
+        unsigned inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(inc, d);
+            if ((tid & 63) >= d) inc += o;
+        }
+        if ((tid & 63) == 63) wcnt[tid >> 6] = inc;
+        __syncthreads();
+        unsigned pre = inc - cnt;
+        for (int w = 0; w < (tid >> 6); w++) pre += wcnt[w];
+        if (pre < rank && rank <= pre + cnt) {
+            unsigned seen = pre;
+#pragma unroll
+            for (int k = 0; k < C; k++) {
+                if (key[k] == kpick) { seen++; if (seen == rank) s_pick = lo + k; }
+            }
+        }
+    }
+    __syncthreads();
+    SAMP_STAMP(13);
+    const int pick = s_pick == 0x7fffffff ? 0 : s_pick;
+    samp_embed_tail(P, pick);
+    // recent window: append, drop the oldest when full (go/main.go:197-200)
+    const int n = *P.recent_n;
+    int shifted = 0;
+    if (P.rep_window > 0 && n >= P.rep_window && tid + 1 < n) shifted = P.recent[tid + 1];   // rep_window <= 1024
+    __syncthreads();
+    if (P.rep_window > 0) {
+        if (n >= P.rep_window) {
+            if (tid + 1 < n) P.recent[tid] = shifted;
+            if (tid == 0) P.recent[n - 1] = pick;
+        } else if (tid == 0) {
+            P.recent[n] = pick;
+            *P.recent_n = n + 1;
+        }
+    }
+    if (tid == 0) {
+        P.ids[step] = pick;
+        P.ctl[CTL_STEP] = step + 1;
+        P.ctl[CTL_TOKEN] = pick;
+        P.ctl[CTL_POS] = P.ctl[CTL_POS] + 1;
+    }
+    SAMP_STAMP(14);
 }
 
 }  // namespace nl

@@ -72,8 +72,41 @@ def _tree256(x):
     return y[:, 0]
 
 
+def _ceil_mul(f, x):
+    """exact ceil(f * x) for a float32 f in [0, 1] and a Python int x (samp_ceil_mul, nl_sample.h)"""
+    num, den = float(F(f)).as_integer_ratio()
+    return -((-num * int(x)) // den)
+
+
 def device_top_p(lg, temp, top_p, u):
-    """Returns (token, boundary_margin): margin = distance of the two threshold tests from their boundaries,
+    """nl_sample.h's top-p for vocabularies <= 65536 (samp_select_radix_kernel), restated with Python integers: weights
+    W_i = floor(p_i * 2^45), order = p descending / id ascending, cut = first j with CDF_j >= ceil(top_p * TOTAL), pick =
+    first j with CDF_j >= max(1, ceil(u * CDF_cut)).  Returns (token, boundary_margin): margin = relative distance of the
+    two threshold tests from their boundaries -- tiny margins are where the Go float32 chain may legitimately disagree."""
+    if temp <= 0:
+        return int(np.argmax(lg)), 1.0
+    if lg.size > 65536:
+        return device_top_p_sorted(lg, temp, top_p, u)
+    p = _probs(lg, temp)
+    order = np.argsort(-p, kind="stable")
+    w = [int(x) for x in np.floor(p[order].astype(np.float64) * 2.0 ** 45)]
+    cs, acc = [], 0
+    for x in w:
+        acc += x
+        cs.append(acc)
+    total = cs[-1]
+    xcut = max(1, _ceil_mul(top_p, total))
+    cut = next(j for j, c in enumerate(cs) if c >= xcut)
+    xr = max(1, _ceil_mul(u, cs[cut]))
+    pick = next(j for j, c in enumerate(cs) if c >= xr)
+    r = float(F(u)) * cs[cut]
+    margin = min(abs(cs[cut] / total - top_p), abs(cs[pick] - r) / total, abs(cs[pick - 1] - r) / total if pick > 0 else 1.0)
+    return int(order[pick]), margin
+
+
+def device_top_p_sorted(lg, temp, top_p, u):
+    """The sorted path (vocabularies > 65536, or NL_SAMP_SORT=1): the Go algorithm in nl_sample.h's summation order.
+    Returns (token, boundary_margin): margin = distance of the two threshold tests from their boundaries,
     relative -- tiny margins are where the Go chain and the chunked chain may legitimately disagree."""
     if temp <= 0:
         return int(np.argmax(lg)), 1.0

@@ -74,6 +74,37 @@ def test_top_p_matches_the_go_chain(hip, V):
     assert go_mismatch <= max(2, trials // 8)
 
 
+@pytest.mark.parametrize("V", [300, 4096, 32000, 50000])
+def test_top_p_selection_without_a_sort_equals_its_integer_restatement(hip, V):
+    # vocabularies <= 65536 take samp_select_radix_kernel: no sort, weighted radix selection on exact integer weights
+    # (nl_sample.h).  sampling_mirror.device_top_p restates it with Python integers; the device must agree EXACTLY -- every
+    # case, not only the ones the Go chain disagrees on -- including the shapes that leave the common path:
+    #   * thousands of candidates with one identical p: ties go by ascending id, the cut / the pick need the k-th of them
+    #     (64-bit division, the in-order rank search), and their level-1 bucket overflows the LDS candidate list (the
+    #     lower levels then walk the registers);
+    #   * all logits equal (one key: no levels at all), two distinct values, a single dominant token;
+    #   * u = 0, u just below 1, top_p tiny and top_p just below 1.
+    rng = np.random.default_rng(77 + V)
+    cases = []
+    for _ in range(10):
+        lg, window, recent, u = _case(rng, V)
+        cases.append((lg, float(rng.choice([0.8, 1.5])), float(rng.choice([0.5, 0.9, 0.95])), u))
+    flat = np.zeros(V, np.float32)
+    two = np.where(rng.random(V) < 0.5, np.float32(0.25), np.float32(-0.5)).astype(np.float32)
+    ties = (rng.standard_normal(V) * 3.0).astype(np.float32)
+    ties[rng.permutation(V)[: (V * 2) // 3]] = np.float32(1.0)              # two thirds of the vocabulary share one logit
+    peak = (rng.standard_normal(V)).astype(np.float32)
+    peak[V // 3] = 40.0
+    for lg in (flat, two, ties, peak):
+        for u in (0.0, 0.37, float(np.float32(1.0) - np.float32(2.0 ** -24))):
+            for top_p in (0.9, 0.02, float(np.float32(1.0) - np.float32(2.0 ** -24))):
+                cases.append((lg, 0.8, top_p, u))
+    for lg, temp, top_p, u in cases:
+        pick = hip.op_sample(lg, temp, top_p, 50, 1.0, 0, u, [])[0]
+        want, _ = sm.device_top_p(lg, temp, top_p, u)
+        assert pick == want, (V, temp, top_p, u, pick, want)
+
+
 @pytest.mark.parametrize("V", [64, 512, 32000])
 def test_top_k_is_the_go_loop_exactly(hip, V):
     rng = np.random.default_rng(1000 + V)
