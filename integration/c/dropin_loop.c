@@ -16,11 +16,14 @@ static double now_s(void) {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-/* argmax go/main.go:400-408: strict '>' => lowest index wins ties */
+/* argmax go/main.go:400-408: strict '>' => lowest index wins ties.  The running maximum is kept in a register: written as
+ * `v[i] > v[best]`, gcc -O2 turns the update into a conditional move and every iteration's load of v[best] waits for it (a
+ * 6-cycle loop-carried chain, ~95 us for 32000 logits); Go's compiler emits a (well predicted) branch for the same source. */
 static int host_argmax(const float *v, int n) {
     int best = 0, i;
+    float bv = v[0];
     for (i = 1; i < n; i++)
-        if (v[i] > v[best]) best = i;
+        if (v[i] > bv) { bv = v[i]; best = i; }
     return best;
 }
 

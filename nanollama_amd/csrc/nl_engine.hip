@@ -162,6 +162,9 @@ struct nl_engine {
     int *amax_idx = nullptr;
     int amax_slots = 0;
     int *h_ctl = nullptr;  // pinned staging
+    float *h_logits = nullptr;   // pinned [vocab] + one int behind it: the per-call read-backs of nl_forward / nl_forward_argmax /
+                                 // nl_prefill land here by DMA and are copied to the caller's (pageable) buffer by the CPU -- a
+                                 // hipMemcpyAsync to pageable memory is a staged, blocking copy inside the runtime (128 KB: ~90 us)
     std::vector<int> hw;   // per stream: positions [0, hw) hold K/V written since the last nl_reset
     int *h_ctl_ring = nullptr;  // pinned: one ctl block per queued step (prefill / batch)
     int ctl_ring_cap = 0;
@@ -1970,6 +1973,8 @@ int nl_finalize(nl_handle e) {
     HIPCK(e, dalloc(&e->amax_idx, (size_t)e->amax_slots, &e->bytes_state));
     HIPCK(e, hipHostMalloc((void **)&e->h_ctl, CTL_WORDS * sizeof(int), hipHostMallocDefault));
     memset(e->h_ctl, 0, CTL_WORDS * sizeof(int));
+    if (e->h_logits) { hipHostFree(e->h_logits); e->h_logits = nullptr; }
+    HIPCK(e, hipHostMalloc((void **)&e->h_logits, ((size_t)c.vocab + 4) * sizeof(float), hipHostMallocDefault));
     e->ctl_ring_cap = std::max(c.seq_len, c.max_streams);
     HIPCK(e, hipHostMalloc((void **)&e->h_ctl_ring, (size_t)e->ctl_ring_cap * CTL_WORDS * sizeof(int), hipHostMallocDefault));
     HIPCK(e, hipMemcpy(e->ctl, e->h_ctl, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice));
@@ -2197,6 +2202,7 @@ int nl_destroy(nl_handle e) {
                     e->amax_idx};
     for (void *b : bufs) if (b) hipFree(b);
     if (e->h_ctl) hipHostFree(e->h_ctl);
+    if (e->h_logits) hipHostFree(e->h_logits);
     if (e->h_status) hipHostFree(e->h_status);
     if (e->h_ctl_ring) hipHostFree(e->h_ctl_ring);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
@@ -2227,12 +2233,13 @@ int nl_forward(nl_handle e, int stream, int token, int pos, float *logits_out) {
         if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
         if ((rc = launch_step(e, pos))) return rc;
         if (logits_out)
-            HIPCK(e, hipMemcpyAsync(logits_out, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
+            HIPCK(e, hipMemcpyAsync(e->h_logits, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
         HIPCK(e, hipStreamSynchronize(e->stream));
         if (attempt == 0 && take_fused_timeout(e)) continue;   // redo on the general plan
         break;
     }
     if (int prc = p2p_check(e)) return prc;
+    if (logits_out) memcpy(logits_out, e->h_logits, (size_t)e->cfg.vocab * 4);
     return NL_OK;
 }
 
@@ -2245,9 +2252,11 @@ int nl_forward_argmax(nl_handle e, int stream, int token, int pos, int *next_id)
         if ((rc = note_positions(e, stream, pos, 1))) return rc;
         if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
         if ((rc = launch_step(e, pos))) return rc;
-        HIPCK(e, hipMemcpyAsync(next_id, e->result, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        int *h_id = reinterpret_cast<int *>(e->h_logits + e->cfg.vocab);
+        HIPCK(e, hipMemcpyAsync(h_id, e->result, sizeof(int), hipMemcpyDeviceToHost, e->stream));
         HIPCK(e, hipStreamSynchronize(e->stream));
         if (attempt == 0 && take_fused_timeout(e)) continue;   // redo on the general plan
+        *next_id = *h_id;
         break;
     }
     if (int prc = p2p_check(e)) return prc;
@@ -2532,9 +2541,10 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
         }
     }
     if (last_logits_out)
-        HIPCK(e, hipMemcpyAsync(last_logits_out, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCK(e, hipMemcpyAsync(e->h_logits, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCK(e, hipStreamSynchronize(e->stream));
     if (int prc = p2p_check(e)) return prc;
+    if (last_logits_out) memcpy(last_logits_out, e->h_logits, (size_t)e->cfg.vocab * 4);
     return NL_OK;
 }
 
