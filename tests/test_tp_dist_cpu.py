@@ -96,7 +96,7 @@ def test_world_size_2_rendezvous(tmp_path):
         assert parts == [bytes([0]) * 64, bytes([1]) * 65], parts
         assert "torch" not in sys.modules, "the rendezvous must not import torch"
         r.close()
-        print("rank", r.rank, "ok")
+        sys.stdout.write("rank %d ok\\n" % r.rank); sys.stdout.flush()      # one write: two ranks share the pipe
     """))
     out = None
     for attempt in range(3):  # a busy rendezvous port is the only expected flake
