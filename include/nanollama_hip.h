@@ -163,7 +163,7 @@ NL_API int nl_profile_forward(nl_handle h, int stream, int token, int pos, int i
 /* Which launch plans the handle holds (no reference counterpart; tests and bench.py report it).  fused_mode: 0 = only the
  * general five-launches-per-layer plan; 1 = small tiers, attention block + feed-forward block (2 per layer); 2 = wide
  * tiers, projection + attention fused (4 per layer); 3 = a tensor-parallel rank's layer as two launches with the push
- * all-reduce finished in their tails.  fused_max_pos: steps below this position take the fused plan.  launches_*: kernel
+ * all-reduce finished in their tails; 4 = wide tiers on one GPU, projection + attention + WO fused (3 per layer).  fused_max_pos: steps below this position take the fused plan.  launches_*: kernel
  * launches per token of the fused / general plan (0 when the plan does not exist). */
 NL_API int nl_plan_info(nl_handle h, int *fused_mode, int *fused_max_pos, int *launches_fused, int *launches_general);
 /* Device bytes held by the handle (weights, KV, state). */

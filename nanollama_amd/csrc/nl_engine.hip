@@ -226,7 +226,8 @@ struct nl_engine {
     } ps[2];
     bool fused = false;           // ps[1] exists
     int fused_mode = 0;           // 1: whole attention half per layer (nl_block.h); 2: projection + attention (nl_group.h);
-                                  // 3: a tensor-parallel rank's layer as two launches (nl_tp.h)
+                                  // 3: a tensor-parallel rank's layer as two launches (nl_tp.h); 4: one GPU, wide tier: mode 3's
+                                  // attention half with a direct seam (projection + attention + WO), then the two GEMVs
     struct TpGeom {               // mode 3 geometry, fixed at nl_finalize
         int wo_gshift = 0;        // log2 of the 256-column groups of a WO row
         int wo_tpw = 1;           // WO tiles per block of the attention launch's grid
@@ -696,6 +697,41 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         float *kc = e->kcache + (long long)l * e->kv_layer_stride;
         float *vc = e->vcache + (long long)l * e->kv_layer_stride;
         bool parts_pending = false;
+        // nl_tp.h's attention half (projection + RoPE + KV store + attention + WO) as one op: a tensor-parallel rank's (mode 3:
+        // the seam's all-reduce in its tail) or, with a direct seam, the whole layer's on one GPU (mode 4)
+        auto tp_attn_op = [&](const TpSeam &sm, int coll, float *cbuf) {
+        TpAttnParams Q{};
+        GroupParams &B = Q.G;
+        B.qkv_q = L.qkv.q; B.qkv_s = L.qkv.s;
+        B.D = c.dim; B.npairs = L.qkv.npairs; B.n_q_heads = e->Hs; B.n_kv_heads = e->KVs; B.seq_len = c.seq_len;
+        B.rope_conj = c.rope_conjugate; B.qk_norm = c.qk_norm; B.single_stream = c.max_streams == 1 ? 1 : 0;
+        B.tpm = e->grp_tpm; B.members = (e->gqa + 2) * 4 / e->grp_tpm;
+        B.gqa = (unsigned)e->gqa; B.wpt = (unsigned)((GRP_THREADS / 64) / e->grp_tpm); B.wpt_inv = udiv_inv(B.wpt);
+        B.m8_inv = udiv_inv(8u * (unsigned)B.members); B.m_inv = udiv_inv((unsigned)B.members);
+        B.x = e->x[cur]; B.normw = L.attn_norm; B.eps = c.rms_eps; B.scale = (float)(1.0 / std::sqrt((double)e->hd));
+        B.rope_cos = e->rope_cos; B.rope_sin = e->rope_sin; B.kcache = kc; B.vcache = vc;
+        B.kv_stream_stride = e->kv_stream_stride; B.ctl = e->ctl;
+        B.bias_q = L.bq; B.bias_k = L.bk; B.bias_v = L.bv;
+        B.nsplit_max = e->nsplit_max;
+        B.xchg = e->xchg; B.tick = p2p ? e->p2p.epoch : e->tick; B.layer_tag = (unsigned)(l + 1);
+        B.status = e->tick + 1; B.host_status = e->h_status; B.spin_limit = e->spin_limit;
+        Q.wo_q = L.wo.q; Q.wo_s = L.wo.s; Q.wo_npairs = L.wo.npairs; Q.wo_ntiles = L.wo.ntiles; Q.wo_gshift = e->tpg.wo_gshift;
+        Q.wo_tpw = e->tpg.wo_tpw;
+        Q.n_heads_local = e->Hs; Q.xq = e->tp_xq; Q.xo = e->tp_xo; Q.bias_out = L.bo; Q.x = e->x[cur];
+        Q.seam = sm;
+        const int wt = L.qkv.wtype, grid = std::max(grp_grid(e->KVs, B.members), (L.wo.ntiles + e->tpg.wo_tpw - 1) / e->tpg.wo_tpw);
+        const int ngroups = (L.qkv.npairs + KL - 1) / KL, nf = (ngroups + 16 / e->grp_tpm - 1) / (16 / e->grp_tpm);
+        const size_t lds = tp_attn_lds_bytes(L.wo.npairs);
+        Op op{K_ATTNBLOCK, coll, cbuf, (size_t)c.dim, [Q, wt, grid, nf, lds](hipStream_t st) {
+                  if (wt == WT_Q8_0 && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 1>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                  else if (wt == WT_Q8_0) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 2>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                  else if (nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 1>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                  else hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 2>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                  return hipGetLastError();
+              }};
+        op.add_to = e->x[cur];
+        return op;
+        };
         if (fused && e->fused_mode == 3) {
             // a tensor-parallel rank's layer as two launches (nl_tp.h): both finish their all-reduce seam in the tail (push
             // path), or leave the rank's partial in `ar` for the in-process group to sum and add (coll 3)
@@ -714,37 +750,7 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
                 return S;
             };
             {
-                TpAttnParams Q{};
-                GroupParams &B = Q.G;
-                B.qkv_q = L.qkv.q; B.qkv_s = L.qkv.s;
-                B.D = c.dim; B.npairs = L.qkv.npairs; B.n_q_heads = e->Hs; B.n_kv_heads = e->KVs; B.seq_len = c.seq_len;
-                B.rope_conj = c.rope_conjugate; B.qk_norm = c.qk_norm; B.single_stream = c.max_streams == 1 ? 1 : 0;
-                B.tpm = e->grp_tpm; B.members = (e->gqa + 2) * 4 / e->grp_tpm;
-                B.gqa = (unsigned)e->gqa; B.wpt = (unsigned)((GRP_THREADS / 64) / e->grp_tpm); B.wpt_inv = udiv_inv(B.wpt);
-                B.m8_inv = udiv_inv(8u * (unsigned)B.members); B.m_inv = udiv_inv((unsigned)B.members);
-                B.x = e->x[cur]; B.normw = L.attn_norm; B.eps = c.rms_eps; B.scale = (float)(1.0 / std::sqrt((double)e->hd));
-                B.rope_cos = e->rope_cos; B.rope_sin = e->rope_sin; B.kcache = kc; B.vcache = vc;
-                B.kv_stream_stride = e->kv_stream_stride; B.ctl = e->ctl;
-                B.bias_q = L.bq; B.bias_k = L.bk; B.bias_v = L.bv;
-                B.nsplit_max = e->nsplit_max;
-                B.xchg = e->xchg; B.tick = p2p ? e->p2p.epoch : e->tick; B.layer_tag = (unsigned)(l + 1);
-                B.status = e->tick + 1; B.host_status = e->h_status; B.spin_limit = e->spin_limit;
-                Q.wo_q = L.wo.q; Q.wo_s = L.wo.s; Q.wo_npairs = L.wo.npairs; Q.wo_ntiles = L.wo.ntiles; Q.wo_gshift = e->tpg.wo_gshift;
-                Q.wo_tpw = e->tpg.wo_tpw;
-                Q.n_heads_local = e->Hs; Q.xq = e->tp_xq; Q.xo = e->tp_xo; Q.bias_out = L.bo; Q.x = e->x[cur];
-                Q.seam = make_seam(seam++);
-                const int wt = L.qkv.wtype, grid = grp_grid(e->KVs, B.members);
-                const int ngroups = (L.qkv.npairs + KL - 1) / KL, nf = (ngroups + 16 / e->grp_tpm - 1) / (16 / e->grp_tpm);
-                const size_t lds = tp_attn_lds_bytes(L.wo.npairs);
-                Op op{K_ATTNBLOCK, p2p ? 0 : 3, p2p ? nullptr : e->ar, (size_t)c.dim, [Q, wt, grid, nf, lds](hipStream_t st) {
-                          if (wt == WT_Q8_0 && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 1>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
-                          else if (wt == WT_Q8_0) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 2>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
-                          else if (nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 1>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
-                          else hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 2>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
-                          return hipGetLastError();
-                      }};
-                op.add_to = e->x[cur];
-                plan.push_back(op);
+                plan.push_back(tp_attn_op(make_seam(seam++), p2p ? 0 : 3, p2p ? nullptr : e->ar));
             }
             {
                 TpFfnParams F{};
@@ -786,6 +792,12 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
                                                         : launch_attn_block<WT_Q4_0>(B, 0, grid, lds, st);
                                }});
             parts_pending = true;
+        } else if (fused && e->fused_mode == 4) {
+            // one GPU, wide tier: projection + RoPE + KV store + attention + WO + residual as ONE launch (nl_tp.h with a direct
+            // seam); gate / up and down follow as GEMVs on the finished residual stream
+            TpSeam S{};
+            S.n = -1; S.rows = c.dim;
+            plan.push_back(tp_attn_op(S, 0, nullptr));
         } else {
         if (fused && e->fused_mode == 2) {
             // projection + RoPE + KV store + attention as one launch (nl_group.h); WO below consumes its partials
@@ -2032,7 +2044,7 @@ int nl_finalize(nl_handle e) {
             ok3 = gshift <= 4 && (tpw << gshift) <= 16 && (long long)agrid * tpw >= L0.wo.ntiles && L0.wo.npairs <= 64;
             t.wo_gshift = gshift;
             t.wo_tpw = tpw;
-            ok3 = ok3 && e->Hs * 4 * GPT <= TP_THREADS;      // one attention-output granule per thread
+            ok3 = ok3 && e->Hs * 4 * GPT <= 2 * TP_THREADS;  // at most two attention-output granules per thread
             // feed-forward: blocks [0, n_prod) project one gate / up tile each while that grid stays resident (one 1024-thread
             // workgroup per compute unit), else a gate + up tile pair each; EVERY block b < ceil(D / 16) owns W_down tile b
             const int ngroups = (L0.gate.npairs + KL - 1) / KL, dgroups = (L0.down.npairs + KL - 1) / KL;
@@ -2060,13 +2072,35 @@ int nl_finalize(nl_handle e) {
         // mode 1 launches one 768-thread workgroup per (head, member) and one per (slice, member): they only make progress
         // together, so both grids must fit on the device's compute units at once
         if (ok1 && (blk_grid(e->Hs) > e->num_cus || ffn_grid(e->Is / FFN_SLICE) > e->num_cus)) ok1 = false;
-        e->fused_mode = ok1 ? 1 : ok3 ? 3 : ok2 ? 2 : 0;
+        // mode 4: ONE GPU, wide tier -- mode 2's launch with WO behind a second exchange (nl_tp.h's attention half with no
+        // all-reduce at all: every block that owns WO rows gathers the heads' outputs and stores x = resid + WO row itself).
+        // Blocks beyond the projection's grid hold WO rows only; they wait for nobody but the runners, so only the projection's
+        // grid has to be resident together (as in mode 2).  NL_ATTN_WO=0 keeps mode 2.
+        bool ok4 = false;
+        {
+            const char *aw = getenv("NL_ATTN_WO");
+            ok4 = ok2 && !ok1 && !ok3 && want != 2 && e->G == 1 && !e->p2p.on && !(aw && atoi(aw) == 0) && c.n_layers < 127;
+            if (ok4) {
+                nl_engine::TpGeom &t = e->tpg;
+                const nl_engine::Layer &L0 = e->layers[0];
+                const int wo_groups = (L0.wo.npairs + KL - 1) / KL;
+                int gshift = 0;
+                while ((1 << gshift) < wo_groups) gshift++;
+                ok4 = gshift <= 4 && L0.wo.npairs <= 64 && e->Hs * 4 * GPT <= 2 * TP_THREADS;
+                t.wo_gshift = gshift;
+                t.wo_tpw = 16 >> std::min(gshift, 4);
+                for (const auto &L : e->layers)
+                    ok4 = ok4 && (L.qkv.wtype == WT_Q8_0 || L.qkv.wtype == WT_Q4_0) && L.wo.wtype == L.qkv.wtype &&
+                          L.wo.npairs == L0.wo.npairs && L.wo.ntiles == L0.wo.ntiles;
+            }
+        }
+        e->fused_mode = ok1 ? 1 : ok3 ? 3 : ok4 ? 4 : ok2 ? 2 : 0;
         e->fused = e->fused_mode != 0;
         const char *fm = getenv("NL_FUSED_MAX_POS");
         // tools/fused_limit.py: the per-head blocks (mode 1) win up to ~500 (nano) / ~600 (mini) positions, the projection +
         // attention launch of the wide tiers (mode 2) up to ~390 (big)
         e->fused_max_pos = fm ? atoi(fm) : e->fused_mode == 1 ? 512 : 384;
-        if (e->fused_mode == 3) e->fused_max_pos = std::min(e->fused_max_pos, TP_NCH_MAX * ATT_CH);   // passes a head takes inside the launch
+        if (e->fused_mode == 3 || e->fused_mode == 4) e->fused_max_pos = std::min(e->fused_max_pos, TP_NCH_MAX * ATT_CH);   // passes a head takes inside the launch
         {
             const char *ff = getenv("NL_FUSED_FFN");   // knob (tests, tools): 0 keeps gate/up and down as two launches
             bool okf = e->fused_mode == 1 && !(ff && atoi(ff) == 0);
@@ -2089,7 +2123,7 @@ int nl_finalize(nl_handle e) {
             HIPCK(e, hipHostMalloc((void **)&e->h_status, sizeof(unsigned), hipHostMallocMapped));
             *e->h_status = 0;
         }
-        if (e->fused_mode == 3) {
+        if (e->fused_mode == 3 || e->fused_mode == 4) {
             const size_t nq = (size_t)e->KVs * (e->gqa + 2) * 4 * GPT, no = (size_t)e->Hs * 4 * GPT, nh = (size_t)2 * e->layers[0].gate.ntiles * GPT;
             HIPCK(e, dalloc(&e->tp_xq, nq, &e->bytes_state));
             HIPCK(e, hipMemset(e->tp_xq, 0, nq * sizeof(u32x4)));

@@ -47,7 +47,8 @@ struct TpSeam {
     const unsigned *epoch;  // forward counter (tag = epoch << 8 | seam)
     unsigned *status;       // set non-zero when a poll gave up (host: NL_ERR_COMM)
     long long timeout;      // wall_clock64 ticks
-    int n;                  // ranks; 0 = in-process group: store the partial to `partial` and return
+    int n;                  // ranks; 0 = in-process group: store the partial to `partial` and return; -1 = no tensor
+                            // parallelism at all (one GPU holds the whole layer): out[row] = resid + v
     unsigned seam;
     int rows;               // D
     float *partial;         // n == 0: [rows]
@@ -56,6 +57,7 @@ struct TpSeam {
 // out[row] = resid + sum over ranks (rank order) of the partials of `row`; this lane owns the row.
 __device__ __forceinline__ void tp_allreduce_row(const TpSeam &S, unsigned e_tag, int row, float v, float resid, float *out) {
     if (S.n == 0) { S.partial[row] = v; return; }
+    if (S.n < 0) { out[row] = resid + v; return; }
     const u64 gran = ((u64)e_tag << 32) | __float_as_uint(v);
 #pragma unroll
     for (int pr = 0; pr < 8; pr++)
@@ -262,7 +264,7 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     const int pos = sload_i32(P.ctl + CTL_POS);
     const long long soff = P.single_stream ? 0 : (long long)sload_i32(P.ctl + CTL_STREAM) * P.kv_stream_stride;
     const unsigned tag = ((unsigned)sload_i32(reinterpret_cast<const int *>(P.tick)) << 8) | P.layer_tag;
-    const unsigned e_tag = Q.seam.n ? ((unsigned)sload_i32(reinterpret_cast<const int *>(Q.seam.epoch)) << 8) | Q.seam.seam : 0u;
+    const unsigned e_tag = Q.seam.n > 0 ? ((unsigned)sload_i32(reinterpret_cast<const int *>(Q.seam.epoch)) << 8) | Q.seam.seam : 0u;
     const int ngroups = (P.npairs + KL - 1) / KL;
     float4 xv[NF], gv[NF];
     uint4 cw[NF][CPP];
@@ -523,7 +525,8 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     }
 
     // ---- WO (go/model.go:590-594): gather every local head's output, this block's rows of the column slice ----
-    tp_gather16<1, false, true>(Q.xo, Q.xo, Q.n_heads_local * 4, tag, ao, ao, Q.n_heads_local * HD, P.status, P.host_status, P.spin_limit, 32u);
+    // (<= 2 granules per thread: 64 local heads -- the whole 7.9B layer on one GPU -- are 1536 granules)
+    tp_gather16<2, false, true>(Q.xo, Q.xo, Q.n_heads_local * 4, tag, ao, ao, Q.n_heads_local * HD, P.status, P.host_status, P.spin_limit, 32u);
     __syncthreads();
     TP_STAMP(sslot, 8);
     if (wslot < tpw) {
@@ -612,7 +615,7 @@ __device__ __forceinline__ void tp_ffn_body(const TpFfnParams &P, char *smem) {
 #endif
     TP_STAMP(sslot, 0);
     const unsigned tag = ((unsigned)sload_i32(reinterpret_cast<const int *>(P.tick)) << 8) | P.layer_tag;   // (scalar cache: no vector wait before the weight requests)
-    const unsigned e_tag = P.seam.n ? ((unsigned)sload_i32(reinterpret_cast<const int *>(P.seam.epoch)) << 8) | P.seam.seam : 0u;
+    const unsigned e_tag = P.seam.n > 0 ? ((unsigned)sload_i32(reinterpret_cast<const int *>(P.seam.epoch)) << 8) | P.seam.seam : 0u;
 
     // ---- producer part: one gate or up tile (16 wavefronts), or gate tile t + up tile t (8 wavefronts each) ----
     const int wpt = P.pair ? NW / 2 : NW;

@@ -1453,7 +1453,7 @@ def test_fused_attention_block_matches_oracle(hip, orc, tmp_path, monkeypatch, w
     dev.close(); plain.close(); ref.close()
 
 
-@pytest.mark.parametrize("case", ["small_tier_blocks", "wide_tier_projection_attention"])
+@pytest.mark.parametrize("case", ["small_tier_blocks", "wide_tier_projection_attention", "wide_tier_attention_wo"])
 def test_fused_plan_timeout_falls_back_to_the_general_plan(hip, orc, tmp_path, monkeypatch, case):
     # HIP promises nothing about which workgroups of a launch are resident together; on a shared GPU a cluster member can
     # wait for a peer that was never dispatched.  NL_FUSED_SPIN_LIMIT=0 makes every exchange poll give up at once: the
@@ -1464,6 +1464,8 @@ def test_fused_plan_timeout_falls_back_to_the_general_plan(hip, orc, tmp_path, m
         shape = synth.ModelShape("fb_fallback", 3, 192, 3, 3, 1024, seq_len=96)
     else:
         shape = synth.ModelShape("fb_fallback_wide", 2, 2048, 32, 8, 1024, seq_len=96, interm=1024)
+        if case == "wide_tier_projection_attention":
+            monkeypatch.setenv("NL_ATTN_WO", "0")                # mode 2; the default on one GPU is mode 4 (WO in the launch)
     p = tmp_path / "m.gguf"
     synth.generate_gguf(str(p), shape, "q4_0", 67, mode="qrand" if case != "small_tier_blocks" else "float")
     g = gguf.load_gguf(str(p))
@@ -1549,13 +1551,18 @@ def test_greedy_chain_switches_from_the_fused_plan_to_the_split_attention_plan(h
     dev.close(); ref.close()
 
 
+@pytest.mark.parametrize("wo", ["wo_own_launch", "wo_in_the_launch"])
 @pytest.mark.parametrize("variant,wtype", [("g4", "q4_0"), ("g4", "q8_0"), ("g8", "q4_0"), ("mha16", "q4_0"),
                                            ("g4_two_tiles", "q4_0"), ("g4_qknorm_conj_bias", "q8_0")])
-def test_fused_projection_attention_launch_matches_oracle(hip, orc, tmp_path, monkeypatch, variant, wtype):
+def test_fused_projection_attention_launch_matches_oracle(hip, orc, tmp_path, monkeypatch, variant, wtype, wo):
     # nl_group.h: Q/K/V + RoPE + KV store + attention as one launch for models too wide for the per-head block
     # (clusters of workgroups per kv group, granule exchange, G attention workgroups), against the oracle across the
     # 128-position pass boundary; "g4_two_tiles" is wide enough that a workgroup holds two tiles and a wavefront two
-    # column groups (the 7.9B tier's geometry)
+    # column groups (the 7.9B tier's geometry).  wo_in_the_launch (fused mode 4, the default on one GPU): nl_tp.h's
+    # attention half with a direct seam -- WO + residual behind a second exchange in the same launch, no wo_resid launch;
+    # wo_own_launch (NL_ATTN_WO=0): mode 2, the WO GEMV merges the launch's partials.
+    if wo == "wo_own_launch":
+        monkeypatch.setenv("NL_ATTN_WO", "0")
     shape = {"g4": synth.ModelShape("fg_g4", 2, 1024, 16, 4, 512, seq_len=160, interm=1024),
              "g8": synth.ModelShape("fg_g8", 2, 1024, 16, 2, 512, seq_len=160, interm=1024),
              "mha16": synth.ModelShape("fg_mha", 2, 1024, 16, 16, 512, seq_len=160, interm=1024),
@@ -1580,10 +1587,12 @@ def test_fused_projection_attention_launch_matches_oracle(hip, orc, tmp_path, mo
         worst = max(worst, float(np.abs(dev.state.logits - want).max()) / max(1.0, float(want.std())))
         gap = max(gap, float(np.abs(dev.state.logits - plain.state.logits).max()))
     orc.set_threads(1)
-    print(f"\nfused projection+attention {variant}/{wtype}: max|gpu-oracle|={worst:.2e}, max|fused-unfused|={gap:.2e}")
+    print(f"\nfused projection+attention {variant}/{wtype}/{wo}: max|gpu-oracle|={worst:.2e}, max|fused-unfused|={gap:.2e}")
     assert worst <= LOGIT_TOL
     k = _kinds(dev, 20)
-    assert k.get("attn_block") == shape.n_layer and "qkv_rope" not in k and "attention" not in k and k.get("wo_resid") == shape.n_layer, k
+    assert k.get("attn_block") == shape.n_layer and "qkv_rope" not in k and "attention" not in k, k
+    assert k.get("wo_resid") == (shape.n_layer if wo == "wo_own_launch" else None), k
+    assert dev.plan_info()["fused_mode"] == (2 if wo == "wo_own_launch" else 4), dev.plan_info()
     assert "attn_block" not in _kinds(plain, 20)      # (both engines now hold the probe's row 20)
     n = shape.n_layer * shape.n_kv_head * shape.seq_len * 64
     for which in ("k_cache", "v_cache"):
