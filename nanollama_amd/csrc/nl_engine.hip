@@ -162,6 +162,7 @@ struct nl_engine {
     int *amax_idx = nullptr;
     int amax_slots = 0;
     int *h_ctl = nullptr;  // pinned staging
+    float *d_h_logits = nullptr; // device address of h_logits (the LM head of a per-call Forward stores the logits there itself)
     float *h_logits = nullptr;   // pinned [vocab] + one int behind it: the per-call read-backs of nl_forward / nl_forward_argmax /
                                  // nl_prefill land here by DMA and are copied to the caller's (pageable) buffer by the CPU -- a
                                  // hipMemcpyAsync to pageable memory is a staged, blocking copy inside the runtime (128 KB: ~90 us)
@@ -642,6 +643,7 @@ void build_plan_blocks(nl_engine *e, std::vector<Op> &plan) {
         GemvParams P = base_params(e, e->lm_head);
         P.x = e->x[1]; P.normw = e->output_norm;
         P.out = e->logits; P.amax_val = e->amax_val; P.amax_idx = e->amax_idx;
+        P.host_out = e->d_h_logits;
         lm_blocks = (P.ntiles + P.tw - 1) / P.tw;
         lm_spb = (P.tw * TR + 63) / 64;
         push_gemv(plan, K_LMHEAD, 0, e->logits, (size_t)e->Vs, e->lm_head.wtype, PRO_NORM, EPI_STORE, P);
@@ -911,7 +913,7 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         P.x = e->x[cur]; P.normw = e->output_norm;
         if (pending) { P.add = pending; P.x_out = e->x[cur ^ 1]; }
         P.out = e->logits + (size_t)e->rank * e->Vs;
-        if (!tp) { P.amax_val = e->amax_val; P.amax_idx = e->amax_idx; }
+        if (!tp) { P.amax_val = e->amax_val; P.amax_idx = e->amax_idx; P.host_out = e->d_h_logits; }
         if (p2p)   // the logits all-gather: this rank's slice also lands in every peer's gathered buffer
             for (int r = 0; r < e->G; r++)
                 if (r != e->rank)   // (loopback: the slice fills every other rank's place in this rank's own buffer)
@@ -1061,9 +1063,9 @@ int build_all(nl_engine *e) {
     return NL_OK;
 }
 
-int set_ctl(nl_engine *e, int token, int pos, int chain, int stream) {
+int set_ctl(nl_engine *e, int token, int pos, int chain, int stream, int hostout = 0) {
     e->h_ctl[CTL_TOKEN] = token; e->h_ctl[CTL_POS] = pos; e->h_ctl[CTL_CHAIN] = chain;
-    e->h_ctl[CTL_STEP] = 0; e->h_ctl[CTL_STREAM] = stream;
+    e->h_ctl[CTL_STEP] = 0; e->h_ctl[CTL_STREAM] = stream; e->h_ctl[CTL_HOSTOUT] = hostout;
     HIPCK(e, hipMemcpyAsync(e->ctl, e->h_ctl, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice, e->stream));
     return NL_OK;
 }
@@ -1986,9 +1988,13 @@ int nl_finalize(nl_handle e) {
     HIPCK(e, hipHostMalloc((void **)&e->h_ctl, CTL_WORDS * sizeof(int), hipHostMallocDefault));
     memset(e->h_ctl, 0, CTL_WORDS * sizeof(int));
     if (e->h_logits) { hipHostFree(e->h_logits); e->h_logits = nullptr; }
-    HIPCK(e, hipHostMalloc((void **)&e->h_logits, ((size_t)c.vocab + 4) * sizeof(float), hipHostMallocDefault));
+    HIPCK(e, hipHostMalloc((void **)&e->h_logits, ((size_t)c.vocab + 4) * sizeof(float), hipHostMallocMapped));
+    e->d_h_logits = nullptr;
+    if (hipHostGetDevicePointer((void **)&e->d_h_logits, e->h_logits, 0) != hipSuccess) { (void)hipGetLastError(); e->d_h_logits = nullptr; }
+    if (getenv("NL_NO_HOST_LOGITS")) e->d_h_logits = nullptr;      // knob (A/B): the DMA read-back
     e->ctl_ring_cap = std::max(c.seq_len, c.max_streams);
     HIPCK(e, hipHostMalloc((void **)&e->h_ctl_ring, (size_t)e->ctl_ring_cap * CTL_WORDS * sizeof(int), hipHostMallocDefault));
+    memset(e->h_ctl_ring, 0, (size_t)e->ctl_ring_cap * CTL_WORDS * sizeof(int));       // (the callers fill five of the eight words)
     HIPCK(e, hipMemcpy(e->ctl, e->h_ctl, CTL_WORDS * sizeof(int), hipMemcpyHostToDevice));
     if (e->G > 1 && !e->comm && !e->p2p.on && !(c.flags & NL_FLAG_LOCAL_GROUP))
         return e->fail(NL_ERR_STATE, "tp_size %d needs nl_comm_init or nl_p2p_import before nl_finalize", e->G);
@@ -2264,9 +2270,11 @@ int nl_forward(nl_handle e, int stream, int token, int pos, float *logits_out) {
     HIPCK(e, hipSetDevice(e->dev));
     for (int attempt = 0;; attempt++) {
         if ((rc = note_positions(e, stream, pos, 1))) return rc;
-        if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
+        // one GPU: the LM head stores the logits into the pinned buffer itself (ctl[CTL_HOSTOUT]); groups: a DMA behind the step
+        const bool direct = logits_out && e->d_h_logits && e->G == 1 && !e->force_tp_plan && !e->p2p.on;
+        if ((rc = set_ctl(e, token, pos, 0, stream, direct ? 1 : 0))) return rc;
         if ((rc = launch_step(e, pos))) return rc;
-        if (logits_out)
+        if (logits_out && !direct)
             HIPCK(e, hipMemcpyAsync(e->h_logits, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
         HIPCK(e, hipStreamSynchronize(e->stream));
         if (attempt == 0 && take_fused_timeout(e)) continue;   // redo on the general plan

@@ -29,7 +29,7 @@ constexpr int KL = 4;            // k-lanes per wavefront (64 / TR)
 constexpr int PAIR = 64;         // columns per pair
 constexpr int ATT_CH = 128;      // positions per attention split
 constexpr int ATT_THREADS = 256;
-constexpr int CTL_TOKEN = 0, CTL_POS = 1, CTL_CHAIN = 2, CTL_STEP = 3, CTL_STREAM = 4, CTL_WORDS = 8;
+constexpr int CTL_TOKEN = 0, CTL_POS = 1, CTL_CHAIN = 2, CTL_STEP = 3, CTL_STREAM = 4, CTL_HOSTOUT = 5, CTL_WORDS = 8;
 
 // A word written by an EARLIER launch (ctl / epoch counters) read through the scalar cache: s_load_dword, counted on
 // lgkmcnt.  A vector load of a wave-uniform value is followed by v_readfirstlane, i.e. by an immediate
@@ -531,6 +531,7 @@ struct GemvParams {
     int p2p_n;
     unsigned p2p_seam;
     float *peer_out[8];
+    float *host_out;            // EPI_STORE, LM head on one GPU: device address of the pinned host logits buffer (used when ctl[CTL_HOSTOUT])
     // PRO_NORM_PARTS: x + sum_p parts[p][.] is the input (fixed order p = 0..nparts-1); block 0 stores it to x_out
     const float *parts;
     int nparts;
@@ -737,6 +738,10 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
     }
     unsigned e_tag = 0;
     if (EPI == EPI_P2P) e_tag = ((unsigned)sload_i32(reinterpret_cast<const int *>(P.p2p_epoch)) << 8) | P.p2p_seam;
+    // LM head of a per-call Forward (nl_forward): the logits also go straight into the caller-facing pinned host buffer --
+    // 64-byte posted writes over the link while the launch runs, instead of a DMA operation behind it (~13 us per call)
+    int e_hostout = 0;
+    if (EPI == EPI_STORE && P.host_out) e_hostout = sload_i32(P.ctl + CTL_HOSTOUT);
     int ns = 1;
     if (PRO == PRO_ATTN) ns = sload_i32(P.ctl + CTL_POS) / ATT_CH + 1;
 
@@ -922,6 +927,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(GemvParams P) {
 #pragma unroll
             for (int pr = 0; pr < 8; pr++)
                 if (P.peer_out[pr]) P.peer_out[pr][row] = v;
+            if (e_hostout) P.host_out[row] = v;
         }
         if (P.amax_val) {
             // fused partial argmax over this wave's rows (go/main.go:400-408: strict '>' => lowest index
