@@ -229,6 +229,8 @@ struct nl_engine {
     int fused_mode = 0;           // 1: whole attention half per layer (nl_block.h); 2: projection + attention (nl_group.h);
                                   // 3: a tensor-parallel rank's layer as two launches (nl_tp.h); 4: one GPU, wide tier: mode 3's
                                   // attention half with a direct seam (projection + attention + WO), then the two GEMVs
+    bool wide_ffn = false;        // mode 4: gate || up + down as ONE launch as well (wide_ffn_kernel, nl_tp.h)
+    int wide_nf = 1, wide_ngc = 1;
     struct TpGeom {               // mode 3 geometry, fixed at nl_finalize
         int wo_gshift = 0;        // log2 of the 256-column groups of a WO row
         int wo_tpw = 1;           // WO tiles per block of the attention launch's grid
@@ -800,6 +802,32 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
             TpSeam S{};
             S.n = -1; S.rows = c.dim;
             plan.push_back(tp_attn_op(S, 0, nullptr));
+            if (e->wide_ffn) {
+                WideFfnParams F{};
+                F.gate_q = L.gate.q; F.gate_s = L.gate.s; F.up_q = L.up.q; F.up_s = L.up.s; F.dn_q = L.down.q; F.dn_s = L.down.s;
+                F.D = c.dim; F.I = e->Is; F.npairs = L.gate.npairs; F.gu_tiles = L.gate.ntiles;
+                F.dn_npairs = L.down.npairs; F.dn_ntiles = L.down.ntiles;
+                const int grid = L.down.ntiles;
+                F.rounds = (L.gate.ntiles + grid - 1) / grid;
+                F.normw = L.ffn_norm; F.eps = c.rms_eps; F.x = e->x[cur]; F.hx = e->tp_hx;
+                F.tick = e->tick; F.layer_tag = (unsigned)(l + 1);
+                F.status = e->tick + 1; F.host_status = e->h_status; F.spin_limit = e->spin_limit;
+                const int wt = L.gate.wtype, nf = e->wide_nf, ngc = e->wide_ngc, rounds = F.rounds;
+                const size_t lds = wide_ffn_lds_bytes(nf, L.down.npairs);
+                plan.push_back({K_FFNBLOCK, 0, nullptr, 0, [F, wt, grid, nf, ngc, rounds, lds](hipStream_t st) {
+#define NL_WF(WT_, NF_, NGC_, R_) hipLaunchKernelGGL((wide_ffn_kernel<WT_, NF_, NGC_, R_>), dim3(grid), dim3(TP_THREADS), lds, st, F)
+#define NL_WF1(WT_, NF_, NGC_) do { if (rounds <= 1) NL_WF(WT_, NF_, NGC_, 1); else if (rounds == 2) NL_WF(WT_, NF_, NGC_, 2); \
+                                    else if (rounds == 3) NL_WF(WT_, NF_, NGC_, 3); else NL_WF(WT_, NF_, NGC_, 4); } while (0)
+#define NL_WF2(WT_, NF_) do { if (ngc <= 1) NL_WF1(WT_, NF_, 1); else NL_WF1(WT_, NF_, 3); } while (0)
+                                       if (wt == WT_Q8_0) { if (nf == 1) NL_WF2(WT_Q8_0, 1); else NL_WF2(WT_Q8_0, 2); }
+                                       else { if (nf == 1) NL_WF2(WT_Q4_0, 1); else NL_WF2(WT_Q4_0, 2); }
+#undef NL_WF2
+#undef NL_WF1
+#undef NL_WF
+                                       return hipGetLastError();
+                                   }});
+                continue;
+            }
         } else {
         if (fused && e->fused_mode == 2) {
             // projection + RoPE + KV store + attention as one launch (nl_group.h); WO below consumes its partials
@@ -2102,6 +2130,26 @@ int nl_finalize(nl_handle e) {
         }
         e->fused_mode = ok1 ? 1 : ok3 ? 3 : ok4 ? 4 : ok2 ? 2 : 0;
         e->fused = e->fused_mode != 0;
+        e->wide_ffn = false;
+        if (e->fused_mode == 4) {
+            // the feed-forward half as one launch too (wide_ffn_kernel): one workgroup per W_down tile, all resident together
+            const nl_engine::Layer &L0 = e->layers[0];
+            const char *wf = getenv("NL_WIDE_FFN");               // knob (tests, tools): 0 keeps the two GEMV launches
+            const int ngroups = (L0.gate.npairs + KL - 1) / KL, dgroups = (L0.down.npairs + KL - 1) / KL;
+            bool okw = !(wf && atoi(wf) == 0) && ngroups <= 16 && dgroups <= 48 && L0.gate.ntiles * GPT <= 5 * TP_THREADS &&
+                       L0.down.ntiles <= e->num_cus && L0.gate.ntiles >= L0.down.ntiles &&
+                       L0.down.ntiles * 4 >= e->num_cus * 3;     // its grid is one workgroup per W_down tile: only a grid that fills the chip
+                                                                 // streams as fast as the GEMVs' (goldie, 96 tiles: 10.2 us against 4.6 + 4.0)
+            for (const auto &L : e->layers)
+                okw = okw && L.gate.wtype == L.qkv.wtype && L.up.wtype == L.qkv.wtype && L.down.wtype == L.qkv.wtype &&
+                      L.gate.ntiles == L0.gate.ntiles && L.gate.npairs == L0.gate.npairs && L.up.ntiles == L0.gate.ntiles &&
+                      L.down.npairs == L0.down.npairs && L.down.ntiles == L0.down.ntiles;
+            e->wide_nf = (ngroups + 7) / 8;
+            e->wide_ngc = (dgroups + 15) / 16 <= 1 ? 1 : 3;       // (two groups per wavefront run as three, the third masked)
+            okw = okw && (L0.gate.ntiles + L0.down.ntiles - 1) / L0.down.ntiles <= 4;   // rounds are compile-time: 1 .. 4
+            okw = okw && wide_ffn_lds_bytes(e->wide_nf, L0.down.npairs) <= (size_t)160 * 1024;
+            e->wide_ffn = okw;
+        }
         const char *fm = getenv("NL_FUSED_MAX_POS");
         // tools/fused_limit.py: the per-head blocks (mode 1) win up to ~500 (nano) / ~600 (mini) positions, the projection +
         // attention launch of the wide tiers (mode 2) up to ~390 (big)

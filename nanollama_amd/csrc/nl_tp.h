@@ -106,6 +106,12 @@ __device__ __forceinline__ u32x4 gran16_load(const u32x4 *p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
+__device__ __forceinline__ void gran16_load5(const u32x4 *p0, const u32x4 *p1, const u32x4 *p2, const u32x4 *p3, const u32x4 *p4,
+                                             u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, u32x4 &e) {
+    asm volatile("global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\tglobal_load_dwordx4 %2, %7, off sc1\n\t"
+                 "global_load_dwordx4 %3, %8, off sc1\n\tglobal_load_dwordx4 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4) : "memory");
+}
 __device__ __forceinline__ void gran16_load2(const u32x4 *p0, const u32x4 *p1, u32x4 &a, u32x4 &b) {
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b) : "v"(p0), "v"(p1) : "memory");
@@ -763,6 +769,222 @@ __global__ void __launch_bounds__(TP_THREADS) tp_ffn_kernel(TpFfnParams P) {
     if ((int)blockIdx.x < P.n_prod) tp_ffn_body<WT, NF, NGC, NR, true>(P, smem);
     else if ((int)blockIdx.x < P.n_cons) tp_ffn_body<WT, NF, NGC, NR, false>(P, smem);
     TP_CENSUS(1, P.layer_tag, 1);
+}
+
+// ------------------------------------------------------------- feed-forward half of a WHOLE wide layer on one GPU ---
+//
+// go/model.go:597-612 for the 7.9B tier without tensor parallelism: gate || up (51 MB) and down (25 MB) were two GEMV launches,
+// 12.7 + 6.8 us, each with its ~3 us of launch-fixed cost.  Here one launch of one 1024-thread workgroup per W_down tile
+// (256 for D = 4096 -- every compute unit) keeps HBM streaming from its first request to the last W_down byte:
+//   rounds r = 0 .. R-1: the workgroup projects gate tile t and up tile t, t = block + r * grid (8 wavefronts each, a
+//     wavefront holds NF 256-column groups of its tile's rows; the next round's weights are requested before this round's dot
+//     products), sums them in LDS, applies RMSNorm's 1 / rms, SiLU(gate) * up (go/quant.go:629-631) and publishes the 16
+//     values of h as six tagged 16-byte granules;
+//   its W_down tile (16 rows x I columns, NGC 256-column groups per wavefront: 99 KB per workgroup, in registers) and its
+//     residual rows are requested behind the LAST round's weights and arrive while that round and the gather run;
+//   every workgroup gathers all of h (I / 16 tiles) into LDS, multiplies its rows and stores x = resid + row.
+// No workgroup waits for anything but the h granules, so the grid only has to be resident together (one workgroup per compute
+// unit: the host enables the launch only when the device has that many); polls are bounded like every exchange here.
+struct WideFfnParams {
+    const uint8_t *gate_q, *up_q;
+    const uint32_t *gate_s, *up_s;
+    const uint8_t *dn_q;
+    const uint32_t *dn_s;
+    int D, I, npairs, gu_tiles;       // npairs of a gate / up row (D / 64); gu_tiles = ceil(I / 16)
+    int dn_npairs, dn_ntiles, rounds; // rounds = ceil(gu_tiles / grid)
+    const float *normw;
+    float eps;
+    float *x;                         // residual stream: RMSNorm input, rewritten row by row by the tile owners
+    u32x4 *hx;                        // [gu_tiles][6] granules of h
+    const unsigned *tick;
+    unsigned layer_tag;
+    unsigned *status, *host_status;
+    int spin_limit;
+};
+
+__host__ __device__ constexpr size_t wide_ffn_lds_bytes(int nf, int dn_npairs) {
+    return 16 * sizeof(double) + sizeof(float) * (size_t)(16 * nf * XS_WAVE + 2 * 16 * TR + dn_npairs * XS_PAIR + 16 * TR);
+}
+
+// R = rounds (compile time: every load below is unconditional and in program order, so hipcc's counted waits are exact -- the
+// first version looped over a runtime round count with the prefetches behind branches and waited vmcnt(0) between single loads:
+// 29 us for what two GEMV launches do in 19.6).  One weight buffer: a round's registers are re-requested for the next round as
+// soon as its dot products have consumed them; the W_down tile goes out behind the last round.  Measured and dropped: two
+// rounds in flight (20.9 against 19.7 us per launch, and 2 us per layer slower inside the chain); W_down requested by twelve
+// wavefronts only so that the other four -- whose queues stay empty: a wavefront's loads return in order, a granule cannot
+// overtake weights in flight -- gather h while it streams (21.6 us: four wavefronts need four dependent sweeps for the 4128
+// granules).
+template <int WT, int NF, int NGC, int R>
+__global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
+    NL_KARGS8(P.gate_q, P.up_q, P.gate_s, P.up_s, P.dn_q, P.dn_s, P.x, P.normw);
+    NL_KARGS8(P.D, P.I, P.npairs, P.gu_tiles, P.dn_npairs, P.dn_ntiles, P.rounds, P.eps);
+    NL_KARGS8(P.hx, P.tick, P.layer_tag, P.status, P.host_status, P.spin_limit, P.x, P.normw);
+    constexpr int CPP = WTraits<WT>::CPP, NW = TP_THREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *dred = reinterpret_cast<double *>(smem);                 // [16]
+    float *xs = reinterpret_cast<float *>(dred + 16);                // [16 wavefronts][NF][XS_WAVE]: x * g of the wavefront's groups
+    float *red = xs + NW * NF * XS_WAVE;                             // [2][16][16]: a round's per-wavefront row sums (parity of the round)
+    float *hs = red + 2 * NW * TR;                                   // [dn_npairs][XS_PAIR]: h
+    float *red2 = hs + P.dn_npairs * XS_PAIR;                        // [16][16]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane >> 2, k = lane & 3, D = P.D;
+    const int b = (int)blockIdx.x, nb = (int)gridDim.x;
+    const unsigned tag = ((unsigned)sload_i32(reinterpret_cast<const int *>(P.tick)) << 8) | P.layer_tag;
+    const int wsel = wave >> 3, cs = wave & 7;                       // 0: the gate tile's wavefronts, 1: the up tile's
+    const uint8_t *const Wq = wsel ? P.up_q : P.gate_q;
+    const uint32_t *const Ws = wsel ? P.up_s : P.gate_s;
+    const int ngroups = (P.npairs + KL - 1) / KL;
+
+    // ---- x and the norm weights of this wavefront's groups, the residual rows of the block's tile, round 0's weights ----
+    float4 xv[NF], gv[NF];
+    uint4 cw[NF][CPP];
+    uint2 sw[NF];
+    bool lv[NF], xin[NF];
+    int ggs[NF], gsz[NF];
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        const int g = cs + f * 8;
+        ggs[f] = min(g, ngroups - 1);
+        gsz[f] = min(KL, P.npairs - ggs[f] * KL);
+        lv[f] = g < ngroups && k < gsz[f];
+        const int xcol = ggs[f] * (KL * PAIR) + lane * 4;
+        xin[f] = g < ngroups && xcol < D;
+        xv[f] = ld_off<float4>(P.x, (unsigned)(xcol < D ? xcol : 0) * 4u);
+        gv[f] = ld_off<float4>(P.normw, (unsigned)(xcol < D ? xcol : 0) * 4u);
+    }
+    const int o_row = b * TR + (tid & 15);
+    const bool o_act = tid < TR && b < P.dn_ntiles && o_row < D;
+    const float e_resid = P.x[min(o_row, D - 1)];
+    auto load_round = [&](int rnd) {
+        const int t = min(b + rnd * nb, P.gu_tiles - 1);                       // (a block without a tile in the last round repeats a request)
+#pragma unroll
+        for (int f = 0; f < NF; f++) load_pair<WT>(Wq, Ws, (long long)t * P.npairs, ggs[f], gsz[f], r, min(k, gsz[f] - 1), cw[f], sw[f]);
+    };
+    load_round(0);
+    const int dgroups = (P.dn_npairs + KL - 1) / KL;
+    const int dtile = min(b, P.dn_ntiles - 1);
+    uint4 dw[NGC][CPP];
+    uint2 dsw[NGC];
+    bool dlv[NGC];
+    int gsel[NGC];
+#pragma unroll
+    for (int j = 0; j < NGC; j++) { dlv[j] = false; gsel[j] = 0; }
+    auto down_loads = [&]() {
+#pragma unroll
+        for (int j = 0; j < NGC; j++) {
+            const int g = wave + j * NW, gg = min(g, dgroups - 1);
+            const int gs = min(KL, P.dn_npairs - gg * KL);
+            dlv[j] = b < P.dn_ntiles && g < dgroups && k < gs;
+            gsel[j] = min(gg * KL + k, P.dn_npairs - 1);
+            load_pair<WT>(P.dn_q, P.dn_s, (long long)dtile * P.dn_npairs, gg, gs, r, min(k, gs - 1), dw[j], dsw[j]);
+        }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- x * g into wave-private LDS (once), the sum of squares by the gate wavefronts ----
+    float *xw = xs + wave * NF * XS_WAVE;
+    double ss = 0.0;
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        float4 xa = xin[f] ? xv[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wsel == 0) {
+            ss = fma((double)xa.x, (double)xa.x, ss); ss = fma((double)xa.y, (double)xa.y, ss);
+            ss = fma((double)xa.z, (double)xa.z, ss); ss = fma((double)xa.w, (double)xa.w, ss);
+        }
+        xa.x *= gv[f].x; xa.y *= gv[f].y; xa.z *= gv[f].z; xa.w *= gv[f].w;
+        *reinterpret_cast<float4 *>(xw + f * XS_WAVE + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
+    }
+    ss = wave_sum_f64(ss);
+    if (wsel == 0 && lane == 0) dred[cs] = ss;
+    __builtin_amdgcn_wave_barrier();
+
+    float inv = 0.f;
+#pragma unroll
+    for (int rnd = 0; rnd < R; rnd++) {
+        const int t = b + rnd * nb;
+        const bool has = t < P.gu_tiles;                     // (block-uniform; a block without a tile computes on a repeated one and drops it)
+        float acc = 0.f;
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            const float a1 = PairDot<WT>::run(cw[f], sw[f], xw + f * XS_WAVE + k * XS_PAIR, acc);
+            acc = lv[f] ? a1 : acc;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (rnd + 1 < R) load_round(rnd + 1);                // the freed registers go straight back out
+        else down_loads();
+        __builtin_amdgcn_sched_barrier(0);
+        acc = quad_sum(acc);
+        float *rd = red + (rnd & 1) * NW * TR;
+        if (k == 0) rd[wave * TR + r] = acc;
+        __syncthreads();
+        if (rnd == 0 && tid < TR) {
+            double tot = 0.0;
+            for (int w = 0; w < 8; w++) tot += dred[w];
+            inv = (float)(1.0 / sqrt(tot / (double)D + (double)P.eps));
+        }
+        if (wave == 0 && has) {
+            float outv = 0.f;
+            if (lane < TR) {
+                float a = 0.f, u = 0.f;
+                for (int w = 0; w < 8; w++) { a += rd[w * TR + lane]; u += rd[(8 + w) * TR + lane]; }   // fixed order
+                const float g = a * inv;
+                outv = (g / (1.0f + exp_f64_as_f32(-g))) * (u * inv);                                     // go/quant.go:629-631, go/model.go:604-606
+            }
+            gran16_publish(P.hx + (size_t)t * GPT, 1, tag, outv, lane);
+        }
+    }
+    if (b >= P.dn_ntiles) return;
+
+    // ---- gather h into LDS as padded pairs (every granule fetched once, five in flight per thread, every tag checked) ----
+    {
+        for (int i = P.I + tid; i < P.dn_npairs * PAIR; i += TP_THREADS) hs[(i >> 6) * XS_PAIR + (i & 63)] = 0.f;   // ragged last pair
+        constexpr int NRG = 5, GT = TP_THREADS;
+        const int ng = P.gu_tiles * GPT;
+        const bool dead = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        for (int q0 = 0; q0 < ng; q0 += NRG * GT) {
+            u32x4 ga[NRG];
+            for (int spins = 0;; spins++) {
+                bool ok = true;
+                const u32x4 *gp[NRG];
+#pragma unroll
+                for (int q = 0; q < NRG; q++) gp[q] = P.hx + min(q0 + q * GT + tid, ng - 1);
+                gran16_load5(gp[0], gp[1], gp[2], gp[3], gp[4], ga[0], ga[1], ga[2], ga[3], ga[4]);
+#pragma unroll
+                for (int q = 0; q < NRG; q++) ok = ok && ga[q].x == tag;
+                if (__all(ok)) break;
+                if (dead || spins >= P.spin_limit) { if (lane == 0) { atomicOr(P.status, 64u); *P.host_status = 64u; } break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int q = 0; q < NRG; q++) {
+                const int gi = q0 + q * GT + tid;
+                if (gi < ng) {
+                    const int t = gi / GPT, j = gi - t * GPT;
+                    const unsigned va[3] = {ga[q].y, ga[q].z, ga[q].w};
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const int i = t * 16 + 3 * j + c;
+                        if (3 * j + c < 16 && i < P.I) hs[(i >> 6) * XS_PAIR + (i & 63)] = __uint_as_float(va[c]);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < NGC; j++) {
+        const float a1 = PairDot<WT>::run(dw[j], dsw[j], hs + gsel[j] * XS_PAIR, acc);
+        acc = dlv[j] ? a1 : acc;
+    }
+    acc = quad_sum(acc);
+    if (k == 0) red2[wave * TR + r] = acc;
+    __syncthreads();
+    if (o_act) {
+        float v = 0.f;
+        for (int w = 0; w < NW; w++) v += red2[w * TR + (tid & 15)];      // fixed order (a wavefront without a group left 0)
+        P.x[o_row] = e_resid + v;
+    }
 }
 
 // x[i] += sum[i]: the in-process shard group's counterpart of the owner lanes' store (nl_group_forward)

@@ -1603,6 +1603,54 @@ def test_fused_projection_attention_launch_matches_oracle(hip, orc, tmp_path, mo
     dev.close(); plain.close(); ref.close()
 
 
+@pytest.mark.parametrize("name,wtype", [("d3072_i8192", "q4_0"), ("d4096_i5632", "q4_0"), ("d3072_i8192", "q8_0")])
+def test_wide_layer_as_two_launches_matches_oracle(hip, orc, tmp_path, monkeypatch, name, wtype):
+    # One GPU, a layer as wide as the 7.9B tier's: projection + attention + WO in one launch (fused mode 4) and gate || up +
+    # SwiGLU + down in one launch (wide_ffn_kernel, nl_tp.h: one workgroup per W_down tile, compile-time rounds of gate / up
+    # tiles, h through tagged granules) -- 2 launches per layer.  Against the oracle across the 128-position pass boundary,
+    # against the same model with the two GEMV launches (NL_WIDE_FFN=0), greedy continuation, and the timeout fallback.
+    shape = {"d3072_i8192": synth.ModelShape("wl_a", 2, 3072, 48, 12, 2048, seq_len=160, interm=8192),      # 3 rounds, 32 W_down groups
+             "d4096_i5632": synth.ModelShape("wl_b", 2, 4096, 64, 16, 2048, seq_len=160, interm=5632)}[name]  # 2 rounds (the second partial), 22 groups
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, wtype, 91, mode="qrand")
+    g = gguf.load_gguf(str(p))
+    dev = hip.load_llama_model(g)
+    info = dev.plan_info()
+    assert info["fused_mode"] == 4 and info["launches_fused"] == 2 * shape.n_layer + 3, info
+    monkeypatch.setenv("NL_WIDE_FFN", "0")
+    split = hip.load_llama_model(g)
+    assert split.plan_info()["launches_fused"] == 3 * shape.n_layer + 3
+    monkeypatch.delenv("NL_WIDE_FFN")
+    ref = orc.OracleModel(g)
+    orc.set_threads(min(16, os.cpu_count() or 1))
+    toks = synth.prompt_ids(134, shape.vocab, seed=37)
+    worst = gap = 0.0
+    for pos, t in enumerate(toks):
+        dev.forward(t, pos)
+        split.forward(t, pos)
+        want = ref.forward(t, pos)
+        worst = max(worst, float(np.abs(dev.state.logits - want).max()) / max(1.0, float(want.std())))
+        gap = max(gap, float(np.abs(dev.state.logits - split.state.logits).max()))
+    orc.set_threads(1)
+    print(f"\nwide layer as two launches {name}/{wtype}: max|gpu-oracle|={worst:.2e}, max|fused-split|={gap:.2e}")
+    assert worst <= LOGIT_TOL
+    first = int(np.argmax(dev.state.logits))
+    assert dev.decode_greedy(first, len(toks), 12) == split.decode_greedy(first, len(toks), 12)
+    assert dev.last_error() == ""
+    dev.close(); split.close()
+    # every exchange poll gives up at once: the step is redone on the general plan, same logits as the oracle's
+    monkeypatch.setenv("NL_FUSED_SPIN_LIMIT", "0")
+    monkeypatch.setenv("NL_QUIET", "1")
+    fb = hip.load_llama_model(g)
+    ref2 = orc.OracleModel(g)
+    for pos, t in enumerate(toks[:3]):
+        fb.forward(t, pos)
+        want = ref2.forward(t, pos)
+        assert np.abs(fb.state.logits - want).max() <= LOGIT_TOL * max(1.0, float(want.std()))
+    assert "timed out" in fb.last_error() and fb.plan_info()["fused_mode"] == 0
+    fb.close(); ref.close(); ref2.close()
+
+
 def test_f16_prompt_prefill_runs_on_the_matrix_cores(hip, orc, tmp_path):
     # F16 files (BASELINE.json configs[0]'s format, go/quant.go:527-563) take the multi-token MFMA path too: the
     # fp16 weights are their own exact operand, no scale step; a prompt long enough for the fused RoPE and SwiGLU
