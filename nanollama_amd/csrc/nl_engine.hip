@@ -229,7 +229,8 @@ struct nl_engine {
     int fused_mode = 0;           // 1: whole attention half per layer (nl_block.h); 2: projection + attention (nl_group.h);
                                   // 3: a tensor-parallel rank's layer as two launches (nl_tp.h); 4: one GPU, wide tier: mode 3's
                                   // attention half with a direct seam (projection + attention + WO), then the two GEMVs
-    bool wide_ffn = false;        // mode 4: gate || up + down as ONE launch as well (wide_ffn_kernel, nl_tp.h)
+    bool wide_ffn = false;        // modes 3 / 4: the feed-forward half is wide_ffn_kernel (nl_tp.h): always in mode 4 when eligible, in
+                                  // mode 3 when the rank's shard is too large for tp_ffn_kernel's one-tile producers (tp 2 of the 7.9B tier)
     int wide_nf = 1, wide_ngc = 1;
     struct TpGeom {               // mode 3 geometry, fixed at nl_finalize
         int wo_gshift = 0;        // log2 of the 256-column groups of a WO row
@@ -736,6 +737,35 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         op.add_to = e->x[cur];
         return op;
         };
+        // the feed-forward half as one launch of wide_ffn_kernel (nl_tp.h): one GPU (direct seam) or a tensor-parallel rank's
+        auto wide_ffn_op = [&](const TpSeam &sm, int coll, float *cbuf) {
+        WideFfnParams F{};
+        F.gate_q = L.gate.q; F.gate_s = L.gate.s; F.up_q = L.up.q; F.up_s = L.up.s; F.dn_q = L.down.q; F.dn_s = L.down.s;
+        F.D = c.dim; F.I = e->Is; F.npairs = L.gate.npairs; F.gu_tiles = L.gate.ntiles;
+        F.dn_npairs = L.down.npairs; F.dn_ntiles = L.down.ntiles;
+        const int grid = L.down.ntiles;
+        F.rounds = (L.gate.ntiles + grid - 1) / grid;
+        F.normw = L.ffn_norm; F.eps = c.rms_eps; F.x = e->x[cur]; F.hx = e->tp_hx;
+        F.tick = p2p ? e->p2p.epoch : e->tick; F.layer_tag = (unsigned)(l + 1);
+        F.status = e->tick + 1; F.host_status = e->h_status; F.spin_limit = e->spin_limit;
+        const int wt = L.gate.wtype, nf = e->wide_nf, ngc = e->wide_ngc, rounds = F.rounds;
+        const size_t lds = wide_ffn_lds_bytes(nf, L.down.npairs);
+        F.seam = sm;
+        Op op{K_FFNBLOCK, coll, cbuf, (size_t)c.dim, [F, wt, grid, nf, ngc, rounds, lds](hipStream_t st) {
+#define NL_WF(WT_, NF_, NGC_, R_) hipLaunchKernelGGL((wide_ffn_kernel<WT_, NF_, NGC_, R_>), dim3(grid), dim3(TP_THREADS), lds, st, F)
+#define NL_WF1(WT_, NF_, NGC_) do { if (rounds <= 1) NL_WF(WT_, NF_, NGC_, 1); else if (rounds == 2) NL_WF(WT_, NF_, NGC_, 2); \
+                            else if (rounds == 3) NL_WF(WT_, NF_, NGC_, 3); else NL_WF(WT_, NF_, NGC_, 4); } while (0)
+#define NL_WF2(WT_, NF_) do { if (ngc <= 1) NL_WF1(WT_, NF_, 1); else NL_WF1(WT_, NF_, 3); } while (0)
+                               if (wt == WT_Q8_0) { if (nf == 1) NL_WF2(WT_Q8_0, 1); else NL_WF2(WT_Q8_0, 2); }
+                               else { if (nf == 1) NL_WF2(WT_Q4_0, 1); else NL_WF2(WT_Q4_0, 2); }
+#undef NL_WF2
+#undef NL_WF1
+#undef NL_WF
+                               return hipGetLastError();
+                           }};
+        op.add_to = e->x[cur];
+        return op;
+        };
         if (fused && e->fused_mode == 3) {
             // a tensor-parallel rank's layer as two launches (nl_tp.h): both finish their all-reduce seam in the tail (push
             // path), or leave the rank's partial in `ar` for the in-process group to sum and add (coll 3)
@@ -755,6 +785,10 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
             };
             {
                 plan.push_back(tp_attn_op(make_seam(seam++), p2p ? 0 : 3, p2p ? nullptr : e->ar));
+            }
+            if (e->wide_ffn) {
+                plan.push_back(wide_ffn_op(make_seam(seam++), p2p ? 0 : 3, p2p ? nullptr : e->ar));
+                continue;
             }
             {
                 TpFfnParams F{};
@@ -803,29 +837,7 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
             S.n = -1; S.rows = c.dim;
             plan.push_back(tp_attn_op(S, 0, nullptr));
             if (e->wide_ffn) {
-                WideFfnParams F{};
-                F.gate_q = L.gate.q; F.gate_s = L.gate.s; F.up_q = L.up.q; F.up_s = L.up.s; F.dn_q = L.down.q; F.dn_s = L.down.s;
-                F.D = c.dim; F.I = e->Is; F.npairs = L.gate.npairs; F.gu_tiles = L.gate.ntiles;
-                F.dn_npairs = L.down.npairs; F.dn_ntiles = L.down.ntiles;
-                const int grid = L.down.ntiles;
-                F.rounds = (L.gate.ntiles + grid - 1) / grid;
-                F.normw = L.ffn_norm; F.eps = c.rms_eps; F.x = e->x[cur]; F.hx = e->tp_hx;
-                F.tick = e->tick; F.layer_tag = (unsigned)(l + 1);
-                F.status = e->tick + 1; F.host_status = e->h_status; F.spin_limit = e->spin_limit;
-                const int wt = L.gate.wtype, nf = e->wide_nf, ngc = e->wide_ngc, rounds = F.rounds;
-                const size_t lds = wide_ffn_lds_bytes(nf, L.down.npairs);
-                plan.push_back({K_FFNBLOCK, 0, nullptr, 0, [F, wt, grid, nf, ngc, rounds, lds](hipStream_t st) {
-#define NL_WF(WT_, NF_, NGC_, R_) hipLaunchKernelGGL((wide_ffn_kernel<WT_, NF_, NGC_, R_>), dim3(grid), dim3(TP_THREADS), lds, st, F)
-#define NL_WF1(WT_, NF_, NGC_) do { if (rounds <= 1) NL_WF(WT_, NF_, NGC_, 1); else if (rounds == 2) NL_WF(WT_, NF_, NGC_, 2); \
-                                    else if (rounds == 3) NL_WF(WT_, NF_, NGC_, 3); else NL_WF(WT_, NF_, NGC_, 4); } while (0)
-#define NL_WF2(WT_, NF_) do { if (ngc <= 1) NL_WF1(WT_, NF_, 1); else NL_WF1(WT_, NF_, 3); } while (0)
-                                       if (wt == WT_Q8_0) { if (nf == 1) NL_WF2(WT_Q8_0, 1); else NL_WF2(WT_Q8_0, 2); }
-                                       else { if (nf == 1) NL_WF2(WT_Q4_0, 1); else NL_WF2(WT_Q4_0, 2); }
-#undef NL_WF2
-#undef NL_WF1
-#undef NL_WF
-                                       return hipGetLastError();
-                                   }});
+                plan.push_back(wide_ffn_op(S, 0, nullptr));
                 continue;
             }
         } else {
@@ -2044,6 +2056,27 @@ int nl_finalize(nl_handle e) {
         // mode 3 (nl_tp.h): a tensor-parallel rank's layer as two launches -- ranks of a push group, or the shards of an
         // in-process group that asked for it (NL_FLAG_GROUP_FUSED: the same kernels, the group adds the partials itself)
         const bool group_fused = (c.flags & NL_FLAG_LOCAL_GROUP) && (c.flags & NL_FLAG_GROUP_FUSED);
+        // wide_ffn_kernel (nl_tp.h) for this handle's (shard of the) feed-forward half: one workgroup per W_down tile, all resident
+        // together.  NL_WIDE_FFN: 0 = never, 2 = also when its grid does not fill the chip (tests at small shapes)
+        auto wide_ffn_ok = [&]() {
+            const nl_engine::Layer &L0 = e->layers[0];
+            const char *wf = getenv("NL_WIDE_FFN");
+            const int wfv = wf ? atoi(wf) : 1;
+            const int ngroups = (L0.gate.npairs + KL - 1) / KL, dgroups = (L0.down.npairs + KL - 1) / KL;
+            bool okw = wfv != 0 && ngroups <= 16 && dgroups <= 48 && L0.gate.ntiles * GPT <= 5 * TP_THREADS && L0.down.ntiles <= e->num_cus &&
+                       (L0.gate.ntiles + L0.down.ntiles - 1) / L0.down.ntiles <= 4 &&          // rounds are compile-time: 1 .. 4
+                       // its grid is one workgroup per W_down tile: only a grid that fills the chip streams as fast as the GEMVs'
+                       // (goldie, 96 tiles: 10.2 us against 4.6 + 4.0)
+                       (wfv == 2 || L0.down.ntiles * 4 >= e->num_cus * 3);
+            for (const auto &L : e->layers)
+                okw = okw && L.gate.wtype == L.qkv.wtype && L.up.wtype == L.qkv.wtype && L.down.wtype == L.qkv.wtype &&
+                      (L.qkv.wtype == WT_Q8_0 || L.qkv.wtype == WT_Q4_0) &&
+                      L.gate.ntiles == L0.gate.ntiles && L.gate.npairs == L0.gate.npairs && L.up.ntiles == L0.gate.ntiles &&
+                      L.down.npairs == L0.down.npairs && L.down.ntiles == L0.down.ntiles;
+            e->wide_nf = (ngroups + 7) / 8;
+            e->wide_ngc = (dgroups + 15) / 16 <= 1 ? 1 : 3;       // (two groups per wavefront run as three, the third masked)
+            return okw && wide_ffn_lds_bytes(e->wide_nf, L0.down.npairs) <= (size_t)160 * 1024;
+        };
         const char *tf = getenv("NL_TP_FUSED");            // knob (tests, tools): 0 keeps a rank on the projection + attention plan
         bool ok3 = want != 0 && want != 2 && !(tf && atoi(tf) == 0) && e->hd == 64 && e->G > 1 && c.n_layers < 127 &&
                    ((e->p2p.on && !(c.flags & NL_FLAG_LOCAL_GROUP)) || group_fused);
@@ -2098,7 +2131,9 @@ int nl_finalize(nl_handle e) {
             t.nf = (ngroups + (t.pair ? 8 : 16) - 1) / (t.pair ? 8 : 16);
             t.ngc = (dgroups + 16 / ct - 1) / (16 / ct);
             t.nr = (L0.gate.ntiles * GPT + TP_THREADS - 1) / TP_THREADS;
-            ok3 = ok3 && t.ngc <= 2 && t.nf <= 2 && t.nr <= 2 && t.n_prod <= budget && L0.down.npairs <= 128;
+            const bool tpffn = t.ngc <= 2 && t.nf <= 2 && t.nr <= 2 && t.n_prod <= budget && L0.down.npairs <= 128;
+            e->wide_ffn = ok3 && !tpffn && wide_ffn_ok();        // (a shard too large for one-tile producers: tp 2 of the 7.9B tier)
+            ok3 = ok3 && (tpffn || e->wide_ffn);
             for (const auto &L : e->layers)   // (every layer has the shapes of layer 0: checked, not assumed)
                 ok3 = ok3 && L.wo.npairs == L0.wo.npairs && L.gate.ntiles == L0.gate.ntiles && L.down.npairs == L0.down.npairs &&
                       L.down.ntiles == L0.down.ntiles && L.gate.npairs == L0.gate.npairs;
@@ -2130,26 +2165,7 @@ int nl_finalize(nl_handle e) {
         }
         e->fused_mode = ok1 ? 1 : ok3 ? 3 : ok4 ? 4 : ok2 ? 2 : 0;
         e->fused = e->fused_mode != 0;
-        e->wide_ffn = false;
-        if (e->fused_mode == 4) {
-            // the feed-forward half as one launch too (wide_ffn_kernel): one workgroup per W_down tile, all resident together
-            const nl_engine::Layer &L0 = e->layers[0];
-            const char *wf = getenv("NL_WIDE_FFN");               // knob (tests, tools): 0 keeps the two GEMV launches
-            const int ngroups = (L0.gate.npairs + KL - 1) / KL, dgroups = (L0.down.npairs + KL - 1) / KL;
-            bool okw = !(wf && atoi(wf) == 0) && ngroups <= 16 && dgroups <= 48 && L0.gate.ntiles * GPT <= 5 * TP_THREADS &&
-                       L0.down.ntiles <= e->num_cus && L0.gate.ntiles >= L0.down.ntiles &&
-                       L0.down.ntiles * 4 >= e->num_cus * 3;     // its grid is one workgroup per W_down tile: only a grid that fills the chip
-                                                                 // streams as fast as the GEMVs' (goldie, 96 tiles: 10.2 us against 4.6 + 4.0)
-            for (const auto &L : e->layers)
-                okw = okw && L.gate.wtype == L.qkv.wtype && L.up.wtype == L.qkv.wtype && L.down.wtype == L.qkv.wtype &&
-                      L.gate.ntiles == L0.gate.ntiles && L.gate.npairs == L0.gate.npairs && L.up.ntiles == L0.gate.ntiles &&
-                      L.down.npairs == L0.down.npairs && L.down.ntiles == L0.down.ntiles;
-            e->wide_nf = (ngroups + 7) / 8;
-            e->wide_ngc = (dgroups + 15) / 16 <= 1 ? 1 : 3;       // (two groups per wavefront run as three, the third masked)
-            okw = okw && (L0.gate.ntiles + L0.down.ntiles - 1) / L0.down.ntiles <= 4;   // rounds are compile-time: 1 .. 4
-            okw = okw && wide_ffn_lds_bytes(e->wide_nf, L0.down.npairs) <= (size_t)160 * 1024;
-            e->wide_ffn = okw;
-        }
+        if (e->fused_mode != 3) e->wide_ffn = e->fused_mode == 4 && wide_ffn_ok();     // the feed-forward half as one launch too
         const char *fm = getenv("NL_FUSED_MAX_POS");
         // tools/fused_limit.py: the per-head blocks (mode 1) win up to ~500 (nano) / ~600 (mini) positions, the projection +
         // attention launch of the wide tiers (mode 2) up to ~390 (big)

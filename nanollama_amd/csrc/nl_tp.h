@@ -800,6 +800,7 @@ struct WideFfnParams {
     unsigned layer_tag;
     unsigned *status, *host_status;
     int spin_limit;
+    TpSeam seam;                      // n = -1: one GPU (x = resid + row); else a tensor-parallel rank's all-reduce seam
 };
 
 __host__ __device__ constexpr size_t wide_ffn_lds_bytes(int nf, int dn_npairs) {
@@ -819,6 +820,7 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
     NL_KARGS8(P.gate_q, P.up_q, P.gate_s, P.up_s, P.dn_q, P.dn_s, P.x, P.normw);
     NL_KARGS8(P.D, P.I, P.npairs, P.gu_tiles, P.dn_npairs, P.dn_ntiles, P.rounds, P.eps);
     NL_KARGS8(P.hx, P.tick, P.layer_tag, P.status, P.host_status, P.spin_limit, P.x, P.normw);
+    NL_KARGS4(P.seam.slots, P.seam.epoch, P.seam.status, P.seam.n);
     constexpr int CPP = WTraits<WT>::CPP, NW = TP_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *dred = reinterpret_cast<double *>(smem);                 // [16]
@@ -830,6 +832,7 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
     const int r = lane >> 2, k = lane & 3, D = P.D;
     const int b = (int)blockIdx.x, nb = (int)gridDim.x;
     const unsigned tag = ((unsigned)sload_i32(reinterpret_cast<const int *>(P.tick)) << 8) | P.layer_tag;
+    const unsigned e_tag = P.seam.n > 0 ? ((unsigned)sload_i32(reinterpret_cast<const int *>(P.seam.epoch)) << 8) | P.seam.seam : 0u;
     const int wsel = wave >> 3, cs = wave & 7;                       // 0: the gate tile's wavefronts, 1: the up tile's
     const uint8_t *const Wq = wsel ? P.up_q : P.gate_q;
     const uint32_t *const Ws = wsel ? P.up_s : P.gate_s;
@@ -983,7 +986,7 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
     if (o_act) {
         float v = 0.f;
         for (int w = 0; w < NW; w++) v += red2[w * TR + (tid & 15)];      // fixed order (a wavefront without a group left 0)
-        P.x[o_row] = e_resid + v;
+        tp_allreduce_row(P.seam, e_tag, o_row, v, e_resid, P.x);
     }
 }
 

@@ -106,19 +106,25 @@ def test_push_allreduce_with_4_and_8_ranks(tmp_path, n, dim, heads, kv, interm):
     grp.close()
 
 
-@pytest.mark.parametrize("n,dim,heads,kv,interm", [(2, 1024, 16, 4, 2048), (4, 512, 8, 4, 1024), (8, 512, 8, 8, 1024)])
-def test_two_launch_layer_ranks_match_the_in_process_group(tmp_path, n, dim, heads, kv, interm):
+@pytest.mark.parametrize("n,dim,heads,kv,interm", [(2, 1024, 16, 4, 2048), (4, 512, 8, 4, 1024), (8, 512, 8, 8, 1024), (2, 1024, 16, 4, 8192)])
+def test_two_launch_layer_ranks_match_the_in_process_group(tmp_path, monkeypatch, n, dim, heads, kv, interm):
     # a rank's layer as TWO launches (nl_tp.h, the default plan of a push group at short contexts): the in-process group
     # steps the same kernels and adds the partial vectors in the same rank order -- bitwise equal.  (Shapes small enough that
     # the n rank processes' resident workgroups fit the ONE GPU they share here: every block of these launches stays
     # resident until its rows are done, and a rank whose exchange starves would -- correctly -- retire the plan.)
+    # interm 8192 at 2 ranks: 256 gate tiles per rank, too many for tp_ffn_kernel's one-tile producers -- the second launch is
+    # wide_ffn_kernel with the seam in its tail (NL_WIDE_FFN=2: its 64-workgroup grid does not fill the chip at this width)
     from nanollama_amd import model
     shape = synth.ModelShape("p2p_tp_probe", 3, dim, heads, kv, 4096, seq_len=64, interm=interm)
     p = str(tmp_path / "m.gguf")
     synth.generate_gguf(p, shape, "q4_0", 59, mode="qrand")
     g = gguf.load_gguf(p)
     out = str(tmp_path / "r0_tp.npz")
-    run_ranks(n, p, out, n_tok=6, n_greedy=20, timeout=240, extra_env={"NL_QUIET": "1", "NL_P2P_SAMPLED": "20", "NL_EXPECT_FUSED_MODE": "3"})
+    env = {"NL_QUIET": "1", "NL_P2P_SAMPLED": "20", "NL_EXPECT_FUSED_MODE": "3"}
+    if interm == 8192:
+        env["NL_WIDE_FFN"] = "2"
+        monkeypatch.setenv("NL_WIDE_FFN", "2")
+    run_ranks(n, p, out, n_tok=6, n_greedy=20, timeout=240, extra_env=env)
     tp = np.load(out)
     grp = model.LocalTPGroup(g, n, fused=True)
     assert grp.shards[0].plan_info()["fused_mode"] == 3

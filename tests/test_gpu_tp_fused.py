@@ -35,6 +35,10 @@ SHAPES = {
     "wide": (synth.ModelShape("tpf_wide", 2, 4096, 64, 16, 2048, seq_len=160, interm=4096), (4,)),
     # 16 kv groups of 2 heads per rank at tp 2: a projection workgroup holds two tiles, a wavefront two column groups
     "two_tiles": (synth.ModelShape("tpf_two_tiles", 2, 4096, 64, 32, 2048, seq_len=160, interm=2048), (2,)),
+    # a rank's shard of the feed-forward half too large for one-tile producers (256 gate tiles per rank at tp 2 > the compute
+    # units' budget: the 7.9B tier at tp 2): its second launch is wide_ffn_kernel with the all-reduce seam in its tail -- four
+    # rounds of gate / up tiles per workgroup (NL_WIDE_FFN=2 lets the 64-workgroup grid of this small width through)
+    "wide_ffn": (synth.ModelShape("tpf_wide_ffn", 2, 1024, 16, 4, 4096, seq_len=160, interm=8192), (2,)),
 }
 
 
@@ -54,7 +58,8 @@ def orc():
 
 @pytest.mark.parametrize("pair", ["auto", "pair", "split"])
 @pytest.mark.parametrize("name,wtype", [("gqa4", "q4_0"), ("gqa4", "q8_0"), ("mha8", "q4_0"), ("ragged", "q4_0"),
-                                        ("qknorm_conj_bias", "q8_0"), ("wide", "q4_0"), ("two_tiles", "q4_0")])
+                                        ("qknorm_conj_bias", "q8_0"), ("wide", "q4_0"), ("two_tiles", "q4_0"), ("wide_ffn", "q4_0"),
+                                        ("wide_ffn", "q8_0")])
 def test_two_launch_layer_in_process_group_matches_oracle(hip, orc, tmp_path, monkeypatch, name, wtype, pair):
     shape, sizes = SHAPES[name]
     if pair != "auto" and name not in ("gqa4", "ragged", "wide"):
@@ -64,6 +69,8 @@ def test_two_launch_layer_in_process_group_matches_oracle(hip, orc, tmp_path, mo
     g = gguf.load_gguf(str(p))
     if pair != "auto":
         monkeypatch.setenv("NL_TP_PAIR", "1" if pair == "pair" else "0")
+    if name == "wide_ffn":
+        monkeypatch.setenv("NL_WIDE_FFN", "2")
     ref = orc.OracleModel(g)
     orc.set_threads(min(16, os.cpu_count() or 1))
     toks = synth.prompt_ids(140, shape.vocab, seed=29)          # crosses the 128-position pass boundary inside the launch

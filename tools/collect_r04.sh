@@ -8,6 +8,12 @@
 #   x1       mini prefill per-kernel stats in both prompt precision modes (hi + lo, fp16x1) and the mode's logit error
 #   ab       nano / big / mini one-GPU bench one-liners (A/B after a kernel change)
 #   bench    the driver's bench line (python bench.py --steps 20 --warmup 5) and the default one
+#   stats    rocprofv3 per-kernel stats of nano / big decode (eager launches), goldie x 64 decode streams, nano sampled decode;
+#            HBM traffic counters of nano / big (one PMC pass per counter) -> r04_traffic.json
+#   sampler  phase stamps of the sort-free top-p selection launch
+#   ingest   tools/ingest_probe.hip
+#   wide     big on one GPU: 2 launches per layer (mode 4 + wide_ffn_kernel) against NL_WIDE_FFN=0 and NL_ATTN_WO=0, alternating
+#   tests    the whole -m gpu suite
 ulimit -c 0; export TMPDIR=/tmp NL_QUIET=1; cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 O=gpurun_out/r04; mkdir -p $O
 hip="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17"
@@ -60,6 +66,24 @@ bench)
   (timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench_steps20.err | tail -1) > $O/r04_bench_n1_steps20.json.log
   (timeout 900 python bench.py 2>$O/bench_n1.err | tail -1) > $O/r04_bench_n1.json.log
   cut -c1-600 $O/r04_bench_n1_steps20.json.log ;;
+stats)
+  bash scripts_gpu_run.sh prof > $O/prof_head.txt 2>&1
+  cp gpurun_out/prof/nano_kernel_stats.csv $O/r04_nano_q8_0_kernel_stats.csv 2>/dev/null; cp gpurun_out/prof/big_kernel_stats.csv $O/r04_big_q4_0_kernel_stats.csv 2>/dev/null
+  bash tools/prof_batch.sh > /dev/null 2>&1; cp gpurun_out/prof_b/*kernel_stats.csv $O/r04_goldie_q4_0_batch64_kernel_stats.csv 2>/dev/null
+  bash tools/prof_sampling.sh > /dev/null 2>&1; cp gpurun_out/prof_s/*kernel_stats.csv $O/r04_nano_q8_0_sampling_kernel_stats.csv 2>/dev/null
+  bash tools/pmc_run.sh nano:q8_0 nano_q8_0 > /dev/null 2>&1
+  bash tools/pmc_run.sh big:q4_0 big_q4_0 > /dev/null 2>&1
+  for t in nano_q8_0 big_q4_0; do for c in FETCH_SIZE WRITE_SIZE; do cp gpurun_out/pmc_${t}_${c}_summary.csv $O/r04_${t}_pmc_${c}.csv 2>/dev/null; done; done
+  head -12 $O/r04_big_q4_0_kernel_stats.csv | cut -c1-160 ;;     # (then, in the repo: cp the csvs to profiles/ and python tools/make_traffic_json.py r04)
+sampler)
+  $hip -DNL_SAMP_STAMPS -Inanollama_amd/csrc tools/samp_probe.hip -o /tmp/sp 2>/dev/null && (/tmp/sp 1.0; /tmp/sp 0.2) > $O/r04_sampler_select_stamps.log 2>&1
+  tail -18 $O/r04_sampler_select_stamps.log ;;
+ingest)
+  $hip tools/ingest_probe.hip -o /tmp/ip 2>/dev/null && /tmp/ip > $O/r04_ingest_probe.log 2>&1; tail -5 $O/r04_ingest_probe.log ;;
+wide)
+  (bash tools/ab_env2.sh NL_WIDE_FFN=0; bash tools/ab_env2.sh NL_ATTN_WO=0) > $O/r04_big_two_launch_layer_ab.log 2>&1; cat $O/r04_big_two_launch_layer_ab.log ;;
+tests)
+  (timeout 2000 python -m pytest tests -m gpu -q 2>&1 | tail -6) > $O/pytest_gpu.log; cat $O/pytest_gpu.log ;;
 *) echo "unknown target $target" ;;
 esac
 done

@@ -22,7 +22,8 @@ def kind_of(name):
     m = re.search(r"gemv_kernel<\d+, (\d+), (\d+)(, \d+)?>", name)
     if m:
         return KIND.get((m.group(1), m.group(2)))
-    for key, kind in (("ffn_block_kernel", "ffn_block"), ("attn_block_kernel", "attn_block"), ("qkv_attn_kernel", "attn_block"), ("attn_kernel", "attention"),
+    for key, kind in (("ffn_block_kernel", "ffn_block"), ("wide_ffn_kernel", "ffn_block"), ("tp_ffn_kernel", "ffn_block"), ("attn_block_kernel", "attn_block"),
+                      ("tp_attn_kernel", "attn_block"), ("qkv_attn_kernel", "attn_block"), ("attn_kernel", "attention"),
                       ("argmax_kernel", "argmax"), ("embed_kernel", "embed")):
         if key in name and "bembed" not in name and "bargmax" not in name:
             return kind
