@@ -2169,7 +2169,9 @@ int nl_finalize(nl_handle e) {
         const char *fm = getenv("NL_FUSED_MAX_POS");
         // tools/fused_limit.py: the per-head blocks (mode 1) win up to ~500 (nano) / ~600 (mini) positions, the projection +
         // attention launch of the wide tiers (mode 2) up to ~390 (big)
-        e->fused_max_pos = fm ? atoi(fm) : e->fused_mode == 1 ? 512 : 384;
+        // (mode 4, tools/fused_limit.py on big, profiles/r04_big_fused_limit.log: the two-launch layers stay ahead of the five-launch
+        //  plan up to the 512 positions their in-launch attention covers -- 1.80 against 1.85 ms at position 470)
+        e->fused_max_pos = fm ? atoi(fm) : (e->fused_mode == 1 || e->fused_mode == 4) ? 512 : 384;
         if (e->fused_mode == 3 || e->fused_mode == 4) e->fused_max_pos = std::min(e->fused_max_pos, TP_NCH_MAX * ATT_CH);   // passes a head takes inside the launch
         {
             const char *ff = getenv("NL_FUSED_FFN");   // knob (tests, tools): 0 keeps gate/up and down as two launches
