@@ -1580,7 +1580,7 @@ def test_wide_tier_chain_crosses_all_four_attention_passes_and_the_plan_switch(h
 
 @pytest.mark.parametrize("wo", ["wo_own_launch", "wo_in_the_launch"])
 @pytest.mark.parametrize("variant,wtype", [("g4", "q4_0"), ("g4", "q8_0"), ("g8", "q4_0"), ("mha16", "q4_0"),
-                                           ("g4_two_tiles", "q4_0"), ("g4_qknorm_conj_bias", "q8_0")])
+                                           ("g4_two_tiles", "q4_0"), ("g4_qknorm_conj_bias", "q8_0"), ("goldie_width", "q4_0")])
 def test_fused_projection_attention_launch_matches_oracle(hip, orc, tmp_path, monkeypatch, variant, wtype, wo):
     # nl_group.h: Q/K/V + RoPE + KV store + attention as one launch for models too wide for the per-head block
     # (clusters of workgroups per kv group, granule exchange, G attention workgroups), against the oracle across the
@@ -1591,6 +1591,7 @@ def test_fused_projection_attention_launch_matches_oracle(hip, orc, tmp_path, mo
     if wo == "wo_own_launch":
         monkeypatch.setenv("NL_ATTN_WO", "0")
     shape = {"g4": synth.ModelShape("fg_g4", 2, 1024, 16, 4, 512, seq_len=160, interm=1024),
+             "goldie_width": synth.ModelShape("fg_goldie", 2, 1536, 24, 6, 512, seq_len=160, interm=4096),   # BASELINE config 4's tier: six column groups, six kv groups
              "g8": synth.ModelShape("fg_g8", 2, 1024, 16, 2, 512, seq_len=160, interm=1024),
              "mha16": synth.ModelShape("fg_mha", 2, 1024, 16, 16, 512, seq_len=160, interm=1024),
              "g4_two_tiles": synth.ModelShape("fg_wide", 2, 2560, 40, 10, 512, seq_len=160, interm=1024),
