@@ -2438,12 +2438,13 @@ hipError_t launch_sample(const SampScratch &s, float *logits, int vocab, const n
     // top-p up to 65536 candidates: weighted radix selection in one launch, no sort (nl_sample.h).  NL_SAMP_SORT=1 keeps the
     // sorted path (developer A/B; read once)
     static const bool force_sort = getenv("NL_SAMP_SORT") && atoi(getenv("NL_SAMP_SORT")) != 0;
-    P.radix = p.temperature > 0.f && p.top_p < 1.0f && samp_chunk(vocab) <= 64 && !force_sort ? 1 : 0;
+    P.radix = p.temperature > 0.f && p.top_p < 1.0f && !force_sort ? 1 : 0;
     hipLaunchKernelGGL(samp_penalty_kernel, dim3(P.nblocks), dim3(256), 0, st, P);
     if (P.radix) {
         hipLaunchKernelGGL(samp_prob_kernel, dim3(P.nblocks), dim3(256), 0, st, P);
+        // (<= 32768 candidates: in the registers of the one workgroup; up to 131072: streamed out of L2 pass by pass)
         if (samp_chunk(vocab) == 32) hipLaunchKernelGGL(samp_select_radix_kernel<32>, dim3(1), dim3(SAMP_THREADS), 0, st, P);
-        else hipLaunchKernelGGL(samp_select_radix_kernel<64>, dim3(1), dim3(SAMP_THREADS), 0, st, P);
+        else hipLaunchKernelGGL(samp_select_radix_stream_kernel, dim3(1), dim3(SAMP_THREADS), 0, st, P);
         return hipGetLastError();
     }
     if (p.temperature > 0.f) {

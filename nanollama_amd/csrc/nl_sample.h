@@ -15,7 +15,7 @@
 // chunk totals accumulated left to right) -- deterministic, but not the Go loop's single left-to-right chain, so a
 // u within ~1e-7 of a cdf boundary can select the neighbouring candidate.
 //
-// Round 4: top-p for vocabularies up to 65536 needs NO sort.  Both questions the Go loop asks of the sorted list -- where
+// Round 4: top-p needs NO sort (vocabularies up to 131072; the top-k branch keeps the sorted list it walks).  Both questions the Go loop asks of the sorted list -- where
 // does the cumulative probability reach top_p, and where does it reach r = u * cumsum -- are weighted rank selections, and
 // samp_select_radix_kernel answers them by radix selection on the bits of p (three histogram levels of 11 + 11 + 10 bits,
 // each bucket holding the SUM of its candidates' weights) inside one workgroup that keeps the candidates in registers.
@@ -592,6 +592,180 @@ __global__ void __launch_bounds__(SAMP_THREADS) samp_select_radix_kernel(SampleP
         P.ctl[CTL_POS] = P.ctl[CTL_POS] + 1;
     }
     SAMP_STAMP(14);
+}
+
+// ---- the same selection for vocabularies of 32769 .. 131072 candidates (the 7.9B tier): they do not fit the registers of one
+// workgroup, so every pass STREAMS the keys out of L2 -- coalesced 16-byte loads through the L2 only (agent scope: plain loads
+// of an L2-resident array reach 37 GB/s per compute unit, these 60-110, tools/ingest_probe.hip), eight in flight per lane.
+// Passes over the keys: range, level-1 histogram, one list pass per selection, the pick's id -- five instead of a 2 x 12-launch
+// device-wide sort; everything else is samp_select_radix_kernel's.
+__device__ __forceinline__ uint4 samp_ld_l2(const unsigned *base, unsigned word_off) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(base), 0, -1, 0x00020000);
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(word_off * 4u), 0, 16 /* sc1 */);
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+template <class F>
+__device__ __forceinline__ void samp_each_key(const unsigned *kin, int V, F f) {
+    const int nq = (V + 3) >> 2, tid = threadIdx.x;
+    for (int q0 = 0; q0 < nq; q0 += 8 * SAMP_THREADS) {
+        uint4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = samp_ld_l2(kin, (unsigned)min(q0 + j * SAMP_THREADS + tid, nq - 1) * 4u);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int q = q0 + j * SAMP_THREADS + tid, i = q * 4;
+            if (q < nq) {
+                f(v[j].x, i);
+                if (i + 1 < V) f(v[j].y, i + 1);
+                if (i + 2 < V) f(v[j].z, i + 2);
+                if (i + 3 < V) f(v[j].w, i + 3);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(SAMP_THREADS) samp_select_radix_stream_kernel(SampleParams P) {
+    __shared__ samp_u64 h1[2048], hw[2048];
+    __shared__ unsigned list[SAMP_LIST_CAP];
+    __shared__ samp_u64 scr[16];
+    __shared__ unsigned wcnt[SAMP_THREADS / 64], wmin[SAMP_THREADS / 64], wmax[SAMP_THREADS / 64];
+    __shared__ unsigned list_n;
+    __shared__ int s_pick;
+    const int tid = threadIdx.x, V = P.vocab;
+    const int step = P.ctl[CTL_STEP];
+    const float u = P.uniforms[step];
+    const unsigned *kin = reinterpret_cast<const unsigned *>(P.keys_in);
+    h1[tid] = 0; h1[tid + 1024] = 0;
+    if (tid == 0) s_pick = 0x7fffffff;
+    int par = 0;
+    unsigned kmin = 0xffffffffu, kmax = 0u;
+    samp_each_key(kin, V, [&](unsigned key, int) { kmin = min(kmin, max(key, SAMP_KEY_MIN)); kmax = max(kmax, key); });
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { kmin = min(kmin, (unsigned)__shfl_xor(kmin, o)); kmax = max(kmax, (unsigned)__shfl_xor(kmax, o)); }
+    if ((tid & 63) == 0) { wmin[tid >> 6] = kmin; wmax[tid >> 6] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < SAMP_THREADS / 64; w++) { kmin = min(kmin, wmin[w]); kmax = max(kmax, wmax[w]); }
+    const int B = 32 - __clz((int)(kmax - kmin));
+    const int s1 = max(B - 11, 0), s2 = max(B - 22, 0);
+    auto weight_of = [&](unsigned k) {
+        const samp_u64 m = (samp_u64)((k & 0x7fffffu) | 0x800000u) << 22;
+        return m >> (127u - (k >> 23));
+    };
+    samp_each_key(kin, V, [&](unsigned key, int) { if (key >= kmin) atomicAdd(&h1[(key - kmin) >> s1], weight_of(key)); });
+    __syncthreads();
+    auto select = [&](auto x_of, unsigned &dout, samp_u64 &rem, samp_u64 &x) {
+        const SampSel a = samp_select_bucket(h1, x_of, scr, par);
+        unsigned prefix = (unsigned)a.bucket;
+        rem = a.rem;
+        x = a.x;
+        if (s1 == 0) { dout = prefix; return; }
+        if (tid == 0) list_n = 0;
+        hw[tid] = 0; hw[tid + 1024] = 0;
+        __syncthreads();
+        samp_each_key(kin, V, [&](unsigned key, int) {
+            const unsigned d = key - kmin;                  // (a non-candidate wraps to >= 2^32 - 2^30: its d >> s1 is no bucket)
+            if ((d >> s1) == prefix) {
+                const unsigned at = atomicAdd(&list_n, 1u);
+                if (at < (unsigned)SAMP_LIST_CAP) list[at] = d;
+            }
+        });
+        __syncthreads();
+        const unsigned n = list_n;
+        const bool listed = n <= (unsigned)SAMP_LIST_CAP;
+        auto same = [](samp_u64 r) { return [r](samp_u64) { return r; }; };
+        {
+            const unsigned mask = (1u << (s1 - s2)) - 1u;
+            if (listed) {
+                for (unsigned i = tid; i < n; i += SAMP_THREADS) { const unsigned d = list[i]; atomicAdd(&hw[(d >> s2) & mask], weight_of(d + kmin)); }
+            } else {
+                samp_each_key(kin, V, [&](unsigned key, int) {
+                    const unsigned d = key - kmin;
+                    if ((d >> s1) == prefix) atomicAdd(&hw[(d >> s2) & mask], weight_of(key));
+                });
+            }
+            __syncthreads();
+            const SampSel b = samp_select_bucket(hw, same(rem), scr, par);
+            prefix = (prefix << (s1 - s2)) | (unsigned)b.bucket;
+            rem = b.rem;
+        }
+        if (s2 > 0) {
+            hw[tid] = 0; hw[tid + 1024] = 0;
+            __syncthreads();
+            const unsigned mask = (1u << s2) - 1u;
+            if (listed) {
+                for (unsigned i = tid; i < n; i += SAMP_THREADS) { const unsigned d = list[i]; if ((d >> s2) == prefix) atomicAdd(&hw[d & mask], weight_of(d + kmin)); }
+            } else {
+                samp_each_key(kin, V, [&](unsigned key, int) {
+                    const unsigned d = key - kmin;
+                    if ((d >> s2) == prefix) atomicAdd(&hw[d & mask], weight_of(key));
+                });
+            }
+            __syncthreads();
+            const SampSel c = samp_select_bucket(hw, same(rem), scr, par);
+            prefix = (prefix << s2) | (unsigned)c.bucket;
+            rem = c.rem;
+        }
+        dout = prefix;
+    };
+    auto tie_rank = [](samp_u64 rem, samp_u64 w) { return rem <= w ? (samp_u64)1 : (rem + w - 1) / w; };
+    unsigned dc, dp;
+    samp_u64 rem, xcut, xr;
+    const float top_p = P.top_p;
+    select([top_p](samp_u64 total) { const samp_u64 x = samp_ceil_mul(top_p, total); return x < 1 ? (samp_u64)1 : x; }, dc, rem, xcut);
+    const samp_u64 wc = weight_of(dc + kmin);
+    const samp_u64 cum = xcut - rem + tie_rank(rem, wc) * wc;
+    select([u, cum](samp_u64) { const samp_u64 x = samp_ceil_mul(u, cum); return x < 1 ? (samp_u64)1 : x; }, dp, rem, xr);
+    const unsigned rank = (unsigned)tie_rank(rem, weight_of(dp + kmin));
+    const unsigned kpick = dp + kmin;
+    if (rank == 1) {
+        int first = 0x7fffffff;
+        samp_each_key(kin, V, [&](unsigned key, int i) { if (key == kpick) first = min(first, i); });
+        if (first != 0x7fffffff) atomicMin(&s_pick, first);
+    } else {
+        // ties: the rank-th candidate with this p in ascending id -- contiguous ids per thread (uncoalesced reads: the rare path)
+        const int C = (V + SAMP_THREADS - 1) / SAMP_THREADS, lo = tid * C;
+        unsigned cnt = 0;
+        for (int k = 0; k < C; k++) cnt += (lo + k < V && kin[lo + k] == kpick) ? 1u : 0u;
+        unsigned inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(inc, d);
+            if ((tid & 63) >= d) inc += o;
+        }
+        if ((tid & 63) == 63) wcnt[tid >> 6] = inc;
+        __syncthreads();
+        unsigned pre = inc - cnt;
+        for (int w = 0; w < (tid >> 6); w++) pre += wcnt[w];
+        if (pre < rank && rank <= pre + cnt) {
+            unsigned seen = pre;
+            for (int k = 0; k < C; k++)
+                if (lo + k < V && kin[lo + k] == kpick) { seen++; if (seen == rank) s_pick = lo + k; }
+        }
+    }
+    __syncthreads();
+    const int pick = s_pick == 0x7fffffff ? 0 : s_pick;
+    samp_embed_tail(P, pick);
+    const int n = *P.recent_n;
+    int shifted = 0;
+    if (P.rep_window > 0 && n >= P.rep_window && tid + 1 < n) shifted = P.recent[tid + 1];   // rep_window <= 1024
+    __syncthreads();
+    if (P.rep_window > 0) {
+        if (n >= P.rep_window) {
+            if (tid + 1 < n) P.recent[tid] = shifted;
+            if (tid == 0) P.recent[n - 1] = pick;
+        } else if (tid == 0) {
+            P.recent[n] = pick;
+            *P.recent_n = n + 1;
+        }
+    }
+    if (tid == 0) {
+        P.ids[step] = pick;
+        P.ctl[CTL_STEP] = step + 1;
+        P.ctl[CTL_TOKEN] = pick;
+        P.ctl[CTL_POS] = P.ctl[CTL_POS] + 1;
+    }
 }
 
 }  // namespace nl

@@ -79,14 +79,12 @@ def _ceil_mul(f, x):
 
 
 def device_top_p(lg, temp, top_p, u):
-    """nl_sample.h's top-p for vocabularies <= 65536 (samp_select_radix_kernel), restated with Python integers: weights
+    """nl_sample.h's top-p (samp_select_radix_kernel / _stream_kernel), restated with Python integers: weights
     W_i = floor(p_i * 2^45), order = p descending / id ascending, cut = first j with CDF_j >= ceil(top_p * TOTAL), pick =
     first j with CDF_j >= max(1, ceil(u * CDF_cut)).  Returns (token, boundary_margin): margin = relative distance of the
     two threshold tests from their boundaries -- tiny margins are where the Go float32 chain may legitimately disagree."""
     if temp <= 0:
         return int(np.argmax(lg)), 1.0
-    if lg.size > 65536:
-        return device_top_p_sorted(lg, temp, top_p, u)
     p = _probs(lg, temp)
     order = np.argsort(-p, kind="stable")
     w = [int(x) for x in np.floor(p[order].astype(np.float64) * 2.0 ** 45)]
@@ -105,7 +103,7 @@ def device_top_p(lg, temp, top_p, u):
 
 
 def device_top_p_sorted(lg, temp, top_p, u):
-    """The sorted path (vocabularies > 65536, or NL_SAMP_SORT=1): the Go algorithm in nl_sample.h's summation order.
+    """The sorted path (NL_SAMP_SORT=1; the top-k branch sorts too): the Go algorithm in nl_sample.h's summation order.
     Returns (token, boundary_margin): margin = distance of the two threshold tests from their boundaries,
     relative -- tiny margins are where the Go chain and the chunked chain may legitimately disagree."""
     if temp <= 0:

@@ -74,10 +74,11 @@ def test_top_p_matches_the_go_chain(hip, V):
     assert go_mismatch <= max(2, trials // 8)
 
 
-@pytest.mark.parametrize("V", [300, 4096, 32000, 50000])
+@pytest.mark.parametrize("V", [300, 4096, 32000, 50000, 128256])
 def test_top_p_selection_without_a_sort_equals_its_integer_restatement(hip, V):
-    # vocabularies <= 65536 take samp_select_radix_kernel: no sort, weighted radix selection on exact integer weights
-    # (nl_sample.h).  sampling_mirror.device_top_p restates it with Python integers; the device must agree EXACTLY -- every
+    # top-p takes no sort: weighted radix selection on exact integer weights (nl_sample.h) -- the candidates in the registers of
+    # one workgroup up to 32768 of them (samp_select_radix_kernel), streamed out of L2 pass by pass beyond (the 7.9B tier's
+    # 128256: samp_select_radix_stream_kernel).  sampling_mirror.device_top_p restates it with Python integers; the device must agree EXACTLY -- every
     # case, not only the ones the Go chain disagrees on -- including the shapes that leave the common path:
     #   * thousands of candidates with one identical p: ties go by ascending id, the cut / the pick need the k-th of them
     #     (64-bit division, the in-order rank search), and their level-1 bucket overflows the LDS candidate list (the
