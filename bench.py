@@ -499,6 +499,20 @@ def side_configs(model):
         res[key] = round(len(ids) / (time.perf_counter() - t0), 1)
     out["nano_q8_0_default_sampling"] = res
     dev.close()
+    # -- the same settings on the 7.9B tier (96000-entry vocabulary: the selection streams its candidates out of L2)
+    try:
+        shape = synth.TIERS["big"]
+        g = gguf.load_gguf(ensure_gguf(shape, "q4_0", "qrand"))
+        dev = model.load_llama_model(g)
+        prompt = synth.prompt_ids(PROMPT_LEN, shape.vocab)
+        eng = Engine(dev, eos_id=-1, rep_penalty=1.15, rep_window=64, seed=1, device_sampling=True)
+        eng.generate_ids(prompt, GenParams(max_tokens=16, temperature=0.8, top_p=0.9))
+        t0 = time.perf_counter()
+        ids = eng.generate_ids(prompt, GenParams(max_tokens=96, temperature=0.8, top_p=0.9))
+        out["big_q4_0_default_sampling"] = {"device_loop_tokens_per_s": round(len(ids) / (time.perf_counter() - t0), 1)}
+        dev.close()
+    except Exception as exc:  # a side measurement: the line must survive it
+        out["big_q4_0_default_sampling"] = {"error": repr(exc)}
     return out
 
 
