@@ -2132,7 +2132,8 @@ int nl_finalize(nl_handle e) {
             t.ngc = (dgroups + 16 / ct - 1) / (16 / ct);
             t.nr = (L0.gate.ntiles * GPT + TP_THREADS - 1) / TP_THREADS;
             const bool tpffn = t.ngc <= 2 && t.nf <= 2 && t.nr <= 2 && t.n_prod <= budget && L0.down.npairs <= 128;
-            e->wide_ffn = ok3 && !tpffn && wide_ffn_ok();        // (a shard too large for one-tile producers: tp 2 of the 7.9B tier)
+            const char *tw = getenv("NL_TP_WIDE");               // developer knob: 1 = prefer wide_ffn_kernel wherever it is eligible
+            e->wide_ffn = ok3 && (!tpffn || (tw && atoi(tw) != 0)) && wide_ffn_ok();   // (a shard too large for one-tile producers: tp 2 of the 7.9B tier)
             ok3 = ok3 && (tpffn || e->wide_ffn);
             for (const auto &L : e->layers)   // (every layer has the shapes of layer 0: checked, not assumed)
                 ok3 = ok3 && L.wo.npairs == L0.wo.npairs && L.gate.ntiles == L0.gate.ntiles && L.down.npairs == L0.down.npairs &&

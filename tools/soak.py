@@ -58,3 +58,25 @@ while time.time() - t0 < budget:
     runs += 1
 print(f"mini prefill 2047: {runs} runs in {time.time() - t0:.1f} s, bit-identical logits every run; last_error: {dev.last_error()!r}", flush=True)
 dev.close()
+
+# 4. (round 4) big greedy decode across the two-launch layers, the plan switch at position 512 and the split-attention plan,
+#    and big at the default sampled settings (top-p by streamed radix selection), repeated
+from nanollama_amd.engine import Engine, GenParams
+g = b.gen("big", "q4_0")
+dev = model.load_llama_model(g)
+prompt = synth.prompt_ids(440, g.meta.vocab_size)
+ref_ids, ref_s, runs, toks = None, None, 0, 0
+t0 = time.time()
+while time.time() - t0 < budget:
+    dev.reset(); dev.prefill(prompt)
+    ids = dev.decode_greedy(int(np.argmax(dev.state.logits)), len(prompt), 160)
+    ref_ids = ref_ids or ids
+    assert ids == ref_ids, f"big greedy run {runs} differs"
+    eng = Engine(dev, eos_id=-1, rep_penalty=1.15, rep_window=64, seed=3, device_sampling=True)
+    sid = eng.generate_ids(prompt[:16], GenParams(max_tokens=96, temperature=0.8, top_p=0.9))
+    ref_s = ref_s or sid
+    assert sid == ref_s, f"big sampled run {runs} differs"
+    runs += 1; toks += len(ids) + len(sid)
+print(f"big greedy (positions 440..600) + sampled: {runs} runs, {toks} tokens in {time.time() - t0:.1f} s, identical ids every run; "
+      f"plan {dev.plan_info()}; last_error: {dev.last_error()!r}", flush=True)
+dev.close()
