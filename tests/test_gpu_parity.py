@@ -423,7 +423,7 @@ def test_big_full_shape_matches_oracle(hip, orc, tmp_path):
             assert d <= LOGIT_TOL * max(1.0, float(wants[pos].std()))
             assert int(np.argmax(lg)) == int(orc.argmax(wants[pos]))
         grp.close()
-    for n in (4, 8):         # ... and a rank's layer as TWO launches (nl_tp.h: the plan of a push group at tp 4 / 8), full shape
+    for n in (2, 4, 8):      # ... and a rank's layer as TWO launches (nl_tp.h: the plan of a push group; at tp 2 its second launch is wide_ffn_kernel), full shape
         grp = hip.LocalTPGroup(g, n, fused=True)
         assert grp.shards[0].plan_info()["fused_mode"] == 3, grp.shards[0].plan_info()
         for pos, t in enumerate(toks):
