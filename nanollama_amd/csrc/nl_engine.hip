@@ -2413,7 +2413,8 @@ hipError_t samp_alloc(SampScratch &s, int vocab, int n_uniforms) {
 #define SA(ptr, count) if ((rc = hipMalloc((void **)&(ptr), (size_t)(count) * 4)) != hipSuccess) return rc
     SA(s.keys_in, SAMP_THREADS * samp_chunk(vocab)); SA(s.keys_out, SAMP_THREADS * samp_chunk(vocab)); SA(s.idx_in, vocab); SA(s.idx_out, vocab);   // (whole lane chunks: the select kernels load past vocab and mask)
     if ((rc = hipMemset(s.keys_out, 0, (size_t)SAMP_THREADS * samp_chunk(vocab) * 4)) != hipSuccess) return rc;  // zero tail past vocab
-    SA(s.partial, nblocks); SA(s.scal, 4); SA(s.pmax, nblocks); SA(s.uniforms, std::max(n_uniforms, 1)); SA(s.recent, SAMP_THREADS); SA(s.recent_n, 1);
+    SA(s.partial, nblocks); SA(s.scal, 4); SA(s.pmax, nblocks); SA(s.h1g, 2 * 2048);
+    if ((rc = hipMemset(s.h1g, 0, 2048 * 8)) != hipSuccess) return rc; SA(s.uniforms, std::max(n_uniforms, 1)); SA(s.recent, SAMP_THREADS); SA(s.recent_n, 1);
 #undef SA
     if ((rc = rocprim::radix_sort_pairs_desc(nullptr, s.sort_tmp_bytes, s.keys_in, s.keys_out, s.idx_in, s.idx_out,
                                              (unsigned)vocab, 0, 32, (hipStream_t)0)) != hipSuccess) return rc;
@@ -2421,7 +2422,7 @@ hipError_t samp_alloc(SampScratch &s, int vocab, int n_uniforms) {
 }
 
 void samp_free(SampScratch &s) {
-    void *p[] = {s.keys_in, s.keys_out, s.idx_in, s.idx_out, s.partial, s.scal, s.pmax, s.uniforms, s.recent, s.recent_n, s.sort_tmp};
+    void *p[] = {s.keys_in, s.keys_out, s.idx_in, s.idx_out, s.partial, s.scal, s.pmax, s.h1g, s.uniforms, s.recent, s.recent_n, s.sort_tmp};
     for (void *q : p) if (q) (void)hipFree(q);
     s = SampScratch{};
 }
@@ -2436,13 +2437,14 @@ hipError_t launch_sample(const SampScratch &s, float *logits, int vocab, const n
     P.uniforms = s.uniforms; P.ctl = ctl; P.ids = ids;
     P.keys_in = s.keys_in; P.keys_out = s.keys_out; P.idx_in = s.idx_in; P.idx_out = s.idx_out;
     P.partial = s.partial; P.scal = s.scal; P.pmax = s.pmax; P.nblocks = (vocab + 255) / 256;
+    P.h1g = s.h1g; P.nblocks_pen = P.nblocks;
     // top-p up to 65536 candidates: weighted radix selection in one launch, no sort (nl_sample.h).  NL_SAMP_SORT=1 keeps the
     // sorted path (developer A/B; read once)
     static const bool force_sort = getenv("NL_SAMP_SORT") && atoi(getenv("NL_SAMP_SORT")) != 0;
     P.radix = p.temperature > 0.f && p.top_p < 1.0f && !force_sort ? 1 : 0;
     hipLaunchKernelGGL(samp_penalty_kernel, dim3(P.nblocks), dim3(256), 0, st, P);
     if (P.radix) {
-        hipLaunchKernelGGL(samp_prob_kernel, dim3(P.nblocks), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(samp_prob_hist_kernel, dim3((vocab + SAMP_THREADS - 1) / SAMP_THREADS), dim3(SAMP_THREADS), 0, st, P);
         // (<= 32768 candidates: in the registers of the one workgroup; up to 131072: streamed out of L2 pass by pass)
         if (samp_chunk(vocab) == 32) hipLaunchKernelGGL(samp_select_radix_kernel<32>, dim3(1), dim3(SAMP_THREADS), 0, st, P);
         else hipLaunchKernelGGL(samp_select_radix_stream_kernel, dim3(1), dim3(SAMP_THREADS), 0, st, P);

@@ -50,7 +50,10 @@ struct SampleParams {
     float *scal;          // (spare scalars)
     float *pmax;          // [nblocks] workgroup maxima of the penalised logits (samp_penalty_kernel)
     int nblocks;
-    int radix;            // top-p by radix selection (samp_select_radix_kernel): keys_in = p, nothing else is prepared
+    int radix;            // top-p by radix selection (samp_select_radix_kernel): keys_in = p and the level-1 histogram h1g
+    unsigned long long *h1g;   // [2048] sums of candidate weights per level-1 bucket: zeroed by samp_penalty_kernel, filled by
+                               // samp_prob_hist_kernel (all compute units), read by the selecting workgroup
+    int nblocks_pen;      // workgroups of samp_penalty_kernel (pmax entries)
     int embed;            // the select launch also writes the picked token's embedding row (emb): the next Forward then starts
     EmbedParams emb;      //   at its first layer, as the chained greedy graph does with argmax_embed_kernel
 };
@@ -71,6 +74,7 @@ __device__ __forceinline__ void samp_embed_tail(const SampleParams &P, int token
 // device scratch of one sampler (one vocabulary)
 struct SampScratch {
     float *keys_in = nullptr, *keys_out = nullptr, *partial = nullptr, *scal = nullptr, *pmax = nullptr, *uniforms = nullptr;
+    unsigned long long *h1g = nullptr;
     int *idx_in = nullptr, *idx_out = nullptr, *recent = nullptr, *recent_n = nullptr;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
@@ -85,6 +89,8 @@ __global__ void __launch_bounds__(256) samp_penalty_kernel(SampleParams P) {
     const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
     const int n = sload_i32(P.recent_n);
     float v = P.logits[min(i, P.vocab - 1)];
+    if (P.radix)      // the level-1 histogram of this step's selection (filled by the next launch)
+        for (int j = i; j < 2048; j += (int)gridDim.x * 256) P.h1g[j] = 0;
     if (P.rep_penalty > 1.0f && n > 0) {
         for (int s = tid; s < n; s += 256) win[s] = P.recent[s];
         __syncthreads();
@@ -132,6 +138,43 @@ __global__ void __launch_bounds__(256) samp_prob_kernel(SampleParams P) {
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
         if (threadIdx.x == 0) P.partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// The radix path's probabilities: p_i as samp_prob_kernel computes them, plus level 1 of the selection's histograms, built HERE by
+// every compute unit instead of by the one selecting workgroup (3.8 us of its 20): a candidate (p >= 2^-45, weight >= 1) goes
+// to bucket (bits(p) - bits(2^-45)) >> 18 -- 32 buckets per binary exponent, 1440 in all -- with its exact integer weight;
+// a workgroup sums its 1024 candidates in LDS and flushes the non-empty buckets with 64-bit device-scope atomics (integer sums:
+// the order does not matter; 32 workgroups x ~150 buckets cost 0.2 us, tools/atomic_probe.hip).
+constexpr unsigned SAMP_KEY_MIN = 82u << 23;                 // bits of 2^-45: the smallest p of weight 1
+constexpr int SAMP_S1 = 18, SAMP_S2 = 7;                     // level 1: bits 28..18 of key - SAMP_KEY_MIN, level 2: 17..7, level 3: 6..0
+__device__ __forceinline__ unsigned long long samp_weight_of(unsigned k) {   // floor(p 2^45) = (m 2^22) >> (127 - e), k >= SAMP_KEY_MIN
+    const unsigned long long m = (unsigned long long)((k & 0x7fffffu) | 0x800000u) << 22;
+    return m >> (127u - (k >> 23));
+}
+__global__ void __launch_bounds__(SAMP_THREADS) samp_prob_hist_kernel(SampleParams P) {
+    __shared__ float red[SAMP_THREADS / 64];
+    __shared__ unsigned long long hl[2048];
+    const int tid = threadIdx.x, i = blockIdx.x * SAMP_THREADS + tid;
+    const float l = P.logits[min(i, P.vocab - 1)];
+    hl[tid] = 0; hl[tid + 1024] = 0;
+    float gmax = tid < P.nblocks_pen ? P.pmax[tid] : -INFINITY;          // (<= 512 workgroup maxima)
+    gmax = wave_max_f32(gmax);
+    if ((tid & 63) == 0) red[tid >> 6] = gmax;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < SAMP_THREADS / 64; w++) gmax = fmaxf(gmax, red[w]);
+    if (i < P.vocab) {
+        const float key = (float)exp((double)((l - gmax) / P.temp));
+        P.keys_in[i] = key;
+        const unsigned kb = __float_as_uint(key);
+        if (kb >= SAMP_KEY_MIN) atomicAdd(&hl[(kb - SAMP_KEY_MIN) >> SAMP_S1], samp_weight_of(kb));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const unsigned long long v = hl[tid + q * 1024];
+        if (v) atomicAdd(&P.h1g[tid + q * 1024], v);
     }
 }
 
@@ -385,13 +428,13 @@ __device__ __forceinline__ SampSel samp_select_bucket(const samp_u64 *h, XF x_of
 }
 
 // 1 workgroup: C candidates per thread in registers (1024 * C >= vocab), the cut, the pick, the decode state.
-// Candidates = the entries of weight >= 1 (p >= 2^-45).  Keys are taken relative to the smallest candidate and the
-// histogram levels split the POPULATED key range [kmin, kmax] (B = its width in bits: digits of 11 / 11 / rest bits from the
-// top of B, fewer levels when B is small) -- a flat distribution whose p all share three exponents would otherwise put
-// every candidate into a handful of buckets, and LDS atomics on one address are served one at a time.  Only the first
-// level walks all candidates with their weights; a selection then copies the candidates of its level-1 bucket into an LDS
-// list (one compare per candidate) and the lower levels work on that list.
-constexpr unsigned SAMP_KEY_MIN = 82u << 23;                 // bits of 2^-45: the smallest p of weight 1
+// Candidates = the entries of weight >= 1 (p >= 2^-45); keys are taken relative to bits(2^-45).  Level 1 of the histograms
+// (2048 buckets of 2^18 key values: 32 per binary exponent) arrives ready-made from samp_prob_hist_kernel; a selection scans it,
+// copies the candidates of the crossing bucket into an LDS list (one compare per candidate) and runs levels 2 (11 bits) and 3
+// (7 bits) on that list -- or, when the bucket holds more than the list (thousands of candidates with one p), on the registers.
+// (Until the histogram moved out, this workgroup also took the range of the keys and built level 1 relative to the smallest
+// candidate -- a flat distribution's keys share three exponents and LDS atomics on one address are served one at a time:
+// 0.6 + 3.8 us of the launch's 20.)
 #ifdef NL_SAMP_STAMPS   // developer build (tools/samp_probe.hip): shader-clock stamps of thread 0
 __device__ unsigned long long g_samp_stamps[32];
 #define SAMP_STAMP(i) do { if (threadIdx.x == 0) g_samp_stamps[i] = wall_clock64(); } while (0)
@@ -401,10 +444,10 @@ __device__ unsigned long long g_samp_stamps[32];
 constexpr int SAMP_LIST_CAP = 8192;
 template <int C>
 __global__ void __launch_bounds__(SAMP_THREADS) samp_select_radix_kernel(SampleParams P) {
-    __shared__ samp_u64 h1[2048], hw[2048];
+    __shared__ samp_u64 hw[2048];
     __shared__ unsigned list[SAMP_LIST_CAP];
     __shared__ samp_u64 scr[16];
-    __shared__ unsigned wcnt[SAMP_THREADS / 64], wmin[SAMP_THREADS / 64], wmax[SAMP_THREADS / 64];
+    __shared__ unsigned wcnt[SAMP_THREADS / 64];
     __shared__ unsigned list_n;
     __shared__ int s_pick;
     const int tid = threadIdx.x, V = P.vocab, lo = tid * C;
@@ -419,41 +462,15 @@ __global__ void __launch_bounds__(SAMP_THREADS) samp_select_radix_kernel(SampleP
         key[k] = lo + k < V ? t4.x : 0u; key[k + 1] = lo + k + 1 < V ? t4.y : 0u;
         key[k + 2] = lo + k + 2 < V ? t4.z : 0u; key[k + 3] = lo + k + 3 < V ? t4.w : 0u;
     }
-    h1[tid] = 0; h1[tid + 1024] = 0;
     if (tid == 0) s_pick = 0x7fffffff;
     int par = 0;
-    unsigned kmin = 0xffffffffu, kmax = 0u;
     SAMP_STAMP(1);
-#pragma unroll
-    for (int k = 0; k < C; k++) {                           // (a key below SAMP_KEY_MIN counts as SAMP_KEY_MIN: the range only widens)
-        kmin = min(kmin, max(key[k], SAMP_KEY_MIN));
-        kmax = max(kmax, key[k]);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { kmin = min(kmin, (unsigned)__shfl_xor(kmin, o)); kmax = max(kmax, (unsigned)__shfl_xor(kmax, o)); }
-    if ((tid & 63) == 0) { wmin[tid >> 6] = kmin; wmax[tid >> 6] = kmax; }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < SAMP_THREADS / 64; w++) { kmin = min(kmin, wmin[w]); kmax = max(kmax, wmax[w]); }
-    // (the largest p is exp(0) = 1: kmax = bits of 1.0f and at least one candidate exists.  kmin >= SAMP_KEY_MIN, so
-    //  "key >= kmin" is the candidate test and d = key - kmin < 2^B <= 2^30)
-    const int B = 32 - __clz((int)(kmax - kmin));           // __clz(0) = 32: B = 0 when all candidates share one p
-    const int s1 = max(B - 11, 0), s2 = max(B - 22, 0);
-    // weight of the candidate with relative key d: floor(p 2^45) = (m 2^22) >> (127 - e), 127 - e <= 45 for candidates
-    auto weight_of = [&](unsigned k) {
-        const samp_u64 m = (samp_u64)((k & 0x7fffffu) | 0x800000u) << 22;
-        return m >> (127u - (k >> 23));
-    };
+    // level 1 comes from samp_prob_hist_kernel (global memory, built by every compute unit); keys relative to SAMP_KEY_MIN
+    constexpr unsigned kmin = SAMP_KEY_MIN;
+    constexpr int s1 = SAMP_S1, s2 = SAMP_S2;
+    const samp_u64 *const h1 = P.h1g;
+    auto weight_of = [](unsigned k) { return samp_weight_of(k); };
     SAMP_STAMP(2);
-    // level 1, the only pass that weighs every candidate.  (The empty asm pins every pass to "one candidate at a time":
-    // left alone, hipcc keeps all C 64-bit weights live across the passes and spills 450 registers)
-#pragma unroll
-    for (int k = 0; k < C; k++) {
-        unsigned kk = key[k];
-        asm volatile("" : "+v"(kk));
-        if (kk >= kmin) atomicAdd(&h1[(kk - kmin) >> s1], weight_of(kk));
-    }
-    __syncthreads();
     SAMP_STAMP(3);
     [[maybe_unused]] int stamp_base = 4;
     // one weighted selection: up to three levels; returns the relative key of the crossing candidates and what is left of x
@@ -464,7 +481,6 @@ __global__ void __launch_bounds__(SAMP_THREADS) samp_select_radix_kernel(SampleP
         rem = a.rem;
         x = a.x;
         SAMP_STAMP(stamp_base + 0);
-        if (s1 == 0) { dout = prefix; return; }
         // the candidates of that bucket -> list (relative keys).  (Counting first and reserving one run per thread was
         // measured slower: the second walk over the registers costs more than the atomics it saves)
         if (tid == 0) list_n = 0;
@@ -626,41 +642,28 @@ __device__ __forceinline__ void samp_each_key(const unsigned *kin, int V, F f) {
 }
 
 __global__ void __launch_bounds__(SAMP_THREADS) samp_select_radix_stream_kernel(SampleParams P) {
-    __shared__ samp_u64 h1[2048], hw[2048];
+    __shared__ samp_u64 hw[2048];
     __shared__ unsigned list[SAMP_LIST_CAP];
     __shared__ samp_u64 scr[16];
-    __shared__ unsigned wcnt[SAMP_THREADS / 64], wmin[SAMP_THREADS / 64], wmax[SAMP_THREADS / 64];
+    __shared__ unsigned wcnt[SAMP_THREADS / 64];
     __shared__ unsigned list_n;
     __shared__ int s_pick;
     const int tid = threadIdx.x, V = P.vocab;
     const int step = P.ctl[CTL_STEP];
     const float u = P.uniforms[step];
     const unsigned *kin = reinterpret_cast<const unsigned *>(P.keys_in);
-    h1[tid] = 0; h1[tid + 1024] = 0;
     if (tid == 0) s_pick = 0x7fffffff;
     int par = 0;
-    unsigned kmin = 0xffffffffu, kmax = 0u;
-    samp_each_key(kin, V, [&](unsigned key, int) { kmin = min(kmin, max(key, SAMP_KEY_MIN)); kmax = max(kmax, key); });
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { kmin = min(kmin, (unsigned)__shfl_xor(kmin, o)); kmax = max(kmax, (unsigned)__shfl_xor(kmax, o)); }
-    if ((tid & 63) == 0) { wmin[tid >> 6] = kmin; wmax[tid >> 6] = kmax; }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < SAMP_THREADS / 64; w++) { kmin = min(kmin, wmin[w]); kmax = max(kmax, wmax[w]); }
-    const int B = 32 - __clz((int)(kmax - kmin));
-    const int s1 = max(B - 11, 0), s2 = max(B - 22, 0);
-    auto weight_of = [&](unsigned k) {
-        const samp_u64 m = (samp_u64)((k & 0x7fffffu) | 0x800000u) << 22;
-        return m >> (127u - (k >> 23));
-    };
-    samp_each_key(kin, V, [&](unsigned key, int) { if (key >= kmin) atomicAdd(&h1[(key - kmin) >> s1], weight_of(key)); });
+    constexpr unsigned kmin = SAMP_KEY_MIN;                  // level 1 comes from samp_prob_hist_kernel, keys relative to SAMP_KEY_MIN
+    constexpr int s1 = SAMP_S1, s2 = SAMP_S2;
+    const samp_u64 *const h1 = P.h1g;
+    auto weight_of = [](unsigned k) { return samp_weight_of(k); };
     __syncthreads();
     auto select = [&](auto x_of, unsigned &dout, samp_u64 &rem, samp_u64 &x) {
         const SampSel a = samp_select_bucket(h1, x_of, scr, par);
         unsigned prefix = (unsigned)a.bucket;
         rem = a.rem;
         x = a.x;
-        if (s1 == 0) { dout = prefix; return; }
         if (tid == 0) list_n = 0;
         hw[tid] = 0; hw[tid + 1024] = 0;
         __syncthreads();
