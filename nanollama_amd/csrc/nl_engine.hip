@@ -2170,10 +2170,12 @@ int nl_finalize(nl_handle e) {
         const char *fm = getenv("NL_FUSED_MAX_POS");
         // tools/fused_limit.py: the per-head blocks (mode 1) win up to ~500 (nano) / ~600 (mini) positions, the projection +
         // attention launch of the wide tiers (mode 2) up to ~390 (big)
-        // (mode 4, tools/fused_limit.py on big, profiles/r04_big_fused_limit.log: the two-launch layers stay ahead of the five-launch
-        //  plan up to the 512 positions their in-launch attention covers -- 1.80 against 1.85 ms at position 470)
-        e->fused_max_pos = fm ? atoi(fm) : (e->fused_mode == 1 || e->fused_mode == 4) ? 512 : 384;
-        if (e->fused_mode == 3 || e->fused_mode == 4) e->fused_max_pos = std::min(e->fused_max_pos, TP_NCH_MAX * ATT_CH);   // passes a head takes inside the launch
+        // (mode 4, tools/fused_limit.py on big, profiles/r04_big_fused_limit.log: with 256-position passes the two-launch layers
+        //  stay ahead of the five-launch plan through three passes -- 1.69 against 1.85 ms at position 470, 1.81 against 1.86 at
+        //  600 -- and fall behind in the fourth, 1.98 against 1.87 at 900)
+        //  (mode 3 runs the same attention half: 512 = two of its passes, where 384 was three of the old 128-position ones)
+        e->fused_max_pos = fm ? atoi(fm) : e->fused_mode == 4 ? 768 : (e->fused_mode == 1 || e->fused_mode == 3) ? 512 : 384;
+        if (e->fused_mode == 3 || e->fused_mode == 4) e->fused_max_pos = std::min(e->fused_max_pos, TP_NCH_MAX * TP_PASS);   // passes a head takes inside the launch
         {
             const char *ff = getenv("NL_FUSED_FFN");   // knob (tests, tools): 0 keeps gate/up and down as two launches
             bool okf = e->fused_mode == 1 && !(ff && atoi(ff) == 0);

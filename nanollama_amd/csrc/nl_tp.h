@@ -38,7 +38,10 @@ __device__ long long g_tp_census[2][512][2];     // [launch kind][block][entry, 
 #endif
 
 constexpr int TP_THREADS = 1024;
-constexpr int TP_NCH_MAX = 4;        // 128-position passes a head's attention may take inside the launch (fused_max_pos <= 512)
+constexpr int TP_NCH_MAX = 4;        // passes a head's attention may take inside the launch
+constexpr int TP_PASS = 256;         // positions per pass: ALL sixteen wavefronts of the runner hold 16 cache rows each (the first
+                                     // version used eight, 128 positions per pass, and left the other eight idle: at position 470
+                                     // four dependent passes of ~1.7 us per layer instead of two).  fused_max_pos <= 4 x 256
 
 // One all-reduce seam as the tail of a launch sees it.
 struct TpSeam {
@@ -227,7 +230,7 @@ struct TpAttnParams {
 };
 
 __host__ __device__ constexpr size_t tp_attn_lds_bytes(int wo_npairs) {
-    return 16 * sizeof(double) + sizeof(float) * (size_t)(16 * XS_WAVE + 16 * TR + 3 * 64 + 8 * 68 + TP_NCH_MAX * 66 + wo_npairs * XS_PAIR + 16 * TR);
+    return 16 * sizeof(double) + sizeof(float) * (size_t)(16 * XS_WAVE + 16 * TR + 3 * 64 + 16 * 68 + TP_NCH_MAX * 66 + wo_npairs * XS_PAIR + 16 * TR);
 }
 
 // One role of the launch as straight-line code: every load below is unconditional (clamped addresses, masked uses), so
@@ -243,8 +246,8 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     float *red = xs + NW * XS_WAVE;                                  // [16][16]
     float *qs = red + NW * TR;                                       // [64]
     float *kcur = qs + 64, *vcur = kcur + 64;
-    float *wpart = vcur + 64;                                        // [8][68]: a cache wavefront's (max, sum, -, -, sum p*v[64]) of the pass
-    float *chunk = wpart + 8 * 68;                                   // [TP_NCH_MAX][66]: (M, L, o[64]) per pass
+    float *wpart = vcur + 64;                                        // [16][68]: a cache wavefront's (max, sum, -, -, sum p*v[64]) of the pass
+    float *chunk = wpart + 16 * 68;                                  // [TP_NCH_MAX][66]: (M, L, o[64]) per pass
     float *ao = chunk + TP_NCH_MAX * 66;                             // [wo_npairs][XS_PAIR]: every local head's output
     float *red2 = ao + Q.wo_npairs * XS_PAIR;                        // [16][16]
 
@@ -341,8 +344,8 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
         // the row AT pos is produced by this launch and replaced from LDS below).  Eight cache wavefronts x 16 consecutive
         // positions of a pass: K as 16 of the row's 64 dims per lane (a score = 16 in-lane FMAs + two quad adds), V as float4
         // columns of four rows per lane -- nl_block.h's attention phase.
-        if (RUNNER && wave < 8) {
-            const int lim = min(min(ATT_CH, P.seq_len), pos + 1);
+        if (RUNNER) {
+            const int lim = min(min(TP_PASS, P.seq_len), pos + 1);
             const unsigned krow = (unsigned)min(wave * 16 + kr, lim - 1) * R4 + (unsigned)kq;
 #pragma unroll
             for (int kk = 0; kk < NV; kk++) {
@@ -449,10 +452,10 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
 
         // ---- positions 0..pos, 128 per pass; every cache wavefront reduces its 16 positions to ONE (max, sum, sum p*v)
         //      partial in registers, eight partials per pass meet in LDS behind one barrier (nl_block.h) ----
-        const int nch = min(pos / ATT_CH + 1, TP_NCH_MAX);
+        const int nch = min(pos / TP_PASS + 1, TP_NCH_MAX);
         for (int ch = 0; ch < nch; ch++) {
-            const int t0 = ch * ATT_CH, n = min(ATT_CH, pos + 1 - t0);
-            if (wave < 8) {
+            const int t0 = ch * TP_PASS, n = min(TP_PASS, pos + 1 - t0);
+            {
                 if (ch > 0) {
 #pragma unroll
                     for (int kk = 0; kk < NV; kk++) {
@@ -461,9 +464,9 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
                     }
                 }
                 if (ch + 1 < nch) {
-                    const int n1 = min(ATT_CH, pos + 1 - t0 - ATT_CH);
+                    const int n1 = min(TP_PASS, pos + 1 - t0 - TP_PASS);
 #pragma unroll
-                    for (int kk = 0; kk < NV; kk++) kregn[kk] = K4[(long long)(t0 + ATT_CH + min(wave * 16 + kr, n1 - 1)) * R4 + kq + 4 * kk];
+                    for (int kk = 0; kk < NV; kk++) kregn[kk] = K4[(long long)(t0 + TP_PASS + min(wave * 16 + kr, n1 - 1)) * R4 + kq + 4 * kk];
                 }
                 const int krow = wave * 16 + kr;
                 const bool kcurrow = t0 + krow == pos;   // the row this launch produced: not in memory yet for this workgroup
@@ -495,14 +498,14 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
             }
             __syncthreads();
             if (wave == 0) {
-                // the eight partials of the pass merged like position splits (fixed order); the weights f32(exp(f64(m_w - M)))
-                const float mw = lane < 8 ? wpart[min(lane, 7) * 68] : -INFINITY;
+                // the sixteen partials of the pass merged like position splits (fixed order); the weights f32(exp(f64(m_w - M)))
+                const float mw = lane < 16 ? wpart[min(lane, 15) * 68] : -INFINITY;
                 const float Mx = wave_max_f32(mw);
-                const float wgt = (lane < 8 && mw != -INFINITY) ? exp_f64_as_f32(mw - Mx) : 0.f;
-                const float L = wave_sum_f32(lane < 8 ? wgt * wpart[min(lane, 7) * 68 + 1] : 0.f);
+                const float wgt = (lane < 16 && mw != -INFINITY) ? exp_f64_as_f32(mw - Mx) : 0.f;
+                const float L = wave_sum_f32(lane < 16 ? wgt * wpart[min(lane, 15) * 68 + 1] : 0.f);
                 float ov = 0.f;
 #pragma unroll
-                for (int w = 0; w < 8; w++) ov = fmaf(__shfl(wgt, w), wpart[w * 68 + 4 + lane], ov);
+                for (int w = 0; w < 16; w++) ov = fmaf(__shfl(wgt, w), wpart[w * 68 + 4 + lane], ov);
                 chunk[ch * 66 + 2 + lane] = ov;
                 if (lane == 0) { chunk[ch * 66] = Mx; chunk[ch * 66 + 1] = L; }
             }

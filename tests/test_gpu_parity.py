@@ -1551,30 +1551,31 @@ def test_greedy_chain_switches_from_the_fused_plan_to_the_split_attention_plan(h
     dev.close(); ref.close()
 
 
-def test_wide_tier_chain_crosses_all_four_attention_passes_and_the_plan_switch(hip, orc, tmp_path):
-    # fused mode 4 serves positions below 512: its attention runs 1 .. 4 passes of 128 positions inside the launch.  A prompt of
-    # 458 tokens, then 100 chained greedy steps: the fourth pass, the switch to the split-attention plan at 512 (16-step
-    # graphs of either plan, single steps at the seam) -- the oracle's ids throughout, and its logits at three positions
-    shape = synth.ModelShape("m4_switch", 2, 1024, 16, 4, 1024, seq_len=608, interm=2048)
+def test_wide_tier_chain_crosses_the_attention_passes_and_the_plan_switch(hip, orc, tmp_path):
+    # fused mode 4 serves positions below 768: its attention runs 1 .. 3 passes of 256 positions inside the launch (all sixteen
+    # wavefronts of the runner hold cache rows).  A prompt of 718 tokens, then 100 chained greedy steps: the third pass, the switch
+    # to the split-attention plan at 768 (16-step graphs of either plan, single steps at the seam) -- the oracle's ids throughout,
+    # and its logits at positions in every pass
+    shape = synth.ModelShape("m4_switch", 2, 1024, 16, 4, 1024, seq_len=864, interm=2048)
     p = tmp_path / "m.gguf"
     synth.generate_gguf(str(p), shape, "q4_0", 73, mode="qrand")
     g = gguf.load_gguf(str(p))
     dev = hip.load_llama_model(g)
-    assert dev.plan_info()["fused_mode"] == 4 and dev.plan_info()["fused_max_pos"] == 512
+    assert dev.plan_info()["fused_mode"] == 4 and dev.plan_info()["fused_max_pos"] == 768
     ref = orc.OracleModel(g)
     orc.set_threads(min(16, os.cpu_count() or 1))
-    prompt = synth.prompt_ids(458, shape.vocab, seed=5)
+    prompt = synth.prompt_ids(718, shape.vocab, seed=5)
     want, _ = ref.generate_greedy(prompt, 100)
     dev.prefill(prompt)
     first = int(np.argmax(dev.state.logits))
     got = [first] + dev.decode_greedy(first, len(prompt), 99)
     assert got == want
-    for pos in (300, 390, 505):                   # third and fourth pass of the in-launch attention
+    for pos in (130, 255, 256, 300, 511, 512, 700, 767):      # first, second and third pass of the in-launch attention and their edges
         lg = ref.forward(want[3], pos).copy()
         dev.forward(want[3], pos)
         assert np.abs(dev.state.logits - lg).max() <= LOGIT_TOL * max(1.0, float(lg.std())), pos
     orc.set_threads(1)
-    assert "attn_block" in _kinds(dev, 100) and "attn_block" not in _kinds(dev, 580)
+    assert "attn_block" in _kinds(dev, 100) and "attn_block" in _kinds(dev, 760) and "attn_block" not in _kinds(dev, 800)
     dev.close(); ref.close()
 
 

@@ -25,7 +25,7 @@ LOGIT_TOL = 1e-4
 
 SHAPES = {
     # name: (shape, tp sizes)
-    "gqa4": (synth.ModelShape("tpf_gqa4", 3, 1024, 16, 4, 4096, seq_len=160, interm=2048), (2, 4)),
+    "gqa4": (synth.ModelShape("tpf_gqa4", 3, 1024, 16, 4, 4096, seq_len=320, interm=2048), (2, 4)),   # 300 positions: two 256-position passes
     "mha8": (synth.ModelShape("tpf_mha8", 3, 512, 8, 8, 4096, seq_len=160, interm=1024), (2, 8)),
     # interm = 43 blocks of 32 per rank at tp 2 (the 7.9B tier's 1376 rows per rank at tp 8): a ragged last pair and group
     "ragged": (synth.ModelShape("tpf_ragged", 2, 1024, 16, 4, 4096, seq_len=160, interm=2752), (2,)),
@@ -73,7 +73,7 @@ def test_two_launch_layer_in_process_group_matches_oracle(hip, orc, tmp_path, mo
         monkeypatch.setenv("NL_WIDE_FFN", "2")
     ref = orc.OracleModel(g)
     orc.set_threads(min(16, os.cpu_count() or 1))
-    toks = synth.prompt_ids(140, shape.vocab, seed=29)          # crosses the 128-position pass boundary inside the launch
+    toks = synth.prompt_ids(shape.seq_len - 20, shape.vocab, seed=29)      # (gqa4: crosses the 256-position pass boundary inside the launch)
     wants = [ref.forward(t, pos).copy() for pos, t in enumerate(toks)]
     orc.set_threads(1)
     ref.close()
