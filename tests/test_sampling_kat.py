@@ -33,3 +33,38 @@ def test_go_mirror_answers_the_kat():
     after = sm.apply_penalty(lg, kat.RECENT, kat.PENALTY, lg.size)
     assert after.tolist() == kat.LOGITS_AFTER_PENALTY
     assert sm.push_recent([1, 2, 3], 9, 3) == [2, 3, 9] and sm.push_recent([1], 9, 3) == [1, 9]
+
+
+def test_integer_restatement_of_top_p_equals_the_go_chain_away_from_cdf_boundaries():
+    # nl_sample.h selects by exact integer weights (device_top_p restates it with Python integers; the GPU tests hold the device
+    # to that restatement bit for bit).  Here, without a GPU: over random distributions of several spreads and sizes the integer
+    # selection picks what the literal Go float32 chain picks, except where u (or the top-p cut) lies within float32 rounding
+    # of a cumulative-probability boundary -- and there it picks the neighbouring candidate.
+    rng = np.random.default_rng(2024)
+    total = differ = 0
+    for V in (64, 1000, 4096):
+        for _ in range(60):
+            lg = (rng.standard_normal(V) * rng.choice([0.3, 1.0, 4.0])).astype(np.float32)
+            temp, top_p = float(rng.choice([0.7, 1.0, 1.4])), float(rng.choice([0.3, 0.9, 0.97]))
+            u = float(rng.random(dtype=np.float32))
+            a = sm.go_top_p(lg, temp, top_p, u)
+            b, margin = sm.device_top_p(lg, temp, top_p, u)
+            total += 1
+            if a != b:
+                differ += 1
+                assert margin < 5e-4, (V, temp, top_p, u, margin)
+    assert differ <= max(2, total // 50), (differ, total)
+
+
+def test_integer_restatement_orders_ties_by_id_and_needs_no_normalisation():
+    # thousands of candidates with one p: ascending id within the tie; scaling all logits by a constant shift changes nothing
+    lg = np.full(3000, np.float32(0.5))
+    lg[7], lg[1999] = np.float32(3.0), np.float32(3.0)
+    for u, top_p in ((0.0, 0.9), (0.49, 0.9), (0.999, 0.05), (0.73, 0.999)):
+        pick, _ = sm.device_top_p(lg, 0.8, top_p, u)
+        shifted, _ = sm.device_top_p((lg + np.float32(11.0)).astype(np.float32), 0.8, top_p, u)
+        assert pick == shifted
+    assert sm.device_top_p(lg, 0.8, 0.9, 0.0)[0] == 7                       # the first of the two largest
+    assert sm.device_top_p(lg, 0.8, 1e-6, 0.9999)[0] == 7                   # a one-candidate nucleus
+    flat = np.zeros(500, np.float32)
+    assert sm.device_top_p(flat, 1.0, 0.5, 0.0)[0] == 0 and sm.device_top_p(flat, 1.0, 0.5, 0.9999)[0] == 249
