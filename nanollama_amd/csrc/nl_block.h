@@ -328,12 +328,14 @@ __global__ void __launch_bounds__(BLK_THREADS) attn_block_kernel(BlockParams P) 
         if (ch == 0) BLK_STAMP(13);
         if (wave == 0) {
             // the eight partials of the pass, merged in a fixed order.  The weights exp(m_w - M) are this engine's own
-            // construct -- the reference has one softmax over all positions -- so they use the reference's exponential,
-            // float32(exp(float64)) (go/quant.go:619): p * wgt then differs from exp(s - M) by roundings only, not by the
-            // fast exponential's error (eight lanes of one wavefront: no cost): (M, L, o[64]) of the pass
+            // construct -- the reference has one softmax over all positions -- and use the f32 exponential, as the merge of
+            // the passes below and the split merge of the five-launch plan do (load_x4<PRO_ATTN>).  (Round 4 tried the
+            // reference's float32(exp(float64)) here, go/quant.go:619: only eight lanes compute it, but they are wavefront 0
+            // on the launch's critical path -- this step went from 850 to 1200 cycles, 1 % of nano's token; the logits of the
+            // fused block are held to the oracle's within 1e-4 either way, test_fused_attention_block_matches_oracle)
             const float mw = lane < 8 ? wpart[min(lane, 7) * 68] : -INFINITY;
             const float M = wave_max_f32(mw);
-            const float wgt = (lane < 8 && mw != -INFINITY) ? exp_f64_as_f32(mw - M) : 0.f;   // (an empty wavefront weighs 0)
+            const float wgt = (lane < 8 && mw != -INFINITY) ? __expf(mw - M) : 0.f;   // (an empty wavefront weighs 0)
             const float L = wave_sum_f32(lane < 8 ? wgt * wpart[min(lane, 7) * 68 + 1] : 0.f);
             float ov = 0.f;
 #pragma unroll

@@ -498,10 +498,12 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
             }
             __syncthreads();
             if (wave == 0) {
-                // the sixteen partials of the pass merged like position splits (fixed order); the weights f32(exp(f64(m_w - M)))
+                // the sixteen partials of the pass merged like position splits (fixed order); the weights exp(m_w - M) are this
+                // engine's own construct and use the f32 exponential like every split merge here (nl_block.h: the float64 form
+                // on this one wavefront costs 350 cycles of the launch's critical path)
                 const float mw = lane < 16 ? wpart[min(lane, 15) * 68] : -INFINITY;
                 const float Mx = wave_max_f32(mw);
-                const float wgt = (lane < 16 && mw != -INFINITY) ? exp_f64_as_f32(mw - Mx) : 0.f;
+                const float wgt = (lane < 16 && mw != -INFINITY) ? __expf(mw - Mx) : 0.f;
                 const float L = wave_sum_f32(lane < 16 ? wgt * wpart[min(lane, 15) * 68 + 1] : 0.f);
                 float ov = 0.f;
 #pragma unroll
