@@ -45,10 +45,38 @@ def test_create_without_gpu_fails_loudly_or_succeeds_with_one():
     assert L.nl_create(ctypes.byref(bad), ctypes.byref(h)) in (-1, -2, -3)
 
 
+# What "using the oracle" looks like in source: an import, an include, a dlopen / CDLL of the checker's library, or a path
+# into oracle/.  (A comment that merely names the oracle as the thing a kernel is held to is not a use; the round-4 tree
+# went red on exactly such a comment.)
+_ORACLE_USE = [
+    re.compile(r"^\s*(from|import)\s+oracle\b", re.M),                 # import oracle / from oracle import ...
+    re.compile(r"import_module\(\s*['\"]oracle"), re.compile(r"__import__\(\s*['\"]oracle"),
+    re.compile(r"#\s*include\s*[<\"][^>\"]*oracle"),                   # #include "…oracle…"
+    re.compile(r"libnl_oracle|nl_oracle\.(c|h|so)|oracle\.py"),          # the checker's files by name
+    re.compile(r"(dlopen|CDLL|LoadLibrary)\s*\([^)]*oracle"),
+    re.compile(r"['\"][^'\"\n]*\boracle/[^'\"\n]*['\"]"),             # a string literal holding a path into oracle/
+]
+
+
+def _oracle_uses(src):
+    return [m.group(0) for rx in _ORACLE_USE for m in rx.finditer(src)]
+
+
+def test_oracle_use_detector_sees_real_uses_and_ignores_prose():
+    assert _oracle_uses("from oracle import oracle\n") and _oracle_uses("    import oracle\n")
+    assert _oracle_uses('#include "../../oracle/nl_oracle.c"') and _oracle_uses('dlopen("x/oracle/lib.so", 2)')
+    assert _oracle_uses('p = os.path.join(ROOT, "oracle/libnl_oracle.so")') and _oracle_uses("ctypes.CDLL(oracle_path)")
+    assert not _oracle_uses("// held to the oracle's logits within 1e-4 (tests/test_gpu_parity.py)")
+    assert not _oracle_uses("# the CPU oracle (oracle/) is test infrastructure")
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "nanollama_amd")
+    seen = 0
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
-                assert "oracle" not in src.replace("oracle/", "ORACLE_DIR_MENTION"), f
+                assert not _oracle_uses(src), (f, _oracle_uses(src))
+                seen += 1
+    assert seen >= 20
