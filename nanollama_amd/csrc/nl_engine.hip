@@ -241,6 +241,7 @@ struct nl_engine {
     u32x4 *tp_xo = nullptr;       //   the heads' attention outputs,
     u32x4 *tp_hx = nullptr;       //   g | u (or h) tiles of the feed-forward half
     int grp_tpm = 1;              // mode 2: 16-row tiles per workgroup
+    bool grp_grid_fits = false;   // modes 3 / 4: the projection grid (incl. its blocks without a tile, which stay) fits the compute units
     bool ffn_fused = false;       // mode 1: the feed-forward half is one launch too (ffn_block_kernel)
     float *parts_ffn = nullptr;   // [I / 256][D] per-slice W_down partials
     unsigned long long *xchg_ffn = nullptr;   // [I] granules
@@ -2096,6 +2097,13 @@ int nl_finalize(nl_handle e) {
             ok2 = ok2 && geo;
             ok3 = ok3 && geo;
             e->grp_tpm = tpm;
+            // Modes 3 and 4 launch grp_grid = ceil(KVs / 8) * 8 * members blocks and, unlike mode 2, the blocks that hold no
+            // projection tile STAY (they own WO rows and spin on the heads' outputs): a live block with an index beyond the
+            // compute units could not be dispatched while they wait for it.  The whole projection grid must be resident
+            // (KVs = 1 per rank at gqa 8: 40 members x 8 = 320 blocks do not fit 256 compute units) -- such shapes keep mode 2
+            // / the four-launch rank plan instead of stalling into the fallback.
+            e->grp_grid_fits = geo && grp_grid(e->KVs, NT / tpm) <= e->num_cus;
+            ok3 = ok3 && e->grp_grid_fits;
         }
         if (ok3) {
             nl_engine::TpGeom &t = e->tpg;
@@ -2149,7 +2157,7 @@ int nl_finalize(nl_handle e) {
         bool ok4 = false;
         {
             const char *aw = getenv("NL_ATTN_WO");
-            ok4 = ok2 && !ok1 && !ok3 && want != 2 && e->G == 1 && !e->p2p.on && !(aw && atoi(aw) == 0) && c.n_layers < 127;
+            ok4 = ok2 && !ok1 && !ok3 && want != 2 && e->G == 1 && !e->p2p.on && !(aw && atoi(aw) == 0) && c.n_layers < 127 && e->grp_grid_fits;
             if (ok4) {
                 nl_engine::TpGeom &t = e->tpg;
                 const nl_engine::Layer &L0 = e->layers[0];

@@ -7,7 +7,7 @@ error behaviour, so host code above it reads like the Go engine's.
 Writer: produces files byte-identical to the reference's
 ``scripts/export_gguf.py`` ``GGUFWriter.write`` (:266-311): KV pairs in
 insertion order, tensor infos with reversed dims, per-tensor 32-byte alignment
-inside the data section.  Pinned by tests/test_gguf.py against fixtures written
+inside the data section.  Pinned by tests/test_gguf_quant.py against fixtures written
 by the reference's own writer.
 """
 from __future__ import annotations

@@ -7,7 +7,7 @@ Rules follow the reference exporter, not ggml:
   * Q4_0: scripts/export_gguf.py:85-121 -- POSITIVE d = amax/8 (unlike ggml's
     signed-max rule), q = clamp(round(x / d) + 8, 0, 15), low nibble =
     element j, high nibble = element j+16.
-Pinned by tests/test_quant.py against bytes captured from the reference
+Pinned by tests/test_gguf_quant.py against bytes captured from the reference
 functions (tests/golden/quant_kat.npz).
 """
 from __future__ import annotations

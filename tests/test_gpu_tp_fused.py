@@ -125,3 +125,90 @@ def test_group_exchange_timeout_falls_back_to_the_general_plan(hip, orc, tmp_pat
     assert fused.shards[0].plan_info()["fused_mode"] == 0        # retired
     assert "timed out" in fused.shards[0].last_error()
     fused.close(); plain.close()
+
+
+def test_big_attention_geometry_across_the_in_launch_passes(hip, orc, tmp_path):
+    # The 7.9B tier's TRUE attention geometry (D 4096 / 64 heads / 16 kv heads: two projection tiles per workgroup, a wavefront
+    # holding two column groups) with a context long enough for every in-launch attention pass: fused mode 4 (one GPU) serves
+    # positions < 768 with 256-position passes, fused mode 3 (tensor-parallel shards, tp 2 / 4 / 8) positions < 512.  Round 4
+    # only checked passes 2 and 3 at D 1024 / 16 heads.  Teacher-forced against the oracle at the pass edges
+    # (go/model.go:557-587), then a chained greedy run across the switch to the split-attention plan at 768.
+    shape = synth.ModelShape("big_geo", 2, 4096, 64, 16, 1024, seq_len=864, interm=2048)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", 97, mode="qrand")
+    g = gguf.load_gguf(str(p))
+    check = (255, 256, 300, 511, 512, 700, 767, 768)
+    prompt = synth.prompt_ids(718, shape.vocab, seed=41)
+    ref = orc.OracleModel(g)
+    orc.set_threads(min(32, os.cpu_count() or 1))
+    seq, wants = list(prompt), {}
+    for pos in range(800):                      # the prompt teacher-forced, then the oracle's own greedy ids
+        lg = ref.forward(seq[pos], pos)
+        if pos in check:
+            wants[pos] = lg.copy()
+        if pos + 1 >= len(seq):
+            seq.append(int(orc.argmax(lg)))
+    orc.set_threads(1)
+    ref.close()
+    greedy = seq[len(prompt):]                  # ids at positions 718 .. 800
+
+    def held(lg, pos, what):
+        d = float(np.abs(lg - wants[pos]).max()) / max(1.0, float(wants[pos].std()))
+        assert d <= LOGIT_TOL, (what, pos, d)
+        return d
+
+    # one GPU: mode 4 (projection + attention + WO in one launch), passes 1 .. 3 and the first position of the general plan
+    dev = hip.load_llama_model(g)
+    info = dev.plan_info()
+    assert info["fused_mode"] == 4 and info["fused_max_pos"] == 768, info
+    worst = 0.0
+    for pos in range(769):
+        dev.forward(seq[pos], pos)
+        if pos in check:
+            worst = max(worst, held(dev.state.logits, pos, "mode 4"))
+    assert dev.last_error() == ""
+    # chained greedy decode from the prompt: 16-step graphs of the fused plan, the seam at 768, then the general plan
+    dev.reset()
+    dev.prefill(prompt)
+    first = int(np.argmax(dev.state.logits))
+    got = [first] + dev.decode_greedy(first, len(prompt), len(greedy) - 1)
+    assert got == greedy
+    assert dev.last_error() == ""
+    dev.close()
+    print(f"\nbig geometry, mode 4: max|gpu-oracle| = {worst:.2e} over positions {check}; {len(greedy)} greedy ids across 768 equal")
+
+    # tensor-parallel shards: mode 3 below 512, the four-launch rank plan from there on
+    for n in (2, 4, 8):
+        grp = hip.LocalTPGroup(g, n, fused=True)
+        info = grp.shards[0].plan_info()
+        assert info["fused_mode"] == 3 and info["fused_max_pos"] == 512, info
+        worst = 0.0
+        for pos in range(769):
+            lg = grp.forward(seq[pos], pos)
+            if pos in check:
+                worst = max(worst, held(lg, pos, f"mode 3 tp {n}"))
+        assert not grp.shards[0].last_error()
+        grp.close()
+        print(f"big geometry, mode 3 tp {n}: max|gpu-oracle| = {worst:.2e}")
+
+
+def test_fused_modes_keep_out_of_a_projection_grid_beyond_the_compute_units(hip, orc, tmp_path):
+    # Modes 3 / 4 keep every block of the projection grid resident (blocks without a tile hold WO rows and wait): with 3 kv
+    # groups of 8 query heads the grid is ceil(3 / 8) * 8 * 40 = 320 blocks > 256 compute units, live blocks beyond the
+    # chip could never start and the first step would spin into the timeout fallback.  The engine must pick mode 2 (whose
+    # blocks without a tile leave at once) up front, silently and correctly.
+    shape = synth.ModelShape("fg_grid", 2, 1536, 24, 3, 512, seq_len=160, interm=1024)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", 99, mode="qrand")
+    g = gguf.load_gguf(str(p))
+    dev = hip.load_llama_model(g)
+    assert dev.plan_info()["fused_mode"] == 2, dev.plan_info()
+    ref = orc.OracleModel(g)
+    orc.set_threads(min(16, os.cpu_count() or 1))
+    for pos, t in enumerate(synth.prompt_ids(24, shape.vocab, seed=43)):
+        dev.forward(t, pos)
+        want = ref.forward(t, pos)
+        assert np.abs(dev.state.logits - want).max() <= LOGIT_TOL * max(1.0, float(want.std())), pos
+    orc.set_threads(1)
+    assert dev.last_error() == "" and dev.plan_info()["fused_mode"] == 2      # no stall, no retirement
+    dev.close(); ref.close()
