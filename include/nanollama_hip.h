@@ -166,6 +166,10 @@ NL_API int nl_profile_forward(nl_handle h, int stream, int token, int pos, int i
  * all-reduce finished in their tails; 4 = wide tiers on one GPU, projection + attention + WO fused (3 per layer).  fused_max_pos: steps below this position take the fused plan.  launches_*: kernel
  * launches per token of the fused / general plan (0 when the plan does not exist). */
 NL_API int nl_plan_info(nl_handle h, int *fused_mode, int *fused_max_pos, int *launches_fused, int *launches_general);
+/* The weight-stationary persistent decode of the smallest tier (nl_persist.h; no reference counterpart, the Go loop is
+ * go/main.go:173-219): ready = nl_decode_greedy takes ONE launch per chunk while the chunk ends below max_pos (Q8_0 files of
+ * nano's shape class on a 256-CU device); launches / tokens count what went through it on this handle. */
+NL_API int nl_persist_info(nl_handle h, int *ready, int *max_pos, long long *launches, long long *tokens);
 /* Device bytes held by the handle (weights, KV, state). */
 NL_API int nl_memory_usage(nl_handle h, uint64_t *weights, uint64_t *kv_cache, uint64_t *state);
 /* Read back a device state buffer for tests ("x","q","xb2","hb","logits",

@@ -17,6 +17,7 @@
 #include "nl_block.h"
 #include "nl_group.h"
 #include "nl_tp.h"
+#include "nl_persist.h"
 
 #include <dlfcn.h>
 #include <algorithm>
@@ -278,6 +279,26 @@ struct nl_engine {
         long long timeout_ticks = 0;
         size_t off_amax = 0, off_logits = 0;             // byte offsets inside an area
     } p2p;
+    // weight-stationary, XCD-pipelined persistent greedy decode of the smallest tier (nl_persist.h): one launch decodes a
+    // whole chunk of tokens with every layer's weights resident in the registers of one XCD's compute units
+    struct Persist {
+        bool candidate = false;      // shape / type admit the path; raw Q8_0 tensors are kept on the device until nl_finalize
+        bool ready = false;          // images built: nl_decode_greedy takes it for chunks that end below max_pos
+        bool retired = false;        // a poll gave up once (or the census was not 8 x 32): the handle keeps the launch plans
+        uint8_t *raw[PD_MAXL][7] = {};
+        uint8_t *lm_raw = nullptr;
+        uint4 *wimg = nullptr, *lmimg = nullptr;
+        unsigned short *simg = nullptr, *lmsimg = nullptr;
+        pd_u64 *gx = nullptr, *go = nullptr, *gxp = nullptr, *gh = nullptr;
+        pd_u32x4 *gam = nullptr;
+        unsigned *census = nullptr, *status = nullptr, *h_status = nullptr;
+        float *norms = nullptr;      // [L][2][D] + [D]: attn_norm | ffn_norm of every layer, output_norm (one pointer for the kernel)
+        unsigned tag_base = 0;
+        int max_pos = PD_MAX_POS;
+        int spin_limit = 2000000;
+        long long *dbg = nullptr;
+        long long launches = 0, tokens = 0;
+    } pd;
     int tw_override = 0, kw_override = 0;
     bool force_tp_plan = false;  // NL_FORCE_TP_PLAN: use the all-reduce / all-gather seams even with one rank
 
@@ -1166,6 +1187,139 @@ bool take_fused_timeout(nl_engine *e) {
     return true;
 }
 
+// ---- persistent greedy decode of the smallest tier (nl_persist.h) -----------------------------------------------------------
+void pd_free_raw(nl_engine *e) {
+    for (auto &row : e->pd.raw)
+        for (uint8_t *&p : row) if (p) { (void)hipFree(p); p = nullptr; }
+    if (e->pd.lm_raw) { (void)hipFree(e->pd.lm_raw); e->pd.lm_raw = nullptr; }
+}
+void pd_free(nl_engine *e) {
+    pd_free_raw(e);
+    nl_engine::Persist &d = e->pd;
+    void *bufs[] = {d.wimg, d.lmimg, d.simg, d.lmsimg, d.gx, d.go, d.gxp, d.gh, d.gam, d.census, d.status, d.dbg, d.norms};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    if (d.h_status) (void)hipHostFree(d.h_status);
+    d = nl_engine::Persist{};
+}
+
+// nl_finalize: pack the lane images (registers of every compute unit's role, LM-head slice for its LDS) from the raw tensors.
+// Anything missing or unsuitable just leaves the path off: the launch plans serve every call.
+int pd_build(nl_engine *e) {
+    nl_engine::Persist &d = e->pd;
+    const nl_config &c = e->cfg;
+    bool ok = d.candidate && e->embd_type == WT_Q8_0 && e->G == 1 && !e->force_tp_plan && e->num_cus == PD_GRID;
+    for (int l = 0; ok && l < c.n_layers; l++) {
+        for (int i = 0; i < 7; i++) ok = ok && d.raw[l][i];
+        const nl_engine::Layer &L = e->layers[l];
+        ok = ok && !L.bq && !L.bk && !L.bv && !L.bo;
+    }
+    if (!ok) { d.candidate = false; pd_free_raw(e); return NL_OK; }
+    const size_t nw = (size_t)PD_GRID * PD_SLOTS * PD_UNITS * PD_THREADS, nlm = (size_t)PD_GRID * PD_ULM * PD_THREADS;
+    HIPCK(e, hipMalloc((void **)&d.wimg, nw * 2 * sizeof(uint4)));
+    HIPCK(e, hipMalloc((void **)&d.simg, nw * sizeof(unsigned short)));
+    HIPCK(e, hipMalloc((void **)&d.lmimg, nlm * 2 * sizeof(uint4)));
+    HIPCK(e, hipMalloc((void **)&d.lmsimg, nlm * sizeof(unsigned short)));
+    e->bytes_weights += nw * 34 + nlm * 34;
+    PdPackParams K{};
+    for (int l = 0; l < c.n_layers; l++)
+        for (int i = 0; i < 7; i++) K.raw[l][i] = d.raw[l][i];
+    K.lm_raw = d.lm_raw ? d.lm_raw : e->embd_raw;        // tied head: output.weight missing -> token_embd (go/model.go:195-201)
+    K.D = c.dim; K.I = c.interm; K.H = c.n_heads; K.V = c.vocab; K.L = c.n_layers;
+    K.wimg = d.wimg; K.simg = d.simg; K.lmimg = d.lmimg; K.lmsimg = d.lmsimg;
+    hipLaunchKernelGGL(pd_pack_kernel, dim3(PD_GRID, PD_SLOTS * PD_UNITS + PD_ULM), dim3(PD_THREADS), 0, e->stream, K);
+    HIPCK(e, hipGetLastError());
+    HIPCK(e, hipStreamSynchronize(e->stream));
+    pd_free_raw(e);
+    const size_t L1 = (size_t)c.n_layers + 1;
+    HIPCK(e, dalloc(&d.gx, L1 * c.dim, &e->bytes_state));
+    HIPCK(e, dalloc(&d.go, L1 * c.dim, &e->bytes_state));
+    HIPCK(e, dalloc(&d.gxp, L1 * c.dim, &e->bytes_state));
+    HIPCK(e, dalloc(&d.gh, L1 * c.interm, &e->bytes_state));
+    HIPCK(e, dalloc(&d.gam, (size_t)PD_GRID, &e->bytes_state));
+    HIPCK(e, hipMemset(d.gx, 0, L1 * c.dim * 8)); HIPCK(e, hipMemset(d.go, 0, L1 * c.dim * 8)); HIPCK(e, hipMemset(d.gxp, 0, L1 * c.dim * 8));
+    HIPCK(e, hipMemset(d.gh, 0, L1 * c.interm * 8)); HIPCK(e, hipMemset(d.gam, 0, (size_t)PD_GRID * 16));
+    HIPCK(e, dalloc(&d.norms, ((size_t)c.n_layers * 2 + 1) * c.dim, &e->bytes_state));
+    for (int l = 0; l < c.n_layers; l++) {
+        HIPCK(e, hipMemcpy(d.norms + (size_t)(2 * l) * c.dim, e->layers[l].attn_norm, (size_t)c.dim * 4, hipMemcpyDeviceToDevice));
+        HIPCK(e, hipMemcpy(d.norms + (size_t)(2 * l + 1) * c.dim, e->layers[l].ffn_norm, (size_t)c.dim * 4, hipMemcpyDeviceToDevice));
+    }
+    HIPCK(e, hipMemcpy(d.norms + (size_t)(2 * c.n_layers) * c.dim, e->output_norm, (size_t)c.dim * 4, hipMemcpyDeviceToDevice));
+    HIPCK(e, dalloc(&d.census, (size_t)16, &e->bytes_state));
+    HIPCK(e, dalloc(&d.status, (size_t)4, &e->bytes_state));
+    HIPCK(e, hipMemset(d.status, 0, 16));
+    HIPCK(e, dalloc(&d.dbg, (size_t)64, &e->bytes_state));
+    HIPCK(e, hipMemset(d.dbg, 0, 64 * sizeof(long long)));
+    HIPCK(e, hipHostMalloc((void **)&d.h_status, sizeof(unsigned), hipHostMallocMapped));
+    *d.h_status = 0;
+    const void *kfn = c.dim == 576 ? reinterpret_cast<const void *>(pd_decode_kernel<18, 48>) : reinterpret_cast<const void *>(pd_decode_kernel<8, 16>);
+    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd_lds_bytes()) != hipSuccess) {
+        (void)hipGetLastError();
+        d.candidate = false;
+        return NL_OK;
+    }
+    if (const char *mp = getenv("NL_PERSIST_MAX_POS")) d.max_pos = std::max(0, std::min(PD_MAX_POS, atoi(mp)));   // knob (tests, tools)
+    if (const char *sl = getenv("NL_PERSIST_SPIN_LIMIT")) d.spin_limit = atoi(sl);   // knob (tests): 0 makes every poll give up
+    d.max_pos = std::min(d.max_pos, c.seq_len);
+    d.tag_base = 0;
+    d.ready = true;
+    return NL_OK;
+}
+
+bool pd_usable(const nl_engine *e, int pos, int n) {
+    return e->pd.ready && !e->pd.retired && n > 0 && pos + n <= e->pd.max_pos && !e->gamma_row && e->G == 1;
+}
+
+// One launch = n greedy tokens from (token, pos); ids land in e->ids.  The caller synchronises and then asks pd_take_timeout.
+int pd_launch(nl_engine *e, int stream, int token, int pos, int n) {
+    nl_engine::Persist &d = e->pd;
+    const nl_config &c = e->cfg;
+    if (d.tag_base > 0xf0000000u) {      // (tags never repeat inside the life of the areas: start over from clean ones)
+        const size_t L1 = (size_t)c.n_layers + 1;
+        HIPCK(e, hipMemsetAsync(d.gx, 0, L1 * c.dim * 8, e->stream)); HIPCK(e, hipMemsetAsync(d.go, 0, L1 * c.dim * 8, e->stream));
+        HIPCK(e, hipMemsetAsync(d.gxp, 0, L1 * c.dim * 8, e->stream)); HIPCK(e, hipMemsetAsync(d.gh, 0, L1 * c.interm * 8, e->stream));
+        HIPCK(e, hipMemsetAsync(d.gam, 0, (size_t)PD_GRID * 16, e->stream));
+        d.tag_base = 0;
+    }
+    HIPCK(e, hipMemsetAsync(d.census, 0, 16 * sizeof(unsigned), e->stream));
+    PdParams P{};
+    P.D = c.dim; P.I = c.interm; P.H = c.n_heads; P.V = c.vocab; P.L = c.n_layers; P.seq_len = c.seq_len; P.rope_conj = c.rope_conjugate;
+    P.n_steps = n; P.token0 = token; P.pos0 = pos; P.spin_limit = d.spin_limit;
+    P.eps = c.rms_eps; P.scale = (float)(1.0 / std::sqrt((double)e->hd));
+    P.tag_base = d.tag_base;
+    d.tag_base += (unsigned)n + 2u;
+    P.wimg = d.wimg; P.simg = d.simg; P.lmimg = d.lmimg; P.lmsimg = d.lmsimg;
+    P.norms = d.norms;
+    P.embd_raw = e->embd_raw;
+    P.rope_cos = e->rope_cos; P.rope_sin = e->rope_sin;
+    P.kcache = e->kcache + (long long)stream * e->kv_stream_stride; P.vcache = e->vcache + (long long)stream * e->kv_stream_stride;
+    P.kv_layer_stride = e->kv_layer_stride;
+    P.gx = d.gx; P.go = d.go; P.gxp = d.gxp; P.gh = d.gh; P.gam = d.gam;
+    P.census = d.census; P.ids_out = e->ids; P.logits = e->logits;
+    P.status = d.status; P.host_status = d.h_status; P.dbg = d.dbg;
+    if (c.dim == 576) hipLaunchKernelGGL((pd_decode_kernel<18, 48>), dim3(PD_GRID), dim3(PD_THREADS), pd_lds_bytes(), e->stream, P);
+    else hipLaunchKernelGGL((pd_decode_kernel<8, 16>), dim3(PD_GRID), dim3(PD_THREADS), pd_lds_bytes(), e->stream, P);
+    HIPCK(e, hipGetLastError());
+    d.launches++; d.tokens += n;
+    return NL_OK;
+}
+
+// after a synchronize: did the persistent launch give up (a poll ran out, or the census was not 8 x 32)?  The caller then
+// redoes its chunk on the launch plans -- every buffer the chunk writes (K / V rows, ids, logits) is rewritten by the redo --
+// and this handle keeps them from now on.
+bool pd_take_timeout(nl_engine *e) {
+    nl_engine::Persist &d = e->pd;
+    if (!d.h_status || !*d.h_status) return false;
+    const unsigned st = *d.h_status;
+    *d.h_status = 0;
+    (void)hipMemsetAsync(d.status, 0, sizeof(unsigned), e->stream);
+    (void)hipStreamSynchronize(e->stream);
+    d.retired = true;
+    e->fail(NL_OK, "warning: the persistent decode launch gave up (status %u: %s); the chunk was redone on the launch plans, which this "
+                   "handle keeps from now on", st, (st & 64u) ? "its workgroups were not placed 32 per XCD" : "a hand-off poll timed out");
+    if (!getenv("NL_QUIET")) fprintf(stderr, "[nanollama_hip] %s\n", e->err.c_str());
+    return true;
+}
+
 struct Slot { int layer; std::string field; };
 
 bool parse_name(const char *name, Slot &s) {
@@ -1770,6 +1924,11 @@ int nl_create(const nl_config *cfg, nl_handle *out) {
     e->layers.resize(c.n_layers);
     e->use_graph = !(c.flags & NL_FLAG_NO_GRAPH) && !getenv("NL_NO_GRAPH");
     if (getenv("NL_FORCE_TP_PLAN")) e->force_tp_plan = true;
+    {
+        const char *pk = getenv("NL_PERSIST");      // knob (tests, tools): 0 keeps the launch plans for greedy chains too
+        e->pd.candidate = !(pk && atoi(pk) == 0) && c.tp_size == 1 && !(c.flags & NL_FLAG_LOCAL_GROUP) && !c.qk_norm &&
+                          pd_shape_ok(c.dim, c.interm, c.n_heads, c.n_kv_heads, c.head_dim, c.vocab, c.n_layers);
+    }
     if (const char *v = getenv("NL_SUB_BATCHES")) e->sub_batches = std::max(1, std::min(4, atoi(v)));   // knob (tests, tools)
     if (const char *v = getenv("NL_TW")) e->tw_override = atoi(v);
     if (const char *v = getenv("NL_KW")) e->kw_override = atoi(v);
@@ -1844,6 +2003,23 @@ int nl_upload_tensor(nl_handle e, const char *name, uint32_t type, const void *d
         return NL_OK;
     };
 
+    if (e->pd.candidate) {
+        // the persistent decode (nl_persist.h) packs its own lane images from the raw Q8_0 tensors at nl_finalize: keep them
+        static const char *const kMat[7] = {"attn_q.weight", "attn_k.weight", "attn_v.weight", "attn_output.weight", "ffn_gate.weight",
+                                            "ffn_up.weight", "ffn_down.weight"};
+        int slot = -1;
+        for (int i = 0; i < 7; i++) if (sl.layer >= 0 && f == kMat[i]) slot = i;
+        const bool is_lm = sl.layer < 0 && f == "output.weight";
+        const bool is_bias = f.size() > 5 && f.compare(f.size() - 5, 5, ".bias") == 0;
+        if (((slot >= 0 || is_lm) && type != WT_Q8_0) || is_bias) {
+            e->pd.candidate = false;
+        } else if (slot >= 0 || is_lm) {
+            uint8_t **dst = is_lm ? &e->pd.lm_raw : &e->pd.raw[sl.layer][slot];
+            if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+            HIPCK(e, hipMalloc((void **)dst, nbytes));
+            HIPCK(e, hipMemcpy(*dst, data, nbytes, hipMemcpyHostToDevice));
+        }
+    }
     const int hd = e->hd, D = c.dim;
     if (sl.layer < 0) {
         if (f == "token_embd.weight") {
@@ -2221,6 +2397,7 @@ int nl_finalize(nl_handle e) {
         return e->fail(NL_ERR_STATE, "collective plan needs nl_comm_init before nl_finalize");
     HIPCK(e, hipStreamSynchronize(e->stream));
     if (int rc = build_all(e)) return rc;
+    if (int rc = pd_build(e)) return rc;
     e->finalized = true;
     return NL_OK;
 }
@@ -2289,6 +2466,7 @@ int nl_destroy(nl_handle e) {
         float *bs[] = {L.bq, L.bk, L.bv, L.bo};
         for (float *b : bs) if (b) hipFree(b);
     }
+    pd_free(e);
     if (e->gamma_row) hipFree(e->gamma_row);
     if (e->gamma_val) hipFree(e->gamma_val);
     for (void *c : e->arena_chunks) hipFree(c);
@@ -2389,21 +2567,34 @@ int nl_decode_greedy(nl_handle e, int stream, int token, int pos, int n_steps, i
     HIPCK(e, hipSetDevice(e->dev));
     int n = std::min(n_steps, e->cfg.seq_len - pos);
     n = std::min(n, e->ids_cap);
-    for (int attempt = 0;; attempt++) {
-        if ((rc = note_positions(e, stream, pos, n))) return rc;
-        if ((rc = set_ctl(e, token, pos, 1, stream))) return rc;
-        int i = 0;
-        for (; i + e->graph_steps <= n && e->graph_steps > 1; i += e->graph_steps) {
-            nl_engine::PlanSet &S = pick_plan(e, pos + i + e->graph_steps - 1);   // highest position of these steps
-            if (!S.multi_exec) break;
-            HIPCK(e, hipGraphLaunch(S.multi_exec, e->stream));
-        }
-        for (; i < n; i++)
-            if ((rc = launch_step(e, pos + i))) return rc;
-        if (n > 0) HIPCK(e, hipMemcpyAsync(ids_out, e->ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    if ((rc = note_positions(e, stream, pos, n))) return rc;
+    int done = 0;
+    if (n > 0 && pd_usable(e, pos, 1)) {
+        // the smallest tier, short contexts: ONE persistent launch decodes the tokens below its position limit (nl_persist.h);
+        // what lies beyond continues on the launch plans from the last id
+        const int n1 = std::min(n, e->pd.max_pos - pos);
+        if ((rc = pd_launch(e, stream, token, pos, n1))) return rc;
+        HIPCK(e, hipMemcpyAsync(ids_out, e->ids, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
         HIPCK(e, hipStreamSynchronize(e->stream));
-        if (attempt == 0 && take_fused_timeout(e)) continue;   // the whole chain again, on the general plan
-        break;
+        if (!pd_take_timeout(e)) done = n1;              // (a give-up: the whole chunk on the launch plans)
+    }
+    if (done < n) {
+        const int tok = done ? ids_out[done - 1] : token, p0 = pos + done, m = n - done;
+        for (int attempt = 0;; attempt++) {
+            if ((rc = set_ctl(e, tok, p0, 1, stream))) return rc;
+            int i = 0;
+            for (; i + e->graph_steps <= m && e->graph_steps > 1; i += e->graph_steps) {
+                nl_engine::PlanSet &S = pick_plan(e, p0 + i + e->graph_steps - 1);   // highest position of these steps
+                if (!S.multi_exec) break;
+                HIPCK(e, hipGraphLaunch(S.multi_exec, e->stream));
+            }
+            for (; i < m; i++)
+                if ((rc = launch_step(e, p0 + i))) return rc;
+            HIPCK(e, hipMemcpyAsync(ids_out + done, e->ids, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+            HIPCK(e, hipStreamSynchronize(e->stream));
+            if (attempt == 0 && take_fused_timeout(e)) continue;   // the whole chain again, on the general plan
+            break;
+        }
     }
     if (int prc = p2p_check(e)) return prc;
     if (n_done) *n_done = n;
@@ -2868,6 +3059,15 @@ int nl_plan_info(nl_handle e, int *fused_mode, int *fused_max_pos, int *launches
     return NL_OK;
 }
 
+int nl_persist_info(nl_handle e, int *ready, int *max_pos, long long *launches, long long *tokens) {
+    if (!e) return NL_ERR_INVALID;
+    if (ready) *ready = (e->pd.ready && !e->pd.retired) ? 1 : 0;
+    if (max_pos) *max_pos = e->pd.ready ? e->pd.max_pos : 0;
+    if (launches) *launches = e->pd.launches;
+    if (tokens) *tokens = e->pd.tokens;
+    return NL_OK;
+}
+
 int nl_memory_usage(nl_handle e, uint64_t *w, uint64_t *kv, uint64_t *st) {
     if (!e) return NL_ERR_INVALID;
     if (w) *w = e->bytes_weights;
@@ -2888,6 +3088,7 @@ int64_t nl_debug_read(nl_handle e, const char *which, int stream, float *out, in
     else if (w == "logits") { src = e->logits; n = e->cfg.vocab; }
     else if (w == "k_cache") { src = e->kcache + (long long)stream * e->kv_stream_stride; n = e->kv_stream_stride; }
     else if (w == "v_cache") { src = e->vcache + (long long)stream * e->kv_stream_stride; n = e->kv_stream_stride; }
+    else if (w == "pd_dbg" && e->pd.dbg) { src = reinterpret_cast<const float *>(e->pd.dbg); n = 128; }   // 64 wall-clock stamps (int64) of nl_persist.h
     else return e->fail(NL_ERR_INVALID, "unknown debug buffer %s", which);
     n = std::min(n, max_floats);
     if (hipSetDevice(e->dev) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess ||

@@ -1,0 +1,885 @@
+// nl_persist.h -- weight-stationary, XCD-pipelined persistent greedy decode for the smallest tier (round 5).
+//
+// go/main.go:173-219 decodes token after token through go/model.go:490-620.  For nano (75 MB of Q8_0) the HBM time of a
+// token is 9 us, yet the launch plans of nl_block.h need 180: thirty dependent launches, each re-fetching its weights cold
+// and each meeting its peers through the fabric.  tools/xcd_exchange_probe.hip (profiles/r05_xcd_exchange_probe.log) measured
+// what decides the structure here: a hand-off between two compute units of the SAME XCD through that XCD's own L2 (plain
+// store, L1-bypassing load) is 0.25 us, against 0.58 us for the write-through form every cross-XCD exchange needs; an
+// all-gather among the 32 compute units of one XCD 1.27 us against 2.8 us chip-wide.
+//
+// So ONE launch decodes n tokens, and every layer lives on ONE XCD:
+//   * 256 persistent workgroups (one per compute unit) read HW_REG_XCC_ID and take a ticket from their XCD's counter; roles
+//     follow the REAL placement (nothing assumes block b -> XCD b % 8; a census that is not 8 x 32 makes the launch give up
+//     and the caller keeps the launch plans);
+//   * XCD x owns layers first(x) .. first(x) + nslots(x) - 1 (13 layers: two on XCDs 0-4, one on 5-7).  The weights of its
+//     layers sit in the REGISTERS of its 32 compute units for the whole launch (8 wavefronts x 256 VGPRs: 4.2 MB per layer
+//     = 132 KB per compute unit and layer); the LM head's 1/256 slice (76 KB) sits in each compute unit's LDS.  Nothing
+//     but activations and K / V rows moves per token;
+//   * inside a layer H compute units are HEADS (Q | K | V rows of one head, RoPE, KV store, softmax attention over the cache,
+//     all local to the workgroup: go/model.go:517-587) and the other 32 - H are WORKERS (rows of WO, gate / up, down:
+//     go/model.go:590-612).  Four hand-offs per layer, all inside the XCD: x -> heads, o -> workers, x' among workers,
+//     h among workers; the layer's output leaves as the next layer's x (write-through only where the next layer lives on
+//     another XCD);
+//   * after the last layer every compute unit multiplies its LM-head rows, the per-unit (max, index) pairs meet on layer 0's
+//     XCD, whose compute units pick the token (go/main.go:400-408: strict '>', lowest index on ties), look up its embedding
+//     row (go/model.go:389-446) and start the next token.
+// Hand-offs are 8-byte {tag, value} granules (tag = launch base + step + 1; one aligned store each, the value is its own
+// arrival flag), polled with L1-bypassing loads; every poll is bounded and a give-up sets the status word the host checks
+// (it then redoes the chunk on the launch plans and retires this path, like the fused plans of nl_block.h).
+//
+// Arithmetic per block is BlockDot's (four accumulators per 32-element block, then * d), block products of a row are added
+// in block order as go/quant.go:149-165 does; RMSNorm's 1/rms multiplies the row sum (as every GEMV here does); softmax
+// pieces as nl_block.h.  Held to the oracle's logits within 1e-4 and to its greedy ids (tests/test_gpu_persist.py).
+#pragma once
+#include "nl_kernels.h"
+
+namespace nl {
+
+typedef unsigned long long pd_u64;
+typedef unsigned pd_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned pd_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PD_THREADS = 512, PD_WAVES = 8, PD_XCDS = 8, PD_CUS = 32, PD_GRID = PD_XCDS * PD_CUS;
+constexpr int PD_UQ = 7;      // unit slots per lane of a head: Q | K | V rows of one head (192 rows x D / 32 blocks <= 7 x 512)
+constexpr int PD_UW = 1, PD_UG = 5, PD_UD = 3;   // ... of a worker: WO rows, gate + up rows, down rows
+constexpr int PD_UNITS = 9;   // max(PD_UQ, PD_UW + PD_UG + PD_UD): registers hold 9 units of 32 int8 + an fp16 scale per layer slot
+constexpr int PD_ULM = 5;     // LM-head unit slots per lane (LDS)
+constexpr int PD_SLOTS = 2;   // layers per XCD
+constexpr int PD_MAXL = PD_SLOTS * PD_XCDS;
+constexpr int PD_MAXD = 576, PD_MAXI = 1536, PD_NBD_MAX = PD_MAXD / 32, PD_NBI_MAX = PD_MAXI / 32;
+constexpr int PD_PART = 192 * (PD_NBD_MAX + 1) + 64;   // floats: block products of the largest phase (Q | K | V), rows padded to an odd pitch
+constexpr int PD_MAX_PASSES = 4;                       // attention passes of 128 positions: contexts below 512
+constexpr int PD_MAX_POS = PD_MAX_PASSES * 128;
+
+// ---- who holds what (host packer and kernel share these) -----------------------------------------------------------------
+__host__ __device__ inline int pd_nslots(int L, int xcd) { return L / PD_XCDS + (xcd < L % PD_XCDS ? 1 : 0); }
+__host__ __device__ inline int pd_first(int L, int xcd) { return xcd * (L / PD_XCDS) + (xcd < L % PD_XCDS ? xcd : L % PD_XCDS); }
+// slot 0: heads are units 0 .. H-1 of the XCD, slot 1: units 32-H .. 31 -- a unit is a head in at most one slot (H <= 16)
+__host__ __device__ inline bool pd_is_head(int slot, int idx, int H) { return slot == 0 ? idx < H : idx >= PD_CUS - H; }
+__host__ __device__ inline int pd_head_index(int slot, int idx, int H) { return slot == 0 ? idx : idx - (PD_CUS - H); }
+__host__ __device__ inline int pd_worker_index(int slot, int idx, int H) { return slot == 0 ? idx - H : idx; }
+__host__ __device__ inline int pd_split(int n, int parts, int i) { return (int)(((long long)n * i) / parts); }   // first row of part i
+__host__ __device__ inline int pd_lm_rows(int V) { return (V + PD_GRID - 1) / PD_GRID; }
+__host__ __device__ inline int pd_pad4(int n) { return (n + 3) & ~3; }
+// Unit u of a phase = lane (u & 3) of a group of four lanes that share one 32-column block: rows 4 * (G / NB) + (u & 3) of this
+// compute unit's (padded) rows, block G % NB, G = u / 4 -- one v_mfma_i32_4x4x4_16b_i8 is sixteen such groups
+__host__ __device__ inline void pd_unit_rc(int u, int NB, int &row, int &blk) { const int G = u >> 2; row = (G / NB) * 4 + (u & 3); blk = G % NB; }
+
+inline bool pd_shape_ok(int D, int I, int H, int KV, int hd, int V, int L) {
+    if (hd != 64 || KV != H || D != H * 64 || D % 32 || I % 32 || H < 1 || H > 16 || L < 1 || L > PD_MAXL) return false;
+    if (!((D == 576 && I == 1536) || (D == 256 && I == 512))) return false;     // the instantiations of pd_decode_kernel (nano's shape; a small test shape)
+    const int NB = D / 32, NBI = I / 32, NWK = PD_CUS - H;
+    int rw = 0, rg = 0;
+    for (int w = 0; w < NWK; w++) {
+        rw = rw > pd_split(D, NWK, w + 1) - pd_split(D, NWK, w) ? rw : pd_split(D, NWK, w + 1) - pd_split(D, NWK, w);
+        rg = rg > pd_split(I, NWK, w + 1) - pd_split(I, NWK, w) ? rg : pd_split(I, NWK, w + 1) - pd_split(I, NWK, w);
+    }
+    rw = pd_pad4(rw); rg = pd_pad4(rg);
+    if (192 * NB > PD_UQ * PD_THREADS || rw * NB > PD_UW * PD_THREADS || 2 * rg * NB > PD_UG * PD_THREADS || rw * NBI > PD_UD * PD_THREADS) return false;
+    if (2 * rg > 256 || 4 * rw > PD_THREADS || 2 * rg * (NB + 1) > PD_PART || rw * (NBI + 1) > PD_PART) return false;
+    const int lr = pd_pad4(pd_lm_rows(V));
+    return lr <= 128 && lr * NB <= PD_ULM * PD_THREADS && lr * (NB + 1) <= PD_PART;
+}
+
+__host__ __device__ constexpr size_t pd_lds_bytes() {
+    return (size_t)PD_ULM * 2 * PD_THREADS * 16 + (size_t)PD_ULM * PD_THREADS * 2       // LM-head slice: quants, fp16 scales
+           + 640 * 4 + 20 * 128 + PD_NBI_MAX * 128                                      // x, digit images of x * g and of h
+           + (size_t)PD_PART * 4 + 256 * 4 + 16 * 8                                     // block products, row sums, float64 partials
+           + (192 + 64 + 8 * 68 + PD_MAX_PASSES * 66) * 4 + 64 * 4 + 80 * 4;            // q | k | v, attention output, pass partials, misc, block scales
+}
+
+struct PdParams {
+    int D, I, H, V, L, seq_len, rope_conj, n_steps, token0, pos0, spin_limit;
+    float eps, scale;
+    unsigned tag_base;
+    const uint4 *wimg;               // [256][2][9][2][512] x 16 B: lane images of the layer weights (pd_pack_kernel)
+    const unsigned short *simg;      // [256][2][9][512] fp16 scale bits
+    const uint4 *lmimg;              // [256][5][2][512]
+    const unsigned short *lmsimg;    // [256][5][512]
+    const float *norms;              // [L][2][D] attn_norm | ffn_norm of every layer, then [D] output_norm (packed by pd_build)
+    const uint8_t *embd_raw;         // Q8_0 rows of token_embd
+    const float *rope_cos, *rope_sin;
+    float *kcache, *vcache;          // layer 0 of the stream: [kv head][seq][64]
+    long long kv_layer_stride;
+    pd_u64 *gx;                      // [L + 1][D]: input x of layer l >= 1; [L] = the final residual stream
+    pd_u64 *go, *gxp;                // [L][D]: heads' attention outputs; x' = x + WO o
+    pd_u64 *gh;                      // [L][I]: SiLU(gate) * up
+    pd_u32x4 *gam;                   // [256] {tag, max bits, index, -}
+    unsigned *census;                // [8] tickets per XCD, [8] arrivals, [9] the token the launch ended on
+    int *ids_out;                    // [n_steps]
+    float *logits;                   // [V] of the last step
+    unsigned *status, *host_status;
+    long long *dbg;                  // optional stamps of (xcd 0, unit 0), thread 0
+};
+
+struct PdPackParams {
+    const uint8_t *raw[PD_MAXL][7];  // q, k, v, o, gate, up, down: raw GGUF Q8_0 tensors on the device
+    const uint8_t *lm_raw;           // output.weight (or token_embd for tied heads)
+    int D, I, H, V, L;
+    uint4 *wimg; unsigned short *simg; uint4 *lmimg; unsigned short *lmsimg;
+};
+
+// One block per (compute unit, unit slot): lane l's 34-byte block of that slot, split into two 16-byte chunks and the scale.
+// grid (256, 2 * 9 + 5), 512 threads.
+__global__ void __launch_bounds__(PD_THREADS) pd_pack_kernel(PdPackParams P) {
+    const int cu = blockIdx.x, xcd = cu / PD_CUS, idx = cu % PD_CUS, unit = blockIdx.y, tid = threadIdx.x;
+    const int NB = P.D / 32, NBI = P.I / 32, NWK = PD_CUS - P.H;
+    const uint8_t *src = nullptr;     // the 34-byte block, or null = zeros
+    if (unit < PD_SLOTS * PD_UNITS) {
+        const int s = unit / PD_UNITS, k = unit % PD_UNITS;
+        if (s < pd_nslots(P.L, xcd)) {
+            const int layer = pd_first(P.L, xcd) + s;
+            if (pd_is_head(s, idx, P.H)) {
+                const int h = pd_head_index(s, idx, P.H), u = k * PD_THREADS + tid;
+                if (k < PD_UQ && u < 192 * NB) {
+                    int row, blk;
+                    pd_unit_rc(u, NB, row, blk);
+                    const int sect = row >> 6, e = row & 63;
+                    src = P.raw[layer][sect] + ((size_t)(h * 64 + e) * NB + blk) * 34;
+                }
+            } else {
+                const int w = pd_worker_index(s, idx, P.H);
+                const int r0 = pd_split(P.D, NWK, w), nr = pd_split(P.D, NWK, w + 1) - r0, g0 = pd_split(P.I, NWK, w), rg = pd_split(P.I, NWK, w + 1) - g0;
+                const int nrp = pd_pad4(nr), rgp = pd_pad4(rg);
+                int row, blk;
+                if (k < PD_UW) {
+                    const int u = k * PD_THREADS + tid;
+                    pd_unit_rc(u, NB, row, blk);
+                    if (u < nrp * NB && row < nr) src = P.raw[layer][3] + ((size_t)(r0 + row) * NB + blk) * 34;
+                } else if (k < PD_UW + PD_UG) {
+                    const int u = (k - PD_UW) * PD_THREADS + tid;
+                    pd_unit_rc(u, NB, row, blk);
+                    if (u < 2 * rgp * NB) {            // rows [0, rgp): gate, [rgp, 2 rgp): up -- the padding rows stay zero
+                        const bool up = row >= rgp;
+                        const int rr = up ? row - rgp : row;
+                        if (rr < rg) src = P.raw[layer][up ? 5 : 4] + ((size_t)(g0 + rr) * NB + blk) * 34;
+                    }
+                } else {
+                    const int u = (k - PD_UW - PD_UG) * PD_THREADS + tid;
+                    pd_unit_rc(u, NBI, row, blk);
+                    if (u < nrp * NBI && row < nr) src = P.raw[layer][6] + ((size_t)(r0 + row) * NBI + blk) * 34;
+                }
+            }
+        }
+    } else {
+        const int k = unit - PD_SLOTS * PD_UNITS, u = k * PD_THREADS + tid, lr = pd_lm_rows(P.V);
+        const int r0 = cu * lr, nrows = max(0, min(lr, P.V - r0));
+        int row, blk;
+        pd_unit_rc(u, NB, row, blk);
+        if (u < pd_pad4(lr) * NB && row < nrows) src = P.lm_raw + ((size_t)(r0 + row) * NB + blk) * 34;
+    }
+    uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+    unsigned short d16 = 0;
+    if (src) {
+        uint8_t b[34];
+        for (int i = 0; i < 34; i++) b[i] = src[i];
+        d16 = (unsigned short)(b[0] | (b[1] << 8));
+        auto w32 = [&](int o) { return (unsigned)b[o] | ((unsigned)b[o + 1] << 8) | ((unsigned)b[o + 2] << 16) | ((unsigned)b[o + 3] << 24); };
+        lo = make_uint4(w32(2), w32(6), w32(10), w32(14));
+        hi = make_uint4(w32(18), w32(22), w32(26), w32(30));
+    }
+    if (unit < PD_SLOTS * PD_UNITS) {
+        const size_t base = ((size_t)cu * PD_SLOTS * PD_UNITS + unit);
+        P.wimg[(base * 2 + 0) * PD_THREADS + tid] = lo;
+        P.wimg[(base * 2 + 1) * PD_THREADS + tid] = hi;
+        P.simg[base * PD_THREADS + tid] = d16;
+    } else {
+        const size_t base = (size_t)cu * PD_ULM + (unit - PD_SLOTS * PD_UNITS);
+        P.lmimg[(base * 2 + 0) * PD_THREADS + tid] = lo;
+        P.lmimg[(base * 2 + 1) * PD_THREADS + tid] = hi;
+        P.lmsimg[base * PD_THREADS + tid] = d16;
+    }
+}
+
+// ---- device helpers --------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pd_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+// L1-bypassing loads the compiler counts (buffer_load ... sc1): served by this XCD's L2, or by the fabric for a line a
+// write-through store dropped
+__device__ __forceinline__ pd_u64 pd_ld8(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const pd_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 16);
+    return ((pd_u64)v.y << 32) | v.x;
+}
+__device__ __forceinline__ float4 pd_ld16f(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const pd_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+// a granule for a consumer on THIS XCD stays in the XCD's L2 (workgroup-scope store: written through the L1 only); one
+// for another XCD is written through to the fabric (agent scope)
+template <bool CROSS>
+__device__ __forceinline__ void pd_publish(pd_u64 *p, unsigned tag, float v) {
+    const pd_u64 g = ((pd_u64)tag << 32) | __float_as_uint(v);
+    if (CROSS) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+struct PdPoll {
+    unsigned *status, *host_status;
+    int spin_limit;
+    int *lds_dead;
+};
+__device__ __forceinline__ void pd_give_up(const PdPoll &Q, unsigned code, int tid) {
+    if ((tid & 63) == 0) { atomicOr(Q.status, code); *Q.host_status = code; *Q.lds_dead = 1; }
+}
+// n granules -> v[k] = value of granule tid + 512 k (a wavefront leaves when all of its granules carry the tag); bounded
+template <int NPT>
+__device__ __forceinline__ void pd_gather(const pd_u64 *g, int n, unsigned tag, float (&v)[NPT], const PdPoll &Q, unsigned code, int tid) {
+    const __amdgpu_buffer_rsrc_t r = pd_rsrc(g, (unsigned)n * 8u);
+    unsigned off[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; k++) off[k] = (unsigned)min(tid + k * PD_THREADS, n - 1) * 8u;
+    pd_u64 q[NPT];
+    for (int spins = 0;; spins++) {
+#pragma unroll
+        for (int k = 0; k < NPT; k++) q[k] = pd_ld8(r, off[k]);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NPT; k++) ok &= (unsigned)(q[k] >> 32) == tag;
+        if (__all(ok)) break;
+        if (spins >= Q.spin_limit || ((spins & 63) == 63 && __hip_atomic_load(Q.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            pd_give_up(Q, code, tid);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int k = 0; k < NPT; k++) v[k] = __uint_as_float((unsigned)q[k]);
+}
+
+// U unit slots of a phase: unit u = k * 512 + tid = (row u / NB, block u % NB) of this compute unit's rows; the lane's
+// 32 int8 of slot k times the block's 32 inputs (LDS, transposed so that consecutive blocks are consecutive float4s: the
+// lanes of a wavefront read conflict-free), times d -> part[row * NBP + block]
+typedef int pd_i32x4 __attribute__((ext_vector_type(4)));
+
+// lanes j, j + 16 (permlane16_swap) and j, j + 32 (permlane32_swap) meet on the vector pipe: gfx950's swaps instead of
+// ds_bpermute round trips (nl_batch.h rows4_sum)
+__device__ __forceinline__ float pd_pair16_max(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+__device__ __forceinline__ float pd_rows4_sum(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ double pd_wave_sum_f64(double v) {
+    v += dpp_f64<DPP_QUAD_XOR1>(v);
+    v += dpp_f64<DPP_QUAD_XOR2>(v);
+    v += dpp_f64<DPP_HALF_MIRROR>(v);
+    v += dpp_f64<DPP_ROW_MIRROR>(v);   // every lane: sum of its row of 16
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    return v;
+}
+
+// One 32-element block of a vector as the A operand of v_mfma_i32_4x4x4_16b_i8.  The block's values are scaled by a power of
+// two so that the largest fits 31 bits, rounded to integers X (|X| <= 2^30: 2^-30 of the block's maximum per element, 64 times
+// finer than a float32 mantissa) and written as four SIGNED base-256 digits X = l0 + 256 l1 + 65536 l2 + 2^24 l3: the image holds,
+// per block, digit m of its 32 elements as 32 consecutive bytes ([block][m][32]).  A 4x4x4 product of digit rows with int8
+// weight columns is exact in int32; the digits are recombined in float32 afterwards (pd_units).  The calling HALF wavefront
+// (32 lanes, all active) holds the block: e = element index of this lane, valid = the element exists.
+__device__ __forceinline__ void pd_limbs(float v, bool valid, int e, unsigned char *img, float *scl, int lane) {
+    float a = valid ? fabsf(v) : 0.f;
+    a = fmaxf(a, dpp_f32<DPP_QUAD_XOR1>(a));
+    a = fmaxf(a, dpp_f32<DPP_QUAD_XOR2>(a));
+    a = fmaxf(a, dpp_f32<DPP_HALF_MIRROR>(a));
+    a = fmaxf(a, dpp_f32<DPP_ROW_MIRROR>(a));          // max of the row of 16
+    a = pd_pair16_max(a);                              // ... of the block's 32 lanes
+    unsigned ex = __float_as_uint(a) >> 23;            // biased exponent of the block's maximum (a >= 0)
+    ex = min(max(ex, 30u), 254u);
+    const float scale = __uint_as_float((283u - ex) << 23);      // 2^(29 - (ex - 127)): |v * scale| < 2^30
+    const int X = valid ? __float2int_rn(v * scale) : 0;
+    const int l0 = (X << 24) >> 24, X1 = (X - l0) >> 8;
+    const int l1 = (X1 << 24) >> 24, X2 = (X1 - l1) >> 8;
+    const int l2 = (X2 << 24) >> 24, l3 = (X2 - l2) >> 8;
+    unsigned char *p = img + (e >> 5) * 128 + (e & 31);
+    p[0] = (unsigned char)l0; p[32] = (unsigned char)l1; p[64] = (unsigned char)l2; p[96] = (unsigned char)l3;
+    if ((lane & 31) == 0) scl[e >> 5] = __uint_as_float((ex - 29u) << 23);      // 1 / scale
+}
+
+// U unit slots of a phase (pd_unit_rc): the lane's 32 int8 of slot k are the B operand of eight chained 4x4x4 products whose A
+// operand is digit (lane & 3) of the block (two 16-byte LDS reads); the lane then holds the four digit sums of ITS row, recombines
+// them in float32 and multiplies by d and the block's 1 / scale -> part[row * NBP + block].  (The float32 dot product of the
+// reference, go/quant.go:149-165, has a rounding per element; this form is exact up to the 2^-30 input rounding and three
+// float32 roundings per block.)  One MFMA = 256 weights: a quarter of the instructions of the VALU form.
+template <int K0, int NU, int NB>   // the lane's unit slots K0 .. K0 + NU - 1 of the layer slot; NB blocks per row
+__device__ __forceinline__ void pd_units(const uint4 (&lo_)[PD_UNITS], const uint4 (&hi_)[PD_UNITS], const unsigned (&sc)[(PD_UNITS + 1) / 2], const uint4 *img,
+                                         const float *scl, int total, float *part, int tid) {
+    constexpr int NBP = NB | 1;
+    const uint4 *lo = lo_ + K0, *hi = hi_ + K0;
+    asm volatile("" : "+v"(tid));        // (addresses are derived per phase, not shared across phases and kept live)
+    // the digit rows and the scale of unit k + 1 are requested before unit k's products: one LDS latency per phase, not per unit
+    uint4 a0n, a1n;
+    float sbn;
+    {
+        const unsigned G = (unsigned)tid >> 2, rgp = G / (unsigned)NB, blk = G - rgp * (unsigned)NB;
+        const uint4 *ap = img + blk * 8u + ((unsigned)tid & 3u) * 2u;
+        a0n = ap[0]; a1n = ap[1]; sbn = scl[blk];
+    }
+#pragma unroll
+    for (int k = 0; k < NU; k++) {
+        if (k * PD_THREADS < total) {
+            const unsigned u = (unsigned)(k * PD_THREADS + tid), G = u >> 2;
+            const unsigned rgp = G / (unsigned)NB, blk = G - rgp * (unsigned)NB, row = rgp * 4u + (u & 3u);
+            const uint4 a0 = a0n, a1 = a1n;
+            const float sb = sbn;
+            if (k + 1 < NU && (k + 1) * PD_THREADS < total) {
+                const unsigned Gn = (u + PD_THREADS) >> 2, rn = Gn / (unsigned)NB, bn = Gn - rn * (unsigned)NB;
+                const uint4 *ap = img + bn * 8u + (u & 3u) * 2u;
+                a0n = ap[0]; a1n = ap[1]; sbn = scl[bn];
+            }
+            pd_i32x4 acc = {0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.x, (int)lo[k].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.y, (int)lo[k].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.z, (int)lo[k].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.w, (int)lo[k].w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.x, (int)hi[k].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.y, (int)hi[k].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.z, (int)hi[k].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.w, (int)hi[k].w, acc, 0, 0, 0);
+            const float f = fmaf(fmaf(fmaf((float)acc[3], 256.f, (float)acc[2]), 256.f, (float)acc[1]), 256.f, (float)acc[0]);
+            const float d = h2f_bits((sc[(K0 + k) >> 1] >> (16 * ((K0 + k) & 1))) & 0xffffu);
+            if ((int)u < total) part[row * (unsigned)NBP + blk] = f * (d * sb);
+            __builtin_amdgcn_sched_barrier(0);      // one unit's products at a time (its successor's operands already in flight)
+        }
+    }
+}
+
+// exp_f64_as_f32 (nl_kernels.h: float32(exp(float64(x))), go/quant.go:619, :629-631) with its thirteen coefficients made
+// opaque at the point of use: they are loop-invariant, and in this kernel -- 154 of 256 registers pinned under weights -- the
+// compiler hoisted them in front of the token loop, spilled them and fetched them back from scratch memory at every call site.
+// Here each one is two scalar moves next to its use.  Same operations in the same order: bit-identical results.
+__device__ __forceinline__ double pd_k(double c) { asm volatile("" : "+s"(c)); return c; }
+__device__ __forceinline__ float pd_exp(float xf) {
+    const double x = fmin(fmax((double)xf, -750.0), 710.0);
+    const double k = rint(x * pd_k(1.44269504088896338700e+00));
+    double r = fma(k, pd_k(-6.93147180369123816490e-01), x);
+    r = fma(k, pd_k(-1.90821492927058770002e-10), r);
+    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+    const double a0 = 1.0 + r;
+    const double a1 = fma(r, pd_k(1.0 / 6), 0.5), a2 = fma(r, pd_k(1.0 / 120), pd_k(1.0 / 24)), a3 = fma(r, pd_k(1.0 / 5040), pd_k(1.0 / 720));
+    const double a4 = fma(r, pd_k(1.0 / 362880), pd_k(1.0 / 40320)), a5 = fma(r, pd_k(1.0 / 39916800), pd_k(1.0 / 3628800));
+    const double a6 = fma(r, pd_k(1.0 / 6227020800.0), pd_k(1.0 / 479001600));
+    const double b0 = fma(a1, r2, a0), b1 = fma(a3, r2, a2), b2 = fma(a5, r2, a4);
+    const double d0 = fma(b1, r4, b0), d1 = fma(a6, r4, b2);
+    const double p = fma(d1, r8, d0);
+    const float res = (float)ldexp(p, (int)k);
+    return xf == xf ? res : xf;
+}
+
+// sum of squares of a width-D vector spread two elements per thread -> 1 / rms (go/quant.go:597-607: float64 sum); every
+// compute unit adds the same partials in the same order.  Contains a workgroup barrier.  1 / sqrt(m) = v_rsq_f64 + two Newton
+// steps (relative error < 1e-30 before the float32 rounding) instead of the IEEE divide and square root: sixty dependent
+// float64 instructions shorter.
+__device__ __forceinline__ float pd_inv_rms(float a, float b, bool v0, bool v1, int lane, int wave, double *dred, int D, float eps) {
+    double ss = 0.0;
+    if (v0) ss = fma((double)a, (double)a, ss);
+    if (v1) ss = fma((double)b, (double)b, ss);
+    ss = pd_wave_sum_f64(ss);
+    if (lane == 0) dred[wave] = ss;
+    __syncthreads();
+    double t[PD_WAVES];
+#pragma unroll
+    for (int w = 0; w < PD_WAVES; w++) t[w] = dred[w];
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < PD_WAVES; w++) tot += t[w];
+    const double m = tot / (double)D + (double)eps;          // (D is a compile-time constant at the call sites: a multiply)
+    double y = __builtin_amdgcn_rsq(m);
+    y = y * fma(-0.5 * m * y, y, 1.5);
+    y = y * fma(-0.5 * m * y, y, 1.5);
+    return (float)y;
+}
+
+// a row's block products part[0 .. N) added in block order; LANES lanes share a row (q = this lane's index among them, adjacent
+// lanes): each adds a contiguous run, the runs are joined in lane order.  All reads are issued before the first add.
+template <int N, int LANES>
+__device__ __forceinline__ float pd_rowsum(const float *p, int q) {
+    constexpr int PER = (N + LANES - 1) / LANES;
+    float v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) v[i] = p[min(q * PER + i, N - 1)];
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; i++) a += (q * PER + i < N) ? v[i] : 0.f;
+    if (LANES >= 2) { const float o = dpp_f32<DPP_QUAD_XOR1>(a); a = (q & 1) ? o + a : a + o; }
+    if (LANES == 4) { const float o = dpp_f32<DPP_QUAD_XOR2>(a); a = (q & 2) ? o + a : a + o; }
+    return a;
+}
+
+template <int NB, int NBI>   // D / 32, I / 32: one instantiation per shape class
+__global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4 *lmw = reinterpret_cast<uint4 *>(smem);                                          // [5][2][512]
+    unsigned short *lms = reinterpret_cast<unsigned short *>(lmw + PD_ULM * 2 * PD_THREADS);   // [5][512]
+    float *xraw = reinterpret_cast<float *>(lms + PD_ULM * PD_THREADS);                    // [640] the residual stream this phase adds to
+    unsigned char *xl = reinterpret_cast<unsigned char *>(xraw + 640);                     // [20][4][32] digit image of x * g (or of o)
+    unsigned char *hl = xl + 20 * 128;                                                     // [48][4][32] digit image of h
+    float *part = reinterpret_cast<float *>(hl + PD_NBI_MAX * 128);                        // [PD_PART]
+    float *rs = part + PD_PART;                                                            // [256]: gate | up row sums at 0 / 128
+    double *dred = reinterpret_cast<double *>(rs + 256);                                   // [16]
+    float *qs = reinterpret_cast<float *>(dred + 16);                                      // q | kcur | vcur [192]
+    float *kcur = qs + 64, *vcur = qs + 128;
+    float *on = qs + 192;                                                                  // [64]
+    float *wpart = on + 64;                                                                // [8][68]
+    float *chunk = wpart + 8 * 68;                                                         // [4][66]
+    float *bv = chunk + PD_MAX_PASSES * 66;                                                // [8]
+    int *bi = reinterpret_cast<int *>(bv + 8);                                             // [8]
+    int *misc = bi + 8;                                                                    // [0] ticket, [1] census ok, [2] dead, [3] token
+    float *xs = reinterpret_cast<float *>(misc + 8);                                       // [20] 1 / scale of every block of x
+    float *hs = xs + 20;                                                                   // [48] ... of h
+
+    const int tid0 = threadIdx.x;
+    constexpr int D = NB * 32, I = NBI * 32, H = D / 64, NWK = PD_CUS - H, NBP = NB | 1, NBIP = NBI | 1;
+    const int L = P0.L;
+    unsigned xcd;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcd));
+    xcd &= 7u;
+
+    // ---- census: which unit of which XCD am I (placement is observed, never assumed) ----
+    if (tid0 == 0) {
+        misc[2] = 0;
+        const unsigned t = atomicAdd(P0.census + xcd, 1u);
+        __threadfence();
+        atomicAdd(P0.census + 8, 1u);
+        int spins = 0;
+        while (__hip_atomic_load(P0.census + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)PD_GRID && ++spins < 2000000) __builtin_amdgcn_s_sleep(2);
+        bool ok = spins < 2000000 && gridDim.x == (unsigned)PD_GRID;
+        for (int x = 0; x < PD_XCDS; x++) ok = ok && __hip_atomic_load(P0.census + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)PD_CUS;
+        misc[0] = (int)t;
+        misc[1] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const int idx = misc[0];
+    if (!misc[1]) {
+        if (tid0 == 0) { atomicOr(P0.status, 64u); *P0.host_status = 64u; }
+        return;
+    }
+    const int cu = (int)xcd * PD_CUS + idx;
+    const int nslots = pd_nslots(L, (int)xcd), first = pd_first(L, (int)xcd);
+    const bool embed_xcd = first == 0 && nslots > 0;     // this XCD owns layer 0: it turns the argmax into the next x
+    const PdPoll Q{P0.status, P0.host_status, P0.spin_limit, misc + 2};
+#define PD_STAMP(i) do { if (P0.dbg && cu == 0 && tid0 == 0) P0.dbg[i] = wall_clock64(); } while (0)
+    PD_STAMP(0);
+
+    // ---- the weights of this unit's layers -> registers, its LM-head rows -> LDS (once per launch) ----
+    uint4 wlo[PD_SLOTS][PD_UNITS], whi[PD_SLOTS][PD_UNITS];
+    unsigned wsc[PD_SLOTS][(PD_UNITS + 1) / 2];
+#pragma unroll
+    for (int s = 0; s < PD_SLOTS; s++) {
+        const int ss = min(s, max(nslots - 1, 0));      // an XCD with one layer loads it twice: slot 1 is never used
+#pragma unroll
+        for (int k = 0; k < PD_UNITS; k++) {
+            const size_t base = ((size_t)cu * PD_SLOTS * PD_UNITS + ss * PD_UNITS + k);
+            wlo[s][k] = P0.wimg[(base * 2 + 0) * PD_THREADS + tid0];
+            whi[s][k] = P0.wimg[(base * 2 + 1) * PD_THREADS + tid0];
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < (PD_UNITS + 1) / 2; k2++) {
+            const size_t b0 = ((size_t)cu * PD_SLOTS * PD_UNITS + ss * PD_UNITS + 2 * k2);
+            const unsigned a = P0.simg[b0 * PD_THREADS + tid0];
+            const unsigned b = 2 * k2 + 1 < PD_UNITS ? P0.simg[(b0 + 1) * PD_THREADS + tid0] : 0u;
+            wsc[s][k2] = a | (b << 16);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PD_ULM * 2; i++) lmw[i * PD_THREADS + tid0] = P0.lmimg[((size_t)cu * PD_ULM * 2 + i) * PD_THREADS + tid0];
+#pragma unroll
+    for (int k = 0; k < PD_ULM; k++) lms[k * PD_THREADS + tid0] = P0.lmsimg[((size_t)cu * PD_ULM + k) * PD_THREADS + tid0];
+    const int lm_rows = pd_lm_rows(P0.V), lm_r0 = cu * lm_rows, lm_n = max(0, min(lm_rows, P0.V - lm_r0));
+    __syncthreads();
+    PD_STAMP(1);
+
+    int token = P0.token0;
+    const int n_steps = P0.n_steps;
+    for (int step = 0; step <= n_steps; step++) {
+        // Values the whole step derives its addresses from are made opaque once per step: the loop would otherwise have every
+        // LDS / granule / cache address of every phase hoisted in front of it and kept live (hundreds of registers -- and 154
+        // of the 256 hold weights)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        // ... and the kernel arguments are read again through an opaque pointer where a step needs them, instead of all of them
+        // (and everything derived from them) sitting in scalar registers across the loop: the scalar file spilled 250 values
+        // into vector lanes
+        const __attribute__((address_space(4))) PdParams *pk = (const __attribute__((address_space(4))) PdParams *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(pk));
+        const __attribute__((address_space(4))) PdParams &P = *pk;
+        // ... and so are the weight registers, in place (no instruction): their int8 -> float conversions are loop-invariant and
+        // would otherwise be computed once in front of the loop -- 4608 floats per lane, spilled
+#pragma unroll
+        for (int s = 0; s < PD_SLOTS; s++) {
+#pragma unroll
+            for (int k = 0; k < PD_UNITS; k++) {
+                asm volatile("" : "+v"(wlo[s][k].x), "+v"(wlo[s][k].y), "+v"(wlo[s][k].z), "+v"(wlo[s][k].w));
+                asm volatile("" : "+v"(whi[s][k].x), "+v"(whi[s][k].y), "+v"(whi[s][k].z), "+v"(whi[s][k].w));
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < (PD_UNITS + 1) / 2; k2++) asm volatile("" : "+v"(wsc[s][k2]));
+        }
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const int e0 = tid, e1 = tid + PD_THREADS;
+        const bool v0 = e0 < D, v1 = e1 < D;
+        const int c0 = v0 ? e0 : 0, c1 = v1 ? e1 : 0;
+        const int pos = P.pos0 + step;
+        // developer stamps (tools/persist_stamps.py): step 2 on XCD 1 -- unit 0 (a head of slot 0), unit H (a worker of slot 0)
+#define PD_ST(base, i) do { if (step == 2 && xcd == 1u && tid == 0 && P.dbg) P.dbg[(base) + (i)] = wall_clock64(); } while (0)
+        const unsigned tag = P.tag_base + (unsigned)step + 1u;
+        float xa = 0.f, xb = 0.f;       // this thread's two elements of the residual stream entering the next layer
+        if (embed_xcd) {
+            if (step > 0) {
+                // ---- the 256 (max, index) pairs of the previous step -> token (go/main.go:400-408) ----
+                float best = -INFINITY;
+                int bidx = 0x7fffffff;
+                if (tid < PD_GRID) {
+                    const __amdgpu_buffer_rsrc_t r = pd_rsrc(P.gam, PD_GRID * 16u);
+                    pd_u32x4 g;
+                    for (int spins = 0;; spins++) {
+                        g = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 0, 16);
+                        if (__all(g.x == tag - 1u)) break;
+                        if (spins >= P.spin_limit || ((spins & 63) == 63 && __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            pd_give_up(Q, 128u, tid);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    best = __uint_as_float(g.y); bidx = (int)g.z;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const float ov = __shfl_xor(best, o);
+                        const int oi = __shfl_xor(bidx, o);
+                        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+                    }
+                    if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
+                }
+                __syncthreads();
+                if (misc[2]) return;
+                best = bv[0]; bidx = bi[0];
+#pragma unroll
+                for (int w = 1; w < PD_GRID / 64; w++)
+                    if (bv[w] > best || (bv[w] == best && bi[w] < bidx)) { best = bv[w]; bidx = bi[w]; }
+                token = bidx == 0x7fffffff ? 0 : bidx;      // all-NaN logits: the reference's loop never leaves index 0
+                if (idx == 0 && tid == 0) { P.ids_out[step - 1] = token; if (step == P.n_steps) P.census[9] = (unsigned)token; }
+                __syncthreads();                              // bv / bi are reused by the LM head
+            }
+            if (step == P.n_steps) break;
+            // ---- embedding row (go/model.go:389-446) ----
+            xa = embed_value(P.embd_raw, WT_Q8_0, D, token, c0);
+            xb = embed_value(P.embd_raw, WT_Q8_0, D, token, c1);
+        } else if (step == P.n_steps) break;
+
+        // =================================== this XCD's layers ===================================
+#pragma unroll
+        for (int s = 0; s < PD_SLOTS; s++) {
+            if (s >= nslots) break;
+            const int layer = first + s;
+            const bool head = pd_is_head(s, idx, H);
+            const bool next_here = s + 1 < nslots;           // the next layer lives on this XCD
+            const int sb = s == 0 ? (head ? 8 : 24) : 63;     // stamp base (slot 0 only)
+            if (s == 0 && (idx == 0 || idx == H)) PD_ST(sb, 0);
+            // heads: the first 128 cache rows of the head are requested before anything is waited for (rows >= pos repeat row
+            // pos - 1 .. the row of this position comes from LDS)
+            const int hidx = pd_head_index(s, idx, H);
+            float *const kc = P.kcache + (long long)layer * P.kv_layer_stride + (long long)(head ? hidx : 0) * P.seq_len * 64;
+            float *const vc = P.vcache + (long long)layer * P.kv_layer_stride + (long long)(head ? hidx : 0) * P.seq_len * 64;
+            const __amdgpu_buffer_rsrc_t kr_ = pd_rsrc(kc, (unsigned)P.seq_len * 256u), vr_ = pd_rsrc(vc, (unsigned)P.seq_len * 256u);
+            const int kr = lane >> 2, kq = lane & 3, vg = lane >> 4, vcl = lane & 15;
+            float4 kreg[4], vreg[4];
+            float ecos = 0.f, esin = 0.f;
+            // (norm weights are requested before the polls they would otherwise wait behind)
+            const float ga0 = P.norms[(size_t)(layer * 2) * D + c0], ga1 = P.norms[(size_t)(layer * 2) * D + c1];
+            if (head && tid < 128) { ecos = P.rope_cos[pos * 32 + (tid & 31)]; esin = P.rope_sin[pos * 32 + (tid & 31)]; }
+            // ---- x of this layer: every unit of the XCD needs it (heads: the projection input; workers: the residual) ----
+            if (layer > 0) {
+                float xv[2];
+                pd_gather<2>(P.gx + (size_t)layer * D, D, tag, xv, Q, 1u, tid);
+                xa = xv[0]; xb = xv[1];
+            }
+            if (s == 0 && (idx == 0 || idx == H)) PD_ST(sb, 1);
+            if (v0) xraw[e0] = xa;
+            if (v1) xraw[e1] = xb;
+            if (head) {
+                pd_limbs(xa * ga0, v0, e0, xl, xs, lane);
+                if (wave * 64 + PD_THREADS < D) pd_limbs(xb * ga1, v1, e1, xl, xs, lane);      // (wave-uniform: the wavefronts that hold second elements)
+                const float inv = pd_inv_rms(xa, xb, v0, v1, lane, wave, dred, D, P.eps);            // (its barrier also publishes xT)
+                if (misc[2]) return;
+                // ---- Q | K | V rows of this head (go/model.go:517-523) ----
+                if (s == 0 && idx == 0) PD_ST(sb, 2);
+                pd_units<0, PD_UQ, NB>(wlo[s], whi[s], wsc[s], reinterpret_cast<const uint4 *>(xl), xs, 192 * NB, part, tid);
+                if (s == 0 && idx == 0) PD_ST(sb, 3);
+                {   // the first 128 cache rows of the head are requested behind the dot products (rows >= pos repeat row pos,
+                    // the row of this position comes from LDS): they arrive during the row sums and the rotation
+                    const int lim = min(min(128, P.seq_len), pos + 1);
+                    const unsigned krow = (unsigned)min(wave * 16 + kr, lim - 1) * 16u + (unsigned)kq * 4u;
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        kreg[kk] = pd_ld16f(kr_, (krow + kk) * 16u);
+                        vreg[kk] = pd_ld16f(vr_, (unsigned)(min(wave * 16 + 4 * vg + kk, lim - 1) * 16 + vcl) * 16u);
+                    }
+                }
+                __syncthreads();
+                if (tid < 384) {       // two lanes per row
+                    const float v = pd_rowsum<NB, 2>(part + (tid >> 1) * NBP, tid & 1) * inv;
+                    if (!(tid & 1)) rs[tid >> 1] = v;
+                }
+                __syncthreads();
+                // RoPE on q and k (go/model.go:449-477: pairs (i, i + 32)), v as it is; KV store (go/model.go:552-554)
+                if (tid < 128) {
+                    const int sect = tid >> 6, i = tid & 31, up = (tid >> 5) & 1;
+                    const float x0 = rs[sect * 64 + i], x1 = rs[sect * 64 + i + 32];
+                    float o;
+                    if (!P.rope_conj) o = up ? (x0 * esin + x1 * ecos) : (x0 * ecos - x1 * esin);
+                    else o = up ? (-x0 * esin + x1 * ecos) : (x0 * ecos + x1 * esin);
+                    qs[tid] = o;
+                    if (sect == 1) kc[(long long)pos * 64 + (tid & 63)] = o;
+                } else if (tid < 192) {
+                    const float v = rs[tid];
+                    qs[tid] = v;
+                    vc[(long long)pos * 64 + (tid & 63)] = v;
+                }
+                __syncthreads();
+                // ---- softmax attention over positions 0 .. pos (go/model.go:557-587), 128 positions per pass: nl_block.h's
+                //      one-barrier pass (every wavefront reduces its 16 positions to one (max, sum, sum p v) partial) ----
+                if (s == 0 && idx == 0) PD_ST(sb, 4);
+                const int nch = pos / 128 + 1;
+                for (int ch = 0; ch < nch; ch++) {
+                    const int t0 = ch * 128, n = min(128, pos + 1 - t0);
+                    if (ch > 0) {       // (a later pass fetches its rows at its start: a prefetch a pass ahead costs 16 registers this kernel lacks)
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            kreg[kk] = pd_ld16f(kr_, (unsigned)((t0 + min(wave * 16 + kr, n - 1)) * 16 + kq * 4 + kk) * 16u);
+                            vreg[kk] = pd_ld16f(vr_, (unsigned)((t0 + min(wave * 16 + 4 * vg + kk, n - 1)) * 16 + vcl) * 16u);
+                        }
+                    }
+                    const int krow = wave * 16 + kr;
+                    const bool kcurrow = t0 + krow == pos;
+                    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        const float4 q4 = *reinterpret_cast<const float4 *>(qs + kq * 16 + kk * 4);
+                        const float4 kc4 = *reinterpret_cast<const float4 *>(kcur + kq * 16 + kk * 4);
+                        const float4 k4 = kcurrow ? kc4 : kreg[kk];
+                        d0 = fmaf(q4.x, k4.x, d0); d1 = fmaf(q4.y, k4.y, d1); d2 = fmaf(q4.z, k4.z, d2); d3 = fmaf(q4.w, k4.w, d3);
+                    }
+                    const float sv = krow < n ? quad_sum((d0 + d1) + (d2 + d3)) * P.scale : -INFINITY;
+                    const float mw = wave_max_f32(sv);
+                    const float p = krow < n ? pd_exp(sv - (mw == -INFINITY ? 0.f : mw)) : 0.f;
+                    const float lw = wave_sum_f32(kq == 0 ? p : 0.f);
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 vc4 = *reinterpret_cast<const float4 *>(vcur + vcl * 4);
+                    // the probabilities of this wavefront's 16 rows meet through LDS (one write, one 16-byte read: the lane's V rows
+                    // 4 vg .. 4 vg + 3 are consecutive; the LDS serves a wavefront's operations in order)
+                    if (kq == 0) wpart[wave * 68 + 48 + kr] = p;       // (columns 48 .. 63 of the wavefront's partial row: rewritten below)
+                    const float4 pw4 = *reinterpret_cast<const float4 *>(wpart + wave * 68 + 48 + 4 * vg);
+                    const float pw[4] = {pw4.x, pw4.y, pw4.z, pw4.w};
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        const bool vcurrow = t0 + wave * 16 + 4 * vg + kk == pos;
+                        const float4 v4 = vcurrow ? vc4 : vreg[kk];
+                        o.x = fmaf(pw[kk], v4.x, o.x); o.y = fmaf(pw[kk], v4.y, o.y); o.z = fmaf(pw[kk], v4.z, o.z); o.w = fmaf(pw[kk], v4.w, o.w);
+                    }
+                    o.x = pd_rows4_sum(o.x); o.y = pd_rows4_sum(o.y); o.z = pd_rows4_sum(o.z); o.w = pd_rows4_sum(o.w);
+                    if (lane < 16) *reinterpret_cast<float4 *>(wpart + wave * 68 + 4 + vcl * 4) = o;
+                    if (lane == 0) { wpart[wave * 68] = mw; wpart[wave * 68 + 1] = lw; }
+                    __syncthreads();
+                    if (wave == 0) {
+                        const float mwv = lane < 8 ? wpart[min(lane, 7) * 68] : -INFINITY;
+                        const float M = wave_max_f32(mwv);
+                        const float wgt = (lane < 8 && mwv != -INFINITY) ? __expf(mwv - M) : 0.f;
+                        const float Ls = wave_sum_f32(lane < 8 ? wgt * wpart[min(lane, 7) * 68 + 1] : 0.f);
+                        float ov = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 8; w++) ov = fmaf(__shfl(wgt, w), wpart[w * 68 + 4 + lane], ov);
+                        chunk[ch * 66 + 2 + lane] = ov;
+                        if (lane == 0) { chunk[ch * 66] = M; chunk[ch * 66 + 1] = Ls; }
+                    }
+                    if (ch + 1 < nch) __syncthreads();
+                }
+                __syncthreads();
+                if (s == 0 && idx == 0) PD_ST(sb, 5);
+                if (tid < 64) {
+                    float ov;
+                    if (nch == 1) ov = chunk[2 + tid] * (1.0f / chunk[1]);
+                    else {
+                        float M = chunk[0];
+                        for (int c = 1; c < nch; c++) M = fmaxf(M, chunk[c * 66]);
+                        float v = 0.f, Ls = 0.f;
+                        for (int c = 0; c < nch; c++) {
+                            const float w = pd_exp(chunk[c * 66] - M);
+                            Ls += w * chunk[c * 66 + 1];
+                            v += w * chunk[c * 66 + 2 + tid];
+                        }
+                        ov = v * (1.0f / Ls);
+                    }
+                    pd_publish<false>(P.go + (size_t)layer * D + hidx * 64 + tid, tag, ov);      // -> the workers of this XCD
+                }
+                if (s == 0 && idx == 0) PD_ST(sb, 6);
+            } else {
+                // =============================== worker ===============================
+                const int w = pd_worker_index(s, idx, H);
+                const int r0 = pd_split(D, NWK, w), nr = pd_split(D, NWK, w + 1) - r0, nrp = pd_pad4(nr);
+                const int g0 = pd_split(I, NWK, w), rg = pd_split(I, NWK, w + 1) - g0, rgp = pd_pad4(rg);
+                // ---- o of every head -> LDS; WO rows + residual (go/model.go:590-594) ----
+                {
+                    float ov[2];
+                    pd_gather<2>(P.go + (size_t)layer * D, D, tag, ov, Q, 2u, tid);
+                    pd_limbs(ov[0], v0, e0, xl, xs, lane);
+                    if (wave * 64 + PD_THREADS < D) pd_limbs(ov[1], v1, e1, xl, xs, lane);
+                }
+                __syncthreads();
+                if (s == 0 && idx == H) PD_ST(sb, 2);
+                if (misc[2]) return;
+                pd_units<0, PD_UW, NB>(wlo[s], whi[s], wsc[s], reinterpret_cast<const uint4 *>(xl), xs, nrp * NB, part, tid);
+                __syncthreads();
+                if (s == 0 && idx == H) PD_ST(sb, 3);
+                if (tid < 4 * nr) {    // four lanes per row
+                    const float v = pd_rowsum<NB, 4>(part + (tid >> 2) * NBP, tid & 3);
+                    if (!(tid & 3)) pd_publish<false>(P.gxp + (size_t)layer * D + r0 + (tid >> 2), tag, xraw[r0 + (tid >> 2)] + v);
+                }
+                if (s == 0 && idx == H) PD_ST(sb, 4);
+                // ---- x' of every worker; RMSNorm; gate and up rows, SiLU(gate) * up (go/model.go:597-606) ----
+                const float gf0 = P.norms[(size_t)(layer * 2 + 1) * D + c0], gf1 = P.norms[(size_t)(layer * 2 + 1) * D + c1];
+                float xp[2];
+                pd_gather<2>(P.gxp + (size_t)layer * D, D, tag, xp, Q, 4u, tid);
+                if (s == 0 && idx == H) PD_ST(sb, 5);
+                __syncthreads();                               // (xraw / xT / part of the WO step are free)
+                if (v0) xraw[e0] = xp[0];
+                if (v1) xraw[e1] = xp[1];
+                pd_limbs(xp[0] * gf0, v0, e0, xl, xs, lane);
+                if (wave * 64 + PD_THREADS < D) pd_limbs(xp[1] * gf1, v1, e1, xl, xs, lane);
+                const float inv2 = pd_inv_rms(xp[0], xp[1], v0, v1, lane, wave, dred, D, P.eps);
+                if (misc[2]) return;
+                if (s == 0 && idx == H) PD_ST(sb, 6);
+                pd_units<PD_UW, PD_UG, NB>(wlo[s], whi[s], wsc[s], reinterpret_cast<const uint4 *>(xl), xs, 2 * rgp * NB, part, tid);
+                __syncthreads();
+                if (s == 0 && idx == H) PD_ST(sb, 7);
+                if (((tid & 255) >> 1) < rg) {      // gate rows: threads 0 .., up rows: threads 256 ..; two lanes per row
+                    const int mat = tid >> 8, row = (tid & 255) >> 1;
+                    const float v = pd_rowsum<NB, 2>(part + (mat * rgp + row) * NBP, tid & 1) * inv2;
+                    if (!(tid & 1)) rs[mat * 128 + row] = v;
+                }
+                __syncthreads();
+                if (tid < rg) {
+                    const float g = rs[tid], u = rs[128 + tid];
+                    const float ex = pd_exp(-g);
+                    pd_publish<false>(P.gh + (size_t)layer * I + g0 + tid, tag, (g / (1.0f + ex)) * u);
+                }
+                if (s == 0 && idx == H) PD_ST(sb, 8);
+                // ---- h of every worker -> LDS; down rows + residual (go/model.go:609-612) ----
+                {
+                    float hv[3];
+                    pd_gather<3>(P.gh + (size_t)layer * I, I, tag, hv, Q, 8u, tid);
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                        if (wave * 64 + k * PD_THREADS < I) pd_limbs(hv[k], tid + k * PD_THREADS < I, tid + k * PD_THREADS, hl, hs, lane);
+                }
+                __syncthreads();
+                if (s == 0 && idx == H) PD_ST(sb, 9);
+                if (misc[2]) return;
+                pd_units<PD_UW + PD_UG, PD_UD, NBI>(wlo[s], whi[s], wsc[s], reinterpret_cast<const uint4 *>(hl), hs, nrp * NBI, part, tid);
+                __syncthreads();
+                if (s == 0 && idx == H) PD_ST(sb, 10);
+                if (tid < 4 * nr) {      // four lanes per row, a quarter of the blocks each, joined in lane order
+                    const int row = tid >> 2, q = tid & 3;
+                    const float tot = pd_rowsum<NBI, 4>(part + row * NBIP, q);
+                    if (q == 0) {
+                        const float xo = xraw[r0 + row] + tot;
+                        pd_u64 *dst = P.gx + (size_t)(layer + 1) * D + r0 + row;
+                        if (next_here) pd_publish<false>(dst, tag, xo); else pd_publish<true>(dst, tag, xo);
+                    }
+                }
+            }
+            if (s == 0 && idx == H) PD_ST(sb, 11);
+            __syncthreads();     // LDS of this slot is free for the next one
+        }
+
+        // =================================== LM head (go/model.go:616-619), every compute unit ===================================
+        {
+            if (idx == 0) PD_ST(40, 0);
+            const float go0 = P.norms[(size_t)(L * 2) * D + c0], go1 = P.norms[(size_t)(L * 2) * D + c1];
+            float xv[2];
+            pd_gather<2>(P.gx + (size_t)L * D, D, tag, xv, Q, 16u, tid);
+            if (idx == 0) PD_ST(40, 1);
+            pd_limbs(xv[0] * go0, v0, e0, xl, xs, lane);
+            if (wave * 64 + PD_THREADS < D) pd_limbs(xv[1] * go1, v1, e1, xl, xs, lane);
+            const float inv = pd_inv_rms(xv[0], xv[1], v0, v1, lane, wave, dred, D, P.eps);
+            if (misc[2]) return;
+            const int total = pd_pad4(lm_rows) * NB;
+            {
+                int tl = tid;
+                asm volatile("" : "+v"(tl));
+#pragma unroll
+                for (int k = 0; k < PD_ULM; k++) {
+                    if (k * PD_THREADS < total) {
+                        const unsigned u = (unsigned)(k * PD_THREADS + tl), G = u >> 2;
+                        const unsigned rgp_ = G / (unsigned)NB, blk = G - rgp_ * (unsigned)NB, row = rgp_ * 4u + (u & 3u);
+                        const uint4 *ap = reinterpret_cast<const uint4 *>(xl) + blk * 8u + (u & 3u) * 2u;
+                        const uint4 a0 = ap[0], a1 = ap[1];
+                        const uint4 lo = lmw[(k * 2 + 0) * PD_THREADS + tl], hi = lmw[(k * 2 + 1) * PD_THREADS + tl];
+                        const float sb = xs[blk];
+                        pd_i32x4 acc = {0, 0, 0, 0};
+                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.x, (int)lo.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.y, (int)lo.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.z, (int)lo.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.w, (int)lo.w, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.x, (int)hi.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.y, (int)hi.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.z, (int)hi.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.w, (int)hi.w, acc, 0, 0, 0);
+                        const float f = fmaf(fmaf(fmaf((float)acc[3], 256.f, (float)acc[2]), 256.f, (float)acc[1]), 256.f, (float)acc[0]);
+                        if ((int)u < total) part[row * (unsigned)NBP + blk] = f * (h2f_bits(lms[k * PD_THREADS + tl]) * sb);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            __syncthreads();
+            if (idx == 0) PD_ST(40, 2);
+            float best = -INFINITY;
+            int bidx = 0x7fffffff;
+            if (tid < 256) {       // two lanes per row (both hold the row's logit)
+                const int row = tid >> 1;
+                const float lg = pd_rowsum<NB, 2>(part + min(row, 127) * NBP, tid & 1) * inv;
+                if (row < lm_n) {
+                    if (!(tid & 1)) P.logits[lm_r0 + row] = lg;
+                    if (lg > best) { best = lg; bidx = lm_r0 + row; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(best, o);
+                    const int oi = __shfl_xor(bidx, o);
+                    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+                }
+                if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                best = bv[0]; bidx = bi[0];
+#pragma unroll
+                for (int w = 1; w < 4; w++)
+                    if (bv[w] > best || (bv[w] == best && bi[w] < bidx)) { best = bv[w]; bidx = bi[w]; }
+                const pd_u32x4 g = {tag, __float_as_uint(best), (unsigned)bidx, 0u};
+                __builtin_amdgcn_raw_buffer_store_b128(g, pd_rsrc(P.gam, PD_GRID * 16u), cu * 16, 0, 16);     // write-through: layer 0's XCD reads it
+            }
+            __syncthreads();
+        }
+        if (idx == 0) PD_ST(40, 3);
+        if (step == 0) PD_STAMP(2);
+    }
+    if (P0.dbg && cu == 0 && tid0 == 0) P0.dbg[3] = wall_clock64();
+#undef PD_STAMP
+#undef PD_ST
+}
+
+}  // namespace nl

@@ -167,6 +167,13 @@ class LlamaModel:
         _lib.check(self._h, _lib.lib().nl_plan_info(self._h, *[C.byref(x) for x in v]))
         return {"fused_mode": v[0].value, "fused_max_pos": v[1].value, "launches_fused": v[2].value, "launches_general": v[3].value}
 
+    def persist_info(self):
+        """nl_persist_info: is the one-launch-per-chunk persistent decode (nl_persist.h) serving greedy chains of this handle."""
+        ready, max_pos = C.c_int(0), C.c_int(0)
+        launches, tokens = C.c_longlong(0), C.c_longlong(0)
+        _lib.check(self._h, _lib.lib().nl_persist_info(self._h, C.byref(ready), C.byref(max_pos), C.byref(launches), C.byref(tokens)))
+        return {"ready": bool(ready.value), "max_pos": max_pos.value, "launches": launches.value, "tokens": tokens.value}
+
     def last_error(self) -> str:
         """nl_last_error: the message of the last failed call -- or the one-time note of a call that succeeded after
         retiring the fused launch plan (a cluster exchange timed out and the step was redone on the general plan)."""

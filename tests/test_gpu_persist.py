@@ -1,0 +1,177 @@
+"""GPU tests of the weight-stationary persistent greedy decode (nanollama_amd/csrc/nl_persist.h): one launch decodes a chunk of
+tokens with every layer resident on one XCD.  Reference lines: go/main.go:173-219 (the greedy loop), go/model.go:490-620
+(Forward), go/main.go:400-408 (argmax).  The oracle's ids must be reproduced one for one and its logits within the engine's
+stated tolerance; the launch plans of the same handle (NL_PERSIST=0) are the second witness."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from nanollama_amd import gguf, synth
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from nanollama_amd import _lib, model
+    if _lib.lib().nl_device_count() < 1:
+        pytest.fail("no HIP device visible: the GPU tests must run on the MI355X box")
+    return model
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _oracle_run(orc, g, prompt, n):
+    """teacher-forced prompt, then n greedy steps: ids and the logits of every decode step"""
+    ref = orc.OracleModel(g)
+    orc.set_threads(min(16, os.cpu_count() or 1))
+    lg = None
+    for pos, t in enumerate(prompt):
+        lg = ref.forward(t, pos)
+    ids, logits = [], []
+    tok = int(orc.argmax(lg))
+    first = tok
+    for i in range(n):
+        lg = ref.forward(tok, len(prompt) + i)
+        logits.append(lg.copy())
+        tok = int(orc.argmax(lg))
+        ids.append(tok)
+    orc.set_threads(1)
+    ref.close()
+    return first, ids, logits
+
+
+@pytest.mark.parametrize("layers", [5, 13, 16, 1])
+def test_persistent_decode_matches_oracle_small_shape(hip, orc, tmp_path, monkeypatch, layers):
+    # D 256 / 4 heads / I 512: the small instantiation.  5 layers: XCDs 0-4 hold one layer, 5-7 only LM-head rows; 13: nano's
+    # split (two layers on XCDs 0-4); 16: two everywhere; 1: a single layer.  The handle's launch plans are the second witness.
+    shape = synth.ModelShape(f"pd_small_{layers}", layers, 256, 4, 4, 2048, seq_len=256, interm=512)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 101 + layers)
+    g = gguf.load_gguf(str(p))
+    prompt = synth.prompt_ids(9, shape.vocab, seed=3)
+    first, want, want_logits = _oracle_run(orc, g, prompt, 60)
+    dev = hip.load_llama_model(g)
+    info = dev.persist_info()
+    assert info["ready"] and info["max_pos"] == 256, info
+    dev.prefill(prompt)
+    assert int(np.argmax(dev.state.logits)) == first
+    got = dev.decode_greedy(first, len(prompt), 60)
+    assert dev.last_error() == "", dev.last_error()
+    info = dev.persist_info()
+    assert info["ready"] and info["launches"] == 1 and info["tokens"] == 60, info
+    assert got == want, (got[:12], want[:12])
+    lg = dev.debug_read("logits", shape.vocab)
+    d = float(np.abs(lg - want_logits[-1]).max()) / max(1.0, float(want_logits[-1].std()))
+    print(f"\npersistent decode, {layers} layers: 60 ids equal; last-step max|gpu-oracle| = {d:.2e}")
+    assert d <= LOGIT_TOL
+    # the K / V rows it wrote serve the launch plans: continue per call from where it stopped, same ids as the oracle's next ones
+    monkeypatch.setenv("NL_PERSIST", "0")
+    plain = hip.load_llama_model(g)
+    assert not plain.persist_info()["ready"]
+    plain.prefill(prompt)
+    assert plain.decode_greedy(first, len(prompt), 60) == want
+    for which in ("k_cache", "v_cache"):
+        n = shape.n_layer * shape.n_kv_head * shape.seq_len * 64
+        a = dev.debug_read(which, n).reshape(-1, shape.seq_len, 64)[:, :69]
+        b = plain.debug_read(which, n).reshape(-1, shape.seq_len, 64)[:, :69]
+        assert np.abs(a - b).max() <= 2e-5, which
+    # replay from a reset: bit-identical ids and logits (fixed summation orders)
+    dev.reset()
+    dev.prefill(prompt)
+    assert dev.decode_greedy(first, len(prompt), 60) == got
+    assert dev.debug_read("logits", shape.vocab).tobytes() == lg.tobytes()
+    dev.close(); plain.close()
+
+
+def test_persistent_decode_per_step_logits_and_chunking(hip, orc, tmp_path):
+    # one-token chunks (every step's logits against the oracle's), then ragged chunks: the same ids whatever the chunking
+    shape = synth.ModelShape("pd_steps", 13, 256, 4, 4, 1024, seq_len=192, interm=512)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 131)
+    g = gguf.load_gguf(str(p))
+    prompt = synth.prompt_ids(5, shape.vocab, seed=9)
+    first, want, want_logits = _oracle_run(orc, g, prompt, 150)          # positions 5 .. 154: a second attention pass from 128 on
+    dev = hip.load_llama_model(g)
+    assert dev.persist_info()["ready"]
+    dev.prefill(prompt)
+    tok, worst = first, 0.0
+    for i in range(150):
+        (tok,) = dev.decode_greedy(tok, len(prompt) + i, 1)
+        assert tok == want[i], i
+        lg = dev.debug_read("logits", shape.vocab)
+        worst = max(worst, float(np.abs(lg - want_logits[i]).max()) / max(1.0, float(want_logits[i].std())))
+    print(f"\npersistent decode, per-step logits over 150 positions: max|gpu-oracle| = {worst:.2e}")
+    assert worst <= LOGIT_TOL
+    dev.reset()
+    dev.prefill(prompt)
+    got, tok, pos = [], first, len(prompt)
+    for n in (1, 2, 7, 16, 33, 64, 27):
+        ids = dev.decode_greedy(tok, pos, n)
+        got += ids; tok = ids[-1]; pos += n
+    assert got == want
+    assert dev.last_error() == "" and dev.persist_info()["launches"] == 157
+    dev.close()
+
+
+def test_persistent_decode_hands_over_to_the_launch_plans_at_its_position_limit(hip, orc, tmp_path, monkeypatch):
+    # a chunk that crosses the limit: the tokens below it in one persistent launch, the rest on the launch plans, one call
+    shape = synth.ModelShape("pd_limit", 13, 256, 4, 4, 1024, seq_len=160, interm=512)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 137)
+    g = gguf.load_gguf(str(p))
+    prompt = synth.prompt_ids(8, shape.vocab, seed=11)
+    first, want, _ = _oracle_run(orc, g, prompt, 100)
+    monkeypatch.setenv("NL_PERSIST_MAX_POS", "48")
+    dev = hip.load_llama_model(g)
+    assert dev.persist_info() == {"ready": True, "max_pos": 48, "launches": 0, "tokens": 0}
+    dev.prefill(prompt)
+    assert dev.decode_greedy(first, len(prompt), 100) == want
+    info = dev.persist_info()
+    assert info["launches"] == 1 and info["tokens"] == 40, info
+    assert dev.last_error() == ""
+    dev.close()
+
+
+def test_persistent_decode_give_up_falls_back_to_the_launch_plans(hip, orc, tmp_path, monkeypatch):
+    # every hand-off poll gives up at once (spin limit 0): the call still returns the oracle's ids -- redone on the launch plans --
+    # with a note in nl_last_error, and the handle keeps the plans from then on
+    shape = synth.ModelShape("pd_fallback", 13, 256, 4, 4, 1024, seq_len=96, interm=512)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 139)
+    g = gguf.load_gguf(str(p))
+    prompt = synth.prompt_ids(6, shape.vocab, seed=13)
+    first, want, _ = _oracle_run(orc, g, prompt, 40)
+    monkeypatch.setenv("NL_PERSIST_SPIN_LIMIT", "0")
+    monkeypatch.setenv("NL_QUIET", "1")
+    dev = hip.load_llama_model(g)
+    assert dev.persist_info()["ready"]
+    dev.prefill(prompt)
+    assert dev.decode_greedy(first, len(prompt), 20) == want[:20]
+    assert "persistent decode launch gave up" in dev.last_error()
+    assert not dev.persist_info()["ready"]
+    assert dev.decode_greedy(want[19], len(prompt) + 20, 20) == want[20:]
+    dev.close()
+
+
+def test_shapes_outside_the_instantiations_keep_the_launch_plans(hip, tmp_path):
+    # GQA, other widths, other weight types: not candidates (the launch plans serve them as before)
+    for shape, wt in ((synth.ModelShape("pd_gqa", 2, 256, 4, 2, 512, seq_len=64, interm=512), "q8_0"),
+                      (synth.ModelShape("pd_q4", 2, 256, 4, 4, 512, seq_len=64, interm=512), "q4_0"),
+                      (synth.ModelShape("pd_wide", 2, 512, 8, 8, 512, seq_len=64, interm=1024), "q8_0")):
+        p = tmp_path / f"{shape.name}.gguf"
+        synth.generate_gguf(str(p), shape, wt, 141)
+        dev = hip.load_llama_model(gguf.load_gguf(str(p)))
+        assert not dev.persist_info()["ready"], shape.name
+        assert len(dev.decode_greedy(3, 0, 8)) == 8
+        dev.close()

@@ -2,6 +2,9 @@
 # round 5: measurements behind profiles/r05_*, by target (gpurun -- 'bash tools/collect_r05.sh <target>...').
 #   xcd      tools/xcd_exchange_probe.hip: same-XCD hand-offs through the XCD's own L2 against the cross-XCD granule forms
 #   tests    the whole -m gpu suite
+#   persist  tests/test_gpu_persist.py (the persistent decode of nl_persist.h)
+#   newtests the round's new parity tests of the wide tiers
+#   nano     nano bench one-liner
 #   bench    the driver's bench line (python bench.py --steps 20 --warmup 5)
 ulimit -c 0; export TMPDIR=/tmp NL_QUIET=1; cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 O=gpurun_out/r05; mkdir -p $O
@@ -16,6 +19,19 @@ tests)
 bench)
   (timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench_steps20.err | tail -1) > $O/r05_bench_n1_steps20.json.log
   cut -c1-700 $O/r05_bench_n1_steps20.json.log ;;
+persist)
+  (timeout 900 python -m pytest tests/test_gpu_persist.py -x -q -s 2>&1 | tail -40) > $O/pytest_persist.log; cat $O/pytest_persist.log ;;
+newtests)
+  (timeout 1500 python -m pytest tests/test_gpu_tp_fused.py -x -q -s -k "big_attention_geometry or keep_out_of" 2>&1 | tail -15) > $O/pytest_newtests.log; cat $O/pytest_newtests.log ;;
+m4)
+  $hip tools/mfma4_probe.hip -o /tmp/m4p 2>/dev/null && /tmp/m4p > $O/r05_mfma4_probe.log 2>&1; cat $O/r05_mfma4_probe.log ;;
+pstamps)
+  python3 tools/persist_stamps.py 64 8 > $O/r05_persist_stamps.log 2>&1; cat $O/r05_persist_stamps.log ;;
+nano)
+  for rep in 1 2; do timeout 250 python bench.py --workload nano:q8_0 --steps 64 --warmup 8 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('nano', d['value'],'tok/s', d['ms_per_step'],'ms')"; done ;;
 *) echo "unknown target $target" ;;
 esac
 done
