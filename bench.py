@@ -349,6 +349,32 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
         mean_pos = pos0 + (min(SEGMENT, steps) - 1) / 2.0
         step_bytes = (synth.weight_bytes_per_token(shape, wtype) + synth.kv_bytes_per_token(shape, int(mean_pos))) / (shard_of or 1)
         step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
+        # The smallest tier's greedy chain is ONE persistent launch per segment (nl_persist.h): that launch IS the timed region's
+        # dominant kernel.  Its duration is measured live with HIP events on the engine's stream around single launches of the
+        # timed segment; achieved = algorithmic bytes of the segment's tokens (weights + f32 KV read per token, each
+        # byte counted once per token although the weights stay on chip for the whole launch) / that duration.
+        pinfo = dev.persist_info() if world == 1 and not shard_of else {"ready": False}
+        persist_roof = None
+        if pinfo["ready"] and pos0 + min(SEGMENT, steps) <= pinfo["max_pos"]:
+            seg = min(SEGMENT, steps)
+            n0 = pinfo["launches"]
+            ts = []
+            for _ in range(7):
+                dev.synchronize()
+                dev.timer_start()
+                dev.decode_greedy(first, pos0, seg)
+                ts.append(dev.timer_stop())
+            ts.sort()
+            launch_ms = ts[len(ts) // 2]
+            assert dev.persist_info()["launches"] == n0 + 7, "the persistent launch was retired during the run: " + dev.last_error()
+            gbs = step_bytes * seg / (launch_ms * 1e-3) / 1e9
+            kernels["persistent_decode"] = {"launches": round(1.0 / seg, 5), "tokens_per_launch": seg, "us_per_launch": round(launch_ms * 1e3, 2),
+                                            "us_per_token": round(launch_ms * 1e3 / seg, 3), "GBps": round(gbs, 1)}
+            persist_roof = {"bound": "hbm", "kernel": "persistent_decode (pd_decode_kernel, nl_persist.h)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
+                            "bytes_per_launch": int(step_bytes * seg), "us_per_launch": round(launch_ms * 1e3, 2), "tokens_per_launch": seg,
+                            "launches_per_step": round(1.0 / seg, 5), "time_share_of_step": round(min(1.0, launch_ms / seg / ms_per_step), 3),
+                            "note": "one launch decodes the whole segment with the weights resident on chip; bytes are the algorithmic bytes of its tokens"}
         p2p = dev.p2p_info() if (world > 1 or shard_of) else None
         res = {
             "tier": tier, "wtype": wtype, "path": path, "prompt": prompt,
@@ -358,7 +384,9 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
             "step_bytes": int(step_bytes), "hbm_frac_whole_step": step_gbs / (HBM_PEAK_GBS * max(world, 1)),
             "kernels": kernels, "last_ids": ids[-4:], "head_ids": head_ids, "first_id": first, "prefill_logits": prefill_logits,
             "dropin": (dropin_rates(dev, first, pos0, 64 if tier != "big" else 32, head_ids) if dropin and world == 1 and not shard_of else None),
-            "roofline": roof(dom), "roofline_by_bytes": roof(dom_bytes),
+            "roofline": persist_roof or roof(dom), "roofline_by_bytes": roof(dom_bytes), "persist": pinfo,
+            "launch_plan_kernels_note": ("the per-kind entries beside persistent_decode are the launch plans this handle keeps for per-call Forward, "
+                                         "sampling and contexts beyond the persistent launch's position limit" if persist_roof else None),
             "segment": min(SEGMENT, steps), "pos_first": pos0, "pos_last": pos0 + min(SEGMENT, steps) - 1,
         }
     except BaseException:
@@ -572,6 +600,9 @@ def summary(r, keys=("kernels",)):
            "roofline_by_bytes": r["roofline_by_bytes"]}
     for k in keys:
         out[k] = r[k]
+    if r.get("persist", {}).get("ready"):
+        out["persistent_decode"] = r["persist"]      # nl_persist_info: the one-launch-per-chunk decode served the timed steps
+        out["launch_plan_kernels_note"] = r.get("launch_plan_kernels_note")
     return out
 
 

@@ -19,11 +19,23 @@ import "C"
 
 import (
 	"fmt"
+	"os"
 	"regexp"
+	"strconv"
 	"unsafe"
 )
 
 const hipEnabled = true
+
+// hipGPUs is how many GPUs of the node the model is sharded over: NANOLLAMA_GPUS=2|4|8 (default 1).  One process, one
+// LlamaModel, one mutex in go/serve.go -- the sharding is behind the handle (nl_create_group).
+func hipGPUs() int {
+	n, err := strconv.Atoi(os.Getenv("NANOLLAMA_GPUS"))
+	if err != nil || n < 1 {
+		return 1
+	}
+	return n
+}
 
 // hipBackend owns the device handle that replaces LlamaWeights and the KV cache of LlamaState.
 type hipBackend struct{ h C.nl_handle }
@@ -38,7 +50,9 @@ var hipTensor = regexp.MustCompile(`^(token_embd\.weight|output_norm\.weight|out
 // loadHIP is called from LoadLlamaModel (go/model.go:121) instead of loadWeights / allocState / precomputeRoPE.
 // Every tensor is handed over with its raw GGUF bytes; the library copies during the call (cgo pointer rule: no
 // Go pointer is retained), re-packs and keeps only what the device needs.
-func loadHIP(gguf *GGUFFile, cfg *LlamaConfig, device int) (*hipBackend, error) {
+// gpus > 1 shards the model tensor-parallel over devices device .. device+gpus-1 of this process (nl_create_group): the
+// handle behaves like a single-device one, so Forward / Reset / the decode fast paths below are unchanged.
+func loadHIP(gguf *GGUFFile, cfg *LlamaConfig, device int, gpus int) (*hipBackend, error) {
 	c := C.nl_config{
 		n_layers: C.int32_t(cfg.NumLayers), dim: C.int32_t(cfg.EmbedDim),
 		n_heads: C.int32_t(cfg.NumHeads), n_kv_heads: C.int32_t(cfg.NumKVHeads),
@@ -54,7 +68,15 @@ func loadHIP(gguf *GGUFFile, cfg *LlamaConfig, device int) (*hipBackend, error) 
 		c.rope_conjugate = 1
 	}
 	b := &hipBackend{}
-	if rc := C.nl_create(&c, &b.h); rc != 0 {
+	if gpus > 1 {
+		ids := make([]C.int, gpus)
+		for i := range ids {
+			ids[i] = C.int(device + i)
+		}
+		if rc := C.nl_create_group(&c, &ids[0], C.int(gpus), &b.h); rc != 0 {
+			return nil, hipErr(nil, rc, "nl_create_group")
+		}
+	} else if rc := C.nl_create(&c, &b.h); rc != 0 {
 		return nil, hipErr(nil, rc, "nl_create")
 	}
 	for name, info := range gguf.Tensors {

@@ -7,6 +7,9 @@ const hipEnabled = false
 
 type hipBackend struct{}
 
-func loadHIP(gguf *GGUFFile, cfg *LlamaConfig, device int) (*hipBackend, error) { return nil, nil }
+func hipGPUs() int                                                              { return 1 }
+func loadHIP(gguf *GGUFFile, cfg *LlamaConfig, device int, gpus int) (*hipBackend, error) {
+	return nil, nil
+}
 func (m *LlamaModel) forwardHIP(token, pos int)                                 {}
 func (m *LlamaModel) resetHIP()                                                 {}

@@ -7,6 +7,7 @@
 from __future__ import annotations
 
 import argparse
+import os
 import sys
 
 from .engine import GenParams
@@ -32,6 +33,9 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--port", type=int, default=8080, help="HTTP server port (used with --serve)")
     ap.add_argument("--list-tensors", action="store_true", help="List all tensors and exit")
     ap.add_argument("--device", type=int, default=0, help="HIP device ordinal")
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="shard the model tensor-parallel over this many GPUs of the node (2, 4 or 8: devices --device .. --device + N - 1; "
+                         "the 7.9B tier's configuration).  One process, one engine: --serve and --interactive work unchanged")
     ap.add_argument("--seed", type=int, default=None, help="sampling seed (default: entropy, like the reference)")
     return ap
 
@@ -54,7 +58,16 @@ def list_tensors(g) -> None:
 def load_engine(args) -> TextEngine:
     print(f"[nanollama] loading {args.model}")
     g = load_gguf(args.model, verbose=True)
-    model = load_llama_model(g, device=args.device, verbose=True)
+    if args.gpus > 1:
+        if args.gpus not in (2, 4, 8):
+            raise RuntimeError("--gpus must be 1, 2, 4 or 8")
+        devs = list(range(args.device, args.device + args.gpus))
+        if os.environ.get("NL_GROUP_ONE_DEVICE"):      # test pool: every rank on --device (what a one-GPU box can run)
+            devs = [args.device] * args.gpus
+        print(f"[nanollama] tensor-parallel over devices {devs} (push all-reduce between the ranks of this process)")
+        model = load_llama_model(g, devices=devs, verbose=True)
+    else:
+        model = load_llama_model(g, device=args.device, verbose=True)
     if args.gamma:
         from .gamma import load_gamma
         try:

@@ -8,6 +8,7 @@
 // go/main.go:400-408.  There is no CPU fallback in this library: without a
 // HIP device every entry point that computes returns NL_ERR_HIP.
 #include "../../include/nanollama_hip.h"
+#include <mutex>
 #include "nl_kernels.h"
 #include "nl_qgemm.h"
 #include "nl_qgemm2.h"
@@ -27,7 +28,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include <rocprim/device/device_radix_sort.hpp>   // the descending candidate order of sampleTopP / sampleTopK
 
@@ -38,6 +42,10 @@ using namespace nl;
 namespace {
 
 thread_local std::string g_create_error;
+// Allocation / graph-capture sections of different rank engines of ONE process (nl_create_group: a host thread per rank) must not
+// overlap: a synchronous legacy-stream call of one thread (hipMalloc, hipMemset) fails while another thread's capture is open.
+// Neither kind of section waits for a peer, so holding this across them cannot deadlock.
+std::mutex g_setup_mu;
 
 enum Kind { K_EMBED = 0, K_QKV, K_ATTN, K_WO, K_GATEUP, K_DOWN, K_LMHEAD, K_ARGMAX, K_ALLREDUCE, K_ATTNBLOCK, K_FFNBLOCK };
 const char *kKindNames[NL_NUM_KINDS] = {"embed", "qkv_rope", "attention", "wo_resid", "gate_up_swiglu",
@@ -299,6 +307,11 @@ struct nl_engine {
         long long *dbg = nullptr;
         long long launches = 0, tokens = 0;
     } pd;
+    // One-process tensor-parallel group (nl_create_group): THIS handle is the leader the caller holds -- it owns no device
+    // state -- and grp->members are the rank engines (one per device, tp_rank = index), wired through the push all-reduce
+    // with plain peer pointers.  Every entry point called on the leader runs the same entry point on every member, each
+    // on its own host thread (a rank's step cannot finish before its peers have launched theirs).
+    struct GroupCtl *grp = nullptr;
     int tw_override = 0, kw_override = 0;
     bool force_tp_plan = false;  // NL_FORCE_TP_PLAN: use the all-reduce / all-gather seams even with one rank
 
@@ -1839,6 +1852,75 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
 
 }  // namespace
 
+// ---- one-process tensor-parallel group (nl_create_group) ---------------------------------------------------------------------
+struct GroupCtl {
+    std::vector<nl_engine *> members;
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::function<int(nl_engine *, int)> job;
+    unsigned long long generation = 0;
+    int pending = 0;
+    bool quit = false;
+    std::vector<int> rc;
+};
+
+namespace {
+
+void group_worker(GroupCtl *g, int r) {
+    unsigned long long seen = 0;
+    for (;;) {
+        std::function<int(nl_engine *, int)> job;
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv_job.wait(lk, [&] { return g->quit || g->generation != seen; });
+            if (g->quit) return;
+            seen = g->generation;
+            job = g->job;
+        }
+        const int rc = job(g->members[r], r);
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->rc[r] = rc;
+            if (--g->pending == 0) g->cv_done.notify_all();
+        }
+    }
+}
+
+// run f(member, rank) on every rank's thread and wait for all; the first failing rank's code and message become the leader's
+int group_run(nl_engine *lead, std::function<int(nl_engine *, int)> f) {
+    GroupCtl *g = lead->grp;
+    {
+        std::unique_lock<std::mutex> lk(g->mu);
+        g->job = std::move(f);
+        g->pending = (int)g->members.size();
+        g->generation++;
+        g->cv_job.notify_all();
+        g->cv_done.wait(lk, [&] { return g->pending == 0; });
+    }
+    for (size_t r = 0; r < g->members.size(); r++)
+        if (g->rc[r] != NL_OK) {
+            lead->err = "rank " + std::to_string(r) + ": " + g->members[r]->err;
+            return g->rc[r];
+        }
+    // a warning a rank left while returning NL_OK (a retired fused plan) is the leader's note too
+    lead->err = g->members[0]->err;
+    return NL_OK;
+}
+
+void group_stop(GroupCtl *g) {
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->quit = true;
+        g->cv_job.notify_all();
+    }
+    for (auto &t : g->workers) if (t.joinable()) t.join();
+}
+
+int p2p_alloc_area(nl_engine *e);   // below (shared with nl_p2p_export)
+
+}  // namespace
+
 // ============================================================== C ABI =====
 
 extern "C" {
@@ -1942,6 +2024,64 @@ int nl_create(const nl_config *cfg, nl_handle *out) {
     return NL_OK;
 }
 
+// LoadLlamaModel for a model sharded over the GPUs of ONE process (go/main.go:63 is one process; BASELINE's 7.9B tier shards
+// across the node's 8 GPUs): the returned handle is used exactly like nl_create's -- nl_upload_tensor takes the FULL tensors
+// (every rank keeps its slice), nl_finalize, nl_forward, nl_decode_greedy, nl_sample_decode, nl_prefill, nl_reset,
+// nl_destroy ... -- and steps n rank engines (tp_rank r on device_ids[r]) behind it: row / column tensor parallelism with
+// the push all-reduce of nl_p2p.h between them, the receive areas reached through plain peer pointers
+// (hipDeviceEnablePeerAccess) instead of hipIpc handles.  device_ids may repeat (all ranks on one device: the one-GPU test
+// configuration, bitwise equal to the in-process shard group).
+int nl_create_group(const nl_config *cfg, const int *device_ids, int n, nl_handle *out) {
+    if (!cfg || !device_ids || !out) { g_create_error = "null argument"; return NL_ERR_INVALID; }
+    *out = nullptr;
+    if (n != 2 && n != 4 && n != 8) { g_create_error = "nl_create_group: 2, 4 or 8 ranks"; return NL_ERR_UNSUPPORTED; }
+    if (cfg->tp_size > 1 && cfg->tp_size != n) { g_create_error = "nl_create_group: tp_size disagrees with the device list"; return NL_ERR_INVALID; }
+    nl_engine *lead = new nl_engine();
+    GroupCtl *g = new GroupCtl();
+    lead->grp = g;
+    auto fail = [&](int rc, const std::string &msg) {
+        for (nl_engine *m : g->members) nl_destroy(m);
+        delete g;
+        delete lead;
+        g_create_error = msg;
+        return rc;
+    };
+    for (int r = 0; r < n; r++) {
+        nl_config c = *cfg;
+        c.tp_size = n; c.tp_rank = r; c.device = device_ids[r];
+        c.flags &= ~(NL_FLAG_LOCAL_GROUP | NL_FLAG_GROUP_FUSED);
+        nl_engine *m = nullptr;
+        const int rc = nl_create(&c, &m);
+        if (rc != NL_OK) return fail(rc, "rank " + std::to_string(r) + ": " + g_create_error);
+        g->members.push_back(m);
+    }
+    lead->cfg = g->members[0]->cfg;          // the effective configuration (seq_len cap, head_dim) as the caller sees it:
+    lead->cfg.tp_size = 1; lead->cfg.tp_rank = 0; lead->cfg.device = device_ids[0];   // ... one model
+    lead->dev = device_ids[0];
+    // peers: every rank's device may store into every other rank's receive area
+    for (int a = 0; a < n; a++)
+        for (int b = 0; b < n; b++) {
+            if (device_ids[a] == device_ids[b]) continue;
+            int can = 0;
+            if (hipSetDevice(device_ids[a]) != hipSuccess || hipDeviceCanAccessPeer(&can, device_ids[a], device_ids[b]) != hipSuccess || !can)
+                return fail(NL_ERR_UNSUPPORTED, "device " + std::to_string(device_ids[a]) + " cannot reach device " + std::to_string(device_ids[b]) + " (no peer access)");
+            const hipError_t s = hipDeviceEnablePeerAccess(device_ids[b], 0);
+            if (s != hipSuccess && s != hipErrorPeerAccessAlreadyEnabled) return fail(NL_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(s));
+            (void)hipGetLastError();
+        }
+    for (int r = 0; r < n; r++)
+        if (int rc = p2p_alloc_area(g->members[r])) return fail(rc, "rank " + std::to_string(r) + ": " + g->members[r]->err);
+    for (int r = 0; r < n; r++) {
+        nl_engine::P2P &p = g->members[r]->p2p;
+        for (int q = 0; q < n; q++) p.peer[q] = g->members[q]->p2p.area;       // plain peer pointers: one address space in one process
+        p.on = true;
+    }
+    g->rc.assign(n, NL_OK);
+    for (int r = 0; r < n; r++) g->workers.emplace_back(group_worker, g, r);
+    *out = lead;
+    return NL_OK;
+}
+
 int nl_get_config(nl_handle h, nl_config *out) {
     if (!h || !out) return NL_ERR_INVALID;
     *out = h->cfg;
@@ -1950,6 +2090,7 @@ int nl_get_config(nl_handle h, nl_config *out) {
 
 int nl_upload_tensor(nl_handle e, const char *name, uint32_t type, const void *data, uint64_t nbytes, uint64_t rows,
                      uint64_t cols) {
+    if (e && e->grp) return group_run(e, [&](nl_engine *m, int) { return nl_upload_tensor(m, name, type, data, nbytes, rows, cols); });
     if (!e || !name || !data) return NL_ERR_INVALID;
     if (e->finalized) return e->fail(NL_ERR_STATE, "upload after nl_finalize");
     const nl_config &c = e->cfg;
@@ -2130,6 +2271,16 @@ int nl_upload_tensor(nl_handle e, const char *name, uint32_t type, const void *d
 }
 
 int nl_finalize(nl_handle e) {
+    if (e && e->grp) {
+        if (e->finalized) return e->fail(NL_ERR_STATE, "nl_finalize called twice");
+        // one rank after the other (allocations and graph captures; nothing here waits for a peer)
+        for (size_t r = 0; r < e->grp->members.size(); r++) {
+            const int rc = nl_finalize(e->grp->members[r]);
+            if (rc != NL_OK) { e->err = "rank " + std::to_string(r) + ": " + e->grp->members[r]->err; return rc; }
+        }
+        e->finalized = true;
+        return NL_OK;
+    }
     if (!e) return NL_ERR_INVALID;
     if (e->finalized) return e->fail(NL_ERR_STATE, "nl_finalize called twice");
     const nl_config &c = e->cfg;
@@ -2405,6 +2556,7 @@ int nl_finalize(nl_handle e) {
 // Gamma essence (go/gamma.go): embed[token] += gamma[token] for the listed tokens (go/model.go:503-505).
 // indices: n token ids; values: [n][dim] float32, or raw IEEE binary16 when is_f16.  n == 0 clears it.
 int nl_set_gamma(nl_handle e, const int32_t *indices, int n, const void *values, int is_f16) {
+    if (e && e->grp) return group_run(e, [&](nl_engine *m, int) { return nl_set_gamma(m, indices, n, values, is_f16); });
     if (!e || n < 0 || (n > 0 && (!indices || !values))) return NL_ERR_INVALID;
     const nl_config &c = e->cfg;
     HIPCK(e, hipSetDevice(e->dev));
@@ -2454,6 +2606,14 @@ int nl_set_gamma(nl_handle e, const int32_t *indices, int n, const void *values,
 }
 
 int nl_destroy(nl_handle e) {
+    if (e && e->grp) {
+        GroupCtl *g = e->grp;
+        group_stop(g);
+        for (nl_engine *m : g->members) nl_destroy(m);
+        delete g;
+        delete e;
+        return NL_OK;
+    }
     if (!e) return NL_OK;
     hipSetDevice(e->dev);
     hipDeviceSynchronize();
@@ -2509,6 +2669,7 @@ int nl_destroy(nl_handle e) {
 }
 
 int nl_reset(nl_handle e, int stream) {
+    if (e && e->grp) return group_run(e, [&](nl_engine *m, int) { return nl_reset(m, stream); });
     if (!e) return NL_ERR_INVALID;
     if (!e->finalized) return e->fail(NL_ERR_STATE, "reset before nl_finalize");
     if (stream < 0 || stream >= e->cfg.max_streams) return e->fail(NL_ERR_INVALID, "stream %d out of range", stream);
@@ -2519,6 +2680,7 @@ int nl_reset(nl_handle e, int stream) {
 }
 
 int nl_forward(nl_handle e, int stream, int token, int pos, float *logits_out) {
+    if (e && e->grp) return group_run(e, [&](nl_engine *m, int r) { return nl_forward(m, stream, token, pos, r == 0 ? logits_out : nullptr); });
     if (!e) return NL_ERR_INVALID;
     int rc = check_step_args(e, stream, token, pos);
     if (rc) return rc;
@@ -2541,6 +2703,13 @@ int nl_forward(nl_handle e, int stream, int token, int pos, float *logits_out) {
 }
 
 int nl_forward_argmax(nl_handle e, int stream, int token, int pos, int *next_id) {
+    if (e && e->grp) {
+        if (!next_id) return NL_ERR_INVALID;
+        int ids[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int rc = group_run(e, [&](nl_engine *m, int r) { return nl_forward_argmax(m, stream, token, pos, &ids[r]); });
+        *next_id = ids[0];
+        return rc;
+    }
     if (!e || !next_id) return NL_ERR_INVALID;
     int rc = check_step_args(e, stream, token, pos);
     if (rc) return rc;
@@ -2561,6 +2730,14 @@ int nl_forward_argmax(nl_handle e, int stream, int token, int pos, int *next_id)
 }
 
 int nl_decode_greedy(nl_handle e, int stream, int token, int pos, int n_steps, int *ids_out, int *n_done) {
+    if (e && e->grp) {
+        if (!ids_out || n_steps < 0) return NL_ERR_INVALID;
+        std::vector<std::vector<int>> ids(e->grp->members.size(), std::vector<int>((size_t)std::max(n_steps, 1)));
+        int done[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int rc = group_run(e, [&](nl_engine *m, int r) { return nl_decode_greedy(m, stream, token, pos, n_steps, ids[r].data(), &done[r]); });
+        if (rc == NL_OK) { memcpy(ids_out, ids[0].data(), (size_t)done[0] * sizeof(int)); if (n_done) *n_done = done[0]; }
+        return rc;
+    }
     if (!e || !ids_out || n_steps < 0) return NL_ERR_INVALID;
     int rc = check_step_args(e, stream, token, pos);
     if (rc) return rc;
@@ -2681,6 +2858,22 @@ int check_sample_params(nl_engine *e, const nl_sample_params *p) {
 
 int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sample_params *p, const float *uniforms,
                      int *recent, int *n_recent, int *ids_out, int *n_done) {
+    if (e && e->grp) {
+        // every rank samples from the same gathered logits with the same uniforms: the same ids; rank 0's results are returned
+        if (!ids_out || !uniforms || !recent || !n_recent || !p || n_steps < 0) return NL_ERR_INVALID;
+        const size_t nr = e->grp->members.size(), cap = (size_t)std::max(p->rep_window, 1);
+        std::vector<std::vector<int>> ids(nr, std::vector<int>((size_t)std::max(n_steps, 1))), rec(nr, std::vector<int>(cap));
+        int nrec[8], done[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t r = 0; r < nr; r++) { nrec[r] = *n_recent; memcpy(rec[r].data(), recent, std::min((size_t)std::max(*n_recent, 0), cap) * sizeof(int)); }
+        const int rc = group_run(e, [&](nl_engine *m, int r) { return nl_sample_decode(m, stream, pos, n_steps, p, uniforms, rec[r].data(), &nrec[r], ids[r].data(), &done[r]); });
+        if (rc == NL_OK) {
+            memcpy(ids_out, ids[0].data(), (size_t)done[0] * sizeof(int));
+            memcpy(recent, rec[0].data(), (size_t)std::max(nrec[0], 0) * sizeof(int));
+            *n_recent = nrec[0];
+            if (n_done) *n_done = done[0];
+        }
+        return rc;
+    }
     if (!e || !ids_out || !uniforms || !recent || !n_recent || n_steps < 0) return NL_ERR_INVALID;
     int rc = check_sample_params(e, p);
     if (rc) return rc;
@@ -2694,6 +2887,7 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
     if (n_done) *n_done = std::max(n, 0);
     if (n <= 0) return NL_OK;
     if (!e->sp_ready || e->sp_uniforms_cap < n) {
+        std::lock_guard<std::mutex> setup(g_setup_mu);
         HIPCK(e, hipStreamSynchronize(e->stream));
         destroy_samp_graphs(e);   // they hold the old scratch pointers
         samp_free(e->sp);
@@ -2705,7 +2899,7 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
     const SampScratch &s = e->sp;
     const int n_recent_in = *n_recent;
     if (e->fused) {   // a redo after a fused-launch timeout restarts from the logits this call found (take_fused_timeout)
-        if (!e->samp_keep) HIPCK(e, dalloc(&e->samp_keep, (size_t)e->cfg.vocab, &e->bytes_state));
+        if (!e->samp_keep) { std::lock_guard<std::mutex> setup(g_setup_mu); HIPCK(e, dalloc(&e->samp_keep, (size_t)e->cfg.vocab, &e->bytes_state)); }
         HIPCK(e, hipMemcpyAsync(e->samp_keep, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToDevice, e->stream));
     }
     for (int attempt = 0;; attempt++) {
@@ -2723,6 +2917,7 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
             // parameters: re-captured when they change); the plan is chosen by the highest position of the 16 steps
             const int k = (e->fused && pos + i + e->graph_steps - 1 < e->fused_max_pos) ? 1 : 0;
             if (!e->samp_graph_exec[k] || memcmp(&e->samp_graph_params[k], p, sizeof(*p)) != 0) {
+                std::lock_guard<std::mutex> setup(g_setup_mu);
                 if (e->samp_graph_exec[k]) { hipGraphExecDestroy(e->samp_graph_exec[k]); e->samp_graph_exec[k] = nullptr; }
                 if (e->samp_graph[k]) { hipGraphDestroy(e->samp_graph[k]); e->samp_graph[k] = nullptr; }
                 hipError_t cs = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
@@ -2811,6 +3006,7 @@ int nl_op_sample(int device, float *logits, int vocab, const nl_sample_params *p
 }
 
 int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, float *last_logits_out) {
+    if (e && e->grp) return group_run(e, [&](nl_engine *m, int r) { return nl_prefill(m, stream, tokens, n, pos0, r == 0 ? last_logits_out : nullptr); });
     if (!e || !tokens || n < 0) return NL_ERR_INVALID;
     if (n == 0) return NL_OK;
     int rc = check_step_args(e, stream, tokens[0], pos0);
@@ -2863,6 +3059,13 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
 
 int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const int *pos, int n, float *logits_out,
                      int *next_ids) {
+    if (e && e->grp) {
+        if (n < 0) return NL_ERR_INVALID;
+        std::vector<std::vector<int>> ids(e->grp->members.size(), std::vector<int>((size_t)std::max(n, 1)));
+        const int rc = group_run(e, [&](nl_engine *m, int r) { return nl_forward_batch(m, streams, tokens, pos, n, r == 0 ? logits_out : nullptr, ids[r].data()); });
+        if (rc == NL_OK && next_ids) memcpy(next_ids, ids[0].data(), (size_t)n * sizeof(int));
+        return rc;
+    }
     if (!e || !streams || !tokens || !pos || n < 0) return NL_ERR_INVALID;
     if (n > e->cfg.max_streams) return e->fail(NL_ERR_INVALID, "batch of %d exceeds max_streams %d", n, e->cfg.max_streams);
     int rc;
@@ -2985,6 +3188,7 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
 }
 
 int nl_synchronize(nl_handle e) {
+    if (e && e->grp) return group_run(e, [&](nl_engine *m, int) { return nl_synchronize(m); });
     if (!e) return NL_ERR_INVALID;
     HIPCK(e, hipSetDevice(e->dev));
     HIPCK(e, hipStreamSynchronize(e->stream));
@@ -2993,12 +3197,14 @@ int nl_synchronize(nl_handle e) {
 }
 
 int nl_timer_start(nl_handle e) {
+    if (e && e->grp) return nl_timer_start(e->grp->members[0]);
     if (!e) return NL_ERR_INVALID;
     HIPCK(e, hipEventRecord(e->ev0, e->stream));
     return NL_OK;
 }
 
 int nl_timer_stop(nl_handle e, float *ms) {
+    if (e && e->grp) return nl_timer_stop(e->grp->members[0], ms);
     if (!e || !ms) return NL_ERR_INVALID;
     HIPCK(e, hipEventRecord(e->ev1, e->stream));
     HIPCK(e, hipEventSynchronize(e->ev1));
@@ -3009,6 +3215,7 @@ int nl_timer_stop(nl_handle e, float *ms) {
 const char *nl_kernel_kind_name(int k) { return (k >= 0 && k < NL_NUM_KINDS) ? kKindNames[k] : ""; }
 
 int nl_profile_forward(nl_handle e, int stream, int token, int pos, int iters, float *ms_out, int *calls_out) {
+    if (e && e->grp) return e->fail(NL_ERR_UNSUPPORTED, "nl_profile_forward on a device group: profile one rank with nl_p2p_loopback instead");
     // One eager Forward to put valid data in every buffer, then every launch of the plan is replayed
     // `iters` times back to back between two HIP events on the engine's stream: per-launch time =
     // elapsed / iters (this includes the dependent-launch boundary, ~1-2 us, which a single short kernel
@@ -3050,6 +3257,7 @@ int nl_profile_forward(nl_handle e, int stream, int token, int pos, int iters, f
 }
 
 int nl_plan_info(nl_handle e, int *fused_mode, int *fused_max_pos, int *launches_fused, int *launches_general) {
+    if (e && e->grp) return nl_plan_info(e->grp->members[0], fused_mode, fused_max_pos, launches_fused, launches_general);
     if (!e) return NL_ERR_INVALID;
     if (!e->finalized) return e->fail(NL_ERR_STATE, "nl_plan_info before nl_finalize");
     if (fused_mode) *fused_mode = e->fused ? e->fused_mode : 0;
@@ -3060,6 +3268,7 @@ int nl_plan_info(nl_handle e, int *fused_mode, int *fused_max_pos, int *launches
 }
 
 int nl_persist_info(nl_handle e, int *ready, int *max_pos, long long *launches, long long *tokens) {
+    if (e && e->grp) return nl_persist_info(e->grp->members[0], ready, max_pos, launches, tokens);
     if (!e) return NL_ERR_INVALID;
     if (ready) *ready = (e->pd.ready && !e->pd.retired) ? 1 : 0;
     if (max_pos) *max_pos = e->pd.ready ? e->pd.max_pos : 0;
@@ -3069,6 +3278,12 @@ int nl_persist_info(nl_handle e, int *ready, int *max_pos, long long *launches, 
 }
 
 int nl_memory_usage(nl_handle e, uint64_t *w, uint64_t *kv, uint64_t *st) {
+    if (e && e->grp) {
+        uint64_t a = 0, b = 0, c = 0;
+        for (nl_engine *m : e->grp->members) { a += m->bytes_weights; b += m->bytes_kv; c += m->bytes_state; }
+        if (w) *w = a; if (kv) *kv = b; if (st) *st = c;
+        return NL_OK;
+    }
     if (!e) return NL_ERR_INVALID;
     if (w) *w = e->bytes_weights;
     if (kv) *kv = e->bytes_kv;
@@ -3077,6 +3292,7 @@ int nl_memory_usage(nl_handle e, uint64_t *w, uint64_t *kv, uint64_t *st) {
 }
 
 int64_t nl_debug_read(nl_handle e, const char *which, int stream, float *out, int64_t max_floats) {
+    if (e && e->grp) return nl_debug_read(e->grp->members[0], which, stream, out, max_floats);     // rank 0's buffers (the logits are the gathered ones)
     if (!e || !which || !out || !e->finalized) return NL_ERR_INVALID;
     const float *src = nullptr;
     int64_t n = 0;
@@ -3399,13 +3615,9 @@ int nl_comm_init(nl_handle e, const void *id) {
 
 // ---- push all-reduce between the ranks of one node (nl_p2p.h) ------------------
 
-int nl_p2p_export(nl_handle e, void *handle_out) {
-    if (!e || !handle_out) return NL_ERR_INVALID;
-    if (e->finalized) return e->fail(NL_ERR_STATE, "nl_p2p_export after nl_finalize");
-    if (e->G < 2) return e->fail(NL_ERR_INVALID, "nl_p2p_export needs tp_size >= 2");
-    if (e->G != 2 && e->G != 4 && e->G != 8) return e->fail(NL_ERR_UNSUPPORTED, "push all-reduce supports 2, 4 or 8 ranks");
-    if (e->cfg.n_layers > 127) return e->fail(NL_ERR_UNSUPPORTED, "push all-reduce tags cover at most 127 layers");
-    if (e->cfg.flags & NL_FLAG_LOCAL_GROUP) return e->fail(NL_ERR_INVALID, "local groups sum in-process; no export");
+namespace {
+// this rank's receive area of the push all-reduce (uncached; see nl_p2p_export), allocated once
+int p2p_alloc_area(nl_engine *e) {
     HIPCK(e, hipSetDevice(e->dev));
     nl_engine::P2P &p = e->p2p;
     if (!p.area) {
@@ -3435,6 +3647,19 @@ int nl_p2p_export(nl_handle e, void *handle_out) {
         p.timeout_ticks = (long long)(tm ? atoi(tm) : 10000) * 100000;   // wall_clock64: 100 MHz
         e->bytes_state += p.bytes;
     }
+    return NL_OK;
+}
+}  // namespace
+
+int nl_p2p_export(nl_handle e, void *handle_out) {
+    if (!e || !handle_out) return NL_ERR_INVALID;
+    if (e->finalized) return e->fail(NL_ERR_STATE, "nl_p2p_export after nl_finalize");
+    if (e->G < 2) return e->fail(NL_ERR_INVALID, "nl_p2p_export needs tp_size >= 2");
+    if (e->G != 2 && e->G != 4 && e->G != 8) return e->fail(NL_ERR_UNSUPPORTED, "push all-reduce supports 2, 4 or 8 ranks");
+    if (e->cfg.n_layers > 127) return e->fail(NL_ERR_UNSUPPORTED, "push all-reduce tags cover at most 127 layers");
+    if (e->cfg.flags & NL_FLAG_LOCAL_GROUP) return e->fail(NL_ERR_INVALID, "local groups sum in-process; no export");
+    if (int rc = p2p_alloc_area(e)) return rc;
+    nl_engine::P2P &p = e->p2p;
     hipIpcMemHandle_t h;
     hipError_t s = hipIpcGetMemHandle(&h, p.area);
     if (s != hipSuccess) {
@@ -3487,6 +3712,7 @@ int nl_p2p_loopback(nl_handle e) {
 }
 
 int nl_p2p_info(nl_handle e, int *enabled, int *uncached) {
+    if (e && e->grp) return nl_p2p_info(e->grp->members[0], enabled, uncached);
     if (!e) return NL_ERR_INVALID;
     if (enabled) *enabled = e->p2p.on ? 1 : 0;
     if (uncached) *uncached = e->p2p.uncached ? 1 : 0;

@@ -85,7 +85,8 @@ __host__ __device__ constexpr size_t pd_lds_bytes() {
     return (size_t)PD_ULM * 2 * PD_THREADS * 16 + (size_t)PD_ULM * PD_THREADS * 2       // LM-head slice: quants, fp16 scales
            + 640 * 4 + 20 * 128 + PD_NBI_MAX * 128                                      // x, digit images of x * g and of h
            + (size_t)PD_PART * 4 + 256 * 4 + 16 * 8                                     // block products, row sums, float64 partials
-           + (192 + 64 + 8 * 68 + PD_MAX_PASSES * 66) * 4 + 64 * 4 + 80 * 4;            // q | k | v, attention output, pass partials, misc, block scales
+           + (192 + 64 + 8 * 68 + PD_MAX_PASSES * 66) * 4 + 64 * 4 + 80 * 4            // q | k | v, attention output, pass partials, misc, block scales
+           + (size_t)PD_SLOTS * PD_UNITS * PD_THREADS * 2;                              // fp16 scales of the register-resident units
 }
 
 struct PdParams {
@@ -265,6 +266,13 @@ __device__ __forceinline__ float pd_rows4_sum(float v) {
     const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+__device__ __forceinline__ float dpp_row_sum_f32(float v) {      // sum of the lane's row of 16, in every lane of the row
+    v += dpp_f32<DPP_QUAD_XOR1>(v);
+    v += dpp_f32<DPP_QUAD_XOR2>(v);
+    v += dpp_f32<DPP_HALF_MIRROR>(v);
+    v += dpp_f32<DPP_ROW_MIRROR>(v);
+    return v;
+}
 __device__ __forceinline__ double pd_wave_sum_f64(double v) {
     v += dpp_f64<DPP_QUAD_XOR1>(v);
     v += dpp_f64<DPP_QUAD_XOR2>(v);
@@ -316,44 +324,57 @@ __device__ __forceinline__ void pd_limbs(float v, bool valid, int e, unsigned ch
 // reference, go/quant.go:149-165, has a rounding per element; this form is exact up to the 2^-30 input rounding and three
 // float32 roundings per block.)  One MFMA = 256 weights: a quarter of the instructions of the VALU form.
 template <int K0, int NU, int NB>   // the lane's unit slots K0 .. K0 + NU - 1 of the layer slot; NB blocks per row
-__device__ __forceinline__ void pd_units(const uint4 (&lo_)[PD_UNITS], const uint4 (&hi_)[PD_UNITS], const unsigned (&sc)[(PD_UNITS + 1) / 2], const uint4 *img,
+__device__ __forceinline__ void pd_units(const uint4 (&lo_)[PD_UNITS], const uint4 (&hi_)[PD_UNITS], const unsigned short *sc /* LDS: [9][512] of the slot */, const uint4 *img,
                                          const float *scl, int total, float *part, int tid) {
     constexpr int NBP = NB | 1;
     const uint4 *lo = lo_ + K0, *hi = hi_ + K0;
     asm volatile("" : "+v"(tid));        // (addresses are derived per phase, not shared across phases and kept live)
-    // the digit rows and the scale of unit k + 1 are requested before unit k's products: one LDS latency per phase, not per unit
-    uint4 a0n, a1n;
-    float sbn;
-    {
-        const unsigned G = (unsigned)tid >> 2, rgp = G / (unsigned)NB, blk = G - rgp * (unsigned)NB;
-        const uint4 *ap = img + blk * 8u + ((unsigned)tid & 3u) * 2u;
-        a0n = ap[0]; a1n = ap[1]; sbn = scl[blk];
-    }
+    // Units go two at a time: the two chains of eight dependent products interleave (a 4x4x4 product has a few cycles of latency
+    // its successor would otherwise wait for), their digit rows are requested together, and the scheduling fence sits between
+    // pairs -- hoisting every unit's operands in front of the first product costs registers this kernel does not have.
 #pragma unroll
-    for (int k = 0; k < NU; k++) {
-        if (k * PD_THREADS < total) {
-            const unsigned u = (unsigned)(k * PD_THREADS + tid), G = u >> 2;
-            const unsigned rgp = G / (unsigned)NB, blk = G - rgp * (unsigned)NB, row = rgp * 4u + (u & 3u);
-            const uint4 a0 = a0n, a1 = a1n;
-            const float sb = sbn;
-            if (k + 1 < NU && (k + 1) * PD_THREADS < total) {
-                const unsigned Gn = (u + PD_THREADS) >> 2, rn = Gn / (unsigned)NB, bn = Gn - rn * (unsigned)NB;
-                const uint4 *ap = img + bn * 8u + (u & 3u) * 2u;
-                a0n = ap[0]; a1n = ap[1]; sbn = scl[bn];
+    for (int k0 = 0; k0 < NU; k0 += 2) {
+        if (k0 * PD_THREADS < total) {
+            constexpr int NBPc = NBP;
+            const bool two = k0 + 1 < NU && (k0 + 1) * PD_THREADS < total;
+            unsigned u[2], row[2], blk[2];
+            uint4 a0[2], a1[2];
+            float sb[2], d[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int k = (j == 1 && !(k0 + 1 < NU)) ? k0 : k0 + j;
+                u[j] = (unsigned)(k * PD_THREADS + tid);
+                const unsigned G = u[j] >> 2, rgp = G / (unsigned)NB;
+                blk[j] = G - rgp * (unsigned)NB; row[j] = rgp * 4u + (u[j] & 3u);
+                const uint4 *ap = img + blk[j] * 8u + (u[j] & 3u) * 2u;
+                a0[j] = ap[0]; a1[j] = ap[1]; sb[j] = scl[blk[j]];
+                d[j] = h2f_bits(sc[(K0 + k) * PD_THREADS + tid]);
             }
-            pd_i32x4 acc = {0, 0, 0, 0};
-            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.x, (int)lo[k].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.y, (int)lo[k].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.z, (int)lo[k].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.w, (int)lo[k].w, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.x, (int)hi[k].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.y, (int)hi[k].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.z, (int)hi[k].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.w, (int)hi[k].w, acc, 0, 0, 0);
-            const float f = fmaf(fmaf(fmaf((float)acc[3], 256.f, (float)acc[2]), 256.f, (float)acc[1]), 256.f, (float)acc[0]);
-            const float d = h2f_bits((sc[(K0 + k) >> 1] >> (16 * ((K0 + k) & 1))) & 0xffffu);
-            if ((int)u < total) part[row * (unsigned)NBP + blk] = f * (d * sb);
-            __builtin_amdgcn_sched_barrier(0);      // one unit's products at a time (its successor's operands already in flight)
+            pd_i32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            constexpr int K1 = 0;
+            (void)K1;
+#define PD_MF(A, W, ACC) ACC = __builtin_amdgcn_mfma_i32_4x4x4i8((int)(A), (int)(W), ACC, 0, 0, 0)
+            if (k0 + 1 < NU) {
+                PD_MF(a0[0].x, lo[k0].x, acc0); PD_MF(a0[1].x, lo[k0 + 1 < NU ? k0 + 1 : k0].x, acc1);
+                PD_MF(a0[0].y, lo[k0].y, acc0); PD_MF(a0[1].y, lo[k0 + 1 < NU ? k0 + 1 : k0].y, acc1);
+                PD_MF(a0[0].z, lo[k0].z, acc0); PD_MF(a0[1].z, lo[k0 + 1 < NU ? k0 + 1 : k0].z, acc1);
+                PD_MF(a0[0].w, lo[k0].w, acc0); PD_MF(a0[1].w, lo[k0 + 1 < NU ? k0 + 1 : k0].w, acc1);
+                PD_MF(a1[0].x, hi[k0].x, acc0); PD_MF(a1[1].x, hi[k0 + 1 < NU ? k0 + 1 : k0].x, acc1);
+                PD_MF(a1[0].y, hi[k0].y, acc0); PD_MF(a1[1].y, hi[k0 + 1 < NU ? k0 + 1 : k0].y, acc1);
+                PD_MF(a1[0].z, hi[k0].z, acc0); PD_MF(a1[1].z, hi[k0 + 1 < NU ? k0 + 1 : k0].z, acc1);
+                PD_MF(a1[0].w, hi[k0].w, acc0); PD_MF(a1[1].w, hi[k0 + 1 < NU ? k0 + 1 : k0].w, acc1);
+            } else {
+                PD_MF(a0[0].x, lo[k0].x, acc0); PD_MF(a0[0].y, lo[k0].y, acc0); PD_MF(a0[0].z, lo[k0].z, acc0); PD_MF(a0[0].w, lo[k0].w, acc0);
+                PD_MF(a1[0].x, hi[k0].x, acc0); PD_MF(a1[0].y, hi[k0].y, acc0); PD_MF(a1[0].z, hi[k0].z, acc0); PD_MF(a1[0].w, hi[k0].w, acc0);
+            }
+#undef PD_MF
+            const float f0 = fmaf(fmaf(fmaf((float)acc0[3], 256.f, (float)acc0[2]), 256.f, (float)acc0[1]), 256.f, (float)acc0[0]);
+            if ((int)u[0] < total) part[row[0] * (unsigned)NBPc + blk[0]] = f0 * (d[0] * sb[0]);
+            if (k0 + 1 < NU) {
+                const float f1 = fmaf(fmaf(fmaf((float)acc1[3], 256.f, (float)acc1[2]), 256.f, (float)acc1[1]), 256.f, (float)acc1[0]);
+                if (two && (int)u[1] < total) part[row[1] * (unsigned)NBPc + blk[1]] = f1 * (d[1] * sb[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -388,8 +409,11 @@ __device__ __forceinline__ float pd_inv_rms(float a, float b, bool v0, bool v1, 
     double ss = 0.0;
     if (v0) ss = fma((double)a, (double)a, ss);
     if (v1) ss = fma((double)b, (double)b, ss);
-    ss = pd_wave_sum_f64(ss);
-    if (lane == 0) dred[wave] = ss;
+    // (the lane's two squares are exact in float64; the 64 lanes of a wavefront meet in float32 -- one rounding of 2^-24 per
+    //  add on a sum of positive terms, well inside the float32 the result is rounded to -- on the DPP / swap path, a third of the
+    //  instructions of the float64 form; wavefronts are added in float64)
+    const float sw = pd_rows4_sum(dpp_row_sum_f32((float)ss));
+    if (lane == 0) dred[wave] = (double)sw;
     __syncthreads();
     double t[PD_WAVES];
 #pragma unroll
@@ -441,6 +465,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
     int *misc = bi + 8;                                                                    // [0] ticket, [1] census ok, [2] dead, [3] token
     float *xs = reinterpret_cast<float *>(misc + 8);                                       // [20] 1 / scale of every block of x
     float *hs = xs + 20;                                                                   // [48] ... of h
+    unsigned short *wsl = reinterpret_cast<unsigned short *>(hs + 60);                     // [2][9][512] fp16 d of the register-resident units (registers hold the quants only)
 
     const int tid0 = threadIdx.x;
     constexpr int D = NB * 32, I = NBI * 32, H = D / 64, NWK = PD_CUS - H, NBP = NB | 1, NBIP = NBI | 1;
@@ -463,21 +488,20 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
         misc[1] = ok ? 1 : 0;
     }
     __syncthreads();
-    const int idx = misc[0];
+    const int idx0 = misc[0];
     if (!misc[1]) {
         if (tid0 == 0) { atomicOr(P0.status, 64u); *P0.host_status = 64u; }
         return;
     }
-    const int cu = (int)xcd * PD_CUS + idx;
+    const int cu = (int)xcd * PD_CUS + idx0;
     const int nslots = pd_nslots(L, (int)xcd), first = pd_first(L, (int)xcd);
-    const bool embed_xcd = first == 0 && nslots > 0;     // this XCD owns layer 0: it turns the argmax into the next x
+    const unsigned xcd0 = xcd;
     const PdPoll Q{P0.status, P0.host_status, P0.spin_limit, misc + 2};
 #define PD_STAMP(i) do { if (P0.dbg && cu == 0 && tid0 == 0) P0.dbg[i] = wall_clock64(); } while (0)
     PD_STAMP(0);
 
     // ---- the weights of this unit's layers -> registers, its LM-head rows -> LDS (once per launch) ----
     uint4 wlo[PD_SLOTS][PD_UNITS], whi[PD_SLOTS][PD_UNITS];
-    unsigned wsc[PD_SLOTS][(PD_UNITS + 1) / 2];
 #pragma unroll
     for (int s = 0; s < PD_SLOTS; s++) {
         const int ss = min(s, max(nslots - 1, 0));      // an XCD with one layer loads it twice: slot 1 is never used
@@ -488,18 +512,12 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
             whi[s][k] = P0.wimg[(base * 2 + 1) * PD_THREADS + tid0];
         }
 #pragma unroll
-        for (int k2 = 0; k2 < (PD_UNITS + 1) / 2; k2++) {
-            const size_t b0 = ((size_t)cu * PD_SLOTS * PD_UNITS + ss * PD_UNITS + 2 * k2);
-            const unsigned a = P0.simg[b0 * PD_THREADS + tid0];
-            const unsigned b = 2 * k2 + 1 < PD_UNITS ? P0.simg[(b0 + 1) * PD_THREADS + tid0] : 0u;
-            wsc[s][k2] = a | (b << 16);
-        }
+        for (int k = 0; k < PD_UNITS; k++) wsl[(s * PD_UNITS + k) * PD_THREADS + tid0] = P0.simg[((size_t)cu * PD_SLOTS * PD_UNITS + ss * PD_UNITS + k) * PD_THREADS + tid0];
     }
 #pragma unroll
     for (int i = 0; i < PD_ULM * 2; i++) lmw[i * PD_THREADS + tid0] = P0.lmimg[((size_t)cu * PD_ULM * 2 + i) * PD_THREADS + tid0];
 #pragma unroll
     for (int k = 0; k < PD_ULM; k++) lms[k * PD_THREADS + tid0] = P0.lmsimg[((size_t)cu * PD_ULM + k) * PD_THREADS + tid0];
-    const int lm_rows = pd_lm_rows(P0.V), lm_r0 = cu * lm_rows, lm_n = max(0, min(lm_rows, P0.V - lm_r0));
     __syncthreads();
     PD_STAMP(1);
 
@@ -509,14 +527,21 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
         // Values the whole step derives its addresses from are made opaque once per step: the loop would otherwise have every
         // LDS / granule / cache address of every phase hoisted in front of it and kept live (hundreds of registers -- and 154
         // of the 256 hold weights)
-        int tid = tid0;
-        asm volatile("" : "+v"(tid));
         // ... and the kernel arguments are read again through an opaque pointer where a step needs them, instead of all of them
         // (and everything derived from them) sitting in scalar registers across the loop: the scalar file spilled 250 values
         // into vector lanes
         const __attribute__((address_space(4))) PdParams *pk = (const __attribute__((address_space(4))) PdParams *)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(pk));
         const __attribute__((address_space(4))) PdParams &P = *pk;
+        int tid = tid0, idx = idx0;
+        unsigned xcd = xcd0;
+        asm volatile("" : "+v"(tid), "+s"(idx), "+s"(xcd));
+        // (roles, row ranges and layer numbers follow from idx / xcd with a few scalar operations per step; hoisted in front of
+        //  the loop they were two hundred scalar values spilled into vector lanes)
+        const int cu = (int)xcd * PD_CUS + idx;
+        const int nslots = pd_nslots(L, (int)xcd), first = pd_first(L, (int)xcd);
+        const bool embed_xcd = first == 0 && nslots > 0;     // this XCD owns layer 0: it turns the argmax into the next x
+        const int lm_rows = pd_lm_rows(P.V), lm_r0 = cu * lm_rows, lm_n = max(0, min(lm_rows, P.V - lm_r0));
         // ... and so are the weight registers, in place (no instruction): their int8 -> float conversions are loop-invariant and
         // would otherwise be computed once in front of the loop -- 4608 floats per lane, spilled
 #pragma unroll
@@ -526,16 +551,22 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 asm volatile("" : "+v"(wlo[s][k].x), "+v"(wlo[s][k].y), "+v"(wlo[s][k].z), "+v"(wlo[s][k].w));
                 asm volatile("" : "+v"(whi[s][k].x), "+v"(whi[s][k].y), "+v"(whi[s][k].z), "+v"(whi[s][k].w));
             }
-#pragma unroll
-            for (int k2 = 0; k2 < (PD_UNITS + 1) / 2; k2++) asm volatile("" : "+v"(wsc[s][k2]));
         }
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-        const int e0 = tid, e1 = tid + PD_THREADS;
-        const bool v0 = e0 < D, v1 = e1 < D;
-        const int c0 = v0 ? e0 : 0, c1 = v1 ? e1 : 0;
+        int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        int e0 = tid, e1 = tid + PD_THREADS;
+        bool v0 = e0 < D, v1 = e1 < D;
+        int c0 = v0 ? e0 : 0, c1 = v1 ? e1 : 0;
+        // at every phase boundary the lane's index values are made opaque and derived again: nothing computed from them in
+        // one phase (LDS / granule addresses) is shared with, or kept live into, a later one
+#define PD_RELANE() do { asm volatile("" : "+v"(tid)); wave = __builtin_amdgcn_readfirstlane(tid >> 6); lane = tid & 63; e0 = tid; e1 = tid + PD_THREADS; \
+                         v0 = e0 < D; v1 = e1 < D; c0 = v0 ? e0 : 0; c1 = v1 ? e1 : 0; } while (0)
         const int pos = P.pos0 + step;
         // developer stamps (tools/persist_stamps.py): step 2 on XCD 1 -- unit 0 (a head of slot 0), unit H (a worker of slot 0)
+#ifdef NL_PD_STAMPS
 #define PD_ST(base, i) do { if (step == 2 && xcd == 1u && tid == 0 && P.dbg) P.dbg[(base) + (i)] = wall_clock64(); } while (0)
+#else
+#define PD_ST(base, i) do { } while (0)       // (the stamps' conditions cost scalar registers the production build does not have)
+#endif
         const unsigned tag = P.tag_base + (unsigned)step + 1u;
         float xa = 0.f, xb = 0.f;       // this thread's two elements of the residual stream entering the next layer
         if (embed_xcd) {
@@ -565,6 +596,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                     if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
                 }
                 __syncthreads();
+                PD_RELANE();
                 if (misc[2]) return;
                 best = bv[0]; bidx = bi[0];
 #pragma unroll
@@ -573,6 +605,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 token = bidx == 0x7fffffff ? 0 : bidx;      // all-NaN logits: the reference's loop never leaves index 0
                 if (idx == 0 && tid == 0) { P.ids_out[step - 1] = token; if (step == P.n_steps) P.census[9] = (unsigned)token; }
                 __syncthreads();                              // bv / bi are reused by the LM head
+                PD_RELANE();
             }
             if (step == P.n_steps) break;
             // ---- embedding row (go/model.go:389-446) ----
@@ -597,10 +630,8 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
             const __amdgpu_buffer_rsrc_t kr_ = pd_rsrc(kc, (unsigned)P.seq_len * 256u), vr_ = pd_rsrc(vc, (unsigned)P.seq_len * 256u);
             const int kr = lane >> 2, kq = lane & 3, vg = lane >> 4, vcl = lane & 15;
             float4 kreg[4], vreg[4];
-            float ecos = 0.f, esin = 0.f;
             // (norm weights are requested before the polls they would otherwise wait behind)
             const float ga0 = P.norms[(size_t)(layer * 2) * D + c0], ga1 = P.norms[(size_t)(layer * 2) * D + c1];
-            if (head && tid < 128) { ecos = P.rope_cos[pos * 32 + (tid & 31)]; esin = P.rope_sin[pos * 32 + (tid & 31)]; }
             // ---- x of this layer: every unit of the XCD needs it (heads: the projection input; workers: the residual) ----
             if (layer > 0) {
                 float xv[2];
@@ -617,7 +648,9 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 if (misc[2]) return;
                 // ---- Q | K | V rows of this head (go/model.go:517-523) ----
                 if (s == 0 && idx == 0) PD_ST(sb, 2);
-                pd_units<0, PD_UQ, NB>(wlo[s], whi[s], wsc[s], reinterpret_cast<const uint4 *>(xl), xs, 192 * NB, part, tid);
+                float ec = 0.f, es = 0.f;      // (requested before the products: the rotation below must not wait for them)
+                if (tid < 256) { ec = P.rope_cos[pos * 32 + ((tid & 127) >> 2)]; es = P.rope_sin[pos * 32 + ((tid & 127) >> 2)]; }
+                pd_units<0, PD_UQ, NB>(wlo[s], whi[s], wsl + s * PD_UNITS * PD_THREADS, reinterpret_cast<const uint4 *>(xl), xs, 192 * NB, part, tid);
                 if (s == 0 && idx == 0) PD_ST(sb, 3);
                 {   // the first 128 cache rows of the head are requested behind the dot products (rows >= pos repeat row pos,
                     // the row of this position comes from LDS): they arrive during the row sums and the rotation
@@ -630,26 +663,29 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                     }
                 }
                 __syncthreads();
-                if (tid < 384) {       // two lanes per row
-                    const float v = pd_rowsum<NB, 2>(part + (tid >> 1) * NBP, tid & 1) * inv;
-                    if (!(tid & 1)) rs[tid >> 1] = v;
-                }
-                __syncthreads();
-                // RoPE on q and k (go/model.go:449-477: pairs (i, i + 32)), v as it is; KV store (go/model.go:552-554)
-                if (tid < 128) {
-                    const int sect = tid >> 6, i = tid & 31, up = (tid >> 5) & 1;
-                    const float x0 = rs[sect * 64 + i], x1 = rs[sect * 64 + i + 32];
+                PD_RELANE();
+                // row sums, RoPE (go/model.go:449-477: pairs (i, i + 32)) and the KV store (go/model.go:552-554) without a round
+                // trip through LDS: a quad of lanes = rows i and i + 32 of q (threads 0-127) or k (128-255), two lanes per row; v
+                // rows: threads 256-383, two lanes per row
+                if (tid < 256) {
+                    const int sect = tid >> 7, i = (tid & 127) >> 2, up = (tid >> 1) & 1, e = i + 32 * up;
+                    const float own = pd_rowsum<NB, 2>(part + (sect * 64 + e) * NBP, tid & 1) * inv;
+                    const float other = dpp_f32<DPP_QUAD_XOR2>(own);
+                    const float x0 = up ? other : own, x1 = up ? own : other;
                     float o;
-                    if (!P.rope_conj) o = up ? (x0 * esin + x1 * ecos) : (x0 * ecos - x1 * esin);
-                    else o = up ? (-x0 * esin + x1 * ecos) : (x0 * ecos + x1 * esin);
-                    qs[tid] = o;
-                    if (sect == 1) kc[(long long)pos * 64 + (tid & 63)] = o;
-                } else if (tid < 192) {
-                    const float v = rs[tid];
-                    qs[tid] = v;
-                    vc[(long long)pos * 64 + (tid & 63)] = v;
+                    if (!P.rope_conj) o = up ? (x0 * es + x1 * ec) : (x0 * ec - x1 * es);
+                    else o = up ? (-x0 * es + x1 * ec) : (x0 * ec + x1 * es);
+                    if (!(tid & 1)) {
+                        qs[sect * 64 + e] = o;
+                        if (sect == 1) kc[(long long)pos * 64 + e] = o;
+                    }
+                } else if (tid < 384) {
+                    const int e = (tid - 256) >> 1;
+                    const float v = pd_rowsum<NB, 2>(part + (128 + e) * NBP, tid & 1) * inv;
+                    if (!(tid & 1)) { qs[128 + e] = v; vc[(long long)pos * 64 + e] = v; }
                 }
                 __syncthreads();
+                PD_RELANE();
                 // ---- softmax attention over positions 0 .. pos (go/model.go:557-587), 128 positions per pass: nl_block.h's
                 //      one-barrier pass (every wavefront reduces its 16 positions to one (max, sum, sum p v) partial) ----
                 if (s == 0 && idx == 0) PD_ST(sb, 4);
@@ -694,6 +730,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                     if (lane < 16) *reinterpret_cast<float4 *>(wpart + wave * 68 + 4 + vcl * 4) = o;
                     if (lane == 0) { wpart[wave * 68] = mw; wpart[wave * 68 + 1] = lw; }
                     __syncthreads();
+                    PD_RELANE();
                     if (wave == 0) {
                         const float mwv = lane < 8 ? wpart[min(lane, 7) * 68] : -INFINITY;
                         const float M = wave_max_f32(mwv);
@@ -701,13 +738,14 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                         const float Ls = wave_sum_f32(lane < 8 ? wgt * wpart[min(lane, 7) * 68 + 1] : 0.f);
                         float ov = 0.f;
 #pragma unroll
-                        for (int w = 0; w < 8; w++) ov = fmaf(__shfl(wgt, w), wpart[w * 68 + 4 + lane], ov);
+                        for (int w = 0; w < 8; w++) ov = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt), w)), wpart[w * 68 + 4 + lane], ov);
                         chunk[ch * 66 + 2 + lane] = ov;
                         if (lane == 0) { chunk[ch * 66] = M; chunk[ch * 66 + 1] = Ls; }
                     }
                     if (ch + 1 < nch) __syncthreads();
                 }
                 __syncthreads();
+                PD_RELANE();
                 if (s == 0 && idx == 0) PD_ST(sb, 5);
                 if (tid < 64) {
                     float ov;
@@ -739,10 +777,12 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                     if (wave * 64 + PD_THREADS < D) pd_limbs(ov[1], v1, e1, xl, xs, lane);
                 }
                 __syncthreads();
+                PD_RELANE();
                 if (s == 0 && idx == H) PD_ST(sb, 2);
                 if (misc[2]) return;
-                pd_units<0, PD_UW, NB>(wlo[s], whi[s], wsc[s], reinterpret_cast<const uint4 *>(xl), xs, nrp * NB, part, tid);
+                pd_units<0, PD_UW, NB>(wlo[s], whi[s], wsl + s * PD_UNITS * PD_THREADS, reinterpret_cast<const uint4 *>(xl), xs, nrp * NB, part, tid);
                 __syncthreads();
+                PD_RELANE();
                 if (s == 0 && idx == H) PD_ST(sb, 3);
                 if (tid < 4 * nr) {    // four lanes per row
                     const float v = pd_rowsum<NB, 4>(part + (tid >> 2) * NBP, tid & 3);
@@ -755,6 +795,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 pd_gather<2>(P.gxp + (size_t)layer * D, D, tag, xp, Q, 4u, tid);
                 if (s == 0 && idx == H) PD_ST(sb, 5);
                 __syncthreads();                               // (xraw / xT / part of the WO step are free)
+                PD_RELANE();
                 if (v0) xraw[e0] = xp[0];
                 if (v1) xraw[e1] = xp[1];
                 pd_limbs(xp[0] * gf0, v0, e0, xl, xs, lane);
@@ -762,19 +803,21 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 const float inv2 = pd_inv_rms(xp[0], xp[1], v0, v1, lane, wave, dred, D, P.eps);
                 if (misc[2]) return;
                 if (s == 0 && idx == H) PD_ST(sb, 6);
-                pd_units<PD_UW, PD_UG, NB>(wlo[s], whi[s], wsc[s], reinterpret_cast<const uint4 *>(xl), xs, 2 * rgp * NB, part, tid);
+                pd_units<PD_UW, PD_UG, NB>(wlo[s], whi[s], wsl + s * PD_UNITS * PD_THREADS, reinterpret_cast<const uint4 *>(xl), xs, 2 * rgp * NB, part, tid);
                 __syncthreads();
+                PD_RELANE();
                 if (s == 0 && idx == H) PD_ST(sb, 7);
-                if (((tid & 255) >> 1) < rg) {      // gate rows: threads 0 .., up rows: threads 256 ..; two lanes per row
-                    const int mat = tid >> 8, row = (tid & 255) >> 1;
-                    const float v = pd_rowsum<NB, 2>(part + (mat * rgp + row) * NBP, tid & 1) * inv2;
-                    if (!(tid & 1)) rs[mat * 128 + row] = v;
-                }
-                __syncthreads();
-                if (tid < rg) {
-                    const float g = rs[tid], u = rs[128 + tid];
-                    const float ex = pd_exp(-g);
-                    pd_publish<false>(P.gh + (size_t)layer * I + g0 + tid, tag, (g / (1.0f + ex)) * u);
+                // row sums and SiLU(gate) * up without a round trip through LDS: a quad = the gate row and the up row of one index,
+                // two lanes each
+                if ((tid >> 2) < rg) {
+                    const int row = tid >> 2, mat = (tid >> 1) & 1;
+                    const float own = pd_rowsum<NB, 2>(part + (mat * rgp + row) * NBP, tid & 1) * inv2;
+                    const float other = dpp_f32<DPP_QUAD_XOR2>(own);
+                    if (!(tid & 3)) {
+                        const float g = own, u = other;
+                        const float ex = pd_exp(-g);
+                        pd_publish<false>(P.gh + (size_t)layer * I + g0 + row, tag, (g / (1.0f + ex)) * u);
+                    }
                 }
                 if (s == 0 && idx == H) PD_ST(sb, 8);
                 // ---- h of every worker -> LDS; down rows + residual (go/model.go:609-612) ----
@@ -786,10 +829,12 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                         if (wave * 64 + k * PD_THREADS < I) pd_limbs(hv[k], tid + k * PD_THREADS < I, tid + k * PD_THREADS, hl, hs, lane);
                 }
                 __syncthreads();
+                PD_RELANE();
                 if (s == 0 && idx == H) PD_ST(sb, 9);
                 if (misc[2]) return;
-                pd_units<PD_UW + PD_UG, PD_UD, NBI>(wlo[s], whi[s], wsc[s], reinterpret_cast<const uint4 *>(hl), hs, nrp * NBI, part, tid);
+                pd_units<PD_UW + PD_UG, PD_UD, NBI>(wlo[s], whi[s], wsl + s * PD_UNITS * PD_THREADS, reinterpret_cast<const uint4 *>(hl), hs, nrp * NBI, part, tid);
                 __syncthreads();
+                PD_RELANE();
                 if (s == 0 && idx == H) PD_ST(sb, 10);
                 if (tid < 4 * nr) {      // four lanes per row, a quarter of the blocks each, joined in lane order
                     const int row = tid >> 2, q = tid & 3;
@@ -803,6 +848,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
             }
             if (s == 0 && idx == H) PD_ST(sb, 11);
             __syncthreads();     // LDS of this slot is free for the next one
+            PD_RELANE();
         }
 
         // =================================== LM head (go/model.go:616-619), every compute unit ===================================
@@ -845,6 +891,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 }
             }
             __syncthreads();
+            PD_RELANE();
             if (idx == 0) PD_ST(40, 2);
             float best = -INFINITY;
             int bidx = 0x7fffffff;
@@ -864,6 +911,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
             }
             __syncthreads();
+            PD_RELANE();
             if (tid == 0) {
                 best = bv[0]; bidx = bi[0];
 #pragma unroll
@@ -873,6 +921,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 __builtin_amdgcn_raw_buffer_store_b128(g, pd_rsrc(P.gam, PD_GRID * 16u), cu * 16, 0, 16);     // write-through: layer 0's XCD reads it
             }
             __syncthreads();
+            PD_RELANE();
         }
         if (idx == 0) PD_ST(40, 3);
         if (step == 0) PD_STAMP(2);
@@ -880,6 +929,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
     if (P0.dbg && cu == 0 && tid0 == 0) P0.dbg[3] = wall_clock64();
 #undef PD_STAMP
 #undef PD_ST
+#undef PD_RELANE
 }
 
 }  // namespace nl

@@ -200,13 +200,16 @@ class LlamaModel:
 
 def load_llama_model(gguf: GGUFFile, device: int = 0, max_streams: int = 1, tp_rank: int = 0, tp_size: int = 1,
                      comm_id: Optional[bytes] = None, flags: int = 0, verbose: bool = False,
-                     p2p_allgather=None, p2p_loopback: bool = False) -> LlamaModel:
+                     p2p_allgather=None, p2p_loopback: bool = False, devices: Optional[List[int]] = None) -> LlamaModel:
     """LoadLlamaModel go/model.go:121-174: config from GGUF metadata, every
     tensor handed to the device library, state allocated there.
 
     Tensor-parallel runs (one process per GPU, tp_size 2/4/8): `p2p_allgather(bytes) -> [bytes per rank]` (e.g.
     Rendezvous.allgather_bytes) selects the push all-reduce over xGMI -- it carries the hipIpc handles of the ranks'
-    receive areas; `comm_id` selects RCCL instead."""
+    receive areas; `comm_id` selects RCCL instead.
+
+    `devices` = [d0, d1, ...] (2, 4 or 8 entries): ONE process, the model sharded tensor-parallel over those GPUs behind
+    one handle (nl_create_group) -- what `--gpus N` of the CLI / server uses; the returned model is used like any other."""
     L = _lib.lib()
     m = gguf.meta
     head_dim = m.head_dim
@@ -221,11 +224,19 @@ def load_llama_model(gguf: GGUFFile, device: int = 0, max_streams: int = 1, tp_r
                         seq_len, m.rms_norm_eps, m.rope_theta, int(m.qk_norm), int(m.rope_conjugate), max_streams,
                         device, tp_rank, tp_size, flags)
     h = C.c_void_p()
-    rc = L.nl_create(C.byref(cfg), C.byref(h))
+    if devices is not None:
+        if tp_size != 1 or comm_id is not None or p2p_allgather is not None or p2p_loopback:
+            raise ValueError("devices=[...] is the one-process group: no tp_rank / tp_size / communicator arguments")
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = L.nl_create_group(C.byref(cfg), ids, len(devices), C.byref(h))
+    else:
+        rc = L.nl_create(C.byref(cfg), C.byref(h))
     if rc != 0:
         raise _lib.NlError(rc, (L.nl_last_error(None) or b"").decode())
     try:
-        if tp_size > 1 and p2p_loopback:
+        if devices is not None:
+            pass                                  # the group wires its ranks itself
+        elif tp_size > 1 and p2p_loopback:
             # measurement only (bench.py --shard-of): this rank alone, tensor-parallel plan, own area in place of the peers'
             _lib.check(h, L.nl_p2p_loopback(h))
         elif tp_size > 1 and p2p_allgather is not None and not (flags & _lib.NL_FLAG_LOCAL_GROUP):

@@ -45,6 +45,23 @@ def test_create_without_gpu_fails_loudly_or_succeeds_with_one():
     assert L.nl_create(ctypes.byref(bad), ctypes.byref(h)) in (-1, -2, -3)
 
 
+def test_create_group_without_gpu_fails_loudly():
+    # nl_create_group (one process, N GPUs): argument errors are reported before any device is touched; with no device the
+    # rank engines cannot be created -- NL_ERR_HIP, never a CPU fallback
+    L = _lib.lib()
+    cfg = _lib.NlConfig(2, 256, 4, 4, 64, 512, 512, 64, 1e-5, 10000.0, 0, 0, 1, 0, 0, 1, 0)
+    h = ctypes.c_void_p()
+    ids = (ctypes.c_int * 8)(0, 0, 0, 0, 0, 0, 0, 0)
+    assert L.nl_create_group(ctypes.byref(cfg), ids, 3, ctypes.byref(h)) == -2 and b"2, 4 or 8" in L.nl_last_error(None)
+    assert L.nl_create_group(ctypes.byref(cfg), None, 2, ctypes.byref(h)) == -1
+    rc = L.nl_create_group(ctypes.byref(cfg), ids, 2, ctypes.byref(h))
+    if L.nl_device_count() == 0:
+        assert rc == -3 and b"no HIP device" in L.nl_last_error(None) and not h.value
+    else:
+        assert rc == 0
+        L.nl_destroy(h)
+
+
 # What "using the oracle" looks like in source: an import, an include, a dlopen / CDLL of the checker's library, or a path
 # into oracle/.  (A comment that merely names the oracle as the thing a kernel is held to is not a use; the round-4 tree
 # went red on exactly such a comment.)

@@ -21,12 +21,15 @@ bench)
   cut -c1-700 $O/r05_bench_n1_steps20.json.log ;;
 persist)
   (timeout 900 python -m pytest tests/test_gpu_persist.py -x -q -s 2>&1 | tail -40) > $O/pytest_persist.log; cat $O/pytest_persist.log ;;
+group)
+  (GPU_MAX_HW_QUEUES=8 timeout 900 python -m pytest tests/test_gpu_group.py -x -q -s 2>&1 | tail -25) > $O/pytest_group.log; cat $O/pytest_group.log ;;
 newtests)
   (timeout 1500 python -m pytest tests/test_gpu_tp_fused.py -x -q -s -k "big_attention_geometry or keep_out_of" 2>&1 | tail -15) > $O/pytest_newtests.log; cat $O/pytest_newtests.log ;;
 m4)
   $hip tools/mfma4_probe.hip -o /tmp/m4p 2>/dev/null && /tmp/m4p > $O/r05_mfma4_probe.log 2>&1; cat $O/r05_mfma4_probe.log ;;
 pstamps)
-  python3 tools/persist_stamps.py 64 8 > $O/r05_persist_stamps.log 2>&1; cat $O/r05_persist_stamps.log ;;
+  (cd nanollama_amd/csrc && $hip -fPIC -ffp-contract=off -fno-slp-vectorize -fvisibility=hidden -DNL_PD_STAMPS -DNL_SRC_SHA=\"pdstamps\" -DNL_GIT_HEAD=\"pdstamps\" -shared -o /tmp/libnl_pd.so nl_engine.hip -ldl 2>&1 | grep -E " error" | head)
+  NL_LIB_PATH=/tmp/libnl_pd.so python3 tools/persist_stamps.py 64 8 > $O/r05_persist_stamps.log 2>&1; cat $O/r05_persist_stamps.log ;;
 nano)
   for rep in 1 2; do timeout 250 python bench.py --workload nano:q8_0 --steps 64 --warmup 8 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python3 -c "
 import json,sys
