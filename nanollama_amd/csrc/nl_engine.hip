@@ -2270,6 +2270,20 @@ int nl_upload_tensor(nl_handle e, const char *name, uint32_t type, const void *d
     return e->fail(NL_ERR_INVALID, "unknown tensor %s", name);
 }
 
+namespace {
+// modes 3 / 4: how many blocks of the projection + attention + WO launch stay until their rows are done (live: they hold projection
+// tiles of a kv group that exists; WO owners: b * tpw < WO tiles) -- all of them must fit the compute units at once
+bool stayers_fit(const nl_engine *e, int members, int grid, int tpw, int wo_ntiles) {
+    int stay = 0;
+    for (int b = 0; b < grid; b++) {
+        const int cluster = (b / (8 * members)) * 8 + (b & 7);
+        const bool live = b < grp_grid(e->KVs, members) && cluster < e->KVs;
+        if (live || (long long)b * tpw < wo_ntiles) stay++;
+    }
+    return stay <= e->num_cus;
+}
+}  // namespace
+
 int nl_finalize(nl_handle e) {
     if (e && e->grp) {
         if (e->finalized) return e->fail(NL_ERR_STATE, "nl_finalize called twice");
@@ -2424,13 +2438,11 @@ int nl_finalize(nl_handle e) {
             ok2 = ok2 && geo;
             ok3 = ok3 && geo;
             e->grp_tpm = tpm;
-            // Modes 3 and 4 launch grp_grid = ceil(KVs / 8) * 8 * members blocks and, unlike mode 2, the blocks that hold no
-            // projection tile STAY (they own WO rows and spin on the heads' outputs): a live block with an index beyond the
-            // compute units could not be dispatched while they wait for it.  The whole projection grid must be resident
-            // (KVs = 1 per rank at gqa 8: 40 members x 8 = 320 blocks do not fit 256 compute units) -- such shapes keep mode 2
-            // / the four-launch rank plan instead of stalling into the fallback.
-            e->grp_grid_fits = geo && grp_grid(e->KVs, NT / tpm) <= e->num_cus;
-            ok3 = ok3 && e->grp_grid_fits;
+            // Modes 3 and 4 launch max(grp_grid, WO grid) blocks and, unlike mode 2, a block that holds no projection tile but
+            // owns WO rows STAYS (it spins on the heads' outputs); the other tile-less blocks leave at once.  Every block that
+            // stays -- live (cluster < KVs) or WO-owning (b * wo_tpw < WO tiles) -- must be resident together: a live block that
+            // cannot be dispatched while WO owners wait for it would stall the launch into the fallback (stayers_fit below).
+            e->grp_grid_fits = geo;      // (refined below, per mode, once the WO share of a block is known)
         }
         if (ok3) {
             nl_engine::TpGeom &t = e->tpg;
@@ -2444,6 +2456,7 @@ int nl_finalize(nl_handle e) {
             int tpw = 1;
             while (tpw < 16 && (long long)agrid * tpw < L0.wo.ntiles) tpw *= 2;
             ok3 = gshift <= 4 && (tpw << gshift) <= 16 && (long long)agrid * tpw >= L0.wo.ntiles && L0.wo.npairs <= 64;
+            ok3 = ok3 && stayers_fit(e, (e->gqa + 2) * 4 / e->grp_tpm, agrid, tpw, L0.wo.ntiles);
             t.wo_gshift = gshift;
             t.wo_tpw = tpw;
             ok3 = ok3 && e->Hs * 4 * GPT <= 2 * TP_THREADS;  // at most two attention-output granules per thread
@@ -2494,6 +2507,11 @@ int nl_finalize(nl_handle e) {
                 ok4 = gshift <= 4 && L0.wo.npairs <= 64 && e->Hs * 4 * GPT <= 2 * TP_THREADS;
                 t.wo_gshift = gshift;
                 t.wo_tpw = 16 >> std::min(gshift, 4);
+                {
+                    const int members = (e->gqa + 2) * 4 / e->grp_tpm;
+                    const int grid4 = std::max(grp_grid(e->KVs, members), (L0.wo.ntiles + t.wo_tpw - 1) / t.wo_tpw);
+                    ok4 = ok4 && stayers_fit(e, members, grid4, t.wo_tpw, L0.wo.ntiles);
+                }
                 for (const auto &L : e->layers)
                     ok4 = ok4 && (L.qkv.wtype == WT_Q8_0 || L.qkv.wtype == WT_Q4_0) && L.wo.wtype == L.qkv.wtype &&
                           L.wo.npairs == L0.wo.npairs && L.wo.ntiles == L0.wo.ntiles;

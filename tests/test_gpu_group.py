@@ -33,53 +33,72 @@ def orc():
     return oracle
 
 
+WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from nanollama_amd import gguf, model, synth
+from oracle import oracle as orc
+n, plan, path = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+LOGIT_TOL = 1e-4
+g = gguf.load_gguf(path)
+vocab = g.meta.vocab_size
+grp = model.load_llama_model(g, devices=[0] * n)
+assert grp.plan_info()["fused_mode"] == (0 if plan == "five_launch" else 3), grp.plan_info()
+assert grp.p2p_info()["push_allreduce"]
+local = model.LocalTPGroup(g, n, fused=(plan == "two_launch"))
+ref = orc.OracleModel(g)
+toks = synth.prompt_ids(12, vocab, seed=9)
+worst = 0.0
+for pos, t in enumerate(toks):
+    grp.forward(t, pos)
+    want_bits = local.forward(t, pos)
+    assert grp.state.logits.tobytes() == want_bits.tobytes(), f"pos {{pos}}: one-process group != in-process shard group"
+    want = ref.forward(t, pos)
+    worst = max(worst, float(np.abs(grp.state.logits - want).max()) / max(1.0, float(want.std())))
+assert worst <= LOGIT_TOL, worst
+# chained greedy decode through the 16-step graphs and the argmax exchange: the oracle's ids, and a replay repeats them
+tok, want_ids = int(np.argmax(grp.state.logits)), []
+first = tok
+for k in range(24):
+    tok = int(orc.argmax(ref.forward(tok, len(toks) + k)))
+    want_ids.append(tok)
+ids = grp.decode_greedy(first, len(toks), 24)
+assert ids == want_ids, (ids, want_ids)
+assert grp.decode_greedy(first, len(toks), 24) == ids
+# per-call argmax, prefill, reset, sampled decode from the gathered logits, memory accounting: the handle is an ordinary one
+assert grp.forward_argmax(first, len(toks)) == want_ids[0]
+grp.reset()
+grp.prefill(toks[:5])
+ref.reset()
+for pos, t in enumerate(toks[:5]):
+    want = ref.forward(t, pos)
+assert np.abs(grp.state.logits - want).max() <= LOGIT_TOL * max(1.0, float(want.std()))
+us = np.random.default_rng(5).random(12, dtype=np.float32)
+sampled, recent = grp.sample_decode(5, 12, 0.8, 0.9, 50, 1.15, 16, us, [])
+assert len(sampled) == 12 and all(0 <= t < vocab for t in sampled)
+mem = grp.memory_usage()
+assert mem["weights"] > 0 and mem["kv_cache"] > 0
+assert grp.last_error() == "", grp.last_error()
+grp.close(); local.close(); ref.close()
+print(f"group ok: {{n}} ranks on device 0, {{plan}} plan: bitwise = in-process shard group; max|gpu-oracle| = {{worst:.2e}}")
+"""
+
+
 @pytest.mark.parametrize("n,plan", [(2, "five_launch"), (4, "five_launch"), (2, "two_launch"), (4, "two_launch")])
-def test_one_process_group_equals_the_shard_group_bitwise(hip, orc, tmp_path, monkeypatch, n, plan):
+def test_one_process_group_equals_the_shard_group_bitwise(tmp_path, n, plan):
+    # (a fresh process with GPU_MAX_HW_QUEUES >= ranks: the ranks share ONE device here, and a rank's launch spins until its
+    #  peers' launches run -- two rank streams on one hardware queue would wait for each other.  One rank per GPU has its own
+    #  device's queues and needs no such setting.)
     shape = synth.ModelShape("grp_probe", 3, 1024 if n == 2 else 512, 16 if n == 2 else 8, 4, 4096, seq_len=64, interm=2048 if n == 2 else 1024)
-    p = tmp_path / "m.gguf"
-    synth.generate_gguf(str(p), shape, "q4_0", 61, mode="qrand")
-    g = gguf.load_gguf(str(p))
+    p = str(tmp_path / "m.gguf")
+    synth.generate_gguf(p, shape, "q4_0", 61, mode="qrand")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", NL_P2P_TIMEOUT_MS="5000")
     if plan == "five_launch":
-        monkeypatch.setenv("NL_FUSED_ATTN", "0")       # (the plain shard group steps the five-launch plan: hold the ranks to it)
-    grp = hip.load_llama_model(g, devices=[0] * n)
-    assert grp.plan_info()["fused_mode"] == (0 if plan == "five_launch" else 3), grp.plan_info()
-    assert grp.p2p_info()["push_allreduce"]
-    local = hip.LocalTPGroup(g, n, fused=(plan == "two_launch"))
-    ref = orc.OracleModel(g)
-    toks = synth.prompt_ids(12, shape.vocab, seed=9)
-    worst = 0.0
-    for pos, t in enumerate(toks):
-        grp.forward(t, pos)
-        want_bits = local.forward(t, pos)
-        assert grp.state.logits.tobytes() == want_bits.tobytes(), f"pos {pos}: one-process group != in-process shard group"
-        want = ref.forward(t, pos)
-        worst = max(worst, float(np.abs(grp.state.logits - want).max()) / max(1.0, float(want.std())))
-    assert worst <= LOGIT_TOL
-    # chained greedy decode through the 16-step graphs and the argmax exchange: the oracle's ids, and a replay repeats them
-    tok, want_ids = int(np.argmax(grp.state.logits)), []
-    first = tok
-    for k in range(24):
-        tok = int(orc.argmax(ref.forward(tok, len(toks) + k)))
-        want_ids.append(tok)
-    ids = grp.decode_greedy(first, len(toks), 24)
-    assert ids == want_ids
-    assert grp.decode_greedy(first, len(toks), 24) == ids
-    # per-call argmax, prefill, reset, sampled decode from the gathered logits, memory accounting: the handle is an ordinary one
-    assert grp.forward_argmax(first, len(toks)) == want_ids[0]
-    grp.reset()
-    grp.prefill(toks[:5])
-    ref.reset()
-    for pos, t in enumerate(toks[:5]):
-        want = ref.forward(t, pos)
-    assert np.abs(grp.state.logits - want).max() <= LOGIT_TOL * max(1.0, float(want.std()))
-    us = np.random.default_rng(5).random(12, dtype=np.float32)
-    sampled, recent = grp.sample_decode(5, 12, 0.8, 0.9, 50, 1.15, 16, us, [])
-    assert len(sampled) == 12 and all(0 <= t < shape.vocab for t in sampled)
-    mem = grp.memory_usage()
-    assert mem["weights"] > 0 and mem["kv_cache"] > 0
-    assert grp.last_error() == ""
-    grp.close(); local.close(); ref.close()
-    print(f"\none-process group, {n} ranks on device 0, {plan} plan: bitwise = in-process shard group; max|gpu-oracle| = {worst:.2e}")
+        env["NL_FUSED_ATTN"] = "0"       # (the plain shard group steps the five-launch plan: hold the ranks to it)
+    r = subprocess.run([sys.executable, "-c", WORKER.format(root=ROOT), str(n), plan, p], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "group ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    print("\n" + r.stdout.strip().splitlines()[-1])
 
 
 def test_group_of_eight_ranks_in_a_fresh_process(tmp_path):
@@ -128,7 +147,7 @@ def test_cli_shards_over_gpus(tmp_path):
     shape = synth.ModelShape("grp_cli", 2, 256, 4, 4, 512, seq_len=64, interm=512)
     p = str(tmp_path / "m.gguf")
     synth.generate_gguf(p, shape, "q8_0", 71)
-    env = dict(os.environ, NL_GROUP_ONE_DEVICE="1", NL_QUIET="1")
+    env = dict(os.environ, NL_GROUP_ONE_DEVICE="1", NL_QUIET="1", GPU_MAX_HW_QUEUES="8")
     r = subprocess.run([sys.executable, "-m", "nanollama_amd", "--model", p, "--gpus", "2", "--prompt", "ab", "--max-tokens", "8", "--temp", "0",
                         "--rep-penalty", "1.0"], env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])

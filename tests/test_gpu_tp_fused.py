@@ -192,23 +192,26 @@ def test_big_attention_geometry_across_the_in_launch_passes(hip, orc, tmp_path):
         print(f"big geometry, mode 3 tp {n}: max|gpu-oracle| = {worst:.2e}")
 
 
-def test_fused_modes_keep_out_of_a_projection_grid_beyond_the_compute_units(hip, orc, tmp_path):
-    # Modes 3 / 4 keep every block of the projection grid resident (blocks without a tile hold WO rows and wait): with 3 kv
-    # groups of 8 query heads the grid is ceil(3 / 8) * 8 * 40 = 320 blocks > 256 compute units, live blocks beyond the
-    # chip could never start and the first step would spin into the timeout fallback.  The engine must pick mode 2 (whose
-    # blocks without a tile leave at once) up front, silently and correctly.
-    shape = synth.ModelShape("fg_grid", 2, 1536, 24, 3, 512, seq_len=160, interm=1024)
-    p = tmp_path / "m.gguf"
-    synth.generate_gguf(str(p), shape, "q4_0", 99, mode="qrand")
-    g = gguf.load_gguf(str(p))
-    dev = hip.load_llama_model(g)
-    assert dev.plan_info()["fused_mode"] == 2, dev.plan_info()
-    ref = orc.OracleModel(g)
-    orc.set_threads(min(16, os.cpu_count() or 1))
-    for pos, t in enumerate(synth.prompt_ids(24, shape.vocab, seed=43)):
-        dev.forward(t, pos)
-        want = ref.forward(t, pos)
-        assert np.abs(dev.state.logits - want).max() <= LOGIT_TOL * max(1.0, float(want.std())), pos
-    orc.set_threads(1)
-    assert dev.last_error() == "" and dev.plan_info()["fused_mode"] == 2      # no stall, no retirement
-    dev.close(); ref.close()
+def test_fused_modes_keep_out_of_a_launch_whose_staying_blocks_exceed_the_compute_units(hip, orc, tmp_path):
+    # Modes 3 / 4 keep every LIVE block (projection tiles of an existing kv group) and every WO-owning block resident until its
+    # rows are done; tile-less blocks without WO rows leave at once.  D 2560 / 40 heads / 5 kv heads: 200 live blocks in a grid of
+    # 320 (block b is live when b % 8 < 5) + 160 WO owners (b < 160), 100 of them both = 260 blocks that stay > 256 compute
+    # units: the last live blocks could never start and the first step would spin into the timeout fallback.  The engine must
+    # pick mode 2 (whose tile-less blocks all leave) up front, silently and correctly; 3 kv groups of 8 heads at D 1536 -- a grid
+    # of 320 too, but only 150 blocks stay -- keeps mode 4.
+    for name, shape, mode in (("stay260", synth.ModelShape("fg_stay", 2, 2560, 40, 5, 512, seq_len=160, interm=1024), 2),
+                              ("stay150", synth.ModelShape("fg_grid", 2, 1536, 24, 3, 512, seq_len=160, interm=1024), 4)):
+        p = tmp_path / f"{name}.gguf"
+        synth.generate_gguf(str(p), shape, "q4_0", 99, mode="qrand")
+        g = gguf.load_gguf(str(p))
+        dev = hip.load_llama_model(g)
+        assert dev.plan_info()["fused_mode"] == mode, (name, dev.plan_info())
+        ref = orc.OracleModel(g)
+        orc.set_threads(min(16, os.cpu_count() or 1))
+        for pos, t in enumerate(synth.prompt_ids(24, shape.vocab, seed=43)):
+            dev.forward(t, pos)
+            want = ref.forward(t, pos)
+            assert np.abs(dev.state.logits - want).max() <= LOGIT_TOL * max(1.0, float(want.std())), (name, pos)
+        orc.set_threads(1)
+        assert dev.last_error() == "" and dev.plan_info()["fused_mode"] == mode      # no stall, no retirement
+        dev.close(); ref.close()

@@ -15,7 +15,7 @@ xcd)
   $hip tools/xcd_exchange_probe.hip -o /tmp/xcdp 2>&1 | grep -E "error" | head
   timeout 600 /tmp/xcdp > $O/r05_xcd_exchange_probe.log 2>&1; cat $O/r05_xcd_exchange_probe.log ;;
 tests)
-  (timeout 2000 python -m pytest tests -m gpu -q -x 2>&1 | tail -8) > $O/pytest_gpu.log; cat $O/pytest_gpu.log ;;
+  (timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -25) > $O/pytest_gpu.log; cat $O/pytest_gpu.log ;;
 bench)
   (timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench_steps20.err | tail -1) > $O/r05_bench_n1_steps20.json.log
   cut -c1-700 $O/r05_bench_n1_steps20.json.log ;;
@@ -24,6 +24,8 @@ persist)
 group)
   (GPU_MAX_HW_QUEUES=8 timeout 900 python -m pytest tests/test_gpu_group.py -x -q -s 2>&1 | tail -25) > $O/pytest_group.log; cat $O/pytest_group.log ;;
 newtests)
+  (timeout 1500 python -m pytest tests/test_gpu_tp_fused.py tests/test_gpu_group.py tests/test_gpu_parity.py -q -k "big_attention_geometry or staying_blocks or group or fused_projection_attention_launch" 2>&1 | tail -15) > $O/pytest_newtests2.log; cat $O/pytest_newtests2.log ;;
+newtests_unused)
   (timeout 1500 python -m pytest tests/test_gpu_tp_fused.py -x -q -s -k "big_attention_geometry or keep_out_of" 2>&1 | tail -15) > $O/pytest_newtests.log; cat $O/pytest_newtests.log ;;
 m4)
   $hip tools/mfma4_probe.hip -o /tmp/m4p 2>/dev/null && /tmp/m4p > $O/r05_mfma4_probe.log 2>&1; cat $O/r05_mfma4_probe.log ;;
