@@ -33,7 +33,6 @@
 #include <string>
 #include <thread>
 #include <vector>
-#include <rocprim/device/device_radix_sort.hpp>   // the descending candidate order of sampleTopP / sampleTopK
 
 namespace { void samp_free(nl::SampScratch &s); }
 
@@ -2807,18 +2806,17 @@ hipError_t samp_alloc(SampScratch &s, int vocab, int n_uniforms) {
     if (samp_chunk(vocab) > 128) return hipErrorInvalidValue;   // vocab > 131072
     const int nblocks = (vocab + 255) / 256;
 #define SA(ptr, count) if ((rc = hipMalloc((void **)&(ptr), (size_t)(count) * 4)) != hipSuccess) return rc
-    SA(s.keys_in, SAMP_THREADS * samp_chunk(vocab)); SA(s.keys_out, SAMP_THREADS * samp_chunk(vocab)); SA(s.idx_in, vocab); SA(s.idx_out, vocab);   // (whole lane chunks: the select kernels load past vocab and mask)
-    if ((rc = hipMemset(s.keys_out, 0, (size_t)SAMP_THREADS * samp_chunk(vocab) * 4)) != hipSuccess) return rc;  // zero tail past vocab
-    SA(s.partial, nblocks); SA(s.scal, 4); SA(s.pmax, nblocks); SA(s.h1g, 2 * 2048);
-    if ((rc = hipMemset(s.h1g, 0, 2048 * 8)) != hipSuccess) return rc; SA(s.uniforms, std::max(n_uniforms, 1)); SA(s.recent, SAMP_THREADS); SA(s.recent_n, 1);
+    SA(s.keys_in, SAMP_THREADS * samp_chunk(vocab));   // (whole lane chunks: the select kernels load past vocab and mask)
+    if ((rc = hipMemset(s.keys_in, 0, (size_t)SAMP_THREADS * samp_chunk(vocab) * 4)) != hipSuccess) return rc;
+    SA(s.scal, 4); SA(s.pmax, nblocks); SA(s.h1g, 2 * 2048);
+    if ((rc = hipMemset(s.h1g, 0, 2048 * 8)) != hipSuccess) return rc;
+    SA(s.uniforms, std::max(n_uniforms, 1)); SA(s.recent, SAMP_THREADS); SA(s.recent_n, 1);
 #undef SA
-    if ((rc = rocprim::radix_sort_pairs_desc(nullptr, s.sort_tmp_bytes, s.keys_in, s.keys_out, s.idx_in, s.idx_out,
-                                             (unsigned)vocab, 0, 32, (hipStream_t)0)) != hipSuccess) return rc;
-    return hipMalloc(&s.sort_tmp, std::max<size_t>(s.sort_tmp_bytes, 16));
+    return hipSuccess;
 }
 
 void samp_free(SampScratch &s) {
-    void *p[] = {s.keys_in, s.keys_out, s.idx_in, s.idx_out, s.partial, s.scal, s.pmax, s.h1g, s.uniforms, s.recent, s.recent_n, s.sort_tmp};
+    void *p[] = {s.keys_in, s.scal, s.pmax, s.h1g, s.uniforms, s.recent, s.recent_n};
     for (void *q : p) if (q) (void)hipFree(q);
     s = SampScratch{};
 }
@@ -2831,34 +2829,23 @@ hipError_t launch_sample(const SampScratch &s, float *logits, int vocab, const n
     P.logits = logits; P.vocab = vocab; P.temp = p.temperature; P.top_p = p.top_p; P.top_k = std::max(p.top_k, 1);
     P.rep_penalty = p.rep_penalty; P.recent = s.recent; P.recent_n = s.recent_n; P.rep_window = p.rep_window;
     P.uniforms = s.uniforms; P.ctl = ctl; P.ids = ids;
-    P.keys_in = s.keys_in; P.keys_out = s.keys_out; P.idx_in = s.idx_in; P.idx_out = s.idx_out;
-    P.partial = s.partial; P.scal = s.scal; P.pmax = s.pmax; P.nblocks = (vocab + 255) / 256;
+    P.keys_in = s.keys_in;
+    P.scal = s.scal; P.pmax = s.pmax; P.nblocks = (vocab + 255) / 256;
     P.h1g = s.h1g; P.nblocks_pen = P.nblocks;
-    // top-p up to 65536 candidates: weighted radix selection in one launch, no sort (nl_sample.h).  NL_SAMP_SORT=1 keeps the
-    // sorted path (developer A/B; read once)
-    static const bool force_sort = getenv("NL_SAMP_SORT") && atoi(getenv("NL_SAMP_SORT")) != 0;
-    P.radix = p.temperature > 0.f && p.top_p < 1.0f && !force_sort ? 1 : 0;
+    // Three selections, none with a sort (nl_sample.h): temp <= 0 -> argmax of the penalised logits; top_p < 1 -> sampleTopP by
+    // weighted radix selection (<= 32768 candidates in the registers of the one workgroup, up to 131072 streamed out of L2);
+    // otherwise sampleTopK by a 2-bit-per-pass selection of the k-th largest logit + a bitonic network over the <= 1024 candidates
+    P.radix = p.temperature > 0.f && p.top_p < 1.0f ? 1 : 0;
     hipLaunchKernelGGL(samp_penalty_kernel, dim3(P.nblocks), dim3(256), 0, st, P);
     if (P.radix) {
         hipLaunchKernelGGL(samp_prob_hist_kernel, dim3((vocab + SAMP_THREADS - 1) / SAMP_THREADS), dim3(SAMP_THREADS), 0, st, P);
-        // (<= 32768 candidates: in the registers of the one workgroup; up to 131072: streamed out of L2 pass by pass)
         if (samp_chunk(vocab) == 32) hipLaunchKernelGGL(samp_select_radix_kernel<32>, dim3(1), dim3(SAMP_THREADS), 0, st, P);
         else hipLaunchKernelGGL(samp_select_radix_stream_kernel, dim3(1), dim3(SAMP_THREADS), 0, st, P);
-        return hipGetLastError();
-    }
-    if (p.temperature > 0.f) {
-        hipLaunchKernelGGL(samp_prob_kernel, dim3(P.nblocks), dim3(256), 0, st, P);
-        size_t tmp = s.sort_tmp_bytes;
-        hipError_t rc = rocprim::radix_sort_pairs_desc(s.sort_tmp, tmp, s.keys_in, s.keys_out, s.idx_in, s.idx_out,
-                                                       (unsigned)vocab, 0, 32, st);
-        if (rc != hipSuccess) return rc;
-    }
-    switch (samp_chunk(vocab)) {
-    case 32: hipLaunchKernelGGL(samp_select_kernel<32>, dim3(1), dim3(SAMP_THREADS), 0, st, P); break;
-    case 64: hipLaunchKernelGGL(samp_select_kernel<64>, dim3(1), dim3(SAMP_THREADS), 0, st, P); break;
-    case 96: hipLaunchKernelGGL(samp_select_kernel<96>, dim3(1), dim3(SAMP_THREADS), 0, st, P); break;
-    case 128: hipLaunchKernelGGL(samp_select_kernel<128>, dim3(1), dim3(SAMP_THREADS), 0, st, P); break;
-    default: return hipErrorInvalidValue;
+    } else if (p.temperature > 0.f) {
+        if (samp_chunk(vocab) == 32) hipLaunchKernelGGL(samp_topk_kernel<false>, dim3(1), dim3(SAMP_THREADS), 0, st, P);
+        else hipLaunchKernelGGL(samp_topk_kernel<true>, dim3(1), dim3(SAMP_THREADS), 0, st, P);
+    } else {
+        hipLaunchKernelGGL(samp_argmax_select_kernel, dim3(1), dim3(SAMP_THREADS), 0, st, P);
     }
     return hipGetLastError();
 }
@@ -2869,6 +2856,7 @@ int check_sample_params(nl_engine *e, const nl_sample_params *p) {
     if (p->rep_window < 0 || p->rep_window > SAMP_THREADS) return bad("rep_window must be in [0, 1024] for on-device sampling");
     if (!(p->top_p > 0.f)) return bad("top_p must be > 0");
     if (p->top_k < 1 && p->top_p >= 1.f && p->temperature > 0.f) return bad("top_k must be >= 1");
+    if (p->top_k > SAMP_THREADS && p->top_p >= 1.f && p->temperature > 0.f) return bad("top_k must be <= 1024 for on-device sampling (the host loop takes larger lists)");
     return NL_OK;
 }
 

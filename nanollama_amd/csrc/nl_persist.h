@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
         return;
     }
     const int cu = (int)xcd * PD_CUS + idx0;
-    const int nslots = pd_nslots(L, (int)xcd), first = pd_first(L, (int)xcd);
+    const int nslots = pd_nslots(L, (int)xcd);
     const unsigned xcd0 = xcd;
     const PdPoll Q{P0.status, P0.host_status, P0.spin_limit, misc + 2};
 #define PD_STAMP(i) do { if (P0.dbg && cu == 0 && tid0 == 0) P0.dbg[i] = wall_clock64(); } while (0)
@@ -621,6 +621,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
             const bool head = pd_is_head(s, idx, H);
             const bool next_here = s + 1 < nslots;           // the next layer lives on this XCD
             const int sb = s == 0 ? (head ? 8 : 24) : 63;     // stamp base (slot 0 only)
+            (void)sb;
             if (s == 0 && (idx == 0 || idx == H)) PD_ST(sb, 0);
             // heads: the first 128 cache rows of the head are requested before anything is waited for (rows >= pos repeat row
             // pos - 1 .. the row of this position comes from LDS)

@@ -9,13 +9,12 @@
 //   recent window append / drop-oldest                                                        :197-200
 // The uniform u comes from the host's generator (one float32 per step, uploaded up front): Go's math/rand
 // stream is not reproducible from another language anyway, the algorithm around it is what is mirrored.
-// The descending order is a stable radix sort (rocPRIM, ties keep ascending index -- Go's sort.Slice leaves the
-// order of equal probabilities unspecified).  Sums: the top-k path adds its <= top_k terms sequentially exactly as
-// the Go loop does; the top-p path adds V terms in fixed chunks (1024 contiguous chunks, each summed left to right,
-// chunk totals accumulated left to right) -- deterministic, but not the Go loop's single left-to-right chain, so a
-// u within ~1e-7 of a cdf boundary can select the neighbouring candidate.
+// No library sort is involved (round 5): top-k finds its k-th largest logit by a 2-bit-per-pass selection on the keys' bits,
+// collects the candidates above it (equal ones by ascending index, as the Go insertion list keeps them) and orders the <= 1024
+// of them with a bitonic network in LDS (samp_topk_kernel); its sums run sequentially over the <= top_k terms exactly as the Go
+// loop's.  top-p needs no order at all:
 //
-// Round 4: top-p needs NO sort (vocabularies up to 131072; the top-k branch keeps the sorted list it walks).  Both questions the Go loop asks of the sorted list -- where
+// Round 4: top-p needs NO sort (vocabularies up to 131072).  Both questions the Go loop asks of the sorted list -- where
 // does the cumulative probability reach top_p, and where does it reach r = u * cumsum -- are weighted rank selections, and
 // samp_select_radix_kernel answers them by radix selection on the bits of p (three histogram levels of 11 + 11 + 10 bits,
 // each bucket holding the SUM of its candidates' weights) inside one workgroup that keeps the candidates in registers.
@@ -44,9 +43,7 @@ struct SampleParams {
     int rep_window;
     const float *uniforms;
     int *ctl, *ids;
-    float *keys_in, *keys_out;
-    int *idx_in, *idx_out;
-    float *partial;       // [nblocks of samp_prob_kernel]
+    float *keys_in;       // [1024 * chunk] unnormalised probabilities of the top-p selection
     float *scal;          // (spare scalars)
     float *pmax;          // [nblocks] workgroup maxima of the penalised logits (samp_penalty_kernel)
     int nblocks;
@@ -73,11 +70,9 @@ __device__ __forceinline__ void samp_embed_tail(const SampleParams &P, int token
 
 // device scratch of one sampler (one vocabulary)
 struct SampScratch {
-    float *keys_in = nullptr, *keys_out = nullptr, *partial = nullptr, *scal = nullptr, *pmax = nullptr, *uniforms = nullptr;
+    float *keys_in = nullptr, *scal = nullptr, *pmax = nullptr, *uniforms = nullptr;
     unsigned long long *h1g = nullptr;
-    int *idx_in = nullptr, *idx_out = nullptr, *recent = nullptr, *recent_n = nullptr;
-    void *sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
+    int *recent = nullptr, *recent_n = nullptr;
 };
 
 // vocab / 256 workgroups: repetition penalty on the workgroup's own 256 logits (every workgroup reads the window and
@@ -108,40 +103,7 @@ __global__ void __launch_bounds__(256) samp_penalty_kernel(SampleParams P) {
     if (tid == 0) P.pmax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-// sort keys: top-p mode = unnormalised probabilities (+ per-workgroup partial sums), top-k mode = the logits
-__global__ void __launch_bounds__(256) samp_prob_kernel(SampleParams P) {
-    __shared__ float red[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool top_p_mode = P.top_p < 1.0f;
-    float key = 0.f;
-    const float l = P.logits[min(i, P.vocab - 1)];
-    float gmax = -INFINITY;
-    if (top_p_mode) {
-        // the maximum over the workgroup maxima of samp_penalty_kernel (nblocks <= 512)
-        const float m0 = P.pmax[min((int)threadIdx.x, P.nblocks - 1)], m1 = P.pmax[min((int)threadIdx.x + 256, P.nblocks - 1)];
-        gmax = wave_max_f32(fmaxf(m0, m1));
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gmax;
-        __syncthreads();
-        gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        __syncthreads();
-    }
-    if (i < P.vocab) {
-        key = top_p_mode ? (float)exp((double)((l - gmax) / P.temp)) : l;
-        P.keys_in[i] = key;
-        if (!P.radix) P.idx_in[i] = i;
-    } else if (top_p_mode) {
-        key = 0.f;
-    }
-    if (top_p_mode && !P.radix) {
-        float s = i < P.vocab ? key : 0.f;
-        s = wave_sum_f32(s);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) P.partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-    }
-}
-
-// The radix path's probabilities: p_i as samp_prob_kernel computes them, plus level 1 of the selection's histograms, built HERE by
+// The top-p path's probabilities p_i = f32(exp(f64((l_i - max) / temp))), plus level 1 of the selection's histograms, built HERE by
 // every compute unit instead of by the one selecting workgroup (3.8 us of its 20): a candidate (p >= 2^-45, weight >= 1) goes
 // to bucket (bits(p) - bits(2^-45)) >> 18 -- 32 buckets per binary exponent, 1440 in all -- with its exact integer weight;
 // a workgroup sums its 1024 candidates in LDS and flushes the non-empty buckets with 64-bit device-scope atomics (integer sums:
@@ -178,143 +140,39 @@ __global__ void __launch_bounds__(SAMP_THREADS) samp_prob_hist_kernel(SamplePara
     }
 }
 
-// 1 workgroup: pick the token from the sorted candidates and advance the decode state
-template <int C>   // chunk length per lane: a multiple of 32 with 1024 * C >= vocab (keys_out is zero-padded to 1024 * C)
-__global__ void __launch_bounds__(SAMP_THREADS) samp_select_kernel(SampleParams P) {
-    __shared__ float chunk[SAMP_THREADS];
-    __shared__ float bval[SAMP_THREADS / 64];
-    __shared__ int bidx[SAMP_THREADS / 64];
-    __shared__ float wtot[SAMP_THREADS / 64];
-    __shared__ int s_cut, s_pick, s_pick_pos;
-    __shared__ float s_cum, s_inv;
-    const int tid = threadIdx.x, V = P.vocab;
-    const int step = P.ctl[CTL_STEP];
-    const float u = P.uniforms[step];
-    if (tid == 0) { s_cut = 0x7fffffff; s_pick = -1; s_pick_pos = 0x7fffffff; s_cum = 0.f; }
-    int pick = 0;
-    if (P.temp <= 0.f) {
-        // argmax over the penalised logits, lowest index wins ties
-        float best = -INFINITY;
-        int idx = 0x7fffffff;
-        for (int i = tid; i < V; i += SAMP_THREADS) {
-            const float v = P.logits[i];
-            if (v > best || idx == 0x7fffffff) { best = v; idx = i; }
-        }
+// every thread of the workgroup visits the V 32-bit words of an L2-resident array: coalesced 16-byte agent-scope loads (through the
+// L2 only: 60-110 GB/s per compute unit against 37 for plain loads, tools/ingest_probe.hip), eight in flight per lane
+__device__ __forceinline__ uint4 samp_ld_l2(const unsigned *base, unsigned word_off) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(base), 0, -1, 0x00020000);
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(word_off * 4u), 0, 16 /* sc1 */);
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+template <class F>
+__device__ __forceinline__ void samp_each_key(const unsigned *kin, int V, F f) {
+    const int nq = (V + 3) >> 2, tid = threadIdx.x;
+    for (int q0 = 0; q0 < nq; q0 += 8 * SAMP_THREADS) {
+        uint4 v[8];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o);
-            const int oi = __shfl_xor(idx, o);
-            if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
-        }
-        if ((tid & 63) == 0) { bval[tid >> 6] = best; bidx[tid >> 6] = idx; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < SAMP_THREADS / 64; w++)
-                if (bval[w] > best || (bval[w] == best && bidx[w] < idx)) { best = bval[w]; idx = bidx[w]; }
-            s_pick = idx == 0x7fffffff ? 0 : idx;
-        }
-    } else if (P.top_p < 1.0f) {
-        if (tid == 0) {
-            float sum = 0.f;
-            for (int b = 0; b < P.nblocks; b++) sum += P.partial[b];
-            s_inv = 1.0f / sum;
-        }
-        __syncthreads();
-        const float inv = s_inv;
-        // cum(i) = (prefix of the earlier wavefronts' totals + prefix of the earlier lanes' chunk totals) + the
-        // left-to-right sum inside this lane's contiguous chunk: every chain is a fixed left-to-right order
-        const int lo = tid * C, hi = min(lo + C, V);
-        float q[C];                                        // this lane's chunk, normalised; one round of loads
+        for (int j = 0; j < 8; j++) v[j] = samp_ld_l2(kin, (unsigned)min(q0 + j * SAMP_THREADS + tid, nq - 1) * 4u);
 #pragma unroll
-        for (int k = 0; k < C; k += 4) {
-            const float4 t4 = *reinterpret_cast<const float4 *>(P.keys_out + lo + k);
-            q[k] = t4.x * inv; q[k + 1] = t4.y * inv; q[k + 2] = t4.z * inv; q[k + 3] = t4.w * inv;
-        }
-        float local = 0.f;
-#pragma unroll
-        for (int k = 0; k < C; k++) local += q[k];         // entries past vocab are +0.0f
-        chunk[tid] = local;
-        __syncthreads();
-        const int wv = tid >> 6, ln = tid & 63;
-        float within = 0.f;
-        for (int t = wv * 64; t < tid; t++) within += chunk[t];
-        if (ln == 63) wtot[wv] = within + local;
-        __syncthreads();
-        float pre = 0.f;
-        for (int w = 0; w < wv; w++) pre += wtot[w];
-        pre += within;
-        // (1) the cut: the smallest i with cum(i) >= top_p.  Every lane scans its own chunk and the minimum wins, so
-        //     a one-ulp disagreement between a chunk's last cum and the next chunk's prefix cannot lose the cut.
-        {
-            float part = 0.f;
-            int found = 0x7fffffff;
-#pragma unroll
-            for (int k = 0; k < C; k++) {
-                part += q[k];
-                if (found == 0x7fffffff && lo + k < hi && pre + part >= P.top_p) found = lo + k;
+        for (int j = 0; j < 8; j++) {
+            const int q = q0 + j * SAMP_THREADS + tid, i = q * 4;
+            if (q < nq) {
+                f(v[j].x, i);
+                if (i + 1 < V) f(v[j].y, i + 1);
+                if (i + 2 < V) f(v[j].z, i + 2);
+                if (i + 3 < V) f(v[j].w, i + 3);
             }
-            if (found != 0x7fffffff) atomicMin(&s_cut, found);
-        }
-        __syncthreads();
-        const int cut = s_cut;
-        if (cut < 0x7fffffff) {
-            if (lo <= cut && cut < hi) {
-                float part = 0.f;
-#pragma unroll
-                for (int k = 0; k < C; k++) part += lo + k <= cut ? q[k] : 0.f;
-                s_cum = pre + part;
-            }
-            __syncthreads();
-            // (2) the smallest j <= cut with r <= cum(j)
-            const float r = u * s_cum;
-            float part = 0.f;
-            int found = 0x7fffffff;
-#pragma unroll
-            for (int k = 0; k < C; k++) {
-                part += q[k];
-                if (found == 0x7fffffff && lo + k < hi && lo + k <= cut && r <= pre + part) found = lo + k;
-            }
-            if (found != 0x7fffffff) atomicMin(&s_pick_pos, found);
-        }
-        __syncthreads();
-        if (tid == 0) s_pick = P.idx_out[s_pick_pos < 0x7fffffff ? s_pick_pos : 0];
-    } else {
-        // top-k: the Go loop (go/main.go:325-342).  The <= 1024 candidate probabilities are computed one per lane
-        // (each is a pure function of its own logit), the two sums run left to right on lane 0 exactly as in Go.
-        const int K = min(P.top_k, V);
-        const float v0 = P.keys_out[0];
-        if (K <= SAMP_THREADS) {
-            if (tid < K) chunk[tid] = (float)exp((double)((P.keys_out[tid] - v0) / P.temp));
-            __syncthreads();
-            if (tid == 0) {
-                float sum = 0.f;
-                for (int i = 0; i < K; i++) sum += chunk[i];
-                const float r = u * sum;
-                float cdf = 0.f;
-                int sel = 0;
-                for (int i = 0; i < K; i++) {
-                    cdf += chunk[i];
-                    if (r <= cdf) { sel = i; break; }
-                }
-                s_pick = P.idx_out[sel];
-            }
-        } else if (tid == 0) {
-            float sum = 0.f;
-            for (int i = 0; i < K; i++) sum += (float)exp((double)((P.keys_out[i] - v0) / P.temp));
-            const float r = u * sum;
-            float cdf = 0.f;
-            int sel = 0;
-            for (int i = 0; i < K; i++) {
-                cdf += (float)exp((double)((P.keys_out[i] - v0) / P.temp));
-                if (r <= cdf) { sel = i; break; }
-            }
-            s_pick = P.idx_out[sel];
         }
     }
-    __syncthreads();
-    pick = s_pick;
+}
+
+// the end of every selecting launch: embedding row of the pick (opens the next Forward), recent window append / drop-oldest
+// (go/main.go:197-200), decode state.  Called by all SAMP_THREADS threads of the one workgroup.
+__device__ __forceinline__ void samp_finish(const SampleParams &P, int pick, int step) {
+    const int tid = threadIdx.x;
     samp_embed_tail(P, pick);
-    // recent window: append, drop the oldest when full (go/main.go:197-200)
     const int n = *P.recent_n;
     int shifted = 0;
     if (P.rep_window > 0 && n >= P.rep_window && tid + 1 < n) shifted = P.recent[tid + 1];   // rep_window <= 1024
@@ -334,6 +192,227 @@ __global__ void __launch_bounds__(SAMP_THREADS) samp_select_kernel(SampleParams 
         P.ctl[CTL_TOKEN] = pick;
         P.ctl[CTL_POS] = P.ctl[CTL_POS] + 1;
     }
+}
+
+// temp <= 0 with a repetition penalty: argmax over the penalised logits, lowest index wins ties (go/main.go:297-299, :400-408)
+__global__ void __launch_bounds__(SAMP_THREADS) samp_argmax_select_kernel(SampleParams P) {
+    __shared__ float bval[SAMP_THREADS / 64];
+    __shared__ int bidx[SAMP_THREADS / 64];
+    __shared__ int s_pick;
+    const int tid = threadIdx.x, V = P.vocab;
+    const int step = P.ctl[CTL_STEP];
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = tid; i < V; i += SAMP_THREADS) {
+        const float v = P.logits[i];
+        if (v > best || idx == 0x7fffffff) { best = v; idx = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(idx, o);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((tid & 63) == 0) { bval[tid >> 6] = best; bidx[tid >> 6] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < SAMP_THREADS / 64; w++)
+            if (bval[w] > best || (bval[w] == best && bidx[w] < idx)) { best = bval[w]; idx = bidx[w]; }
+        s_pick = idx == 0x7fffffff ? 0 : idx;
+    }
+    __syncthreads();
+    samp_finish(P, s_pick, step);
+}
+
+// ---- sampleTopK (go/main.go:294-343) without a sort of the vocabulary ----------------------------------------------------------
+// The Go loop keeps an insertion list of the top_k largest logits (strict '>': of equal logits the earlier index stays ahead) and
+// walks it.  Here, one workgroup:
+//   1. the logits become order-preserving 32-bit keys (a NaN never enters the Go list: lowest key);
+//   2. the k-th largest key T is found two bits at a time, sixteen passes: every lane counts, among its keys that match the
+//      bits fixed so far, those whose next digit is >= 1, >= 2, = 3 (three counters in ONE 64-bit sum, 21 bits each: <= 131072
+//      keys), the counts meet by DPP + LDS, and the digit where the cumulative count from the top reaches what is still needed
+//      is fixed -- no atomics, nothing data-dependent in the control flow.  Vocabularies up to 32768 keep their keys in
+//      registers; larger ones stream them out of L2 each pass (agent-scope 16-byte loads, samp_each_key);
+//   3. candidates = every key > T and, of the keys == T, the first `need` in index order (two block scans: ranks of the equal
+//      keys, then list positions) as (key, ~index) pairs in LDS;
+//   4. a bitonic network orders the <= 1024 pairs descending (equal keys by ascending index) -- only next_pow2(top_k) of them;
+//   5. probabilities, their sum and the cdf walk exactly as the Go loop: one lane, left to right.
+// top_k <= 1024 (check_sample_params; the reference's default is 50).
+typedef unsigned long long samp_u64_t;
+__device__ __forceinline__ unsigned samp_key_of(float v) {
+    const unsigned b = __float_as_uint(v);
+    if (v != v) return 0u;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float samp_val_of(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// sum of a 64-bit value over the workgroup, result in every thread (two barriers; scr: 16 entries)
+__device__ __forceinline__ samp_u64_t samp_block_sum_u64(samp_u64_t v, samp_u64_t *scr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
+        v += ((samp_u64_t)hi << 32) | lo;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
+    __syncthreads();
+    samp_u64_t t = 0;
+#pragma unroll
+    for (int w = 0; w < SAMP_THREADS / 64; w++) t += scr[w];
+    return t;
+}
+// exclusive prefix of a per-thread count over the workgroup (thread order) and the total
+__device__ __forceinline__ unsigned samp_block_excl_scan(unsigned c, unsigned *wtot, unsigned &total) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    unsigned pre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SAMP_THREADS / 64; w++) { const unsigned t = wtot[w]; if (w < wv) pre += t; tot += t; }
+    total = tot;
+    return pre + incl - c;
+}
+
+template <bool STREAM>     // false: vocab <= 32768, 32 keys per lane in registers; true: keys streamed out of L2 every pass
+__global__ void __launch_bounds__(SAMP_THREADS) samp_topk_kernel(SampleParams P) {
+    constexpr int C = 32;
+    __shared__ samp_u64_t list[SAMP_THREADS];
+    __shared__ samp_u64_t scr[SAMP_THREADS / 64];
+    __shared__ unsigned wtot[SAMP_THREADS / 64];
+    __shared__ float prob[SAMP_THREADS];
+    __shared__ int s_pick;
+    const int tid = threadIdx.x, V = P.vocab;
+    const int step = P.ctl[CTL_STEP];
+    const float u = P.uniforms[step];
+    const int K = min(min(P.top_k, V), SAMP_THREADS);
+    const unsigned *lg = reinterpret_cast<const unsigned *>(P.logits);
+    unsigned key[STREAM ? 1 : C];
+    const int lo = tid * C;
+    if (!STREAM) {
+#pragma unroll
+        for (int k = 0; k < C; k++) key[k] = lo + k < V ? samp_key_of(P.logits[min(lo + k, V - 1)]) : 0u;     // (past the vocabulary: the lowest key, never needed: K <= V)
+    }
+    list[tid] = 0;
+    // ---- 2. the k-th largest key, two bits per pass ----
+    unsigned prefix = 0, need = (unsigned)K;
+    for (int sft = 30; sft >= 0; sft -= 2) {
+        samp_u64_t cnt = 0;
+        auto tally = [&](unsigned k) {
+            const bool m = sft == 30 || (k >> (sft + 2)) == prefix;
+            const unsigned d = (k >> sft) & 3u;
+            cnt += m ? ((samp_u64_t)(d >= 1u) | ((samp_u64_t)(d >= 2u) << 21) | ((samp_u64_t)(d == 3u) << 42)) : 0ull;
+        };
+        if (STREAM) samp_each_key(lg, V, [&](unsigned raw, int) { tally(samp_key_of(__uint_as_float(raw))); });
+        else {
+#pragma unroll
+            for (int k = 0; k < C; k++) if (lo + k < V) tally(key[k]);
+        }
+        const samp_u64_t tot = samp_block_sum_u64(cnt, scr);
+        const unsigned c1 = (unsigned)(tot & 0x1fffffu), c2 = (unsigned)((tot >> 21) & 0x1fffffu), c3 = (unsigned)(tot >> 42);
+        unsigned d;
+        if (c3 >= need) d = 3u;
+        else if (c2 >= need) { d = 2u; need -= c3; }
+        else if (c1 >= need) { d = 1u; need -= c2; }
+        else { d = 0u; need -= c1; }
+        prefix = (prefix << 2) | d;
+    }
+    const unsigned T = prefix;        // need = how many of the keys == T belong to the top K (>= 1)
+    // ---- 3. candidates -> list, by two scans ----
+    unsigned n_eq = 0, n_gt = 0;
+    if (STREAM) samp_each_key(lg, V, [&](unsigned raw, int) { const unsigned k = samp_key_of(__uint_as_float(raw)); n_eq += k == T; n_gt += k > T; });
+    else {
+#pragma unroll
+        for (int k = 0; k < C; k++) if (lo + k < V) { n_eq += key[k] == T; n_gt += key[k] > T; }
+    }
+    // (streamed keys visit a lane in index order within each of its 16-byte loads but the lanes interleave: ranks of equal keys are
+    //  taken in the lane-major order below for the register form, and by index through a second counting pass for the streamed one)
+    unsigned tot_eq, tot_take;
+    unsigned eq_before = samp_block_excl_scan(n_eq, wtot, tot_eq);
+    if (!STREAM) {
+        const unsigned take_eq = eq_before >= need ? 0u : min(n_eq, need - eq_before);
+        unsigned posn = samp_block_excl_scan(n_gt + take_eq, wtot, tot_take);
+        unsigned eq_seen = 0;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            if (lo + k < V) {
+                const bool gt = key[k] > T, eq = key[k] == T;
+                const bool take = gt || (eq && eq_before + eq_seen < need);
+                eq_seen += eq;
+                if (take) { list[min(posn, (unsigned)SAMP_THREADS - 1)] = ((samp_u64_t)key[k] << 32) | (0xffffffffu - (unsigned)(lo + k)); posn++; }
+            }
+        }
+    } else {
+        // streamed: lane order is not index order, so the equal keys are ranked by INDEX: a key == T at index i is taken when fewer
+        // than `need` equal keys have a smaller index -- counted exactly by a pass per candidate would be quadratic; instead the
+        // equal keys' indices go through the same 2-bit selection (the need-th smallest index among them), below
+        unsigned iprefix = 0, ineed = need;         // the ineed-th SMALLEST index among keys == T: select on ~index, largest first
+        for (int sft = 30; sft >= 0; sft -= 2) {
+            samp_u64_t cnt = 0;
+            samp_each_key(lg, V, [&](unsigned raw, int i) {
+                if (samp_key_of(__uint_as_float(raw)) != T) return;
+                const unsigned k = 0xffffffffu - (unsigned)i;
+                const bool m = sft == 30 || (k >> (sft + 2)) == iprefix;
+                const unsigned d = (k >> sft) & 3u;
+                cnt += m ? ((samp_u64_t)(d >= 1u) | ((samp_u64_t)(d >= 2u) << 21) | ((samp_u64_t)(d == 3u) << 42)) : 0ull;
+            });
+            const samp_u64_t tot = samp_block_sum_u64(cnt, scr);
+            const unsigned c1 = (unsigned)(tot & 0x1fffffu), c2 = (unsigned)((tot >> 21) & 0x1fffffu), c3 = (unsigned)(tot >> 42);
+            unsigned d;
+            if (c3 >= ineed) d = 3u;
+            else if (c2 >= ineed) { d = 2u; ineed -= c3; }
+            else if (c1 >= ineed) { d = 1u; ineed -= c2; }
+            else { d = 0u; ineed -= c1; }
+            iprefix = (iprefix << 2) | d;
+        }
+        const unsigned last_idx = 0xffffffffu - iprefix;      // equal keys with index <= last_idx are taken
+        unsigned n_take = 0;
+        samp_each_key(lg, V, [&](unsigned raw, int i) { const unsigned k = samp_key_of(__uint_as_float(raw)); n_take += k > T || (k == T && (unsigned)i <= last_idx); });
+        unsigned posn = samp_block_excl_scan(n_take, wtot, tot_take);
+        samp_each_key(lg, V, [&](unsigned raw, int i) {
+            const unsigned k = samp_key_of(__uint_as_float(raw));
+            if (k > T || (k == T && (unsigned)i <= last_idx)) { list[min(posn, (unsigned)SAMP_THREADS - 1)] = ((samp_u64_t)k << 32) | (0xffffffffu - (unsigned)i); posn++; }
+        });
+    }
+    __syncthreads();
+    // ---- 4. bitonic network, descending, over the first P2 = next_pow2(K) entries (the rest are 0 = below every candidate) ----
+    int P2 = 1;
+    while (P2 < K) P2 <<= 1;
+    for (int size = 2; size <= P2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (tid < (P2 >> 1)) {
+                const int i = ((tid & ~(stride - 1)) << 1) | (tid & (stride - 1)), j = i | stride;
+                const bool desc = (i & size) == 0;
+                const samp_u64_t a = list[i], b = list[j];
+                if ((a < b) == desc) { list[i] = b; list[j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- 5. the Go loop (go/main.go:325-342): probabilities relative to the largest, sequential sums on one lane ----
+    const float v0 = samp_val_of((unsigned)(list[0] >> 32));
+    if (tid < K) prob[tid] = (float)exp((double)((samp_val_of((unsigned)(list[tid] >> 32)) - v0) / P.temp));
+    __syncthreads();
+    if (tid == 0) {
+        float sum = 0.f;
+        for (int i = 0; i < K; i++) sum += prob[i];
+        const float r = u * sum;
+        float cdf = 0.f;
+        int sel = 0;
+        for (int i = 0; i < K; i++) {
+            cdf += prob[i];
+            if (r <= cdf) { sel = i; break; }
+        }
+        s_pick = (int)(0xffffffffu - (unsigned)list[sel]);
+    }
+    __syncthreads();
+    samp_finish(P, s_pick, step);
 }
 
 // ---- top-p without a sort: weighted radix selection in one workgroup -----------------------------------------------
@@ -615,32 +694,6 @@ __global__ void __launch_bounds__(SAMP_THREADS) samp_select_radix_kernel(SampleP
 // of an L2-resident array reach 37 GB/s per compute unit, these 60-110, tools/ingest_probe.hip), eight in flight per lane.
 // Passes over the keys: range, level-1 histogram, one list pass per selection, the pick's id -- five instead of a 2 x 12-launch
 // device-wide sort; everything else is samp_select_radix_kernel's.
-__device__ __forceinline__ uint4 samp_ld_l2(const unsigned *base, unsigned word_off) {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(base), 0, -1, 0x00020000);
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    const v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(word_off * 4u), 0, 16 /* sc1 */);
-    return make_uint4(t.x, t.y, t.z, t.w);
-}
-template <class F>
-__device__ __forceinline__ void samp_each_key(const unsigned *kin, int V, F f) {
-    const int nq = (V + 3) >> 2, tid = threadIdx.x;
-    for (int q0 = 0; q0 < nq; q0 += 8 * SAMP_THREADS) {
-        uint4 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = samp_ld_l2(kin, (unsigned)min(q0 + j * SAMP_THREADS + tid, nq - 1) * 4u);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int q = q0 + j * SAMP_THREADS + tid, i = q * 4;
-            if (q < nq) {
-                f(v[j].x, i);
-                if (i + 1 < V) f(v[j].y, i + 1);
-                if (i + 2 < V) f(v[j].z, i + 2);
-                if (i + 3 < V) f(v[j].w, i + 3);
-            }
-        }
-    }
-}
-
 __global__ void __launch_bounds__(SAMP_THREADS) samp_select_radix_stream_kernel(SampleParams P) {
     __shared__ samp_u64 hw[2048];
     __shared__ unsigned list[SAMP_LIST_CAP];

@@ -101,7 +101,7 @@ class Engine:
         # (the device sampler's select kernel covers vocabularies up to 131072 entries; larger ones take the host loop)
         device_sampling = (not greedy_fast and self.device_sampling and n_prompt > 0 and self.rep_window <= 1024
                            and cfg.vocab_size <= 131072
-                           and p.top_p > 0 and (p.top_p < 1.0 or p.top_k >= 1 or p.temperature <= 0))
+                           and p.top_p > 0 and (p.top_p < 1.0 or 1 <= p.top_k <= 1024 or p.temperature <= 0))
         if greedy_fast and p.max_tokens > 0:
             # sample_0 comes from the prefill logits; sample_k (k >= 1) exists iff k < max_tokens, the
             # k-th Forward left pos + k < SeqLen (go/main.go:216) and sample_{k-1} was not EOS (:203).

@@ -102,47 +102,3 @@ def device_top_p(lg, temp, top_p, u):
     return int(order[pick]), margin
 
 
-def device_top_p_sorted(lg, temp, top_p, u):
-    """The sorted path (NL_SAMP_SORT=1; the top-k branch sorts too): the Go algorithm in nl_sample.h's summation order.
-    Returns (token, boundary_margin): margin = distance of the two threshold tests from their boundaries,
-    relative -- tiny margins are where the Go chain and the chunked chain may legitimately disagree."""
-    if temp <= 0:
-        return int(np.argmax(lg)), 1.0
-    V = lg.size
-    p = _probs(lg, temp)
-    total = np.cumsum(_tree256(p), dtype=np.float32)[-1]
-    inv = F(1.0) / total
-    order = np.argsort(-p, kind="stable")
-    q = (p[order] * inv).astype(np.float32)
-    C = ((V + 1023) // 1024 + 31) // 32 * 32
-    cum = np.empty(V, np.float32)
-    local = np.zeros(1024, np.float32)
-    parts = {}
-    for t in range(1024):
-        lo, hi = min(t * C, V), min(t * C + C, V)
-        if lo < hi:
-            parts[t] = np.cumsum(q[lo:hi], dtype=np.float32)
-            local[t] = parts[t][-1]
-    pw = F(0.0)                                     # prefix over the earlier wavefronts' totals
-    for w in range(16):
-        within = F(0.0)                             # prefix over the earlier lanes of this wavefront
-        for ln in range(64):
-            t = w * 64 + ln
-            pre = F(pw + within)
-            if t in parts:
-                lo = t * C
-                cum[lo:lo + parts[t].size] = (pre + parts[t]).astype(np.float32)
-            if ln == 63:
-                wtot = F(within + local[t])
-            within = F(within + local[t])
-        pw = F(pw + wtot)
-    hit = np.nonzero(cum >= F(top_p))[0]
-    if len(hit) == 0:
-        return int(order[0]), 1.0
-    cut = int(hit[0])
-    r = F(u) * cum[cut]
-    j = np.nonzero(r <= cum[:cut + 1])[0]
-    pick = int(j[0]) if len(j) else 0
-    margin = min(abs(float(cum[cut]) - top_p), abs(float(cum[pick]) - float(r)),
-                 abs(float(cum[pick - 1]) - float(r)) if pick > 0 else 1.0)
-    return int(order[pick]), margin

@@ -106,7 +106,7 @@ def test_top_p_selection_without_a_sort_equals_its_integer_restatement(hip, V):
         assert pick == want, (V, temp, top_p, u, pick, want)
 
 
-@pytest.mark.parametrize("V", [64, 512, 32000])
+@pytest.mark.parametrize("V", [64, 512, 32000, 50000])        # (50000: the keys are streamed out of L2, samp_topk_kernel<true>)
 def test_top_k_is_the_go_loop_exactly(hip, V):
     rng = np.random.default_rng(1000 + V)
     for _ in range(16):
@@ -119,6 +119,29 @@ def test_top_k_is_the_go_loop_exactly(hip, V):
         assert np.array_equal(lg_after, want_lg)
         assert pick == sm.go_top_k(want_lg, temp, k, u)
         assert rec_after == sm.push_recent(recent, pick, window)
+
+
+@pytest.mark.parametrize("V", [2048, 40000])
+def test_top_k_selection_edge_cases(hip, V):
+    # the selection without a sort (samp_topk_kernel): every logit equal (the Go list keeps the FIRST top_k indices), a plateau of
+    # equal logits straddling the k-th place, top_k = 1024 (the device limit) and top_k > V, negative and denormal logits, -inf
+    rng = np.random.default_rng(77 + V)
+    cases = []
+    cases.append((np.full(V, 0.25, np.float32), 50))
+    lg = rng.normal(0, 2, V).astype(np.float32)
+    lg[rng.choice(V, 300, replace=False)] = np.float32(lg.max() - 0.5)       # 300 equal logits around the 50th place
+    cases.append((lg, 50)); cases.append((lg, 7)); cases.append((lg, 1024))
+    neg = -np.abs(rng.normal(0, 3, V)).astype(np.float32)
+    neg[::97] = np.float32(-1e-41)                                           # denormals
+    neg[5::101] = -np.inf
+    cases.append((neg, 200))
+    cases.append((rng.normal(0, 1, V).astype(np.float32), 1))
+    for lg, k in cases:
+        for u in (0.0, 0.31, 0.77, float(np.float32(1.0) - np.float32(2.0 ** -24))):
+            pick = hip.op_sample(lg.copy(), 0.9, 1.0, k, 1.0, 0, u, [])[0]
+            assert pick == sm.go_top_k(lg, 0.9, k, u), (V, k, u)
+    small = rng.normal(0, 1, 64).astype(np.float32)
+    assert hip.op_sample(small.copy(), 0.9, 1.0, 500, 1.0, 0, 0.4, [])[0] == sm.go_top_k(small, 0.9, 500, 0.4)     # top_k > V
 
 
 def test_zero_temperature_is_argmax_of_the_penalised_logits(hip):

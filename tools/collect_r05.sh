@@ -27,6 +27,9 @@ newtests)
   (timeout 1500 python -m pytest tests/test_gpu_tp_fused.py tests/test_gpu_group.py tests/test_gpu_parity.py -q -k "big_attention_geometry or staying_blocks or group or fused_projection_attention_launch" 2>&1 | tail -15) > $O/pytest_newtests2.log; cat $O/pytest_newtests2.log ;;
 newtests_unused)
   (timeout 1500 python -m pytest tests/test_gpu_tp_fused.py -x -q -s -k "big_attention_geometry or keep_out_of" 2>&1 | tail -15) > $O/pytest_newtests.log; cat $O/pytest_newtests.log ;;
+sampling)
+  (timeout 900 python -m pytest tests/test_gpu_sampling.py tests/test_sampling_kat.py -q 2>&1 | tail -8) > $O/pytest_sampling.log; cat $O/pytest_sampling.log
+  python3 tools/bench_sampling.py > $O/r05_bench_sampling.log 2>&1; tail -12 $O/r05_bench_sampling.log ;;
 m4)
   $hip tools/mfma4_probe.hip -o /tmp/m4p 2>/dev/null && /tmp/m4p > $O/r05_mfma4_probe.log 2>&1; cat $O/r05_mfma4_probe.log ;;
 pstamps)
