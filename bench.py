@@ -258,6 +258,19 @@ def measured_traffic(tier, wtype):
     return None, None
 
 
+def persist_traffic_current():
+    """the persistent launch's PMC traffic is reported only while nl_persist.h is the source it was measured on"""
+    from nanollama_amd import _lib
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if "nl_persist_sha16" in tj:
+            return tj["nl_persist_sha16"] == _lib.source_sha([os.path.join(ROOT, "nanollama_amd", "csrc", "nl_persist.h")])
+    return False
+
+
 def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, comm=None, keep=None, shard_of=None, dropin=False):
     """Load the tier's random-weight GGUF, run `warmup` + REPEATS x `steps` chained greedy decode steps, profile the
     launches.  tp=True: the ranks of rdv form one tensor-parallel engine (comm = "p2p" push all-reduce or "rccl");
@@ -370,8 +383,10 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
             gbs = step_bytes * seg / (launch_ms * 1e-3) / 1e9
             kernels["persistent_decode"] = {"launches": round(1.0 / seg, 5), "tokens_per_launch": seg, "us_per_launch": round(launch_ms * 1e3, 2),
                                             "us_per_token": round(launch_ms * 1e3 / seg, 3), "GBps": round(gbs, 1)}
+            ptr = (traffic or {}).get("persistent_decode") or {}
+            ptraffic = ptr.get("bytes_per_launch") if ptr.get("tokens_per_launch") == seg and persist_traffic_current() else None
             persist_roof = {"bound": "hbm", "kernel": "persistent_decode (pd_decode_kernel, nl_persist.h)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
+                            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": ptraffic, "traffic_source": traffic_file if ptraffic else None,
                             "bytes_per_launch": int(step_bytes * seg), "us_per_launch": round(launch_ms * 1e3, 2), "tokens_per_launch": seg,
                             "launches_per_step": round(1.0 / seg, 5), "time_share_of_step": round(min(1.0, launch_ms / seg / ms_per_step), 3),
                             "note": "one launch decodes the whole segment with the weights resident on chip; bytes are the algorithmic bytes of its tokens"}

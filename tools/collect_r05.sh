@@ -27,6 +27,51 @@ newtests)
   (timeout 1500 python -m pytest tests/test_gpu_tp_fused.py tests/test_gpu_group.py tests/test_gpu_parity.py -q -k "big_attention_geometry or staying_blocks or group or fused_projection_attention_launch" 2>&1 | tail -15) > $O/pytest_newtests2.log; cat $O/pytest_newtests2.log ;;
 newtests_unused)
   (timeout 1500 python -m pytest tests/test_gpu_tp_fused.py -x -q -s -k "big_attention_geometry or keep_out_of" 2>&1 | tail -15) > $O/pytest_newtests.log; cat $O/pytest_newtests.log ;;
+prof)
+  # rocprofv3 per-kernel stats of the driver's own bench command (nano: the persistent launch) and of big; HBM traffic counters, one PMC pass per counter
+  rm -rf gpurun_out/prof5; mkdir -p gpurun_out/prof5
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof5 -o nano -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > gpurun_out/prof5/nano.log 2>&1 < /dev/null
+  NL_NO_GRAPH=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof5 -o big -- python3 bench.py --workload big:q4_0 --steps 64 --warmup 8 --no-cpu-baseline > gpurun_out/prof5/big.log 2>&1 < /dev/null
+  for t in nano big; do f=$(ls gpurun_out/prof5/${t}_kernel_stats.csv gpurun_out/prof5/*/${t}_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $O/r05_${t}_kernel_stats.csv && head -8 "$f" | cut -c1-170; done
+  grep '^{' gpurun_out/prof5/nano.log | tail -1 > $O/r05_bench_n1_steps20_under_rocprof.json.log
+  # every dispatch of the persistent launch in order (the bench issues 1 x 128 tokens, 1 x 5 (warm-up), 5 x 20 timed, 7 x 20 profiled)
+  python3 - $(ls gpurun_out/prof5/nano_kernel_trace.csv gpurun_out/prof5/*/nano_kernel_trace.csv 2>/dev/null | head -1) > $O/r05_nano_pd_decode_dispatch_durations.csv <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "pd_decode_kernel" in r.get("Kernel_Name", "")]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+print("dispatch,duration_us")
+for i, r in enumerate(rows):
+    print(f'{i},{(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3:.2f}')
+PY
+  cat $O/r05_nano_pd_decode_dispatch_durations.csv | tr '\n' ' '; echo
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    out=gpurun_out/pmc5_$ctr; rm -rf $out; mkdir -p $out
+    timeout 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out -o p -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $out/log.txt 2>&1 < /dev/null
+    f=$(ls $out/*counter_collection.csv $out/*/*counter_collection.csv 2>/dev/null | head -1)
+    if [ -n "$f" ]; then python3 - "$f" "$ctr" > $O/r05_nano_q8_0_pmc_${ctr}.csv <<'PY'
+import csv, sys, collections
+f, ctr = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(lambda: [0, 0.0])
+with open(f) as fh:
+    for row in csv.DictReader(fh):
+        if row.get("Counter_Name") != ctr: continue
+        k = row["Kernel_Name"]
+        acc[k][0] += 1; acc[k][1] += float(row["Counter_Value"])
+print("kernel,dispatches,mean_" + ctr)
+for k, (n, s) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+    print(f'"{k}",{n},{s / n:.3f}')
+# the persistent launch dispatch by dispatch (dispatch order = Dispatch_Id)
+with open(f) as fh:
+    pd = sorted(((int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(fh)
+                 if r.get("Counter_Name") == ctr and "pd_decode_kernel" in r["Kernel_Name"]))
+for i, (_, v) in enumerate(pd):
+    print(f'"pd_decode_kernel dispatch {i}",1,{v:.3f}')
+PY
+      head -4 $O/r05_nano_q8_0_pmc_${ctr}.csv | cut -c1-160; grep "pd_decode_kernel dispatch" $O/r05_nano_q8_0_pmc_${ctr}.csv | tr '\n' ' '; echo
+    else tail -5 $out/log.txt; fi
+    rm -rf $out
+  done
+  rm -rf gpurun_out/prof5 ;;
 sampling)
   (timeout 900 python -m pytest tests/test_gpu_sampling.py tests/test_sampling_kat.py -q 2>&1 | tail -8) > $O/pytest_sampling.log; cat $O/pytest_sampling.log
   python3 tools/bench_sampling.py > $O/r05_bench_sampling.log 2>&1; tail -12 $O/r05_bench_sampling.log ;;

@@ -41,11 +41,33 @@ def load(tag, ctr):
     return out
 
 
+def persistent(tag, tokens_per_launch):
+    """the persistent decode launch (nl_persist.h): the per-dispatch rows of tools/collect_r05.sh; the steady-state launch is the median
+    dispatch (twelve of the fourteen are the bench's 20-token segments; the 128-token and the warm-up launch differ)"""
+    import collections
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        path = os.path.join(ROOT, "profiles", f"{ROUND}_{tag}_pmc_{ctr}.csv")
+        if not os.path.exists(path):
+            return None
+        with open(path) as fh:
+            v = [float(r["mean_" + ctr]) for r in csv.DictReader(fh) if r["kernel"].startswith("pd_decode_kernel dispatch")]
+        if not v:
+            return None
+        vals[ctr] = sorted(v)[len(v) // 2]          # the median dispatch: one of the bench's equal segments
+    return {"bytes_per_launch": int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024), "tokens_per_launch": tokens_per_launch,
+            "fetch_bytes": int(vals["FETCH_SIZE"] * 1024 * 2), "write_bytes": int(vals["WRITE_SIZE"] * 1024)}
+
+
 res = {"_doc": "HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE KiB x1024 x2 [gfx950 correction] + WRITE_SIZE KiB x1024); "
                f"tools/make_traffic_json.py from profiles/{ROUND}_*_pmc_*.csv",
        "nl_kernels_sha16": _lib.source_sha([os.path.join(ROOT, "nanollama_amd", "csrc", "nl_kernels.h")])}
 for tag in ("nano_q8_0", "big_q4_0"):
     f, w = load(tag, "FETCH_SIZE"), load(tag, "WRITE_SIZE")
     res[tag] = {k: int(round(f[k] * 1024 * 2 + w.get(k, 0.0) * 1024)) for k in f}
+pd = persistent("nano_q8_0", int(sys.argv[2]) if len(sys.argv) > 2 else 20)
+if pd:
+    res["nano_q8_0"]["persistent_decode"] = pd
+    res["nl_persist_sha16"] = _lib.source_sha([os.path.join(ROOT, "nanollama_amd", "csrc", "nl_persist.h")])
 json.dump(res, open(os.path.join(ROOT, "profiles", f"{ROUND}_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
