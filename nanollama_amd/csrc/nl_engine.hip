@@ -296,7 +296,7 @@ struct nl_engine {
         uint8_t *lm_raw = nullptr;
         uint4 *wimg = nullptr, *lmimg = nullptr;
         unsigned short *simg = nullptr, *lmsimg = nullptr;
-        pd_u64 *gx = nullptr, *go = nullptr, *gxp = nullptr, *gh = nullptr;
+        pd_u64 *gx = nullptr, *gqkv = nullptr, *go = nullptr, *gxp = nullptr, *gh = nullptr;
         pd_u32x4 *gam = nullptr;
         unsigned *census = nullptr, *status = nullptr, *h_status = nullptr;
         float *norms = nullptr;      // [L][2][D] + [D]: attn_norm | ffn_norm of every layer, output_norm (one pointer for the kernel)
@@ -1208,7 +1208,7 @@ void pd_free_raw(nl_engine *e) {
 void pd_free(nl_engine *e) {
     pd_free_raw(e);
     nl_engine::Persist &d = e->pd;
-    void *bufs[] = {d.wimg, d.lmimg, d.simg, d.lmsimg, d.gx, d.go, d.gxp, d.gh, d.gam, d.census, d.status, d.dbg, d.norms};
+    void *bufs[] = {d.wimg, d.lmimg, d.simg, d.lmsimg, d.gx, d.gqkv, d.go, d.gxp, d.gh, d.gam, d.census, d.status, d.dbg, d.norms};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (d.h_status) (void)hipHostFree(d.h_status);
     d = nl_engine::Persist{};
@@ -1245,6 +1245,8 @@ int pd_build(nl_engine *e) {
     const size_t L1 = (size_t)c.n_layers + 1;
     HIPCK(e, dalloc(&d.gx, L1 * c.dim, &e->bytes_state));
     HIPCK(e, dalloc(&d.go, L1 * c.dim, &e->bytes_state));
+    HIPCK(e, dalloc(&d.gqkv, L1 * 3 * c.dim, &e->bytes_state));
+    HIPCK(e, hipMemset(d.gqkv, 0, L1 * 3 * c.dim * 8));
     HIPCK(e, dalloc(&d.gxp, L1 * c.dim, &e->bytes_state));
     HIPCK(e, dalloc(&d.gh, L1 * c.interm, &e->bytes_state));
     HIPCK(e, dalloc(&d.gam, (size_t)PD_GRID, &e->bytes_state));
@@ -1288,6 +1290,7 @@ int pd_launch(nl_engine *e, int stream, int token, int pos, int n) {
     if (d.tag_base > 0xf0000000u) {      // (tags never repeat inside the life of the areas: start over from clean ones)
         const size_t L1 = (size_t)c.n_layers + 1;
         HIPCK(e, hipMemsetAsync(d.gx, 0, L1 * c.dim * 8, e->stream)); HIPCK(e, hipMemsetAsync(d.go, 0, L1 * c.dim * 8, e->stream));
+        HIPCK(e, hipMemsetAsync(d.gqkv, 0, L1 * 3 * c.dim * 8, e->stream));
         HIPCK(e, hipMemsetAsync(d.gxp, 0, L1 * c.dim * 8, e->stream)); HIPCK(e, hipMemsetAsync(d.gh, 0, L1 * c.interm * 8, e->stream));
         HIPCK(e, hipMemsetAsync(d.gam, 0, (size_t)PD_GRID * 16, e->stream));
         d.tag_base = 0;
@@ -1305,7 +1308,7 @@ int pd_launch(nl_engine *e, int stream, int token, int pos, int n) {
     P.rope_cos = e->rope_cos; P.rope_sin = e->rope_sin;
     P.kcache = e->kcache + (long long)stream * e->kv_stream_stride; P.vcache = e->vcache + (long long)stream * e->kv_stream_stride;
     P.kv_layer_stride = e->kv_layer_stride;
-    P.gx = d.gx; P.go = d.go; P.gxp = d.gxp; P.gh = d.gh; P.gam = d.gam;
+    P.gx = d.gx; P.gqkv = d.gqkv; P.go = d.go; P.gxp = d.gxp; P.gh = d.gh; P.gam = d.gam;
     P.census = d.census; P.ids_out = e->ids; P.logits = e->logits;
     P.status = d.status; P.host_status = d.h_status; P.dbg = d.dbg;
     if (c.dim == 576) hipLaunchKernelGGL((pd_decode_kernel<18, 48>), dim3(PD_GRID), dim3(PD_THREADS), pd_lds_bytes(), e->stream, P);

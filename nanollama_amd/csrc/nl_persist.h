@@ -40,25 +40,24 @@ typedef unsigned pd_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned pd_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PD_THREADS = 512, PD_WAVES = 8, PD_XCDS = 8, PD_CUS = 32, PD_GRID = PD_XCDS * PD_CUS;
-constexpr int PD_UQ = 7;      // unit slots per lane of a head: Q | K | V rows of one head (192 rows x D / 32 blocks <= 7 x 512)
-constexpr int PD_UW = 1, PD_UG = 5, PD_UD = 3;   // ... of a worker: WO rows, gate + up rows, down rows
-constexpr int PD_UNITS = 9;   // max(PD_UQ, PD_UW + PD_UG + PD_UD): registers hold 9 units of 32 int8 + an fp16 scale per layer slot
+constexpr int PD_UQ = 2, PD_UW = 1, PD_UG = 4, PD_UD = 2;   // unit slots per lane: this unit's rows of Q | K | V, of WO, of gate + up, of down
+constexpr int PD_UNITS = PD_UQ + PD_UW + PD_UG + PD_UD;   // 9: the registers hold 9 units of 32 int8 per layer slot (their fp16 scales sit in LDS)
 constexpr int PD_ULM = 5;     // LM-head unit slots per lane (LDS)
 constexpr int PD_SLOTS = 2;   // layers per XCD
 constexpr int PD_MAXL = PD_SLOTS * PD_XCDS;
 constexpr int PD_MAXD = 576, PD_MAXI = 1536, PD_NBD_MAX = PD_MAXD / 32, PD_NBI_MAX = PD_MAXI / 32;
-constexpr int PD_PART = 192 * (PD_NBD_MAX + 1) + 64;   // floats: block products of the largest phase (Q | K | V), rows padded to an odd pitch
+constexpr int PD_PART = 128 * (PD_NBD_MAX + 1) + 128;  // floats: block products of the largest phase (the LM head's 128 rows), rows padded to an odd pitch
 constexpr int PD_MAX_PASSES = 4;                       // attention passes of 128 positions: contexts below 512
 constexpr int PD_MAX_POS = PD_MAX_PASSES * 128;
 
 // ---- who holds what (host packer and kernel share these) -----------------------------------------------------------------
 __host__ __device__ inline int pd_nslots(int L, int xcd) { return L / PD_XCDS + (xcd < L % PD_XCDS ? 1 : 0); }
 __host__ __device__ inline int pd_first(int L, int xcd) { return xcd * (L / PD_XCDS) + (xcd < L % PD_XCDS ? xcd : L % PD_XCDS); }
-// slot 0: heads are units 0 .. H-1 of the XCD, slot 1: units 32-H .. 31 -- a unit is a head in at most one slot (H <= 16)
+// Every matrix of a layer is split by rows over ALL 32 units of the layer's XCD (unit idx: rows [idx * R / 32, (idx + 1) * R / 32));
+// H of the units additionally run the attention of one head each -- slot 0: units 0 .. H-1, slot 1: units 32-H .. 31, so that a
+// unit is a head in at most one slot (H <= 16)
 __host__ __device__ inline bool pd_is_head(int slot, int idx, int H) { return slot == 0 ? idx < H : idx >= PD_CUS - H; }
 __host__ __device__ inline int pd_head_index(int slot, int idx, int H) { return slot == 0 ? idx : idx - (PD_CUS - H); }
-__host__ __device__ inline int pd_worker_index(int slot, int idx, int H) { return slot == 0 ? idx - H : idx; }
-__host__ __device__ inline int pd_split(int n, int parts, int i) { return (int)(((long long)n * i) / parts); }   // first row of part i
 __host__ __device__ inline int pd_lm_rows(int V) { return (V + PD_GRID - 1) / PD_GRID; }
 __host__ __device__ inline int pd_pad4(int n) { return (n + 3) & ~3; }
 // Unit u of a phase = lane (u & 3) of a group of four lanes that share one 32-column block: rows 4 * (G / NB) + (u & 3) of this
@@ -68,15 +67,10 @@ __host__ __device__ inline void pd_unit_rc(int u, int NB, int &row, int &blk) { 
 inline bool pd_shape_ok(int D, int I, int H, int KV, int hd, int V, int L) {
     if (hd != 64 || KV != H || D != H * 64 || D % 32 || I % 32 || H < 1 || H > 16 || L < 1 || L > PD_MAXL) return false;
     if (!((D == 576 && I == 1536) || (D == 256 && I == 512))) return false;     // the instantiations of pd_decode_kernel (nano's shape; a small test shape)
-    const int NB = D / 32, NBI = I / 32, NWK = PD_CUS - H;
-    int rw = 0, rg = 0;
-    for (int w = 0; w < NWK; w++) {
-        rw = rw > pd_split(D, NWK, w + 1) - pd_split(D, NWK, w) ? rw : pd_split(D, NWK, w + 1) - pd_split(D, NWK, w);
-        rg = rg > pd_split(I, NWK, w + 1) - pd_split(I, NWK, w) ? rg : pd_split(I, NWK, w + 1) - pd_split(I, NWK, w);
-    }
-    rw = pd_pad4(rw); rg = pd_pad4(rg);
-    if (192 * NB > PD_UQ * PD_THREADS || rw * NB > PD_UW * PD_THREADS || 2 * rg * NB > PD_UG * PD_THREADS || rw * NBI > PD_UD * PD_THREADS) return false;
-    if (2 * rg > 256 || 4 * rw > PD_THREADS || 2 * rg * (NB + 1) > PD_PART || rw * (NBI + 1) > PD_PART) return false;
+    if ((3 * D) % PD_CUS || D % PD_CUS || I % PD_CUS) return false;              // equal row shares
+    const int NB = D / 32, NBI = I / 32, qr = pd_pad4(3 * D / PD_CUS), wr = pd_pad4(D / PD_CUS), gr = pd_pad4(I / PD_CUS);
+    if (qr * NB > PD_UQ * PD_THREADS || wr * NB > PD_UW * PD_THREADS || 2 * gr * NB > PD_UG * PD_THREADS || wr * NBI > PD_UD * PD_THREADS) return false;
+    if (4 * qr > PD_THREADS || 4 * gr > PD_THREADS || 4 * wr > PD_THREADS || 2 * gr * (NB + 1) > PD_PART || wr * (NBI + 1) > PD_PART || qr * (NB + 1) > PD_PART) return false;
     const int lr = pd_pad4(pd_lm_rows(V));
     return lr <= 128 && lr * NB <= PD_ULM * PD_THREADS && lr * (NB + 1) <= PD_PART;
 }
@@ -103,6 +97,7 @@ struct PdParams {
     float *kcache, *vcache;          // layer 0 of the stream: [kv head][seq][64]
     long long kv_layer_stride;
     pd_u64 *gx;                      // [L + 1][D]: input x of layer l >= 1; [L] = the final residual stream
+    pd_u64 *gqkv;                    // [L][3 D]: q | k | v rows of the position before RoPE (row-split over the XCD's units, read by the heads)
     pd_u64 *go, *gxp;                // [L][D]: heads' attention outputs; x' = x + WO o
     pd_u64 *gh;                      // [L][I]: SiLU(gate) * up
     pd_u32x4 *gam;                   // [256] {tag, max bits, index, -}
@@ -124,42 +119,37 @@ struct PdPackParams {
 // grid (256, 2 * 9 + 5), 512 threads.
 __global__ void __launch_bounds__(PD_THREADS) pd_pack_kernel(PdPackParams P) {
     const int cu = blockIdx.x, xcd = cu / PD_CUS, idx = cu % PD_CUS, unit = blockIdx.y, tid = threadIdx.x;
-    const int NB = P.D / 32, NBI = P.I / 32, NWK = PD_CUS - P.H;
+    const int NB = P.D / 32, NBI = P.I / 32;
     const uint8_t *src = nullptr;     // the 34-byte block, or null = zeros
     if (unit < PD_SLOTS * PD_UNITS) {
         const int s = unit / PD_UNITS, k = unit % PD_UNITS;
         if (s < pd_nslots(P.L, xcd)) {
             const int layer = pd_first(P.L, xcd) + s;
-            if (pd_is_head(s, idx, P.H)) {
-                const int h = pd_head_index(s, idx, P.H), u = k * PD_THREADS + tid;
-                if (k < PD_UQ && u < 192 * NB) {
-                    int row, blk;
-                    pd_unit_rc(u, NB, row, blk);
-                    const int sect = row >> 6, e = row & 63;
-                    src = P.raw[layer][sect] + ((size_t)(h * 64 + e) * NB + blk) * 34;
+            const int qr = 3 * P.D / PD_CUS, wr = P.D / PD_CUS, gr = P.I / PD_CUS;       // this unit's rows of Q | K | V, of WO / down, of gate / up
+            int row, blk;
+            if (k < PD_UQ) {
+                const int u = k * PD_THREADS + tid;
+                pd_unit_rc(u, NB, row, blk);
+                if (u < pd_pad4(qr) * NB && row < qr) {
+                    const int R = idx * qr + row, sect = R / P.D;          // row R of [q; k; v]
+                    src = P.raw[layer][sect] + ((size_t)(R - sect * P.D) * NB + blk) * 34;
+                }
+            } else if (k < PD_UQ + PD_UW) {
+                const int u = (k - PD_UQ) * PD_THREADS + tid;
+                pd_unit_rc(u, NB, row, blk);
+                if (u < pd_pad4(wr) * NB && row < wr) src = P.raw[layer][3] + ((size_t)(idx * wr + row) * NB + blk) * 34;
+            } else if (k < PD_UQ + PD_UW + PD_UG) {
+                const int u = (k - PD_UQ - PD_UW) * PD_THREADS + tid, grp = pd_pad4(gr);
+                pd_unit_rc(u, NB, row, blk);
+                if (u < 2 * grp * NB) {            // rows [0, grp): gate, [grp, 2 grp): up -- padding rows stay zero
+                    const bool up = row >= grp;
+                    const int rr = up ? row - grp : row;
+                    if (rr < gr) src = P.raw[layer][up ? 5 : 4] + ((size_t)(idx * gr + rr) * NB + blk) * 34;
                 }
             } else {
-                const int w = pd_worker_index(s, idx, P.H);
-                const int r0 = pd_split(P.D, NWK, w), nr = pd_split(P.D, NWK, w + 1) - r0, g0 = pd_split(P.I, NWK, w), rg = pd_split(P.I, NWK, w + 1) - g0;
-                const int nrp = pd_pad4(nr), rgp = pd_pad4(rg);
-                int row, blk;
-                if (k < PD_UW) {
-                    const int u = k * PD_THREADS + tid;
-                    pd_unit_rc(u, NB, row, blk);
-                    if (u < nrp * NB && row < nr) src = P.raw[layer][3] + ((size_t)(r0 + row) * NB + blk) * 34;
-                } else if (k < PD_UW + PD_UG) {
-                    const int u = (k - PD_UW) * PD_THREADS + tid;
-                    pd_unit_rc(u, NB, row, blk);
-                    if (u < 2 * rgp * NB) {            // rows [0, rgp): gate, [rgp, 2 rgp): up -- the padding rows stay zero
-                        const bool up = row >= rgp;
-                        const int rr = up ? row - rgp : row;
-                        if (rr < rg) src = P.raw[layer][up ? 5 : 4] + ((size_t)(g0 + rr) * NB + blk) * 34;
-                    }
-                } else {
-                    const int u = (k - PD_UW - PD_UG) * PD_THREADS + tid;
-                    pd_unit_rc(u, NBI, row, blk);
-                    if (u < nrp * NBI && row < nr) src = P.raw[layer][6] + ((size_t)(r0 + row) * NBI + blk) * 34;
-                }
+                const int u = (k - PD_UQ - PD_UW - PD_UG) * PD_THREADS + tid;
+                pd_unit_rc(u, NBI, row, blk);
+                if (u < pd_pad4(wr) * NBI && row < wr) src = P.raw[layer][6] + ((size_t)(idx * wr + row) * NBI + blk) * 34;
             }
         }
     } else {
@@ -468,7 +458,8 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
     unsigned short *wsl = reinterpret_cast<unsigned short *>(hs + 60);                     // [2][9][512] fp16 d of the register-resident units (registers hold the quants only)
 
     const int tid0 = threadIdx.x;
-    constexpr int D = NB * 32, I = NBI * 32, H = D / 64, NWK = PD_CUS - H, NBP = NB | 1, NBIP = NBI | 1;
+    constexpr int D = NB * 32, I = NBI * 32, H = D / 64, NBP = NB | 1, NBIP = NBI | 1;
+    constexpr int QR = 3 * D / PD_CUS, QRP = (QR + 3) & ~3, WR = D / PD_CUS, WRP = (WR + 3) & ~3, GR = I / PD_CUS, GRP = (GR + 3) & ~3;   // this unit's rows per matrix
     const int L = P0.L;
     unsigned xcd;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcd));
@@ -620,11 +611,9 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
             const int layer = first + s;
             const bool head = pd_is_head(s, idx, H);
             const bool next_here = s + 1 < nslots;           // the next layer lives on this XCD
-            const int sb = s == 0 ? (head ? 8 : 24) : 63;     // stamp base (slot 0 only)
+            const int sb = s == 0 ? 8 : 63;                  // stamp base (slot 0 of XCD 1, unit 0: a head)
             (void)sb;
-            if (s == 0 && (idx == 0 || idx == H)) PD_ST(sb, 0);
-            // heads: the first 128 cache rows of the head are requested before anything is waited for (rows >= pos repeat row
-            // pos - 1 .. the row of this position comes from LDS)
+            if (s == 0 && idx == 0) PD_ST(sb, 0);
             const int hidx = pd_head_index(s, idx, H);
             float *const kc = P.kcache + (long long)layer * P.kv_layer_stride + (long long)(head ? hidx : 0) * P.seq_len * 64;
             float *const vc = P.vcache + (long long)layer * P.kv_layer_stride + (long long)(head ? hidx : 0) * P.seq_len * 64;
@@ -633,28 +622,28 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
             float4 kreg[4], vreg[4];
             // (norm weights are requested before the polls they would otherwise wait behind)
             const float ga0 = P.norms[(size_t)(layer * 2) * D + c0], ga1 = P.norms[(size_t)(layer * 2) * D + c1];
-            // ---- x of this layer: every unit of the XCD needs it (heads: the projection input; workers: the residual) ----
+            // ---- x of this layer (go/model.go:517): every unit of the XCD projects its rows of Q | K | V and adds residuals ----
             if (layer > 0) {
                 float xv[2];
                 pd_gather<2>(P.gx + (size_t)layer * D, D, tag, xv, Q, 1u, tid);
                 xa = xv[0]; xb = xv[1];
             }
-            if (s == 0 && (idx == 0 || idx == H)) PD_ST(sb, 1);
+            if (s == 0 && idx == 0) PD_ST(sb, 1);
             if (v0) xraw[e0] = xa;
             if (v1) xraw[e1] = xb;
-            if (head) {
-                pd_limbs(xa * ga0, v0, e0, xl, xs, lane);
-                if (wave * 64 + PD_THREADS < D) pd_limbs(xb * ga1, v1, e1, xl, xs, lane);      // (wave-uniform: the wavefronts that hold second elements)
-                const float inv = pd_inv_rms(xa, xb, v0, v1, lane, wave, dred, D, P.eps);            // (its barrier also publishes xT)
+            pd_limbs(xa * ga0, v0, e0, xl, xs, lane);
+            if (wave * 64 + PD_THREADS < D) pd_limbs(xb * ga1, v1, e1, xl, xs, lane);      // (wave-uniform: the wavefronts that hold second elements)
+            {
+                const float inv = pd_inv_rms(xa, xb, v0, v1, lane, wave, dred, D, P.eps);   // (its barrier also publishes the digit image)
                 if (misc[2]) return;
-                // ---- Q | K | V rows of this head (go/model.go:517-523) ----
                 if (s == 0 && idx == 0) PD_ST(sb, 2);
-                float ec = 0.f, es = 0.f;      // (requested before the products: the rotation below must not wait for them)
-                if (tid < 256) { ec = P.rope_cos[pos * 32 + ((tid & 127) >> 2)]; es = P.rope_sin[pos * 32 + ((tid & 127) >> 2)]; }
-                pd_units<0, PD_UQ, NB>(wlo[s], whi[s], wsl + s * PD_UNITS * PD_THREADS, reinterpret_cast<const uint4 *>(xl), xs, 192 * NB, part, tid);
+                // ---- this unit's rows of [Q; K; V] (go/model.go:517-523): 3 D / 32 rows ----
+                float ec = 0.f, es = 0.f;      // (heads: requested before the products, the rotation below must not wait for them)
+                if (head && tid < 128) { ec = P.rope_cos[pos * 32 + (tid & 31)]; es = P.rope_sin[pos * 32 + (tid & 31)]; }
+                pd_units<0, PD_UQ, NB>(wlo[s], whi[s], wsl + s * PD_UNITS * PD_THREADS, reinterpret_cast<const uint4 *>(xl), xs, QRP * NB, part, tid);
                 if (s == 0 && idx == 0) PD_ST(sb, 3);
-                {   // the first 128 cache rows of the head are requested behind the dot products (rows >= pos repeat row pos,
-                    // the row of this position comes from LDS): they arrive during the row sums and the rotation
+                if (head) {   // the first 128 cache rows of the head are requested behind the dot products (rows >= pos repeat row pos,
+                              // the row of this position comes from LDS): they arrive during the row sums and the exchange
                     const int lim = min(min(128, P.seq_len), pos + 1);
                     const unsigned krow = (unsigned)min(wave * 16 + kr, lim - 1) * 16u + (unsigned)kq * 4u;
 #pragma unroll
@@ -665,111 +654,127 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 }
                 __syncthreads();
                 PD_RELANE();
-                // row sums, RoPE (go/model.go:449-477: pairs (i, i + 32)) and the KV store (go/model.go:552-554) without a round
-                // trip through LDS: a quad of lanes = rows i and i + 32 of q (threads 0-127) or k (128-255), two lanes per row; v
-                // rows: threads 256-383, two lanes per row
-                if (tid < 256) {
-                    const int sect = tid >> 7, i = (tid & 127) >> 2, up = (tid >> 1) & 1, e = i + 32 * up;
-                    const float own = pd_rowsum<NB, 2>(part + (sect * 64 + e) * NBP, tid & 1) * inv;
-                    const float other = dpp_f32<DPP_QUAD_XOR2>(own);
-                    const float x0 = up ? other : own, x1 = up ? own : other;
-                    float o;
-                    if (!P.rope_conj) o = up ? (x0 * es + x1 * ec) : (x0 * ec - x1 * es);
-                    else o = up ? (-x0 * es + x1 * ec) : (x0 * ec + x1 * es);
-                    if (!(tid & 1)) {
-                        qs[sect * 64 + e] = o;
-                        if (sect == 1) kc[(long long)pos * 64 + e] = o;
-                    }
-                } else if (tid < 384) {
-                    const int e = (tid - 256) >> 1;
-                    const float v = pd_rowsum<NB, 2>(part + (128 + e) * NBP, tid & 1) * inv;
-                    if (!(tid & 1)) { qs[128 + e] = v; vc[(long long)pos * 64 + e] = v; }
+                if (tid < 4 * QR) {       // four lanes per row; the row leaves for the head that owns it (before RoPE)
+                    const float v = pd_rowsum<NB, 4>(part + (tid >> 2) * NBP, tid & 3) * inv;
+                    if (!(tid & 3)) pd_publish<false>(P.gqkv + (size_t)layer * 3 * D + idx * QR + (tid >> 2), tag, v);
                 }
-                __syncthreads();
-                PD_RELANE();
-                // ---- softmax attention over positions 0 .. pos (go/model.go:557-587), 128 positions per pass: nl_block.h's
-                //      one-barrier pass (every wavefront reduces its 16 positions to one (max, sum, sum p v) partial) ----
-                if (s == 0 && idx == 0) PD_ST(sb, 4);
-                const int nch = pos / 128 + 1;
-                for (int ch = 0; ch < nch; ch++) {
-                    const int t0 = ch * 128, n = min(128, pos + 1 - t0);
-                    if (ch > 0) {       // (a later pass fetches its rows at its start: a prefetch a pass ahead costs 16 registers this kernel lacks)
-#pragma unroll
-                        for (int kk = 0; kk < 4; kk++) {
-                            kreg[kk] = pd_ld16f(kr_, (unsigned)((t0 + min(wave * 16 + kr, n - 1)) * 16 + kq * 4 + kk) * 16u);
-                            vreg[kk] = pd_ld16f(vr_, (unsigned)((t0 + min(wave * 16 + 4 * vg + kk, n - 1)) * 16 + vcl) * 16u);
+                if (head) {
+                    // ---- the head's q | k | v of this position: 192 granules; RoPE (go/model.go:449-477: pairs (i, i + 32) = lanes
+                    //      l, l ^ 32 of a wavefront), KV store (go/model.go:552-554) ----
+                    if (tid < 192) {
+                        const int sect = tid >> 6, e = tid & 63;
+                        const __amdgpu_buffer_rsrc_t r = pd_rsrc(P.gqkv + (size_t)layer * 3 * D, 3u * D * 8u);
+                        const unsigned off = (unsigned)(sect * D + hidx * 64 + e) * 8u;
+                        pd_u64 g;
+                        for (int spins = 0;; spins++) {
+                            g = pd_ld8(r, off);
+                            if (__all((unsigned)(g >> 32) == tag)) break;
+                            if (spins >= Q.spin_limit || ((spins & 63) == 63 && __hip_atomic_load(Q.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                                pd_give_up(Q, 32u, tid);
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
                         }
+                        const float v = __uint_as_float((unsigned)g);
+                        float o = v;
+                        if (sect < 2) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                            const float x0 = __uint_as_float(sw[0]), x1 = __uint_as_float(sw[1]);      // elements i and i + 32 of the head, in every lane
+                            const int up = e >> 5;
+                            if (!P.rope_conj) o = up ? (x0 * es + x1 * ec) : (x0 * ec - x1 * es);
+                            else o = up ? (-x0 * es + x1 * ec) : (x0 * ec + x1 * es);
+                        }
+                        qs[tid] = o;
+                        if (sect == 1) kc[(long long)pos * 64 + e] = o;
+                        if (sect == 2) vc[(long long)pos * 64 + e] = o;
                     }
-                    const int krow = wave * 16 + kr;
-                    const bool kcurrow = t0 + krow == pos;
-                    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) {
-                        const float4 q4 = *reinterpret_cast<const float4 *>(qs + kq * 16 + kk * 4);
-                        const float4 kc4 = *reinterpret_cast<const float4 *>(kcur + kq * 16 + kk * 4);
-                        const float4 k4 = kcurrow ? kc4 : kreg[kk];
-                        d0 = fmaf(q4.x, k4.x, d0); d1 = fmaf(q4.y, k4.y, d1); d2 = fmaf(q4.z, k4.z, d2); d3 = fmaf(q4.w, k4.w, d3);
-                    }
-                    const float sv = krow < n ? quad_sum((d0 + d1) + (d2 + d3)) * P.scale : -INFINITY;
-                    const float mw = wave_max_f32(sv);
-                    const float p = krow < n ? pd_exp(sv - (mw == -INFINITY ? 0.f : mw)) : 0.f;
-                    const float lw = wave_sum_f32(kq == 0 ? p : 0.f);
-                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float4 vc4 = *reinterpret_cast<const float4 *>(vcur + vcl * 4);
-                    // the probabilities of this wavefront's 16 rows meet through LDS (one write, one 16-byte read: the lane's V rows
-                    // 4 vg .. 4 vg + 3 are consecutive; the LDS serves a wavefront's operations in order)
-                    if (kq == 0) wpart[wave * 68 + 48 + kr] = p;       // (columns 48 .. 63 of the wavefront's partial row: rewritten below)
-                    const float4 pw4 = *reinterpret_cast<const float4 *>(wpart + wave * 68 + 48 + 4 * vg);
-                    const float pw[4] = {pw4.x, pw4.y, pw4.z, pw4.w};
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) {
-                        const bool vcurrow = t0 + wave * 16 + 4 * vg + kk == pos;
-                        const float4 v4 = vcurrow ? vc4 : vreg[kk];
-                        o.x = fmaf(pw[kk], v4.x, o.x); o.y = fmaf(pw[kk], v4.y, o.y); o.z = fmaf(pw[kk], v4.z, o.z); o.w = fmaf(pw[kk], v4.w, o.w);
-                    }
-                    o.x = pd_rows4_sum(o.x); o.y = pd_rows4_sum(o.y); o.z = pd_rows4_sum(o.z); o.w = pd_rows4_sum(o.w);
-                    if (lane < 16) *reinterpret_cast<float4 *>(wpart + wave * 68 + 4 + vcl * 4) = o;
-                    if (lane == 0) { wpart[wave * 68] = mw; wpart[wave * 68 + 1] = lw; }
                     __syncthreads();
                     PD_RELANE();
-                    if (wave == 0) {
-                        const float mwv = lane < 8 ? wpart[min(lane, 7) * 68] : -INFINITY;
-                        const float M = wave_max_f32(mwv);
-                        const float wgt = (lane < 8 && mwv != -INFINITY) ? __expf(mwv - M) : 0.f;
-                        const float Ls = wave_sum_f32(lane < 8 ? wgt * wpart[min(lane, 7) * 68 + 1] : 0.f);
-                        float ov = 0.f;
+                    if (misc[2]) return;
+                // ---- softmax attention over positions 0 .. pos (go/model.go:557-587), 128 positions per pass: nl_block.h's
+                    //      one-barrier pass (every wavefront reduces its 16 positions to one (max, sum, sum p v) partial) ----
+                    if (s == 0 && idx == 0) PD_ST(sb, 4);
+                    const int nch = pos / 128 + 1;
+                    for (int ch = 0; ch < nch; ch++) {
+                        const int t0 = ch * 128, n = min(128, pos + 1 - t0);
+                        if (ch > 0) {       // (a later pass fetches its rows at its start: a prefetch a pass ahead costs 16 registers this kernel lacks)
 #pragma unroll
-                        for (int w = 0; w < 8; w++) ov = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt), w)), wpart[w * 68 + 4 + lane], ov);
-                        chunk[ch * 66 + 2 + lane] = ov;
-                        if (lane == 0) { chunk[ch * 66] = M; chunk[ch * 66 + 1] = Ls; }
-                    }
-                    if (ch + 1 < nch) __syncthreads();
-                }
-                __syncthreads();
-                PD_RELANE();
-                if (s == 0 && idx == 0) PD_ST(sb, 5);
-                if (tid < 64) {
-                    float ov;
-                    if (nch == 1) ov = chunk[2 + tid] * (1.0f / chunk[1]);
-                    else {
-                        float M = chunk[0];
-                        for (int c = 1; c < nch; c++) M = fmaxf(M, chunk[c * 66]);
-                        float v = 0.f, Ls = 0.f;
-                        for (int c = 0; c < nch; c++) {
-                            const float w = pd_exp(chunk[c * 66] - M);
-                            Ls += w * chunk[c * 66 + 1];
-                            v += w * chunk[c * 66 + 2 + tid];
+                            for (int kk = 0; kk < 4; kk++) {
+                                kreg[kk] = pd_ld16f(kr_, (unsigned)((t0 + min(wave * 16 + kr, n - 1)) * 16 + kq * 4 + kk) * 16u);
+                                vreg[kk] = pd_ld16f(vr_, (unsigned)((t0 + min(wave * 16 + 4 * vg + kk, n - 1)) * 16 + vcl) * 16u);
+                            }
                         }
-                        ov = v * (1.0f / Ls);
+                        const int krow = wave * 16 + kr;
+                        const bool kcurrow = t0 + krow == pos;
+                        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            const float4 q4 = *reinterpret_cast<const float4 *>(qs + kq * 16 + kk * 4);
+                            const float4 kc4 = *reinterpret_cast<const float4 *>(kcur + kq * 16 + kk * 4);
+                            const float4 k4 = kcurrow ? kc4 : kreg[kk];
+                            d0 = fmaf(q4.x, k4.x, d0); d1 = fmaf(q4.y, k4.y, d1); d2 = fmaf(q4.z, k4.z, d2); d3 = fmaf(q4.w, k4.w, d3);
+                        }
+                        const float sv = krow < n ? quad_sum((d0 + d1) + (d2 + d3)) * P.scale : -INFINITY;
+                        const float mw = wave_max_f32(sv);
+                        const float p = krow < n ? pd_exp(sv - (mw == -INFINITY ? 0.f : mw)) : 0.f;
+                        const float lw = wave_sum_f32(kq == 0 ? p : 0.f);
+                        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 vc4 = *reinterpret_cast<const float4 *>(vcur + vcl * 4);
+                        // the probabilities of this wavefront's 16 rows meet through LDS (one write, one 16-byte read: the lane's V rows
+                        // 4 vg .. 4 vg + 3 are consecutive; the LDS serves a wavefront's operations in order)
+                        if (kq == 0) wpart[wave * 68 + 48 + kr] = p;       // (columns 48 .. 63 of the wavefront's partial row: rewritten below)
+                        const float4 pw4 = *reinterpret_cast<const float4 *>(wpart + wave * 68 + 48 + 4 * vg);
+                        const float pw[4] = {pw4.x, pw4.y, pw4.z, pw4.w};
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            const bool vcurrow = t0 + wave * 16 + 4 * vg + kk == pos;
+                            const float4 v4 = vcurrow ? vc4 : vreg[kk];
+                            o.x = fmaf(pw[kk], v4.x, o.x); o.y = fmaf(pw[kk], v4.y, o.y); o.z = fmaf(pw[kk], v4.z, o.z); o.w = fmaf(pw[kk], v4.w, o.w);
+                        }
+                        o.x = pd_rows4_sum(o.x); o.y = pd_rows4_sum(o.y); o.z = pd_rows4_sum(o.z); o.w = pd_rows4_sum(o.w);
+                        if (lane < 16) *reinterpret_cast<float4 *>(wpart + wave * 68 + 4 + vcl * 4) = o;
+                        if (lane == 0) { wpart[wave * 68] = mw; wpart[wave * 68 + 1] = lw; }
+                        __syncthreads();
+                        PD_RELANE();
+                        if (wave == 0) {
+                            const float mwv = lane < 8 ? wpart[min(lane, 7) * 68] : -INFINITY;
+                            const float M = wave_max_f32(mwv);
+                            const float wgt = (lane < 8 && mwv != -INFINITY) ? __expf(mwv - M) : 0.f;
+                            const float Ls = wave_sum_f32(lane < 8 ? wgt * wpart[min(lane, 7) * 68 + 1] : 0.f);
+                            float ov = 0.f;
+#pragma unroll
+                            for (int w = 0; w < 8; w++) ov = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt), w)), wpart[w * 68 + 4 + lane], ov);
+                            chunk[ch * 66 + 2 + lane] = ov;
+                            if (lane == 0) { chunk[ch * 66] = M; chunk[ch * 66 + 1] = Ls; }
+                        }
+                        if (ch + 1 < nch) __syncthreads();
                     }
-                    pd_publish<false>(P.go + (size_t)layer * D + hidx * 64 + tid, tag, ov);      // -> the workers of this XCD
+                    __syncthreads();
+                    PD_RELANE();
+                    if (s == 0 && idx == 0) PD_ST(sb, 5);
+                    if (tid < 64) {
+                        float ov;
+                        if (nch == 1) ov = chunk[2 + tid] * (1.0f / chunk[1]);
+                        else {
+                            float M = chunk[0];
+                            for (int c = 1; c < nch; c++) M = fmaxf(M, chunk[c * 66]);
+                            float v = 0.f, Ls = 0.f;
+                            for (int c = 0; c < nch; c++) {
+                                const float w = pd_exp(chunk[c * 66] - M);
+                                Ls += w * chunk[c * 66 + 1];
+                                v += w * chunk[c * 66 + 2 + tid];
+                            }
+                            ov = v * (1.0f / Ls);
+                        }
+                        pd_publish<false>(P.go + (size_t)layer * D + hidx * 64 + tid, tag, ov);      // -> every unit of this XCD
+                    }
+                    if (s == 0 && idx == 0) PD_ST(sb, 6);
                 }
-                if (s == 0 && idx == 0) PD_ST(sb, 6);
-            } else {
-                // =============================== worker ===============================
-                const int w = pd_worker_index(s, idx, H);
-                const int r0 = pd_split(D, NWK, w), nr = pd_split(D, NWK, w + 1) - r0, nrp = pd_pad4(nr);
-                const int g0 = pd_split(I, NWK, w), rg = pd_split(I, NWK, w + 1) - g0, rgp = pd_pad4(rg);
+            }
+            {
+                // =============================== every unit: WO, gate / up, down rows ===============================
+                constexpr int nr = WR, nrp = WRP, rg = GR, rgp = GRP;
+                const int r0 = idx * WR, g0 = idx * GR;
                 // ---- o of every head -> LDS; WO rows + residual (go/model.go:590-594) ----
                 {
                     float ov[2];
@@ -779,22 +784,22 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 }
                 __syncthreads();
                 PD_RELANE();
-                if (s == 0 && idx == H) PD_ST(sb, 2);
+                if (s == 0 && idx == 0) PD_ST(sb + 16, 2);
                 if (misc[2]) return;
-                pd_units<0, PD_UW, NB>(wlo[s], whi[s], wsl + s * PD_UNITS * PD_THREADS, reinterpret_cast<const uint4 *>(xl), xs, nrp * NB, part, tid);
+                pd_units<PD_UQ, PD_UW, NB>(wlo[s], whi[s], wsl + s * PD_UNITS * PD_THREADS, reinterpret_cast<const uint4 *>(xl), xs, nrp * NB, part, tid);
                 __syncthreads();
                 PD_RELANE();
-                if (s == 0 && idx == H) PD_ST(sb, 3);
+                if (s == 0 && idx == 0) PD_ST(sb + 16, 3);
                 if (tid < 4 * nr) {    // four lanes per row
                     const float v = pd_rowsum<NB, 4>(part + (tid >> 2) * NBP, tid & 3);
                     if (!(tid & 3)) pd_publish<false>(P.gxp + (size_t)layer * D + r0 + (tid >> 2), tag, xraw[r0 + (tid >> 2)] + v);
                 }
-                if (s == 0 && idx == H) PD_ST(sb, 4);
+                if (s == 0 && idx == 0) PD_ST(sb + 16, 4);
                 // ---- x' of every worker; RMSNorm; gate and up rows, SiLU(gate) * up (go/model.go:597-606) ----
                 const float gf0 = P.norms[(size_t)(layer * 2 + 1) * D + c0], gf1 = P.norms[(size_t)(layer * 2 + 1) * D + c1];
                 float xp[2];
                 pd_gather<2>(P.gxp + (size_t)layer * D, D, tag, xp, Q, 4u, tid);
-                if (s == 0 && idx == H) PD_ST(sb, 5);
+                if (s == 0 && idx == 0) PD_ST(sb + 16, 5);
                 __syncthreads();                               // (xraw / xT / part of the WO step are free)
                 PD_RELANE();
                 if (v0) xraw[e0] = xp[0];
@@ -803,11 +808,11 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 if (wave * 64 + PD_THREADS < D) pd_limbs(xp[1] * gf1, v1, e1, xl, xs, lane);
                 const float inv2 = pd_inv_rms(xp[0], xp[1], v0, v1, lane, wave, dred, D, P.eps);
                 if (misc[2]) return;
-                if (s == 0 && idx == H) PD_ST(sb, 6);
-                pd_units<PD_UW, PD_UG, NB>(wlo[s], whi[s], wsl + s * PD_UNITS * PD_THREADS, reinterpret_cast<const uint4 *>(xl), xs, 2 * rgp * NB, part, tid);
+                if (s == 0 && idx == 0) PD_ST(sb + 16, 6);
+                pd_units<PD_UQ + PD_UW, PD_UG, NB>(wlo[s], whi[s], wsl + s * PD_UNITS * PD_THREADS, reinterpret_cast<const uint4 *>(xl), xs, 2 * rgp * NB, part, tid);
                 __syncthreads();
                 PD_RELANE();
-                if (s == 0 && idx == H) PD_ST(sb, 7);
+                if (s == 0 && idx == 0) PD_ST(sb + 16, 7);
                 // row sums and SiLU(gate) * up without a round trip through LDS: a quad = the gate row and the up row of one index,
                 // two lanes each
                 if ((tid >> 2) < rg) {
@@ -820,7 +825,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                         pd_publish<false>(P.gh + (size_t)layer * I + g0 + row, tag, (g / (1.0f + ex)) * u);
                     }
                 }
-                if (s == 0 && idx == H) PD_ST(sb, 8);
+                if (s == 0 && idx == 0) PD_ST(sb + 16, 8);
                 // ---- h of every worker -> LDS; down rows + residual (go/model.go:609-612) ----
                 {
                     float hv[3];
@@ -831,12 +836,12 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 }
                 __syncthreads();
                 PD_RELANE();
-                if (s == 0 && idx == H) PD_ST(sb, 9);
+                if (s == 0 && idx == 0) PD_ST(sb + 16, 9);
                 if (misc[2]) return;
-                pd_units<PD_UW + PD_UG, PD_UD, NBI>(wlo[s], whi[s], wsl + s * PD_UNITS * PD_THREADS, reinterpret_cast<const uint4 *>(hl), hs, nrp * NBI, part, tid);
+                pd_units<PD_UQ + PD_UW + PD_UG, PD_UD, NBI>(wlo[s], whi[s], wsl + s * PD_UNITS * PD_THREADS, reinterpret_cast<const uint4 *>(hl), hs, nrp * NBI, part, tid);
                 __syncthreads();
                 PD_RELANE();
-                if (s == 0 && idx == H) PD_ST(sb, 10);
+                if (s == 0 && idx == 0) PD_ST(sb + 16, 10);
                 if (tid < 4 * nr) {      // four lanes per row, a quarter of the blocks each, joined in lane order
                     const int row = tid >> 2, q = tid & 3;
                     const float tot = pd_rowsum<NBI, 4>(part + row * NBIP, q);
@@ -847,7 +852,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                     }
                 }
             }
-            if (s == 0 && idx == H) PD_ST(sb, 11);
+            if (s == 0 && idx == 0) PD_ST(sb + 16, 11);
             __syncthreads();     // LDS of this slot is free for the next one
             PD_RELANE();
         }

@@ -24,9 +24,9 @@ for rep in range(3):
     us = lambda a, b: (st[b] - st[a]) / 100.0
     print(f"launch: weights resident after {us(0, 1):.1f} us, first token {us(1, 2):.1f} us, {n} tokens {us(1, 3):.1f} us = {us(1, 3) / n:.2f} us per token")
     h = st[8:15]; w = st[24:36]; l = st[40:44]
-    t0 = min(h[0], w[0])
-    names_h = ["slot start", "x gathered", "rms + x*g in LDS", "Q|K|V units", "row sums + RoPE + KV store", "attention passes", "o published"]
-    names_w = ["slot start", "x gathered", "o gathered", "WO units", "x' published", "x' gathered", "rms", "gate|up units", "h published",
+    t0 = h[0]
+    names_h = ["slot start", "x gathered", "rms + digits", "Q|K|V units (this unit's rows)", "row sums, publish, head gathers q|k|v, RoPE, KV store", "attention passes", "o published"]
+    names_w = ["-", "-", "o gathered", "WO units", "x' published", "x' gathered", "rms", "gate|up units", "h published",
                "h gathered", "down units", "x'' published"]
     print("  head  :", ", ".join(f"{nm} {(v - t0) / 100.0:.2f}" for nm, v in zip(names_h, h)))
     print("  worker:", ", ".join(f"{nm} {(v - t0) / 100.0:.2f}" for nm, v in zip(names_w, w)))
