@@ -1284,7 +1284,7 @@ bool pd_usable(const nl_engine *e, int pos, int n) {
 }
 
 // One launch = n greedy tokens from (token, pos); ids land in e->ids.  The caller synchronises and then asks pd_take_timeout.
-int pd_launch(nl_engine *e, int stream, int token, int pos, int n) {
+int pd_launch(nl_engine *e, int stream, int token, int pos, int n, float *host_logits = nullptr) {
     nl_engine::Persist &d = e->pd;
     const nl_config &c = e->cfg;
     if (d.tag_base > 0xf0000000u) {      // (tags never repeat inside the life of the areas: start over from clean ones)
@@ -1309,7 +1309,7 @@ int pd_launch(nl_engine *e, int stream, int token, int pos, int n) {
     P.kcache = e->kcache + (long long)stream * e->kv_stream_stride; P.vcache = e->vcache + (long long)stream * e->kv_stream_stride;
     P.kv_layer_stride = e->kv_layer_stride;
     P.gx = d.gx; P.gqkv = d.gqkv; P.go = d.go; P.gxp = d.gxp; P.gh = d.gh; P.gam = d.gam;
-    P.census = d.census; P.ids_out = e->ids; P.logits = e->logits;
+    P.census = d.census; P.ids_out = e->ids; P.logits = e->logits; P.host_logits = host_logits;
     P.status = d.status; P.host_status = d.h_status; P.dbg = d.dbg;
     if (c.dim == 576) hipLaunchKernelGGL((pd_decode_kernel<18, 48>), dim3(PD_GRID), dim3(PD_THREADS), pd_lds_bytes(), e->stream, P);
     else hipLaunchKernelGGL((pd_decode_kernel<8, 16>), dim3(PD_GRID), dim3(PD_THREADS), pd_lds_bytes(), e->stream, P);
@@ -2705,6 +2705,19 @@ int nl_forward(nl_handle e, int stream, int token, int pos, float *logits_out) {
     int rc = check_step_args(e, stream, token, pos);
     if (rc) return rc;
     HIPCK(e, hipSetDevice(e->dev));
+    if (pd_usable(e, pos, 1)) {
+        // the smallest tier: one token as a persistent launch of one step (nl_persist.h: weights to the registers, one pass, logits
+        // stored into the pinned host buffer by the LM-head units themselves) -- 150 us against 215 for the thirty launches
+        if ((rc = note_positions(e, stream, pos, 1))) return rc;
+        const bool direct = logits_out && e->d_h_logits;
+        if ((rc = pd_launch(e, stream, token, pos, 1, direct ? e->d_h_logits : nullptr))) return rc;
+        if (logits_out && !direct) HIPCK(e, hipMemcpyAsync(e->h_logits, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCK(e, hipStreamSynchronize(e->stream));
+        if (!pd_take_timeout(e)) {
+            if (logits_out) memcpy(logits_out, e->h_logits, (size_t)e->cfg.vocab * 4);
+            return NL_OK;
+        }
+    }
     for (int attempt = 0;; attempt++) {
         if ((rc = note_positions(e, stream, pos, 1))) return rc;
         // one GPU: the LM head stores the logits into the pinned buffer itself (ctl[CTL_HOSTOUT]); groups: a DMA behind the step
@@ -2734,6 +2747,14 @@ int nl_forward_argmax(nl_handle e, int stream, int token, int pos, int *next_id)
     int rc = check_step_args(e, stream, token, pos);
     if (rc) return rc;
     HIPCK(e, hipSetDevice(e->dev));
+    if (pd_usable(e, pos, 1)) {          // (see nl_forward)
+        if ((rc = note_positions(e, stream, pos, 1))) return rc;
+        if ((rc = pd_launch(e, stream, token, pos, 1))) return rc;
+        int *h_id = reinterpret_cast<int *>(e->h_logits + e->cfg.vocab);
+        HIPCK(e, hipMemcpyAsync(h_id, e->ids, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCK(e, hipStreamSynchronize(e->stream));
+        if (!pd_take_timeout(e)) { *next_id = *h_id; return NL_OK; }
+    }
     for (int attempt = 0;; attempt++) {
         if ((rc = note_positions(e, stream, pos, 1))) return rc;
         if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;

@@ -104,6 +104,7 @@ struct PdParams {
     unsigned *census;                // [8] tickets per XCD, [8] arrivals, [9] the token the launch ended on
     int *ids_out;                    // [n_steps]
     float *logits;                   // [V] of the last step
+    float *host_logits;              // optional: the last step's logits also go straight into this (pinned, device-visible) host buffer
     unsigned *status, *host_status;
     long long *dbg;                  // optional stamps of (xcd 0, unit 0), thread 0
 };
@@ -313,11 +314,9 @@ __device__ __forceinline__ void pd_limbs(float v, bool valid, int e, unsigned ch
 // them in float32 and multiplies by d and the block's 1 / scale -> part[row * NBP + block].  (The float32 dot product of the
 // reference, go/quant.go:149-165, has a rounding per element; this form is exact up to the 2^-30 input rounding and three
 // float32 roundings per block.)  One MFMA = 256 weights: a quarter of the instructions of the VALU form.
-template <int K0, int NU, int NB>   // the lane's unit slots K0 .. K0 + NU - 1 of the layer slot; NB blocks per row
-__device__ __forceinline__ void pd_units(const uint4 (&lo_)[PD_UNITS], const uint4 (&hi_)[PD_UNITS], const unsigned short *sc /* LDS: [9][512] of the slot */, const uint4 *img,
-                                         const float *scl, int total, float *part, int tid) {
+template <int NU, int NB, class WF>   // NU unit slots; NB blocks per row; wf(k, lo, hi, d): the lane's 32 int8 and fp16 scale bits of slot k
+__device__ __forceinline__ void pd_units_impl(WF wf, const uint4 *img, const float *scl, int total, float *part, int tid) {
     constexpr int NBP = NB | 1;
-    const uint4 *lo = lo_ + K0, *hi = hi_ + K0;
     asm volatile("" : "+v"(tid));        // (addresses are derived per phase, not shared across phases and kept live)
     // Units go two at a time: the two chains of eight dependent products interleave (a 4x4x4 product has a few cycles of latency
     // its successor would otherwise wait for), their digit rows are requested together, and the scheduling fence sits between
@@ -325,48 +324,66 @@ __device__ __forceinline__ void pd_units(const uint4 (&lo_)[PD_UNITS], const uin
 #pragma unroll
     for (int k0 = 0; k0 < NU; k0 += 2) {
         if (k0 * PD_THREADS < total) {
-            constexpr int NBPc = NBP;
-            const bool two = k0 + 1 < NU && (k0 + 1) * PD_THREADS < total;
+            constexpr bool kPair = true;
+            (void)kPair;
+            const bool has2 = k0 + 1 < NU;
+            const int k1 = has2 ? k0 + 1 : k0;
+            const bool two = has2 && k1 * PD_THREADS < total;
             unsigned u[2], row[2], blk[2];
-            uint4 a0[2], a1[2];
-            float sb[2], d[2];
+            uint4 a0[2], a1[2], wl[2], wh[2];
+            unsigned d16[2];
+            float sb[2];
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const int k = (j == 1 && !(k0 + 1 < NU)) ? k0 : k0 + j;
+                const int k = j ? k1 : k0;
                 u[j] = (unsigned)(k * PD_THREADS + tid);
                 const unsigned G = u[j] >> 2, rgp = G / (unsigned)NB;
                 blk[j] = G - rgp * (unsigned)NB; row[j] = rgp * 4u + (u[j] & 3u);
                 const uint4 *ap = img + blk[j] * 8u + (u[j] & 3u) * 2u;
                 a0[j] = ap[0]; a1[j] = ap[1]; sb[j] = scl[blk[j]];
-                d[j] = h2f_bits(sc[(K0 + k) * PD_THREADS + tid]);
+                wf(k, wl[j], wh[j], d16[j]);
             }
             pd_i32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-            constexpr int K1 = 0;
-            (void)K1;
 #define PD_MF(A, W, ACC) ACC = __builtin_amdgcn_mfma_i32_4x4x4i8((int)(A), (int)(W), ACC, 0, 0, 0)
-            if (k0 + 1 < NU) {
-                PD_MF(a0[0].x, lo[k0].x, acc0); PD_MF(a0[1].x, lo[k0 + 1 < NU ? k0 + 1 : k0].x, acc1);
-                PD_MF(a0[0].y, lo[k0].y, acc0); PD_MF(a0[1].y, lo[k0 + 1 < NU ? k0 + 1 : k0].y, acc1);
-                PD_MF(a0[0].z, lo[k0].z, acc0); PD_MF(a0[1].z, lo[k0 + 1 < NU ? k0 + 1 : k0].z, acc1);
-                PD_MF(a0[0].w, lo[k0].w, acc0); PD_MF(a0[1].w, lo[k0 + 1 < NU ? k0 + 1 : k0].w, acc1);
-                PD_MF(a1[0].x, hi[k0].x, acc0); PD_MF(a1[1].x, hi[k0 + 1 < NU ? k0 + 1 : k0].x, acc1);
-                PD_MF(a1[0].y, hi[k0].y, acc0); PD_MF(a1[1].y, hi[k0 + 1 < NU ? k0 + 1 : k0].y, acc1);
-                PD_MF(a1[0].z, hi[k0].z, acc0); PD_MF(a1[1].z, hi[k0 + 1 < NU ? k0 + 1 : k0].z, acc1);
-                PD_MF(a1[0].w, hi[k0].w, acc0); PD_MF(a1[1].w, hi[k0 + 1 < NU ? k0 + 1 : k0].w, acc1);
+            if (has2) {
+                PD_MF(a0[0].x, wl[0].x, acc0); PD_MF(a0[1].x, wl[1].x, acc1);
+                PD_MF(a0[0].y, wl[0].y, acc0); PD_MF(a0[1].y, wl[1].y, acc1);
+                PD_MF(a0[0].z, wl[0].z, acc0); PD_MF(a0[1].z, wl[1].z, acc1);
+                PD_MF(a0[0].w, wl[0].w, acc0); PD_MF(a0[1].w, wl[1].w, acc1);
+                PD_MF(a1[0].x, wh[0].x, acc0); PD_MF(a1[1].x, wh[1].x, acc1);
+                PD_MF(a1[0].y, wh[0].y, acc0); PD_MF(a1[1].y, wh[1].y, acc1);
+                PD_MF(a1[0].z, wh[0].z, acc0); PD_MF(a1[1].z, wh[1].z, acc1);
+                PD_MF(a1[0].w, wh[0].w, acc0); PD_MF(a1[1].w, wh[1].w, acc1);
             } else {
-                PD_MF(a0[0].x, lo[k0].x, acc0); PD_MF(a0[0].y, lo[k0].y, acc0); PD_MF(a0[0].z, lo[k0].z, acc0); PD_MF(a0[0].w, lo[k0].w, acc0);
-                PD_MF(a1[0].x, hi[k0].x, acc0); PD_MF(a1[0].y, hi[k0].y, acc0); PD_MF(a1[0].z, hi[k0].z, acc0); PD_MF(a1[0].w, hi[k0].w, acc0);
+                PD_MF(a0[0].x, wl[0].x, acc0); PD_MF(a0[0].y, wl[0].y, acc0); PD_MF(a0[0].z, wl[0].z, acc0); PD_MF(a0[0].w, wl[0].w, acc0);
+                PD_MF(a1[0].x, wh[0].x, acc0); PD_MF(a1[0].y, wh[0].y, acc0); PD_MF(a1[0].z, wh[0].z, acc0); PD_MF(a1[0].w, wh[0].w, acc0);
             }
 #undef PD_MF
             const float f0 = fmaf(fmaf(fmaf((float)acc0[3], 256.f, (float)acc0[2]), 256.f, (float)acc0[1]), 256.f, (float)acc0[0]);
-            if ((int)u[0] < total) part[row[0] * (unsigned)NBPc + blk[0]] = f0 * (d[0] * sb[0]);
-            if (k0 + 1 < NU) {
+            if ((int)u[0] < total) part[row[0] * (unsigned)NBP + blk[0]] = f0 * (h2f_bits(d16[0]) * sb[0]);
+            if (has2) {
                 const float f1 = fmaf(fmaf(fmaf((float)acc1[3], 256.f, (float)acc1[2]), 256.f, (float)acc1[1]), 256.f, (float)acc1[0]);
-                if (two && (int)u[1] < total) part[row[1] * (unsigned)NBPc + blk[1]] = f1 * (d[1] * sb[1]);
+                if (two && (int)u[1] < total) part[row[1] * (unsigned)NBP + blk[1]] = f1 * (h2f_bits(d16[1]) * sb[1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+}
+// the layer matrices: quants in registers (slots K0 .. K0 + NU - 1 of the layer slot), scales in LDS
+template <int K0, int NU, int NB>
+__device__ __forceinline__ void pd_units(const uint4 (&lo)[PD_UNITS], const uint4 (&hi)[PD_UNITS], const unsigned short *sc /* LDS: [9][512] of the slot */, const uint4 *img,
+                                         const float *scl, int total, float *part, int tid) {
+    pd_units_impl<NU, NB>([&](int k, uint4 &l, uint4 &h, unsigned &d) { l = lo[K0 + k]; h = hi[K0 + k]; d = sc[(K0 + k) * PD_THREADS + tid]; }, img, scl, total, part, tid);
+}
+
+// argmax over a wavefront whose lanes hold candidates in ascending index order: the maximum on DPP, the lowest lane that holds
+// it (go/main.go:400-408: strict '>', the earlier index wins) by a ballot -- no ds_bpermute round trips
+__device__ __forceinline__ void pd_wave_argmax(float &best, int &bidx) {
+    const float m = wave_max_f32(best);
+    const unsigned long long mask = __ballot(best == m);
+    const int l = mask ? (int)__ffsll((long long)mask) - 1 : 0;
+    bidx = __builtin_amdgcn_readlane(bidx, __builtin_amdgcn_readfirstlane(l));
+    best = m;
 }
 
 // exp_f64_as_f32 (nl_kernels.h: float32(exp(float64(x))), go/quant.go:619, :629-631) with its thirteen coefficients made
@@ -578,12 +595,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                         __builtin_amdgcn_s_sleep(1);
                     }
                     best = __uint_as_float(g.y); bidx = (int)g.z;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const float ov = __shfl_xor(best, o);
-                        const int oi = __shfl_xor(bidx, o);
-                        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-                    }
+                    pd_wave_argmax(best, bidx);          // (lane = compute unit = ascending vocabulary rows)
                     if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
                 }
                 __syncthreads();
@@ -869,33 +881,9 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
             const float inv = pd_inv_rms(xv[0], xv[1], v0, v1, lane, wave, dred, D, P.eps);
             if (misc[2]) return;
             const int total = pd_pad4(lm_rows) * NB;
-            {
-                int tl = tid;
-                asm volatile("" : "+v"(tl));
-#pragma unroll
-                for (int k = 0; k < PD_ULM; k++) {
-                    if (k * PD_THREADS < total) {
-                        const unsigned u = (unsigned)(k * PD_THREADS + tl), G = u >> 2;
-                        const unsigned rgp_ = G / (unsigned)NB, blk = G - rgp_ * (unsigned)NB, row = rgp_ * 4u + (u & 3u);
-                        const uint4 *ap = reinterpret_cast<const uint4 *>(xl) + blk * 8u + (u & 3u) * 2u;
-                        const uint4 a0 = ap[0], a1 = ap[1];
-                        const uint4 lo = lmw[(k * 2 + 0) * PD_THREADS + tl], hi = lmw[(k * 2 + 1) * PD_THREADS + tl];
-                        const float sb = xs[blk];
-                        pd_i32x4 acc = {0, 0, 0, 0};
-                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.x, (int)lo.x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.y, (int)lo.y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.z, (int)lo.z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a0.w, (int)lo.w, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.x, (int)hi.x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.y, (int)hi.y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.z, (int)hi.z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)a1.w, (int)hi.w, acc, 0, 0, 0);
-                        const float f = fmaf(fmaf(fmaf((float)acc[3], 256.f, (float)acc[2]), 256.f, (float)acc[1]), 256.f, (float)acc[0]);
-                        if ((int)u < total) part[row * (unsigned)NBP + blk] = f * (h2f_bits(lms[k * PD_THREADS + tl]) * sb);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
+            pd_units_impl<PD_ULM, NB>([&](int k, uint4 &l, uint4 &h, unsigned &d) {
+                l = lmw[(k * 2 + 0) * PD_THREADS + tid]; h = lmw[(k * 2 + 1) * PD_THREADS + tid]; d = lms[k * PD_THREADS + tid]; },
+                reinterpret_cast<const uint4 *>(xl), xs, total, part, tid);
             __syncthreads();
             PD_RELANE();
             if (idx == 0) PD_ST(40, 2);
@@ -905,15 +893,13 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 const int row = tid >> 1;
                 const float lg = pd_rowsum<NB, 2>(part + min(row, 127) * NBP, tid & 1) * inv;
                 if (row < lm_n) {
-                    if (!(tid & 1)) P.logits[lm_r0 + row] = lg;
+                    if (!(tid & 1)) {
+                        P.logits[lm_r0 + row] = lg;
+                        if (P.host_logits && step == P.n_steps - 1) P.host_logits[lm_r0 + row] = lg;     // per-call Forward: no DMA behind the launch
+                    }
                     if (lg > best) { best = lg; bidx = lm_r0 + row; }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(best, o);
-                    const int oi = __shfl_xor(bidx, o);
-                    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-                }
+                pd_wave_argmax(best, bidx);              // (lane pairs = ascending rows)
                 if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
             }
             __syncthreads();
