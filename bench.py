@@ -207,6 +207,7 @@ def dropin_lib():
         ip, fp = C.POINTER(C.c_int), C.POINTER(C.c_float)
         L.nl_dropin_forward_loop.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, ip, C.POINTER(C.c_double)]
         L.nl_dropin_forward_argmax_loop.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.POINTER(C.c_double)]
+        L.nl_dropin_forward_inplace_loop.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _DROPIN = L
     except (OSError, subprocess.CalledProcessError) as exc:
         print(f"[bench] drop-in loop library not built ({exc!r})", file=sys.stderr)
@@ -225,10 +226,12 @@ def dropin_rates(dev, first, pos0, n, chained_ids):
     v = dev.config.vocab_size
     logits = np.zeros(v, dtype=np.float32)
     ids = (C.c_int * n)()
-    sec = C.c_double(0.0)
+    sec, csec = C.c_double(0.0), C.c_double(0.0)
     out = {"loop": "integration/c/dropin_loop.c (C99, gcc -O2), one call per token", "tokens": n}
     for key, call in (("nl_forward_plus_host_argmax_tokens_per_s",
                        lambda: L.nl_dropin_forward_loop(dev._h, 0, first, pos0, n, logits.ctypes.data_as(C.POINTER(C.c_float)), v, ids, C.byref(sec))),
+                      ("nl_forward_inplace_plus_host_argmax_tokens_per_s",      # State.Logits = nl_host_logits (integration/go/hip_backend.go)
+                       lambda: L.nl_dropin_forward_inplace_loop(dev._h, 0, first, pos0, n, v, ids, C.byref(sec), C.byref(csec))),
                       ("nl_forward_argmax_tokens_per_s",
                        lambda: L.nl_dropin_forward_argmax_loop(dev._h, 0, first, pos0, n, ids, C.byref(sec)))):
         best = None
@@ -238,6 +241,8 @@ def dropin_rates(dev, first, pos0, n, chained_ids):
                 return {"error": f"{key}: status {rc}"}
             best = sec.value if best is None else min(best, sec.value)
         out[key] = round(n / best, 1)
+        if "inplace" in key:
+            out["nl_forward_inplace_us_per_call"] = round(csec.value / n * 1e6, 1)      # (of the last repeat)
         out[key.replace("_tokens_per_s", "_ids_equal_chained")] = [int(ids[i]) for i in range(n)] == list(chained_ids[:n])
     return out
 

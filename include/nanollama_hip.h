@@ -104,6 +104,11 @@ NL_API int nl_reset(nl_handle h, int stream);
  * logits_out receives `vocab` floats (caller-owned, e.g. the Go State.Logits
  * slice).  Synchronous on return. */
 NL_API int nl_forward(nl_handle h, int stream, int token, int pos, float *logits_out);
+/* The library's own pinned host buffer of `vocab` floats (valid from nl_finalize to nl_destroy).  Passed as logits_out,
+ * nl_forward / nl_prefill leave the logits there without the copy into a caller-owned slice: the LM head's compute units
+ * store them into it directly.  The cgo shim points State.Logits (go/model.go:30, read by go/main.go:186-213) at it.
+ * NULL before nl_finalize. */
+NL_API float *nl_host_logits(nl_handle h);
 /* Forward + argmax (strict '>' => lowest index wins ties, go/main.go:400-408)
  * without moving the logits to the host. */
 NL_API int nl_forward_argmax(nl_handle h, int stream, int token, int pos, int *next_id);
@@ -178,7 +183,9 @@ NL_API int nl_profile_forward(nl_handle h, int stream, int token, int pos, int i
 NL_API int nl_plan_info(nl_handle h, int *fused_mode, int *fused_max_pos, int *launches_fused, int *launches_general);
 /* The weight-stationary persistent decode of the smallest tier (nl_persist.h; no reference counterpart, the Go loop is
  * go/main.go:173-219): ready = nl_decode_greedy takes ONE launch per chunk while the chunk ends below max_pos (Q8_0 files of
- * nano's shape class on a 256-CU device); launches / tokens count what went through it on this handle. */
+ * nano's shape class on a 256-CU device), and consecutive nl_forward / nl_forward_argmax calls below max_pos are steps of
+ * ONE resident launch that takes each call's token from a pinned mailbox word (it leaves when another entry point is called,
+ * or NL_PERSIST_IDLE_US -- 2000 by default -- after its last token); launches / tokens count what went through it. */
 NL_API int nl_persist_info(nl_handle h, int *ready, int *max_pos, long long *launches, long long *tokens);
 /* Device bytes held by the handle (weights, KV, state). */
 NL_API int nl_memory_usage(nl_handle h, uint64_t *weights, uint64_t *kv_cache, uint64_t *state);

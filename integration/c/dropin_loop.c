@@ -41,6 +41,27 @@ NL_API int nl_dropin_forward_loop(nl_handle h, int stream, int token, int pos, i
     return NL_OK;
 }
 
+/* the same loop as the cgo shim runs it: State.Logits IS the library's pinned buffer (nl_host_logits), nl_forward copies
+ * nothing; *call_seconds = the time inside nl_forward alone (the rest of a step is the host's argmax) */
+NL_API int nl_dropin_forward_inplace_loop(nl_handle h, int stream, int token, int pos, int n, int vocab, int *ids_out, double *seconds,
+                                          double *call_seconds) {
+    int i, rc;
+    float *logits = nl_host_logits(h);
+    double in_calls = 0.0;
+    const double t0 = now_s();
+    if (!logits) return NL_ERR_STATE;
+    for (i = 0; i < n; i++) {
+        const double c0 = now_s();
+        if ((rc = nl_forward(h, stream, token, pos + i, logits)) != NL_OK) return rc;
+        in_calls += now_s() - c0;
+        token = host_argmax(logits, vocab);
+        ids_out[i] = token;
+    }
+    *seconds = now_s() - t0;
+    *call_seconds = in_calls;
+    return NL_OK;
+}
+
 /* the greedy fast path of the ABI: Forward + argmax on the device, one id back per token */
 NL_API int nl_dropin_forward_argmax_loop(nl_handle h, int stream, int token, int pos, int n, int *ids_out, double *seconds) {
     int i, rc;

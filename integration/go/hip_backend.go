@@ -110,8 +110,20 @@ func loadHIP(gguf *GGUFFile, cfg *LlamaConfig, device int, gpus int) (*hipBacken
 	return b, nil
 }
 
-// forwardHIP replaces the body of (*LlamaModel).Forward (go/model.go:490-620): State.Logits stays the Go slice the
-// sampling code reads and mutates (go/main.go:174-187).
+// logits is the slice LoadLlamaModel installs as State.Logits (go/model.go:30): the library's pinned host buffer
+// (nl_host_logits), so that nl_forward / nl_prefill leave the logits where the sampling code reads and mutates them
+// (go/main.go:174-213) without a copy -- C memory, which Go code may read and write freely; it lives until nl_destroy.
+func (b *hipBackend) logits(vocab int) []float32 {
+	p := C.nl_host_logits(b.h)
+	if p == nil {
+		return make([]float32, vocab)
+	}
+	return unsafe.Slice((*float32)(unsafe.Pointer(p)), vocab)
+}
+
+// forwardHIP replaces the body of (*LlamaModel).Forward (go/model.go:490-620): State.Logits stays the slice the
+// sampling code reads and mutates (go/main.go:174-187).  Consecutive calls are steps of one resident launch for the
+// smallest tier (nl_persist_info): no launch per token.
 func (m *LlamaModel) forwardHIP(token, pos int) {
 	rc := C.nl_forward(m.hip.h, 0, C.int(token), C.int(pos), (*C.float)(unsafe.Pointer(&m.State.Logits[0])))
 	if rc != 0 {

@@ -11,5 +11,6 @@ func hipGPUs() int                                                              
 func loadHIP(gguf *GGUFFile, cfg *LlamaConfig, device int, gpus int) (*hipBackend, error) {
 	return nil, nil
 }
+func (b *hipBackend) logits(vocab int) []float32                                { return nil }
 func (m *LlamaModel) forwardHIP(token, pos int)                                 {}
 func (m *LlamaModel) resetHIP()                                                 {}

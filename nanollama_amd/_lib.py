@@ -90,7 +90,7 @@ EXPORTS = ["nl_build_info", "nl_set_gamma", "nl_abi_version", "nl_device_count",
            "nl_synchronize", "nl_timer_start", "nl_timer_stop", "nl_kernel_kind_name", "nl_profile_forward",
            "nl_memory_usage", "nl_debug_read", "nl_op_matmul", "nl_op_matmul_batch", "nl_op_rmsnorm", "nl_comm_get_unique_id",
            "nl_comm_init", "nl_group_forward", "nl_debug_stamps", "nl_sample_decode", "nl_op_sample", "nl_p2p_export",
-           "nl_p2p_import", "nl_p2p_info", "nl_p2p_loopback", "nl_op_exp", "nl_plan_info", "nl_persist_info", "nl_create_group"]
+           "nl_p2p_import", "nl_p2p_info", "nl_p2p_loopback", "nl_op_exp", "nl_plan_info", "nl_persist_info", "nl_create_group", "nl_host_logits"]
 
 
 def lib():
@@ -138,6 +138,8 @@ def lib():
     L.nl_p2p_loopback.argtypes = [vp]
     L.nl_plan_info.argtypes = [vp, ip, ip, ip, ip]
     L.nl_create_group.argtypes = [C.POINTER(NlConfig), ip, i32, C.POINTER(vp)]
+    L.nl_host_logits.argtypes = [vp]
+    L.nl_host_logits.restype = C.POINTER(C.c_float)
     L.nl_persist_info.argtypes = [vp, ip, ip, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.nl_op_exp.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
     L.nl_group_forward.argtypes = [C.POINTER(vp), i32, i32, i32, i32, fp]

@@ -29,6 +29,7 @@
 #include <cstring>
 #include <functional>
 #include <condition_variable>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -305,6 +306,17 @@ struct nl_engine {
         int spin_limit = 2000000;
         long long *dbg = nullptr;
         long long launches = 0, tokens = 0;
+        // resident session (per-call Forward): the launch stays on the chip between nl_forward calls and takes every next
+        // token from a pinned mailbox word; see PdParams::session
+        bool session_on = true;      // NL_PERSIST_SESSION=0: one launch of one step per call instead
+        bool live = false;           // a session launch is (or may still be) resident on e->stream
+        bool s_logits = false;       // ... whose LM-head units store every step's logits into h_logits
+        int s_stream = 0, s_next_pos = 0, s_step = 0, s_nsteps = 0;
+        long long idle_ticks = 200000;   // 2 ms of the 100 MHz clock (NL_PERSIST_IDLE_US)
+        pd_u64 *h_mail = nullptr, *d_mail = nullptr;   // pinned: [0] mailbox, [8] done word (own cache lines); device view
+        pd_u64 *gtok = nullptr;
+        unsigned launch_no = 0;
+        long long sessions = 0;
     } pd;
     // One-process tensor-parallel group (nl_create_group): THIS handle is the leader the caller holds -- it owns no device
     // state -- and grp->members are the rank engines (one per device, tp_rank = index), wired through the push all-reduce
@@ -1208,9 +1220,10 @@ void pd_free_raw(nl_engine *e) {
 void pd_free(nl_engine *e) {
     pd_free_raw(e);
     nl_engine::Persist &d = e->pd;
-    void *bufs[] = {d.wimg, d.lmimg, d.simg, d.lmsimg, d.gx, d.gqkv, d.go, d.gxp, d.gh, d.gam, d.census, d.status, d.dbg, d.norms};
+    void *bufs[] = {d.wimg, d.lmimg, d.simg, d.lmsimg, d.gx, d.gqkv, d.go, d.gxp, d.gh, d.gam, d.census, d.status, d.dbg, d.norms, d.gtok};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (d.h_status) (void)hipHostFree(d.h_status);
+    if (d.h_mail) (void)hipHostFree(d.h_mail);
     d = nl_engine::Persist{};
 }
 
@@ -1258,7 +1271,13 @@ int pd_build(nl_engine *e) {
         HIPCK(e, hipMemcpy(d.norms + (size_t)(2 * l + 1) * c.dim, e->layers[l].ffn_norm, (size_t)c.dim * 4, hipMemcpyDeviceToDevice));
     }
     HIPCK(e, hipMemcpy(d.norms + (size_t)(2 * c.n_layers) * c.dim, e->output_norm, (size_t)c.dim * 4, hipMemcpyDeviceToDevice));
-    HIPCK(e, dalloc(&d.census, (size_t)16, &e->bytes_state));
+    HIPCK(e, dalloc(&d.census, (size_t)32, &e->bytes_state));       // two launches' words, used alternately (each launch zeroes the other's)
+    HIPCK(e, hipMemset(d.census, 0, 32 * sizeof(unsigned)));
+    HIPCK(e, dalloc(&d.gtok, (size_t)2, &e->bytes_state));
+    HIPCK(e, hipMemset(d.gtok, 0, 16));
+    HIPCK(e, hipHostMalloc((void **)&d.h_mail, 16 * sizeof(pd_u64), hipHostMallocMapped));
+    memset(d.h_mail, 0, 16 * sizeof(pd_u64));
+    if (hipHostGetDevicePointer((void **)&d.d_mail, d.h_mail, 0) != hipSuccess) { (void)hipGetLastError(); d.d_mail = nullptr; }
     HIPCK(e, dalloc(&d.status, (size_t)4, &e->bytes_state));
     HIPCK(e, hipMemset(d.status, 0, 16));
     HIPCK(e, dalloc(&d.dbg, (size_t)64, &e->bytes_state));
@@ -1273,6 +1292,9 @@ int pd_build(nl_engine *e) {
     }
     if (const char *mp = getenv("NL_PERSIST_MAX_POS")) d.max_pos = std::max(0, std::min(PD_MAX_POS, atoi(mp)));   // knob (tests, tools)
     if (const char *sl = getenv("NL_PERSIST_SPIN_LIMIT")) d.spin_limit = atoi(sl);   // knob (tests): 0 makes every poll give up
+    if (const char *ss = getenv("NL_PERSIST_SESSION")) d.session_on = atoi(ss) != 0;  // knob (A/B): 0 = one launch per call
+    if (const char *iu = getenv("NL_PERSIST_IDLE_US")) d.idle_ticks = std::max(1LL, std::min(2000000LL, atoll(iu))) * 100;   // at most 2 s
+    if (!d.d_mail) d.session_on = false;
     d.max_pos = std::min(d.max_pos, c.seq_len);
     d.tag_base = 0;
     d.ready = true;
@@ -1284,7 +1306,7 @@ bool pd_usable(const nl_engine *e, int pos, int n) {
 }
 
 // One launch = n greedy tokens from (token, pos); ids land in e->ids.  The caller synchronises and then asks pd_take_timeout.
-int pd_launch(nl_engine *e, int stream, int token, int pos, int n, float *host_logits = nullptr) {
+int pd_launch(nl_engine *e, int stream, int token, int pos, int n, float *host_logits = nullptr, bool session = false) {
     nl_engine::Persist &d = e->pd;
     const nl_config &c = e->cfg;
     if (d.tag_base > 0xf0000000u) {      // (tags never repeat inside the life of the areas: start over from clean ones)
@@ -1295,8 +1317,10 @@ int pd_launch(nl_engine *e, int stream, int token, int pos, int n, float *host_l
         HIPCK(e, hipMemsetAsync(d.gam, 0, (size_t)PD_GRID * 16, e->stream));
         d.tag_base = 0;
     }
-    HIPCK(e, hipMemsetAsync(d.census, 0, 16 * sizeof(unsigned), e->stream));
     PdParams P{};
+    P.census = d.census + (d.launch_no & 1u) * 16; P.census_next = d.census + ((d.launch_no + 1u) & 1u) * 16;
+    d.launch_no++;
+    P.session = session ? 1 : 0; P.idle_ticks = d.idle_ticks; P.mbox = d.d_mail; P.host_done = d.d_mail ? d.d_mail + 8 : nullptr; P.gtok = d.gtok;
     P.D = c.dim; P.I = c.interm; P.H = c.n_heads; P.V = c.vocab; P.L = c.n_layers; P.seq_len = c.seq_len; P.rope_conj = c.rope_conjugate;
     P.n_steps = n; P.token0 = token; P.pos0 = pos; P.spin_limit = d.spin_limit;
     P.eps = c.rms_eps; P.scale = (float)(1.0 / std::sqrt((double)e->hd));
@@ -1309,7 +1333,7 @@ int pd_launch(nl_engine *e, int stream, int token, int pos, int n, float *host_l
     P.kcache = e->kcache + (long long)stream * e->kv_stream_stride; P.vcache = e->vcache + (long long)stream * e->kv_stream_stride;
     P.kv_layer_stride = e->kv_layer_stride;
     P.gx = d.gx; P.gqkv = d.gqkv; P.go = d.go; P.gxp = d.gxp; P.gh = d.gh; P.gam = d.gam;
-    P.census = d.census; P.ids_out = e->ids; P.logits = e->logits; P.host_logits = host_logits;
+    P.ids_out = e->ids; P.logits = e->logits; P.host_logits = host_logits;
     P.status = d.status; P.host_status = d.h_status; P.dbg = d.dbg;
     if (c.dim == 576) hipLaunchKernelGGL((pd_decode_kernel<18, 48>), dim3(PD_GRID), dim3(PD_THREADS), pd_lds_bytes(), e->stream, P);
     else hipLaunchKernelGGL((pd_decode_kernel<8, 16>), dim3(PD_GRID), dim3(PD_THREADS), pd_lds_bytes(), e->stream, P);
@@ -1333,6 +1357,87 @@ bool pd_take_timeout(nl_engine *e) {
                    "handle keeps from now on", st, (st & 64u) ? "its workgroups were not placed 32 per XCD" : "a hand-off poll timed out");
     if (!getenv("NL_QUIET")) fprintf(stderr, "[nanollama_hip] %s\n", e->err.c_str());
     return true;
+}
+
+// ---- resident session: per-call Forward without a launch per call ---------------------------------------------------------
+// End the session (if one is live): a quit in the mailbox, the doorman sets the status bit every poll of the launch watches,
+// the launch drains.  Every entry point that enqueues work behind e->stream calls this first -- not for correctness (work
+// behind the stream waits for the launch, which ends by itself idle_ticks after its last command) but so as not to wait.
+int pd_session_close(nl_engine *e) {
+    nl_engine::Persist &d = e->pd;
+    if (!d.live) return NL_OK;
+    __atomic_store_n(d.h_mail, (pd_u64)0xffffffffu, __ATOMIC_RELEASE);
+    HIPCK(e, hipStreamSynchronize(e->stream));
+    d.live = false;
+    const unsigned st = *d.h_status;
+    if (st & 256u) {                       // the clean end (quit or idle); every other bit is a poll that saw it
+        *d.h_status = 0;
+        HIPCK(e, hipMemsetAsync(d.status, 0, sizeof(unsigned), e->stream));
+    } else if (st) {
+        pd_take_timeout(e);
+    }
+    return NL_OK;
+}
+
+// One Forward at (token, pos) on the session: continue the resident launch when this call is its next step, otherwise start
+// one.  *served = false leaves the call to the caller's other paths (the path is off, retired, or gave up just now -- the
+// launch plans redo the step: every buffer it writes is rewritten).  id = the step's argmax; logits (want_logits) are in
+// e->h_logits when the call returns.
+int pd_session_step(nl_engine *e, int stream, int token, int pos, bool want_logits, int *id, bool *served) {
+    nl_engine::Persist &d = e->pd;
+    *served = false;
+    if (!d.session_on || !pd_usable(e, pos, 1) || (want_logits && !e->d_h_logits)) return pd_session_close(e);
+    int rc;
+    if (d.live && (d.s_stream != stream || d.s_next_pos != pos || (want_logits && !d.s_logits) || e->hw[stream] < pos || *d.h_status))
+        if ((rc = pd_session_close(e))) return rc;
+    if (!pd_usable(e, pos, 1)) return NL_OK;         // (the close may have retired the path)
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rc = note_positions(e, stream, pos, 1))) return rc;
+        if (!d.live) {
+            const int n = std::min(d.max_pos - pos, e->ids_cap);
+            __atomic_store_n(d.h_mail, (pd_u64)0, __ATOMIC_RELAXED);
+            __atomic_store_n(d.h_mail + 8, (pd_u64)0, __ATOMIC_RELEASE);
+            if ((rc = pd_launch(e, stream, token, pos, n, want_logits ? e->d_h_logits : nullptr, true))) return rc;
+            d.tokens -= n;              // (pd_launch counted the whole session; steps are counted as they are served)
+            d.live = true; d.s_logits = want_logits; d.s_stream = stream; d.s_next_pos = pos; d.s_step = 0; d.s_nsteps = n;
+            d.sessions++;
+        } else {
+            __atomic_store_n(d.h_mail, ((pd_u64)(unsigned)d.s_step << 32) | (unsigned)token, __ATOMIC_RELEASE);
+        }
+        const unsigned want = (unsigned)d.s_step + 1u;
+        const auto t0 = std::chrono::steady_clock::now();
+        pd_u64 v = 0;
+        bool done = false;
+        for (unsigned spins = 0;; spins++) {
+            v = __atomic_load_n(d.h_mail + 8, __ATOMIC_ACQUIRE);
+            if ((unsigned)(v >> 32) == want) { done = true; break; }
+            if (__atomic_load_n(d.h_status, __ATOMIC_ACQUIRE)) break;
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) break;
+            __builtin_ia32_pause();
+        }
+        if (!done) {       // the launch ended (idle just as the command arrived, or a poll gave up) -- or is stuck
+            HIPCK(e, hipStreamSynchronize(e->stream));
+            d.live = false;
+            v = __atomic_load_n(d.h_mail + 8, __ATOMIC_ACQUIRE);
+            done = (unsigned)(v >> 32) == want;
+            const unsigned st = *d.h_status;
+            if (st & 256u) {
+                *d.h_status = 0;
+                HIPCK(e, hipMemsetAsync(d.status, 0, sizeof(unsigned), e->stream));
+                if (!done) continue;                 // this call's step never began: a fresh session takes it
+            } else if (!done || st) {
+                if (!st) *d.h_status = 1024u;        // (no word from the launch at all)
+                pd_take_timeout(e);
+                return NL_OK;
+            }
+        }
+        if (id) *id = (int)(unsigned)v;
+        d.s_step++; d.s_next_pos++; d.tokens++;
+        if (d.s_step == d.s_nsteps) d.live = false;   // (its last step: the launch leaves by itself)
+        *served = true;
+        return NL_OK;
+    }
+    return NL_OK;
 }
 
 struct Slot { int layer; std::string field; };
@@ -2580,6 +2685,7 @@ int nl_set_gamma(nl_handle e, const int32_t *indices, int n, const void *values,
     if (!e || n < 0 || (n > 0 && (!indices || !values))) return NL_ERR_INVALID;
     const nl_config &c = e->cfg;
     HIPCK(e, hipSetDevice(e->dev));
+    if (int qrc = pd_session_close(e)) return qrc;
     HIPCK(e, hipStreamSynchronize(e->stream));
     // Build and upload the new tables BEFORE touching the old ones: the plan closures and captured graphs hold the
     // old device pointers until they are rebuilt below, so no error path may leave them dangling.  Indices outside
@@ -2636,6 +2742,7 @@ int nl_destroy(nl_handle e) {
     }
     if (!e) return NL_OK;
     hipSetDevice(e->dev);
+    (void)pd_session_close(e);
     hipDeviceSynchronize();
     samp_free(e->sp);
     for (auto &S : e->ps) destroy_graphs(S);
@@ -2699,22 +2806,36 @@ int nl_reset(nl_handle e, int stream) {
     return NL_OK;
 }
 
+float *nl_host_logits(nl_handle e) {
+    if (e && e->grp) return e->grp->members.empty() ? nullptr : e->grp->members[0]->h_logits;
+    return (e && e->finalized) ? e->h_logits : nullptr;
+}
+
 int nl_forward(nl_handle e, int stream, int token, int pos, float *logits_out) {
     if (e && e->grp) return group_run(e, [&](nl_engine *m, int r) { return nl_forward(m, stream, token, pos, r == 0 ? logits_out : nullptr); });
     if (!e) return NL_ERR_INVALID;
     int rc = check_step_args(e, stream, token, pos);
     if (rc) return rc;
     HIPCK(e, hipSetDevice(e->dev));
+    {
+        // the smallest tier: the resident session takes the token (nl_persist.h: no launch, no weight fetch, the LM-head units
+        // store the logits into the pinned host buffer themselves)
+        bool served = false;
+        if ((rc = pd_session_step(e, stream, token, pos, logits_out != nullptr, nullptr, &served))) return rc;
+        if (served) {
+            if (logits_out && logits_out != e->h_logits) memcpy(logits_out, e->h_logits, (size_t)e->cfg.vocab * 4);
+            return NL_OK;
+        }
+    }
     if (pd_usable(e, pos, 1)) {
-        // the smallest tier: one token as a persistent launch of one step (nl_persist.h: weights to the registers, one pass, logits
-        // stored into the pinned host buffer by the LM-head units themselves) -- 150 us against 215 for the thirty launches
+        // ... or, sessions off: one token as a persistent launch of one step (weights to the registers, one pass)
         if ((rc = note_positions(e, stream, pos, 1))) return rc;
         const bool direct = logits_out && e->d_h_logits;
         if ((rc = pd_launch(e, stream, token, pos, 1, direct ? e->d_h_logits : nullptr))) return rc;
         if (logits_out && !direct) HIPCK(e, hipMemcpyAsync(e->h_logits, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
         HIPCK(e, hipStreamSynchronize(e->stream));
         if (!pd_take_timeout(e)) {
-            if (logits_out) memcpy(logits_out, e->h_logits, (size_t)e->cfg.vocab * 4);
+            if (logits_out && logits_out != e->h_logits) memcpy(logits_out, e->h_logits, (size_t)e->cfg.vocab * 4);
             return NL_OK;
         }
     }
@@ -2731,7 +2852,7 @@ int nl_forward(nl_handle e, int stream, int token, int pos, float *logits_out) {
         break;
     }
     if (int prc = p2p_check(e)) return prc;
-    if (logits_out) memcpy(logits_out, e->h_logits, (size_t)e->cfg.vocab * 4);
+    if (logits_out && logits_out != e->h_logits) memcpy(logits_out, e->h_logits, (size_t)e->cfg.vocab * 4);
     return NL_OK;
 }
 
@@ -2747,6 +2868,11 @@ int nl_forward_argmax(nl_handle e, int stream, int token, int pos, int *next_id)
     int rc = check_step_args(e, stream, token, pos);
     if (rc) return rc;
     HIPCK(e, hipSetDevice(e->dev));
+    {
+        bool served = false;
+        if ((rc = pd_session_step(e, stream, token, pos, false, next_id, &served))) return rc;
+        if (served) return NL_OK;
+    }
     if (pd_usable(e, pos, 1)) {          // (see nl_forward)
         if ((rc = note_positions(e, stream, pos, 1))) return rc;
         if ((rc = pd_launch(e, stream, token, pos, 1))) return rc;
@@ -2783,6 +2909,7 @@ int nl_decode_greedy(nl_handle e, int stream, int token, int pos, int n_steps, i
     int rc = check_step_args(e, stream, token, pos);
     if (rc) return rc;
     HIPCK(e, hipSetDevice(e->dev));
+    if (int qrc = pd_session_close(e)) return qrc;
     int n = std::min(n_steps, e->cfg.seq_len - pos);
     n = std::min(n, e->ids_cap);
     if ((rc = note_positions(e, stream, pos, n))) return rc;
@@ -2912,6 +3039,7 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
     if (pos < 1 || pos > e->cfg.seq_len) return e->fail(NL_ERR_INVALID, "pos %d out of range [1,%d]", pos, e->cfg.seq_len);
     if (*n_recent < 0 || *n_recent > p->rep_window) return e->fail(NL_ERR_INVALID, "n_recent %d exceeds rep_window %d", *n_recent, p->rep_window);
     HIPCK(e, hipSetDevice(e->dev));
+    if (int qrc = pd_session_close(e)) return qrc;
     int n = std::min(n_steps, e->cfg.seq_len - pos);
     n = std::min(n, e->ids_cap);
     if (n_done) *n_done = std::max(n, 0);
@@ -3045,6 +3173,7 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
     for (int i = 0; i < n; i++)
         if (tokens[i] < 0 || tokens[i] >= e->cfg.vocab) return e->fail(NL_ERR_INVALID, "token %d out of range [0,%d)", tokens[i], e->cfg.vocab);
     HIPCK(e, hipSetDevice(e->dev));
+    if (int qrc = pd_session_close(e)) return qrc;
     if ((rc = note_positions(e, stream, pos0, n))) return rc;
     if (n >= NL_BATCH_MIN && batch_supported(e)) {
         // multi-token path: 64-token tiles on the matrix cores; causality comes from each token's own pos
@@ -3083,7 +3212,7 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
         HIPCK(e, hipMemcpyAsync(e->h_logits, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCK(e, hipStreamSynchronize(e->stream));
     if (int prc = p2p_check(e)) return prc;
-    if (last_logits_out) memcpy(last_logits_out, e->h_logits, (size_t)e->cfg.vocab * 4);
+    if (last_logits_out && last_logits_out != e->h_logits) memcpy(last_logits_out, e->h_logits, (size_t)e->cfg.vocab * 4);
     return NL_OK;
 }
 
@@ -3106,6 +3235,7 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
     }
     if (n == 0) return NL_OK;
     HIPCK(e, hipSetDevice(e->dev));
+    if (int qrc = pd_session_close(e)) return qrc;
     for (int i = 0; i < n; i++)
         if ((rc = note_positions(e, streams[i], pos[i], 1))) return rc;
     if (n >= NL_BATCH_MIN && batch_supported(e)) {
@@ -3221,6 +3351,7 @@ int nl_synchronize(nl_handle e) {
     if (e && e->grp) return group_run(e, [&](nl_engine *m, int) { return nl_synchronize(m); });
     if (!e) return NL_ERR_INVALID;
     HIPCK(e, hipSetDevice(e->dev));
+    if (int qrc = pd_session_close(e)) return qrc;
     HIPCK(e, hipStreamSynchronize(e->stream));
     if (int prc = p2p_check(e)) return prc;
     return NL_OK;
@@ -3229,6 +3360,7 @@ int nl_synchronize(nl_handle e) {
 int nl_timer_start(nl_handle e) {
     if (e && e->grp) return nl_timer_start(e->grp->members[0]);
     if (!e) return NL_ERR_INVALID;
+    if (int qrc = pd_session_close(e)) return qrc;
     HIPCK(e, hipEventRecord(e->ev0, e->stream));
     return NL_OK;
 }
@@ -3236,6 +3368,7 @@ int nl_timer_start(nl_handle e) {
 int nl_timer_stop(nl_handle e, float *ms) {
     if (e && e->grp) return nl_timer_stop(e->grp->members[0], ms);
     if (!e || !ms) return NL_ERR_INVALID;
+    if (int qrc = pd_session_close(e)) return qrc;
     HIPCK(e, hipEventRecord(e->ev1, e->stream));
     HIPCK(e, hipEventSynchronize(e->ev1));
     HIPCK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
@@ -3254,6 +3387,7 @@ int nl_profile_forward(nl_handle e, int stream, int token, int pos, int iters, f
     int rc = check_step_args(e, stream, token, pos);
     if (rc) return rc;
     HIPCK(e, hipSetDevice(e->dev));
+    if (int qrc = pd_session_close(e)) return qrc;
     for (int k = 0; k < NL_NUM_KINDS; k++) { ms_out[k] = 0.f; calls_out[k] = 0; }
     if ((rc = note_positions(e, stream, pos, 1))) return rc;
     if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
@@ -3337,6 +3471,7 @@ int64_t nl_debug_read(nl_handle e, const char *which, int stream, float *out, in
     else if (w == "pd_dbg" && e->pd.dbg) { src = reinterpret_cast<const float *>(e->pd.dbg); n = 128; }   // 64 wall-clock stamps (int64) of nl_persist.h
     else return e->fail(NL_ERR_INVALID, "unknown debug buffer %s", which);
     n = std::min(n, max_floats);
+    if (hipSetDevice(e->dev) == hipSuccess) (void)pd_session_close(e);
     if (hipSetDevice(e->dev) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess ||
         hipMemcpy(out, src, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
         return e->fail(NL_ERR_HIP, "debug read failed");
@@ -3347,6 +3482,7 @@ int64_t nl_debug_read(nl_handle e, const char *which, int stream, float *out, in
 int nl_debug_stamps(nl_handle e, int kind, long long *out /* 16 waves x 8 */) {
     if (!e || !e->finalized || !out) return NL_ERR_INVALID;
     HIPCK(e, hipSetDevice(e->dev));
+    if (int qrc = pd_session_close(e)) return qrc;
     long long *d = nullptr;
     HIPCK(e, hipMalloc((void **)&d, 128 * sizeof(long long)));
     HIPCK(e, hipMemset(d, 0, 128 * sizeof(long long)));

@@ -101,12 +101,21 @@ struct PdParams {
     pd_u64 *go, *gxp;                // [L][D]: heads' attention outputs; x' = x + WO o
     pd_u64 *gh;                      // [L][I]: SiLU(gate) * up
     pd_u32x4 *gam;                   // [256] {tag, max bits, index, -}
-    unsigned *census;                // [8] tickets per XCD, [8] arrivals, [9] the token the launch ended on
+    unsigned *census, *census_next;  // [8] tickets per XCD, [8] arrivals of THIS launch; the next launch's words (zeroed here: no memset between launches)
     int *ids_out;                    // [n_steps]
     float *logits;                   // [V] of the last step
     float *host_logits;              // optional: the last step's logits also go straight into this (pinned, device-visible) host buffer
     unsigned *status, *host_status;
     long long *dbg;                  // optional stamps of (xcd 0, unit 0), thread 0
+    // resident session (per-call Forward: go/main.go:173-219 calls Forward once per token and samples on the host): the launch
+    // stays on the chip between calls.  After step s the doorman (unit 0 of layer 0's XCD) stores {s + 1, argmax} into *host_done
+    // and polls *mbox (both pinned host words) for {s + 1, token} -- the caller's next token -- or for a quit (token 0xffffffff);
+    // idle_ticks (100 MHz) without a command end the launch the same way, so a caller that went away costs the chip that long.
+    int session;
+    long long idle_ticks;
+    const pd_u64 *mbox;
+    pd_u64 *host_done;
+    pd_u64 *gtok;                    // the doorman's {tag, token} for the other units of its XCD
 };
 
 struct PdPackParams {
@@ -213,7 +222,7 @@ struct PdPoll {
     int *lds_dead;
 };
 __device__ __forceinline__ void pd_give_up(const PdPoll &Q, unsigned code, int tid) {
-    if ((tid & 63) == 0) { atomicOr(Q.status, code); *Q.host_status = code; *Q.lds_dead = 1; }
+    if ((tid & 63) == 0) { const unsigned old = atomicOr(Q.status, code); *Q.host_status = old | code; *Q.lds_dead = 1; }
 }
 // n granules -> v[k] = value of granule tid + 512 k (a wavefront leaves when all of its granules carry the tag); bounded
 template <int NPT>
@@ -483,6 +492,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
     xcd &= 7u;
 
     // ---- census: which unit of which XCD am I (placement is observed, never assumed) ----
+    if (blockIdx.x == 0 && tid0 < 16) P0.census_next[tid0] = 0u;     // (the launch that used those words has ended; the next one starts after this one)
     if (tid0 == 0) {
         misc[2] = 0;
         const unsigned t = atomicAdd(P0.census + xcd, 1u);
@@ -606,11 +616,57 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 for (int w = 1; w < PD_GRID / 64; w++)
                     if (bv[w] > best || (bv[w] == best && bi[w] < bidx)) { best = bv[w]; bidx = bi[w]; }
                 token = bidx == 0x7fffffff ? 0 : bidx;      // all-NaN logits: the reference's loop never leaves index 0
-                if (idx == 0 && tid == 0) { P.ids_out[step - 1] = token; if (step == P.n_steps) P.census[9] = (unsigned)token; }
+                if (idx == 0 && tid == 0) {
+                    P.ids_out[step - 1] = token;
+                    // (every unit's host rows were acknowledged before its granule left -- see the LM head -- so a plain system-scope
+                    //  store suffices: a release here would write this XCD's whole L2 back first)
+                    if (P.session) __hip_atomic_store(P.host_done, ((pd_u64)(unsigned)step << 32) | (unsigned)token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 __syncthreads();                              // bv / bi are reused by the LM head
                 PD_RELANE();
             }
             if (step == P.n_steps) break;
+            if (P.session && step > 0) {
+                // ---- resident session: the caller's token for this step (or the end of the session) ----
+                if (tid == 0) {
+                    if (idx == 0) {
+                        const long long t0 = wall_clock64();
+                        unsigned tk = 0xffffffffu;
+                        bool failed = false;
+                        for (;;) {
+                            const pd_u64 m = __hip_atomic_load(P.mbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            if ((unsigned)m == 0xffffffffu) break;                                           // quit
+                            if ((unsigned)(m >> 32) == (unsigned)step) { tk = (unsigned)m; break; }
+                            if (__hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { failed = true; break; }
+                            if (wall_clock64() - t0 > P.idle_ticks) break;                                   // the caller went away
+                            __builtin_amdgcn_s_sleep(4);
+                        }
+                        if (failed) misc[2] = 1;
+                        else if (tk == 0xffffffffu) { const unsigned old = atomicOr(P.status, 256u); *P.host_status = old | 256u; misc[2] = 1; }
+                        else pd_publish<false>(P.gtok, tag, __uint_as_float(tk));
+                    }
+                    if (!misc[2]) {
+                        const __amdgpu_buffer_rsrc_t r = pd_rsrc(P.gtok, 8u);
+                        pd_u64 g;
+                        for (int spins = 0;; spins++) {
+                            g = pd_ld8(r, 0);
+                            if ((unsigned)(g >> 32) == tag) break;
+                            if (spins >= P.spin_limit || ((spins & 63) == 63 && __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                                pd_give_up(Q, 512u, tid);
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        misc[3] = (int)(unsigned)g;
+                    }
+                }
+                __syncthreads();
+                PD_RELANE();
+                if (misc[2]) return;
+                token = misc[3];
+                __syncthreads();
+                PD_RELANE();
+            }
             // ---- embedding row (go/model.go:389-446) ----
             xa = embed_value(P.embd_raw, WT_Q8_0, D, token, c0);
             xb = embed_value(P.embd_raw, WT_Q8_0, D, token, c1);
@@ -895,12 +951,16 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 if (row < lm_n) {
                     if (!(tid & 1)) {
                         P.logits[lm_r0 + row] = lg;
-                        if (P.host_logits && step == P.n_steps - 1) P.host_logits[lm_r0 + row] = lg;     // per-call Forward: no DMA behind the launch
+                        if (P.host_logits && (P.session || step == P.n_steps - 1))      // per-call Forward: no DMA behind the launch
+                            __hip_atomic_store(P.host_logits + lm_r0 + row, lg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
                     if (lg > best) { best = lg; bidx = lm_r0 + row; }
                 }
                 pd_wave_argmax(best, bidx);              // (lane pairs = ascending rows)
                 if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
+                // the host rows are acknowledged before this unit's granule says so (they bypass the caches: waiting for the stores is
+                // enough -- a system-scope release fence would also write the XCD's L2 back, 17 us per step measured)
+                if (P.session && P.host_logits) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
             PD_RELANE();

@@ -164,6 +164,129 @@ def test_persistent_decode_give_up_falls_back_to_the_launch_plans(hip, orc, tmp_
     dev.close()
 
 
+def _teacher_forced(orc, g, tokens):
+    """the oracle's logits of Forward(tokens[i], i)"""
+    ref = orc.OracleModel(g)
+    orc.set_threads(min(16, os.cpu_count() or 1))
+    out = [ref.forward(t, pos).copy() for pos, t in enumerate(tokens)]
+    orc.set_threads(1)
+    ref.close()
+    return out
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max()) / max(1.0, float(b.std()))
+
+
+def test_resident_session_serves_per_call_forward(hip, orc, tmp_path, monkeypatch):
+    # go/main.go:173-219 calls Forward once per token with a token the HOST chose: here arbitrary (not the argmax) tokens.  One
+    # resident launch serves the whole run of nl_forward calls; every step's logits against the oracle's.
+    shape = synth.ModelShape("pd_session", 13, 256, 4, 4, 1024, seq_len=192, interm=512)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 151)
+    g = gguf.load_gguf(str(p))
+    tokens = synth.prompt_ids(150, shape.vocab, seed=21)
+    want = _teacher_forced(orc, g, tokens)
+    dev = hip.load_llama_model(g)
+    assert dev.persist_info()["ready"]
+    worst = 0.0
+    for pos, t in enumerate(tokens):
+        dev.forward(t, pos)
+        worst = max(worst, _rel(dev.state.logits, want[pos]))
+    info = dev.persist_info()
+    print(f"\nresident session, 150 forced tokens: max|gpu-oracle| = {worst:.2e}; launches {info['launches']}")
+    assert worst <= LOGIT_TOL and dev.last_error() == ""
+    assert info["launches"] == 1 and info["tokens"] == 150, info
+    keep = dev.state.logits.copy()
+    # the launch has left when another entry point needs the stream; what it wrote is what the launch plans read
+    assert _rel(dev.debug_read("logits", shape.vocab), want[-1]) <= LOGIT_TOL
+    got = dev.decode_greedy(int(np.argmax(keep)), 150, 8)
+    monkeypatch.setenv("NL_PERSIST", "0")
+    plain = hip.load_llama_model(g)
+    plain.prefill(tokens)
+    assert plain.decode_greedy(int(np.argmax(plain.state.logits)), 150, 8) == got
+    monkeypatch.delenv("NL_PERSIST")
+    # nl_forward_argmax on the same kind of session; then a call that needs logits starts a session that stores them
+    dev.reset()
+    for pos, t in enumerate(tokens[:40]):
+        assert dev.forward_argmax(t, pos) == int(np.argmax(want[pos])), pos
+    base = dev.persist_info()["launches"]
+    dev.forward(tokens[40], 40)
+    assert _rel(dev.state.logits, want[40]) <= LOGIT_TOL
+    assert dev.persist_info()["launches"] == base + 1
+    # ... which also serves argmax calls
+    assert dev.forward_argmax(tokens[41], 41) == int(np.argmax(want[41]))
+    assert dev.persist_info()["launches"] == base + 1
+    # a repeated position, a reset, a jump over unwritten rows: each starts over and agrees with the launch plans
+    dev.forward(tokens[41], 41)
+    assert _rel(dev.state.logits, want[41]) <= LOGIT_TOL
+    dev.reset(); plain.reset()
+    for pos in (0, 1, 2, 9, 10):
+        dev.forward(tokens[pos], pos); plain.forward(tokens[pos], pos)
+        assert _rel(dev.state.logits, plain.state.logits) <= 2e-5, pos
+    assert dev.last_error() == ""
+    dev.close(); plain.close()
+
+
+def test_resident_session_idles_out_and_is_restarted(hip, orc, tmp_path, monkeypatch):
+    # a caller slower than the idle limit: the launch has left by the time the next token arrives; the call starts another
+    import time
+    shape = synth.ModelShape("pd_idle", 5, 256, 4, 4, 512, seq_len=64, interm=512)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 157)
+    g = gguf.load_gguf(str(p))
+    tokens = synth.prompt_ids(12, shape.vocab, seed=23)
+    want = _teacher_forced(orc, g, tokens)
+    monkeypatch.setenv("NL_PERSIST_IDLE_US", "300")
+    dev = hip.load_llama_model(g)
+    for pos, t in enumerate(tokens):
+        dev.forward(t, pos)
+        assert _rel(dev.state.logits, want[pos]) <= LOGIT_TOL, pos
+        time.sleep(0.02)
+    info = dev.persist_info()
+    assert info["launches"] == 12 and info["tokens"] == 12 and info["ready"], info
+    assert dev.last_error() == ""
+    dev.close()
+
+
+def test_resident_session_position_limit_and_give_up(hip, orc, tmp_path, monkeypatch):
+    shape = synth.ModelShape("pd_slimit", 13, 256, 4, 4, 1024, seq_len=96, interm=512)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 163)
+    g = gguf.load_gguf(str(p))
+    tokens = synth.prompt_ids(60, shape.vocab, seed=27)
+    want = _teacher_forced(orc, g, tokens)
+    # positions below the limit on the session (it ends by itself on its last step), the rest on the launch plans
+    monkeypatch.setenv("NL_PERSIST_MAX_POS", "32")
+    dev = hip.load_llama_model(g)
+    for pos, t in enumerate(tokens):
+        dev.forward(t, pos)
+        assert _rel(dev.state.logits, want[pos]) <= LOGIT_TOL, pos
+    info = dev.persist_info()
+    assert info["launches"] == 1 and info["tokens"] == 32 and dev.last_error() == "", info
+    dev.close()
+    # every poll gives up at once: the call is redone on the launch plans, which the handle keeps
+    monkeypatch.delenv("NL_PERSIST_MAX_POS")
+    monkeypatch.setenv("NL_PERSIST_SPIN_LIMIT", "0")
+    monkeypatch.setenv("NL_QUIET", "1")
+    dev = hip.load_llama_model(g)
+    for pos, t in enumerate(tokens[:6]):
+        dev.forward(t, pos)
+        assert _rel(dev.state.logits, want[pos]) <= LOGIT_TOL, pos
+    assert "persistent decode launch gave up" in dev.last_error()
+    assert not dev.persist_info()["ready"]
+    dev.close()
+    # sessions off: one launch of one step per call
+    monkeypatch.delenv("NL_PERSIST_SPIN_LIMIT")
+    monkeypatch.setenv("NL_PERSIST_SESSION", "0")
+    dev = hip.load_llama_model(g)
+    for pos, t in enumerate(tokens[:6]):
+        dev.forward(t, pos)
+        assert _rel(dev.state.logits, want[pos]) <= LOGIT_TOL, pos
+    assert dev.persist_info()["launches"] == 6
+    dev.close()
+
+
 def test_shapes_outside_the_instantiations_keep_the_launch_plans(hip, tmp_path):
     # GQA, other widths, other weight types: not candidates (the launch plans serve them as before)
     for shape, wt in ((synth.ModelShape("pd_gqa", 2, 256, 4, 2, 512, seq_len=64, interm=512), "q8_0"),

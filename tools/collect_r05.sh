@@ -5,6 +5,7 @@
 #   persist  tests/test_gpu_persist.py (the persistent decode of nl_persist.h)
 #   newtests the round's new parity tests of the wide tiers
 #   nano     nano bench one-liner
+#   dropin   tools/dropin_rates.py: nl_forward / nl_forward_argmax per call (integration/c/dropin_loop.c) against nl_decode_greedy
 #   bench    the driver's bench line (python bench.py --steps 20 --warmup 5)
 ulimit -c 0; export TMPDIR=/tmp NL_QUIET=1; cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 O=gpurun_out/r05; mkdir -p $O
@@ -19,6 +20,9 @@ tests)
 bench)
   (timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench_steps20.err | tail -1) > $O/r05_bench_n1_steps20.json.log
   cut -c1-700 $O/r05_bench_n1_steps20.json.log ;;
+dropin)
+  # per-call loops of a C host against the chained loop, nano Q8_0 (and with the resident session off)
+  for sess in 1 0; do NL_PERSIST_SESSION=$sess timeout 600 python3 tools/dropin_rates.py nano q8_0 2>&1 | tail -3; done > $O/r05_dropin_rates.log; cat $O/r05_dropin_rates.log ;;
 persist)
   (timeout 900 python -m pytest tests/test_gpu_persist.py -x -q -s 2>&1 | tail -40) > $O/pytest_persist.log; cat $O/pytest_persist.log ;;
 group)
