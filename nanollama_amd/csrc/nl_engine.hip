@@ -238,6 +238,10 @@ struct nl_engine {
     int fused_mode = 0;           // 1: whole attention half per layer (nl_block.h); 2: projection + attention (nl_group.h);
                                   // 3: a tensor-parallel rank's layer as two launches (nl_tp.h); 4: one GPU, wide tier: mode 3's
                                   // attention half with a direct seam (projection + attention + WO), then the two GEMVs
+    int prefetch = 1;             // NL_PREFETCH bits (nl_tp.h PfTiles): 1 = the attention launch warms round 0 of the feed-forward launch (kept:
+                                  // big 670 -> 698 tok/s); measured and left off (profiles/r05_prefetch_ab.log): 2 = the feed-forward launch warms
+                                  // the next layer's projection tiles (+0.8 %), 4 = a feed-forward round warms the round after the next (-5 %: two
+                                  // rounds and the touched one exceed the L2), 8 = bit 1's touches issued right after the block's own projection
     bool wide_ffn = false;        // modes 3 / 4: the feed-forward half is wide_ffn_kernel (nl_tp.h): always in mode 4 when eligible, in
                                   // mode 3 when the rank's shard is too large for tp_ffn_kernel's one-tile producers (tp 2 of the 7.9B tier)
     int wide_nf = 1, wide_ngc = 1;
@@ -344,6 +348,13 @@ struct nl_engine {
     } while (0)
 
 namespace {
+
+// bytes of one packed 16-row tile of a matrix with `npairs` 64-column pairs per row (nl_kernels.h load_pair)
+inline unsigned tile_qbytes(int wt, int npairs) {
+    const int cpp = wt == WT_Q8_0 ? 4 : wt == WT_Q4_0 ? 2 : wt == WT_F16 ? 8 : wt == WT_F32 ? 16 : wt == WT_Q4_K ? 2 : 4;
+    return (unsigned)npairs * (unsigned)cpp * TR * 16u;
+}
+inline unsigned tile_sbytes(int wt, int npairs) { return (unsigned)npairs * TR * 4u * (unsigned)scale_words(wt); }
 
 template <typename T>
 hipError_t dalloc(T **p, size_t n, size_t *acct = nullptr) {
@@ -770,6 +781,11 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         Q.wo_tpw = e->tpg.wo_tpw;
         Q.n_heads_local = e->Hs; Q.xq = e->tp_xq; Q.xo = e->tp_xo; Q.bias_out = L.bo; Q.x = e->x[cur];
         Q.seam = sm;
+        if (e->wide_ffn && (e->prefetch & 1) && L.gate.wtype == L.up.wtype && (L.gate.wtype == WT_Q4_0 || L.gate.wtype == WT_Q8_0)) {
+            Q.pf.q[0] = L.gate.q; Q.pf.q[1] = L.up.q; Q.pf.s[0] = L.gate.s; Q.pf.s[1] = L.up.s;
+            Q.pf.tile_qbytes = tile_qbytes(L.gate.wtype, L.gate.npairs); Q.pf.tile_sbytes = tile_sbytes(L.gate.wtype, L.gate.npairs);
+            Q.pf.ntiles = L.gate.ntiles; Q.pf.nmat = 2; Q.pf.blocks = L.down.ntiles; Q.pf_early = (e->prefetch & 8) ? 1 : 0;
+        }
         const int wt = L.qkv.wtype, grid = std::max(grp_grid(e->KVs, B.members), (L.wo.ntiles + e->tpg.wo_tpw - 1) / e->tpg.wo_tpw);
         const int ngroups = (L.qkv.npairs + KL - 1) / KL, nf = (ngroups + 16 / e->grp_tpm - 1) / (16 / e->grp_tpm);
         const size_t lds = tp_attn_lds_bytes(L.wo.npairs);
@@ -797,6 +813,18 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         const int wt = L.gate.wtype, nf = e->wide_nf, ngc = e->wide_ngc, rounds = F.rounds;
         const size_t lds = wide_ffn_lds_bytes(nf, L.down.npairs);
         F.seam = sm;
+        F.pf_ahead = (e->prefetch & 4) ? 1 : 0;
+        if ((e->prefetch & 2) && fused && (e->fused_mode == 3 || e->fused_mode == 4) && l + 1 < c.n_layers) {
+            const nl_engine::Layer &N = e->layers[l + 1];
+            if (N.qkv.wtype == WT_Q4_0 || N.qkv.wtype == WT_Q8_0) {
+                PfQkv &X = F.pf;
+                X.T.q[0] = N.qkv.q; X.T.s[0] = N.qkv.s; X.T.q[1] = N.qkv.q; X.T.s[1] = N.qkv.s;
+                X.T.tile_qbytes = tile_qbytes(N.qkv.wtype, N.qkv.npairs); X.T.tile_sbytes = tile_sbytes(N.qkv.wtype, N.qkv.npairs);
+                X.T.ntiles = N.qkv.ntiles; X.T.nmat = 1; X.T.blocks = grid;
+                X.tpm = e->grp_tpm; X.members = (e->gqa + 2) * 4 / e->grp_tpm; X.gqa = e->gqa; X.n_q_heads = e->Hs; X.n_kv_heads = e->KVs;
+                X.m8_inv = udiv_inv(8u * (unsigned)X.members); X.m_inv = udiv_inv((unsigned)X.members);
+            }
+        }
         Op op{K_FFNBLOCK, coll, cbuf, (size_t)c.dim, [F, wt, grid, nf, ngc, rounds, lds](hipStream_t st) {
 #define NL_WF(WT_, NF_, NGC_, R_) hipLaunchKernelGGL((wide_ffn_kernel<WT_, NF_, NGC_, R_>), dim3(grid), dim3(TP_THREADS), lds, st, F)
 #define NL_WF1(WT_, NF_, NGC_) do { if (rounds <= 1) NL_WF(WT_, NF_, NGC_, 1); else if (rounds == 2) NL_WF(WT_, NF_, NGC_, 2); \
@@ -2495,6 +2523,7 @@ int nl_finalize(nl_handle e) {
             hipDeviceProp_t prop{};
             if (hipGetDeviceProperties(&prop, e->dev) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
             if (const char *sl = getenv("NL_FUSED_SPIN_LIMIT")) e->spin_limit = atoi(sl);   // knob (tests): 0 makes every exchange give up
+            if (const char *pf = getenv("NL_PREFETCH")) e->prefetch = atoi(pf);              // knob (A/B): bits of nl_engine::prefetch
         }
         const char *fa = getenv("NL_FUSED_ATTN");          // knob (tests, tools): 0 keeps the five-launch plan only, 2 forces mode 2
         const int want = fa ? atoi(fa) : -1;

@@ -125,6 +125,38 @@ __device__ __forceinline__ void gran16_load4(const u32x4 *p0, const u32x4 *p1, c
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
 }
 
+// ---- warming the NEXT launch's first weight bytes (round 5; tools/l2_prefetch_probe.hip, profiles/r05_l2_prefetch_probe.log) ----
+// A launch of the wide tier starts cold: its first weight round (18.9 MB of gate || up, 14.2 MB of Q | K | V) costs the 2 us of a
+// first fetch plus 3 us of transfer while nothing else can run -- and the launch before it leaves HBM idle for longer than that
+// (the attention chain; the h gather and the tail).  So wavefronts that are waiting anyway read ONE dword of every 128-byte
+// line the SAME-numbered block of the next launch will request first: block b runs on XCD b % 8 in both launches (dispatch
+// order; an assumption that costs nothing but the benefit when it fails), the lines land in that XCD's L2, and the next
+// launch's first round is L2 hits (probe: 27.5 MB re-read 2.1 us faster than cold; 37 MB -- beyond the 32 MB of L2 -- 3.4 us).
+// A touch is an ordinary load whose result is only consumed at the end of the kernel (pf_done).  A wavefront's loads return
+// in order, so only wavefronts whose NEXT load comes after the touched bytes have landed may touch.
+struct PfTiles {
+    const uint8_t *q[2];             // packed quants of up to two matrices (gate, up) -- or one (Q | K | V: q[1] unused)
+    const uint32_t *s[2];
+    unsigned tile_qbytes, tile_sbytes;    // bytes of one 16-row tile's quants / scales (contiguous per tile)
+    int ntiles;                      // tiles per matrix
+    int nmat;                        // 0 = off
+    int blocks;                      // grid of the launch that will read them
+};
+__device__ __forceinline__ unsigned pf_lines(const PfTiles &T) { return (T.tile_qbytes + 127u) / 128u + (T.tile_sbytes + 127u) / 128u; }
+__device__ __forceinline__ unsigned pf_touch(const PfTiles &T, int mat, int tile, unsigned l) {
+    const unsigned ql = (T.tile_qbytes + 127u) / 128u;
+    const uint8_t *p = l < ql ? T.q[mat] + (size_t)tile * T.tile_qbytes + min(l * 128u, T.tile_qbytes - 4u)
+                              : reinterpret_cast<const uint8_t *>(T.s[mat]) + (size_t)tile * T.tile_sbytes + min((l - ql) * 128u, T.tile_sbytes - 4u);
+    return *reinterpret_cast<const unsigned *>(p);
+}
+__device__ __forceinline__ void pf_done(unsigned a, unsigned b) { asm volatile("" :: "v"(a), "v"(b)); }
+// what a block of tp_attn_kernel requests at entry (its projection tiles), for the launch in front of it
+struct PfQkv {
+    PfTiles T;                       // q[0] / s[0]: the packed [q; k; v] rows
+    int tpm, members, gqa, n_q_heads, n_kv_heads;
+    unsigned m8_inv, m_inv;
+};
+
 // Every thread with gi < ng spins on granule gi until its tag matches (a wavefront leaves together); bounded.
 __device__ __forceinline__ u32x4 gran16_wait(const u32x4 *src, int gi, int ng, unsigned tag, unsigned *status, unsigned *host_status,
                                              int spin_limit, unsigned code, bool dead) {
@@ -227,6 +259,8 @@ struct TpAttnParams {
     const float *bias_out;
     float *x;                    // residual stream, read at entry (RMSNorm input, owner rows) and rewritten by the owners
     TpSeam seam;
+    PfTiles pf;                  // round 0 of the feed-forward launch behind this one (gate, up tiles b of block b); nmat 0 = off
+    int pf_early;                // 1: touched as soon as the block's own projection tiles are out (else: just before the WO gather)
 };
 
 __host__ __device__ constexpr size_t tp_attn_lds_bytes(int wo_npairs) {
@@ -337,6 +371,32 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     float4 kreg[NV], vreg[NV], kregn[NV];
     const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + (long long)cl * P.seq_len * HD);
     const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + (long long)cl * P.seq_len * HD);
+    // ---- the blocks that only wait for the heads warm the next launch's first round (see PfTiles): wavefronts 1 .. 15
+    //      (wavefront 0 polls), one line per thread, split over the non-runner blocks of this block's XCD ----
+    unsigned pf0 = 0, pf1 = 0;
+    auto warm = [&]() {
+        if (!RUNNER && Q.pf.nmat > 0 && wave > 0) {
+            const int x = (int)(blockIdx.x & 7), b8 = (int)(blockIdx.x >> 3), M = P.members;
+            const int lg = max(0, (P.n_kv_heads - x + 7) >> 3);                 // cluster groups of this XCD lane that hold projection tiles
+            const int nb8 = ((int)gridDim.x - x + 7) >> 3;
+            const int j = LIVE ? (b8 / M) * (M - G) + (mem - G) : lg * (M - G) + (b8 - lg * M);     // rank among the lane's non-runners
+            const int np = lg * (M - G) + max(nb8 - lg * M, 0);
+            const unsigned lpt = pf_lines(Q.pf), per_block = (unsigned)Q.pf.nmat * lpt;
+            const unsigned total = (unsigned)((Q.pf.blocks - x + 7) >> 3) * per_block, stride = (unsigned)np * (TP_THREADS - 64);
+            const unsigned p0 = (unsigned)j * (TP_THREADS - 64) + (unsigned)(tid - 64), p1 = p0 + stride;
+            if (p0 < total) {
+                const unsigned tb = p0 / per_block, rem = p0 - tb * per_block, mat = rem / lpt;
+                const int tile = (int)tb * 8 + x;
+                if (tile < Q.pf.ntiles) pf0 = pf_touch(Q.pf, (int)mat, tile, rem - mat * lpt);
+            }
+            if (p1 < total) {
+                const unsigned tb = p1 / per_block, rem = p1 - tb * per_block, mat = rem / lpt;
+                const int tile = (int)tb * 8 + x;
+                if (tile < Q.pf.ntiles) pf1 = pf_touch(Q.pf, (int)mat, tile, rem - mat * lpt);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     auto second_half_loads = [&]() {
         load_pair<WT>(Q.wo_q, Q.wo_s, (long long)min(wtile, Q.wo_ntiles - 1) * Q.wo_npairs, wgg, wgs, r, min(k, wgs - 1), wc, wsc);
         e_resid = Q.x[min(w_row, D - 1)];
@@ -356,6 +416,7 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
         if (Q.bias_out) e_bo = Q.bias_out[min(w_row, D - 1)];
     };
     if (!LIVE) second_half_loads();
+    if (!LIVE && Q.pf_early) warm();
     __builtin_amdgcn_sched_barrier(0);      // (every request above leaves before anything below consumes one)
     TP_STAMP(sslot, 1);
 
@@ -415,6 +476,7 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
             gran16_publish(Q.xq + ((size_t)cl * (G + 2) * 4 + (size_t)mem * P.tpm) * GPT, P.tpm, tag, outv, lane);
         }
         TP_STAMP(sslot, 4);
+        if (!RUNNER && Q.pf_early) warm();
     }
     if (!RUNNER && !wg_has_wo) return;
 
@@ -535,6 +597,8 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
         if (!wg_has_wo) return;
     }
 
+    if (!RUNNER && !Q.pf_early) warm();
+
     // ---- WO (go/model.go:590-594): gather every local head's output, this block's rows of the column slice ----
     // (<= 2 granules per thread: 64 local heads -- the whole 7.9B layer on one GPU -- are 1536 granules)
     tp_gather16<2, false, true>(Q.xo, Q.xo, Q.n_heads_local * 4, tag, ao, ao, Q.n_heads_local * HD, P.status, P.host_status, P.spin_limit, 32u);
@@ -555,6 +619,7 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
         tp_allreduce_row(Q.seam, e_tag, w_row, v, e_resid, Q.x);
     }
     TP_STAMP(sslot, 10);
+    pf_done(pf0, pf1);
 }
 
 template <int WT, int NF>
@@ -806,6 +871,8 @@ struct WideFfnParams {
     unsigned *status, *host_status;
     int spin_limit;
     TpSeam seam;                      // n = -1: one GPU (x = resid + row); else a tensor-parallel rank's all-reduce seam
+    PfQkv pf;                         // the projection tiles the attention launch of the NEXT layer requests at entry (T.nmat 0 = off)
+    int pf_ahead;                     // 1: a round's request is followed by one dword per line of the round after it (into this XCD's L2)
 };
 
 __host__ __device__ constexpr size_t wide_ffn_lds_bytes(int nf, int dn_npairs) {
@@ -907,6 +974,7 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
     __builtin_amdgcn_wave_barrier();
 
     float inv = 0.f;
+    unsigned pfa[2] = {0u, 0u}, pfn = 0u;
 #pragma unroll
     for (int rnd = 0; rnd < R; rnd++) {
         const int t = b + rnd * nb;
@@ -920,6 +988,16 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
         __builtin_amdgcn_sched_barrier(0);
         if (rnd + 1 < R) load_round(rnd + 1);                // the freed registers go straight back out
         else down_loads();
+        if (rnd + 2 < R && P.pf_ahead) {                     // ... and the round after it starts moving into this XCD's L2
+            const int t2 = b + (rnd + 2) * nb;
+            const unsigned lpt = (unsigned)P.npairs * (CPP * TR * 16 + TR * 4 * scale_words(WT)) / 128u, ql = (unsigned)P.npairs * (CPP * TR * 16) / 128u;
+            if (t2 < P.gu_tiles && (unsigned)tid < 2u * lpt) {
+                const unsigned mat = (unsigned)tid >= lpt ? 1u : 0u, l = (unsigned)tid - mat * lpt;
+                const uint8_t *pq = (mat ? P.up_q : P.gate_q) + ((size_t)t2 * ql + l) * 128u;
+                const uint8_t *ps = reinterpret_cast<const uint8_t *>(mat ? P.up_s : P.gate_s) + ((size_t)t2 * (lpt - ql) + (l - ql)) * 128u;
+                pfa[rnd & 1] = *reinterpret_cast<const unsigned *>(l < ql ? pq : ps);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         acc = quad_sum(acc);
         float *rd = red + (rnd & 1) * NW * TR;
@@ -979,6 +1057,23 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
         }
     }
     __syncthreads();
+    if (P.pf.T.nmat > 0) {
+        // h is here and the W_down tile has landed: nothing else of this launch will ask memory for anything but the row stores.
+        // The projection tiles block b of the NEXT layer's attention launch requests at entry (tp_attn_body: tile_of) start moving
+        // into this XCD's L2 while the last dot products, the tail and the launch boundary pass.
+        const PfQkv &N = P.pf;
+        const int M = N.members, b8 = b >> 3;
+        const int cl = (int)udiv_by((unsigned)b, 8u * (unsigned)M, N.m8_inv) * 8 + (b & 7), mem = b8 - (int)udiv_by((unsigned)b8, (unsigned)M, N.m_inv) * M;
+        const unsigned lpt = pf_lines(N.T);
+        if (cl < N.n_kv_heads && (unsigned)tid < (unsigned)N.tpm * lpt) {
+            const unsigned slot = (unsigned)tid / lpt, l = (unsigned)tid - slot * lpt;
+            const int u = mem * N.tpm + (int)slot, jj = u & 3, hq = u >> 2;
+            const int sect = hq < N.gqa ? 0 : hq == N.gqa ? 1 : 2;
+            const int tile = (sect == 0 ? cl * N.gqa + hq : sect == 1 ? N.n_q_heads + cl : N.n_q_heads + N.n_kv_heads + cl) * 4 + jj;
+            if (hq < N.gqa + 2 && tile < N.T.ntiles) pfn = pf_touch(N.T, 0, tile, l);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < NGC; j++) {
@@ -993,6 +1088,7 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
         for (int w = 0; w < NW; w++) v += red2[w * TR + (tid & 15)];      // fixed order (a wavefront without a group left 0)
         tp_allreduce_row(P.seam, e_tag, o_row, v, e_resid, P.x);
     }
+    pf_done(pfa[0] ^ pfa[1], pfn);
 }
 
 // x[i] += sum[i]: the in-process shard group's counterpart of the owner lanes' store (nl_group_forward)

@@ -20,6 +20,11 @@ tests)
 bench)
   (timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench_steps20.err | tail -1) > $O/r05_bench_n1_steps20.json.log
   cut -c1-700 $O/r05_bench_n1_steps20.json.log ;;
+pfab)
+  # NL_PREFETCH A/B on the big tier (nl_tp.h PfTiles): bits 1 attention -> ffn round 0, 2 ffn -> next projection, 4 ffn round-ahead
+  for pf in ${PFAB_SET:-0 1 2 3 4 7}; do
+    echo -n "NL_PREFETCH=$pf "; NL_PREFETCH=$pf timeout 600 python3 bench.py --workload big:q4_0 --steps 64 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('kernels'))"
+  done > $O/r05_prefetch_ab.log 2>&1; cat $O/r05_prefetch_ab.log ;;
 dropin)
   # per-call loops of a C host against the chained loop, nano Q8_0 (and with the resident session off)
   for sess in 1 0; do NL_PERSIST_SESSION=$sess timeout 600 python3 tools/dropin_rates.py nano q8_0 2>&1 | tail -3; done > $O/r05_dropin_rates.log; cat $O/r05_dropin_rates.log ;;
