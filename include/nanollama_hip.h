@@ -211,6 +211,10 @@ NL_API int nl_op_rmsnorm(int device, const float *x, const float *w, float eps, 
 /* float32(math.Exp(float64(x))) of Softmax and SiLU (go/quant.go:619, :629-631) as the forward kernels compute it
  * (short-chain float64 exponential, nl_kernels.h exp_f64_as_f32), element-wise on host arrays. */
 NL_API int nl_op_exp(int device, const float *x, float *out, int n);
+/* Soak of the 16-byte {tag, v0, v1, v2} granules the fused launches exchange (nl_tp.h; no reference counterpart): n writer
+ * blocks store `iters` generations each, n reader blocks on other XCDs count every copy they read (*seen) and every copy whose
+ * four words are not of one generation (*torn; the engine assumes 0). */
+NL_API int nl_op_gran16_soak(int device, int n, unsigned iters, unsigned long long *torn, unsigned long long *seen);
 
 /* Sampling operator on host logits: one decision of sampleTopP / sampleTopK / argmax (go/main.go:294-408)
  * after the in-place repetition penalty (:177-187), on the device.  logits (in/out: the penalty is applied in

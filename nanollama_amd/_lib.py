@@ -90,7 +90,8 @@ EXPORTS = ["nl_build_info", "nl_set_gamma", "nl_abi_version", "nl_device_count",
            "nl_synchronize", "nl_timer_start", "nl_timer_stop", "nl_kernel_kind_name", "nl_profile_forward",
            "nl_memory_usage", "nl_debug_read", "nl_op_matmul", "nl_op_matmul_batch", "nl_op_rmsnorm", "nl_comm_get_unique_id",
            "nl_comm_init", "nl_group_forward", "nl_debug_stamps", "nl_sample_decode", "nl_op_sample", "nl_p2p_export",
-           "nl_p2p_import", "nl_p2p_info", "nl_p2p_loopback", "nl_op_exp", "nl_plan_info", "nl_persist_info", "nl_create_group", "nl_host_logits"]
+           "nl_p2p_import", "nl_p2p_info", "nl_p2p_loopback", "nl_op_exp", "nl_plan_info", "nl_persist_info", "nl_create_group", "nl_host_logits",
+           "nl_op_gran16_soak"]
 
 
 def lib():
@@ -142,6 +143,7 @@ def lib():
     L.nl_host_logits.restype = C.POINTER(C.c_float)
     L.nl_persist_info.argtypes = [vp, ip, ip, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.nl_op_exp.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
+    L.nl_op_gran16_soak.argtypes = [C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.nl_group_forward.argtypes = [C.POINTER(vp), i32, i32, i32, i32, fp]
     L.nl_sample_decode.argtypes = [vp, i32, i32, i32, C.POINTER(NlSampleParams), fp, ip, ip, ip, ip]
     L.nl_op_sample.argtypes = [i32, fp, i32, C.POINTER(NlSampleParams), C.c_float, ip, ip, ip]

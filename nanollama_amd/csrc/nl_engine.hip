@@ -3272,13 +3272,17 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
         // stream with its own step buffers, so that one dependent chain's launch heads and memory round trips overlap
         // another's work (a 64-stream step of the 841M tier is ~224 launches of <= 144 workgroups on a 256-CU chip).  The
         // arithmetic per stream does not depend on the group it steps in: results are bitwise those of the one-step form.
-        const int groups = std::max((n + QG_TOK - 1) / QG_TOK, std::min(e->sub_batches, n / 16));
+        // (off unless NL_SUB_BATCHES > 1 -- measured slower, profiles/r04_subbatch_groups.log: the default is the chunked loop below)
+        const int groups = e->sub_batches > 1 ? std::max((n + QG_TOK - 1) / QG_TOK, std::min(e->sub_batches, n / 16)) : 1;
         if (groups > 1 && groups <= 4) {
             if (!e->sub_fork) HIPCK(e, hipEventCreateWithFlags(&e->sub_fork, hipEventDisableTiming));
             HIPCK(e, hipEventRecord(e->sub_fork, e->stream));      // (the position bookkeeping above may have queued row clears)
             const int per = (n + groups - 1) / groups;
-            const char *rk = getenv("NL_ROPE_IN_ATTN");
-            const int knob_sig = rk ? atoi(rk) + 1 : 0;            // (a step's launch list also depends on this test knob)
+            // (a step's launch list and kernel arguments also depend on the test knobs batched_step reads per step: all of them
+            //  are part of the key of a cached step graph)
+            const char *rk = getenv("NL_ROPE_IN_ATTN"), *fk = getenv("NL_FOLD_NORM"), *pk = getenv("NL_PREFILL_PRECISION"), *kk = getenv("NL_KV16_MIN_TOKENS");
+            const int knob_sig = (rk ? atoi(rk) + 1 : 0) + 3 * (fk ? atoi(fk) + 1 : 0) + 9 * (pk && !strcmp(pk, "fp16x1") ? 1 : 0) +
+                                 18 * (kk ? (atoi(kk) & 0xfff) + 1 : 0);
             for (int g = 0, t0 = 0; g < groups; g++, t0 += per) {
                 const int m = std::min(per, n - t0);
                 if (m <= 0) break;
@@ -3296,7 +3300,7 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
                     b.h_meta[2 * b.cap + i] = streams[t0 + i];
                     nsplit = std::max(nsplit, pos[t0 + i] / ATT_CH + 1);
                 }
-                const int key_split = nsplit * 8 + knob_sig;
+                const int key_split = nsplit * 131072 + knob_sig;
                 HIPCK(e, hipStreamWaitEvent(sb.st, e->sub_fork, 0));
                 hipGraphExec_t exec = nullptr;
                 for (auto &G : sb.graphs)
@@ -3699,6 +3703,28 @@ int nl_op_exp(int device, const float *x, float *out, int n) {
         rc = NL_OK;
     } while (0);
     hipFree(d);
+    return rc;
+}
+
+// Soak of the 16-byte granule form (nl_tp.h gran16_soak_kernel): pairs writers on `n` compute units with readers on other XCDs.
+int nl_op_gran16_soak(int device, int n, unsigned iters, unsigned long long *torn, unsigned long long *seen) {
+    if (!torn || !seen || n < 1 || n > 128 || iters < 1) return NL_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return NL_ERR_HIP;
+    u32x4 *slots = nullptr;
+    unsigned long long *cnt = nullptr;
+    int rc = NL_ERR_HIP;
+    do {
+        if (hipMalloc((void **)&slots, (size_t)n * 256 * sizeof(u32x4)) != hipSuccess || hipMalloc((void **)&cnt, 16) != hipSuccess) break;
+        if (hipMemset(slots, 0, (size_t)n * 256 * sizeof(u32x4)) != hipSuccess || hipMemset(cnt, 0, 16) != hipSuccess) break;
+        hipLaunchKernelGGL(gran16_soak_kernel, dim3(2 * n), dim3(256), 0, 0, slots, n, iters, cnt, cnt + 1);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) break;
+        unsigned long long h[2];
+        if (hipMemcpy(h, cnt, 16, hipMemcpyDeviceToHost) != hipSuccess) break;
+        *torn = h[0]; *seen = h[1];
+        rc = NL_OK;
+    } while (0);
+    if (slots) hipFree(slots);
+    if (cnt) hipFree(cnt);
     return rc;
 }
 

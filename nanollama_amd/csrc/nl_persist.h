@@ -11,25 +11,35 @@
 //   * 256 persistent workgroups (one per compute unit) read HW_REG_XCC_ID and take a ticket from their XCD's counter; roles
 //     follow the REAL placement (nothing assumes block b -> XCD b % 8; a census that is not 8 x 32 makes the launch give up
 //     and the caller keeps the launch plans);
-//   * XCD x owns layers first(x) .. first(x) + nslots(x) - 1 (13 layers: two on XCDs 0-4, one on 5-7).  The weights of its
-//     layers sit in the REGISTERS of its 32 compute units for the whole launch (8 wavefronts x 256 VGPRs: 4.2 MB per layer
-//     = 132 KB per compute unit and layer); the LM head's 1/256 slice (76 KB) sits in each compute unit's LDS.  Nothing
-//     but activations and K / V rows moves per token;
-//   * inside a layer H compute units are HEADS (Q | K | V rows of one head, RoPE, KV store, softmax attention over the cache,
-//     all local to the workgroup: go/model.go:517-587) and the other 32 - H are WORKERS (rows of WO, gate / up, down:
-//     go/model.go:590-612).  Four hand-offs per layer, all inside the XCD: x -> heads, o -> workers, x' among workers,
-//     h among workers; the layer's output leaves as the next layer's x (write-through only where the next layer lives on
-//     another XCD);
+//   * XCD x owns layers first(x) .. first(x) + nslots(x) - 1 (13 layers: two on XCDs 0-4, one on 5-7).  The int8 quants of its
+//     layers sit in the REGISTERS of its 32 compute units for the whole launch (8 wavefronts x 144 of 256 VGPRs: 4.2 MB per
+//     layer), their fp16 scales and the LM head's 1/256 slice (85 KB) in each compute unit's LDS.  Nothing but activations and
+//     K / V rows moves per token;
+//   * inside a layer EVERY matrix is split by rows over all 32 units of the XCD (unit idx: rows idx * R / 32 ...): Q | K | V
+//     (go/model.go:517-523), WO + residual (:590-594), gate / up + SiLU (:597-606), down + residual (:609-612).  H of the units
+//     additionally run the attention of one head each (RoPE, KV store, softmax over the cache: :449-477, :552-587) on the
+//     q | k | v rows that reach them through one more hand-off.  Five hand-offs per layer, all inside the XCD: q|k|v -> heads,
+//     o -> all, x' -> all, h -> all, and the layer's output as the next layer's x (write-through only where the next layer
+//     lives on another XCD);
 //   * after the last layer every compute unit multiplies its LM-head rows, the per-unit (max, index) pairs meet on layer 0's
 //     XCD, whose compute units pick the token (go/main.go:400-408: strict '>', lowest index on ties), look up its embedding
 //     row (go/model.go:389-446) and start the next token.
+// Dot products run on the matrix pipe: v_mfma_i32_4x4x4_16b_i8 over the int8 weights and four signed base-256 digits of the
+// 2^-30-rounded inputs (pd_limbs / pd_units_impl below).
 // Hand-offs are 8-byte {tag, value} granules (tag = launch base + step + 1; one aligned store each, the value is its own
 // arrival flag), polled with L1-bypassing loads; every poll is bounded and a give-up sets the status word the host checks
 // (it then redoes the chunk on the launch plans and retires this path, like the fused plans of nl_block.h).
 //
-// Arithmetic per block is BlockDot's (four accumulators per 32-element block, then * d), block products of a row are added
-// in block order as go/quant.go:149-165 does; RMSNorm's 1/rms multiplies the row sum (as every GEMV here does); softmax
-// pieces as nl_block.h.  Held to the oracle's logits within 1e-4 and to its greedy ids (tests/test_gpu_persist.py).
+// RESIDENT SESSION (per-call Forward).  go/main.go:173-219 calls Forward once per token and samples on the host, so the
+// reference's own loop cannot use a chunked launch.  PdParams::session keeps the launch on the chip between nl_forward calls
+// instead: after a step the doorman (unit 0 of layer 0's XCD) stores {step, argmax} into a pinned host word and polls a pinned
+// mailbox word for the caller's next token; the LM-head units store every step's logits straight into the pinned host buffer
+// (nl_host_logits).  A quit in the mailbox -- or idle_ticks without a command -- raises a status bit every poll of the launch
+// watches, and the launch drains; the host starts another one when the next call comes (nl_engine.hip pd_session_step).
+//
+// Arithmetic per block is exact in int32 up to the 2^-30 input rounding, block products of a row are added in block order as
+// go/quant.go:149-165 does; RMSNorm's 1/rms multiplies the row sum (as every GEMV here does); softmax pieces as nl_block.h.
+// Held to the oracle's logits within 1e-4 and to its greedy ids (tests/test_gpu_persist.py).
 #pragma once
 #include "nl_kernels.h"
 

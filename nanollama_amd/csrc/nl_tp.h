@@ -85,8 +85,10 @@ __device__ __forceinline__ void tp_allreduce_row(const TpSeam &S, unsigned e_tag
     out[row] = resid + sum;
 }
 
-// ---- 16-byte granules {tag, v0, v1, v2}: ONE dwordx4 write-through store each (observed untorn on gfx950 like the 8-byte
-// form, cdna_hip_programming.md G16 R2; every consumer validates the tag of every granule it uses).  Measured
+// ---- 16-byte granules {tag, v0, v1, v2}: ONE dwordx4 write-through store each.  That a 16-byte aligned dwordx4 store is seen
+// whole or not at all by a dwordx4 load is an ASSUMED hardware property (the ISA documents no single-copy atomicity beyond 8
+// bytes; one lane's 16 bytes travel as one request to one cache line): soaked by gran16_soak_kernel below -- 1e8+ cross-XCD
+// reads per run in tests/test_gpu_tp_fused.py, never a mixed copy -- and every consumer validates the tag of every granule.  Measured
 // (tools/allgather_probe.hip, profiles/r04_allgather_probe.log): an all-gather of 2752 floats to 256 workgroups costs 1.77 us
 // from the last publish with these against 2.05 us with 8-byte granules and 2.6-4.5 us with flag + payload forms.
 // A TILE of 16 values (one 16-row projection tile, a quarter of a head) is six granules: granule j holds values 3j .. 3j+2.
@@ -200,18 +202,19 @@ __device__ __forceinline__ void tp_gather16(const u32x4 *src, const u32x4 *src2,
     static_assert(NR == 1 || NR == 2, "granules per thread");
     u32x4 ga[NR], gb[NR];
     if ((tid & ~63) < ng) {           // this wavefront holds granules
+        const bool second = (tid & ~63) + TP_THREADS < ng;      // ... and a second one per lane (wave-uniform: lanes past the end re-read the last granule)
         for (int spins = 0;; spins++) {
             const u32x4 *p0 = src + min(tid, ng - 1), *p1 = src + min(tid + TP_THREADS, ng - 1);
             if (TWO) {
                 const u32x4 *q0 = src2 + min(tid, ng - 1), *q1 = src2 + min(tid + TP_THREADS, ng - 1);
-                if (NR == 1 || tid + TP_THREADS >= ng + 63) gran16_load2(p0, q0, ga[0], gb[0]);
+                if (NR == 1 || !second) gran16_load2(p0, q0, ga[0], gb[0]);
                 else gran16_load4(p0, p1, q0, q1, ga[0], ga[NR - 1], gb[0], gb[NR - 1]);
             } else {
-                if (NR == 1 || tid + TP_THREADS >= ng + 63) ga[0] = gran16_load(p0);
+                if (NR == 1 || !second) ga[0] = gran16_load(p0);
                 else gran16_load2(p0, p1, ga[0], ga[NR - 1]);
             }
             bool ok = ga[0].x == tag && (!TWO || gb[0].x == tag);
-            if (NR == 2 && tid + TP_THREADS < ng + 63) ok = ok && ga[NR - 1].x == tag && (!TWO || gb[NR - 1].x == tag);
+            if (NR == 2 && second) ok = ok && ga[NR - 1].x == tag && (!TWO || gb[NR - 1].x == tag);
             if (__all(ok)) break;
             if (dead || spins >= spin_limit) { if (lane == 0) { atomicOr(status, code); *host_status = code; } break; }
             __builtin_amdgcn_s_sleep(PROBE ? 1 : 3);
@@ -1089,6 +1092,33 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
         tp_allreduce_row(P.seam, e_tag, o_row, v, e_resid, P.x);
     }
     pf_done(pfa[0] ^ pfa[1], pfn);
+}
+
+// Soak test of the property the 16-byte granules rest on (nl_op_gran16_soak; tests/test_gpu_tp_fused.py): one dwordx4
+// write-through store is seen whole or not at all by a dwordx4 L1-bypassing load of another compute unit.  Blocks [0, n) write
+// generations 1 .. iters of a granule whose three payload words are functions of its tag; blocks [n, 2n) -- on other XCDs: the
+// reader of writer b is block n + (b + 1) % n -- read it as fast as they can and count every copy whose words disagree.
+__global__ void __launch_bounds__(256) gran16_soak_kernel(u32x4 *slots, int n, unsigned iters, unsigned long long *torn, unsigned long long *seen) {
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    if (b < n) {
+        u32x4 *p = slots + (size_t)b * 256 + tid;
+        for (unsigned g = 1; g <= iters; g++) {
+            const u32x4 v = {g, g * 2654435761u + 1u, g ^ 0x5bd1e995u, ~g};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+            if ((g & 7u) == 0u) __builtin_amdgcn_s_sleep(1);
+        }
+        return;
+    }
+    const u32x4 *p = slots + (size_t)((b - n + 1) % n) * 256 + tid;
+    unsigned long long bad = 0, reads = 0;
+    for (unsigned spins = 0; spins < 40000000u; spins++) {
+        const u32x4 v = gran16_load(p);
+        reads++;
+        if (v.x != 0u && (v.y != v.x * 2654435761u + 1u || v.z != (v.x ^ 0x5bd1e995u) || v.w != ~v.x)) bad++;
+        if (v.x == iters) break;
+    }
+    atomicAdd(torn, bad);
+    atomicAdd(seen, reads);
 }
 
 // x[i] += sum[i]: the in-process shard group's counterpart of the owner lanes' store (nl_group_forward)

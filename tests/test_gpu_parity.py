@@ -1743,6 +1743,46 @@ def test_fused_launches_keep_streams_independent(hip, tmp_path, shape):
     dev.close(); solo.close()
 
 
+def test_batches_above_64_streams_chunked_loop_and_sub_batches_agree_bitwise(hip, tmp_path, monkeypatch):
+    # more streams than one 64-token step holds: by default nl_forward_batch walks them in chunks on the engine's stream; with
+    # NL_SUB_BATCHES > 1 the chunks step concurrently.  Same arithmetic per stream: bitwise the same logits and ids, and every
+    # stream agrees with its own single-stream run.
+    shape = synth.ModelShape("over64", 2, 256, 4, 2, 2048, seq_len=64, interm=768)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", 79, mode="qrand")
+    g = gguf.load_gguf(str(p))
+    ns, nsteps = 96, 5
+    rng = np.random.Generator(np.random.PCG64(67))
+    seqs = [[int(t) for t in rng.integers(3, shape.vocab, size=nsteps)] for _ in range(ns)]
+
+    def run(sub):
+        if sub:
+            monkeypatch.setenv("NL_SUB_BATCHES", str(sub))
+        else:
+            monkeypatch.delenv("NL_SUB_BATCHES", raising=False)
+        dev = hip.load_llama_model(g, max_streams=ns)
+        out = []
+        for k in range(nsteps):
+            ids, lg = dev.forward_batch(list(range(ns)), [seqs[s][k] for s in range(ns)], [k] * ns, want_logits=True)
+            out.append((list(ids), lg.copy()))
+        dev.close()
+        return out
+
+    base, cut = run(0), run(2)
+    for k, ((ids_a, lg_a), (ids_b, lg_b)) in enumerate(zip(base, cut)):
+        assert ids_a == ids_b, k
+        assert lg_a.tobytes() == lg_b.tobytes(), f"step {k}: the sub-batched step differs from the chunked loop"
+    monkeypatch.delenv("NL_SUB_BATCHES", raising=False)
+    solo = hip.load_llama_model(g)
+    for s in (0, 63, 64, 95):
+        solo.reset()
+        for k in range(nsteps):
+            solo.forward(seqs[s][k], k)
+            d = float(np.abs(solo.state.logits - base[k][1][s]).max()) / max(1.0, float(solo.state.logits.std()))
+            assert d <= 1e-4, (s, k, d)
+    solo.close()
+
+
 @pytest.mark.parametrize("groups", [2, 4])
 def test_concurrent_sub_batches_equal_the_one_step_batch_bitwise(hip, tmp_path, monkeypatch, groups):
     # nl_forward_batch cuts a decode batch into groups that step concurrently on their own HIP streams (each group's step a

@@ -215,3 +215,16 @@ def test_fused_modes_keep_out_of_a_launch_whose_staying_blocks_exceed_the_comput
         orc.set_threads(1)
         assert dev.last_error() == "" and dev.plan_info()["fused_mode"] == mode      # no stall, no retirement
         dev.close(); ref.close()
+
+
+def test_sixteen_byte_granules_are_never_seen_torn(hip):
+    # the in-launch exchanges of nl_tp.h publish {tag, v0, v1, v2} with ONE dwordx4 store and read it with ONE dwordx4 load; that
+    # the pair is single-copy atomic is an assumed hardware property (the tag check alone cannot see a torn copy).  128 writer
+    # blocks x 256 lanes x 20000 generations against readers on other XCDs: every copy read must be of one generation.
+    import ctypes as C
+    from nanollama_amd import _lib
+    torn, seen = C.c_ulonglong(0), C.c_ulonglong(0)
+    rc = _lib.lib().nl_op_gran16_soak(0, 128, 20000, C.byref(torn), C.byref(seen))
+    assert rc == 0
+    print(f"\n16-byte granule soak: {seen.value:.3e} cross-XCD reads, {torn.value} torn")
+    assert seen.value > 128 * 256 * 100 and torn.value == 0
