@@ -14,7 +14,7 @@ if not os.path.exists(path):
     synth.generate_gguf(path + ".tmp", synth.TIERS["big"], "q4_0", mode="qrand")
     os.replace(path + ".tmp", path)
 g = gguf.load_gguf(path)
-dev = model.load_llama_model(g, tp_rank=0, tp_size=n, p2p_loopback=True)
+dev = model.load_llama_model(g, tp_rank=0, tp_size=n, p2p_loopback=True) if n > 1 else model.load_llama_model(g)   # 1: the whole layer on one GPU (mode 4)
 print("plan", dev.plan_info())
 dev.prefill(synth.prompt_ids(8, g.meta.vocab_size))
 L = _lib.lib()
