@@ -54,6 +54,8 @@ const char *kKindNames[NL_NUM_KINDS] = {"embed", "qkv_rope", "attention", "wo_re
 struct PackedMat {
     uint8_t *q = nullptr;
     uint32_t *s = nullptr;
+    uint8_t *q2 = nullptr;       // Q4_0 matrices the wide fused launches multiply on the matrix pipe: the same bytes with the chunks of
+    uint32_t *s2 = nullptr;      // every (tile, 256-column group) permuted so that a quad of lanes holds four ROWS of a block (nl_tp.h)
     int wtype = -1, src_type = -1, rows = 0, cols = 0, ntiles = 0, npairs = 0;  // wtype = device layout type
     size_t q_bytes = 0, s_bytes = 0;
     bool ready = false;
@@ -238,6 +240,7 @@ struct nl_engine {
     int fused_mode = 0;           // 1: whole attention half per layer (nl_block.h); 2: projection + attention (nl_group.h);
                                   // 3: a tensor-parallel rank's layer as two launches (nl_tp.h); 4: one GPU, wide tier: mode 3's
                                   // attention half with a direct seam (projection + attention + WO), then the two GEMVs
+    bool mf_attn = false, mf_ffn = false;   // the attention / feed-forward launch of modes 3 / 4 multiplies on the matrix pipe (NL_MFMA_DOT=0: off)
     int prefetch = 1;             // NL_PREFETCH bits (nl_tp.h PfTiles): 1 = the attention launch warms round 0 of the feed-forward launch (kept:
                                   // big 670 -> 698 tok/s); measured and left off (profiles/r05_prefetch_ab.log): 2 = the feed-forward launch warms
                                   // the next layer's projection tiles (+0.8 %), 4 = a feed-forward round warms the round after the next (-5 %: two
@@ -781,16 +784,21 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         Q.wo_tpw = e->tpg.wo_tpw;
         Q.n_heads_local = e->Hs; Q.xq = e->tp_xq; Q.xo = e->tp_xo; Q.bias_out = L.bo; Q.x = e->x[cur];
         Q.seam = sm;
+        const bool mfa = e->mf_attn;
+        if (mfa) { B.qkv_q = L.qkv.q2; B.qkv_s = L.qkv.s2; Q.wo_q = L.wo.q2; Q.wo_s = L.wo.s2; }
         if (e->wide_ffn && (e->prefetch & 1) && L.gate.wtype == L.up.wtype && (L.gate.wtype == WT_Q4_0 || L.gate.wtype == WT_Q8_0)) {
-            Q.pf.q[0] = L.gate.q; Q.pf.q[1] = L.up.q; Q.pf.s[0] = L.gate.s; Q.pf.s[1] = L.up.s;
+            Q.pf.q[0] = e->mf_ffn ? L.gate.q2 : L.gate.q; Q.pf.q[1] = e->mf_ffn ? L.up.q2 : L.up.q;
+            Q.pf.s[0] = e->mf_ffn ? L.gate.s2 : L.gate.s; Q.pf.s[1] = e->mf_ffn ? L.up.s2 : L.up.s;
             Q.pf.tile_qbytes = tile_qbytes(L.gate.wtype, L.gate.npairs); Q.pf.tile_sbytes = tile_sbytes(L.gate.wtype, L.gate.npairs);
             Q.pf.ntiles = L.gate.ntiles; Q.pf.nmat = 2; Q.pf.blocks = L.down.ntiles; Q.pf_early = (e->prefetch & 8) ? 1 : 0;
         }
         const int wt = L.qkv.wtype, grid = std::max(grp_grid(e->KVs, B.members), (L.wo.ntiles + e->tpg.wo_tpw - 1) / e->tpg.wo_tpw);
         const int ngroups = (L.qkv.npairs + KL - 1) / KL, nf = (ngroups + 16 / e->grp_tpm - 1) / (16 / e->grp_tpm);
         const size_t lds = tp_attn_lds_bytes(L.wo.npairs);
-        Op op{K_ATTNBLOCK, coll, cbuf, (size_t)c.dim, [Q, wt, grid, nf, lds](hipStream_t st) {
-                  if (wt == WT_Q8_0 && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 1>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+        Op op{K_ATTNBLOCK, coll, cbuf, (size_t)c.dim, [Q, wt, grid, nf, lds, mfa](hipStream_t st) {
+                  if (mfa && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 1, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                  else if (mfa) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 2, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                  else if (wt == WT_Q8_0 && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 1>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
                   else if (wt == WT_Q8_0) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 2>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
                   else if (nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 1>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
                   else hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 2>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
@@ -813,20 +821,23 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         const int wt = L.gate.wtype, nf = e->wide_nf, ngc = e->wide_ngc, rounds = F.rounds;
         const size_t lds = wide_ffn_lds_bytes(nf, L.down.npairs);
         F.seam = sm;
+        const bool mff = e->mf_ffn;
+        if (mff) { F.gate_q = L.gate.q2; F.gate_s = L.gate.s2; F.up_q = L.up.q2; F.up_s = L.up.s2; F.dn_q = L.down.q2; F.dn_s = L.down.s2; }
         F.pf_ahead = (e->prefetch & 4) ? 1 : 0;
         if ((e->prefetch & 2) && fused && (e->fused_mode == 3 || e->fused_mode == 4) && l + 1 < c.n_layers) {
             const nl_engine::Layer &N = e->layers[l + 1];
             if (N.qkv.wtype == WT_Q4_0 || N.qkv.wtype == WT_Q8_0) {
                 PfQkv &X = F.pf;
-                X.T.q[0] = N.qkv.q; X.T.s[0] = N.qkv.s; X.T.q[1] = N.qkv.q; X.T.s[1] = N.qkv.s;
+                X.T.q[0] = X.T.q[1] = e->mf_attn ? N.qkv.q2 : N.qkv.q; X.T.s[0] = X.T.s[1] = e->mf_attn ? N.qkv.s2 : N.qkv.s;
                 X.T.tile_qbytes = tile_qbytes(N.qkv.wtype, N.qkv.npairs); X.T.tile_sbytes = tile_sbytes(N.qkv.wtype, N.qkv.npairs);
                 X.T.ntiles = N.qkv.ntiles; X.T.nmat = 1; X.T.blocks = grid;
                 X.tpm = e->grp_tpm; X.members = (e->gqa + 2) * 4 / e->grp_tpm; X.gqa = e->gqa; X.n_q_heads = e->Hs; X.n_kv_heads = e->KVs;
                 X.m8_inv = udiv_inv(8u * (unsigned)X.members); X.m_inv = udiv_inv((unsigned)X.members);
             }
         }
-        Op op{K_FFNBLOCK, coll, cbuf, (size_t)c.dim, [F, wt, grid, nf, ngc, rounds, lds](hipStream_t st) {
-#define NL_WF(WT_, NF_, NGC_, R_) hipLaunchKernelGGL((wide_ffn_kernel<WT_, NF_, NGC_, R_>), dim3(grid), dim3(TP_THREADS), lds, st, F)
+        Op op{K_FFNBLOCK, coll, cbuf, (size_t)c.dim, [F, wt, grid, nf, ngc, rounds, lds, mff](hipStream_t st) {
+#define NL_WF(WT_, NF_, NGC_, R_) do { if (mff && WT_ == WT_Q4_0) hipLaunchKernelGGL((wide_ffn_kernel<WT_Q4_0, NF_, NGC_, R_, true>), dim3(grid), dim3(TP_THREADS), lds, st, F); \
+                                       else hipLaunchKernelGGL((wide_ffn_kernel<WT_, NF_, NGC_, R_>), dim3(grid), dim3(TP_THREADS), lds, st, F); } while (0)
 #define NL_WF1(WT_, NF_, NGC_) do { if (rounds <= 1) NL_WF(WT_, NF_, NGC_, 1); else if (rounds == 2) NL_WF(WT_, NF_, NGC_, 2); \
                             else if (rounds == 3) NL_WF(WT_, NF_, NGC_, 3); else NL_WF(WT_, NF_, NGC_, 4); } while (0)
 #define NL_WF2(WT_, NF_) do { if (ngc <= 1) NL_WF1(WT_, NF_, 1); else NL_WF1(WT_, NF_, 3); } while (0)
@@ -2695,6 +2706,34 @@ int nl_finalize(nl_handle e) {
             HIPCK(e, hipMemset(e->tp_xo, 0, no * sizeof(u32x4)));
             HIPCK(e, dalloc(&e->tp_hx, nh, &e->bytes_state));
             HIPCK(e, hipMemset(e->tp_hx, 0, nh * sizeof(u32x4)));
+            // Q4_0 dot products of the two launches on the matrix pipe (nl_tp.h mf_*): matrices whose rows are whole 256-column
+            // groups get the permuted second copy the quads of v_mfma_i32_4x4x4_16b_i8 need (+ their size in HBM)
+            const char *mk = getenv("NL_MFMA_DOT");          // knob (A/B, tests): 0 keeps the vector-pipe dot products
+            // (1, the default: the feed-forward launch only -- there a column group's digit image serves three rounds; in the attention
+            //  launch it serves one tile and the conversion eats the gain: 13.5 against 13.3 us, profiles/r05_big_kernel_times_variants.log;
+            //  2 switches that one on as well)
+            bool ma = mk && atoi(mk) == 2 && e->Hs % 4 == 0, mf = !(mk && atoi(mk) == 0) && e->wide_ffn;
+            for (const auto &L : e->layers) {
+                ma = ma && L.qkv.wtype == WT_Q4_0 && L.wo.wtype == WT_Q4_0 && L.qkv.npairs % KL == 0 && L.wo.npairs % KL == 0;
+                mf = mf && L.gate.wtype == WT_Q4_0 && L.up.wtype == WT_Q4_0 && L.down.wtype == WT_Q4_0 && L.gate.npairs % KL == 0 && L.down.npairs % KL == 0;
+            }
+            auto permute = [&](PackedMat &m) -> int {
+                if (m.q2) return NL_OK;
+                HIPCK(e, arena_alloc(e, (void **)&m.q2, m.q_bytes));
+                HIPCK(e, arena_alloc(e, (void **)&m.s2, m.s_bytes));
+                e->bytes_weights += m.q_bytes + m.s_bytes;
+                const long long groups = (long long)m.ntiles * (m.npairs / KL);
+                hipLaunchKernelGGL(mf_permute_kernel, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, e->stream, reinterpret_cast<const uint4 *>(m.q), m.s,
+                                   reinterpret_cast<uint4 *>(m.q2), m.s2, groups);
+                HIPCK(e, hipGetLastError());
+                return NL_OK;
+            };
+            for (auto &L : e->layers) {
+                if (ma) { if (int prc = permute(L.qkv)) return prc; if (int prc = permute(L.wo)) return prc; }
+                if (mf) { if (int prc = permute(L.gate)) return prc; if (int prc = permute(L.up)) return prc; if (int prc = permute(L.down)) return prc; }
+            }
+            HIPCK(e, hipStreamSynchronize(e->stream));
+            e->mf_attn = ma; e->mf_ffn = mf;
         }
     }
     const bool has_coll = (e->G > 1 || e->force_tp_plan) && !e->p2p.on;

@@ -351,9 +351,13 @@ template <> struct PairDot<WT_Q4_0> {
             Acc4 s{0.f, 0.f, 0.f, 0.f};
             uint4 q = c[b];
             dot_q4_word(q.x, x4[8 * b + 0], x4[8 * b + 4], s);
+#ifndef NL_FAKE_DOT   // developer experiment (tools/collect_r05.sh fakedot): a quarter of the vector work, wrong results -- how much of a step is it?
             dot_q4_word(q.y, x4[8 * b + 1], x4[8 * b + 5], s);
             dot_q4_word(q.z, x4[8 * b + 2], x4[8 * b + 6], s);
             dot_q4_word(q.w, x4[8 * b + 3], x4[8 * b + 7], s);
+#else
+            s.b += __uint_as_float(q.y & 1u) + __uint_as_float(q.z & 1u) + __uint_as_float(q.w & 1u);      // (the loads stay)
+#endif
             acc = fmaf((s.a + s.b) + (s.c + s.d), h2f_bits((sc >> (16 * b)) & 0xffff), acc);
         }
         return acc;

@@ -247,6 +247,117 @@ __device__ __forceinline__ void tp_gather16(const u32x4 *src, const u32x4 *src2,
     }
 }
 
+// ---- Q4_0 dot products on the matrix pipe (round 5; profiles/r05_fake_dot.log: with a quarter of the vector instructions of
+// the dot products the 7.9B step drops from 1.43 to 1.23 ms -- the decode GEMV of a wide layer is NOT purely memory-bound on
+// this chip: 2.1 vector operations and 4 bytes of LDS per weight leave 6.5 us of a 35 us layer exposed) ----------------------
+// The arithmetic is nl_persist.h's: a 32-element block of the input is scaled by a power of two so that its largest element
+// fits 31 bits, rounded to integers X (2^-30 of the block maximum per element) and written as four SIGNED base-256 digits;
+// v_mfma_i32_4x4x4_16b_i8 multiplies the digit rows (A) with int8 weights (B) exactly in int32.  Sixteen independent 4x4x4
+// products per instruction: a QUAD of lanes = four weight ROWS of one block, so the fused launches read a second copy of their
+// matrices in which the 16-byte chunks of every (16-row tile, 256-column group) are permuted (mf_permute_kernel): lane
+// l = 4 q + j, chunk slot s <- row 4 (q & 3) + j, block (q >> 2) + 4 s of the group.  A Q4_0 weight is (n - 8) d: the products use
+// the nibbles n as they are and the block's -8 sum(X) is added once per unit.
+typedef int mf_i32x4 __attribute__((ext_vector_type(4)));
+constexpr int MF_GROUP_BYTES = 8 * 128 + 8 * 8;      // image of one 256-column group: 8 blocks x [4 digits][32 bytes], then {1/scale, offset} per block
+static_assert(MF_GROUP_BYTES == XS_WAVE * 4, "a group's digit image replaces its float staging area");
+
+__device__ __forceinline__ float mf_rows4_sum(float v) {      // lanes l, l + 16, l + 32, l + 48 (nl_batch.h rows4_sum)
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+template <int CTRL> __device__ __forceinline__ int mf_dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+
+// This lane's four consecutive elements v (elements 4 e4 .. 4 e4 + 3 of a block whose eight lanes are adjacent and all active)
+// -> the block's digit image blk_img[m][32] and {1 / scale, -8 sum(X) / scale}
+__device__ __forceinline__ void mf_digits4(float4 v, unsigned char *blk_img, float2 *bs, int e4) {
+    float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    a = fmaxf(a, dpp_f32<DPP_QUAD_XOR1>(a));
+    a = fmaxf(a, dpp_f32<DPP_QUAD_XOR2>(a));
+    a = fmaxf(a, dpp_f32<DPP_HALF_MIRROR>(a));                    // the block's 8 lanes
+    unsigned ex = __float_as_uint(a) >> 23;
+    ex = min(max(ex, 30u), 254u);
+    const float scale = __uint_as_float((283u - ex) << 23);        // 2^(29 - (ex - 127)): |v * scale| < 2^30
+    const int X0 = __float2int_rn(v.x * scale), X1 = __float2int_rn(v.y * scale), X2 = __float2int_rn(v.z * scale), X3 = __float2int_rn(v.w * scale);
+    // the signed base-256 digits of X are the bytes of (X + 0x808080) ^ 0x808080 (digit + 128 never carries)
+    const unsigned W0 = ((unsigned)X0 + 0x00808080u) ^ 0x00808080u, W1 = ((unsigned)X1 + 0x00808080u) ^ 0x00808080u;
+    const unsigned W2 = ((unsigned)X2 + 0x00808080u) ^ 0x00808080u, W3 = ((unsigned)X3 + 0x00808080u) ^ 0x00808080u;
+    // 4 x 4 byte transpose: word m = digit m of the four elements
+    const unsigned l01 = __builtin_amdgcn_perm(W1, W0, 0x05010400u), h01 = __builtin_amdgcn_perm(W1, W0, 0x07030602u);
+    const unsigned l23 = __builtin_amdgcn_perm(W3, W2, 0x05010400u), h23 = __builtin_amdgcn_perm(W3, W2, 0x07030602u);
+    unsigned *p = reinterpret_cast<unsigned *>(blk_img) + e4;
+    p[0] = __builtin_amdgcn_perm(l23, l01, 0x05040100u);
+    p[8] = __builtin_amdgcn_perm(l23, l01, 0x07060302u);
+    p[16] = __builtin_amdgcn_perm(h23, h01, 0x05040100u);
+    p[24] = __builtin_amdgcn_perm(h23, h01, 0x07060302u);
+    // sum of the block's X, exactly: 15 low bits and the rest summed apart (each below 2^21), joined in float32 with one rounding
+    int sl = (X0 & 0x7fff) + (X1 & 0x7fff) + (X2 & 0x7fff) + (X3 & 0x7fff), sh = (X0 >> 15) + (X1 >> 15) + (X2 >> 15) + (X3 >> 15);
+    sl += mf_dpp_i32<DPP_QUAD_XOR1>(sl); sh += mf_dpp_i32<DPP_QUAD_XOR1>(sh);
+    sl += mf_dpp_i32<DPP_QUAD_XOR2>(sl); sh += mf_dpp_i32<DPP_QUAD_XOR2>(sh);
+    sl += mf_dpp_i32<DPP_HALF_MIRROR>(sl); sh += mf_dpp_i32<DPP_HALF_MIRROR>(sh);
+    if (e4 == 0) {
+        const float inv = __uint_as_float((ex - 29u) << 23);       // 1 / scale
+        *bs = make_float2(inv, -8.0f * fmaf((float)sh, 32768.0f, (float)sl) * inv);
+    }
+}
+
+// One unit: the lane's 32 nibbles (row and block as mf_permute_kernel placed them) times the block's inputs -> d * sum (n - 8) x.
+// img: the block's digit image; j = lane & 3 = the digit row this lane feeds the quad's products with.
+__device__ __forceinline__ float mf_unit_q4(uint4 nib, unsigned d16, const unsigned char *blk_img, float2 bs, int j) {
+    const uint4 *ap = reinterpret_cast<const uint4 *>(blk_img + j * 32);
+    const uint4 a0 = ap[0], a1 = ap[1];
+    const unsigned m = 0x0f0f0f0fu;
+    mf_i32x4 acc = {0, 0, 0, 0};
+#define MF_P(A, W) acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)(A), (int)(W), acc, 0, 0, 0)
+    MF_P(a0.x, nib.x & m); MF_P(a0.y, nib.y & m); MF_P(a0.z, nib.z & m); MF_P(a0.w, nib.w & m);                          // elements 0 .. 15: the low nibbles
+    MF_P(a1.x, (nib.x >> 4) & m); MF_P(a1.y, (nib.y >> 4) & m); MF_P(a1.z, (nib.z >> 4) & m); MF_P(a1.w, (nib.w >> 4) & m);  // 16 .. 31: the high ones
+#undef MF_P
+    const float f = fmaf(fmaf(fmaf((float)acc[3], 256.f, (float)acc[2]), 256.f, (float)acc[1]), 256.f, (float)acc[0]);
+    return fmaf(f, bs.x, bs.y) * h2f_bits(d16);
+}
+
+// Two units of a lane (its two chunk slots: blocks b and b + 4 of a group) with their chains of eight dependent products
+// interleaved: a 4x4x4 product has a few cycles of latency its successor in the chain would otherwise wait for.
+__device__ __forceinline__ float mf_unit2_q4(const uint4 *nib, unsigned d16x2, const unsigned char *img0 /* block b's image */, const float2 *bs0, int j) {
+    const uint4 *ap = reinterpret_cast<const uint4 *>(img0 + j * 32), *bp = reinterpret_cast<const uint4 *>(img0 + 4 * 128 + j * 32);
+    const uint4 a0 = ap[0], a1 = ap[1], b0 = bp[0], b1 = bp[1];
+    const float2 s0 = bs0[0], s1 = bs0[4];
+    const unsigned m = 0x0f0f0f0fu;
+    mf_i32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#define MF_P(ACC, A, W) ACC = __builtin_amdgcn_mfma_i32_4x4x4i8((int)(A), (int)(W), ACC, 0, 0, 0)
+    MF_P(acc0, a0.x, nib[0].x & m); MF_P(acc1, b0.x, nib[1].x & m);
+    MF_P(acc0, a0.y, nib[0].y & m); MF_P(acc1, b0.y, nib[1].y & m);
+    MF_P(acc0, a0.z, nib[0].z & m); MF_P(acc1, b0.z, nib[1].z & m);
+    MF_P(acc0, a0.w, nib[0].w & m); MF_P(acc1, b0.w, nib[1].w & m);
+    MF_P(acc0, a1.x, (nib[0].x >> 4) & m); MF_P(acc1, b1.x, (nib[1].x >> 4) & m);
+    MF_P(acc0, a1.y, (nib[0].y >> 4) & m); MF_P(acc1, b1.y, (nib[1].y >> 4) & m);
+    MF_P(acc0, a1.z, (nib[0].z >> 4) & m); MF_P(acc1, b1.z, (nib[1].z >> 4) & m);
+    MF_P(acc0, a1.w, (nib[0].w >> 4) & m); MF_P(acc1, b1.w, (nib[1].w >> 4) & m);
+#undef MF_P
+    // digits joined two by two in int32 (each pair below 2^25), then one float32 multiply-add
+    const float f0 = fmaf((float)(acc0[2] + (acc0[3] << 8)), 65536.f, (float)(acc0[0] + (acc0[1] << 8)));
+    const float f1 = fmaf((float)(acc1[2] + (acc1[3] << 8)), 65536.f, (float)(acc1[0] + (acc1[1] << 8)));
+    return fmaf(f0, s0.x, s0.y) * h2f_bits(d16x2 & 0xffffu) + fmaf(f1, s1.x, s1.y) * h2f_bits(d16x2 >> 16);
+}
+
+// The permuted copy (see above): one thread per (tile, group, lane, slot) of a Q4_0 matrix whose rows are whole groups.
+__global__ void mf_permute_kernel(const uint4 *q, const uint32_t *s, uint4 *q2, uint32_t *s2, long long ngroups_total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ngroups_total * 64) return;
+    const long long grp = i >> 6;
+    const int lane = (int)(i & 63), qd = lane >> 2, j = lane & 3;
+    const int row = 4 * (qd & 3) + j;
+    uint32_t sw = 0;
+#pragma unroll
+    for (int slot = 0; slot < 2; slot++) {
+        const int blk = (qd >> 2) + 4 * slot, k = blk >> 1, c = blk & 1;      // source: pair k of the row, chunk c (nl_kernels.h load_pair)
+        q2[grp * 128 + slot * 64 + lane] = q[grp * 128 + c * 64 + row * 4 + k];
+        sw |= ((s[grp * 64 + row * 4 + k] >> (16 * c)) & 0xffffu) << (16 * slot);
+    }
+    s2[grp * 64 + lane] = sw;
+}
+
 // ------------------------------------------------------------------------------------------------ attention half ---
 
 struct TpAttnParams {
@@ -267,14 +378,15 @@ struct TpAttnParams {
 };
 
 __host__ __device__ constexpr size_t tp_attn_lds_bytes(int wo_npairs) {
-    return 16 * sizeof(double) + sizeof(float) * (size_t)(16 * XS_WAVE + 16 * TR + 3 * 64 + 16 * 68 + TP_NCH_MAX * 66 + wo_npairs * XS_PAIR + 16 * TR);
+    return 16 * sizeof(double) + sizeof(float) * (size_t)(16 * XS_WAVE + 16 * TR + 3 * 64 + 16 * 68 + TP_NCH_MAX * 66 + wo_npairs * XS_PAIR + 16 * TR) +
+           (size_t)wo_npairs * (256 + 16);        // (the digit image of the heads' outputs: matrix-pipe dot products)
 }
 
 // One role of the launch as straight-line code: every load below is unconditional (clamped addresses, masked uses), so
 // hipcc's counted s_waitcnt in front of the first use of x is exact -- with loads behind role branches it assumes the
 // shortest path and makes the RMSNorm wait for the weights, the dots for the cache rows and the WO tiles.
 // LIVE: the block holds projection tiles; RUNNER: ... and runs the attention of one query head.
-template <int WT, int NF, bool LIVE, bool RUNNER>
+template <int WT, int NF, bool LIVE, bool RUNNER, bool MF>
 __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, int cl, int mem) {
     const GroupParams &P = Q.G;
     constexpr int HD = 64, CPP = WTraits<WT>::CPP, R4 = HD / 4, NV = 4, NW = TP_THREADS / 64;
@@ -287,6 +399,9 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     float *chunk = wpart + 16 * 68;                                  // [TP_NCH_MAX][66]: (M, L, o[64]) per pass
     float *ao = chunk + TP_NCH_MAX * 66;                             // [wo_npairs][XS_PAIR]: every local head's output
     float *red2 = ao + Q.wo_npairs * XS_PAIR;                        // [16][16]
+    unsigned char *aimg = reinterpret_cast<unsigned char *>(red2 + NW * TR);   // MF: [2 wo_npairs blocks][4 digits][32]: the digit image of ao ...
+    float2 *abs2 = reinterpret_cast<float2 *>(aimg + Q.wo_npairs * 256);       // ... and {1 / scale, offset} per block
+    static_assert(!MF || WT == WT_Q4_0, "matrix-pipe dot products: Q4_0");
 
     const int G = (int)P.gqa, D = P.D;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -438,16 +553,34 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
                 ss = fma((double)xa.z, (double)xa.z, ss); ss = fma((double)xa.w, (double)xa.w, ss);
             }
             xa.x *= gv[f].x; xa.y *= gv[f].y; xa.z *= gv[f].z; xa.w *= gv[f].w;
-            *reinterpret_cast<float4 *>(xw + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
-            __builtin_amdgcn_wave_barrier();
-            const float a1 = PairDot<WT>::run(cw[f], sw[f], xw + k * XS_PAIR, acc);
-            acc = lv[f] ? a1 : acc;
+            if (!MF) {
+                *reinterpret_cast<float4 *>(xw + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
+                __builtin_amdgcn_wave_barrier();
+                const float a1 = PairDot<WT>::run(cw[f], sw[f], xw + k * XS_PAIR, acc);
+                acc = lv[f] ? a1 : acc;
+            } else {
+                // the wavefront's 256 columns as a digit image (eight blocks, eight adjacent lanes each); two units per lane
+                unsigned char *img = reinterpret_cast<unsigned char *>(xw);
+                float2 *bs = reinterpret_cast<float2 *>(img + 1024);
+                mf_digits4(xa, img + (lane >> 3) * 128, bs + (lane >> 3), lane & 7);
+                __builtin_amdgcn_wave_barrier();
+                const int b0 = lane >> 4;
+                float a1 = acc;
+                a1 += mf_unit_q4(cw[f][0], sw[f].x & 0xffffu, img + b0 * 128, bs[b0], lane & 3);
+                a1 += mf_unit_q4(cw[f][1], sw[f].x >> 16, img + (b0 + 4) * 128, bs[b0 + 4], lane & 3);
+                acc = lv[f] ? a1 : acc;
+            }
             __builtin_amdgcn_wave_barrier();
         }
         second_half_loads();
         __builtin_amdgcn_sched_barrier(0);
-        acc = quad_sum(acc);
-        if (k == 0) red[wave * TR + r] = acc;
+        if (!MF) {
+            acc = quad_sum(acc);
+            if (k == 0) red[wave * TR + r] = acc;
+        } else {
+            acc = mf_rows4_sum(acc);               // lanes 0 .. 15: row = lane
+            if (lane < TR) red[wave * TR + lane] = acc;
+        }
         ss = wave_sum_f64(ss);
         if (slot == 0 && lane == 0) dred[cs] = ss;
         TP_STAMP(sslot, 2);
@@ -606,12 +739,29 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     // (<= 2 granules per thread: 64 local heads -- the whole 7.9B layer on one GPU -- are 1536 granules)
     tp_gather16<2, false, true>(Q.xo, Q.xo, Q.n_heads_local * 4, tag, ao, ao, Q.n_heads_local * HD, P.status, P.host_status, P.spin_limit, 32u);
     __syncthreads();
+    if (MF) {       // ao -> digit image: a thread = four consecutive values, a block = eight adjacent threads
+        if (tid < Q.n_heads_local * (HD / 4)) {
+            const int e = tid * 4;
+            const float4 v = *reinterpret_cast<const float4 *>(ao + (e >> 6) * XS_PAIR + (e & 63));
+            mf_digits4(v, aimg + (tid >> 3) * 128, abs2 + (tid >> 3), tid & 7);
+        }
+        __syncthreads();
+    }
     TP_STAMP(sslot, 8);
     if (wslot < tpw) {
-        const float a1 = PairDot<WT>::run(wc, wsc, ao + min(wgg * KL + k, Q.wo_npairs - 1) * XS_PAIR, 0.f);
-        float a = wlv ? a1 : 0.f;
-        a = quad_sum(a);
-        if (k == 0) red2[wave * TR + r] = a;
+        if (!MF) {
+            const float a1 = PairDot<WT>::run(wc, wsc, ao + min(wgg * KL + k, Q.wo_npairs - 1) * XS_PAIR, 0.f);
+            float a = wlv ? a1 : 0.f;
+            a = quad_sum(a);
+            if (k == 0) red2[wave * TR + r] = a;
+        } else {
+            const int b0 = wgg * 8 + (lane >> 4);
+            float a = mf_unit_q4(wc[0], wsc.x & 0xffffu, aimg + b0 * 128, abs2[b0], lane & 3) +
+                      mf_unit_q4(wc[1], wsc.x >> 16, aimg + (b0 + 4) * 128, abs2[b0 + 4], lane & 3);
+            a = wlv ? a : 0.f;
+            a = mf_rows4_sum(a);
+            if (lane < TR) red2[wave * TR + lane] = a;
+        }
     }
     __syncthreads();
     TP_STAMP(sslot, 9);
@@ -625,7 +775,7 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     pf_done(pf0, pf1);
 }
 
-template <int WT, int NF>
+template <int WT, int NF, bool MF = false>
 __global__ void __launch_bounds__(TP_THREADS) tp_attn_kernel(TpAttnParams Q) {
     const GroupParams &P = Q.G;
     NL_KARGS8(P.qkv_q, P.qkv_s, P.x, P.normw, P.rope_cos, P.rope_sin, P.kcache, P.vcache);
@@ -642,9 +792,9 @@ __global__ void __launch_bounds__(TP_THREADS) tp_attn_kernel(TpAttnParams Q) {
     TP_CENSUS(0, P.layer_tag, 0);
     if (!live) {
         if ((int)blockIdx.x * Q.wo_tpw >= Q.wo_ntiles) return;
-        tp_attn_body<WT, NF, false, false>(Q, smem, 0, 0);
-    } else if (mem < (int)P.gqa) tp_attn_body<WT, NF, true, true>(Q, smem, cl, mem);
-    else tp_attn_body<WT, NF, true, false>(Q, smem, cl, mem);
+        tp_attn_body<WT, NF, false, false, MF>(Q, smem, 0, 0);
+    } else if (mem < (int)P.gqa) tp_attn_body<WT, NF, true, true, MF>(Q, smem, cl, mem);
+    else tp_attn_body<WT, NF, true, false, MF>(Q, smem, cl, mem);
     TP_CENSUS(0, P.layer_tag, 1);
 }
 
@@ -681,6 +831,7 @@ __host__ __device__ constexpr size_t tp_ffn_lds_bytes(int dn_npairs) {
 template <int WT, int NF, int NGC, int NR, bool PROD>
 __device__ __forceinline__ void tp_ffn_body(const TpFfnParams &P, char *smem) {
     constexpr int CPP = WTraits<WT>::CPP, NW = TP_THREADS / 64;
+    constexpr bool MF = false;        // (the vector-pipe dot products: a rank's W_down slice is not whole 256-column groups)
     double *dred = reinterpret_cast<double *>(smem);                 // [16]
     float *xs = reinterpret_cast<float *>(dred + 16);                // [16][XS_WAVE]
     float *red = xs + NW * XS_WAVE;                                  // [16][16]
@@ -735,7 +886,7 @@ __device__ __forceinline__ void tp_ffn_body(const TpFfnParams &P, char *smem) {
     uint4 dw[NGC][CPP];
     uint2 dsw[NGC];
     bool dlv[NGC];
-    int gsel[NGC];
+    int gsel[NGC], dgg[NGC];
     const int o_slot = tid >> 4, o_rr = tid & 15;
     const int o_row = (b * ct + o_slot) * TR + o_rr;
     const bool o_act = is_cons && tid < ct * TR && b * ct + o_slot < P.dn_ntiles && o_row < D;
@@ -747,6 +898,7 @@ __device__ __forceinline__ void tp_ffn_body(const TpFfnParams &P, char *smem) {
             const int gs = min(KL, P.dn_npairs - gg * KL);
             dlv[j] = is_cons && dtile < P.dn_ntiles && g < dgroups && k < gs;
             gsel[j] = min(gg * KL + k, P.dn_npairs - 1);
+            dgg[j] = gg;
             load_pair<WT>(P.dn_q, P.dn_s, (long long)min(dtile, P.dn_ntiles - 1) * P.dn_npairs, gg, gs, r, min(k, gs - 1), dw[j], dsw[j]);
         }
         e_resid = P.x[min(o_row, D - 1)];
@@ -765,16 +917,34 @@ __device__ __forceinline__ void tp_ffn_body(const TpFfnParams &P, char *smem) {
                 ss = fma((double)xa.z, (double)xa.z, ss); ss = fma((double)xa.w, (double)xa.w, ss);
             }
             xa.x *= gv[f].x; xa.y *= gv[f].y; xa.z *= gv[f].z; xa.w *= gv[f].w;
-            *reinterpret_cast<float4 *>(xw + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
-            __builtin_amdgcn_wave_barrier();
-            const float a1 = PairDot<WT>::run(cw[f], sw[f], xw + k * XS_PAIR, acc);
-            acc = lv[f] ? a1 : acc;
+            if (!MF) {
+                *reinterpret_cast<float4 *>(xw + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
+                __builtin_amdgcn_wave_barrier();
+                const float a1 = PairDot<WT>::run(cw[f], sw[f], xw + k * XS_PAIR, acc);
+                acc = lv[f] ? a1 : acc;
+            } else {
+                // the wavefront's 256 columns as a digit image (eight blocks, eight adjacent lanes each); two units per lane
+                unsigned char *img = reinterpret_cast<unsigned char *>(xw);
+                float2 *bs = reinterpret_cast<float2 *>(img + 1024);
+                mf_digits4(xa, img + (lane >> 3) * 128, bs + (lane >> 3), lane & 7);
+                __builtin_amdgcn_wave_barrier();
+                const int b0 = lane >> 4;
+                float a1 = acc;
+                a1 += mf_unit_q4(cw[f][0], sw[f].x & 0xffffu, img + b0 * 128, bs[b0], lane & 3);
+                a1 += mf_unit_q4(cw[f][1], sw[f].x >> 16, img + (b0 + 4) * 128, bs[b0 + 4], lane & 3);
+                acc = lv[f] ? a1 : acc;
+            }
             __builtin_amdgcn_wave_barrier();
         }
         second_half_loads();
         __builtin_amdgcn_sched_barrier(0);
-        acc = quad_sum(acc);
-        if (k == 0) red[wave * TR + r] = acc;
+        if (!MF) {
+            acc = quad_sum(acc);
+            if (k == 0) red[wave * TR + r] = acc;
+        } else {
+            acc = mf_rows4_sum(acc);               // lanes 0 .. 15: row = lane
+            if (lane < TR) red[wave * TR + lane] = acc;
+        }
         ss = wave_sum_f64(ss);
         if (wsel == 0 && lane == 0) dred[cs] = ss;
         TP_STAMP(sslot, 2);
@@ -879,7 +1049,8 @@ struct WideFfnParams {
 };
 
 __host__ __device__ constexpr size_t wide_ffn_lds_bytes(int nf, int dn_npairs) {
-    return 16 * sizeof(double) + sizeof(float) * (size_t)(16 * nf * XS_WAVE + 2 * 16 * TR + dn_npairs * XS_PAIR + 16 * TR);
+    return 16 * sizeof(double) + sizeof(float) * (size_t)(16 * nf * XS_WAVE + 2 * 16 * TR + dn_npairs * XS_PAIR + 16 * TR) +
+           (size_t)dn_npairs * (256 + 16);        // (the digit image of h: matrix-pipe dot products)
 }
 
 // R = rounds (compile time: every load below is unconditional and in program order, so hipcc's counted waits are exact -- the
@@ -890,8 +1061,9 @@ __host__ __device__ constexpr size_t wide_ffn_lds_bytes(int nf, int dn_npairs) {
 // wavefronts only so that the other four -- whose queues stay empty: a wavefront's loads return in order, a granule cannot
 // overtake weights in flight -- gather h while it streams (21.6 us: four wavefronts need four dependent sweeps for the 4128
 // granules).
-template <int WT, int NF, int NGC, int R>
+template <int WT, int NF, int NGC, int R, bool MF = false>
 __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
+    static_assert(!MF || WT == WT_Q4_0, "matrix-pipe dot products: Q4_0");
     NL_KARGS8(P.gate_q, P.up_q, P.gate_s, P.up_s, P.dn_q, P.dn_s, P.x, P.normw);
     NL_KARGS8(P.D, P.I, P.npairs, P.gu_tiles, P.dn_npairs, P.dn_ntiles, P.rounds, P.eps);
     NL_KARGS8(P.hx, P.tick, P.layer_tag, P.status, P.host_status, P.spin_limit, P.x, P.normw);
@@ -903,6 +1075,8 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
     float *red = xs + NW * NF * XS_WAVE;                             // [2][16][16]: a round's per-wavefront row sums (parity of the round)
     float *hs = red + 2 * NW * TR;                                   // [dn_npairs][XS_PAIR]: h
     float *red2 = hs + P.dn_npairs * XS_PAIR;                        // [16][16]
+    unsigned char *himg = reinterpret_cast<unsigned char *>(red2 + NW * TR);   // MF: [2 dn_npairs blocks][4 digits][32]: the digit image of h ...
+    float2 *hbs = reinterpret_cast<float2 *>(himg + P.dn_npairs * 256);         // ... and {1 / scale, offset} per block
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane >> 2, k = lane & 3, D = P.D;
     const int b = (int)blockIdx.x, nb = (int)gridDim.x;
@@ -933,6 +1107,9 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
     const int o_row = b * TR + (tid & 15);
     const bool o_act = tid < TR && b < P.dn_ntiles && o_row < D;
     const float e_resid = P.x[min(o_row, D - 1)];
+    // (One weight buffer.  A second one -- a round's dot products running while the next round's weights are in flight -- was
+    //  measured twice and lost both times: 20.9 against 19.7 us on the vector pipe (round 4), 19.1 against 17.8 us with the
+    //  matrix-pipe dot products and 98 registers (round 5): two rounds in flight are 38 MB against 32 MB of L2.)
     auto load_round = [&](int rnd) {
         const int t = min(b + rnd * nb, P.gu_tiles - 1);                       // (a block without a tile in the last round repeats a request)
 #pragma unroll
@@ -944,9 +1121,9 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
     uint4 dw[NGC][CPP];
     uint2 dsw[NGC];
     bool dlv[NGC];
-    int gsel[NGC];
+    int gsel[NGC], dgg[NGC];
 #pragma unroll
-    for (int j = 0; j < NGC; j++) { dlv[j] = false; gsel[j] = 0; }
+    for (int j = 0; j < NGC; j++) { dlv[j] = false; gsel[j] = 0; dgg[j] = 0; }
     auto down_loads = [&]() {
 #pragma unroll
         for (int j = 0; j < NGC; j++) {
@@ -954,6 +1131,7 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
             const int gs = min(KL, P.dn_npairs - gg * KL);
             dlv[j] = b < P.dn_ntiles && g < dgroups && k < gs;
             gsel[j] = min(gg * KL + k, P.dn_npairs - 1);
+            dgg[j] = gg;
             load_pair<WT>(P.dn_q, P.dn_s, (long long)dtile * P.dn_npairs, gg, gs, r, min(k, gs - 1), dw[j], dsw[j]);
         }
     };
@@ -970,7 +1148,11 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
             ss = fma((double)xa.z, (double)xa.z, ss); ss = fma((double)xa.w, (double)xa.w, ss);
         }
         xa.x *= gv[f].x; xa.y *= gv[f].y; xa.z *= gv[f].z; xa.w *= gv[f].w;
-        *reinterpret_cast<float4 *>(xw + f * XS_WAVE + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
+        if (!MF) *reinterpret_cast<float4 *>(xw + f * XS_WAVE + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
+        else {
+            unsigned char *img = reinterpret_cast<unsigned char *>(xw + f * XS_WAVE);
+            mf_digits4(xa, img + (lane >> 3) * 128, reinterpret_cast<float2 *>(img + 1024) + (lane >> 3), lane & 7);
+        }
     }
     ss = wave_sum_f64(ss);
     if (wsel == 0 && lane == 0) dred[cs] = ss;
@@ -985,12 +1167,26 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
         float acc = 0.f;
 #pragma unroll
         for (int f = 0; f < NF; f++) {
-            const float a1 = PairDot<WT>::run(cw[f], sw[f], xw + f * XS_WAVE + k * XS_PAIR, acc);
-            acc = lv[f] ? a1 : acc;
+            if (!MF) {
+                const float a1 = PairDot<WT>::run(cw[f], sw[f], xw + f * XS_WAVE + k * XS_PAIR, acc);
+                acc = lv[f] ? a1 : acc;
+            } else {
+                const unsigned char *img = reinterpret_cast<const unsigned char *>(xw + f * XS_WAVE);
+                const float2 *bs = reinterpret_cast<const float2 *>(img + 1024);
+                const int b0 = lane >> 4;
+                const float a1 = acc + mf_unit2_q4(cw[f], sw[f].x, img + b0 * 128, bs + b0, lane & 3);
+                acc = lv[f] ? a1 : acc;
+                if (rnd + 1 < R) {       // this group's registers go back out before the next group's products
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int t1 = min(b + (rnd + 1) * nb, P.gu_tiles - 1);
+                    load_pair<WT>(Wq, Ws, (long long)t1 * P.npairs, ggs[f], gsz[f], r, min(k, gsz[f] - 1), cw[f], sw[f]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (rnd + 1 < R) load_round(rnd + 1);                // the freed registers go straight back out
-        else down_loads();
+        if (!MF && rnd + 1 < R) load_round(rnd + 1);         // the freed registers go straight back out
+        if (rnd + 1 == R) down_loads();
         if (rnd + 2 < R && P.pf_ahead) {                     // ... and the round after it starts moving into this XCD's L2
             const int t2 = b + (rnd + 2) * nb;
             const unsigned lpt = (unsigned)P.npairs * (CPP * TR * 16 + TR * 4 * scale_words(WT)) / 128u, ql = (unsigned)P.npairs * (CPP * TR * 16) / 128u;
@@ -1002,9 +1198,14 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        acc = quad_sum(acc);
         float *rd = red + (rnd & 1) * NW * TR;
-        if (k == 0) rd[wave * TR + r] = acc;
+        if (!MF) {
+            acc = quad_sum(acc);
+            if (k == 0) rd[wave * TR + r] = acc;
+        } else {
+            acc = mf_rows4_sum(acc);
+            if (lane < TR) rd[wave * TR + lane] = acc;
+        }
         __syncthreads();
         if (rnd == 0 && tid < TR) {
             double tot = 0.0;
@@ -1060,6 +1261,14 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
         }
     }
     __syncthreads();
+    if (MF) {       // h -> digit image: a thread = four consecutive values, a block = eight adjacent threads
+        for (int i4 = tid; i4 < P.dn_npairs * (PAIR / 4); i4 += TP_THREADS) {
+            const int e = i4 * 4;
+            const float4 v = *reinterpret_cast<const float4 *>(hs + (e >> 6) * XS_PAIR + (e & 63));
+            mf_digits4(v, himg + (i4 >> 3) * 128, hbs + (i4 >> 3), i4 & 7);
+        }
+        __syncthreads();
+    }
     if (P.pf.T.nmat > 0) {
         // h is here and the W_down tile has landed: nothing else of this launch will ask memory for anything but the row stores.
         // The projection tiles block b of the NEXT layer's attention launch requests at entry (tp_attn_body: tile_of) start moving
@@ -1080,11 +1289,22 @@ __global__ void __launch_bounds__(TP_THREADS) wide_ffn_kernel(WideFfnParams P) {
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < NGC; j++) {
-        const float a1 = PairDot<WT>::run(dw[j], dsw[j], hs + gsel[j] * XS_PAIR, acc);
-        acc = dlv[j] ? a1 : acc;
+        if (!MF) {
+            const float a1 = PairDot<WT>::run(dw[j], dsw[j], hs + gsel[j] * XS_PAIR, acc);
+            acc = dlv[j] ? a1 : acc;
+        } else {
+            const int b0 = dgg[j] * 8 + (lane >> 4);
+            const float a1 = acc + mf_unit2_q4(dw[j], dsw[j].x, himg + b0 * 128, hbs + b0, lane & 3);
+            acc = dlv[j] ? a1 : acc;
+        }
     }
-    acc = quad_sum(acc);
-    if (k == 0) red2[wave * TR + r] = acc;
+    if (!MF) {
+        acc = quad_sum(acc);
+        if (k == 0) red2[wave * TR + r] = acc;
+    } else {
+        acc = mf_rows4_sum(acc);
+        if (lane < TR) red2[wave * TR + lane] = acc;
+    }
     __syncthreads();
     if (o_act) {
         float v = 0.f;

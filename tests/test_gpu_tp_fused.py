@@ -217,6 +217,46 @@ def test_fused_modes_keep_out_of_a_launch_whose_staying_blocks_exceed_the_comput
         dev.close(); ref.close()
 
 
+def test_matrix_pipe_dot_products_match_oracle_and_vector_pipe(hip, orc, tmp_path, monkeypatch):
+    # nl_tp.h mf_*: the feed-forward launch of the wide tiers multiplies Q4_0 weights on the matrix pipe (v_mfma_i32_4x4x4_16b_i8
+    # over base-256 digits of the inputs, a permuted second copy of the matrices); NL_MFMA_DOT=0 keeps the vector pipe, 2 puts the
+    # attention launch on the matrix pipe as well.  go/quant.go:45-94 (Q4_0 rows), go/model.go:597-612.  Four gate / up rounds per
+    # workgroup (I 4096 on a 64-block grid).  All three against the oracle; the matrix-pipe results are NOT the vector pipe's bits
+    # (which proves the path ran) but agree with them far inside the tolerance.
+    shape = synth.ModelShape("mf_dot", 2, 1024, 16, 4, 2048, seq_len=96, interm=4096)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", 211, mode="qrand")
+    g = gguf.load_gguf(str(p))
+    tokens = synth.prompt_ids(40, shape.vocab, seed=43)
+    ref = orc.OracleModel(g)
+    orc.set_threads(min(16, os.cpu_count() or 1))
+    want = [ref.forward(t, pos).copy() for pos, t in enumerate(tokens)]
+    orc.set_threads(1)
+    ref.close()
+    got = {}
+    monkeypatch.setenv("NL_WIDE_FFN", "2")      # (the one-launch feed-forward half on a 64-block grid too: by default it waits for grids that fill the chip)
+    for knob in ("0", "1", "2"):
+        monkeypatch.setenv("NL_MFMA_DOT", knob)
+        dev = hip.load_llama_model(g)
+        assert dev.plan_info()["fused_mode"] == 4, dev.plan_info()
+        out, worst = [], 0.0
+        for pos, t in enumerate(tokens):
+            dev.forward(t, pos)
+            out.append(dev.state.logits.copy())
+            worst = max(worst, float(np.abs(out[-1] - want[pos]).max()) / max(1.0, float(want[pos].std())))
+        assert dev.last_error() == ""
+        dev.close()
+        print(f"\nNL_MFMA_DOT={knob}: max|gpu-oracle| = {worst:.2e} over 40 positions")
+        assert worst <= LOGIT_TOL, knob
+        got[knob] = out
+    monkeypatch.delenv("NL_MFMA_DOT")
+    for knob in ("1", "2"):
+        assert any(a.tobytes() != b.tobytes() for a, b in zip(got["0"], got[knob])), f"NL_MFMA_DOT={knob} ran the vector pipe"
+        d = max(float(np.abs(a - b).max()) / max(1.0, float(a.std())) for a, b in zip(got["0"], got[knob]))
+        assert d <= 2e-5, (knob, d)
+    assert any(a.tobytes() != b.tobytes() for a, b in zip(got["1"], got["2"]))
+
+
 def test_sixteen_byte_granules_are_never_seen_torn(hip):
     # the in-launch exchanges of nl_tp.h publish {tag, v0, v1, v2} with ONE dwordx4 store and read it with ONE dwordx4 load; that
     # the pair is single-copy atomic is an assumed hardware property (the tag check alone cannot see a torn copy).  128 writer

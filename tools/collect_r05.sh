@@ -25,6 +25,21 @@ pfab)
   for pf in ${PFAB_SET:-0 1 2 3 4 7}; do
     echo -n "NL_PREFETCH=$pf "; NL_PREFETCH=$pf timeout 600 python3 bench.py --workload big:q4_0 --steps 64 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('kernels'))"
   done > $O/r05_prefetch_ab.log 2>&1; cat $O/r05_prefetch_ab.log ;;
+mfab)
+  # Q4_0 dot products of the wide fused launches on the matrix pipe (nl_tp.h mf_*) against the vector pipe: parity tests, then big A/B
+  (timeout 1500 python -m pytest tests/test_gpu_tp_fused.py -x -q 2>&1 | tail -6) > $O/pytest_tp_fused.log; cat $O/pytest_tp_fused.log
+  for mf in 0 1; do
+    echo -n "NL_MFMA_DOT=$mf "; NL_MFMA_DOT=$mf timeout 600 python3 bench.py --workload big:q4_0 --steps 64 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('greedy_ids_vs_cpu'), {k: v['us_per_launch'] for k, v in d.get('kernels', {}).items()})"
+  done > $O/r05_mfma_dot_ab.log 2>&1; cat $O/r05_mfma_dot_ab.log ;;
+ktimes)
+  # per-launch times of big under the library variants: tree (matrix-pipe dots), NL_MFMA_DOT=0 (vector pipe), -DNL_FAKE_DOT (a quarter of the vector dots)
+  (cd nanollama_amd/csrc && $hip -fPIC -ffp-contract=off -fno-slp-vectorize -fvisibility=hidden -DNL_FAKE_DOT -DNL_SRC_SHA=\"fakedot\" -DNL_GIT_HEAD=\"fakedot\" -shared -o /tmp/libnl_fake.so nl_engine.hip -ldl 2>&1 | grep -E " error" | head)
+  (timeout 300 python3 tools/kernel_times.py big q4_0 2>&1 | tail -1; NL_MFMA_DOT=0 timeout 300 python3 tools/kernel_times.py big q4_0 2>&1 | tail -1
+   NL_MFMA_DOT=0 NL_LIB_PATH=/tmp/libnl_fake.so timeout 300 python3 tools/kernel_times.py big q4_0 2>&1 | tail -1) > $O/r05_big_kernel_times_variants.log; cat $O/r05_big_kernel_times_variants.log ;;
+fakedot)
+  # how much of big's step is vector work?  A -DNL_FAKE_DOT copy of the library (a quarter of the Q4_0 dot products; wrong results) against the real one
+  (cd nanollama_amd/csrc && $hip -fPIC -ffp-contract=off -fno-slp-vectorize -fvisibility=hidden -DNL_FAKE_DOT -DNL_SRC_SHA=\"fakedot\" -DNL_GIT_HEAD=\"fakedot\" -shared -o /tmp/libnl_fake.so nl_engine.hip -ldl 2>&1 | grep -E " error" | head)
+  (echo "real:"; timeout 600 python3 tools/dropin_rates.py big q4_0 32 2>&1 | tail -1 | cut -c1-200; echo "a quarter of the Q4_0 dot-product instructions (wrong results):"; NL_LIB_PATH=/tmp/libnl_fake.so timeout 600 python3 tools/dropin_rates.py big q4_0 32 2>&1 | tail -1 | cut -c1-200) > $O/r05_fake_dot.log; cat $O/r05_fake_dot.log ;;
 dropin)
   # per-call loops of a C host against the chained loop, nano Q8_0 (and with the resident session off)
   for sess in 1 0; do NL_PERSIST_SESSION=$sess timeout 600 python3 tools/dropin_rates.py nano q8_0 2>&1 | tail -3; done > $O/r05_dropin_rates.log; cat $O/r05_dropin_rates.log ;;
