@@ -785,12 +785,20 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         Q.n_heads_local = e->Hs; Q.xq = e->tp_xq; Q.xo = e->tp_xo; Q.bias_out = L.bo; Q.x = e->x[cur];
         Q.seam = sm;
         const bool mfa = e->mf_attn;
-        if (mfa) { B.qkv_q = L.qkv.q2; B.qkv_s = L.qkv.s2; Q.wo_q = L.wo.q2; Q.wo_s = L.wo.s2; }
+        if (mfa) { B.qkv_q = L.qkv.q2; B.qkv_s = L.qkv.s2; }       // (WO stays on the vector pipe: nl_tp.h)
         if (e->wide_ffn && (e->prefetch & 1) && L.gate.wtype == L.up.wtype && (L.gate.wtype == WT_Q4_0 || L.gate.wtype == WT_Q8_0)) {
             Q.pf.q[0] = e->mf_ffn ? L.gate.q2 : L.gate.q; Q.pf.q[1] = e->mf_ffn ? L.up.q2 : L.up.q;
             Q.pf.s[0] = e->mf_ffn ? L.gate.s2 : L.gate.s; Q.pf.s[1] = e->mf_ffn ? L.up.s2 : L.up.s;
             Q.pf.tile_qbytes = tile_qbytes(L.gate.wtype, L.gate.npairs); Q.pf.tile_sbytes = tile_sbytes(L.gate.wtype, L.gate.npairs);
             Q.pf.ntiles = L.gate.ntiles; Q.pf.nmat = 2; Q.pf.blocks = L.down.ntiles; Q.pf_early = (e->prefetch & 8) ? 1 : 0;
+        }
+        if ((e->prefetch & 16) && Q.pf.nmat > 0 && l + 1 < c.n_layers) {
+            const nl_engine::Layer &N = e->layers[l + 1];
+            if (N.qkv.wtype == WT_Q4_0 || N.qkv.wtype == WT_Q8_0) {
+                Q.pf2.q[0] = Q.pf2.q[1] = e->mf_attn ? N.qkv.q2 : N.qkv.q; Q.pf2.s[0] = Q.pf2.s[1] = e->mf_attn ? N.qkv.s2 : N.qkv.s;
+                Q.pf2.tile_qbytes = tile_qbytes(N.qkv.wtype, N.qkv.npairs); Q.pf2.tile_sbytes = tile_sbytes(N.qkv.wtype, N.qkv.npairs);
+                Q.pf2.ntiles = N.qkv.ntiles; Q.pf2.nmat = 1; Q.pf2.blocks = 0;
+            }
         }
         const int wt = L.qkv.wtype, grid = std::max(grp_grid(e->KVs, B.members), (L.wo.ntiles + e->tpg.wo_tpw - 1) / e->tpg.wo_tpw);
         const int ngroups = (L.qkv.npairs + KL - 1) / KL, nf = (ngroups + 16 / e->grp_tpm - 1) / (16 / e->grp_tpm);
@@ -2714,7 +2722,7 @@ int nl_finalize(nl_handle e) {
             //  2 switches that one on as well)
             bool ma = mk && atoi(mk) == 2 && e->Hs % 4 == 0, mf = !(mk && atoi(mk) == 0) && e->wide_ffn;
             for (const auto &L : e->layers) {
-                ma = ma && L.qkv.wtype == WT_Q4_0 && L.wo.wtype == WT_Q4_0 && L.qkv.npairs % KL == 0 && L.wo.npairs % KL == 0;
+                ma = ma && L.qkv.wtype == WT_Q4_0 && L.qkv.npairs % KL == 0 && (L.qkv.npairs / KL) <= 16;
                 mf = mf && L.gate.wtype == WT_Q4_0 && L.up.wtype == WT_Q4_0 && L.down.wtype == WT_Q4_0 && L.gate.npairs % KL == 0 && L.down.npairs % KL == 0;
             }
             auto permute = [&](PackedMat &m) -> int {
@@ -2729,7 +2737,7 @@ int nl_finalize(nl_handle e) {
                 return NL_OK;
             };
             for (auto &L : e->layers) {
-                if (ma) { if (int prc = permute(L.qkv)) return prc; if (int prc = permute(L.wo)) return prc; }
+                if (ma) { if (int prc = permute(L.qkv)) return prc; }
                 if (mf) { if (int prc = permute(L.gate)) return prc; if (int prc = permute(L.up)) return prc; if (int prc = permute(L.down)) return prc; }
             }
             HIPCK(e, hipStreamSynchronize(e->stream));

@@ -374,12 +374,14 @@ struct TpAttnParams {
     float *x;                    // residual stream, read at entry (RMSNorm input, owner rows) and rewritten by the owners
     TpSeam seam;
     PfTiles pf;                  // round 0 of the feed-forward launch behind this one (gate, up tiles b of block b); nmat 0 = off
+    PfTiles pf2;                 // the NEXT layer's projection tiles, for the memory-side Infinity Cache to keep (NL_PREFETCH bit 16; measured
+                                 // and left off: 1.389 against 1.336 ms per token -- the extra lines push round 0 out of the L2s)
     int pf_early;                // 1: touched as soon as the block's own projection tiles are out (else: just before the WO gather)
 };
 
 __host__ __device__ constexpr size_t tp_attn_lds_bytes(int wo_npairs) {
     return 16 * sizeof(double) + sizeof(float) * (size_t)(16 * XS_WAVE + 16 * TR + 3 * 64 + 16 * 68 + TP_NCH_MAX * 66 + wo_npairs * XS_PAIR + 16 * TR) +
-           (size_t)wo_npairs * (256 + 16);        // (the digit image of the heads' outputs: matrix-pipe dot products)
+           0;
 }
 
 // One role of the launch as straight-line code: every load below is unconditional (clamped addresses, masked uses), so
@@ -399,8 +401,6 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     float *chunk = wpart + 16 * 68;                                  // [TP_NCH_MAX][66]: (M, L, o[64]) per pass
     float *ao = chunk + TP_NCH_MAX * 66;                             // [wo_npairs][XS_PAIR]: every local head's output
     float *red2 = ao + Q.wo_npairs * XS_PAIR;                        // [16][16]
-    unsigned char *aimg = reinterpret_cast<unsigned char *>(red2 + NW * TR);   // MF: [2 wo_npairs blocks][4 digits][32]: the digit image of ao ...
-    float2 *abs2 = reinterpret_cast<float2 *>(aimg + Q.wo_npairs * 256);       // ... and {1 / scale, offset} per block
     static_assert(!MF || WT == WT_Q4_0, "matrix-pipe dot products: Q4_0");
 
     const int G = (int)P.gqa, D = P.D;
@@ -491,7 +491,7 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + (long long)cl * P.seq_len * HD);
     // ---- the blocks that only wait for the heads warm the next launch's first round (see PfTiles): wavefronts 1 .. 15
     //      (wavefront 0 polls), one line per thread, split over the non-runner blocks of this block's XCD ----
-    unsigned pf0 = 0, pf1 = 0;
+    unsigned pf0 = 0, pf1 = 0, pf2v = 0;
     auto warm = [&]() {
         if (!RUNNER && Q.pf.nmat > 0 && wave > 0) {
             const int x = (int)(blockIdx.x & 7), b8 = (int)(blockIdx.x >> 3), M = P.members;
@@ -511,6 +511,14 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
                 const unsigned tb = p1 / per_block, rem = p1 - tb * per_block, mat = rem / lpt;
                 const int tile = (int)tb * 8 + x;
                 if (tile < Q.pf.ntiles) pf1 = pf_touch(Q.pf, (int)mat, tile, rem - mat * lpt);
+            }
+            if (Q.pf2.nmat > 0) {
+                const unsigned lpt2 = pf_lines(Q.pf2);
+                const unsigned total2 = (unsigned)((Q.pf2.ntiles - x + 7) >> 3) * lpt2;
+                if (p0 < total2) {
+                    const unsigned tb = p0 / lpt2;
+                    pf2v = pf_touch(Q.pf2, 0, (int)tb * 8 + x, p0 - tb * lpt2);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -558,19 +566,25 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
                 __builtin_amdgcn_wave_barrier();
                 const float a1 = PairDot<WT>::run(cw[f], sw[f], xw + k * XS_PAIR, acc);
                 acc = lv[f] ? a1 : acc;
-            } else {
-                // the wavefront's 256 columns as a digit image (eight blocks, eight adjacent lanes each); two units per lane
-                unsigned char *img = reinterpret_cast<unsigned char *>(xw);
-                float2 *bs = reinterpret_cast<float2 *>(img + 1024);
-                mf_digits4(xa, img + (lane >> 3) * 128, bs + (lane >> 3), lane & 7);
                 __builtin_amdgcn_wave_barrier();
+            } else if (f == slot) {
+                // Matrix pipe: column group g's digit image is built ONCE per workgroup, by wavefront g (which holds the group as its
+                // slot-th one: g = cs + slot * wpt), eight blocks of eight adjacent lanes; every wavefront then multiplies from the
+                // shared images
+                unsigned char *img = reinterpret_cast<unsigned char *>(xw);
+                mf_digits4(xa, img + (lane >> 3) * 128, reinterpret_cast<float2 *>(img + 1024) + (lane >> 3), lane & 7);
+            }
+        }
+        if (MF) {
+            __syncthreads();
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                const unsigned char *img = reinterpret_cast<const unsigned char *>(xs + min(cs + f * wpt, ngroups - 1) * XS_WAVE);
+                const float2 *bs = reinterpret_cast<const float2 *>(img + 1024);
                 const int b0 = lane >> 4;
-                float a1 = acc;
-                a1 += mf_unit_q4(cw[f][0], sw[f].x & 0xffffu, img + b0 * 128, bs[b0], lane & 3);
-                a1 += mf_unit_q4(cw[f][1], sw[f].x >> 16, img + (b0 + 4) * 128, bs[b0 + 4], lane & 3);
+                const float a1 = acc + mf_unit2_q4(cw[f], sw[f].x, img + b0 * 128, bs + b0, lane & 3);
                 acc = lv[f] ? a1 : acc;
             }
-            __builtin_amdgcn_wave_barrier();
         }
         second_half_loads();
         __builtin_amdgcn_sched_barrier(0);
@@ -739,29 +753,12 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     // (<= 2 granules per thread: 64 local heads -- the whole 7.9B layer on one GPU -- are 1536 granules)
     tp_gather16<2, false, true>(Q.xo, Q.xo, Q.n_heads_local * 4, tag, ao, ao, Q.n_heads_local * HD, P.status, P.host_status, P.spin_limit, 32u);
     __syncthreads();
-    if (MF) {       // ao -> digit image: a thread = four consecutive values, a block = eight adjacent threads
-        if (tid < Q.n_heads_local * (HD / 4)) {
-            const int e = tid * 4;
-            const float4 v = *reinterpret_cast<const float4 *>(ao + (e >> 6) * XS_PAIR + (e & 63));
-            mf_digits4(v, aimg + (tid >> 3) * 128, abs2 + (tid >> 3), tid & 7);
-        }
-        __syncthreads();
-    }
     TP_STAMP(sslot, 8);
-    if (wslot < tpw) {
-        if (!MF) {
-            const float a1 = PairDot<WT>::run(wc, wsc, ao + min(wgg * KL + k, Q.wo_npairs - 1) * XS_PAIR, 0.f);
-            float a = wlv ? a1 : 0.f;
-            a = quad_sum(a);
-            if (k == 0) red2[wave * TR + r] = a;
-        } else {
-            const int b0 = wgg * 8 + (lane >> 4);
-            float a = mf_unit_q4(wc[0], wsc.x & 0xffffu, aimg + b0 * 128, abs2[b0], lane & 3) +
-                      mf_unit_q4(wc[1], wsc.x >> 16, aimg + (b0 + 4) * 128, abs2[b0 + 4], lane & 3);
-            a = wlv ? a : 0.f;
-            a = mf_rows4_sum(a);
-            if (lane < TR) red2[wave * TR + lane] = a;
-        }
+    if (wslot < tpw) {      // (on the vector pipe in every mode: the heads' outputs serve one tile, their digit image would cost what it saves)
+        const float a1 = PairDot<WT>::run(wc, wsc, ao + min(wgg * KL + k, Q.wo_npairs - 1) * XS_PAIR, 0.f);
+        float a = wlv ? a1 : 0.f;
+        a = quad_sum(a);
+        if (k == 0) red2[wave * TR + r] = a;
     }
     __syncthreads();
     TP_STAMP(sslot, 9);
@@ -772,7 +769,7 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
         tp_allreduce_row(Q.seam, e_tag, w_row, v, e_resid, Q.x);
     }
     TP_STAMP(sslot, 10);
-    pf_done(pf0, pf1);
+    pf_done(pf0 ^ pf2v, pf1);
 }
 
 template <int WT, int NF, bool MF = false>
@@ -917,34 +914,16 @@ __device__ __forceinline__ void tp_ffn_body(const TpFfnParams &P, char *smem) {
                 ss = fma((double)xa.z, (double)xa.z, ss); ss = fma((double)xa.w, (double)xa.w, ss);
             }
             xa.x *= gv[f].x; xa.y *= gv[f].y; xa.z *= gv[f].z; xa.w *= gv[f].w;
-            if (!MF) {
-                *reinterpret_cast<float4 *>(xw + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
-                __builtin_amdgcn_wave_barrier();
-                const float a1 = PairDot<WT>::run(cw[f], sw[f], xw + k * XS_PAIR, acc);
-                acc = lv[f] ? a1 : acc;
-            } else {
-                // the wavefront's 256 columns as a digit image (eight blocks, eight adjacent lanes each); two units per lane
-                unsigned char *img = reinterpret_cast<unsigned char *>(xw);
-                float2 *bs = reinterpret_cast<float2 *>(img + 1024);
-                mf_digits4(xa, img + (lane >> 3) * 128, bs + (lane >> 3), lane & 7);
-                __builtin_amdgcn_wave_barrier();
-                const int b0 = lane >> 4;
-                float a1 = acc;
-                a1 += mf_unit_q4(cw[f][0], sw[f].x & 0xffffu, img + b0 * 128, bs[b0], lane & 3);
-                a1 += mf_unit_q4(cw[f][1], sw[f].x >> 16, img + (b0 + 4) * 128, bs[b0 + 4], lane & 3);
-                acc = lv[f] ? a1 : acc;
-            }
+            *reinterpret_cast<float4 *>(xw + (lane >> 4) * XS_PAIR + (lane & 15) * 4) = xa;
+            __builtin_amdgcn_wave_barrier();
+            const float a1 = PairDot<WT>::run(cw[f], sw[f], xw + k * XS_PAIR, acc);
+            acc = lv[f] ? a1 : acc;
             __builtin_amdgcn_wave_barrier();
         }
         second_half_loads();
         __builtin_amdgcn_sched_barrier(0);
-        if (!MF) {
-            acc = quad_sum(acc);
-            if (k == 0) red[wave * TR + r] = acc;
-        } else {
-            acc = mf_rows4_sum(acc);               // lanes 0 .. 15: row = lane
-            if (lane < TR) red[wave * TR + lane] = acc;
-        }
+        acc = quad_sum(acc);
+        if (k == 0) red[wave * TR + r] = acc;
         ss = wave_sum_f64(ss);
         if (wsel == 0 && lane == 0) dred[cs] = ss;
         TP_STAMP(sslot, 2);
