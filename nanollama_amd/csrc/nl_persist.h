@@ -431,7 +431,7 @@ __device__ __forceinline__ float pd_exp(float xf) {
 // compute unit adds the same partials in the same order.  Contains a workgroup barrier.  1 / sqrt(m) = v_rsq_f64 + two Newton
 // steps (relative error < 1e-30 before the float32 rounding) instead of the IEEE divide and square root: sixty dependent
 // float64 instructions shorter.
-__device__ __forceinline__ void pd_rms_squares(float a, float b, bool v0, bool v1, int lane, int wave, double *dred) {
+__device__ __forceinline__ float pd_inv_rms(float a, float b, bool v0, bool v1, int lane, int wave, double *dred, int D, float eps) {
     double ss = 0.0;
     if (v0) ss = fma((double)a, (double)a, ss);
     if (v1) ss = fma((double)b, (double)b, ss);
@@ -441,10 +441,6 @@ __device__ __forceinline__ void pd_rms_squares(float a, float b, bool v0, bool v
     const float sw = pd_rows4_sum(dpp_row_sum_f32((float)ss));
     if (lane == 0) dred[wave] = (double)sw;
     __syncthreads();
-}
-// ... and the second half, anywhere behind that barrier (the callers put it BEHIND the dot products the norm scales, whose
-// instructions do not wait for it): eight partials in wavefront order, 1 / sqrt
-__device__ __forceinline__ float pd_rms_finish(const double *dred, int D, float eps) {
     double t[PD_WAVES];
 #pragma unroll
     for (int w = 0; w < PD_WAVES; w++) t[w] = dred[w];
@@ -716,7 +712,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
             pd_limbs(xa * ga0, v0, e0, xl, xs, lane);
             if (wave * 64 + PD_THREADS < D) pd_limbs(xb * ga1, v1, e1, xl, xs, lane);      // (wave-uniform: the wavefronts that hold second elements)
             {
-                pd_rms_squares(xa, xb, v0, v1, lane, wave, dred);      // (its barrier also publishes the digit image)
+                const float inv = pd_inv_rms(xa, xb, v0, v1, lane, wave, dred, D, P.eps);   // (its barrier also publishes the digit image)
                 if (misc[2]) return;
                 if (s == 0 && idx == 0) PD_ST(sb, 2);
                 // ---- this unit's rows of [Q; K; V] (go/model.go:517-523): 3 D / 32 rows ----
@@ -734,7 +730,6 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                         vreg[kk] = pd_ld16f(vr_, (unsigned)(min(wave * 16 + 4 * vg + kk, lim - 1) * 16 + vcl) * 16u);
                     }
                 }
-                const float inv = pd_rms_finish(dred, D, P.eps);
                 __syncthreads();
                 PD_RELANE();
                 if (tid < 4 * QR) {       // four lanes per row; the row leaves for the head that owns it (before RoPE)
@@ -889,11 +884,10 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 if (v1) xraw[e1] = xp[1];
                 pd_limbs(xp[0] * gf0, v0, e0, xl, xs, lane);
                 if (wave * 64 + PD_THREADS < D) pd_limbs(xp[1] * gf1, v1, e1, xl, xs, lane);
-                pd_rms_squares(xp[0], xp[1], v0, v1, lane, wave, dred);
+                const float inv2 = pd_inv_rms(xp[0], xp[1], v0, v1, lane, wave, dred, D, P.eps);
                 if (misc[2]) return;
                 if (s == 0 && idx == 0) PD_ST(sb + 16, 6);
                 pd_units<PD_UQ + PD_UW, PD_UG, NB>(wlo[s], whi[s], wsl + s * PD_UNITS * PD_THREADS, reinterpret_cast<const uint4 *>(xl), xs, 2 * rgp * NB, part, tid);
-                const float inv2 = pd_rms_finish(dred, D, P.eps);
                 __syncthreads();
                 PD_RELANE();
                 if (s == 0 && idx == 0) PD_ST(sb + 16, 7);
@@ -950,13 +944,12 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
             if (idx == 0) PD_ST(40, 1);
             pd_limbs(xv[0] * go0, v0, e0, xl, xs, lane);
             if (wave * 64 + PD_THREADS < D) pd_limbs(xv[1] * go1, v1, e1, xl, xs, lane);
-            pd_rms_squares(xv[0], xv[1], v0, v1, lane, wave, dred);
+            const float inv = pd_inv_rms(xv[0], xv[1], v0, v1, lane, wave, dred, D, P.eps);
             if (misc[2]) return;
             const int total = pd_pad4(lm_rows) * NB;
             pd_units_impl<PD_ULM, NB>([&](int k, uint4 &l, uint4 &h, unsigned &d) {
                 l = lmw[(k * 2 + 0) * PD_THREADS + tid]; h = lmw[(k * 2 + 1) * PD_THREADS + tid]; d = lms[k * PD_THREADS + tid]; },
                 reinterpret_cast<const uint4 *>(xl), xs, total, part, tid);
-            const float inv = pd_rms_finish(dred, D, P.eps);
             __syncthreads();
             PD_RELANE();
             if (idx == 0) PD_ST(40, 2);

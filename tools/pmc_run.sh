@@ -7,7 +7,7 @@ WL=${1:-big:q4_0}; TAG=${2:-big_q4_0}
 for ctr in FETCH_SIZE WRITE_SIZE; do
   out=gpurun_out/pmc_${TAG}_${ctr}
   rm -rf $out; mkdir -p $out
-  NL_NO_GRAPH=1 timeout 420 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out -o p -- python3 bench.py --workload $WL --steps 6 --warmup 2 --no-cpu-baseline > $out/log.txt 2>&1 < /dev/null
+  NL_NO_GRAPH=1 timeout 420 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out -o p -- python3 bench.py --workload $WL --steps 6 --warmup 2 --no-cpu-baseline --no-secondary > $out/log.txt 2>&1 < /dev/null
   f=$(ls $out/*counter_collection.csv $out/*/*counter_collection.csv 2>/dev/null | head -1)
   if [ -n "$f" ]; then
     python3 - "$f" "$ctr" > gpurun_out/pmc_${TAG}_${ctr}_summary.csv <<'PY'

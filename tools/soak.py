@@ -80,3 +80,42 @@ while time.time() - t0 < budget:
 print(f"big greedy (positions 440..600) + sampled: {runs} runs, {toks} tokens in {time.time() - t0:.1f} s, identical ids every run; "
       f"plan {dev.plan_info()}; last_error: {dev.last_error()!r}", flush=True)
 dev.close()
+
+# 5. (round 5) nano per-call Forward on the resident session of the persistent decode (nl_persist.h): runs of nl_forward /
+#    nl_forward_argmax calls with a host argmax in between, cut by resets, chained chunks, pauses longer than the idle limit and
+#    repeated positions -- the same ids every run, equal to the chained decode's, no give-up
+g = b.gen("nano", "q8_0")
+dev = model.load_llama_model(g)
+prompt = synth.prompt_ids(16, g.meta.vocab_size)
+dev.prefill(prompt)
+first = int(np.argmax(dev.state.logits))
+want = dev.decode_greedy(first, len(prompt), 300)
+runs, toks = 0, 0
+t0 = time.time()
+while time.time() - t0 < budget:
+    dev.reset(); dev.prefill(prompt)
+    tok, pos, got = first, len(prompt), []
+    for i in range(300):
+        kind = (i + runs) % 7
+        if kind == 3:
+            tok = dev.forward_argmax(tok, pos)
+        elif kind == 5 and i + 4 <= 300 and i % 50 == 5:
+            ids = dev.decode_greedy(tok, pos, 4)          # a chained chunk in the middle of the session
+            got += ids[:-1]; tok = ids[-1]; pos += 3
+        else:
+            dev.forward(tok, pos)
+            if i % 97 == 11:
+                dev.forward(tok, pos)                      # the same position again: a new session, the same logits
+            tok = int(np.argmax(dev.state.logits))
+        got.append(tok); pos += 1
+        if i % 61 == 60:
+            time.sleep(0.004)                              # longer than the idle limit: the launch has left
+        if len(got) >= 300:
+            break
+    assert got[:300] == want[:300], f"session run {runs} differs at {[k for k, (a, c) in enumerate(zip(got, want)) if a != c][:3]}"
+    runs += 1; toks += len(got)
+info = dev.persist_info()
+print(f"nano resident session: {runs} runs, {toks} tokens in {time.time() - t0:.1f} s, ids equal to the chained decode's every run; "
+      f"persist {info}; last_error: {dev.last_error()!r}", flush=True)
+assert info["ready"] and dev.last_error() == ""
+dev.close()
