@@ -253,7 +253,7 @@ __device__ __forceinline__ void pd_gather(const pd_u64 *g, int n, unsigned tag, 
             pd_give_up(Q, code, tid);
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        // (no s_sleep between polls: they are this XCD's own L2 round trips, nobody streams beside them -- 7920 -> 8040 tok/s)
     }
 #pragma unroll
     for (int k = 0; k < NPT; k++) v[k] = __uint_as_float((unsigned)q[k]);
@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                             pd_give_up(Q, 128u, tid);
                             break;
                         }
-                        __builtin_amdgcn_s_sleep(1);
+                        // (no s_sleep: see pd_gather)
                     }
                     best = __uint_as_float(g.y); bidx = (int)g.z;
                     pd_wave_argmax(best, bidx);          // (lane = compute unit = ascending vocabulary rows)
@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                                 pd_give_up(Q, 32u, tid);
                                 break;
                             }
-                            __builtin_amdgcn_s_sleep(1);
+                            // (no s_sleep: see pd_gather)
                         }
                         const float v = __uint_as_float((unsigned)g);
                         float o = v;
