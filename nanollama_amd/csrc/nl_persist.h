@@ -878,7 +878,9 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 float xp[2];
                 pd_gather<2>(P.gxp + (size_t)layer * D, D, tag, xp, Q, 4u, tid);
                 if (s == 0 && idx == 0) PD_ST(sb + 16, 5);
-                __syncthreads();                               // (xraw / xT / part of the WO step are free)
+                // (no barrier: a wavefront is here only when ALL of x' has arrived -- this unit's rows too, published by lanes that read
+                //  xraw and, through their quad, the row's block products first; the digit image of o was released by the barrier
+                //  behind the WO units)
                 PD_RELANE();
                 if (v0) xraw[e0] = xp[0];
                 if (v1) xraw[e1] = xp[1];
@@ -931,7 +933,8 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 }
             }
             if (s == 0 && idx == 0) PD_ST(sb + 16, 11);
-            __syncthreads();     // LDS of this slot is free for the next one
+            // (no barrier between slots: whatever comes next starts with a gather of values that depend on this unit's published
+            //  rows, i.e. on every LDS read of this slot)
             PD_RELANE();
         }
 
