@@ -2682,7 +2682,9 @@ int nl_finalize(nl_handle e) {
         //  stay ahead of the five-launch plan through three passes -- 1.69 against 1.85 ms at position 470, 1.81 against 1.86 at
         //  600 -- and fall behind in the fourth, 1.98 against 1.87 at 900)
         //  (mode 3 runs the same attention half: 512 = two of its passes, where 384 was three of the old 128-position ones)
-        e->fused_max_pos = fm ? atoi(fm) : e->fused_mode == 4 ? 768 : (e->fused_mode == 1 || e->fused_mode == 3) ? 512 : 384;
+        //  (round 5, the same tool with the feed-forward launch on the matrix pipe and its first round warm: 1.76 against 1.85 ms at
+        //  position 800, 1.80 against 1.86 at 980 -- the two-launch layers now stay ahead through all four passes)
+        e->fused_max_pos = fm ? atoi(fm) : e->fused_mode == 4 ? (e->wide_ffn ? 1024 : 768) : (e->fused_mode == 1 || e->fused_mode == 3) ? 512 : 384;
         if (e->fused_mode == 3 || e->fused_mode == 4) e->fused_max_pos = std::min(e->fused_max_pos, TP_NCH_MAX * TP_PASS);   // passes a head takes inside the launch
         {
             const char *ff = getenv("NL_FUSED_FFN");   // knob (tests, tools): 0 keeps gate/up and down as two launches

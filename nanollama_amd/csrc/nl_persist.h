@@ -589,6 +589,14 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
 #define PD_RELANE() do { asm volatile("" : "+v"(tid)); wave = __builtin_amdgcn_readfirstlane(tid >> 6); lane = tid & 63; e0 = tid; e1 = tid + PD_THREADS; \
                          v0 = e0 < D; v1 = e1 < D; c0 = v0 ? e0 : 0; c1 = v1 ? e1 : 0; } while (0)
         const int pos = P.pos0 + step;
+        // The host rows of the previous step (resident session): acknowledged -- they bypass the caches, so waiting for the stores is
+        // enough; a system-scope release fence would also write the XCD's L2 back, 17 us per step measured -- and counted on a
+        // word of this launch's census block.  NOT in front of the unit's argmax granule: the acknowledgement crosses PCIe while
+        // the granules travel and the token is picked; the doorman looks at the count before it tells the host.
+#define PD_ACK_HOST_ROWS() do { if (P.session && P.host_logits && step > 0) { \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+            __syncthreads(); \
+            if (tid == 0) __hip_atomic_fetch_add(P.census + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } } while (0)
         // developer stamps (tools/persist_stamps.py): step 2 on XCD 1 -- unit 0 (a head of slot 0), unit H (a worker of slot 0)
 #ifdef NL_PD_STAMPS
 #define PD_ST(base, i) do { if (step == 2 && xcd == 1u && tid == 0 && P.dbg) P.dbg[(base) + (i)] = wall_clock64(); } while (0)
@@ -626,11 +634,17 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 for (int w = 1; w < PD_GRID / 64; w++)
                     if (bv[w] > best || (bv[w] == best && bi[w] < bidx)) { best = bv[w]; bidx = bi[w]; }
                 token = bidx == 0x7fffffff ? 0 : bidx;      // all-NaN logits: the reference's loop never leaves index 0
+                PD_ACK_HOST_ROWS();
                 if (idx == 0 && tid == 0) {
                     P.ids_out[step - 1] = token;
-                    // (every unit's host rows were acknowledged before its granule left -- see the LM head -- so a plain system-scope
-                    //  store suffices: a release here would write this XCD's whole L2 back first)
-                    if (P.session) __hip_atomic_store(P.host_done, ((pd_u64)(unsigned)step << 32) | (unsigned)token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (P.session) {
+                        if (P.host_logits) {      // every unit's rows of this step have been acknowledged
+                            for (int spins = 0; __hip_atomic_load(P.census + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)PD_GRID * (unsigned)step; spins++)
+                                if (spins >= P.spin_limit) { pd_give_up(Q, 2048u, tid); break; }
+                        }
+                        // (a plain system-scope store: a release here would write this XCD's whole L2 back first)
+                        __hip_atomic_store(P.host_done, ((pd_u64)(unsigned)step << 32) | (unsigned)token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                 }
                 __syncthreads();                              // bv / bi are reused by the LM head
                 PD_RELANE();
@@ -680,7 +694,10 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
             // ---- embedding row (go/model.go:389-446) ----
             xa = embed_value(P.embd_raw, WT_Q8_0, D, token, c0);
             xb = embed_value(P.embd_raw, WT_Q8_0, D, token, c1);
-        } else if (step == P.n_steps) break;
+        } else {
+            PD_ACK_HOST_ROWS();
+            if (step == P.n_steps) break;
+        }
 
         // =================================== this XCD's layers ===================================
 #pragma unroll
@@ -971,9 +988,6 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 }
                 pd_wave_argmax(best, bidx);              // (lane pairs = ascending rows)
                 if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
-                // the host rows are acknowledged before this unit's granule says so (they bypass the caches: waiting for the stores is
-                // enough -- a system-scope release fence would also write the XCD's L2 back, 17 us per step measured)
-                if (P.session && P.host_logits) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
             PD_RELANE();
@@ -995,6 +1009,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
 #undef PD_STAMP
 #undef PD_ST
 #undef PD_RELANE
+#undef PD_ACK_HOST_ROWS
 }
 
 }  // namespace nl

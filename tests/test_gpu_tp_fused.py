@@ -130,19 +130,19 @@ def test_group_exchange_timeout_falls_back_to_the_general_plan(hip, orc, tmp_pat
 def test_big_attention_geometry_across_the_in_launch_passes(hip, orc, tmp_path):
     # The 7.9B tier's TRUE attention geometry (D 4096 / 64 heads / 16 kv heads: two projection tiles per workgroup, a wavefront
     # holding two column groups) with a context long enough for every in-launch attention pass: fused mode 4 (one GPU) serves
-    # positions < 768 with 256-position passes, fused mode 3 (tensor-parallel shards, tp 2 / 4 / 8) positions < 512.  Round 4
-    # only checked passes 2 and 3 at D 1024 / 16 heads.  Teacher-forced against the oracle at the pass edges
-    # (go/model.go:557-587), then a chained greedy run across the switch to the split-attention plan at 768.
-    shape = synth.ModelShape("big_geo", 2, 4096, 64, 16, 1024, seq_len=864, interm=2048)
+    # positions < 1024 with 256-position passes (all four), fused mode 3 (tensor-parallel shards, tp 2 / 4 / 8) positions < 512.
+    # Round 4 only checked passes 2 and 3 at D 1024 / 16 heads.  Teacher-forced against the oracle at the pass edges
+    # (go/model.go:557-587), then a chained greedy run across the switch to the split-attention plan at 1024.
+    shape = synth.ModelShape("big_geo", 2, 4096, 64, 16, 1024, seq_len=1088, interm=2048)
     p = tmp_path / "m.gguf"
     synth.generate_gguf(str(p), shape, "q4_0", 97, mode="qrand")
     g = gguf.load_gguf(str(p))
-    check = (255, 256, 300, 511, 512, 700, 767, 768)
-    prompt = synth.prompt_ids(718, shape.vocab, seed=41)
+    check = (255, 256, 300, 511, 512, 700, 767, 768, 900, 1023, 1024)
+    prompt = synth.prompt_ids(974, shape.vocab, seed=41)
     ref = orc.OracleModel(g)
     orc.set_threads(min(32, os.cpu_count() or 1))
     seq, wants = list(prompt), {}
-    for pos in range(800):                      # the prompt teacher-forced, then the oracle's own greedy ids
+    for pos in range(1056):                     # the prompt teacher-forced, then the oracle's own greedy ids
         lg = ref.forward(seq[pos], pos)
         if pos in check:
             wants[pos] = lg.copy()
@@ -150,7 +150,7 @@ def test_big_attention_geometry_across_the_in_launch_passes(hip, orc, tmp_path):
             seq.append(int(orc.argmax(lg)))
     orc.set_threads(1)
     ref.close()
-    greedy = seq[len(prompt):]                  # ids at positions 718 .. 800
+    greedy = seq[len(prompt):]                  # ids at positions 974 .. 1056
 
     def held(lg, pos, what):
         d = float(np.abs(lg - wants[pos]).max()) / max(1.0, float(wants[pos].std()))
@@ -160,14 +160,14 @@ def test_big_attention_geometry_across_the_in_launch_passes(hip, orc, tmp_path):
     # one GPU: mode 4 (projection + attention + WO in one launch), passes 1 .. 3 and the first position of the general plan
     dev = hip.load_llama_model(g)
     info = dev.plan_info()
-    assert info["fused_mode"] == 4 and info["fused_max_pos"] == 768, info
+    assert info["fused_mode"] == 4 and info["fused_max_pos"] == 1024, info
     worst = 0.0
-    for pos in range(769):
+    for pos in range(1025):
         dev.forward(seq[pos], pos)
         if pos in check:
             worst = max(worst, held(dev.state.logits, pos, "mode 4"))
     assert dev.last_error() == ""
-    # chained greedy decode from the prompt: 16-step graphs of the fused plan, the seam at 768, then the general plan
+    # chained greedy decode from the prompt: 16-step graphs of the fused plan, the seam at 1024, then the general plan
     dev.reset()
     dev.prefill(prompt)
     first = int(np.argmax(dev.state.logits))
@@ -175,7 +175,7 @@ def test_big_attention_geometry_across_the_in_launch_passes(hip, orc, tmp_path):
     assert got == greedy
     assert dev.last_error() == ""
     dev.close()
-    print(f"\nbig geometry, mode 4: max|gpu-oracle| = {worst:.2e} over positions {check}; {len(greedy)} greedy ids across 768 equal")
+    print(f"\nbig geometry, mode 4: max|gpu-oracle| = {worst:.2e} over positions {check}; {len(greedy)} greedy ids across 1024 equal")
 
     # tensor-parallel shards: mode 3 below 512, the four-launch rank plan from there on
     for n in (2, 4, 8):

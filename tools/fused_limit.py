@@ -15,7 +15,7 @@ for limit in ("0", "4096"):
     toks = synth.prompt_ids(1200, g.meta.vocab_size)
     dev.prefill(toks)
     out = []
-    for pos0 in (64, 200, 300, 352, 400, 440, 470, 600, 900, 1150):     # (the in-launch attention of modes 3 / 4 ends at position 512)
+    for pos0 in (64, 300, 470, 600, 700, 800, 900, 980, 1150):     # (the in-launch attention of modes 3 / 4 ends at position 512)
         dev.decode_greedy(5, pos0, 32)
         t0 = time.perf_counter()
         dev.decode_greedy(5, pos0, 32)
