@@ -305,6 +305,7 @@ struct nl_engine {
         uint4 *wimg = nullptr, *lmimg = nullptr;
         unsigned short *simg = nullptr, *lmsimg = nullptr;
         pd_u64 *gx = nullptr, *gqkv = nullptr, *go = nullptr, *gxp = nullptr, *gh = nullptr;
+        pd_u64 *gpart = nullptr;
         pd_u32x4 *gam = nullptr;
         unsigned *census = nullptr, *status = nullptr, *h_status = nullptr;
         float *norms = nullptr;      // [L][2][D] + [D]: attn_norm | ffn_norm of every layer, output_norm (one pointer for the kernel)
@@ -1267,7 +1268,7 @@ void pd_free_raw(nl_engine *e) {
 void pd_free(nl_engine *e) {
     pd_free_raw(e);
     nl_engine::Persist &d = e->pd;
-    void *bufs[] = {d.wimg, d.lmimg, d.simg, d.lmsimg, d.gx, d.gqkv, d.go, d.gxp, d.gh, d.gam, d.census, d.status, d.dbg, d.norms, d.gtok};
+    void *bufs[] = {d.wimg, d.lmimg, d.simg, d.lmsimg, d.gx, d.gqkv, d.go, d.gxp, d.gh, d.gam, d.census, d.status, d.dbg, d.norms, d.gtok, d.gpart};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (d.h_status) (void)hipHostFree(d.h_status);
     if (d.h_mail) (void)hipHostFree(d.h_mail);
@@ -1310,6 +1311,8 @@ int pd_build(nl_engine *e) {
     HIPCK(e, dalloc(&d.gxp, L1 * c.dim, &e->bytes_state));
     HIPCK(e, dalloc(&d.gh, L1 * c.interm, &e->bytes_state));
     HIPCK(e, dalloc(&d.gam, (size_t)PD_GRID, &e->bytes_state));
+    HIPCK(e, dalloc(&d.gpart, (size_t)c.n_layers * c.n_heads * (PD_PARTS - 1) * 66, &e->bytes_state));
+    HIPCK(e, hipMemset(d.gpart, 0, (size_t)c.n_layers * c.n_heads * (PD_PARTS - 1) * 66 * 8));
     HIPCK(e, hipMemset(d.gx, 0, L1 * c.dim * 8)); HIPCK(e, hipMemset(d.go, 0, L1 * c.dim * 8)); HIPCK(e, hipMemset(d.gxp, 0, L1 * c.dim * 8));
     HIPCK(e, hipMemset(d.gh, 0, L1 * c.interm * 8)); HIPCK(e, hipMemset(d.gam, 0, (size_t)PD_GRID * 16));
     HIPCK(e, dalloc(&d.norms, ((size_t)c.n_layers * 2 + 1) * c.dim, &e->bytes_state));
@@ -1362,6 +1365,7 @@ int pd_launch(nl_engine *e, int stream, int token, int pos, int n, float *host_l
         HIPCK(e, hipMemsetAsync(d.gqkv, 0, L1 * 3 * c.dim * 8, e->stream));
         HIPCK(e, hipMemsetAsync(d.gxp, 0, L1 * c.dim * 8, e->stream)); HIPCK(e, hipMemsetAsync(d.gh, 0, L1 * c.interm * 8, e->stream));
         HIPCK(e, hipMemsetAsync(d.gam, 0, (size_t)PD_GRID * 16, e->stream));
+        HIPCK(e, hipMemsetAsync(d.gpart, 0, (size_t)c.n_layers * c.n_heads * (PD_PARTS - 1) * 66 * 8, e->stream));
         d.tag_base = 0;
     }
     PdParams P{};
@@ -1379,7 +1383,7 @@ int pd_launch(nl_engine *e, int stream, int token, int pos, int n, float *host_l
     P.rope_cos = e->rope_cos; P.rope_sin = e->rope_sin;
     P.kcache = e->kcache + (long long)stream * e->kv_stream_stride; P.vcache = e->vcache + (long long)stream * e->kv_stream_stride;
     P.kv_layer_stride = e->kv_layer_stride;
-    P.gx = d.gx; P.gqkv = d.gqkv; P.go = d.go; P.gxp = d.gxp; P.gh = d.gh; P.gam = d.gam;
+    P.gx = d.gx; P.gqkv = d.gqkv; P.go = d.go; P.gxp = d.gxp; P.gh = d.gh; P.gam = d.gam; P.gpart = d.gpart;
     P.ids_out = e->ids; P.logits = e->logits; P.host_logits = host_logits;
     P.status = d.status; P.host_status = d.h_status; P.dbg = d.dbg;
     if (c.dim == 576) hipLaunchKernelGGL((pd_decode_kernel<18, 48>), dim3(PD_GRID), dim3(PD_THREADS), pd_lds_bytes(), e->stream, P);

@@ -57,8 +57,9 @@ constexpr int PD_SLOTS = 2;   // layers per XCD
 constexpr int PD_MAXL = PD_SLOTS * PD_XCDS;
 constexpr int PD_MAXD = 576, PD_MAXI = 1536, PD_NBD_MAX = PD_MAXD / 32, PD_NBI_MAX = PD_MAXI / 32;
 constexpr int PD_PART = 128 * (PD_NBD_MAX + 1) + 128;  // floats: block products of the largest phase (the LM head's 128 rows), rows padded to an odd pitch
-constexpr int PD_MAX_PASSES = 4;                       // attention passes of 128 positions: contexts below 512
-constexpr int PD_MAX_POS = PD_MAX_PASSES * 128;
+constexpr int PD_PARTS = 3;                            // units that share a head's attention passes (its owner + two of the XCD's units that are not heads)
+constexpr int PD_MAX_POS = 1024;                       // eight attention passes of 128 positions: at most three per unit
+constexpr int PD_MAX_PASSES = 8;                       // chunk records in LDS: a unit's own passes + the partials it merges (<= 3 + 2)
 
 // ---- who holds what (host packer and kernel share these) -----------------------------------------------------------------
 __host__ __device__ inline int pd_nslots(int L, int xcd) { return L / PD_XCDS + (xcd < L % PD_XCDS ? 1 : 0); }
@@ -110,6 +111,7 @@ struct PdParams {
     pd_u64 *gqkv;                    // [L][3 D]: q | k | v rows of the position before RoPE (row-split over the XCD's units, read by the heads)
     pd_u64 *go, *gxp;                // [L][D]: heads' attention outputs; x' = x + WO o
     pd_u64 *gh;                      // [L][I]: SiLU(gate) * up
+    pd_u64 *gpart;                   // [L][H][PD_PARTS - 1][66]: a helper's merged (max, sum, sum p v[64]) of its passes, for the head's owner
     pd_u32x4 *gam;                   // [256] {tag, max bits, index, -}
     unsigned *census, *census_next;  // [8] tickets per XCD, [8] arrivals of THIS launch; the next launch's words (zeroed here: no memset between launches)
     int *ids_out;                    // [n_steps]
@@ -709,9 +711,20 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
             const int sb = s == 0 ? 8 : 63;                  // stamp base (slot 0 of XCD 1, unit 0: a head)
             (void)sb;
             if (s == 0 && idx == 0) PD_ST(sb, 0);
-            const int hidx = pd_head_index(s, idx, H);
-            float *const kc = P.kcache + (long long)layer * P.kv_layer_stride + (long long)(head ? hidx : 0) * P.seq_len * 64;
-            float *const vc = P.vcache + (long long)layer * P.kv_layer_stride + (long long)(head ? hidx : 0) * P.seq_len * 64;
+            // Attention roles of the slot: a head's OWNER (part 0: it also ropes and stores k | v) and, from the second pass on, up
+            // to PD_PARTS - 1 HELPERS among the XCD's units that are not heads in this slot: part p takes the passes
+            // nch - 1 - p, nch - 1 - p - PD_PARTS, ... (the last pass -- the one that holds this position -- is the owner's)
+            const int nch = pos / 128 + 1, nparts = min(PD_PARTS, nch);
+            int hidx = pd_head_index(s, idx, H), apart = 0;
+            if (!head) {
+                const int j = s == 0 ? idx - H : idx;             // the slot's non-heads, in order
+                apart = 1 + j / H;
+                hidx = j - (apart - 1) * H;
+            }
+            const bool arole = head || apart < nparts;          // (a helper beyond the passes there are has nothing to do)
+            const int chf = nch - 1 - apart;                    // this unit's first (= highest) pass
+            float *const kc = P.kcache + (long long)layer * P.kv_layer_stride + (long long)(arole ? hidx : 0) * P.seq_len * 64;
+            float *const vc = P.vcache + (long long)layer * P.kv_layer_stride + (long long)(arole ? hidx : 0) * P.seq_len * 64;
             const __amdgpu_buffer_rsrc_t kr_ = pd_rsrc(kc, (unsigned)P.seq_len * 256u), vr_ = pd_rsrc(vc, (unsigned)P.seq_len * 256u);
             const int kr = lane >> 2, kq = lane & 3, vg = lane >> 4, vcl = lane & 15;
             float4 kreg[4], vreg[4];
@@ -734,17 +747,17 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 if (s == 0 && idx == 0) PD_ST(sb, 2);
                 // ---- this unit's rows of [Q; K; V] (go/model.go:517-523): 3 D / 32 rows ----
                 float ec = 0.f, es = 0.f;      // (heads: requested before the products, the rotation below must not wait for them)
-                if (head && tid < 128) { ec = P.rope_cos[pos * 32 + (tid & 31)]; es = P.rope_sin[pos * 32 + (tid & 31)]; }
+                if (arole && tid < 128) { ec = P.rope_cos[pos * 32 + (tid & 31)]; es = P.rope_sin[pos * 32 + (tid & 31)]; }
                 pd_units<0, PD_UQ, NB>(wlo[s], whi[s], wsl + s * PD_UNITS * PD_THREADS, reinterpret_cast<const uint4 *>(xl), xs, QRP * NB, part, tid);
                 if (s == 0 && idx == 0) PD_ST(sb, 3);
-                if (head) {   // the first 128 cache rows of the head are requested behind the dot products (rows >= pos repeat row pos,
-                              // the row of this position comes from LDS): they arrive during the row sums and the exchange
-                    const int lim = min(min(128, P.seq_len), pos + 1);
-                    const unsigned krow = (unsigned)min(wave * 16 + kr, lim - 1) * 16u + (unsigned)kq * 4u;
+                if (arole) {  // the cache rows of the unit's first pass are requested behind the dot products (rows beyond the pass repeat
+                              // its last row; the row of this position comes from LDS): they arrive during the row sums and the exchange
+                    const int t0 = chf * 128, lim = min(128, pos + 1 - t0);
+                    const unsigned krow = (unsigned)(t0 + min(wave * 16 + kr, lim - 1)) * 16u + (unsigned)kq * 4u;
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) {
                         kreg[kk] = pd_ld16f(kr_, (krow + kk) * 16u);
-                        vreg[kk] = pd_ld16f(vr_, (unsigned)(min(wave * 16 + 4 * vg + kk, lim - 1) * 16 + vcl) * 16u);
+                        vreg[kk] = pd_ld16f(vr_, (unsigned)((t0 + min(wave * 16 + 4 * vg + kk, lim - 1)) * 16 + vcl) * 16u);
                     }
                 }
                 __syncthreads();
@@ -753,10 +766,10 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                     const float v = pd_rowsum<NB, 4>(part + (tid >> 2) * NBP, tid & 3) * inv;
                     if (!(tid & 3)) pd_publish<false>(P.gqkv + (size_t)layer * 3 * D + idx * QR + (tid >> 2), tag, v);
                 }
-                if (head) {
-                    // ---- the head's q | k | v of this position: 192 granules; RoPE (go/model.go:449-477: pairs (i, i + 32) = lanes
-                    //      l, l ^ 32 of a wavefront), KV store (go/model.go:552-554) ----
-                    if (tid < 192) {
+                if (arole) {
+                    // ---- the head's q | k | v of this position: 192 granules (a helper: q only); RoPE (go/model.go:449-477: pairs
+                    //      (i, i + 32) = lanes l, l ^ 32 of a wavefront), KV store by the owner (go/model.go:552-554) ----
+                    if (tid < (head ? 192 : 64)) {
                         const int sect = tid >> 6, e = tid & 63;
                         const __amdgpu_buffer_rsrc_t r = pd_rsrc(P.gqkv + (size_t)layer * 3 * D, 3u * D * 8u);
                         const unsigned off = (unsigned)(sect * D + hidx * 64 + e) * 8u;
@@ -789,10 +802,10 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                 // ---- softmax attention over positions 0 .. pos (go/model.go:557-587), 128 positions per pass: nl_block.h's
                     //      one-barrier pass (every wavefront reduces its 16 positions to one (max, sum, sum p v) partial) ----
                     if (s == 0 && idx == 0) PD_ST(sb, 4);
-                    const int nch = pos / 128 + 1;
-                    for (int ch = 0; ch < nch; ch++) {
+                    int nci = 0;            // chunk records of this unit
+                    for (int ch = chf; ch >= 0; ch -= PD_PARTS, nci++) {
                         const int t0 = ch * 128, n = min(128, pos + 1 - t0);
-                        if (ch > 0) {       // (a later pass fetches its rows at its start: a prefetch a pass ahead costs 16 registers this kernel lacks)
+                        if (ch != chf) {    // (a later pass fetches its rows at its start: a prefetch a pass ahead costs 16 registers this kernel lacks)
 #pragma unroll
                             for (int kk = 0; kk < 4; kk++) {
                                 kreg[kk] = pd_ld16f(kr_, (unsigned)((t0 + min(wave * 16 + kr, n - 1)) * 16 + kq * 4 + kk) * 16u);
@@ -839,29 +852,51 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                             float ov = 0.f;
 #pragma unroll
                             for (int w = 0; w < 8; w++) ov = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt), w)), wpart[w * 68 + 4 + lane], ov);
-                            chunk[ch * 66 + 2 + lane] = ov;
-                            if (lane == 0) { chunk[ch * 66] = M; chunk[ch * 66 + 1] = Ls; }
+                            chunk[nci * 66 + 2 + lane] = ov;
+                            if (lane == 0) { chunk[nci * 66] = M; chunk[nci * 66 + 1] = Ls; }
                         }
-                        if (ch + 1 < nch) __syncthreads();
+                        if (ch - PD_PARTS >= 0) __syncthreads();
+                    }
+                    // ---- the owner collects the helpers' partials (each the merge of that helper's passes) behind its own records ----
+                    if (head && nparts > 1) {
+                        const int np1 = nparts - 1;
+                        if (tid < np1 * 66) {
+                            const __amdgpu_buffer_rsrc_t r = pd_rsrc(P.gpart + ((size_t)layer * H + hidx) * (PD_PARTS - 1) * 66, (unsigned)((PD_PARTS - 1) * 66) * 8u);
+                            pd_u64 g;
+                            for (int spins = 0;; spins++) {
+                                g = pd_ld8(r, (unsigned)tid * 8u);
+                                if (__all((unsigned)(g >> 32) == tag || tid >= np1 * 66)) break;
+                                if (spins >= Q.spin_limit || ((spins & 63) == 63 && __hip_atomic_load(Q.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                                    pd_give_up(Q, 4096u, tid);
+                                    break;
+                                }
+                            }
+                            chunk[nci * 66 + tid] = __uint_as_float((unsigned)g);       // (records nci .. nci + np1 - 1: the helpers' layout is the records')
+                        }
+                        nci += np1;
                     }
                     __syncthreads();
                     PD_RELANE();
+                    if (misc[2]) return;
                     if (s == 0 && idx == 0) PD_ST(sb, 5);
                     if (tid < 64) {
-                        float ov;
-                        if (nch == 1) ov = chunk[2 + tid] * (1.0f / chunk[1]);
-                        else {
-                            float M = chunk[0];
-                            for (int c = 1; c < nch; c++) M = fmaxf(M, chunk[c * 66]);
-                            float v = 0.f, Ls = 0.f;
-                            for (int c = 0; c < nch; c++) {
+                        // the records merged like position splits (fixed order: own passes from the highest down, then the helpers by part)
+                        float M = chunk[0];
+                        for (int c = 1; c < nci; c++) M = fmaxf(M, chunk[c * 66]);
+                        float v = 0.f, Ls = 0.f;
+                        if (nci == 1) { v = chunk[2 + tid]; Ls = chunk[1]; }
+                        else
+                            for (int c = 0; c < nci; c++) {
                                 const float w = pd_exp(chunk[c * 66] - M);
                                 Ls += w * chunk[c * 66 + 1];
                                 v += w * chunk[c * 66 + 2 + tid];
                             }
-                            ov = v * (1.0f / Ls);
+                        if (head) pd_publish<false>(P.go + (size_t)layer * D + hidx * 64 + tid, tag, v * (1.0f / Ls));      // -> every unit of this XCD
+                        else {      // a helper: its record for the owner
+                            pd_u64 *dst = P.gpart + (((size_t)layer * H + hidx) * (PD_PARTS - 1) + (apart - 1)) * 66;
+                            pd_publish<false>(dst + 2 + tid, tag, v);
+                            if (tid == 0) { pd_publish<false>(dst, tag, M); pd_publish<false>(dst + 1, tag, Ls); }
                         }
-                        pd_publish<false>(P.go + (size_t)layer * D + hidx * 64 + tid, tag, ov);      // -> every unit of this XCD
                     }
                     if (s == 0 && idx == 0) PD_ST(sb, 6);
                 }

@@ -287,6 +287,55 @@ def test_resident_session_position_limit_and_give_up(hip, orc, tmp_path, monkeyp
     dev.close()
 
 
+def test_persistent_decode_long_context_shares_the_attention_passes(hip, orc, tmp_path):
+    # from position 128 on a head's 128-position passes are shared by up to three units of its XCD (the owner + two helpers that
+    # are not heads in that layer slot; go/model.go:557-587); the owner merges their records.  Teacher-forced against the oracle
+    # across every pass count 1 .. 8, at the pass edges; then a chained run up to the position limit (1024) and over it.
+    shape = synth.ModelShape("pd_long", 13, 256, 4, 4, 1024, seq_len=1100, interm=512)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 167)
+    g = gguf.load_gguf(str(p))
+    tokens = synth.prompt_ids(1040, shape.vocab, seed=29)
+    check = {0, 5, 127, 128, 129, 200, 255, 256, 257, 383, 384, 400, 511, 512, 513, 640, 767, 768, 800, 895, 896, 1000, 1022, 1023, 1024, 1030}
+    ref = orc.OracleModel(g)
+    orc.set_threads(min(16, os.cpu_count() or 1))
+    want = {}
+    for pos, t in enumerate(tokens):
+        lg = ref.forward(t, pos)
+        if pos in check:
+            want[pos] = lg.copy()
+    dev = hip.load_llama_model(g)
+    assert dev.persist_info()["max_pos"] == 1024
+    worst = 0.0
+    for pos, t in enumerate(tokens):
+        dev.forward(t, pos)
+        if pos in check:
+            worst = max(worst, _rel(dev.state.logits, want[pos]))
+    info = dev.persist_info()
+    print(f"\npersistent decode, positions 0 .. 1039 teacher-forced: max|gpu-oracle| = {worst:.2e} at {len(check)} positions; {info}")
+    assert worst <= LOGIT_TOL and dev.last_error() == ""
+    assert info["tokens"] == 1024 and info["launches"] <= 3, info      # (one resident launch unless the host paused longer than the idle limit)
+    # chained: from position 900 over the limit, the oracle's greedy ids
+    first = int(orc.argmax(ref.forward(tokens[900], 900)))       # (the oracle's cache holds positions 0 .. 1039: position 900 again)
+    ref.close()
+    ref = orc.OracleModel(g)
+    for pos, t in enumerate(tokens[:901]):
+        lg = ref.forward(t, pos)
+    ids, tok = [], int(orc.argmax(lg))
+    for i in range(150):
+        lg = ref.forward(tok, 901 + i)
+        tok = int(orc.argmax(lg)); ids.append(tok)
+    orc.set_threads(1)
+    ref.close()
+    dev.reset()
+    dev.prefill(tokens[:901])
+    f0 = int(np.argmax(dev.state.logits))
+    assert f0 == first
+    assert dev.decode_greedy(f0, 901, 150) == ids
+    assert dev.last_error() == ""
+    dev.close()
+
+
 def test_shapes_outside_the_instantiations_keep_the_launch_plans(hip, tmp_path):
     # GQA, other widths, other weight types: not candidates (the launch plans serve them as before)
     for shape, wt in ((synth.ModelShape("pd_gqa", 2, 256, 4, 2, 512, seq_len=64, interm=512), "q8_0"),
