@@ -546,6 +546,22 @@ def side_configs(model):
         ids = eng.generate_ids(prompt, GenParams(max_tokens=n, temperature=0.8, top_p=0.9))
         res[key] = round(len(ids) / (time.perf_counter() - t0), 1)
     out["nano_q8_0_default_sampling"] = res
+    # -- nano greedy decode against the context length (the headline is timed at positions 8 .. 27): 32 chained tokens from each
+    #    position, the persistent launch below its position limit (a head's 128-position passes shared by three units), the launch plans beyond
+    try:
+        long_prompt = synth.prompt_ids(1100, shape.vocab)
+        dev.reset(); dev.prefill(long_prompt)
+        bypos = {}
+        for p0 in (64, 300, 470, 700, 980, 1060):
+            dev.decode_greedy(5, p0, 32)
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter(); dev.decode_greedy(5, p0, 32); dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            bypos[str(p0)] = round(32 / best, 1)
+        out["nano_q8_0_greedy_tokens_per_s_by_position"] = dict(bypos, persistent_decode_below=dev.persist_info()["max_pos"])
+    except Exception as exc:  # a side measurement: the line must survive it
+        out["nano_q8_0_greedy_tokens_per_s_by_position"] = {"error": repr(exc)}
     dev.close()
     # -- the same settings on the 7.9B tier (96000-entry vocabulary: the selection streams its candidates out of L2)
     try:

@@ -24,6 +24,8 @@
 //   * after the last layer every compute unit multiplies its LM-head rows, the per-unit (max, index) pairs meet on layer 0's
 //     XCD, whose compute units pick the token (go/main.go:400-408: strict '>', lowest index on ties), look up its embedding
 //     row (go/model.go:389-446) and start the next token.
+//   * from position 128 on a head's 128-position attention passes are shared by up to three units (the owner and two of the
+//     units that are not heads in that slot); the owner merges their (max, sum, sum p v) records: one more in-XCD hand-off.
 // Dot products run on the matrix pipe: v_mfma_i32_4x4x4_16b_i8 over the int8 weights and four signed base-256 digits of the
 // 2^-30-rounded inputs (pd_limbs / pd_units_impl below).
 // Hand-offs are 8-byte {tag, value} granules (tag = launch base + step + 1; one aligned store each, the value is its own

@@ -10,7 +10,7 @@ import bench_modes as b
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
 
-# 1. nano greedy decode: the same 448-token continuation over and over (fused two-launch plan, chained graphs)
+# 1. nano greedy decode: the same 1000-token continuation over and over (round 5: the persistent launch, positions 16 .. 1015)
 g = b.gen("nano", "q8_0")
 dev = model.load_llama_model(g)
 prompt = synth.prompt_ids(16, g.meta.vocab_size)
@@ -18,7 +18,7 @@ ref_ids, runs, toks = None, 0, 0
 t0 = time.time()
 while time.time() - t0 < budget:
     dev.reset(); dev.prefill(prompt)
-    ids = dev.decode_greedy(int(np.argmax(dev.state.logits)), len(prompt), 448)
+    ids = dev.decode_greedy(int(np.argmax(dev.state.logits)), len(prompt), 1000)      # (round 5: through every pass count of the persistent launch)
     ref_ids = ref_ids or ids
     assert ids == ref_ids, f"nano greedy run {runs} differs"
     runs += 1; toks += len(ids)
