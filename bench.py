@@ -574,6 +574,19 @@ def side_configs(model):
         t0 = time.perf_counter()
         ids = eng.generate_ids(prompt, GenParams(max_tokens=96, temperature=0.8, top_p=0.9))
         out["big_q4_0_default_sampling"] = {"device_loop_tokens_per_s": round(len(ids) / (time.perf_counter() - t0), 1)}
+        # greedy decode against the context length (the secondary line is timed at short positions): 16 chained tokens from each
+        # position; below 1024 the two-launch layers, a head's 256-position passes shared by four blocks from the second pass on
+        long_prompt = synth.prompt_ids(1100, shape.vocab)
+        dev.reset(); dev.prefill(long_prompt)
+        bypos = {}
+        for p0 in (64, 300, 700, 980, 1060):
+            dev.decode_greedy(5, p0, 16)
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter(); dev.decode_greedy(5, p0, 16); dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            bypos[str(p0)] = round(16 / best, 1)
+        out["big_q4_0_greedy_tokens_per_s_by_position"] = dict(bypos, two_launch_layers_below=dev.plan_info()["fused_max_pos"])
         dev.close()
     except Exception as exc:  # a side measurement: the line must survive it
         out["big_q4_0_default_sampling"] = {"error": repr(exc)}

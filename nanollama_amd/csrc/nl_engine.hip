@@ -255,6 +255,8 @@ struct nl_engine {
     } tpg;
     u32x4 *tp_xq = nullptr;       // 16-byte granules of the two-launch layer (nl_tp.h): q | k | v tiles of a kv group,
     u32x4 *tp_xo = nullptr;       //   the heads' attention outputs,
+    u32x4 *tp_xp = nullptr;       //   the helper blocks' pass records (long contexts on one GPU),
+    bool attn_helpers = false;    //   ... when the launch's geometry has three helpers for every head (NL_ATTN_HELPERS=0: off)
     u32x4 *tp_hx = nullptr;       //   g | u (or h) tiles of the feed-forward half
     int grp_tpm = 1;              // mode 2: 16-row tiles per workgroup
     bool grp_grid_fits = false;   // modes 3 / 4: the projection grid (incl. its blocks without a tile, which stay) fits the compute units
@@ -784,6 +786,7 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         Q.wo_q = L.wo.q; Q.wo_s = L.wo.s; Q.wo_npairs = L.wo.npairs; Q.wo_ntiles = L.wo.ntiles; Q.wo_gshift = e->tpg.wo_gshift;
         Q.wo_tpw = e->tpg.wo_tpw;
         Q.n_heads_local = e->Hs; Q.xq = e->tp_xq; Q.xo = e->tp_xo; Q.bias_out = L.bo; Q.x = e->x[cur];
+        Q.xp = e->tp_xp; Q.helpers = e->attn_helpers ? 1 : 0; Q.live_grid = grp_grid(e->KVs, B.members);
         Q.seam = sm;
         const bool mfa = e->mf_attn;
         if (mfa) { B.qkv_q = L.qkv.q2; B.qkv_s = L.qkv.s2; }       // (WO stays on the vector pipe: nl_tp.h)
@@ -2718,6 +2721,16 @@ int nl_finalize(nl_handle e) {
             HIPCK(e, hipMemset(e->tp_xq, 0, nq * sizeof(u32x4)));
             HIPCK(e, dalloc(&e->tp_xo, no, &e->bytes_state));
             HIPCK(e, hipMemset(e->tp_xo, 0, no * sizeof(u32x4)));
+            HIPCK(e, dalloc(&e->tp_xp, (size_t)e->Hs * 3 * 22, &e->bytes_state));
+            HIPCK(e, hipMemset(e->tp_xp, 0, (size_t)e->Hs * 3 * 22 * sizeof(u32x4)));
+            {
+                // long contexts on one GPU (mode 4): a head's 256-position passes below the last run on three blocks that are not
+                // runners -- two of its own kv group (members G .. 3G - 1) and one of the blocks past the kv groups (nl_tp.h)
+                const int members = (e->gqa + 2) * 4 / e->grp_tpm, lgrid = grp_grid(e->KVs, members);
+                const int grid4 = std::max(lgrid, (e->layers[0].wo.ntiles + e->tpg.wo_tpw - 1) / e->tpg.wo_tpw);
+                const char *hk = getenv("NL_ATTN_HELPERS");
+                e->attn_helpers = e->fused_mode == 4 && !(hk && atoi(hk) == 0) && !c.qk_norm && members - e->gqa >= 2 * e->gqa && grid4 - lgrid >= e->Hs;
+            }
             HIPCK(e, dalloc(&e->tp_hx, nh, &e->bytes_state));
             HIPCK(e, hipMemset(e->tp_hx, 0, nh * sizeof(u32x4)));
             // Q4_0 dot products of the two launches on the matrix pipe (nl_tp.h mf_*): matrices whose rows are whole 256-column
@@ -2862,7 +2875,7 @@ int nl_destroy(nl_handle e) {
         if (e->p2p.epoch) (void)hipFree(e->p2p.epoch);
     }
     void *bufs[] = {e->embd_raw, e->output_norm, e->rope_cos, e->rope_sin, e->x[0], e->x[1], e->qbuf, e->part_o,
-                    e->part_ml, e->hb, e->ar, e->parts, e->xchg, e->tp_xq, e->tp_xo, e->tp_hx, e->tick, e->parts_ffn, e->xchg_ffn, e->samp_keep, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result, e->amax_val,
+                    e->part_ml, e->hb, e->ar, e->parts, e->xchg, e->tp_xq, e->tp_xo, e->tp_xp, e->tp_hx, e->tick, e->parts_ffn, e->xchg_ffn, e->samp_keep, e->logits, e->kcache, e->vcache, e->ctl, e->ids, e->result, e->amax_val,
                     e->amax_idx};
     for (void *b : bufs) if (b) hipFree(b);
     if (e->h_ctl) hipHostFree(e->h_ctl);

@@ -373,6 +373,9 @@ struct TpAttnParams {
     const float *bias_out;
     float *x;                    // residual stream, read at entry (RMSNorm input, owner rows) and rewritten by the owners
     TpSeam seam;
+    u32x4 *xp;                   // [Hs][3][22] granules: a helper block's (max, sum, sum p v[64]) record of ONE attention pass, for the head's runner
+    int helpers;                 // 1: from the second 256-position pass on, the passes below the last run on three blocks that are not runners
+    int live_grid;               // blocks [0, live_grid) belong to kv groups (grp_grid); the rest only multiply WO rows -- and help
     PfTiles pf;                  // round 0 of the feed-forward launch behind this one (gate, up tiles b of block b); nmat 0 = off
     PfTiles pf2;                 // the NEXT layer's projection tiles, for the memory-side Infinity Cache to keep (NL_PREFETCH bit 16; measured
                                  // and left off: 1.389 against 1.336 ms per token -- the extra lines push round 0 out of the L2s)
@@ -487,8 +490,23 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     float e_resid = 0.f;
     const int kr = lane >> 2, kq = lane & 3, vg = lane >> 4, vc = lane & 15;
     float4 kreg[NV], vreg[NV], kregn[NV];
-    const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + (long long)cl * P.seq_len * HD);
-    const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + (long long)cl * P.seq_len * HD);
+    // Attention passes are shared once there is more than one (go/model.go:557-587 over 256 positions per pass): the runner of a
+    // head keeps the LAST pass (the one that holds this position); pass nch - 1 - p goes to helper p = 1 .. 3 -- the two blocks of
+    // the head's own kv group that hold k / v tiles or none (mem >= G: same XCD as the runner) and one of the blocks past the kv
+    // groups.  A helper gathers the head's q itself and hands ONE record (max, sum, sum p v[64]) to the runner.
+    const int nch = min(pos / TP_PASS + 1, TP_NCH_MAX);
+    const bool shared = Q.helpers && nch > 1;
+    int hhead = -1, hpart = 0;            // this block as a helper
+    if (!RUNNER && shared) {
+        if (LIVE) { const int j = mem - G; hpart = 1 + j / G; hhead = hpart <= 2 ? cl * G + (j - (hpart - 1) * G) : -1; }
+        else { const int j = (int)blockIdx.x - Q.live_grid; hpart = 3; hhead = (j >= 0 && j < Q.n_heads_local) ? j : -1; }
+    }
+    const int hch = nch - 1 - hpart;      // its pass
+    const bool helper = !RUNNER && shared && hhead >= 0 && hch >= 0;
+    const int kvh = RUNNER ? cl : helper ? hhead / G : 0;
+    const int ch0 = RUNNER ? (shared ? nch - 1 : 0) : hch;     // first pass of this block
+    const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + (long long)kvh * P.seq_len * HD);
+    const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + (long long)kvh * P.seq_len * HD);
     // ---- the blocks that only wait for the heads warm the next launch's first round (see PfTiles): wavefronts 1 .. 15
     //      (wavefront 0 polls), one line per thread, split over the non-runner blocks of this block's XCD ----
     unsigned pf0 = 0, pf1 = 0, pf2v = 0;
@@ -530,13 +548,13 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
         // the row AT pos is produced by this launch and replaced from LDS below).  Eight cache wavefronts x 16 consecutive
         // positions of a pass: K as 16 of the row's 64 dims per lane (a score = 16 in-lane FMAs + two quad adds), V as float4
         // columns of four rows per lane -- nl_block.h's attention phase.
-        if (RUNNER) {
-            const int lim = min(min(TP_PASS, P.seq_len), pos + 1);
-            const unsigned krow = (unsigned)min(wave * 16 + kr, lim - 1) * R4 + (unsigned)kq;
+        if (RUNNER || helper) {       // (the block's first pass: a runner that shares starts on the last one)
+            const int t0 = ch0 * TP_PASS, lim = min(min(TP_PASS, P.seq_len - t0), pos + 1 - t0);
+            const unsigned krow = (unsigned)(t0 + min(wave * 16 + kr, lim - 1)) * R4 + (unsigned)kq;
 #pragma unroll
             for (int kk = 0; kk < NV; kk++) {
                 kreg[kk] = ld_off<float4>(K4, (krow + 4 * kk) * 16u);       // float4 kq + 4 kk of the row: a quad reads 64 contiguous bytes per instruction
-                vreg[kk] = ld_off<float4>(V4, (unsigned)(min(wave * 16 + vg + 4 * kk, lim - 1) * R4 + vc) * 16u);
+                vreg[kk] = ld_off<float4>(V4, (unsigned)((t0 + min(wave * 16 + vg + 4 * kk, lim - 1)) * R4 + vc) * 16u);
             }
         }
         if (Q.bias_out) e_bo = Q.bias_out[min(w_row, D - 1)];
@@ -628,17 +646,20 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
         TP_STAMP(sslot, 4);
         if (!RUNNER && Q.pf_early) warm();
     }
-    if (!RUNNER && !wg_has_wo) return;
+    if (!RUNNER && !wg_has_wo && !helper) return;
 
-    if (RUNNER) {
-        // ---- the attention of query head cl * G + mem (go/model.go:557-587): gather the head's q and the group's k | v ----
-        const int h = cl * G + mem;
+    if (RUNNER || helper) {
+        // ---- the attention of query head cl * G + mem (go/model.go:557-587): gather the head's q and the group's k | v (a helper:
+        //      q of the head it helps; k | v of this position belong to the last pass) ----
+        const int h = RUNNER ? cl * G + mem : hhead;
+        const int qcl = RUNNER ? cl : hhead / G, qmem = RUNNER ? mem : hhead - (hhead / G) * G;
+        const int ntl = RUNNER ? 12 : 4;
         if (tid < 128) {     // 12 tiles x 6 granules on 72 threads (two wavefronts)
             const bool dead = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-            const int gi = min(tid, 12 * GPT - 1), t12 = gi / GPT, j = gi - t12 * GPT;
-            const int sect = t12 >> 2, tj = t12 & 3, hq = sect == 0 ? mem : G + sect - 1;
-            const u32x4 g = gran16_wait(Q.xq + ((size_t)cl * (G + 2) * 4 + hq * 4 + tj) * GPT + j, 0, 1, tag, P.status, P.host_status, P.spin_limit, 8u, dead);
-            if (tid < 12 * GPT) {
+            const int gi = min(tid, ntl * GPT - 1), t12 = gi / GPT, j = gi - t12 * GPT;
+            const int sect = t12 >> 2, tj = t12 & 3, hq = sect == 0 ? qmem : G + sect - 1;
+            const u32x4 g = gran16_wait(Q.xq + ((size_t)qcl * (G + 2) * 4 + hq * 4 + tj) * GPT + j, 0, 1, tag, P.status, P.host_status, P.spin_limit, 8u, dead);
+            if (tid < ntl * GPT) {
                 const unsigned vals[3] = {g.y, g.z, g.w};
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
@@ -649,7 +670,7 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
         }
         __syncthreads();
         TP_STAMP(sslot, 5);
-        if (P.qk_norm) {   // RMSNormBare per head on q and k after RoPE, go/model.go:542-549
+        if (RUNNER && P.qk_norm) {   // RMSNormBare per head on q and k after RoPE, go/model.go:542-549 (the host keeps helpers off with it)
             if (wave < 2) {
                 float *vec = wave == 0 ? qs : kcur;
                 const float val = vec[lane];
@@ -659,23 +680,23 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
             }
             __syncthreads();
         }
-        if (mem == 0 && tid < 128)   // KV store go/model.go:552-554, once per kv head
+        if (RUNNER && mem == 0 && tid < 128)   // KV store go/model.go:552-554, once per kv head
             (tid < 64 ? P.kcache : P.vcache)[soff + ((long long)cl * P.seq_len + pos) * HD + (tid & 63)] = kcur[tid];
 
         // ---- positions 0..pos, 128 per pass; every cache wavefront reduces its 16 positions to ONE (max, sum, sum p*v)
         //      partial in registers, eight partials per pass meet in LDS behind one barrier (nl_block.h) ----
-        const int nch = min(pos / TP_PASS + 1, TP_NCH_MAX);
-        for (int ch = 0; ch < nch; ch++) {
+        const int chend = RUNNER ? nch : hch + 1;
+        for (int ch = ch0; ch < chend; ch++) {
             const int t0 = ch * TP_PASS, n = min(TP_PASS, pos + 1 - t0);
             {
-                if (ch > 0) {
+                if (ch > ch0) {
 #pragma unroll
                     for (int kk = 0; kk < NV; kk++) {
                         kreg[kk] = kregn[kk];
                         vreg[kk] = V4[(long long)(t0 + min(wave * 16 + vg + 4 * kk, n - 1)) * R4 + vc];
                     }
                 }
-                if (ch + 1 < nch) {
+                if (ch + 1 < chend) {
                     const int n1 = min(TP_PASS, pos + 1 - t0 - TP_PASS);
 #pragma unroll
                     for (int kk = 0; kk < NV; kk++) kregn[kk] = K4[(long long)(t0 + TP_PASS + min(wave * 16 + kr, n1 - 1)) * R4 + kq + 4 * kk];
@@ -720,21 +741,37 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
                 float ov = 0.f;
 #pragma unroll
                 for (int w = 0; w < 16; w++) ov = fmaf(__shfl(wgt, w), wpart[w * 68 + 4 + lane], ov);
-                chunk[ch * 66 + 2 + lane] = ov;
-                if (lane == 0) { chunk[ch * 66] = Mx; chunk[ch * 66 + 1] = L; }
+                chunk[(ch - ch0) * 66 + 2 + lane] = ov;
+                if (lane == 0) { chunk[(ch - ch0) * 66] = Mx; chunk[(ch - ch0) * 66 + 1] = L; }
             }
-            if (ch + 1 < nch) __syncthreads();   // wpart is rewritten by the next pass
+            if (ch + 1 < chend) __syncthreads();   // wpart is rewritten by the next pass
         }
         TP_STAMP(sslot, 6);
-        // merge the passes as the WO prologue of the general plan does (load_x4<PRO_ATTN>); publish the head's output
-        if (wave == 0) {
+        int nrec = chend - ch0;      // records in LDS: this block's own passes ...
+        if (RUNNER && shared) {      // ... and one per helper (passes nch - 2 .. max(nch - 4, 0)), 22 granules of three values each
+            const int np = min(nch - 1, 3);
+            __syncthreads();
+            if (tid < np * 22) {
+                const bool dead = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                const int pp = tid / 22, j = tid - pp * 22;
+                const u32x4 g = gran16_wait(Q.xp + ((size_t)h * 3 + pp) * 22 + j, 0, 1, tag, P.status, P.host_status, P.spin_limit, 16u, dead);
+                float *rec = chunk + (1 + pp) * 66 + 3 * j;
+                rec[0] = __uint_as_float(g.y); rec[1] = __uint_as_float(g.z); rec[2] = __uint_as_float(g.w);
+            }
+            nrec += np;
+        }
+        __syncthreads();
+        if (!RUNNER) {               // a helper: its record (one pass) to the head's runner
+            if (tid < 22) gran16_store(Q.xp + ((size_t)hhead * 3 + (hpart - 1)) * 22 + tid, tag, chunk[3 * tid], chunk[3 * tid + 1], chunk[3 * tid + 2]);
+        } else if (wave == 0) {
+            // merge the records as the WO prologue of the general plan does (load_x4<PRO_ATTN>); publish the head's output
             float outv;
-            if (nch == 1) outv = chunk[2 + lane] * (1.0f / chunk[1]);
+            if (nrec == 1) outv = chunk[2 + lane] * (1.0f / chunk[1]);
             else {
                 float Mx = chunk[0];
-                for (int c = 1; c < nch; c++) Mx = fmaxf(Mx, chunk[c * 66]);
+                for (int c = 1; c < nrec; c++) Mx = fmaxf(Mx, chunk[c * 66]);
                 float v = 0.f, L = 0.f;
-                for (int c = 0; c < nch; c++) {
+                for (int c = 0; c < nrec; c++) {
                     const float w = __expf(chunk[c * 66] - Mx);
                     L += w * chunk[c * 66 + 1];
                     v += w * chunk[c * 66 + 2 + lane];
