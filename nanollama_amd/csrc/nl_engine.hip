@@ -235,7 +235,7 @@ struct nl_engine {
         hipGraphExec_t exec = nullptr;
         hipGraph_t multi = nullptr;          // the same plan graph_steps times: chained greedy decode replays it
         hipGraphExec_t multi_exec = nullptr;  // (one inter-graph gap per graph_steps tokens instead of per token)
-    } ps[2];
+    } ps[3];                                 // (ps[2]: ps[1] with the attention launch whose passes are shared by helper blocks: wide tier, one GPU, from the second pass on)
     bool fused = false;           // ps[1] exists
     int fused_mode = 0;           // 1: whole attention half per layer (nl_block.h); 2: projection + attention (nl_group.h);
                                   // 3: a tensor-parallel rank's layer as two launches (nl_tp.h); 4: one GPU, wide tier: mode 3's
@@ -277,9 +277,9 @@ struct nl_engine {
     ArgmaxParams plan_argmax{};
     P2PArgmaxParams plan_p2p_argmax{};
     // sampled chained decode: {sampler, plan} x graph_steps, captured per sampling-parameter set
-    hipGraph_t samp_graph[2] = {nullptr, nullptr};          // per launch plan (ps[0] / ps[1])
-    hipGraphExec_t samp_graph_exec[2] = {nullptr, nullptr};
-    nl_sample_params samp_graph_params[2]{};
+    hipGraph_t samp_graph[3] = {nullptr, nullptr, nullptr};          // per launch plan (ps[0] / ps[1] / ps[2])
+    hipGraphExec_t samp_graph_exec[3] = {nullptr, nullptr, nullptr};
+    nl_sample_params samp_graph_params[3]{};
     bool samp_graph_failed = false;
     bool use_graph = true;
     void *comm = nullptr;
@@ -728,7 +728,7 @@ void build_plan_blocks(nl_engine *e, std::vector<Op> &plan) {
 // Build the per-token launch plan: the device-side restatement of Forward
 // (go/model.go:490-620).  token / pos / stream are read from e->ctl by the
 // kernels, so one captured graph serves every step.
-void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
+void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused, bool help = false) {
     if (fused && e->fused_mode == 1 && e->ffn_fused) { build_plan_blocks(e, plan); return; }
     plan.clear();
     const nl_config &c = e->cfg;
@@ -786,7 +786,7 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         Q.wo_q = L.wo.q; Q.wo_s = L.wo.s; Q.wo_npairs = L.wo.npairs; Q.wo_ntiles = L.wo.ntiles; Q.wo_gshift = e->tpg.wo_gshift;
         Q.wo_tpw = e->tpg.wo_tpw;
         Q.n_heads_local = e->Hs; Q.xq = e->tp_xq; Q.xo = e->tp_xo; Q.bias_out = L.bo; Q.x = e->x[cur];
-        Q.xp = e->tp_xp; Q.helpers = e->attn_helpers ? 1 : 0; Q.live_grid = grp_grid(e->KVs, B.members);
+        Q.xp = e->tp_xp; Q.helpers = (help && e->attn_helpers) ? 1 : 0; Q.live_grid = grp_grid(e->KVs, B.members);
         Q.seam = sm;
         const bool mfa = e->mf_attn;
         if (mfa) { B.qkv_q = L.qkv.q2; B.qkv_s = L.qkv.s2; }       // (WO stays on the vector pipe: nl_tp.h)
@@ -807,8 +807,13 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused) {
         const int wt = L.qkv.wtype, grid = std::max(grp_grid(e->KVs, B.members), (L.wo.ntiles + e->tpg.wo_tpw - 1) / e->tpg.wo_tpw);
         const int ngroups = (L.qkv.npairs + KL - 1) / KL, nf = (ngroups + 16 / e->grp_tpm - 1) / (16 / e->grp_tpm);
         const size_t lds = tp_attn_lds_bytes(L.wo.npairs);
-        Op op{K_ATTNBLOCK, coll, cbuf, (size_t)c.dim, [Q, wt, grid, nf, lds, mfa](hipStream_t st) {
-                  if (mfa && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 1, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+        const bool hlp = Q.helpers != 0;
+        Op op{K_ATTNBLOCK, coll, cbuf, (size_t)c.dim, [Q, wt, grid, nf, lds, mfa, hlp](hipStream_t st) {
+                  if (hlp && wt == WT_Q8_0 && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 1, false, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                  else if (hlp && wt == WT_Q8_0) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 2, false, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                  else if (hlp && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 1, false, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                  else if (hlp) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 2, false, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                  else if (mfa && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 1, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
                   else if (mfa) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 2, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
                   else if (wt == WT_Q8_0 && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 1>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
                   else if (wt == WT_Q8_0) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 2>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
@@ -1157,16 +1162,20 @@ int capture_graph(nl_engine *e, nl_engine::PlanSet &S) {
 }
 
 void destroy_samp_graphs(nl_engine *e) {
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 3; k++) {
         if (e->samp_graph_exec[k]) { (void)hipGraphExecDestroy(e->samp_graph_exec[k]); e->samp_graph_exec[k] = nullptr; }
         if (e->samp_graph[k]) { (void)hipGraphDestroy(e->samp_graph[k]); e->samp_graph[k] = nullptr; }
     }
 }
 
 // the plan that serves a step (or a run of steps) whose highest position is pos_last
-nl_engine::PlanSet &pick_plan(nl_engine *e, int pos_last) {
-    return e->ps[(e->fused && pos_last < e->fused_max_pos) ? 1 : 0];
+// (ps[2]: the fused plan of the wide tier on one GPU from the second attention pass on -- its attention launch is the variant
+//  whose passes are shared by helper blocks, nl_tp.h; the first pass keeps the launch compiled without them: 0.7 us per layer)
+int plan_index(const nl_engine *e, int pos_last) {
+    if (!(e->fused && pos_last < e->fused_max_pos)) return 0;
+    return (e->attn_helpers && pos_last >= TP_PASS) ? 2 : 1;
 }
+nl_engine::PlanSet &pick_plan(nl_engine *e, int pos_last) { return e->ps[plan_index(e, pos_last)]; }
 
 int launch_step(nl_engine *e, int pos) {
     nl_engine::PlanSet &S = pick_plan(e, pos);
@@ -1183,9 +1192,10 @@ int build_all(nl_engine *e) {
     e->graph_steps = 1;
     build_plan(e, e->ps[0].ops, false);
     if (e->fused) build_plan(e, e->ps[1].ops, true);
+    if (e->fused && e->attn_helpers) build_plan(e, e->ps[2].ops, true, true);
     const bool has_coll = (e->G > 1 || e->force_tp_plan) && !e->p2p.on;
     if (e->use_graph && !(e->cfg.flags & NL_FLAG_LOCAL_GROUP)) {
-        for (int k = 0; k < (e->fused ? 2 : 1); k++) {
+        for (int k = 0; k < (e->fused ? (e->attn_helpers ? 3 : 2) : 1); k++) {
             int rc = capture_graph(e, e->ps[k]);
             if (rc && has_coll) {
                 // RCCL inside a captured graph is not guaranteed on every RCCL build: fall back to eager launches
@@ -3168,7 +3178,7 @@ int nl_sample_decode(nl_handle e, int stream, int pos, int n_steps, const nl_sam
         while (e->ps[0].multi_exec && !e->samp_graph_failed && i + e->graph_steps <= n) {
             // {sampler kernels, plan} x graph_steps as one graph per launch plan (its kernel arguments include the sampling
             // parameters: re-captured when they change); the plan is chosen by the highest position of the 16 steps
-            const int k = (e->fused && pos + i + e->graph_steps - 1 < e->fused_max_pos) ? 1 : 0;
+            const int k = plan_index(e, pos + i + e->graph_steps - 1);
             if (!e->samp_graph_exec[k] || memcmp(&e->samp_graph_params[k], p, sizeof(*p)) != 0) {
                 std::lock_guard<std::mutex> setup(g_setup_mu);
                 if (e->samp_graph_exec[k]) { hipGraphExecDestroy(e->samp_graph_exec[k]); e->samp_graph_exec[k] = nullptr; }

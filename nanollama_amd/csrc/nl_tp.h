@@ -391,7 +391,7 @@ __host__ __device__ constexpr size_t tp_attn_lds_bytes(int wo_npairs) {
 // hipcc's counted s_waitcnt in front of the first use of x is exact -- with loads behind role branches it assumes the
 // shortest path and makes the RMSNorm wait for the weights, the dots for the cache rows and the WO tiles.
 // LIVE: the block holds projection tiles; RUNNER: ... and runs the attention of one query head.
-template <int WT, int NF, bool LIVE, bool RUNNER, bool MF>
+template <int WT, int NF, bool LIVE, bool RUNNER, bool MF, bool HELP>
 __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, int cl, int mem) {
     const GroupParams &P = Q.G;
     constexpr int HD = 64, CPP = WTraits<WT>::CPP, R4 = HD / 4, NV = 4, NW = TP_THREADS / 64;
@@ -495,7 +495,8 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     // the head's own kv group that hold k / v tiles or none (mem >= G: same XCD as the runner) and one of the blocks past the kv
     // groups.  A helper gathers the head's q itself and hands ONE record (max, sum, sum p v[64]) to the runner.
     const int nch = min(pos / TP_PASS + 1, TP_NCH_MAX);
-    const bool shared = Q.helpers && nch > 1;
+    const bool shared = HELP && Q.helpers && nch > 1;       // (HELP: the launch plan of positions from the second pass on -- the plan
+                                                            //  of the first pass is compiled without any of this)
     int hhead = -1, hpart = 0;            // this block as a helper
     if (!RUNNER && shared) {
         if (LIVE) { const int j = mem - G; hpart = 1 + j / G; hhead = hpart <= 2 ? cl * G + (j - (hpart - 1) * G) : -1; }
@@ -760,7 +761,7 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
             }
             nrec += np;
         }
-        __syncthreads();
+        if (HELP) __syncthreads();   // (without helpers wavefront 0 reads back its own records)
         if (!RUNNER) {               // a helper: its record (one pass) to the head's runner
             if (tid < 22) gran16_store(Q.xp + ((size_t)hhead * 3 + (hpart - 1)) * 22 + tid, tag, chunk[3 * tid], chunk[3 * tid + 1], chunk[3 * tid + 2]);
         } else if (wave == 0) {
@@ -809,7 +810,7 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     pf_done(pf0 ^ pf2v, pf1);
 }
 
-template <int WT, int NF, bool MF = false>
+template <int WT, int NF, bool MF = false, bool HELP = false>
 __global__ void __launch_bounds__(TP_THREADS) tp_attn_kernel(TpAttnParams Q) {
     const GroupParams &P = Q.G;
     NL_KARGS8(P.qkv_q, P.qkv_s, P.x, P.normw, P.rope_cos, P.rope_sin, P.kcache, P.vcache);
@@ -826,9 +827,9 @@ __global__ void __launch_bounds__(TP_THREADS) tp_attn_kernel(TpAttnParams Q) {
     TP_CENSUS(0, P.layer_tag, 0);
     if (!live) {
         if ((int)blockIdx.x * Q.wo_tpw >= Q.wo_ntiles) return;
-        tp_attn_body<WT, NF, false, false, MF>(Q, smem, 0, 0);
-    } else if (mem < (int)P.gqa) tp_attn_body<WT, NF, true, true, MF>(Q, smem, cl, mem);
-    else tp_attn_body<WT, NF, true, false, MF>(Q, smem, cl, mem);
+        tp_attn_body<WT, NF, false, false, MF, HELP>(Q, smem, 0, 0);
+    } else if (mem < (int)P.gqa) tp_attn_body<WT, NF, true, true, MF, HELP>(Q, smem, cl, mem);
+    else tp_attn_body<WT, NF, true, false, MF, HELP>(Q, smem, cl, mem);
     TP_CENSUS(0, P.layer_tag, 1);
 }
 
