@@ -192,6 +192,38 @@ def test_big_attention_geometry_across_the_in_launch_passes(hip, orc, tmp_path):
         print(f"big geometry, mode 3 tp {n}: max|gpu-oracle| = {worst:.2e}")
 
 
+def test_attention_helpers_agree_with_the_general_plan_after_a_prompt(hip, tmp_path, monkeypatch):
+    # the long-context plan of the wide tier on one GPU (from the second 256-position pass on, the passes below the last run on
+    # three helper blocks: nl_tp.h) against the five-launch plan of the same handle type, on a cache a 1000-token prompt wrote
+    # (the batched path): positions in every pass count and at the pass edges, and the same with the helpers switched off
+    shape = synth.ModelShape("big_geo_h", 2, 4096, 64, 16, 1024, seq_len=1088, interm=2048)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", 97, mode="qrand")
+    g = gguf.load_gguf(str(p))
+    toks = synth.prompt_ids(1030, shape.vocab, seed=41)
+    positions = (100, 255, 256, 300, 511, 512, 700, 767, 768, 769, 900, 1023)
+    res = {}
+    for name, env in (("general", {"NL_FUSED_MAX_POS": "0"}), ("helpers", {}), ("alone", {"NL_ATTN_HELPERS": "0"})):
+        for k in ("NL_FUSED_MAX_POS", "NL_ATTN_HELPERS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dev = hip.load_llama_model(g)
+        dev.prefill(toks[:1024])
+        out = {}
+        for pos in positions:
+            dev.forward(toks[pos], pos)
+            out[pos] = dev.state.logits.copy()
+        assert dev.last_error() == "", (name, dev.last_error())
+        res[name] = out
+        dev.close()
+    for pos in positions:
+        ref = res["general"][pos]
+        for name in ("helpers", "alone"):
+            d = float(np.abs(res[name][pos] - ref).max()) / max(1.0, float(ref.std()))
+            assert d <= 2e-5, (name, pos, d)
+
+
 def test_fused_modes_keep_out_of_a_launch_whose_staying_blocks_exceed_the_compute_units(hip, orc, tmp_path):
     # Modes 3 / 4 keep every LIVE block (projection tiles of an existing kv group) and every WO-owning block resident until its
     # rows are done; tile-less blocks without WO rows leave at once.  D 2560 / 40 heads / 5 kv heads: 200 live blocks in a grid of
