@@ -575,11 +575,11 @@ def side_configs(model):
         ids = eng.generate_ids(prompt, GenParams(max_tokens=96, temperature=0.8, top_p=0.9))
         out["big_q4_0_default_sampling"] = {"device_loop_tokens_per_s": round(len(ids) / (time.perf_counter() - t0), 1)}
         # greedy decode against the context length (the secondary line is timed at short positions): 16 chained tokens from each
-        # position; below 1024 the two-launch layers, a head's 256-position passes shared by four blocks from the second pass on
-        long_prompt = synth.prompt_ids(1100, shape.vocab)
+        # position; the two-launch layers at every position, a head's 256-position passes shared by four blocks from the second pass on
+        long_prompt = synth.prompt_ids(1940, shape.vocab)
         dev.reset(); dev.prefill(long_prompt)
         bypos = {}
-        for p0 in (64, 300, 700, 980, 1060):
+        for p0 in (64, 300, 700, 980, 1500, 1900):
             dev.decode_greedy(5, p0, 16)
             best = None
             for _ in range(3):

@@ -809,9 +809,7 @@ void build_plan(nl_engine *e, std::vector<Op> &plan, bool fused, bool help = fal
         const size_t lds = tp_attn_lds_bytes(L.wo.npairs);
         const bool hlp = Q.helpers != 0;
         Op op{K_ATTNBLOCK, coll, cbuf, (size_t)c.dim, [Q, wt, grid, nf, lds, mfa, hlp](hipStream_t st) {
-                  if (hlp && wt == WT_Q8_0 && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 1, false, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
-                  else if (hlp && wt == WT_Q8_0) hipLaunchKernelGGL((tp_attn_kernel<WT_Q8_0, 2, false, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
-                  else if (hlp && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 1, false, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
+                  if (hlp && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 1, false, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
                   else if (hlp) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 2, false, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
                   else if (mfa && nf == 1) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 1, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
                   else if (mfa) hipLaunchKernelGGL((tp_attn_kernel<WT_Q4_0, 2, true>), dim3(grid), dim3(TP_THREADS), lds, st, Q);
@@ -2702,7 +2700,19 @@ int nl_finalize(nl_handle e) {
         //  (round 5, the same tool with the feed-forward launch on the matrix pipe and its first round warm: 1.76 against 1.85 ms at
         //  position 800, 1.80 against 1.86 at 980 -- the two-launch layers now stay ahead through all four passes)
         e->fused_max_pos = fm ? atoi(fm) : e->fused_mode == 4 ? (e->wide_ffn ? 1024 : 768) : (e->fused_mode == 1 || e->fused_mode == 3) ? 512 : 384;
-        if (e->fused_mode == 3 || e->fused_mode == 4) e->fused_max_pos = std::min(e->fused_max_pos, TP_NCH_MAX * TP_PASS);   // passes a head takes inside the launch
+        {
+            // long contexts on one GPU (mode 4): a head's 256-position passes are shared by its runner and three blocks that are not
+            // runners -- two of its own kv group (members G .. 3G - 1) and one of the blocks past the kv groups (nl_tp.h) --, up to
+            // two passes each: the two-launch layers then serve every position of the reference's context (2048, go/model.go:145-148)
+            const int members = (e->gqa + 2) * 4 / e->grp_tpm, lgrid = grp_grid(e->KVs, members);
+            const int grid4 = std::max(lgrid, (e->layers[0].wo.ntiles + e->tpg.wo_tpw - 1) / e->tpg.wo_tpw);
+            const char *hk = getenv("NL_ATTN_HELPERS");
+            e->attn_helpers = e->fused_mode == 4 && !(hk && atoi(hk) == 0) && !c.qk_norm && members - e->gqa >= 2 * e->gqa && grid4 - lgrid >= e->Hs &&
+                              e->layers[0].qkv.wtype == WT_Q4_0;      // (the Q8_0 variant of that launch does not fit 128 registers: 278 spilled)
+            if (!fm && e->attn_helpers && e->wide_ffn) e->fused_max_pos = 2 * TP_NCH_MAX * TP_PASS;
+        }
+        if (e->fused_mode == 3 || e->fused_mode == 4)      // passes a head takes inside the launch
+            e->fused_max_pos = std::min(e->fused_max_pos, (e->attn_helpers ? 2 : 1) * TP_NCH_MAX * TP_PASS);
         {
             const char *ff = getenv("NL_FUSED_FFN");   // knob (tests, tools): 0 keeps gate/up and down as two launches
             bool okf = e->fused_mode == 1 && !(ff && atoi(ff) == 0);
@@ -2731,16 +2741,8 @@ int nl_finalize(nl_handle e) {
             HIPCK(e, hipMemset(e->tp_xq, 0, nq * sizeof(u32x4)));
             HIPCK(e, dalloc(&e->tp_xo, no, &e->bytes_state));
             HIPCK(e, hipMemset(e->tp_xo, 0, no * sizeof(u32x4)));
-            HIPCK(e, dalloc(&e->tp_xp, (size_t)e->Hs * 3 * 22, &e->bytes_state));
-            HIPCK(e, hipMemset(e->tp_xp, 0, (size_t)e->Hs * 3 * 22 * sizeof(u32x4)));
-            {
-                // long contexts on one GPU (mode 4): a head's 256-position passes below the last run on three blocks that are not
-                // runners -- two of its own kv group (members G .. 3G - 1) and one of the blocks past the kv groups (nl_tp.h)
-                const int members = (e->gqa + 2) * 4 / e->grp_tpm, lgrid = grp_grid(e->KVs, members);
-                const int grid4 = std::max(lgrid, (e->layers[0].wo.ntiles + e->tpg.wo_tpw - 1) / e->tpg.wo_tpw);
-                const char *hk = getenv("NL_ATTN_HELPERS");
-                e->attn_helpers = e->fused_mode == 4 && !(hk && atoi(hk) == 0) && !c.qk_norm && members - e->gqa >= 2 * e->gqa && grid4 - lgrid >= e->Hs;
-            }
+            HIPCK(e, dalloc(&e->tp_xp, (size_t)e->Hs * 3 * 2 * 22, &e->bytes_state));
+            HIPCK(e, hipMemset(e->tp_xp, 0, (size_t)e->Hs * 3 * 2 * 22 * sizeof(u32x4)));
             HIPCK(e, dalloc(&e->tp_hx, nh, &e->bytes_state));
             HIPCK(e, hipMemset(e->tp_hx, 0, nh * sizeof(u32x4)));
             // Q4_0 dot products of the two launches on the matrix pipe (nl_tp.h mf_*): matrices whose rows are whole 256-column

@@ -38,7 +38,8 @@ __device__ long long g_tp_census[2][512][2];     // [launch kind][block][entry, 
 #endif
 
 constexpr int TP_THREADS = 1024;
-constexpr int TP_NCH_MAX = 4;        // passes a head's attention may take inside the launch
+constexpr int TP_NCH_MAX = 4;        // passes a head's attention may take inside the launch on ONE block
+constexpr int TP_REC_MAX = 8;        // records a runner merges: its own passes + the helpers' (with helpers a head covers up to 4 x 2 passes)
 constexpr int TP_PASS = 256;         // positions per pass: ALL sixteen wavefronts of the runner hold 16 cache rows each (the first
                                      // version used eight, 128 positions per pass, and left the other eight idle: at position 470
                                      // four dependent passes of ~1.7 us per layer instead of two).  fused_max_pos <= 4 x 256
@@ -383,7 +384,7 @@ struct TpAttnParams {
 };
 
 __host__ __device__ constexpr size_t tp_attn_lds_bytes(int wo_npairs) {
-    return 16 * sizeof(double) + sizeof(float) * (size_t)(16 * XS_WAVE + 16 * TR + 3 * 64 + 16 * 68 + TP_NCH_MAX * 66 + wo_npairs * XS_PAIR + 16 * TR) +
+    return 16 * sizeof(double) + sizeof(float) * (size_t)(16 * XS_WAVE + 16 * TR + 3 * 64 + 16 * 68 + TP_REC_MAX * 66 + wo_npairs * XS_PAIR + 16 * TR) +
            0;
 }
 
@@ -401,8 +402,8 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     float *qs = red + NW * TR;                                       // [64]
     float *kcur = qs + 64, *vcur = kcur + 64;
     float *wpart = vcur + 64;                                        // [16][68]: a cache wavefront's (max, sum, -, -, sum p*v[64]) of the pass
-    float *chunk = wpart + 16 * 68;                                  // [TP_NCH_MAX][66]: (M, L, o[64]) per pass
-    float *ao = chunk + TP_NCH_MAX * 66;                             // [wo_npairs][XS_PAIR]: every local head's output
+    float *chunk = wpart + 16 * 68;                                  // [TP_REC_MAX][66]: (M, L, o[64]) per pass (own and helpers')
+    float *ao = chunk + TP_REC_MAX * 66;                             // [wo_npairs][XS_PAIR]: every local head's output
     float *red2 = ao + Q.wo_npairs * XS_PAIR;                        // [16][16]
     static_assert(!MF || WT == WT_Q4_0, "matrix-pipe dot products: Q4_0");
 
@@ -494,7 +495,7 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
     // head keeps the LAST pass (the one that holds this position); pass nch - 1 - p goes to helper p = 1 .. 3 -- the two blocks of
     // the head's own kv group that hold k / v tiles or none (mem >= G: same XCD as the runner) and one of the blocks past the kv
     // groups.  A helper gathers the head's q itself and hands ONE record (max, sum, sum p v[64]) to the runner.
-    const int nch = min(pos / TP_PASS + 1, TP_NCH_MAX);
+    const int nch = min(pos / TP_PASS + 1, (HELP && Q.helpers) ? 2 * TP_NCH_MAX : TP_NCH_MAX);
     const bool shared = HELP && Q.helpers && nch > 1;       // (HELP: the launch plan of positions from the second pass on -- the plan
                                                             //  of the first pass is compiled without any of this)
     int hhead = -1, hpart = 0;            // this block as a helper
@@ -502,10 +503,12 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
         if (LIVE) { const int j = mem - G; hpart = 1 + j / G; hhead = hpart <= 2 ? cl * G + (j - (hpart - 1) * G) : -1; }
         else { const int j = (int)blockIdx.x - Q.live_grid; hpart = 3; hhead = (j >= 0 && j < Q.n_heads_local) ? j : -1; }
     }
-    const int hch = nch - 1 - hpart;      // its pass
-    const bool helper = !RUNNER && shared && hhead >= 0 && hch >= 0;
+    // part p (0 = the runner) takes the passes [nch - (p + 1) per, nch - p per), per = ceil(nch / 4): contiguous, the last ones the runner's
+    const int per = shared ? (nch + 3) >> 2 : nch;
+    const int mypart = RUNNER ? 0 : hpart;
+    const int chend = nch - mypart * per, ch0 = max(chend - per, 0);     // this block's passes [ch0, chend)
+    const bool helper = !RUNNER && shared && hhead >= 0 && chend > 0;
     const int kvh = RUNNER ? cl : helper ? hhead / G : 0;
-    const int ch0 = RUNNER ? (shared ? nch - 1 : 0) : hch;     // first pass of this block
     const float4 *K4 = reinterpret_cast<const float4 *>(P.kcache + soff + (long long)kvh * P.seq_len * HD);
     const float4 *V4 = reinterpret_cast<const float4 *>(P.vcache + soff + (long long)kvh * P.seq_len * HD);
     // ---- the blocks that only wait for the heads warm the next launch's first round (see PfTiles): wavefronts 1 .. 15
@@ -686,18 +689,20 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
 
         // ---- positions 0..pos, 128 per pass; every cache wavefront reduces its 16 positions to ONE (max, sum, sum p*v)
         //      partial in registers, eight partials per pass meet in LDS behind one barrier (nl_block.h) ----
-        const int chend = RUNNER ? nch : hch + 1;
         for (int ch = ch0; ch < chend; ch++) {
             const int t0 = ch * TP_PASS, n = min(TP_PASS, pos + 1 - t0);
             {
                 if (ch > ch0) {
 #pragma unroll
                     for (int kk = 0; kk < NV; kk++) {
-                        kreg[kk] = kregn[kk];
+                        // (the launch with helpers fetches a second pass's K rows at its start: the prefetch a pass ahead costs sixteen
+                        //  registers, and this launch at its 128 spilled 22 of them -- with wrong records from the blocks past the kv groups)
+                        if (!HELP) kreg[kk] = kregn[kk];
+                        else kreg[kk] = K4[(long long)(t0 + min(wave * 16 + kr, n - 1)) * R4 + kq + 4 * kk];
                         vreg[kk] = V4[(long long)(t0 + min(wave * 16 + vg + 4 * kk, n - 1)) * R4 + vc];
                     }
                 }
-                if (ch + 1 < chend) {
+                if (!HELP && ch + 1 < chend) {
                     const int n1 = min(TP_PASS, pos + 1 - t0 - TP_PASS);
 #pragma unroll
                     for (int kk = 0; kk < NV; kk++) kregn[kk] = K4[(long long)(t0 + TP_PASS + min(wave * 16 + kr, n1 - 1)) * R4 + kq + 4 * kk];
@@ -744,26 +749,30 @@ __device__ __forceinline__ void tp_attn_body(const TpAttnParams &Q, char *smem, 
                 for (int w = 0; w < 16; w++) ov = fmaf(__shfl(wgt, w), wpart[w * 68 + 4 + lane], ov);
                 chunk[(ch - ch0) * 66 + 2 + lane] = ov;
                 if (lane == 0) { chunk[(ch - ch0) * 66] = Mx; chunk[(ch - ch0) * 66 + 1] = L; }
+                if (!RUNNER) {      // a helper: the pass's record straight to the head's runner (slot = part, pass of the part)
+                    __builtin_amdgcn_wave_barrier();
+                    const float *rec = chunk + (ch - ch0) * 66;
+                    if (lane < 22) gran16_store(Q.xp + (unsigned)(((hhead * 3 + (hpart - 1)) * 2 + (ch - ch0)) * 22 + lane), tag, rec[3 * lane], rec[3 * lane + 1], rec[3 * lane + 2]);
+                }
             }
             if (ch + 1 < chend) __syncthreads();   // wpart is rewritten by the next pass
         }
         TP_STAMP(sslot, 6);
         int nrec = chend - ch0;      // records in LDS: this block's own passes ...
-        if (RUNNER && shared) {      // ... and one per helper (passes nch - 2 .. max(nch - 4, 0)), 22 granules of three values each
-            const int np = min(nch - 1, 3);
+        if (RUNNER && shared) {      // ... and the helpers' (the nch - per passes below the runner's, in order of part and pass), 22 granules each
+            const int nhr = nch - per;
             __syncthreads();
-            if (tid < np * 22) {
+            if (tid < nhr * 22) {
                 const bool dead = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                const int pp = tid / 22, j = tid - pp * 22;
-                const u32x4 g = gran16_wait(Q.xp + ((size_t)h * 3 + pp) * 22 + j, 0, 1, tag, P.status, P.host_status, P.spin_limit, 16u, dead);
-                float *rec = chunk + (1 + pp) * 66 + 3 * j;
+                const int r = tid / 22, j = tid - r * 22, pp = r / per, ci = r - pp * per;
+                const u32x4 g = gran16_wait(Q.xp + (unsigned)(((h * 3 + pp) * 2 + ci) * 22 + j), 0, 1, tag, P.status, P.host_status, P.spin_limit, 16u, dead);
+                float *rec = chunk + (chend - ch0 + r) * 66 + 3 * j;
                 rec[0] = __uint_as_float(g.y); rec[1] = __uint_as_float(g.z); rec[2] = __uint_as_float(g.w);
             }
-            nrec += np;
+            nrec += nhr;
         }
         if (HELP) __syncthreads();   // (without helpers wavefront 0 reads back its own records)
-        if (!RUNNER) {               // a helper: its record (one pass) to the head's runner
-            if (tid < 22) gran16_store(Q.xp + ((size_t)hhead * 3 + (hpart - 1)) * 22 + tid, tag, chunk[3 * tid], chunk[3 * tid + 1], chunk[3 * tid + 2]);
+        if (!RUNNER) {               // (a helper has sent its records)
         } else if (wave == 0) {
             // merge the records as the WO prologue of the general plan does (load_x4<PRO_ATTN>); publish the head's output
             float outv;

@@ -130,19 +130,20 @@ def test_group_exchange_timeout_falls_back_to_the_general_plan(hip, orc, tmp_pat
 def test_big_attention_geometry_across_the_in_launch_passes(hip, orc, tmp_path):
     # The 7.9B tier's TRUE attention geometry (D 4096 / 64 heads / 16 kv heads: two projection tiles per workgroup, a wavefront
     # holding two column groups) with a context long enough for every in-launch attention pass: fused mode 4 (one GPU) serves
-    # positions < 1024 with 256-position passes (all four), fused mode 3 (tensor-parallel shards, tp 2 / 4 / 8) positions < 512.
-    # Round 4 only checked passes 2 and 3 at D 1024 / 16 heads.  Teacher-forced against the oracle at the pass edges
-    # (go/model.go:557-587), then a chained greedy run across the switch to the split-attention plan at 1024.
-    shape = synth.ModelShape("big_geo", 2, 4096, 64, 16, 1024, seq_len=1088, interm=2048)
+    # EVERY position of the context (2048 is the reference's own cap, go/model.go:145-148) with 256-position passes -- from the second
+    # pass on shared by the head's runner and three helper blocks, one or two passes each --, fused mode 3 (tensor-parallel shards,
+    # tp 2 / 4 / 8) positions < 512.  Round 4 only checked passes 2 and 3 at D 1024 / 16 heads.  Teacher-forced against the oracle
+    # at the pass edges (go/model.go:557-587), then a chained greedy run to the end of the context.
+    shape = synth.ModelShape("big_geo", 2, 4096, 64, 16, 1024, seq_len=2048, interm=2048)
     p = tmp_path / "m.gguf"
     synth.generate_gguf(str(p), shape, "q4_0", 97, mode="qrand")
     g = gguf.load_gguf(str(p))
-    check = (255, 256, 300, 511, 512, 700, 767, 768, 900, 1023, 1024)
-    prompt = synth.prompt_ids(974, shape.vocab, seed=41)
+    check = (255, 256, 300, 511, 512, 700, 767, 768, 900, 1023, 1024, 1279, 1280, 1400, 1535, 1536, 1791, 1792, 1900, 2046, 2047)
+    prompt = synth.prompt_ids(1998, shape.vocab, seed=41)
     ref = orc.OracleModel(g)
     orc.set_threads(min(32, os.cpu_count() or 1))
     seq, wants = list(prompt), {}
-    for pos in range(1056):                     # the prompt teacher-forced, then the oracle's own greedy ids
+    for pos in range(2048):                     # the prompt teacher-forced, then the oracle's own greedy ids
         lg = ref.forward(seq[pos], pos)
         if pos in check:
             wants[pos] = lg.copy()
@@ -150,7 +151,7 @@ def test_big_attention_geometry_across_the_in_launch_passes(hip, orc, tmp_path):
             seq.append(int(orc.argmax(lg)))
     orc.set_threads(1)
     ref.close()
-    greedy = seq[len(prompt):]                  # ids at positions 974 .. 1056
+    greedy = seq[len(prompt):]                  # the ids the steps at positions 1997 .. 2047 produce
 
     def held(lg, pos, what):
         d = float(np.abs(lg - wants[pos]).max()) / max(1.0, float(wants[pos].std()))
@@ -160,14 +161,14 @@ def test_big_attention_geometry_across_the_in_launch_passes(hip, orc, tmp_path):
     # one GPU: mode 4 (projection + attention + WO in one launch), passes 1 .. 3 and the first position of the general plan
     dev = hip.load_llama_model(g)
     info = dev.plan_info()
-    assert info["fused_mode"] == 4 and info["fused_max_pos"] == 1024, info
+    assert info["fused_mode"] == 4 and info["fused_max_pos"] == 2048, info
     worst = 0.0
-    for pos in range(1025):
+    for pos in range(2048):
         dev.forward(seq[pos], pos)
         if pos in check:
             worst = max(worst, held(dev.state.logits, pos, "mode 4"))
     assert dev.last_error() == ""
-    # chained greedy decode from the prompt: 16-step graphs of the fused plan, the seam at 1024, then the general plan
+    # chained greedy decode from the prompt to the end of the context: 16-step graphs of the fused plan, single steps at the end
     dev.reset()
     dev.prefill(prompt)
     first = int(np.argmax(dev.state.logits))
@@ -175,7 +176,7 @@ def test_big_attention_geometry_across_the_in_launch_passes(hip, orc, tmp_path):
     assert got == greedy
     assert dev.last_error() == ""
     dev.close()
-    print(f"\nbig geometry, mode 4: max|gpu-oracle| = {worst:.2e} over positions {check}; {len(greedy)} greedy ids across 1024 equal")
+    print(f"\nbig geometry, mode 4: max|gpu-oracle| = {worst:.2e} over positions {check}; {len(greedy)} greedy ids to the end of the context equal")
 
     # tensor-parallel shards: mode 3 below 512, the four-launch rank plan from there on
     for n in (2, 4, 8):
@@ -194,14 +195,15 @@ def test_big_attention_geometry_across_the_in_launch_passes(hip, orc, tmp_path):
 
 def test_attention_helpers_agree_with_the_general_plan_after_a_prompt(hip, tmp_path, monkeypatch):
     # the long-context plan of the wide tier on one GPU (from the second 256-position pass on, the passes below the last run on
-    # three helper blocks: nl_tp.h) against the five-launch plan of the same handle type, on a cache a 1000-token prompt wrote
-    # (the batched path): positions in every pass count and at the pass edges, and the same with the helpers switched off
-    shape = synth.ModelShape("big_geo_h", 2, 4096, 64, 16, 1024, seq_len=1088, interm=2048)
+    # three helper blocks, one or two passes each: nl_tp.h) against the five-launch plan of the same handle type, on a cache a
+    # 2040-token prompt wrote (the batched path): positions in every pass count 1 .. 8 and at the pass edges, and the same with the
+    # helpers switched off (a lone runner: positions below 1024)
+    shape = synth.ModelShape("big_geo_h", 2, 4096, 64, 16, 1024, seq_len=2048, interm=2048)
     p = tmp_path / "m.gguf"
     synth.generate_gguf(str(p), shape, "q4_0", 97, mode="qrand")
     g = gguf.load_gguf(str(p))
-    toks = synth.prompt_ids(1030, shape.vocab, seed=41)
-    positions = (100, 255, 256, 300, 511, 512, 700, 767, 768, 769, 900, 1023)
+    toks = synth.prompt_ids(2048, shape.vocab, seed=41)
+    positions = (100, 255, 256, 300, 511, 512, 700, 767, 768, 769, 900, 1023, 1024, 1279, 1280, 1535, 1536, 1791, 1792, 2000, 2047)
     res = {}
     for name, env in (("general", {"NL_FUSED_MAX_POS": "0"}), ("helpers", {}), ("alone", {"NL_ATTN_HELPERS": "0"})):
         for k in ("NL_FUSED_MAX_POS", "NL_ATTN_HELPERS"):
@@ -209,7 +211,7 @@ def test_attention_helpers_agree_with_the_general_plan_after_a_prompt(hip, tmp_p
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         dev = hip.load_llama_model(g)
-        dev.prefill(toks[:1024])
+        dev.prefill(toks[:2040])
         out = {}
         for pos in positions:
             dev.forward(toks[pos], pos)
@@ -219,7 +221,7 @@ def test_attention_helpers_agree_with_the_general_plan_after_a_prompt(hip, tmp_p
         dev.close()
     for pos in positions:
         ref = res["general"][pos]
-        for name in ("helpers", "alone"):
+        for name in ("helpers", "alone"):      # (beyond 1024 the lone runner's handle is on the five-launch plan itself)
             d = float(np.abs(res[name][pos] - ref).max()) / max(1.0, float(ref.std()))
             assert d <= 2e-5, (name, pos, d)
 

@@ -12,10 +12,10 @@ g = gguf.load_gguf(path)
 for limit in ("0", "4096"):
     os.environ["NL_FUSED_MAX_POS"] = limit
     dev = model.load_llama_model(g)
-    toks = synth.prompt_ids(1200, g.meta.vocab_size)
+    toks = synth.prompt_ids(1960, g.meta.vocab_size)
     dev.prefill(toks)
     out = []
-    for pos0 in (64, 300, 470, 600, 700, 800, 900, 980, 1150):     # (the in-launch attention of modes 3 / 4 ends at position 512)
+    for pos0 in (64, 300, 600, 980, 1150, 1500, 1900):     # (the in-launch attention of modes 3 / 4 ends at position 512)
         dev.decode_greedy(5, pos0, 32)
         t0 = time.perf_counter()
         dev.decode_greedy(5, pos0, 32)
