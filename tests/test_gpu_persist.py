@@ -336,6 +336,80 @@ def test_persistent_decode_long_context_shares_the_attention_passes(hip, orc, tm
     dev.close()
 
 
+def test_nano_true_shape_resident_session_and_chained_decode_across_every_pass_count(hip, orc, tmp_path, monkeypatch):
+    # BASELINE configs[1] at its OWN geometry (D 576 / 9 heads / I 1536, 13 layers, Q8_0): the helper assignment of the shared
+    # attention passes depends on the head count (nl_persist.h: `apart = 1 + j / H`), so the D 256 / 4-head test above does not
+    # cover it.  (a) 1040 teacher-forced tokens through nl_forward -- the resident session, what the patched Go loop of
+    # go/main.go:173-219 calls -- against the oracle at the edges of every pass count 1 .. 8 (go/model.go:557-587) and over the
+    # 1024-position limit; (b) chained nl_decode_greedy from position 900 over the limit = the oracle's ids; (c) the launch
+    # plans of the same file (NL_PERSIST=0) as the second witness of the chained ids.
+    shape = synth.TIERS["nano"]
+    p = tmp_path / "nano.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", mode="float")
+    g = gguf.load_gguf(str(p))
+    tokens = synth.prompt_ids(1040, shape.vocab, seed=31)
+    check = {0, 127, 128, 255, 256, 383, 384, 511, 512, 640, 767, 768, 895, 896, 1000, 1023, 1024, 1030}
+    ref = orc.OracleModel(g)
+    orc.set_threads(min(32, os.cpu_count() or 1))
+    want = {}
+    at900 = None
+    for pos, t in enumerate(tokens):
+        lg = ref.forward(t, pos)
+        if pos in check:
+            want[pos] = lg.copy()
+        if pos == 900:
+            at900 = lg.copy()
+    ref.close()
+    dev = hip.load_llama_model(g)
+    info = dev.persist_info()
+    assert info["ready"] and info["max_pos"] == 1024, info
+    worst, worst_pos = 0.0, -1
+    for pos, t in enumerate(tokens):
+        dev.forward(t, pos)
+        if pos in check:
+            d = _rel(dev.state.logits, want[pos])
+            if d > worst:
+                worst, worst_pos = d, pos
+    info = dev.persist_info()
+    print(f"\nnano true shape, resident session, positions 0 .. 1039 teacher-forced: max|gpu-oracle| = {worst:.2e} (position "
+          f"{worst_pos}) over {len(check)} positions; {info}")
+    assert worst <= LOGIT_TOL and dev.last_error() == ""
+    assert info["tokens"] == 1024 and info["launches"] <= 4, info      # (one resident launch unless the host paused past the idle limit)
+    # (b) chained from position 900 over the limit
+    ref = orc.OracleModel(g)
+    for pos, t in enumerate(tokens[:901]):
+        lg = ref.forward(t, pos)
+    assert np.array_equal(lg, at900)
+    top2 = []
+    ids, tok = [], int(orc.argmax(lg))
+    first = tok
+    for i in range(150):
+        lg = ref.forward(tok, 901 + i)
+        tok = int(orc.argmax(lg)); ids.append(tok)
+        s2 = np.partition(lg, -2)[-2:]
+        top2.append(float(s2[1] - s2[0]))
+    orc.set_threads(1)
+    ref.close()
+    dev.reset()
+    dev.prefill(tokens[:901])
+    f0 = int(np.argmax(dev.state.logits))
+    assert f0 == first
+    base = dev.persist_info()["tokens"]
+    got = dev.decode_greedy(f0, 901, 150)
+    assert dev.last_error() == ""
+    assert dev.persist_info()["tokens"] - base == 1024 - 901, dev.persist_info()      # positions 901 .. 1023 in the persistent launch
+    if got != ids:
+        k = next(i for i in range(150) if got[i] != ids[i])
+        assert top2[k] < 5e-5, (k, got[k], ids[k], top2[k])     # only a tie within summation-order noise may differ
+    # (c) the launch plans of the same file
+    monkeypatch.setenv("NL_PERSIST", "0")
+    plain = hip.load_llama_model(g)
+    assert not plain.persist_info()["ready"]
+    plain.prefill(tokens[:901])
+    assert plain.decode_greedy(f0, 901, 150) == got
+    dev.close(); plain.close()
+
+
 def test_shapes_outside_the_instantiations_keep_the_launch_plans(hip, tmp_path):
     # GQA, other widths, other weight types: not candidates (the launch plans serve them as before)
     for shape, wt in ((synth.ModelShape("pd_gqa", 2, 256, 4, 2, 512, seq_len=64, interm=512), "q8_0"),
