@@ -12,6 +12,7 @@
 #include "nl_kernels.h"
 #include "nl_qgemm.h"
 #include "nl_qgemm2.h"
+#include "nl_dgemm.h"
 #include "nl_batch.h"
 #include "nl_sample.h"
 #include "nl_p2p.h"
@@ -218,6 +219,7 @@ struct nl_engine {
         struct G { int n, nsplit; hipGraph_t graph; hipGraphExec_t exec; };
         std::vector<G> graphs;
     } sub[4];
+    std::vector<SubBatch::G> bt_graphs;   // step graphs of the whole-batch decode step (bt), same key
     hipEvent_t sub_fork = nullptr;
     int sub_batches = 1;          // NL_SUB_BATCHES: groups a decode batch is cut into (1 = the whole batch as one step: measured fastest, profiles/r04_subbatch_groups.log)
 
@@ -1674,6 +1676,14 @@ hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_bu
                        part_buf, ks, count, P.resid, P.out, P.bias, P.ldo);
     return hipGetLastError();
 }
+
+// ---- short token runs on dgemm_kernel (nl_dgemm.h): Q4_0, whole 256-column groups, 32-row producer blocks ----
+bool dgemm_mat_ok(const PackedMat &m, bool rows32) {
+    return m.wtype == WT_Q4_0 && m.cols % 256 == 0 && m.cols > 0 && (!rows32 || m.rows % 32 == 0) && m.ntiles * TR == m.rows;
+}
+hipError_t launch_dgemm_rope(const QGemmParams &P, hipStream_t st) { return dg_launch_rope(P, st); }
+hipError_t launch_dgemm_swiglu(const QGemmParams &P, hipStream_t st) { return dg_launch_swiglu(P, st); }
+hipError_t launch_dgemm_plain(const QGemmParams &P, hipStream_t st) { return dg_launch_plain(P, st); }
 }  // namespace
 
 namespace {
@@ -1722,7 +1732,7 @@ int batch_alloc(nl_engine *e, nl_engine::Batch &b, int cap_limit = 2048) {
         HIPCK(e, dalloc(&raw, nx2 * 4, &e->bytes_state));
         b.xfrag2 = reinterpret_cast<uint4 *>(raw);
     }
-    HIPCK(e, dalloc(&b.ssq, n * (size_t)((c.dim + 63) / 64), &e->bytes_state));
+    HIPCK(e, dalloc(&b.ssq, n * (size_t)((c.dim + 31) / 32), &e->bytes_state));   // (one partial per 64 rows on qgemm2_kernel, per 32 on dgemm_kernel)
     HIPCK(e, dalloc(&b.nscale, 2 * n, &e->bytes_state));
     b.kpart_cap = (size_t)16 * QG_TOK * std::max<size_t>(std::max<size_t>(R, c.dim), e->Is);
     HIPCK(e, dalloc(&b.kpart, b.kpart_cap, &e->bytes_state));
@@ -1740,6 +1750,22 @@ int batch_alloc(nl_engine *e, nl_engine::Batch &b, int cap_limit = 2048) {
     HIPCK(e, hipHostMalloc((void **)&b.h_meta, 5 * n * sizeof(int), hipHostMallocDefault));
     b.ready = true;
     return NL_OK;
+}
+
+// a multi-token step of <= NL_DGEMM_MAX_TOKENS tokens whose layer matrices are all Q4_0 with whole 256-column groups runs its
+// five GEMM-shaped launches per layer on dgemm_kernel (nl_dgemm.h) with the RMSNorms folded around them
+bool dgemm_step_ok(const nl_engine *e, int n) {
+    const char *k = getenv("NL_DGEMM");                 // knob (tests, tools; read per step): 0 keeps the split-K launches
+    if (k && atoi(k) == 0) return false;
+    const char *mk = getenv("NL_DGEMM_MAX_TOKENS");
+    const int max_n = mk ? atoi(mk) : 64;
+    const nl_config &c = e->cfg;
+    if (n > max_n || c.qk_norm || c.dim % 32 || c.n_layers <= 0) return false;
+    for (const auto &L : e->layers)
+        if (!dgemm_mat_ok(L.qkv, false) || !dgemm_mat_ok(L.wo, true) || !dgemm_mat_ok(L.gate, true) || !dgemm_mat_ok(L.up, true) ||
+            !dgemm_mat_ok(L.down, true) || L.gate.rows != L.up.rows || L.wo.rows != c.dim || L.down.rows != c.dim)
+            return false;
+    return c.dim / 32 <= DG_SSQ_MAX_NRB;       // (the consumer's LDS area for the partial sums of squares)
 }
 
 // GEMM of the multi-token step: input = the fragment store the producing kernel just filled; output = `out`
@@ -1843,6 +1869,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
     // reads xfrag2, everything else xfrag.
     const char *fk = getenv("NL_FOLD_NORM");   // knob (tests, tools; read per step so a test can flip it): 0 keeps the bnorm launches
     const bool fold_knob = !(fk && atoi(fk) == 0);
+    const bool dg = dgemm_step_ok(e, n);      // short token runs (decode batches): nl_dgemm.h, always folded
     bool fold = fold_knob && !c.qk_norm && D % 64 == 0 && c.n_layers > 0;
     for (int l = 0; l < c.n_layers && fold; l++) {
         const nl_engine::Layer &L = e->layers[l];
@@ -1851,6 +1878,8 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
                qgemm2_ok(L.qkv.wtype, n) && qgemm_rope_fits(L.qkv.ntiles, n) &&
                L.up.wtype == L.gate.wtype && qgemm2_ok(L.gate.wtype, n) && qgemm_swiglu_fits(L.gate.ntiles, n);
     }
+    if (dg) fold = true;
+    const int nrb = dg ? D / 32 : D / 64;      // partial sums of squares per token
     // NL_PREFILL_PRECISION=fp16x1 (read per step: tests and bench.py flip it): the long-prompt GEMMs (qgemm2_kernel) and the
     // prompt attention multiply only the fp16 hi half of every activation / probability -- half / a third of the matrix work,
     // activations rounded to 11 bits.  The default x = hi + lo keeps float32-grade results (logit tolerance 1e-4).
@@ -1860,7 +1889,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
     // (pre-scales: the attention norm's consumer undoes sA and leaves sB for the WO producer; the feed-forward norm's consumer
     //  undoes sB and leaves sA for the down producer; layer 0's unfolded attention norm leaves the first sB)
     float *const sA = b.nscale, *const sB = b.nscale + b.cap;
-    const QGemmParams::NormIn nin_attn{b.ssq, D / 64, D, c.rms_eps, sA, sB}, nin_ffn{b.ssq, D / 64, D, c.rms_eps, sB, sA},
+    const QGemmParams::NormIn nin_attn{b.ssq, nrb, D, c.rms_eps, sA, sB}, nin_ffn{b.ssq, nrb, D, c.rms_eps, sB, sA},
                               nin_off{nullptr, 0, 0, 0.f, nullptr, nullptr};
     auto norm = [&](const float *w, const PackedMat &next, int item0, int cnt, float *scale_out = nullptr) {
         BNormParams P{b.x, pend, w, c.rms_eps, D, item0, b.xfrag, ((cnt + 63) / 64) * 4, next.wtype == WT_Q4_0 ? 1 : 0, scale_out};
@@ -1880,7 +1909,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
         bool rope_in_attn = false;
         const bool folded_in = fold && l > 0;      // the previous layer's down GEMM wrote this layer's Q|K|V input
         if (!folded_in) LCK(norm(L.attn_norm, L.qkv, 0, n, fold ? sB : nullptr));
-        if (!c.qk_norm && qgemm_rope_fits(L.qkv.ntiles, n)) {
+        if (dg || (!c.qk_norm && qgemm_rope_fits(L.qkv.ntiles, n))) {
             // Q|K|V, RoPE, biases and the KV store in ONE launch (QK-norm needs whole heads: unfused path)
             QGemmParams P{};
             const PackedMat &m = L.qkv;
@@ -1889,7 +1918,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
             P.n_tokens = n; P.ldo = (int)R; P.x1 = x1_gemm;
             P.rope = QGemmParams::Rope{b.pos, b.stream, e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride,
                                        L.bq, L.bk, L.bv, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate};
-            LCK(launch_qgemm_rope(m.wtype, P, st));
+            LCK(dg ? launch_dgemm_rope(P, st) : launch_qgemm_rope(m.wtype, P, st));
         } else {
             LCK(qg(e, b, L.qkv, n, b.qkv, R, nullptr, st, &qkv_out, b.kpart, nullptr, nullptr, nullptr, x1_gemm));
             // decode batches (every token its own stream: no token of the step attends over another's K / V row), no QK-norm:
@@ -1958,7 +1987,19 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
             }
             LCK(hipGetLastError());
         }
-        if (fold) {
+        // dgemm_kernel's producer GEMM: x += W . in (+ bias), the next GEMM's fragments and sums of squares from its epilogue
+        auto dg_plain = [&](const PackedMat &m, const uint4 *in, const float *bias, const QGemmParams::NormOut *nout) {
+            QGemmParams P{};
+            P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
+            P.xf = in; P.n_tokens = n; P.out = b.x; P.ldo = D; P.resid = b.x; P.bias = bias;
+            if (nout) P.nrm_out = *nout;
+            pend = GemmOut{b.x, nullptr, 1, (long long)n * D, nullptr};
+            return launch_dgemm_plain(P, st);
+        };
+        if (fold && dg) {
+            const QGemmParams::NormOut nout{L.ffn_norm, b.xfrag2, b.ssq, sB};
+            LCK(dg_plain(L.wo, b.xfrag, L.bo, &nout));
+        } else if (fold) {
             const QGemmParams::NormOut nout{L.ffn_norm, b.xfrag2, b.ssq, sB};
             LCK(qg(e, b, L.wo, n, b.x, D, b.x, st, &pend, b.kpart, L.bo, nullptr, &nout, x1_gemm));
         } else {
@@ -1968,7 +2009,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
         if (L.up.wtype != L.gate.wtype)   // (a mixed-type file: the fragment k-slot order differs per type)
             return e->fail(NL_ERR_UNSUPPORTED, "gate and up projections of different quantisation types");
         const uint4 *down_in = b.xfrag;
-        if (qgemm_swiglu_fits(L.gate.ntiles, n)) {
+        if (dg || qgemm_swiglu_fits(L.gate.ntiles, n)) {
             // gate, up and SiLU(gate) * up in ONE launch; h leaves as fragments in the second fragment store
             // (the first is still being read by other workgroups of this launch)
             QGemmParams P{};
@@ -1978,7 +2019,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
             P.n_tokens = n; P.ldo = e->Is; P.x1 = x1_gemm;
             P.q1 = L.up.q; P.s1 = L.up.s;
             P.xf_out = fold ? b.xfrag : b.xfrag2; P.out_q4 = L.down.wtype == WT_Q4_0 ? 1 : 0;
-            LCK(launch_qgemm_swiglu(m.wtype, P, st));
+            LCK(dg ? launch_dgemm_swiglu(P, st) : launch_qgemm_swiglu(m.wtype, P, st));
             down_in = P.xf_out;
         } else {
             GemmOut gate, up;
@@ -1998,7 +2039,10 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
             hipLaunchKernelGGL(bswiglu_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 4096)), dim3(256), 0, st, P);
             LCK(hipGetLastError());
         }
-        if (fold && l + 1 < c.n_layers) {
+        if (dg) {
+            const QGemmParams::NormOut nout{l + 1 < c.n_layers ? e->layers[l + 1].attn_norm : nullptr, b.xfrag2, b.ssq, sA};
+            LCK(dg_plain(L.down, down_in, nullptr, l + 1 < c.n_layers ? &nout : nullptr));
+        } else if (fold && l + 1 < c.n_layers) {
             const nl_engine::Layer &Ln = e->layers[l + 1];
             const QGemmParams::NormOut nout{Ln.attn_norm, b.xfrag2, b.ssq, sA};
             LCK(qg(e, b, L.down, n, b.x, D, b.x, st, &pend, b.kpart, nullptr, down_in, &nout, x1_gemm));
@@ -2822,6 +2866,8 @@ int nl_set_gamma(nl_handle e, const int32_t *indices, int n, const void *values,
     float *old_val = e->gamma_val;
     e->gamma_row = new_row;
     e->gamma_val = new_val;
+    for (auto &G : e->bt_graphs) { (void)hipGraphExecDestroy(G.exec); (void)hipGraphDestroy(G.graph); }
+    e->bt_graphs.clear();
     for (auto &sb : e->sub) {   // the sub-batch step graphs hold the old tables too
         for (auto &G : sb.graphs) { (void)hipGraphExecDestroy(G.exec); (void)hipGraphDestroy(G.graph); }
         sb.graphs.clear();
@@ -2872,6 +2918,7 @@ int nl_destroy(nl_handle e) {
         if (b.h_meta) hipHostFree(b.h_meta);
     };
     batch_free(e->bt);
+    for (auto &G : e->bt_graphs) { (void)hipGraphExecDestroy(G.exec); (void)hipGraphDestroy(G.graph); }
     for (auto &sb : e->sub) {
         for (auto &G : sb.graphs) { (void)hipGraphExecDestroy(G.exec); (void)hipGraphDestroy(G.graph); }
         batch_free(sb.bt);
@@ -3284,7 +3331,7 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
     if ((rc = note_positions(e, stream, pos0, n))) return rc;
     if (n >= NL_BATCH_MIN && batch_supported(e)) {
         // multi-token path: 64-token tiles on the matrix cores; causality comes from each token's own pos
-        if ((rc = batch_alloc(e, e->bt))) return rc;
+        { std::lock_guard<std::mutex> setup(g_setup_mu); if ((rc = batch_alloc(e, e->bt))) return rc; }
         nl_engine::Batch &b = e->bt;
         for (int t0 = 0; t0 < n; t0 += b.cap) {
             const int m = std::min(b.cap, n - t0);
@@ -3352,20 +3399,26 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
         // arithmetic per stream does not depend on the group it steps in: results are bitwise those of the one-step form.
         // (off unless NL_SUB_BATCHES > 1 -- measured slower, profiles/r04_subbatch_groups.log: the default is the chunked loop below)
         const int groups = e->sub_batches > 1 ? std::max((n + QG_TOK - 1) / QG_TOK, std::min(e->sub_batches, n / 16)) : 1;
+        // (a step's launch list and kernel arguments also depend on the test knobs batched_step reads per step: all of them are
+        //  part of the key of a cached step graph)
+        auto batch_knob_sig = [] {
+            const char *rk = getenv("NL_ROPE_IN_ATTN"), *fk = getenv("NL_FOLD_NORM"), *pk = getenv("NL_PREFILL_PRECISION"), *kk = getenv("NL_KV16_MIN_TOKENS"),
+                       *dk = getenv("NL_DGEMM"), *dm = getenv("NL_DGEMM_MAX_TOKENS");
+            return (rk ? atoi(rk) + 1 : 0) + 3 * (fk ? atoi(fk) + 1 : 0) + 9 * (pk && !strcmp(pk, "fp16x1") ? 1 : 0) +
+                   18 * (dk ? atoi(dk) + 1 : 0) + 54 * (dm ? (atoi(dm) & 0xff) + 1 : 0) + 13878 * (kk ? (atoi(kk) & 0xfff) + 1 : 0);
+        };
         if (groups > 1 && groups <= 4) {
             if (!e->sub_fork) HIPCK(e, hipEventCreateWithFlags(&e->sub_fork, hipEventDisableTiming));
             HIPCK(e, hipEventRecord(e->sub_fork, e->stream));      // (the position bookkeeping above may have queued row clears)
             const int per = (n + groups - 1) / groups;
             // (a step's launch list and kernel arguments also depend on the test knobs batched_step reads per step: all of them
             //  are part of the key of a cached step graph)
-            const char *rk = getenv("NL_ROPE_IN_ATTN"), *fk = getenv("NL_FOLD_NORM"), *pk = getenv("NL_PREFILL_PRECISION"), *kk = getenv("NL_KV16_MIN_TOKENS");
-            const int knob_sig = (rk ? atoi(rk) + 1 : 0) + 3 * (fk ? atoi(fk) + 1 : 0) + 9 * (pk && !strcmp(pk, "fp16x1") ? 1 : 0) +
-                                 18 * (kk ? (atoi(kk) & 0xfff) + 1 : 0);
+            const int knob_sig = batch_knob_sig();
             for (int g = 0, t0 = 0; g < groups; g++, t0 += per) {
                 const int m = std::min(per, n - t0);
                 if (m <= 0) break;
                 nl_engine::SubBatch &sb = e->sub[g];
-                if ((rc = batch_alloc(e, sb.bt, QG_TOK))) return rc;
+                { std::lock_guard<std::mutex> setup(g_setup_mu); if ((rc = batch_alloc(e, sb.bt, QG_TOK))) return rc; }
                 if (!sb.st) {
                     HIPCK(e, hipStreamCreateWithFlags(&sb.st, hipStreamNonBlocking));
                     HIPCK(e, hipEventCreateWithFlags(&sb.done, hipEventDisableTiming));
@@ -3386,6 +3439,7 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
                 if (!exec && e->use_graph) {
                     // the step reads its tokens / positions / streams from the pinned block behind h_meta (a copy node of the
                     // graph), so one graph serves every step of m streams with as many position splits
+                    std::lock_guard<std::mutex> setup(g_setup_mu);      // (a capture must not overlap another thread's allocations)
                     hipGraph_t gr = nullptr;
                     if (hipStreamBeginCapture(sb.st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                         const int rc2 = batched_step(e, b, sb.st, m, 1);
@@ -3421,7 +3475,7 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
             HIPCK(e, hipStreamSynchronize(e->stream));
             return NL_OK;
         }
-        if ((rc = batch_alloc(e, e->bt))) return rc;
+        { std::lock_guard<std::mutex> setup(g_setup_mu); if ((rc = batch_alloc(e, e->bt))) return rc; }
         nl_engine::Batch &b = e->bt;
         for (int t0 = 0; t0 < n; t0 += b.lm_cap) {
             const int m = std::min(b.lm_cap, n - t0);
@@ -3431,7 +3485,34 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
                 b.h_meta[b.cap + i] = pos[t0 + i];
                 b.h_meta[2 * b.cap + i] = streams[t0 + i];
             }
-            if ((rc = batched_step(e, b, e->stream, m, 1))) return rc;
+            // The step as one hipGraph, cached by (streams, position splits, knobs): it reads its tokens / positions / streams from
+            // the pinned block behind h_meta (a copy node of the graph), so one graph serves every step of that geometry.  The 150+
+            // launches of a step are 3 us each when a host thread queues them one by one -- more than the kernels of a decode batch.
+            hipGraphExec_t exec = nullptr;
+            if (e->use_graph) {
+                int nsplit = 1;
+                for (int i = 0; i < m; i++) nsplit = std::max(nsplit, pos[t0 + i] / ATT_CH + 1);
+                const int key_split = nsplit * 131072 + batch_knob_sig() % 131072;
+                for (auto &G : e->bt_graphs)
+                    if (G.n == m && G.nsplit == key_split) exec = G.exec;
+                if (!exec) {
+                    std::lock_guard<std::mutex> setup(g_setup_mu);      // (a capture must not overlap another thread's allocations)
+                    hipGraph_t gr = nullptr;
+                    if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                        const int rc2 = batched_step(e, b, e->stream, m, 1);
+                        const hipError_t ce = hipStreamEndCapture(e->stream, &gr);
+                        if (!rc2 && ce == hipSuccess && gr && hipGraphInstantiate(&exec, gr, nullptr, nullptr, 0) == hipSuccess) {
+                            e->bt_graphs.push_back({m, key_split, gr, exec});
+                        } else {
+                            if (gr) (void)hipGraphDestroy(gr);
+                            exec = nullptr;
+                        }
+                    }
+                    (void)hipGetLastError();
+                }
+            }
+            if (exec) HIPCK(e, hipGraphLaunch(exec, e->stream));
+            else if ((rc = batched_step(e, b, e->stream, m, 1))) return rc;
             if (logits_out)
                 HIPCK(e, hipMemcpyAsync(logits_out + (size_t)t0 * e->cfg.vocab, b.logits, (size_t)m * e->cfg.vocab * 4,
                                         hipMemcpyDeviceToHost, e->stream));
