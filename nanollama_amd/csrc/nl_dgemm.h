@@ -1,50 +1,57 @@
 // nl_dgemm.h -- the multi-token GEMM for SHORT token runs (decode batches of <= 64 streams, go/serve.go's concurrent requests
-// stepped together; Q4_0): one launch per projection, no split-K, no reduce launch, every epilogue of the layer fused.
+// stepped together; Q4_0): one launch per projection, no split-K launch, no reduce launch, every epilogue of the layer fused.
 //
 // What bounds a GEMM of 64 tokens on this chip is neither HBM (a goldie layer is 14 MB: 2 us) nor the matrix cores, but
-// what ONE compute unit can ingest: 64 B per clock from L2.  The activation matrix of 64 tokens is 4 bytes per element
-// (fp16 hi + lo, nl_qgemm.h) -- 393 KB for K = 1536 -- so a workgroup that sees all 64 tokens and all of K needs 2.6 us just
-// to read its B operand; qgemm_kernel therefore split K over workgroups (<= 6 chunks each), wrote partial slabs and left the
-// sum, the norm, the rotation and SiLU to four more launches per layer: 8 launches of 5-9 us.
-// Here the TOKEN TILE is what a workgroup keeps: 16 tokens x all of K (98 KB for K = 1536) against a few 16-row weight
-// tiles, so a result element is finished inside one workgroup and the qgemm2 epilogues (RoPE + KV store, SiLU(gate) * up as
-// the next GEMM's fragments, residual + the folded RMSNorm of the next GEMM) apply as they are.  The four workgroups that
-// share a row group (one per token tile) are placed on the same XCD (block b runs on XCD b % 8, observed -- for speed only), so
-// a weight byte crosses the fabric once and is an L2 hit for the other three.
+// what ONE compute unit can ingest (64 B per clock from L2) and issue.  The activation matrix of 64 tokens is 4 bytes per
+// element (fp16 hi + lo, nl_qgemm.h) -- 393 KB for K = 1536 -- so a workgroup that sees all 64 tokens and all of K needs 2.6 us
+// just to read its B operand; qgemm_kernel therefore split K over workgroups (<= 6 chunks each), wrote partial slabs and left
+// the sum, the norm, the rotation and SiLU to four more launches per layer: 8 launches of 5-9 us.
+// Here the TOKEN TILE is what a workgroup keeps: 16 tokens x all of K (98 KB for K = 1536) against T 16-row weight tiles, so a
+// result element is finished inside one workgroup and the qgemm2 epilogues (RoPE + KV store, SiLU(gate) * up as the next
+// GEMM's fragments, residual + the folded RMSNorm of the next GEMM) apply as they are.  The four workgroups that share a row
+// group (one per token tile) sit on the same XCD (block b runs on XCD b % 8, observed -- for speed only), so a weight byte
+// crosses the fabric once and is an L2 hit for the other three.
 //
-//   * Everything a workgroup multiplies arrives by LDS-DMA (global_load_lds_dwordx4, 1 KB per wavefront instruction) into a
-//     ring of chunk slots, a chunk = one 256-column group of the tile layout = 8 quant blocks: 16 KB of activation fragments,
-//     2 KB of nibbles + 256 B of fp16 scales per weight tile.  The ring is as deep as the 160 KB of LDS allow (4-7 slots:
-//     3-6 chunks in flight, more than one HBM round trip of ingest), every wavefront issues the same number of pieces per
-//     chunk, so "chunk c has landed" is ONE s_waitcnt vmcnt(immediate) + s_barrier; no register staging, no weight registers.
-//   * The nibble chunks of a (tile, group) are stored XOR-swizzled (the DMA picks its source per lane), so the A-operand
-//     read -- dword lq of the 16-byte chunk of (row li, block) -- is 2-way instead of 8-way bank-conflicted.
-//   * wavefront = RT row tiles x one token tile x 1/KS of every chunk's blocks; the KS partial accumulators meet in LDS in a
-//     fixed order.  Per (block, tile): 1 ds_read_b32, 9 VALU (nibbles -> fp16), 2 MFMA (x = hi + lo), 4 cvt + 4 FMA ("* d").
+//   * K is split over the workgroup's wavefronts by quant block: wavefront w owns block w % 8 of every 8-block group it visits
+//     and multiplies it against ALL T row tiles, so an activation fragment is read by exactly one wavefront and NOTHING is
+//     shared inside the K loop: no barrier.  (The first form shared a chunk ring between all wavefronts behind one barrier per
+//     chunk: with 1-2 (block, tile) products per wavefront between barriers it ran at 140 SIMD cycles per product.)
+//   * Every wavefront is its own LDS-DMA pipeline (global_load_lds_dwordx4, 1 KB per instruction, the source picked per
+//     lane): per step 2 KB of activation fragments + T x (256 B of nibbles + 64 B of fp16 scale words), into a private ring of
+//     DEPTH slots; "my step has landed" is one s_waitcnt vmcnt(immediate) on the wavefront's own counter.
+//   * The nibbles of (block, tile) land as [row][16 B]: the B-operand read -- dword lq of row li -- is conflict-free.  The
+//     MFMA runs as D[token][row] = x . W^T, so a lane needs ONE scale per (block, tile): 1 ds_read_b32, 4 v_fma_mix.
+//     Per (block, tile): 9 VALU (nibbles -> fp16), 2 MFMA (x = hi + lo), 4 FMA ("* d"), 2 + 2/T LDS reads.
+//   * The NWV partial accumulators of a tile meet in LDS (one barrier per launch) in wavefront order and are read back
+//     transposed, as D[row][token] = the layout qgemm2_kernel's epilogues are written for.
 // Arithmetic per output = qgemm_kernel / qgemm2_kernel (exact integer quants in fp16, f32 block sums, * d in f32); the
-// summation order over blocks differs with KS > 1 (block-interleaved partial sums), inside the stated tolerances.
+// summation order over blocks is block-interleaved (NWV partial sums), inside the stated tolerances; deterministic.
+// hipcc waits vmcnt(0) for a register load once LDS-DMA pieces are in flight behind it (it treats the two as unordered): no
+// register load is consumed inside the K loop -- epilogue operands are requested first and pinned behind the loop.
 // Reference: go/quant.go:45-94 (MatMulQ4_0), go/model.go:513-613 (the layer), per stream.
 #pragma once
 #include "nl_qgemm2.h"
 
 namespace nl {
 
-constexpr int DG_KB = 8;                        // quant blocks per chunk (one KL-pair group of the tile layout)
-constexpr int DG_ACT_U4 = DG_KB * 2 * QG_FRAG;  // uint4 of activation fragments per chunk: [block][hi/lo][lane]
 constexpr int DG_LDS_BYTES = 160 * 1024;
-
 constexpr int DG_SSQ_MAX_NRB = 64;              // partial sums of squares per token the consumer side takes (dim <= 2048)
 constexpr int DG_SSQ_BYTES = 16 * DG_SSQ_MAX_NRB * 8;
-template <int T> struct DgLds {                 // T = (weight tile, matrix) entries of a workgroup
-    static constexpr int WQ_U4 = T * 128, WS_PIECES = (T + 3) / 4, WS_U4 = WS_PIECES * 64;
-    static constexpr int SLOT_U4 = DG_ACT_U4 + WQ_U4 + WS_U4;
-    static constexpr int NSLOT_FIT = (DG_LDS_BYTES - DG_SSQ_BYTES - 1024) / (SLOT_U4 * 16);
-    static constexpr int NSLOT = NSLOT_FIT > 8 ? 8 : NSLOT_FIT;
+
+template <int T, int NWV, bool SSQ> struct DgLds {
+    static constexpr int NP = (16 * T + 63) / 64;               // 64-lane pieces that cover the T x 16 rows of a block
+    // one step of one wavefront: x hi | x lo | nibbles [T][16 rows][16 B] | scales [T][16 rows] fp16 pair words
+    static constexpr int REG_U4 = 128 + 16 * T + 4 * T;
+    static constexpr int SSQ_U4 = SSQ ? DG_SSQ_BYTES / 16 : 0;
+    static constexpr int FIT = (DG_LDS_BYTES - SSQ_U4 * 16 - 512) / (NWV * REG_U4 * 16);
+    static constexpr int DEPTH = FIT > 6 ? 6 : FIT;
 };
 
 #ifdef DG_STAMPS
 __device__ long long g_dg_stamps[64];
-#define DG_STAMP(i) do { if (blockIdx.x == 9 && threadIdx.x == 0 && (i) < 64) g_dg_stamps[(i)] = clock64(); } while (0)
+__device__ long long g_dg_census[2 * 2048];      // wall clock (100 MHz) at entry / exit of wavefront 0 of every workgroup
+#define DG_STAMP(i) do { if (blockIdx.x == 9 && threadIdx.x == 0 && (i) < 64) g_dg_stamps[(i)] = clock64(); \
+    if (((i) == 0 || (i) == 40) && threadIdx.x == 0 && blockIdx.x < 2048) g_dg_census[2 * blockIdx.x + ((i) ? 1 : 0)] = wall_clock64(); } while (0)
 #else
 #define DG_STAMP(i) do { } while (0)
 #endif
@@ -52,135 +59,121 @@ __device__ long long g_dg_stamps[64];
 // vmcnt immediate of s_waitcnt on gfx9 (vmcnt[3:0] | expcnt[6:4] = 7 | lgkmcnt[11:8] = 15 | vmcnt[5:4] in [15:14])
 #define DG_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0f70 | ((n) & 15) | (((n) >> 4) << 14))
 
-// RT: row tiles per wavefront (SWIGLU: 4 = two gate tiles + the same two tiles of up); NW: wavefronts over rows; KS: wavefronts
-// over the blocks of a chunk.  grid.x = ceil(row groups / 8) * 8 * token tiles, see dg_block_of().
-template <int RT, int NW, int KS, int EPI>
-__global__ void __launch_bounds__(NW * KS * 64, (NW * KS + 3) / 4) dgemm_kernel(QGemmParams P) {
-    constexpr int NWV = NW * KS, T = NW * RT, BPW = DG_KB / KS;
-    typedef DgLds<T> L;
-    constexpr int NSLOT = L::NSLOT, PD = NSLOT - 1;
-    // DMA pieces of a chunk: 16 of activations, 2 T of nibbles, WS_PIECES of scales.  Every wavefront issues the same number per
-    // chunk (so one vmcnt immediate serves all); with more wavefronts than pieces of a kind, several fetch the same piece
-    constexpr int ACT_PPW = 16 / NWV > 0 ? 16 / NWV : 1, WQ_PPW = 2 * T / NWV > 0 ? 2 * T / NWV : 1, PPW = ACT_PPW + WQ_PPW + 1;
-    static_assert(NWV <= 16 && (16 % NWV == 0) && ((2 * T) % NWV == 0 || NWV % (2 * T) == 0), "pieces divide evenly over the wavefronts");
-    static_assert((PD - 1) * PPW <= 63, "vmcnt is six bits");
-    static_assert(EPI != QG_EPI_SWIGLU || RT == 4, "gate tile pair + up tile pair per wavefront");
-    static_assert(EPI != QG_EPI_PLAIN || RT == 2, "a producer wavefront owns one 32-row block of the next GEMM's K");
-    static_assert(NWV * RT * 64 <= NSLOT * L::SLOT_U4, "the K-split partials fit the ring");
-    __shared__ __attribute__((aligned(16))) uint4 lds_all[DG_SSQ_BYTES / 16 + NSLOT * L::SLOT_U4];
-    uint4 *const lds = lds_all + DG_SSQ_BYTES / 16;
+// T: row tiles of a workgroup (SWIGLU: T / 2 gate tiles + the same T / 2 tiles of up); NWV: wavefronts (8 or 16);
+// grid.x = ceil(row groups / 8) * 8 * token tiles (dg_grid).  cols % 256 == 0.
+template <int T, int NWV, int EPI>
+__global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P) {
+    typedef DgLds<T, NWV, EPI != QG_EPI_PLAIN> L;
+    constexpr int DEPTH = L::DEPTH, REG_U4 = L::REG_U4, SSQ_U4 = L::SSQ_U4;
+    constexpr int NP = L::NP, PPS = 2 + 2 * NP;                  // DMA pieces per step: 2 of activations, NP of nibbles (16 B per lane), NP of scales (4 B per lane)
+    constexpr bool FUSED = EPI == QG_EPI_SWIGLU;
+    constexpr int EG = EPI == QG_EPI_ROPE ? 1 : FUSED ? 4 : 2;   // tiles per epilogue group (one wavefront each)
+    constexpr int NEG = T / EG;
+    constexpr int TPG = FUSED ? T / 2 : T;                       // distinct row tiles of the workgroup per matrix
+    static_assert(NWV == 8 || NWV == 16, "a wavefront owns block w % 8 of the groups it visits");
+    static_assert(DEPTH >= 2 && (DEPTH - 1) * PPS <= 63, "ring depth / vmcnt is six bits");
+    static_assert(T % EG == 0 && NEG <= NWV, "epilogue groups");
+    static_assert(T * 64 <= DEPTH * REG_U4, "a wavefront's partial accumulators fit its ring");
+    __shared__ __attribute__((aligned(16))) uint4 lds_all[SSQ_U4 + NWV * DEPTH * REG_U4];
     DG_STAMP(0);
 
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 15, lq = lane >> 4;
-    const int wr = wv % NW, wk = wv / NW;
+    uint4 *const ring = lds_all + SSQ_U4 + wv * (DEPTH * REG_U4);      // this wavefront's slots
     // block -> (row group, token tile): the token tiles of one row group sit on the same XCD (b % 8), next to each other in
     // dispatch order
     const int ntt = (P.n_tokens + 15) >> 4;
     const int b = blockIdx.x, rg = (b & 7) + 8 * (b / (8 * ntt)), tt = (b >> 3) % ntt;
-    constexpr bool FUSED = EPI == QG_EPI_SWIGLU;
-    constexpr int TPW = FUSED ? 2 : RT;                      // distinct row tiles of a wavefront
-    if (rg * NW * TPW >= P.ntiles) return;                   // (padding of the row groups to a multiple of 8: the whole workgroup)
-    const int nchunks = P.cols / (32 * DG_KB);
-    const int tile0 = (rg * NW + wr) * TPW;                  // this wavefront's first row tile (FUSED: of gate and of up)
+    if (rg * TPG >= P.ntiles) return;                            // (padding of the row groups to a multiple of 8: the whole workgroup)
+    const int tile_base = rg * TPG;                              // first row tile of the workgroup (FUSED: of gate and of up)
+    const int nblocks = P.cols >> 5;
+    // this wavefront's blocks: g = wv, wv + NWV, ... (block g % 8 = wv % 8 of group g / 8)
+    const int nsteps = wv < nblocks ? (nblocks - wv + NWV - 1) / NWV : 0;
+    const int blk0 = wv < nblocks ? wv : 0, k0 = (blk0 >> 1) & 3, cc = blk0 & 1;      // pair of the group, block of the pair
 
-    // ---- DMA pieces of this wavefront: per-lane source pointers, advanced chunk by chunk ----
-    const char *asrc[ACT_PPW];
+    // ---- DMA pieces of this wavefront: per-lane source pointers, advanced step by step ----
     const unsigned xblock = (unsigned)P.nt16 * (2 * QG_FRAG * 16);    // bytes of one block's fragments
-#pragma unroll
-    for (int i = 0; i < ACT_PPW; i++) {
-        const int q = (i * NWV + wv) % 16, bi = q >> 1, part = q & 1;
-        asrc[i] = reinterpret_cast<const char *>(P.xf) + ((size_t)bi * xblock + ((size_t)(tt * 2 + part) * QG_FRAG + lane) * 16);
-    }
+    const char *xsrc = reinterpret_cast<const char *>(P.xf) + ((size_t)blk0 * xblock + ((size_t)(tt * 2) * QG_FRAG + lane) * 16);
     auto tile_of = [&](int ti, int &mat) {          // entry ti of the workgroup's weight area -> (row tile, matrix)
-        const int w = ti / RT, rt = ti % RT;
-        mat = FUSED ? rt >> 1 : 0;
-        return min((rg * NW + w) * TPW + (FUSED ? rt & 1 : rt), P.ntiles - 1);
+        mat = FUSED ? ti / (T / 2) : 0;
+        return min(tile_base + (FUSED ? ti % (T / 2) : ti), P.ntiles - 1);
     };
-    const char *wsrc[WQ_PPW];
+    const char *wsrc[NP], *ssrc[NP];
 #pragma unroll
-    for (int i = 0; i < WQ_PPW; i++) {
-        const int q = (i * NWV + wv) % (2 * T), ti = q >> 1, m = q & 1;
+    for (int i = 0; i < NP; i++) {
+        // lane -> (tile, row) of the workgroup: the 16 nibble bytes of this block, and the scale word of its pair
+        const int u = min(i * 64 + lane, 16 * T - 1), ti = u >> 4, r = u & 15;
         int mat;
         const int tile = tile_of(ti, mat);
-        const int p = m * 64 + lane, u = p ^ ((p >> 3) & 3);        // LDS position p holds chunk u of the (tile, group)
-        wsrc[i] = reinterpret_cast<const char *>(mat ? P.q1 : P.q) + ((size_t)tile * P.npairs * 32 + u) * 16;
+        const size_t grp = (size_t)tile * P.npairs + (size_t)(blk0 >> 3) * KL;
+        wsrc[i] = reinterpret_cast<const char *>(mat ? P.q1 : P.q) + (grp * (2 * TR) + (size_t)((cc * TR + r) * KL + k0)) * 16;
+        ssrc[i] = reinterpret_cast<const char *>(mat ? P.s1 : P.s) + (grp * TR + (size_t)(r * KL + k0)) * 4;
     }
-    const char *ssrc;
-    {
-        const int piece = wv % L::WS_PIECES, ti = min(piece * 4 + (lane >> 4), T - 1);
-        int mat;
-        const int tile = tile_of(ti, mat);
-        ssrc = reinterpret_cast<const char *>(mat ? P.s1 : P.s) + ((size_t)tile * P.npairs * 16 * 4 + (size_t)(lane & 15) * 16);
-    }
-    auto issue = [&](int slot, bool adv) {     // adv: the pointers move on to the next chunk
-        uint4 *const base = lds + slot * L::SLOT_U4;
+    auto issue = [&](int slot, bool adv) {     // adv: the pointers move on to this wavefront's next block
+        uint4 *const base = ring + slot * REG_U4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)xsrc,
+                                         (__attribute__((address_space(3))) void *)base, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xsrc + QG_FRAG * 16),
+                                         (__attribute__((address_space(3))) void *)(base + 64), 16, 0, 0);
+        xsrc += adv ? (size_t)NWV * xblock : (size_t)0;
+        // (lanes past the T x 16 rows are masked off: they neither request nor write)
 #pragma unroll
-        for (int i = 0; i < ACT_PPW; i++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)asrc[i],
-                                             (__attribute__((address_space(3))) void *)(base + ((i * NWV + wv) % 16) * QG_FRAG), 16, 0, 0);
-            asrc[i] += adv ? (size_t)DG_KB * xblock : (size_t)0;
+        for (int i = 0; i < NP; i++) {
+            if ((i + 1) * 64 <= 16 * T || i * 64 + lane < 16 * T)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)wsrc[i],
+                                                 (__attribute__((address_space(3))) void *)(base + 128 + i * 64), 16, 0, 0);
+            wsrc[i] += adv ? KL * 2 * TR * 16 * (NWV / 8) : 0;        // the same block of this wavefront's next group
         }
 #pragma unroll
-        for (int i = 0; i < WQ_PPW; i++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)wsrc[i],
-                                             (__attribute__((address_space(3))) void *)(base + DG_ACT_U4 + ((i * NWV + wv) % (2 * T)) * 64), 16, 0, 0);
-            wsrc[i] += adv ? KL * 2 * TR * 16 : 0;       // the next group of the tile
+        for (int i = 0; i < NP; i++) {
+            if ((i + 1) * 64 <= 16 * T || i * 64 + lane < 16 * T)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)ssrc[i],
+                                                 (__attribute__((address_space(3))) void *)(base + 128 + 16 * T + i * 16), 4, 0, 0);
+            ssrc[i] += adv ? KL * TR * 4 * (NWV / 8) : 0;
         }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)ssrc,
-                                         (__attribute__((address_space(3))) void *)(base + DG_ACT_U4 + L::WQ_U4 + (wv % L::WS_PIECES) * 64), 16, 0, 0);
-        ssrc += adv ? KL * TR * 4 : 0;
     };
-    // ---- what the norm and the epilogue need from memory is requested FIRST and first USED after the K loop.  hipcc waits
-    //      vmcnt(0) for a register load once LDS-DMA pieces are in flight behind it (it treats the two as unordered), i.e. any
-    //      use inside the loop would drain the ring; the values are pinned behind the loop below.  The RoPE position of the
-    //      lane's token comes through the scalar cache (lgkmcnt), so cos / sin can be requested before the first piece. ----
-    const int n = tt * 16 + li, nn = min(n, P.n_tokens - 1);   // this lane's token; its rows are 4 * lq .. + 3 of every tile
+
+    // ---- what the epilogue needs from memory is requested FIRST (by the wavefronts that run an epilogue group) and first USED
+    //      behind the K loop; the RoPE position of the lane's token comes through the scalar cache (lgkmcnt) ----
+    const int n = tt * 16 + li, nn = min(n, P.n_tokens - 1);   // epilogue: this lane's token; its rows are 4 * lq .. + 3 of every tile
     const bool live = n < P.n_tokens;
-    [[maybe_unused]] float nsc = 1.0f;
+    const int etile0 = tile_base + (wv < NEG ? (FUSED ? wv * 2 : wv * EG) : 0);  // first row tile of this wavefront's epilogue group (wv < NEG)
+    [[maybe_unused]] float nsc = 1.0f, psc = 1.0f;
     [[maybe_unused]] int pos = 0, strm = 0;
-    [[maybe_unused]] float4 rv[RT], bv[RT], gw[RT], rc4[RT], rs4[RT];
-    [[maybe_unused]] float psc = 1.0f;
-    if constexpr (EPI != QG_EPI_PLAIN) {
-        {   // (no load behind a branch: an absent operand reads the first bytes of the weight matrix, value unused)
-            const bool on = P.nrm_in.ssq != nullptr;
-            nsc = *(on && P.nrm_in.scale ? P.nrm_in.scale + nn : reinterpret_cast<const float *>(P.q));
-        }
-    }
-    if constexpr (EPI == QG_EPI_ROPE) {
-        const int nlast = P.n_tokens - 1 - tt * 16;        // (>= 0: the grid has no empty token tile)
+    [[maybe_unused]] float4 rv[EG], bv[EG], gw[EG], rc4, rs4;
+    const float *const dummy = reinterpret_cast<const float *>(P.q);     // (an absent operand reads the first bytes of the weights -- value
+                                                                         //  unused -- so that no load sits behind a branch)
+    {   // (every wavefront: a load inside a branch would be waited for at the end of the branch)
+        if constexpr (EPI != QG_EPI_PLAIN) nsc = *(P.nrm_in.ssq && P.nrm_in.scale ? P.nrm_in.scale + nn : dummy);
+        if constexpr (EPI == QG_EPI_ROPE) {
+            const int nlast = P.n_tokens - 1 - tt * 16;        // (>= 0: the grid has no empty token tile)
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int pk = sload_i32(P.rope.pos + tt * 16 + min(k, nlast)), sk = sload_i32(P.rope.stream + tt * 16 + min(k, nlast));
-            pos = li == k ? pk : pos;
-            strm = li == k ? sk : strm;
+            for (int k = 0; k < 16; k++) {
+                const int pk = sload_i32(P.rope.pos + tt * 16 + min(k, nlast)), sk = sload_i32(P.rope.stream + tt * 16 + min(k, nlast));
+                pos = li == k ? pk : pos;
+                strm = li == k ? sk : strm;
+            }
+            const int hd = P.rope.head_dim, half = hd >> 1, tph = hd / 16;
+            const int tile = min(etile0, P.ntiles - 1), i0 = (tile % tph) * 8 + 4 * (lq & 1);
+            rc4 = *reinterpret_cast<const float4 *>(P.rope.cos + pos * half + i0);
+            rs4 = *reinterpret_cast<const float4 *>(P.rope.sin + pos * half + i0);
         }
-        const int hd = P.rope.head_dim, half = hd >> 1, tph = hd / 16;
+        if constexpr (EPI == QG_EPI_PLAIN) {
+            const int row0 = min(etile0, P.ntiles - EG) * TR;
+            const size_t off0 = (size_t)nn * P.ldo + (row0 + lq * 4);
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++) {
-            const int tile = min(tile0 + rt, P.ntiles - 1), i0 = (tile % tph) * 8 + 4 * (lq & 1);
-            rc4[rt] = *reinterpret_cast<const float4 *>(P.rope.cos + pos * half + i0);
-            rs4[rt] = *reinterpret_cast<const float4 *>(P.rope.sin + pos * half + i0);
+            for (int rt = 0; rt < EG; rt++) {
+                rv[rt] = *reinterpret_cast<const float4 *>(P.resid ? P.resid + off0 + rt * TR : dummy);
+                bv[rt] = *reinterpret_cast<const float4 *>(P.bias ? P.bias + row0 + rt * TR + lq * 4 : dummy);
+                gw[rt] = *reinterpret_cast<const float4 *>(P.nrm_out.w ? P.nrm_out.w + row0 + rt * TR + lq * 4 : dummy);
+            }
+            psc = *(P.nrm_out.w && P.nrm_out.scale ? P.nrm_out.scale + nn : dummy);
         }
-    }
-    if constexpr (EPI == QG_EPI_PLAIN) {
-        const int row0 = min(tile0, P.ntiles - RT) * TR;
-        const size_t off0 = (size_t)nn * P.ldo + (row0 + lq * 4);
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++) {
-            // (an absent operand reads the first bytes of the weight matrix instead -- value unused -- so that no load sits behind a
-            //  branch: hipcc waits for a conditional load inside its branch, one round trip each before the first DMA piece)
-            const float *const dummy = reinterpret_cast<const float *>(P.q);
-            rv[rt] = *reinterpret_cast<const float4 *>(P.resid ? P.resid + off0 + rt * TR : dummy);
-            bv[rt] = *reinterpret_cast<const float4 *>(P.bias ? P.bias + row0 + rt * TR + lq * 4 : dummy);
-            gw[rt] = *reinterpret_cast<const float4 *>(P.nrm_out.w ? P.nrm_out.w + row0 + rt * TR + lq * 4 : dummy);
-        }
-        psc = *(P.nrm_out.w && P.nrm_out.scale ? P.nrm_out.scale + nn : reinterpret_cast<const float *>(P.q));
     }
     asm volatile("" ::: "memory");
     if constexpr (EPI != QG_EPI_PLAIN) {
         // the producer's partial sums of squares of this tile's 16 tokens ([token][nrb] float64, contiguous) into LDS, older than
-        // every chunk piece; read behind the loop
+        // every step's pieces; read behind the loop
         if (P.nrm_in.ssq) {
             const unsigned bytes = 16u * (unsigned)P.nrm_in.nrb * 8u;
             const char *const src = reinterpret_cast<const char *>(P.nrm_in.ssq + (size_t)tt * 16 * P.nrm_in.nrb);
@@ -189,103 +182,80 @@ __global__ void __launch_bounds__(NW * KS * 64, (NW * KS + 3) / 4) dgemm_kernel(
                                                  (__attribute__((address_space(3))) void *)(lds_all + p0 / 16), 16, 0, 0);
         }
     }
-    // PD chunks, unconditionally (a K shorter than the ring fetches its last chunk again into slots nobody reads)
+    // DEPTH steps, unconditionally (a wavefront with fewer blocks fetches its last one again into slots it never reads)
 #pragma unroll
-    for (int c = 0; c < PD; c++) issue(c, c + 1 < nchunks);
+    for (int s = 0; s < DEPTH; s++) issue(s, s + 1 < nsteps);
     asm volatile("" ::: "memory");
     DG_STAMP(1);
 
-    f32x4_t acc[RT];
+    f32x4_t acc[T];
 #pragma unroll
-    for (int rt = 0; rt < RT; rt++) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    // per-lane parts of the LDS addresses (uint32 units): nibble dword of (row li, pair k) and the four scale words of a pair
-    const int swz = (li >> 1) & 3;
-    int slot = 0, issued = PD;      // chunks requested so far
-    for (int c = 0; c < nchunks; c++) {
-        // chunk c has landed when at most the pieces of the chunks issued after it are outstanding
-        const int after = issued - 1 - c;
-        if (after == PD - 1) DG_WAIT_VM((PD - 1) * PPW);
-        else if (PD > 2 && after == PD - 2) DG_WAIT_VM((PD > 2 ? PD - 2 : 0) * PPW);
-        else if (PD > 3 && after == PD - 3) DG_WAIT_VM((PD > 3 ? PD - 3 : 0) * PPW);
-        else if (PD > 4 && after == PD - 4) DG_WAIT_VM((PD > 4 ? PD - 4 : 0) * PPW);
-        else if (PD > 5 && after == PD - 5) DG_WAIT_VM((PD > 5 ? PD - 5 : 0) * PPW);
-        else if (PD > 6 && after == PD - 6) DG_WAIT_VM((PD > 6 ? PD - 6 : 0) * PPW);
+    for (int ti = 0; ti < T; ti++) acc[ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int slot = 0, issued = DEPTH;      // steps requested so far
+    for (int s = 0; s < nsteps; s++) {
+        // step s has landed when at most the pieces of the steps issued after it are outstanding
+        const int after = issued - 1 - s;
+        if (after == DEPTH - 1) DG_WAIT_VM((DEPTH - 1) * PPS);
+        else if (DEPTH > 2 && after == DEPTH - 2) DG_WAIT_VM((DEPTH > 2 ? DEPTH - 2 : 0) * PPS);
+        else if (DEPTH > 3 && after == DEPTH - 3) DG_WAIT_VM((DEPTH > 3 ? DEPTH - 3 : 0) * PPS);
+        else if (DEPTH > 4 && after == DEPTH - 4) DG_WAIT_VM((DEPTH > 4 ? DEPTH - 4 : 0) * PPS);
+        else if (DEPTH > 5 && after == DEPTH - 5) DG_WAIT_VM((DEPTH > 5 ? DEPTH - 5 : 0) * PPS);
         else DG_WAIT_VM(0);
         asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();        // every wavefront's pieces of chunk c; and everybody has left chunk c - 1's slot
+        const uint4 *const sb = ring + slot * REG_U4;
+        const uint32_t *const sb32 = reinterpret_cast<const uint32_t *>(sb);
+        const half8_t xh = __builtin_bit_cast(half8_t, sb[lane]), xl = __builtin_bit_cast(half8_t, sb[64 + lane]);
+        // TG tiles at a time: TG independent MFMA chains (lo product, then hi product on the same accumulator)
+        constexpr int TG = T == 8 ? 2 : T % 4 == 0 ? 4 : T % 3 == 0 ? 3 : T % 2 == 0 ? 2 : 1;
+#pragma unroll
+        for (int t0 = 0; t0 < T; t0 += TG) {
+            half8_t a[TG];
+            uint32_t sw[TG];
+            f32x4_t z[TG];
+#pragma unroll
+            for (int g = 0; g < TG; g++) {
+                a[g] = WFrag<WT_Q4_0>::expand(sb32[(128 + (t0 + g) * 16 + li) * 4 + lq]);
+                sw[g] = sb32[(128 + 16 * T) * 4 + (t0 + g) * 16 + li];
+            }
+#pragma unroll
+            for (int g = 0; g < TG; g++) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, a[g], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < TG; g++) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, a[g], z[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < TG; g++) {
+                const float d = scale_of(sw[g], cc);
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[t0 + g][r] = fmaf(z[g][r], d, acc[t0 + g][r]);
+            }
+        }
         asm volatile("" ::: "memory");
-        DG_STAMP(2 + 2 * c);
-        if (c + PD < nchunks) { issue(slot == 0 ? NSLOT - 1 : slot - 1, true); issued++; }
-        const uint4 *const sb = lds + slot * L::SLOT_U4;
-        const uint32_t *const wq32 = reinterpret_cast<const uint32_t *>(sb + DG_ACT_U4);
-        const uint32_t *const ws32 = reinterpret_cast<const uint32_t *>(sb + DG_ACT_U4 + L::WQ_U4);
-        // the fp16 scales of this wavefront's pairs of the chunk: rows 4*lq .. +3 of every tile, NPW pairs each (one LDS read per row)
-        constexpr int NPW = BPW >= 2 ? BPW / 2 : 1;
-        const int k0 = BPW >= 2 ? wk * NPW : wk >> 1;
-        uint32_t sw[RT][4][NPW];
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint32_t *src = ws32 + (wr * RT + rt) * 64 + (4 * lq + r) * 4 + k0;
-                if constexpr (NPW == 4) { const uint4 v = *reinterpret_cast<const uint4 *>(src); sw[rt][r][0] = v.x; sw[rt][r][1] = v.y; sw[rt][r][2] = v.z; sw[rt][r][3] = v.w; }
-                else if constexpr (NPW == 2) { const uint2 v = *reinterpret_cast<const uint2 *>(src); sw[rt][r][0] = v.x; sw[rt][r][1] = v.y; }
-                else sw[rt][r][0] = *src;
-            }
-        // JB blocks at a time: JB * RT independent MFMA chains (lo product, then hi product on the same accumulator)
-        constexpr int JB = BPW < (4 / RT > 0 ? 4 / RT : 1) ? BPW : (4 / RT > 0 ? 4 / RT : 1);
-#pragma unroll
-        for (int j0 = 0; j0 < BPW; j0 += JB) {
-            half8_t xh[JB], xl[JB], a[JB][RT];
-            f32x4_t z[JB][RT];
-#pragma unroll
-            for (int jb = 0; jb < JB; jb++) {
-                const int j = j0 + jb;
-                const int kk = k0 + (BPW >= 2 ? j >> 1 : 0), cc = BPW >= 2 ? j & 1 : wk & 1;      // pair of the group, block of the pair
-                const int bi = 2 * kk + cc;
-                xh[jb] = __builtin_bit_cast(half8_t, sb[(bi * 2 + 0) * QG_FRAG + lane]);
-                xl[jb] = __builtin_bit_cast(half8_t, sb[(bi * 2 + 1) * QG_FRAG + lane]);
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++)
-                    a[jb][rt] = WFrag<WT_Q4_0>::expand(wq32[((wr * RT + rt) * 128 + cc * 64 + li * 4 + (kk ^ swz)) * 4 + lq]);
-            }
-#pragma unroll
-            for (int jb = 0; jb < JB; jb++)
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++)
-                    z[jb][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[jb][rt], xl[jb], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-            for (int jb = 0; jb < JB; jb++)
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++)
-                    z[jb][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[jb][rt], xh[jb], z[jb][rt], 0, 0, 0);
-#pragma unroll
-            for (int jb = 0; jb < JB; jb++) {
-                const int j = j0 + jb, cc = BPW >= 2 ? j & 1 : wk & 1;
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        acc[rt][r] = fmaf(z[jb][rt][r], scale_of(sw[rt][r][BPW >= 2 ? j >> 1 : 0], cc), acc[rt][r]);
-            }
-        }
-        DG_STAMP(3 + 2 * c);
-        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+        DG_STAMP(2 + s);
+        if (s + DEPTH < nsteps) { issue(slot, true); issued++; }       // the slot just read out: nobody else touches it
+        slot = slot + 1 == DEPTH ? 0 : slot + 1;
     }
-    // ---- the KS partial accumulators of a row part meet in wavefront wk = 0, ascending wk ----
-    if constexpr (KS > 1) {
-        __builtin_amdgcn_s_barrier();        // the last chunk's slot is read out
-        f32x4_t *const red = reinterpret_cast<f32x4_t *>(lds);
-        if (wk > 0) {
+    // ---- the NWV partial accumulators of a tile meet in LDS: D[token 4 lq + r][row li] goes out as [tile][token][row], the
+    //      epilogue wavefronts read [row 4 lq ..][token li] back, partials in wavefront order ----
+    DG_WAIT_VM(0);      // (a wavefront with fewer blocks than slots still has its surplus requests in flight: they land in its own ring)
+    asm volatile("" ::: "memory");
+    {
+        float *const mine = reinterpret_cast<float *>(ring);
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++) red[(wv * RT + rt) * 64 + lane] = acc[rt];
-        }
-        __syncthreads();
-        if (wk > 0) return;
+        for (int ti = 0; ti < T; ti++)
 #pragma unroll
-        for (int k2 = 1; k2 < KS; k2++)
+            for (int r = 0; r < 4; r++) mine[ti * 256 + (4 * lq + r) * 16 + li] = acc[ti][r];
+    }
+    __syncthreads();
+    DG_STAMP(40);
+    if (wv >= NEG) return;
+    f32x4_t e[EG];
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++) acc[rt] += red[((k2 * NW + wr) * RT + rt) * 64 + lane];
+    for (int g = 0; g < EG; g++) {
+        // epilogue group wv: PLAIN / ROPE tiles wv * EG + g; FUSED: gate tiles 2 wv, 2 wv + 1, then the same tiles of up
+        const int ti = FUSED ? (g >> 1) * (T / 2) + wv * 2 + (g & 1) : wv * EG + g;
+        e[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int w = 0; w < NWV; w++)      // (four reads in flight: fully unrolled, hipcc hoists all NWV x EG reads -- 256 registers)
+            e[g] += *reinterpret_cast<const f32x4_t *>(reinterpret_cast<const float *>(lds_all + SSQ_U4 + w * (DEPTH * REG_U4)) + ti * 256 + li * 16 + lq * 4);
     }
     // ---- folded RMSNorm, consumer side (QGemmParams::NormIn): inv of this lane's token from the producer's per-32-row sums of
     //      squares: lane lq adds partials lq, lq + 4, ... in ascending order, the four lanes of a token meet in lq order ----
@@ -307,19 +277,19 @@ __global__ void __launch_bounds__(NW * KS * 64, (NW * KS + 3) / 4) dgemm_kernel(
             }
         }
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++) acc[rt] = acc[rt] * inv;
+        for (int g = 0; g < EG; g++) e[g] = e[g] * inv;
     }
     if constexpr (EPI == QG_EPI_SWIGLU) {
         // h = SiLU(gate) * up (go/quant.go:629-631, go/model.go:604-606): rows 4*lq..+3 of both 16-row tiles of one token are
-        // the two float4 groups of k-slot group lq of the wavefront's 32-row block of h (Q4_0 consumer: slot_offsets)
-        const int hblk = tile0 >> 1;
+        // the two float4 groups of k-slot group lq of the group's 32-row block of h (Q4_0 consumer: slot_offsets)
+        const int hblk = etile0 >> 1;
         if (hblk * 32 >= P.rows || !live) return;
         float hv[2][4];
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float gv = acc[r][j], uv = acc[r + 2][j];
+                const float gv = e[r][j], uv = e[r + 2][j];
                 const float ex = exp_f64_as_f32(-gv);
                 hv[r][j] = (gv / (1.0f + ex)) * uv;
             }
@@ -333,75 +303,72 @@ __global__ void __launch_bounds__(NW * KS * 64, (NW * KS + 3) / 4) dgemm_kernel(
         // rotation partner of rows 4*lq + j is rows 4*(lq ^ 2) + j of the same tile and token: lane ^ 32
         const QGemmParams::Rope &R = P.rope;
         const int hd = R.head_dim, half = hd >> 1, tph = hd / 16, nq = R.n_q_heads * hd;
+        const int tile = min(etile0, P.ntiles - 1);
+        const int head = tile / tph, i0 = (tile % tph) * 8 + 4 * (lq & 1), e0 = i0 + (lq >> 1) * half;
+        const bool is_q = head < R.n_q_heads, is_k = !is_q && head < R.n_q_heads + R.n_kv_heads;
+        const int kvh = head - R.n_q_heads - (is_k ? 0 : R.n_kv_heads);
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (R.bias_q) bq = *reinterpret_cast<const float4 *>((is_q ? R.bias_q + head * hd : is_k ? R.bias_k + kvh * hd : R.bias_v + kvh * hd) + e0);
+        const float bj[4] = {bq.x, bq.y, bq.z, bq.w};
+        float4 c4 = rc4, s4 = rs4;
+        asm volatile("" : "+v"(c4.x), "+v"(c4.y), "+v"(c4.z), "+v"(c4.w));      // (first use behind the loop)
+        asm volatile("" : "+v"(s4.x), "+v"(s4.y), "+v"(s4.z), "+v"(s4.w));
+        const float cj[4] = {c4.x, c4.y, c4.z, c4.w}, sj[4] = {s4.x, s4.y, s4.z, s4.w};
+        float o[4];
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++) {
-            const int tile = min(tile0 + rt, P.ntiles - 1);
-            const int head = tile / tph, i0 = (tile % tph) * 8 + 4 * (lq & 1), e0 = i0 + (lq >> 1) * half;
-            const bool is_q = head < R.n_q_heads, is_k = !is_q && head < R.n_q_heads + R.n_kv_heads;
-            const int kvh = head - R.n_q_heads - (is_k ? 0 : R.n_kv_heads);
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (R.bias_q) bv = *reinterpret_cast<const float4 *>((is_q ? R.bias_q + head * hd : is_k ? R.bias_k + kvh * hd : R.bias_v + kvh * hd) + e0);
-            const float bj[4] = {bv.x, bv.y, bv.z, bv.w};
-            float4 c4 = rc4[rt], s4 = rs4[rt];
-            asm volatile("" : "+v"(c4.x), "+v"(c4.y), "+v"(c4.z), "+v"(c4.w));
-            asm volatile("" : "+v"(s4.x), "+v"(s4.y), "+v"(s4.z), "+v"(s4.w));
-            const float cj[4] = {c4.x, c4.y, c4.z, c4.w}, sj[4] = {s4.x, s4.y, s4.z, s4.w};
-            float o[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float v = acc[rt][j] + bj[j];
-                const float partner = __shfl_xor(v, 32);
-                float outv = v;
-                if (is_q || is_k) {
-                    const float x0 = lq < 2 ? v : partner, x1 = lq < 2 ? partner : v;
-                    if (!R.conj) outv = lq < 2 ? (x0 * cj[j] - x1 * sj[j]) : (x0 * sj[j] + x1 * cj[j]);
-                    else outv = lq < 2 ? (x0 * cj[j] + x1 * sj[j]) : (-x0 * sj[j] + x1 * cj[j]);
-                }
-                o[j] = outv;
+        for (int j = 0; j < 4; j++) {
+            const float v = e[0][j] + bj[j];
+            const float partner = __shfl_xor(v, 32);
+            float outv = v;
+            if (is_q || is_k) {
+                const float x0 = lq < 2 ? v : partner, x1 = lq < 2 ? partner : v;
+                if (!R.conj) outv = lq < 2 ? (x0 * cj[j] - x1 * sj[j]) : (x0 * sj[j] + x1 * cj[j]);
+                else outv = lq < 2 ? (x0 * cj[j] + x1 * sj[j]) : (-x0 * sj[j] + x1 * cj[j]);
             }
-            if (!live || tile0 + rt >= P.ntiles) continue;
-            float *dstp = is_q ? R.q + ((long long)n * nq + head * hd + e0)
-                               : (is_k ? R.kcache : R.vcache) + ((long long)strm * R.kv_stream_stride + ((long long)kvh * R.seq_len + pos) * hd + e0);
-            *reinterpret_cast<float4 *>(dstp) = make_float4(o[0], o[1], o[2], o[3]);
+            o[j] = outv;
         }
+        if (!live || etile0 >= P.ntiles) return;
+        float *dstp = is_q ? R.q + ((long long)n * nq + head * hd + e0)
+                           : (is_k ? R.kcache : R.vcache) + ((long long)strm * R.kv_stream_stride + ((long long)kvh * R.seq_len + pos) * hd + e0);
+        *reinterpret_cast<float4 *>(dstp) = make_float4(o[0], o[1], o[2], o[3]);
         return;
     }
     if constexpr (EPI == QG_EPI_PLAIN) {
         // out = resid + bias + y; then (QGemmParams::NormOut) the rows as the NEXT GEMM's fragments, times its norm weights and
-        // the token's power-of-two pre-scale, plus the float64 sum of squares of this wavefront's 32 rows (qgemm2_kernel's
+        // the token's power-of-two pre-scale, plus the float64 sum of squares of this group's 32 rows (qgemm2_kernel's
         // producer epilogue with one partial per 32-row block)
-        const int row0 = tile0 * TR;
-        if (tile0 + RT > P.ntiles) return;        // (row counts are multiples of 32 on this path: never taken)
+        const int row0 = etile0 * TR;
+        if (etile0 + EG > P.ntiles) return;        // (row counts are multiples of 32 on this path: never taken)
         const size_t off0 = (size_t)nn * P.ldo + (row0 + lq * 4);
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++) {
+        for (int rt = 0; rt < EG; rt++) {
             asm volatile("" : "+v"(rv[rt].x), "+v"(rv[rt].y), "+v"(rv[rt].z), "+v"(rv[rt].w));      // (first use behind the loop)
-            float4 v = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+            float4 v = make_float4(e[rt][0], e[rt][1], e[rt][2], e[rt][3]);
             if (P.bias) { v.x += bv[rt].x; v.y += bv[rt].y; v.z += bv[rt].z; v.w += bv[rt].w; }
             if (P.resid) { v.x += rv[rt].x; v.y += rv[rt].y; v.z += rv[rt].z; v.w += rv[rt].w; }
             if (live) *reinterpret_cast<float4 *>(P.out + off0 + rt * TR) = v;
-            acc[rt] = (f32x4_t){v.x, v.y, v.z, v.w};
+            e[rt] = (f32x4_t){v.x, v.y, v.z, v.w};
         }
         if (P.nrm_out.w) {
             const float ps = P.nrm_out.scale ? psc : 1.0f;
             double ss = 0.0;
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++)
+            for (int rt = 0; rt < EG; rt++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) ss = fma((double)acc[rt][j], (double)acc[rt][j], ss);
+                for (int j = 0; j < 4; j++) ss = fma((double)e[rt][j], (double)e[rt][j], ss);
             ss += __shfl_xor(ss, 16);
             ss += __shfl_xor(ss, 32);
-            if (lq == 0 && live) P.nrm_out.ssq[(size_t)n * (P.rows / 32) + (tile0 >> 1)] = ss;
+            if (lq == 0 && live) P.nrm_out.ssq[(size_t)n * (P.rows / 32) + (etile0 >> 1)] = ss;
             float y[2][4];
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 const float4 g = gw[r];
-                y[r][0] = (acc[r][0] * g.x) * ps; y[r][1] = (acc[r][1] * g.y) * ps;
-                y[r][2] = (acc[r][2] * g.z) * ps; y[r][3] = (acc[r][3] * g.w) * ps;
+                y[r][0] = (e[r][0] * g.x) * ps; y[r][1] = (e[r][1] * g.y) * ps;
+                y[r][2] = (e[r][2] * g.z) * ps; y[r][3] = (e[r][3] * g.w) * ps;
             }
             float v[8];
             slots_from(1, make_float4(y[0][0], y[0][1], y[0][2], y[0][3]), make_float4(y[1][0], y[1][1], y[1][2], y[1][3]), v);
-            if (live) store_frag(P.nrm_out.xf, P.nt16, n, tile0 >> 1, lq, v);
+            if (live) store_frag(P.nrm_out.xf, P.nt16, n, etile0 >> 1, lq, v);
         }
     }
 }
@@ -412,25 +379,24 @@ inline unsigned dg_grid(int ntiles, int tiles_per_wg, int n_tokens) {
     return (unsigned)(((nrg + 7) / 8) * 8 * ((n_tokens + 15) / 16));
 }
 
-// the three launches of a layer (geometry: DESIGN.md 3.5 / tools/dgemm_bench.hip)
+// the three launches of a layer: (tiles per workgroup, wavefronts); tools/dgemm_bench.hip measures them on goldie's shapes
 #ifndef DG_ROPE_GEOM
-#define DG_ROPE_GEOM 1, 4, 4
+#define DG_ROPE_GEOM 3, 16
 #endif
 #ifndef DG_SWIGLU_GEOM
-#define DG_SWIGLU_GEOM 4, 2, 8
+#define DG_SWIGLU_GEOM 8, 16
 #endif
 #ifndef DG_PLAIN_GEOM
-#define DG_PLAIN_GEOM 2, 1, 8
+#define DG_PLAIN_GEOM 2, 16
 #endif
-template <int RT, int NW, int KS, int EPI>
+template <int T, int NWV, int EPI>
 inline hipError_t dg_launch(QGemmParams P, hipStream_t st) {
     P.nt16 = ((P.n_tokens + 63) / 64) * 4;
     P.ksplit = 1;
-    constexpr int TILES_PER_WG = NW * (EPI == QG_EPI_SWIGLU ? 2 : RT);
-    hipLaunchKernelGGL((dgemm_kernel<RT, NW, KS, EPI>), dim3(dg_grid(P.ntiles, TILES_PER_WG, P.n_tokens)), dim3(NW * KS * 64), 0, st, P);
+    constexpr int TILES_PER_WG = EPI == QG_EPI_SWIGLU ? T / 2 : T;
+    hipLaunchKernelGGL((dgemm_kernel<T, NWV, EPI>), dim3(dg_grid(P.ntiles, TILES_PER_WG, P.n_tokens)), dim3(NWV * 64), 0, st, P);
     return hipGetLastError();
 }
-#define DG_COMMA_EPI(geom, epi) geom, epi
 inline hipError_t dg_launch_rope(const QGemmParams &P, hipStream_t st) { return dg_launch<DG_ROPE_GEOM, QG_EPI_ROPE>(P, st); }
 inline hipError_t dg_launch_swiglu(const QGemmParams &P, hipStream_t st) { return dg_launch<DG_SWIGLU_GEOM, QG_EPI_SWIGLU>(P, st); }
 inline hipError_t dg_launch_plain(const QGemmParams &P, hipStream_t st) { return dg_launch<DG_PLAIN_GEOM, QG_EPI_PLAIN>(P, st); }

@@ -79,6 +79,23 @@ int main(int argc, char **argv) {
         P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles; P.nt16 = nt16; P.n_tokens = N; P.ksplit = 1;
         return P;
     };
+    auto stamps = [&](const char *name, int grid) {
+#ifdef DG_STAMPS
+        std::vector<long long> s_(64);
+        CK(hipMemcpyFromSymbol(s_.data(), HIP_SYMBOL(g_dg_stamps), 64 * 8));
+        printf("   %s: workgroup 9, wavefront 0, cycles since entry: issued", name);
+        for (int i = 1; i < 40 && s_[i]; i++) printf(" %lld", s_[i] - s_[0]);
+        printf(" | partials out + barrier %lld\n", s_[40] - s_[0]);
+        std::vector<long long> c_(2 * 2048);
+        CK(hipMemcpyFromSymbol(c_.data(), HIP_SYMBOL(g_dg_census), 2 * 2048 * 8));
+        long long e0 = 1LL << 62, e1 = 0, x0 = 1LL << 62, x1 = 0; int nwg = 0;
+        for (int i = 0; i < grid; i++) if (c_[2 * i] && c_[2 * i + 1]) { nwg++; e0 = std::min(e0, c_[2 * i]); e1 = std::max(e1, c_[2 * i]); x0 = std::min(x0, c_[2 * i + 1]); x1 = std::max(x1, c_[2 * i + 1]); }
+        printf("   census: %d workgroups; entries spread %.2f us; first exit +%.2f us, last exit +%.2f us after the first entry; wg 9: entry +%.2f exit +%.2f\n",
+               nwg, (e1 - e0) * 0.01, (x0 - e0) * 0.01, (x1 - e0) * 0.01, (c_[18] - e0) * 0.01, (c_[19] - e0) * 0.01);
+        std::vector<long long> z_(64, 0);
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_dg_stamps), z_.data(), 64 * 8));
+#endif
+    };
     const QGemmParams::NormIn nin{ssq, D / 32, D, 1e-5f, sc1, sc2};
     timeit("qkv+rope", [&](int i) {
         QGemmParams P = base(qkv, i);
@@ -86,32 +103,28 @@ int main(int argc, char **argv) {
         P.rope = QGemmParams::Rope{pos, strm, cs, sn, qout, kc, vc, (long long)kvs, nullptr, nullptr, nullptr, hd, H, KV, seq, 0};
         CK(dg_launch_rope(P, st));
     }, (double)qkv.qbytes * 18 / 16, 2.0 * R * D * N);
+    stamps("qkv", 1024);
     timeit("wo+norm", [&](int i) {
         QGemmParams P = base(wo, i);
         P.xf = xf; P.out = x; P.ldo = D; P.resid = x;
         P.nrm_out = QGemmParams::NormOut{nw, xf2, ssq, sc1};
         CK(dg_launch_plain(P, st));
     }, (double)wo.qbytes * 18 / 16, 2.0 * D * D * N);
+    stamps("wo", 1024);
     timeit("gate|up", [&](int i) {
         QGemmParams P = base(gate, i);
         P.q1 = up.q + (size_t)(i % up.copies) * up.qbytes; P.s1 = up.s + (size_t)(i % up.copies) * up.swords;
         P.xf = xf; P.ldo = I; P.nrm_in = nin; P.xf_out = xf2; P.out_q4 = 1;
         CK(dg_launch_swiglu(P, st));
     }, (double)gate.qbytes * 2 * 18 / 16, 2.0 * 2 * I * D * N);
+    stamps("gate|up", 1024);
     timeit("down+norm", [&](int i) {
         QGemmParams P = base(down, i);
         P.xf = xf2; P.out = x; P.ldo = D; P.resid = x;
         P.nrm_out = QGemmParams::NormOut{nw, xf, ssq, sc1};
         CK(dg_launch_plain(P, st));
     }, (double)down.qbytes * 18 / 16, 2.0 * D * I * N);
-#ifdef DG_STAMPS
-    {
-        std::vector<long long> s_(64);
-        CK(hipMemcpyFromSymbol(s_.data(), HIP_SYMBOL(g_dg_stamps), 64 * 8));
-        printf("stamps of the last launch (down), workgroup 9, wavefront 0, cycles since entry:");
-        for (int i = 1; i < 40 && s_[i]; i++) printf(" %lld", s_[i] - s_[0]);
-        printf("\n");
-    }
-#endif
+    stamps("down", 1024);
+
     return 0;
 }
