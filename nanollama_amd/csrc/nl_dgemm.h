@@ -16,9 +16,12 @@
 //     and multiplies it against ALL T row tiles, so an activation fragment is read by exactly one wavefront and NOTHING is
 //     shared inside the K loop: no barrier.  (The first form shared a chunk ring between all wavefronts behind one barrier per
 //     chunk: with 1-2 (block, tile) products per wavefront between barriers it ran at 140 SIMD cycles per product.)
-//   * Every wavefront is its own LDS-DMA pipeline (global_load_lds_dwordx4, 1 KB per instruction, the source picked per
-//     lane): per step 2 KB of activation fragments + T x (256 B of nibbles + 64 B of fp16 scale words), into a private ring of
-//     DEPTH slots; "my step has landed" is one s_waitcnt vmcnt(immediate) on the wavefront's own counter.
+//   * Everything a wavefront multiplies is requested at its first instruction: its NS activation fragment pairs straight into
+//     registers (global_load_dwordx4 sc1: the fragment store is in MFMA operand order, and a load that skips the vector L1
+//     streams L2-resident data at 110 GB/s per compute unit against 37 through the L1 and 25-45 measured here through
+//     LDS-DMA: EXPERIMENTS, tools/ingest_probe.hip), its NS x T x (256 B of nibbles + 64 B of fp16 scale words) by LDS-DMA
+//     (the source picked per lane) into its own LDS area.  The issue order is static, so "step s has landed" is one
+//     s_waitcnt vmcnt(immediate) on the wavefront's own counter (loads return in order).
 //   * The nibbles of (block, tile) land as [row][16 B]: the B-operand read -- dword lq of row li -- is conflict-free.  The
 //     MFMA runs as D[token][row] = x . W^T, so a lane needs ONE scale per (block, tile): 1 ds_read_b32, 4 v_fma_mix.
 //     Per (block, tile): 9 VALU (nibbles -> fp16), 2 MFMA (x = hi + lo), 4 FMA ("* d"), 2 + 2/T LDS reads.
@@ -26,10 +29,12 @@
 //     transposed, as D[row][token] = the layout qgemm2_kernel's epilogues are written for.
 // Arithmetic per output = qgemm_kernel / qgemm2_kernel (exact integer quants in fp16, f32 block sums, * d in f32); the
 // summation order over blocks is block-interleaved (NWV partial sums), inside the stated tolerances; deterministic.
-// hipcc waits vmcnt(0) for a register load once LDS-DMA pieces are in flight behind it (it treats the two as unordered): no
-// register load is consumed inside the K loop -- epilogue operands are requested first and pinned behind the loop.
+// hipcc waits vmcnt(0) for a register load once LDS-DMA pieces are in flight behind it (it treats the two as unordered): the
+// fragment loads are inline asm with hand-placed waits, and the epilogue operands (compiler-tracked, requested first) are first
+// used behind the loop.
 // Reference: go/quant.go:45-94 (MatMulQ4_0), go/model.go:513-613 (the layer), per stream.
 #pragma once
+#include <algorithm>
 #include "nl_qgemm2.h"
 
 namespace nl {
@@ -38,13 +43,12 @@ constexpr int DG_LDS_BYTES = 160 * 1024;
 constexpr int DG_SSQ_MAX_NRB = 64;              // partial sums of squares per token the consumer side takes (dim <= 2048)
 constexpr int DG_SSQ_BYTES = 16 * DG_SSQ_MAX_NRB * 8;
 
-template <int T, int NWV, bool SSQ> struct DgLds {
+template <int T, int NWV, int NS, bool SSQ> struct DgLds {
     static constexpr int NP = (16 * T + 63) / 64;               // 64-lane pieces that cover the T x 16 rows of a block
-    // one step of one wavefront: x hi | x lo | nibbles [T][16 rows][16 B] | scales [T][16 rows] fp16 pair words
-    static constexpr int REG_U4 = 128 + 16 * T + 4 * T;
+    static constexpr int REG_U4 = 16 * T + 4 * T;               // one step of one wavefront: nibbles [T][16 rows][16 B] | scales [T][16 rows] fp16 pair words
     static constexpr int SSQ_U4 = SSQ ? DG_SSQ_BYTES / 16 : 0;
-    static constexpr int FIT = (DG_LDS_BYTES - SSQ_U4 * 16 - 512) / (NWV * REG_U4 * 16);
-    static constexpr int DEPTH = FIT > 6 ? 6 : FIT;
+    static constexpr int WAVE_U4 = NS * REG_U4 > T * 64 ? NS * REG_U4 : T * 64;     // ... or its T partial accumulator tiles behind the loop
+    static constexpr int TOTAL_U4 = SSQ_U4 + NWV * WAVE_U4;
 };
 
 #ifdef DG_STAMPS
@@ -56,30 +60,42 @@ __device__ long long g_dg_census[2 * 2048];      // wall clock (100 MHz) at entr
 #define DG_STAMP(i) do { } while (0)
 #endif
 
+// cache policy of the LDS-DMA pieces (CPol bits of global_load_lds: 1 = sc0, 2 = nt, 16 = sc1).  The vector L1's fill path gives
+// a compute unit 37 GB/s of L2-resident data whatever is in flight; loads that skip the L1 (a scope bit) reach 110 (EXPERIMENTS,
+// tools/ingest_probe.hip) -- and every byte here is used once per compute unit, so the L1 has nothing to offer.
+#ifndef DG_AUX
+#define DG_AUX 16
+#endif
+
 // vmcnt immediate of s_waitcnt on gfx9 (vmcnt[3:0] | expcnt[6:4] = 7 | lgkmcnt[11:8] = 15 | vmcnt[5:4] in [15:14])
 #define DG_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0f70 | ((n) & 15) | (((n) >> 4) << 14))
 
-// T: row tiles of a workgroup (SWIGLU: T / 2 gate tiles + the same T / 2 tiles of up); NWV: wavefronts (8 or 16);
-// grid.x = ceil(row groups / 8) * 8 * token tiles (dg_grid).  cols % 256 == 0.
-template <int T, int NWV, int EPI>
+typedef unsigned dg_u32x4 __attribute__((ext_vector_type(4)));
+template <int I, int N, class F>
+__device__ __forceinline__ void dg_static_for(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); dg_static_for<I + 1, N>(f); }
+}
+
+// T: row tiles of a workgroup (SWIGLU: T / 2 gate tiles + the same T / 2 tiles of up); NWV: wavefronts (8 or 16); NS: quant
+// blocks per wavefront = cols / 32 / NWV exactly.  grid.x = ceil(row groups / 8) * 8 * token tiles (dg_grid).
+template <int T, int NWV, int NS, int EPI>
 __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P) {
-    typedef DgLds<T, NWV, EPI != QG_EPI_PLAIN> L;
-    constexpr int DEPTH = L::DEPTH, REG_U4 = L::REG_U4, SSQ_U4 = L::SSQ_U4;
-    constexpr int NP = L::NP, PPS = 2 + 2 * NP;                  // DMA pieces per step: 2 of activations, NP of nibbles (16 B per lane), NP of scales (4 B per lane)
+    typedef DgLds<T, NWV, NS, EPI != QG_EPI_PLAIN> L;
+    constexpr int REG_U4 = L::REG_U4, SSQ_U4 = L::SSQ_U4, WAVE_U4 = L::WAVE_U4;
+    constexpr int NP = L::NP, PPS = 2 + 2 * NP;                  // memory operations per step: 2 fragment loads, NP nibble pieces (16 B per lane), NP scale pieces (4 B per lane)
     constexpr bool FUSED = EPI == QG_EPI_SWIGLU;
     constexpr int EG = EPI == QG_EPI_ROPE ? 1 : FUSED ? 4 : 2;   // tiles per epilogue group (one wavefront each)
     constexpr int NEG = T / EG;
     constexpr int TPG = FUSED ? T / 2 : T;                       // distinct row tiles of the workgroup per matrix
     static_assert(NWV == 8 || NWV == 16, "a wavefront owns block w % 8 of the groups it visits");
-    static_assert(DEPTH >= 2 && (DEPTH - 1) * PPS <= 63, "ring depth / vmcnt is six bits");
+    static_assert((NS - 1) * PPS <= 63, "vmcnt is six bits");
     static_assert(T % EG == 0 && NEG <= NWV, "epilogue groups");
-    static_assert(T * 64 <= DEPTH * REG_U4, "a wavefront's partial accumulators fit its ring");
-    __shared__ __attribute__((aligned(16))) uint4 lds_all[SSQ_U4 + NWV * DEPTH * REG_U4];
+    __shared__ __attribute__((aligned(16))) uint4 lds_all[L::TOTAL_U4];
     DG_STAMP(0);
 
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 15, lq = lane >> 4;
-    uint4 *const ring = lds_all + SSQ_U4 + wv * (DEPTH * REG_U4);      // this wavefront's slots
+    uint4 *const ring = lds_all + SSQ_U4 + wv * WAVE_U4;      // this wavefront's area
     // block -> (row group, token tile): the token tiles of one row group sit on the same XCD (b % 8), next to each other in
     // dispatch order
     const int ntt = (P.n_tokens + 15) >> 4;
@@ -87,11 +103,9 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
     if (rg * TPG >= P.ntiles) return;                            // (padding of the row groups to a multiple of 8: the whole workgroup)
     const int tile_base = rg * TPG;                              // first row tile of the workgroup (FUSED: of gate and of up)
     const int nblocks = P.cols >> 5;
-    // this wavefront's blocks: g = wv, wv + NWV, ... (block g % 8 = wv % 8 of group g / 8)
-    const int nsteps = wv < nblocks ? (nblocks - wv + NWV - 1) / NWV : 0;
-    const int blk0 = wv < nblocks ? wv : 0, k0 = (blk0 >> 1) & 3, cc = blk0 & 1;      // pair of the group, block of the pair
-
-    // ---- DMA pieces of this wavefront: per-lane source pointers, advanced step by step ----
+    // this wavefront's blocks: g = wv, wv + NWV, ... (block g % 8 = wv % 8 of group g / 8): NS of them
+    const int blk0 = wv, k0 = (blk0 >> 1) & 3, cc = blk0 & 1;      // pair of the group, block of the pair
+    // ---- per-lane source pointers of this wavefront's loads, advanced step by step ----
     const unsigned xblock = (unsigned)P.nt16 * (2 * QG_FRAG * 16);    // bytes of one block's fragments
     const char *xsrc = reinterpret_cast<const char *>(P.xf) + ((size_t)blk0 * xblock + ((size_t)(tt * 2) * QG_FRAG + lane) * 16);
     auto tile_of = [&](int ti, int &mat) {          // entry ti of the workgroup's weight area -> (row tile, matrix)
@@ -106,30 +120,32 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
         int mat;
         const int tile = tile_of(ti, mat);
         const size_t grp = (size_t)tile * P.npairs + (size_t)(blk0 >> 3) * KL;
-        wsrc[i] = reinterpret_cast<const char *>(mat ? P.q1 : P.q) + (grp * (2 * TR) + (size_t)((cc * TR + r) * KL + k0)) * 16;
-        ssrc[i] = reinterpret_cast<const char *>(mat ? P.s1 : P.s) + (grp * TR + (size_t)(r * KL + k0)) * 4;
+        // (block-major copies of the packed matrix, dg_permute_kernel: the 16 rows of a block are 256 / 64 contiguous bytes.  In
+        //  the decode GEMV's order -- (parity, row, pair) -- a lane's 16 bytes sit 64 bytes apart and every request moves a
+        //  whole sector for a quarter of it: the nibbles cost four times their size on the way in)
+        wsrc[i] = reinterpret_cast<const char *>(mat ? P.q1 : P.q) + (grp * (2 * TR) + (size_t)((k0 * 2 + cc) * TR + r)) * 16;
+        ssrc[i] = reinterpret_cast<const char *>(mat ? P.s1 : P.s) + (grp * TR + (size_t)(k0 * TR + r)) * 4;
     }
-    auto issue = [&](int slot, bool adv) {     // adv: the pointers move on to this wavefront's next block
-        uint4 *const base = ring + slot * REG_U4;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)xsrc,
-                                         (__attribute__((address_space(3))) void *)base, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xsrc + QG_FRAG * 16),
-                                         (__attribute__((address_space(3))) void *)(base + 64), 16, 0, 0);
-        xsrc += adv ? (size_t)NWV * xblock : (size_t)0;
+    dg_u32x4 xh[NS], xl[NS];
+    auto issue = [&](int s) {
+        uint4 *const base = ring + s * REG_U4;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(xh[s]) : "v"(xsrc) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024 sc1" : "=&v"(xl[s]) : "v"(xsrc) : "memory");
+        xsrc += (size_t)NWV * xblock;
         // (lanes past the T x 16 rows are masked off: they neither request nor write)
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             if ((i + 1) * 64 <= 16 * T || i * 64 + lane < 16 * T)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)wsrc[i],
-                                                 (__attribute__((address_space(3))) void *)(base + 128 + i * 64), 16, 0, 0);
-            wsrc[i] += adv ? KL * 2 * TR * 16 * (NWV / 8) : 0;        // the same block of this wavefront's next group
+                                                 (__attribute__((address_space(3))) void *)(base + i * 64), 16, 0, DG_AUX);
+            wsrc[i] += KL * 2 * TR * 16 * (NWV / 8);        // the same block of this wavefront's next group
         }
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             if ((i + 1) * 64 <= 16 * T || i * 64 + lane < 16 * T)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)ssrc[i],
-                                                 (__attribute__((address_space(3))) void *)(base + 128 + 16 * T + i * 16), 4, 0, 0);
-            ssrc[i] += adv ? KL * TR * 4 * (NWV / 8) : 0;
+                                                 (__attribute__((address_space(3))) void *)(base + 16 * T + i * 16), 4, 0, DG_AUX);
+            ssrc[i] += KL * TR * 4 * (NWV / 8);
         }
     };
 
@@ -179,32 +195,25 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
             const char *const src = reinterpret_cast<const char *>(P.nrm_in.ssq + (size_t)tt * 16 * P.nrm_in.nrb);
             for (unsigned p0 = (unsigned)wv * 1024u; p0 < bytes; p0 += NWV * 1024u)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + min(p0 + lane * 16u, bytes - 16u)),
-                                                 (__attribute__((address_space(3))) void *)(lds_all + p0 / 16), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(lds_all + p0 / 16), 16, 0, DG_AUX);
         }
     }
-    // DEPTH steps, unconditionally (a wavefront with fewer blocks fetches its last one again into slots it never reads)
+    // all NS steps: fragments, nibbles, scales, in that order per step
 #pragma unroll
-    for (int s = 0; s < DEPTH; s++) issue(s, s + 1 < nsteps);
+    for (int s = 0; s < NS; s++) issue(s);
     asm volatile("" ::: "memory");
     DG_STAMP(1);
 
     f32x4_t acc[T];
 #pragma unroll
     for (int ti = 0; ti < T; ti++) acc[ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    int slot = 0, issued = DEPTH;      // steps requested so far
-    for (int s = 0; s < nsteps; s++) {
-        // step s has landed when at most the pieces of the steps issued after it are outstanding
-        const int after = issued - 1 - s;
-        if (after == DEPTH - 1) DG_WAIT_VM((DEPTH - 1) * PPS);
-        else if (DEPTH > 2 && after == DEPTH - 2) DG_WAIT_VM((DEPTH > 2 ? DEPTH - 2 : 0) * PPS);
-        else if (DEPTH > 3 && after == DEPTH - 3) DG_WAIT_VM((DEPTH > 3 ? DEPTH - 3 : 0) * PPS);
-        else if (DEPTH > 4 && after == DEPTH - 4) DG_WAIT_VM((DEPTH > 4 ? DEPTH - 4 : 0) * PPS);
-        else if (DEPTH > 5 && after == DEPTH - 5) DG_WAIT_VM((DEPTH > 5 ? DEPTH - 5 : 0) * PPS);
-        else DG_WAIT_VM(0);
-        asm volatile("" ::: "memory");
-        const uint4 *const sb = ring + slot * REG_U4;
-        const uint32_t *const sb32 = reinterpret_cast<const uint32_t *>(sb);
-        const half8_t xh = __builtin_bit_cast(half8_t, sb[lane]), xl = __builtin_bit_cast(half8_t, sb[64 + lane]);
+    dg_static_for<0, NS>([&](auto s_) {
+        constexpr int s = decltype(s_)::value;
+        // step s has landed when at most the operations of the steps issued after it are outstanding
+        DG_WAIT_VM((NS - 1 - s) * PPS);
+        asm volatile("" : "+v"(xh[s]), "+v"(xl[s]) :: "memory");          // (the fragment registers are read from here on)
+        const uint32_t *const sb32 = reinterpret_cast<const uint32_t *>(ring + s * REG_U4);
+        const half8_t xhv = __builtin_bit_cast(half8_t, xh[s]), xlv = __builtin_bit_cast(half8_t, xl[s]);
         // TG tiles at a time: TG independent MFMA chains (lo product, then hi product on the same accumulator)
         constexpr int TG = T == 8 ? 2 : T % 4 == 0 ? 4 : T % 3 == 0 ? 3 : T % 2 == 0 ? 2 : 1;
 #pragma unroll
@@ -214,13 +223,13 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
             f32x4_t z[TG];
 #pragma unroll
             for (int g = 0; g < TG; g++) {
-                a[g] = WFrag<WT_Q4_0>::expand(sb32[(128 + (t0 + g) * 16 + li) * 4 + lq]);
-                sw[g] = sb32[(128 + 16 * T) * 4 + (t0 + g) * 16 + li];
+                a[g] = WFrag<WT_Q4_0>::expand(sb32[((t0 + g) * 16 + li) * 4 + lq]);
+                sw[g] = sb32[(16 * T) * 4 + (t0 + g) * 16 + li];
             }
 #pragma unroll
-            for (int g = 0; g < TG; g++) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, a[g], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            for (int g = 0; g < TG; g++) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xlv, a[g], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < TG; g++) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, a[g], z[g], 0, 0, 0);
+            for (int g = 0; g < TG; g++) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xhv, a[g], z[g], 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < TG; g++) {
                 const float d = scale_of(sw[g], cc);
@@ -228,15 +237,11 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
                 for (int r = 0; r < 4; r++) acc[t0 + g][r] = fmaf(z[g][r], d, acc[t0 + g][r]);
             }
         }
-        asm volatile("" ::: "memory");
         DG_STAMP(2 + s);
-        if (s + DEPTH < nsteps) { issue(slot, true); issued++; }       // the slot just read out: nobody else touches it
-        slot = slot + 1 == DEPTH ? 0 : slot + 1;
-    }
+    });
     // ---- the NWV partial accumulators of a tile meet in LDS: D[token 4 lq + r][row li] goes out as [tile][token][row], the
     //      epilogue wavefronts read [row 4 lq ..][token li] back, partials in wavefront order ----
-    DG_WAIT_VM(0);      // (a wavefront with fewer blocks than slots still has its surplus requests in flight: they land in its own ring)
-    asm volatile("" ::: "memory");
+    if constexpr (T * 64 > NS * REG_U4) __syncthreads();      // (the partial tiles of a wavefront reach into its neighbour's weights)
     {
         float *const mine = reinterpret_cast<float *>(ring);
 #pragma unroll
@@ -255,7 +260,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
         e[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
         for (int w = 0; w < NWV; w++)      // (four reads in flight: fully unrolled, hipcc hoists all NWV x EG reads -- 256 registers)
-            e[g] += *reinterpret_cast<const f32x4_t *>(reinterpret_cast<const float *>(lds_all + SSQ_U4 + w * (DEPTH * REG_U4)) + ti * 256 + li * 16 + lq * 4);
+            e[g] += *reinterpret_cast<const f32x4_t *>(reinterpret_cast<const float *>(lds_all + SSQ_U4 + w * WAVE_U4) + ti * 256 + li * 16 + lq * 4);
     }
     // ---- folded RMSNorm, consumer side (QGemmParams::NormIn): inv of this lane's token from the producer's per-32-row sums of
     //      squares: lane lq adds partials lq, lq + 4, ... in ascending order, the four lanes of a token meet in lq order ----
@@ -373,32 +378,68 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
     }
 }
 
+// The block-major copy dgemm_kernel reads (P.q / P.s of its launches): within every 256-column group of a tile the 16-byte
+// chunks go from (parity c, row r, pair k) order to (pair k, parity c, row r), the scale words from (row, pair) to (pair, row).
+__global__ void dg_permute_kernel(const uint4 *q, const uint32_t *s, uint4 *q3, uint32_t *s3, long long ngroups) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < ngroups * 128; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = i >> 7;
+        const int u = (int)(i & 127), k = u >> 5, c = (u >> 4) & 1, r = u & 15;       // destination chunk (k, c, r)
+        q3[i] = q[g * 128 + (c * TR + r) * KL + k];
+        if (u < 64) s3[g * 64 + u] = s[g * 64 + (u & 15) * KL + (u >> 4)];           // destination word (pair u >> 4, row u & 15)
+    }
+}
+
 // grid.x of a dgemm launch: row groups padded to a multiple of 8 (the block -> XCD map), times the token tiles
 inline unsigned dg_grid(int ntiles, int tiles_per_wg, int n_tokens) {
     const int nrg = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
     return (unsigned)(((nrg + 7) / 8) * 8 * ((n_tokens + 15) / 16));
 }
 
-// the three launches of a layer: (tiles per workgroup, wavefronts); tools/dgemm_bench.hip measures them on goldie's shapes
-#ifndef DG_ROPE_GEOM
-#define DG_ROPE_GEOM 3, 16
-#endif
-#ifndef DG_SWIGLU_GEOM
-#define DG_SWIGLU_GEOM 8, 16
-#endif
-#ifndef DG_PLAIN_GEOM
-#define DG_PLAIN_GEOM 2, 16
-#endif
-template <int T, int NWV, int EPI>
+// the three launches of a layer: T = 3 (Q|K|V), 8 (gate || up), 2 (WO, down); the wavefront count and the blocks per wavefront
+// follow from K.  false: no instantiation for this K (the caller keeps the split-K launches)
+template <int T, int NWV, int NS, int EPI>
 inline hipError_t dg_launch(QGemmParams P, hipStream_t st) {
     P.nt16 = ((P.n_tokens + 63) / 64) * 4;
     P.ksplit = 1;
     constexpr int TILES_PER_WG = EPI == QG_EPI_SWIGLU ? T / 2 : T;
-    hipLaunchKernelGGL((dgemm_kernel<T, NWV, EPI>), dim3(dg_grid(P.ntiles, TILES_PER_WG, P.n_tokens)), dim3(NWV * 64), 0, st, P);
-    return hipGetLastError();
+    if constexpr (DgLds<T, NWV, NS, EPI != QG_EPI_PLAIN>::TOTAL_U4 * 16 <= DG_LDS_BYTES - 512) {
+        hipLaunchKernelGGL((dgemm_kernel<T, NWV, NS, EPI>), dim3(dg_grid(P.ntiles, TILES_PER_WG, P.n_tokens)), dim3(NWV * 64), 0, st, P);
+        return hipGetLastError();
+    } else return hipErrorInvalidValue;      // (the weights of NS steps do not fit the LDS: not instantiated)
 }
-inline hipError_t dg_launch_rope(const QGemmParams &P, hipStream_t st) { return dg_launch<DG_ROPE_GEOM, QG_EPI_ROPE>(P, st); }
-inline hipError_t dg_launch_swiglu(const QGemmParams &P, hipStream_t st) { return dg_launch<DG_SWIGLU_GEOM, QG_EPI_SWIGLU>(P, st); }
-inline hipError_t dg_launch_plain(const QGemmParams &P, hipStream_t st) { return dg_launch<DG_PLAIN_GEOM, QG_EPI_PLAIN>(P, st); }
+// wavefronts for a K of nb quant blocks: eight while that leaves a wavefront <= 8 blocks (measured faster than sixteen on every
+// K = 1536 launch: 7.85 / 5.7 / 11.75 us against 8.4 / 6.6 / 12.8, tools/dgemm_bench.hip), else sixteen; blocks per wavefront
+// in {1, 2, 3, 4, 6, 8}
+inline int dg_waves(int nb) { return nb <= 64 ? 8 : 16; }
+inline bool dg_cols_ok(int cols, int T, bool ssq) {
+    if (cols <= 0 || cols % 256) return false;
+    const int nb = cols / 32, nwv = dg_waves(nb), ns = nb / nwv;
+    if (nb % nwv || !(ns == 1 || ns == 2 || ns == 3 || ns == 4 || ns == 6 || ns == 8)) return false;
+    const int wave_u4 = std::max(ns * 20 * T, 64 * T);
+    return ((ssq ? DG_SSQ_BYTES / 16 : 0) + nwv * wave_u4) * 16 <= DG_LDS_BYTES - 512;
+}
+template <int T, int EPI>
+inline hipError_t dg_launch_k(const QGemmParams &P, hipStream_t st) {
+    const int nb = P.cols / 32, nwv = dg_waves(nb), ns = nb / nwv;
+    if (nwv == 16) {
+        switch (ns) {      // (nb > 64)
+        case 6: return dg_launch<T, 16, 6, EPI>(P, st);
+        case 8: return dg_launch<T, 16, 8, EPI>(P, st);
+        }
+    } else {
+        switch (ns) {
+        case 1: return dg_launch<T, 8, 1, EPI>(P, st);
+        case 3: return dg_launch<T, 8, 3, EPI>(P, st);
+        case 2: return dg_launch<T, 8, 2, EPI>(P, st);
+        case 4: return dg_launch<T, 8, 4, EPI>(P, st);
+        case 6: return dg_launch<T, 8, 6, EPI>(P, st);
+        case 8: return dg_launch<T, 8, 8, EPI>(P, st);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+inline hipError_t dg_launch_rope(const QGemmParams &P, hipStream_t st) { return dg_launch_k<3, QG_EPI_ROPE>(P, st); }
+inline hipError_t dg_launch_swiglu(const QGemmParams &P, hipStream_t st) { return dg_launch_k<8, QG_EPI_SWIGLU>(P, st); }
+inline hipError_t dg_launch_plain(const QGemmParams &P, hipStream_t st) { return dg_launch_k<2, QG_EPI_PLAIN>(P, st); }
 
 }  // namespace nl

@@ -57,6 +57,8 @@ struct PackedMat {
     uint32_t *s = nullptr;
     uint8_t *q2 = nullptr;       // Q4_0 matrices the wide fused launches multiply on the matrix pipe: the same bytes with the chunks of
     uint32_t *s2 = nullptr;      // every (tile, 256-column group) permuted so that a quad of lanes holds four ROWS of a block (nl_tp.h)
+    uint8_t *q3 = nullptr;       // Q4_0 layer matrices of a model whose short multi-token steps run on dgemm_kernel: the block-major copy
+    uint32_t *s3 = nullptr;      // (nl_dgemm.h dg_permute_kernel), built at the first such step
     int wtype = -1, src_type = -1, rows = 0, cols = 0, ntiles = 0, npairs = 0;  // wtype = device layout type
     size_t q_bytes = 0, s_bytes = 0;
     bool ready = false;
@@ -219,6 +221,7 @@ struct nl_engine {
         struct G { int n, nsplit; hipGraph_t graph; hipGraphExec_t exec; };
         std::vector<G> graphs;
     } sub[4];
+    int dg_state = 0;             // dgemm_kernel's weight copies: 0 not looked at yet, 1 built, -1 the model does not qualify
     std::vector<SubBatch::G> bt_graphs;   // step graphs of the whole-batch decode step (bt), same key
     hipEvent_t sub_fork = nullptr;
     int sub_batches = 1;          // NL_SUB_BATCHES: groups a decode batch is cut into (1 = the whole batch as one step: measured fastest, profiles/r04_subbatch_groups.log)
@@ -1678,8 +1681,8 @@ hipError_t launch_qgemm(int wtype, QGemmParams P, hipStream_t st, float *part_bu
 }
 
 // ---- short token runs on dgemm_kernel (nl_dgemm.h): Q4_0, whole 256-column groups, 32-row producer blocks ----
-bool dgemm_mat_ok(const PackedMat &m, bool rows32) {
-    return m.wtype == WT_Q4_0 && m.cols % 256 == 0 && m.cols > 0 && (!rows32 || m.rows % 32 == 0) && m.ntiles * TR == m.rows;
+bool dgemm_mat_ok(const PackedMat &m, bool rows32, int T, bool ssq) {
+    return m.wtype == WT_Q4_0 && dg_cols_ok(m.cols, T, ssq) && (!rows32 || m.rows % 32 == 0) && m.ntiles * TR == m.rows;
 }
 hipError_t launch_dgemm_rope(const QGemmParams &P, hipStream_t st) { return dg_launch_rope(P, st); }
 hipError_t launch_dgemm_swiglu(const QGemmParams &P, hipStream_t st) { return dg_launch_swiglu(P, st); }
@@ -1752,20 +1755,45 @@ int batch_alloc(nl_engine *e, nl_engine::Batch &b, int cap_limit = 2048) {
     return NL_OK;
 }
 
-// a multi-token step of <= NL_DGEMM_MAX_TOKENS tokens whose layer matrices are all Q4_0 with whole 256-column groups runs its
-// five GEMM-shaped launches per layer on dgemm_kernel (nl_dgemm.h) with the RMSNorms folded around them
+// a multi-token step of <= NL_DGEMM_MAX_TOKENS tokens of a model whose layer matrices are all Q4_0 with whole 256-column groups
+// runs its five GEMM-shaped launches per layer on dgemm_kernel (nl_dgemm.h) with the RMSNorms folded around them
+bool dgemm_model_ok(const nl_engine *e) {
+    const nl_config &c = e->cfg;
+    if (c.qk_norm || c.dim % 32 || c.n_layers <= 0 || c.dim / 32 > DG_SSQ_MAX_NRB) return false;   // (nrb: the consumer's LDS area for the partial sums of squares)
+    for (const auto &L : e->layers)
+        if (!dgemm_mat_ok(L.qkv, false, 3, true) || !dgemm_mat_ok(L.wo, true, 2, false) || !dgemm_mat_ok(L.gate, true, 8, true) ||
+            !dgemm_mat_ok(L.up, true, 8, true) || !dgemm_mat_ok(L.down, true, 2, false) || L.gate.rows != L.up.rows || L.gate.rows % 64 ||
+            L.wo.rows != c.dim || L.down.rows != c.dim)
+            return false;
+    return true;
+}
+// the block-major weight copies dgemm_kernel reads, once per handle, at its first multi-token step (outside any capture; the
+// caller holds g_setup_mu)
+int dgemm_prepare(nl_engine *e) {
+    if (e->dg_state) return NL_OK;
+    e->dg_state = -1;
+    if (getenv("NL_DGEMM") && atoi(getenv("NL_DGEMM")) == 0) { e->dg_state = 0; return NL_OK; }     // (knob: looked at again next step)
+    if (!batch_supported(e) || !dgemm_model_ok(e)) return NL_OK;
+    for (auto &L : e->layers)
+        for (PackedMat *m : {&L.qkv, &L.wo, &L.gate, &L.up, &L.down}) {
+            HIPCK(e, arena_alloc(e, (void **)&m->q3, m->q_bytes));
+            HIPCK(e, arena_alloc(e, (void **)&m->s3, m->s_bytes));
+            e->bytes_weights += m->q_bytes + m->s_bytes;
+            const long long groups = (long long)m->ntiles * (m->npairs / KL);
+            hipLaunchKernelGGL(dg_permute_kernel, dim3((unsigned)std::min<long long>((groups * 128 + 255) / 256, 65535)), dim3(256), 0, e->stream,
+                               reinterpret_cast<const uint4 *>(m->q), m->s, reinterpret_cast<uint4 *>(m->q3), m->s3, groups);
+            HIPCK(e, hipGetLastError());
+        }
+    HIPCK(e, hipStreamSynchronize(e->stream));
+    e->dg_state = 1;
+    return NL_OK;
+}
 bool dgemm_step_ok(const nl_engine *e, int n) {
+    if (e->dg_state != 1) return false;
     const char *k = getenv("NL_DGEMM");                 // knob (tests, tools; read per step): 0 keeps the split-K launches
     if (k && atoi(k) == 0) return false;
     const char *mk = getenv("NL_DGEMM_MAX_TOKENS");
-    const int max_n = mk ? atoi(mk) : 64;
-    const nl_config &c = e->cfg;
-    if (n > max_n || c.qk_norm || c.dim % 32 || c.n_layers <= 0) return false;
-    for (const auto &L : e->layers)
-        if (!dgemm_mat_ok(L.qkv, false) || !dgemm_mat_ok(L.wo, true) || !dgemm_mat_ok(L.gate, true) || !dgemm_mat_ok(L.up, true) ||
-            !dgemm_mat_ok(L.down, true) || L.gate.rows != L.up.rows || L.wo.rows != c.dim || L.down.rows != c.dim)
-            return false;
-    return c.dim / 32 <= DG_SSQ_MAX_NRB;       // (the consumer's LDS area for the partial sums of squares)
+    return n <= (mk ? atoi(mk) : 64);
 }
 
 // GEMM of the multi-token step: input = the fragment store the producing kernel just filled; output = `out`
@@ -1913,7 +1941,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
             // Q|K|V, RoPE, biases and the KV store in ONE launch (QK-norm needs whole heads: unfused path)
             QGemmParams P{};
             const PackedMat &m = L.qkv;
-            P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
+            P.q = dg ? m.q3 : m.q; P.s = dg ? m.s3 : m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
             P.xf = folded_in ? b.xfrag2 : b.xfrag; P.nrm_in = folded_in ? nin_attn : nin_off;
             P.n_tokens = n; P.ldo = (int)R; P.x1 = x1_gemm;
             P.rope = QGemmParams::Rope{b.pos, b.stream, e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride,
@@ -1990,7 +2018,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
         // dgemm_kernel's producer GEMM: x += W . in (+ bias), the next GEMM's fragments and sums of squares from its epilogue
         auto dg_plain = [&](const PackedMat &m, const uint4 *in, const float *bias, const QGemmParams::NormOut *nout) {
             QGemmParams P{};
-            P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
+            P.q = m.q3; P.s = m.s3; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
             P.xf = in; P.n_tokens = n; P.out = b.x; P.ldo = D; P.resid = b.x; P.bias = bias;
             if (nout) P.nrm_out = *nout;
             pend = GemmOut{b.x, nullptr, 1, (long long)n * D, nullptr};
@@ -2014,10 +2042,10 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
             // (the first is still being read by other workgroups of this launch)
             QGemmParams P{};
             const PackedMat &m = L.gate;
-            P.q = m.q; P.s = m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
+            P.q = dg ? m.q3 : m.q; P.s = dg ? m.s3 : m.s; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
             P.xf = fold ? b.xfrag2 : b.xfrag; P.nrm_in = fold ? nin_ffn : nin_off;
             P.n_tokens = n; P.ldo = e->Is; P.x1 = x1_gemm;
-            P.q1 = L.up.q; P.s1 = L.up.s;
+            P.q1 = dg ? L.up.q3 : L.up.q; P.s1 = dg ? L.up.s3 : L.up.s;
             P.xf_out = fold ? b.xfrag : b.xfrag2; P.out_q4 = L.down.wtype == WT_Q4_0 ? 1 : 0;
             LCK(dg ? launch_dgemm_swiglu(P, st) : launch_qgemm_swiglu(m.wtype, P, st));
             down_in = P.xf_out;
@@ -3331,7 +3359,7 @@ int nl_prefill(nl_handle e, int stream, const int *tokens, int n, int pos0, floa
     if ((rc = note_positions(e, stream, pos0, n))) return rc;
     if (n >= NL_BATCH_MIN && batch_supported(e)) {
         // multi-token path: 64-token tiles on the matrix cores; causality comes from each token's own pos
-        { std::lock_guard<std::mutex> setup(g_setup_mu); if ((rc = batch_alloc(e, e->bt))) return rc; }
+        { std::lock_guard<std::mutex> setup(g_setup_mu); if ((rc = batch_alloc(e, e->bt)) || (rc = dgemm_prepare(e))) return rc; }
         nl_engine::Batch &b = e->bt;
         for (int t0 = 0; t0 < n; t0 += b.cap) {
             const int m = std::min(b.cap, n - t0);
@@ -3418,7 +3446,7 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
                 const int m = std::min(per, n - t0);
                 if (m <= 0) break;
                 nl_engine::SubBatch &sb = e->sub[g];
-                { std::lock_guard<std::mutex> setup(g_setup_mu); if ((rc = batch_alloc(e, sb.bt, QG_TOK))) return rc; }
+                { std::lock_guard<std::mutex> setup(g_setup_mu); if ((rc = batch_alloc(e, sb.bt, QG_TOK)) || (rc = dgemm_prepare(e))) return rc; }
                 if (!sb.st) {
                     HIPCK(e, hipStreamCreateWithFlags(&sb.st, hipStreamNonBlocking));
                     HIPCK(e, hipEventCreateWithFlags(&sb.done, hipEventDisableTiming));
@@ -3475,7 +3503,7 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
             HIPCK(e, hipStreamSynchronize(e->stream));
             return NL_OK;
         }
-        { std::lock_guard<std::mutex> setup(g_setup_mu); if ((rc = batch_alloc(e, e->bt))) return rc; }
+        { std::lock_guard<std::mutex> setup(g_setup_mu); if ((rc = batch_alloc(e, e->bt)) || (rc = dgemm_prepare(e))) return rc; }
         nl_engine::Batch &b = e->bt;
         for (int t0 = 0; t0 < n; t0 += b.lm_cap) {
             const int m = std::min(b.lm_cap, n - t0);

@@ -36,7 +36,7 @@ int main(int argc, char **argv) {
     auto mk = [&](int rows, int cols) {
         Mat m{}; m.rows = rows; m.cols = cols; m.ntiles = rows / 16; m.npairs = cols / 64;
         m.qbytes = (size_t)m.ntiles * m.npairs * 2 * TR * 16; m.swords = (size_t)m.ntiles * m.npairs * TR;
-        m.copies = (int)std::max<size_t>(2, ((size_t)300 << 20) / m.qbytes);
+        m.copies = getenv("DG_COPIES") ? atoi(getenv("DG_COPIES")) : (int)std::max<size_t>(2, ((size_t)300 << 20) / m.qbytes);   // DG_COPIES=1: the same weights every launch (L2 / Infinity Cache warm)
         CK(hipMalloc(&m.q, m.qbytes * m.copies)); CK(hipMalloc(&m.s, m.swords * 4 * m.copies));
         fill_u32<<<2048, 256, 0, st>>>((uint32_t *)m.q, m.qbytes * m.copies / 4, 1, 0xffffffffu, 0);
         fill_u32<<<2048, 256, 0, st>>>(m.s, m.swords * m.copies, 2, 0x03ff03ffu, 0x20002000u);     // fp16 scales ~2^-7
