@@ -2860,9 +2860,24 @@ int nl_finalize(nl_handle e) {
 // Gamma essence (go/gamma.go): embed[token] += gamma[token] for the listed tokens (go/model.go:503-505).
 // indices: n token ids; values: [n][dim] float32, or raw IEEE binary16 when is_f16.  n == 0 clears it.
 int nl_set_gamma(nl_handle e, const int32_t *indices, int n, const void *values, int is_f16) {
-    if (e && e->grp) return group_run(e, [&](nl_engine *m, int) { return nl_set_gamma(m, indices, n, values, is_f16); });
+    if (e && e->grp) {
+        // one rank after the other, as nl_finalize: the body allocates, frees and re-captures graphs, none of which may overlap
+        // another thread's capture.  A rank that fails keeps its old table (the body only swaps on success); the ranks before it
+        // are put back to "no gamma" and the call reports the error, so the ranks never decode with different embeddings.
+        for (size_t r = 0; r < e->grp->members.size(); r++) {
+            const int rc = nl_set_gamma(e->grp->members[r], indices, n, values, is_f16);
+            if (rc != NL_OK) {
+                e->err = "rank " + std::to_string(r) + ": " + e->grp->members[r]->err;
+                for (size_t q = 0; q <= r; q++) (void)nl_set_gamma(e->grp->members[q], nullptr, 0, nullptr, 0);
+                for (size_t q = r + 1; q < e->grp->members.size(); q++) (void)nl_set_gamma(e->grp->members[q], nullptr, 0, nullptr, 0);
+                return rc;
+            }
+        }
+        return NL_OK;
+    }
     if (!e || n < 0 || (n > 0 && (!indices || !values))) return NL_ERR_INVALID;
     const nl_config &c = e->cfg;
+    std::lock_guard<std::mutex> setup(g_setup_mu);      // (allocations, frees and graph captures below)
     HIPCK(e, hipSetDevice(e->dev));
     if (int qrc = pd_session_close(e)) return qrc;
     HIPCK(e, hipStreamSynchronize(e->stream));

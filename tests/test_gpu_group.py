@@ -127,6 +127,61 @@ print("group of 8 ok")
     assert r.returncode == 0 and "group of 8 ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def test_group_takes_gamma_and_decode_batches_rank_by_rank(tmp_path):
+    # nl_set_gamma on a group handle swaps the embedding table of one rank after the other (allocations, frees and graph
+    # captures must not overlap another rank thread's capture); nl_forward_batch on a group steps every stream through the rank
+    # engines.  Both against the oracle (go/model.go:503-505 gamma, :510-612 per stream), gamma on and off again.
+    shape = synth.ModelShape("grp_gamma", 2, 512, 8, 4, 1024, seq_len=64, interm=1024)
+    p = str(tmp_path / "m.gguf")
+    synth.generate_gguf(p, shape, "q4_0", 73, mode="qrand")
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {ROOT!r})
+from nanollama_amd import gguf, model, synth
+from oracle import oracle as orc
+g = gguf.load_gguf({p!r})
+grp = model.load_llama_model(g, devices=[0, 0], max_streams=4)
+rng = np.random.Generator(np.random.PCG64(3))
+idx = np.array([5, 9, 700], dtype=np.int32)
+vals = (rng.standard_normal((3, 512)) * 0.3).astype(np.float32)
+toks = [5, 11, 9, 700, 3]
+def run(with_gamma):
+    refs = [orc.OracleModel(g) for _ in range(3)]
+    if with_gamma:
+        for r in refs: r.set_gamma(idx, vals)
+    worst = 0.0
+    grp.reset()
+    for s in range(1, 3): grp.reset(stream=s)
+    for pos, t in enumerate(toks):
+        grp.forward(t, pos)
+        want = refs[0].forward(t, pos)
+        worst = max(worst, float(np.abs(grp.state.logits - want).max()) / max(1.0, float(want.std())))
+    # three streams stepped together (stream 0 continues, 1 and 2 start): every stream's logits
+    for k in range(3):
+        st, tk, ps = [0, 1, 2], [toks[k], toks[k + 1], 700 if k == 0 else 9], [len(toks) + k, k, k]
+        ids, lg = grp.forward_batch(st, tk, ps, want_logits=True)
+        for j in range(3):
+            want = refs[j].forward(tk[j], ps[j])
+            worst = max(worst, float(np.abs(lg[j] - want).max()) / max(1.0, float(want.std())))
+            assert ids[j] == int(orc.argmax(want)), (k, j)
+    for r in refs: r.close()
+    return worst
+w0 = run(False)
+grp.set_gamma(idx, vals)
+w1 = run(True)
+grp.set_gamma([], np.zeros((0, 512), np.float32))
+w2 = run(False)
+assert max(w0, w1, w2) <= 1e-4, (w0, w1, w2)
+assert grp.last_error() == "", grp.last_error()
+grp.close()
+print(f"group gamma + batches ok: {{w0:.2e}} {{w1:.2e}} {{w2:.2e}}")
+"""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", NL_P2P_TIMEOUT_MS="5000")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "group gamma + batches ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    print("\n" + r.stdout.strip().splitlines()[-1])
+
+
 def test_group_rejects_what_it_cannot_shard(hip, tmp_path):
     from nanollama_amd import _lib
     shape = synth.ModelShape("grp_bad", 2, 256, 4, 2, 512, seq_len=32, interm=512)      # 2 kv heads: no 4-way shard
