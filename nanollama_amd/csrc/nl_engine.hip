@@ -1341,14 +1341,14 @@ int pd_build(nl_engine *e) {
     HIPCK(e, hipMemset(d.census, 0, 32 * sizeof(unsigned)));
     HIPCK(e, dalloc(&d.gtok, (size_t)2, &e->bytes_state));
     HIPCK(e, hipMemset(d.gtok, 0, 16));
-    HIPCK(e, hipHostMalloc((void **)&d.h_mail, 16 * sizeof(pd_u64), hipHostMallocMapped));
+    HIPCK(e, hipHostMalloc((void **)&d.h_mail, 16 * sizeof(pd_u64), hipHostMallocMapped | hipHostMallocCoherent));   // (coherent by request, not by HIP_HOST_COHERENT's default: both sides poll these words)
     memset(d.h_mail, 0, 16 * sizeof(pd_u64));
     if (hipHostGetDevicePointer((void **)&d.d_mail, d.h_mail, 0) != hipSuccess) { (void)hipGetLastError(); d.d_mail = nullptr; }
     HIPCK(e, dalloc(&d.status, (size_t)4, &e->bytes_state));
     HIPCK(e, hipMemset(d.status, 0, 16));
     HIPCK(e, dalloc(&d.dbg, (size_t)64, &e->bytes_state));
     HIPCK(e, hipMemset(d.dbg, 0, 64 * sizeof(long long)));
-    HIPCK(e, hipHostMalloc((void **)&d.h_status, sizeof(unsigned), hipHostMallocMapped));
+    HIPCK(e, hipHostMalloc((void **)&d.h_status, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
     *d.h_status = 0;
     const void *kfn = c.dim == 576 ? reinterpret_cast<const void *>(pd_decode_kernel<18, 48>) : reinterpret_cast<const void *>(pd_decode_kernel<8, 16>);
     if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd_lds_bytes()) != hipSuccess) {
@@ -1430,12 +1430,33 @@ bool pd_take_timeout(nl_engine *e) {
 // End the session (if one is live): a quit in the mailbox, the doorman sets the status bit every poll of the launch watches,
 // the launch drains.  Every entry point that enqueues work behind e->stream calls this first -- not for correctness (work
 // behind the stream waits for the launch, which ends by itself idle_ticks after its last command) but so as not to wait.
+// A resident launch fills every compute unit of its device: a launch of ANOTHER handle on that device (two models in one server)
+// would find no place until the session idles out.  One live session per device is on record; whoever is about to queue work on
+// the device posts a quit into the other handle's mailbox first (its owner finds the launch gone at its next call and starts
+// another: the idle-out path).  Best effort: if the owner posts a token at the same moment the quit is lost and the newcomer
+// waits out the idle limit, as before.
+std::mutex g_sess_mu;
+nl_engine *g_live_session[64] = {};
+void pd_yield_device(nl_engine *e) {
+    if (e->dev < 0 || e->dev >= 64) return;
+    std::lock_guard<std::mutex> lk(g_sess_mu);
+    nl_engine *o = g_live_session[e->dev];
+    if (o && o != e && o->pd.h_mail) __atomic_store_n(o->pd.h_mail, (pd_u64)0xffffffffu, __ATOMIC_RELEASE);
+}
+void pd_session_record(nl_engine *e, bool live) {
+    if (e->dev < 0 || e->dev >= 64) return;
+    std::lock_guard<std::mutex> lk(g_sess_mu);
+    if (live) g_live_session[e->dev] = e;
+    else if (g_live_session[e->dev] == e) g_live_session[e->dev] = nullptr;
+}
+
 int pd_session_close(nl_engine *e) {
     nl_engine::Persist &d = e->pd;
-    if (!d.live) return NL_OK;
+    if (!d.live) { pd_yield_device(e); return NL_OK; }
     __atomic_store_n(d.h_mail, (pd_u64)0xffffffffu, __ATOMIC_RELEASE);
     HIPCK(e, hipStreamSynchronize(e->stream));
     d.live = false;
+    pd_session_record(e, false);
     const unsigned st = *d.h_status;
     if (st & 256u) {                       // the clean end (quit or idle); every other bit is a poll that saw it
         *d.h_status = 0;
@@ -1464,8 +1485,10 @@ int pd_session_step(nl_engine *e, int stream, int token, int pos, bool want_logi
             const int n = std::min(d.max_pos - pos, e->ids_cap);
             __atomic_store_n(d.h_mail, (pd_u64)0, __ATOMIC_RELAXED);
             __atomic_store_n(d.h_mail + 8, (pd_u64)0, __ATOMIC_RELEASE);
+            pd_yield_device(e);
             if ((rc = pd_launch(e, stream, token, pos, n, want_logits ? e->d_h_logits : nullptr, true))) return rc;
             d.tokens -= n;              // (pd_launch counted the whole session; steps are counted as they are served)
+            pd_session_record(e, true);
             d.live = true; d.s_logits = want_logits; d.s_stream = stream; d.s_next_pos = pos; d.s_step = 0; d.s_nsteps = n;
             d.sessions++;
         } else {
@@ -2315,6 +2338,9 @@ int nl_create_group(const nl_config *cfg, const int *device_ids, int n, nl_handl
     for (int r = 0; r < n; r++) {
         nl_engine::P2P &p = g->members[r]->p2p;
         for (int q = 0; q < n; q++) p.peer[q] = g->members[q]->p2p.area;       // plain peer pointers: one address space in one process
+        if (!p.uncached)      // NL_P2P_CACHED test knob: only sound while every rank shares this device's L2 (as nl_p2p_import checks)
+            for (int q = 0; q < n; q++)
+                if (device_ids[q] != device_ids[r]) return fail(NL_ERR_UNSUPPORTED, "NL_P2P_CACHED is a one-device test knob: rank " + std::to_string(q) + " lives on device " + std::to_string(device_ids[q]));
         p.on = true;
     }
     g->rc.assign(n, NL_OK);
@@ -2611,7 +2637,7 @@ int nl_finalize(nl_handle e) {
     HIPCK(e, hipHostMalloc((void **)&e->h_ctl, CTL_WORDS * sizeof(int), hipHostMallocDefault));
     memset(e->h_ctl, 0, CTL_WORDS * sizeof(int));
     if (e->h_logits) { hipHostFree(e->h_logits); e->h_logits = nullptr; }
-    HIPCK(e, hipHostMalloc((void **)&e->h_logits, ((size_t)c.vocab + 4) * sizeof(float), hipHostMallocMapped));
+    HIPCK(e, hipHostMalloc((void **)&e->h_logits, ((size_t)c.vocab + 4) * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));   // (the resident session's LM-head units store logits straight into it)
     e->d_h_logits = nullptr;
     if (hipHostGetDevicePointer((void **)&e->d_h_logits, e->h_logits, 0) != hipSuccess) { (void)hipGetLastError(); e->d_h_logits = nullptr; }
     if (getenv("NL_NO_HOST_LOGITS")) e->d_h_logits = nullptr;      // knob (A/B): the DMA read-back
@@ -2804,7 +2830,7 @@ int nl_finalize(nl_handle e) {
             HIPCK(e, hipMemset(e->xchg, 0, nx * 8));
             HIPCK(e, dalloc(&e->tick, (size_t)2, &e->bytes_state));
             HIPCK(e, hipMemset(e->tick, 0, 8));
-            HIPCK(e, hipHostMalloc((void **)&e->h_status, sizeof(unsigned), hipHostMallocMapped));
+            HIPCK(e, hipHostMalloc((void **)&e->h_status, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
             *e->h_status = 0;
         }
         if (e->fused_mode == 3 || e->fused_mode == 4) {
@@ -2939,6 +2965,7 @@ int nl_destroy(nl_handle e) {
     if (!e) return NL_OK;
     hipSetDevice(e->dev);
     (void)pd_session_close(e);
+    pd_session_record(e, false);
     hipDeviceSynchronize();
     samp_free(e->sp);
     for (auto &S : e->ps) destroy_graphs(S);
@@ -3715,6 +3742,7 @@ int64_t nl_debug_read(nl_handle e, const char *which, int stream, float *out, in
 
 // Phase timestamps (shader clock) of workgroup 0 for GEMV kind `kind` of layer 0; tools/ only.
 int nl_debug_stamps(nl_handle e, int kind, long long *out /* 16 waves x 8 */) {
+    if (e && e->grp) return e->fail(NL_ERR_UNSUPPORTED, "nl_debug_stamps on a device group: the leader holds no layers (profile one rank)");
     if (!e || !e->finalized || !out) return NL_ERR_INVALID;
     HIPCK(e, hipSetDevice(e->dev));
     if (int qrc = pd_session_close(e)) return qrc;
@@ -4023,6 +4051,7 @@ int nl_comm_get_unique_id(void *id_out) {
 }
 
 int nl_comm_init(nl_handle e, const void *id) {
+    if (e && e->grp) return e->fail(NL_ERR_UNSUPPORTED, "nl_comm_init on a device group: nl_create_group wires its ranks itself");
     if (!e || !id) return NL_ERR_INVALID;
     if (e->finalized) return e->fail(NL_ERR_STATE, "nl_comm_init after nl_finalize");
     if (e->G <= 1 && !e->force_tp_plan) return NL_OK;
@@ -4075,6 +4104,7 @@ int p2p_alloc_area(nl_engine *e) {
 }  // namespace
 
 int nl_p2p_export(nl_handle e, void *handle_out) {
+    if (e && e->grp) return e->fail(NL_ERR_UNSUPPORTED, "nl_p2p_export on a device group: nl_create_group wires its ranks itself");
     if (!e || !handle_out) return NL_ERR_INVALID;
     if (e->finalized) return e->fail(NL_ERR_STATE, "nl_p2p_export after nl_finalize");
     if (e->G < 2) return e->fail(NL_ERR_INVALID, "nl_p2p_export needs tp_size >= 2");
@@ -4095,6 +4125,7 @@ int nl_p2p_export(nl_handle e, void *handle_out) {
 }
 
 int nl_p2p_import(nl_handle e, const void *handles) {
+    if (e && e->grp) return e->fail(NL_ERR_UNSUPPORTED, "nl_p2p_import on a device group: nl_create_group wires its ranks itself");
     if (!e || !handles) return NL_ERR_INVALID;
     if (e->finalized) return e->fail(NL_ERR_STATE, "nl_p2p_import after nl_finalize");
     nl_engine::P2P &p = e->p2p;
@@ -4124,6 +4155,7 @@ int nl_p2p_loopback(nl_handle e) {
     // its partial into all G rank-slots itself, so only the xGMI hop is missing.  The residual stream then holds
     // G x this rank's partial sums: timings are real, logits are NOT a model's.
     if (!e) return NL_ERR_INVALID;
+    if (e->grp) return e->fail(NL_ERR_UNSUPPORTED, "nl_p2p_loopback on a device group: a measurement mode of ONE rank");
     if (e->finalized) return e->fail(NL_ERR_STATE, "nl_p2p_loopback after nl_finalize");
     unsigned char h[NL_P2P_HANDLE_BYTES];
     int rc = nl_p2p_export(e, h);            // allocates the (uncached) area exactly as a real rank does

@@ -410,6 +410,33 @@ def test_nano_true_shape_resident_session_and_chained_decode_across_every_pass_c
     dev.close(); plain.close()
 
 
+def test_two_handles_on_one_device_do_not_wait_out_each_others_sessions(hip, orc, tmp_path):
+    # a resident launch fills every compute unit; a second handle on the device (two models in one server) posts a quit into the
+    # first one's mailbox before it queues work instead of waiting for the 2 ms idle limit: alternating calls stay correct and
+    # cost far less than an idle-out each
+    import time
+    shape = synth.ModelShape("pd_two", 5, 256, 4, 4, 512, seq_len=64, interm=512)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 173)
+    g = gguf.load_gguf(str(p))
+    tokens = synth.prompt_ids(24, shape.vocab, seed=31)
+    want = _teacher_forced(orc, g, tokens)
+    a, b = hip.load_llama_model(g), hip.load_llama_model(g)
+    assert a.persist_info()["ready"] and b.persist_info()["ready"]
+    a.forward(tokens[0], 0); b.forward(tokens[0], 0)        # (first launches: images, graphs)
+    t0 = time.perf_counter()
+    for pos in range(1, 24):
+        a.forward(tokens[pos], pos)
+        assert _rel(a.state.logits, want[pos]) <= LOGIT_TOL, pos
+        b.forward(tokens[pos], pos)
+        assert _rel(b.state.logits, want[pos]) <= LOGIT_TOL, pos
+    dt = (time.perf_counter() - t0) / 46
+    print(f"\ntwo handles alternating on one device: {dt * 1e3:.3f} ms per call")
+    assert dt < 1.2e-3, dt          # (an idle-out per call would be >= 2 ms)
+    assert a.last_error() == "" and b.last_error() == ""
+    a.close(); b.close()
+
+
 def test_shapes_outside_the_instantiations_keep_the_launch_plans(hip, tmp_path):
     # GQA, other widths, other weight types: not candidates (the launch plans serve them as before)
     for shape, wt in ((synth.ModelShape("pd_gqa", 2, 256, 4, 2, 512, seq_len=64, interm=512), "q8_0"),
