@@ -16,8 +16,11 @@
  * caller pointer is retained after a call returns (cgo pointer rule), all
  * sizes are explicit.  A handle is single-caller / non-reentrant, like the Go
  * engine (one Engine per process, HTTP handler under a mutex, go/serve.go:56).
- * One process drives one GPU; tensor-parallel runs are one process per GPU
- * (tp_rank / tp_size) joined by an RCCL communicator (nl_comm_*).
+ * Placement: nl_create drives ONE GPU; a model sharded tensor-parallel over the
+ * GPUs of a node is either ONE process holding a group handle (nl_create_group:
+ * what the drop-in Go host uses, because the reference is one process) or one
+ * process per GPU (tp_rank / tp_size) joined by the push all-reduce
+ * (nl_p2p_export / nl_p2p_import) or an RCCL communicator (nl_comm_*).
  */
 #ifndef NANOLLAMA_HIP_H
 #define NANOLLAMA_HIP_H
@@ -72,6 +75,16 @@ NL_API const char *nl_build_info(void);
 
 /* == LoadLlamaModel (go/model.go:121-174) ================================== */
 NL_API int nl_create(const nl_config *cfg, nl_handle *out);
+/* LoadLlamaModel for a model sharded tensor-parallel over n GPUs of THIS process (go/main.go:63 LoadLlamaModel is one process,
+ * go/serve.go:54-108 one engine behind a mutex; BASELINE's 7.9B tier shards across the node's 8 GPUs).  The handle is used
+ * exactly like nl_create's: nl_upload_tensor takes the FULL tensors (every rank keeps its rows / columns), then nl_finalize,
+ * nl_forward, nl_forward_argmax, nl_decode_greedy, nl_sample_decode, nl_prefill, nl_forward_batch, nl_reset, nl_destroy.
+ * Behind it: n rank engines (tp_rank r on device_ids[r]; n = 2, 4 or 8), heads / FFN rows / vocabulary split by rows,
+ * WO / down by columns, the 2 L seams of a token closed by the push all-reduce (above nl_p2p_export) through plain peer
+ * pointers (hipDeviceEnablePeerAccess), each rank stepped by its own host thread.  cfg->tp_size is ignored (or must equal n),
+ * cfg->device is ignored.  device_ids may repeat -- every rank on one device is the one-GPU test configuration, bitwise
+ * equal to the in-process shard group below.  Errors: NL_ERR_UNSUPPORTED when a device cannot reach a peer. */
+NL_API int nl_create_group(const nl_config *cfg, const int *device_ids, int n, nl_handle *out);
 /* loadWeights (go/model.go:177-265): one call per GGUF tensor, by its GGUF
  * name, with the FULL tensor as stored in the file (raw block bytes, rows x
  * cols in row-major [out,in] order; 1-D tensors: rows = 1).  The bytes are
@@ -152,16 +165,6 @@ NL_API int nl_forward_batch(nl_handle h, const int *streams, const int *tokens, 
                             float *logits_out, int *next_ids);
 
 /* == introspection / measurement ========================================== */
-/* LoadLlamaModel for a model sharded tensor-parallel over n GPUs of THIS process (go/main.go:63 LoadLlamaModel is one process,
- * go/serve.go:54-108 one engine behind a mutex; BASELINE's 7.9B tier shards across the node's 8 GPUs).  The handle is used
- * exactly like nl_create's: nl_upload_tensor takes the FULL tensors (every rank keeps its rows / columns), then nl_finalize,
- * nl_forward, nl_forward_argmax, nl_decode_greedy, nl_sample_decode, nl_prefill, nl_forward_batch, nl_reset, nl_destroy.
- * Behind it: n rank engines (tp_rank r on device_ids[r]; n = 2, 4 or 8), heads / FFN rows / vocabulary split by rows,
- * WO / down by columns, the 2 L seams of a token closed by the push all-reduce (above nl_p2p_export) through plain peer
- * pointers (hipDeviceEnablePeerAccess), each rank stepped by its own host thread.  cfg->tp_size is ignored (or must equal n),
- * cfg->device is ignored.  device_ids may repeat -- every rank on one device is the one-GPU test configuration, bitwise
- * equal to the in-process shard group below.  Errors: NL_ERR_UNSUPPORTED when a device cannot reach a peer. */
-NL_API int nl_create_group(const nl_config *cfg, const int *device_ids, int n, nl_handle *out);
 NL_API int nl_get_config(nl_handle h, nl_config *out); /* effective config (after seq_len cap etc.) */
 NL_API int nl_synchronize(nl_handle h);
 /* HIP events recorded on the engine's own stream (torch.cuda.Event would not

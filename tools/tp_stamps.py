@@ -47,6 +47,9 @@ for rep in range(3):
             m = c[kind][:, 0] > 0
             ent, ext = c[kind][m, 0], c[kind][m, 1]
             done = ext > 0
+            if not m.any() or not done.any():      # (a launch that keeps no census: wide_ffn_kernel on one GPU)
+                print(f"  census {name}: {int(m.sum())} blocks entered, {int(done.sum())} recorded an exit")
+                continue
             print(f"  census {name}: {int(m.sum())} blocks entered over {(ent.max() - ent.min()) / 100.0:.2f} us; first entry {(ent.min() - base) / 100.0:.2f}, "
                   f"exits (blocks that ran a role: {int(done.sum())}) first {(ext[done].min() - base) / 100.0:.2f} / median {(np.median(ext[done]) - base) / 100.0:.2f} / last {(ext[done].max() - base) / 100.0:.2f} us")
 dev.close()
