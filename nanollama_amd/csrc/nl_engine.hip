@@ -176,6 +176,12 @@ struct nl_engine {
     int *amax_idx = nullptr;
     int amax_slots = 0;
     int *h_ctl = nullptr;  // pinned staging
+    // Per-call Forward on the launch plans (go/main.go:173-219 calls Forward once per token): the caller's token / position travel
+    // through a pinned, device-visible box the first launch of the step's graph reads, completion and the argmax come back through
+    // a pinned done word the host spins on -- no control copy, no stream synchronise per token (one GPU, no collectives)
+    int *h_box = nullptr, *d_box = nullptr;              // [0, CTL_WORDS): control words, [8]: sequence number of the call
+    unsigned long long *h_done = nullptr, *d_done = nullptr;
+    unsigned box_seq = 0;
     float *d_h_logits = nullptr; // device address of h_logits (the LM head of a per-call Forward stores the logits there itself)
     float *h_logits = nullptr;   // pinned [vocab] + one int behind it: the per-call read-backs of nl_forward / nl_forward_argmax /
                                  // nl_prefill land here by DMA and are copied to the caller's (pageable) buffer by the CPU -- a
@@ -240,6 +246,8 @@ struct nl_engine {
         hipGraphExec_t exec = nullptr;
         hipGraph_t multi = nullptr;          // the same plan graph_steps times: chained greedy decode replays it
         hipGraphExec_t multi_exec = nullptr;  // (one inter-graph gap per graph_steps tokens instead of per token)
+        hipGraph_t call = nullptr;           // the plan between a fetch of the step's control words from the pinned call box and a
+        hipGraphExec_t call_exec = nullptr;   // store of {sequence, argmax} into its done word: one nl_forward, no copy, no synchronise
     } ps[3];                                 // (ps[2]: ps[1] with the attention launch whose passes are shared by helper blocks: wide tier, one GPU, from the second pass on)
     bool fused = false;           // ps[1] exists
     int fused_mode = 0;           // 1: whole attention half per layer (nl_block.h); 2: projection + attention (nl_group.h);
@@ -1115,7 +1123,18 @@ int run_plan_eager(nl_engine *e, const nl_engine::PlanSet &S) {
     return NL_OK;
 }
 
+__global__ void box_fetch_kernel(const int *box, int *ctl) {
+    if (threadIdx.x < CTL_WORDS) ctl[threadIdx.x] = __hip_atomic_load(box + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void box_done_kernel(const int *box, const int *result, unsigned long long *done) {
+    // (behind the LM head and the argmax of the step: their stores -- the logits rows in the pinned buffer too -- are complete)
+    const unsigned seq = (unsigned)__hip_atomic_load(box + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(done, ((unsigned long long)seq << 32) | (unsigned)*result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 void destroy_graphs(nl_engine::PlanSet &S) {
+    if (S.call_exec) { (void)hipGraphExecDestroy(S.call_exec); S.call_exec = nullptr; }
+    if (S.call) { (void)hipGraphDestroy(S.call); S.call = nullptr; }
     if (S.exec) { (void)hipGraphExecDestroy(S.exec); S.exec = nullptr; }
     if (S.multi_exec) { (void)hipGraphExecDestroy(S.multi_exec); S.multi_exec = nullptr; }
     if (S.multi) { (void)hipGraphDestroy(S.multi); S.multi = nullptr; }
@@ -1131,6 +1150,16 @@ int capture_graph(nl_engine *e, nl_engine::PlanSet &S) {
     if (s != hipSuccess) return e->fail(NL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(s));
     S.graph = g;
     HIPCK(e, hipGraphInstantiate(&S.exec, S.graph, nullptr, nullptr, 0));
+    if (e->d_box && e->G == 1 && !e->force_tp_plan && !e->p2p.on && !getenv("NL_NO_CALL_BOX")) {
+        HIPCK(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        hipLaunchKernelGGL(box_fetch_kernel, dim3(1), dim3(64), 0, e->stream, e->d_box, e->ctl);
+        const int rc3 = run_plan_eager(e, S);
+        hipLaunchKernelGGL(box_done_kernel, dim3(1), dim3(1), 0, e->stream, e->d_box, e->result, e->d_done);
+        hipGraph_t gc = nullptr;
+        const hipError_t s3 = hipStreamEndCapture(e->stream, &gc);
+        if (!rc3 && s3 == hipSuccess && gc && hipGraphInstantiate(&S.call_exec, gc, nullptr, nullptr, 0) == hipSuccess) S.call = gc;
+        else { if (gc) (void)hipGraphDestroy(gc); S.call_exec = nullptr; (void)hipGetLastError(); }     // (the per-call path keeps copy + launch + synchronise)
+    }
     // chained greedy decode replays a graph that holds the plan 16 times: the gap between two graph launches
     // (~8 us on this stack) is then paid once per 16 tokens (nano 3834 -> 3945 tok/s; 4 steps: 3905; 32 / 64: as 16)
     static const int steps = getenv("NL_GRAPH_STEPS") ? atoi(getenv("NL_GRAPH_STEPS")) : 16;   // developer knob (tools/)
@@ -1187,6 +1216,34 @@ int launch_step(nl_engine *e, int pos) {
         return NL_OK;
     }
     return run_plan_eager(e, S);
+}
+
+// One step through the call box: true = served (the done word carries the step's argmax in *id); false = this plan has no call
+// graph and the caller copies, launches and synchronises as before.
+bool call_step(nl_engine *e, int token, int pos, int stream, int hostout, int *id, int *rc) {
+    nl_engine::PlanSet &S = pick_plan(e, pos);
+    *rc = NL_OK;
+    if (!S.call_exec) return false;
+    const unsigned seq = ++e->box_seq;
+    e->h_box[CTL_TOKEN] = token; e->h_box[CTL_POS] = pos; e->h_box[CTL_CHAIN] = 0; e->h_box[CTL_STEP] = 0;
+    e->h_box[CTL_STREAM] = stream; e->h_box[CTL_HOSTOUT] = hostout;
+    __atomic_store_n(e->h_box + 8, (int)seq, __ATOMIC_RELEASE);
+    if (hipGraphLaunch(S.call_exec, e->stream) != hipSuccess) { *rc = e->fail(NL_ERR_HIP, "hipGraphLaunch (call graph): %s", hipGetErrorString(hipGetLastError())); return true; }
+    // spin on the done word; a step that does not answer within two seconds is looked at through the stream instead
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long d;
+    for (unsigned spins = 0;; spins++) {
+        d = __atomic_load_n(e->h_done, __ATOMIC_ACQUIRE);
+        if ((unsigned)(d >> 32) == seq) break;
+        if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            if (hipStreamSynchronize(e->stream) != hipSuccess) { *rc = e->fail(NL_ERR_HIP, "call graph: %s", hipGetErrorString(hipGetLastError())); return true; }
+            d = __atomic_load_n(e->h_done, __ATOMIC_ACQUIRE);
+            if ((unsigned)(d >> 32) != seq) { *rc = e->fail(NL_ERR_HIP, "call graph: the step finished without its done word"); return true; }
+            break;
+        }
+    }
+    if (id) *id = (int)(unsigned)d;
+    return true;
 }
 
 // (re)build both plans and their graphs
@@ -2636,6 +2693,12 @@ int nl_finalize(nl_handle e) {
     HIPCK(e, dalloc(&e->amax_idx, (size_t)e->amax_slots, &e->bytes_state));
     HIPCK(e, hipHostMalloc((void **)&e->h_ctl, CTL_WORDS * sizeof(int), hipHostMallocDefault));
     memset(e->h_ctl, 0, CTL_WORDS * sizeof(int));
+    if (hipHostMalloc((void **)&e->h_box, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+        hipHostMalloc((void **)&e->h_done, 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+        hipHostGetDevicePointer((void **)&e->d_box, e->h_box, 0) == hipSuccess && hipHostGetDevicePointer((void **)&e->d_done, e->h_done, 0) == hipSuccess) {
+        memset(e->h_box, 0, 16 * sizeof(int));
+        e->h_done[0] = e->h_done[1] = 0;
+    } else { e->d_box = nullptr; e->d_done = nullptr; (void)hipGetLastError(); }
     if (e->h_logits) { hipHostFree(e->h_logits); e->h_logits = nullptr; }
     HIPCK(e, hipHostMalloc((void **)&e->h_logits, ((size_t)c.vocab + 4) * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));   // (the resident session's LM-head units store logits straight into it)
     e->d_h_logits = nullptr;
@@ -3011,6 +3074,8 @@ int nl_destroy(nl_handle e) {
     if (e->h_logits) hipHostFree(e->h_logits);
     if (e->h_status) hipHostFree(e->h_status);
     if (e->h_ctl_ring) hipHostFree(e->h_ctl_ring);
+    if (e->h_box) hipHostFree(e->h_box);
+    if (e->h_done) hipHostFree(e->h_done);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
@@ -3067,11 +3132,15 @@ int nl_forward(nl_handle e, int stream, int token, int pos, float *logits_out) {
         if ((rc = note_positions(e, stream, pos, 1))) return rc;
         // one GPU: the LM head stores the logits into the pinned buffer itself (ctl[CTL_HOSTOUT]); groups: a DMA behind the step
         const bool direct = logits_out && e->d_h_logits && e->G == 1 && !e->force_tp_plan && !e->p2p.on;
-        if ((rc = set_ctl(e, token, pos, 0, stream, direct ? 1 : 0))) return rc;
-        if ((rc = launch_step(e, pos))) return rc;
-        if (logits_out && !direct)
-            HIPCK(e, hipMemcpyAsync(e->h_logits, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
-        HIPCK(e, hipStreamSynchronize(e->stream));
+        if ((direct || !logits_out) && call_step(e, token, pos, stream, direct ? 1 : 0, nullptr, &rc)) {
+            if (rc) return rc;       // (the call box: no control copy, no synchronise; the logits rows are in the pinned buffer)
+        } else {
+            if ((rc = set_ctl(e, token, pos, 0, stream, direct ? 1 : 0))) return rc;
+            if ((rc = launch_step(e, pos))) return rc;
+            if (logits_out && !direct)
+                HIPCK(e, hipMemcpyAsync(e->h_logits, e->logits, (size_t)e->cfg.vocab * 4, hipMemcpyDeviceToHost, e->stream));
+            HIPCK(e, hipStreamSynchronize(e->stream));
+        }
         if (attempt == 0 && take_fused_timeout(e)) continue;   // redo on the general plan
         break;
     }
@@ -3107,11 +3176,15 @@ int nl_forward_argmax(nl_handle e, int stream, int token, int pos, int *next_id)
     }
     for (int attempt = 0;; attempt++) {
         if ((rc = note_positions(e, stream, pos, 1))) return rc;
-        if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
-        if ((rc = launch_step(e, pos))) return rc;
         int *h_id = reinterpret_cast<int *>(e->h_logits + e->cfg.vocab);
-        HIPCK(e, hipMemcpyAsync(h_id, e->result, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-        HIPCK(e, hipStreamSynchronize(e->stream));
+        if (call_step(e, token, pos, stream, 0, h_id, &rc)) {
+            if (rc) return rc;
+        } else {
+            if ((rc = set_ctl(e, token, pos, 0, stream))) return rc;
+            if ((rc = launch_step(e, pos))) return rc;
+            HIPCK(e, hipMemcpyAsync(h_id, e->result, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+            HIPCK(e, hipStreamSynchronize(e->stream));
+        }
         if (attempt == 0 && take_fused_timeout(e)) continue;   // redo on the general plan
         *next_id = *h_id;
         break;
