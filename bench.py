@@ -395,6 +395,20 @@ def run_workload(tier, wtype, rdv, steps, warmup, profile_pos, model, tp=True, c
                             "bytes_per_launch": int(step_bytes * seg), "us_per_launch": round(launch_ms * 1e3, 2), "tokens_per_launch": seg,
                             "launches_per_step": round(1.0 / seg, 5), "time_share_of_step": round(min(1.0, launch_ms / seg / ms_per_step), 3),
                             "note": "one launch decodes the whole segment with the weights resident on chip; bytes are the algorithmic bytes of its tokens"}
+            # What actually binds this launch is not HBM (its measured traffic is a fraction of the algorithmic bytes) but the chain of
+            # in-launch hand-offs a token walks through: per layer q|k|v -> heads (one in-XCD hop), then o, x', h and the layer's
+            # output each gathered by all 32 units of the XCD; per token seven cross-XCD hops and the chip-wide argmax exchange.
+            # Priced with the primitives tools/xcd_exchange_probe.hip measured (profiles/r05_xcd_exchange_probe.log): 0.25 us per
+            # in-XCD hop, 1.27 us per in-XCD all-gather of 576 values, 0.58 us per cross-XCD hop, 2.8 us chip-wide -- no compute.
+            n_layers = int(dev.config.num_layers)
+            chain_floor = n_layers * (4 * 1.27 + 0.25) + 7 * 0.58 + 2.8
+            persist_roof.update({
+                "binding": "latency of the in-launch hand-off chain (the weights never leave the chip), not HBM bandwidth",
+                "hbm_traffic_GBps_measured": (round(ptraffic / (launch_ms * 1e-3) / 1e9, 1) if ptraffic else None),
+                "chain_floor_us": round(chain_floor, 1),
+                "chain_floor_model": f"{n_layers} layers x (4 all-gathers x 1.27 + 1 hop x 0.25) + 7 cross-XCD hops x 0.58 + 2.8 (argmax exchange), us per token",
+                "us_per_token": round(launch_ms * 1e3 / seg, 2),
+                "chain_floor_frac": round(chain_floor / (launch_ms * 1e3 / seg), 3)})
         p2p = dev.p2p_info() if (world > 1 or shard_of) else None
         res = {
             "tier": tier, "wtype": wtype, "path": path, "prompt": prompt,
@@ -515,7 +529,7 @@ def side_configs(model):
     step_bytes = synth.weight_bytes_per_token(shape, "q4_0") + ns * synth.kv_bytes_per_token(shape, pos0 + steps // 2)
     out["goldie_q4_0_64_streams"] = {"tokens_per_s_aggregate": round(ns * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
                                      "device_ms_per_step": round(ev_ms / steps, 3), "steps": steps,
-                                     "positions": f"{pos0}..{pos0 + steps - 1}", "launch": "one nl_forward_batch call per step (host loop; ids read back every step)",
+                                     "positions": f"{pos0}..{pos0 + steps - 1}", "launch": "one nl_forward_batch call per step (host loop; ids read back every step); the step is a cached hipGraph of 5 launches per layer (nl_dgemm.h)",
                                      "hbm_frac": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
     # ... and the same batch deep in its context (the K / V rows below are whatever the cache holds: timing only)
     lpos, lsteps = 1000, 16
@@ -552,14 +566,24 @@ def side_configs(model):
         long_prompt = synth.prompt_ids(1100, shape.vocab)
         dev.reset(); dev.prefill(long_prompt)
         bypos = {}
+        # (the second witness of every timed chain: the launch plans of the same file, NL_PERSIST=0)
+        os.environ["NL_PERSIST"] = "0"
+        try:
+            plain = model.load_llama_model(g)
+        finally:
+            del os.environ["NL_PERSIST"]
+        plain.prefill(long_prompt)
+        ids_equal = True
         for p0 in (64, 300, 470, 700, 980, 1060):
-            dev.decode_greedy(5, p0, 32)
+            ids_equal = ids_equal and dev.decode_greedy(5, p0, 32) == plain.decode_greedy(5, p0, 32)
             best = None
             for _ in range(3):
                 t0 = time.perf_counter(); dev.decode_greedy(5, p0, 32); dt = time.perf_counter() - t0
                 best = dt if best is None else min(best, dt)
             bypos[str(p0)] = round(32 / best, 1)
-        out["nano_q8_0_greedy_tokens_per_s_by_position"] = dict(bypos, persistent_decode_below=dev.persist_info()["max_pos"])
+        plain.close()
+        out["nano_q8_0_greedy_tokens_per_s_by_position"] = dict(bypos, persistent_decode_below=dev.persist_info()["max_pos"],
+                                                               ids_equal_launch_plans=bool(ids_equal))
     except Exception as exc:  # a side measurement: the line must survive it
         out["nano_q8_0_greedy_tokens_per_s_by_position"] = {"error": repr(exc)}
     dev.close()
