@@ -1835,7 +1835,7 @@ int batch_alloc(nl_engine *e, nl_engine::Batch &b, int cap_limit = 2048) {
     return NL_OK;
 }
 
-// a multi-token step of <= NL_DGEMM_MAX_TOKENS (192) tokens of a model whose layer matrices are all Q4_0 with whole 256-column groups
+// a short multi-token step (dgemm_step_ok: decode batches, prompts of up to a few hundred tokens) of a model whose layer matrices are all Q4_0 with whole 256-column groups
 // runs its five GEMM-shaped launches per layer on dgemm_kernel (nl_dgemm.h) with the RMSNorms folded around them
 bool dgemm_model_ok(const nl_engine *e) {
     const nl_config &c = e->cfg;
@@ -1873,9 +1873,12 @@ bool dgemm_step_ok(const nl_engine *e, int n) {
     const char *k = getenv("NL_DGEMM");                 // knob (tests, tools; read per step): 0 keeps the split-K launches
     if (k && atoi(k) == 0) return false;
     const char *mk = getenv("NL_DGEMM_MAX_TOKENS");
-    // (decode batches and short prompts: measured ahead of the long-run GEMM of nl_qgemm2.h up to ~200 tokens on goldie and past 512 on
-    //  mini -- tools/bench_short_prompt.py; a token tile per workgroup means ceil(n / 16) x row groups workgroups per launch)
-    return n <= (mk ? atoi(mk) : 192);
+    if (mk) return n <= atoi(mk);
+    // Decode batches and prompts while the largest launch (gate || up: ceil(n / 16) token tiles x I / 64 row groups) stays within
+    // about four rounds of workgroups: measured ahead of the long-run GEMM of nl_qgemm2.h up to 256 tokens on goldie (768 / 1024
+    // workgroups: 2.77 against 2.88 ms, 3.23 against 3.21) and 512 on mini (1.60 against 1.74 ms; 768 tokens 2.21 against 2.19) --
+    // tools/bench_short_prompt.py
+    return (long long)((n + 15) / 16) * (e->cfg.interm / 64) <= 1024;
 }
 
 // GEMM of the multi-token step: input = the fragment store the producing kernel just filled; output = `out`

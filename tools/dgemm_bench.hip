@@ -103,28 +103,28 @@ int main(int argc, char **argv) {
         P.rope = QGemmParams::Rope{pos, strm, cs, sn, qout, kc, vc, (long long)kvs, nullptr, nullptr, nullptr, hd, H, KV, seq, 0};
         CK(dg_launch_rope(P, st));
     }, (double)qkv.qbytes * 18 / 16, 2.0 * R * D * N);
-    stamps("qkv", 1024);
+    stamps("qkv", (int)dg_grid(qkv.ntiles, 3, N));
     timeit("wo+norm", [&](int i) {
         QGemmParams P = base(wo, i);
         P.xf = xf; P.out = x; P.ldo = D; P.resid = x;
         P.nrm_out = QGemmParams::NormOut{nw, xf2, ssq, sc1};
         CK(dg_launch_plain(P, st));
     }, (double)wo.qbytes * 18 / 16, 2.0 * D * D * N);
-    stamps("wo", 1024);
+    stamps("wo", (int)dg_grid(wo.ntiles, 2, N));
     timeit("gate|up", [&](int i) {
         QGemmParams P = base(gate, i);
         P.q1 = up.q + (size_t)(i % up.copies) * up.qbytes; P.s1 = up.s + (size_t)(i % up.copies) * up.swords;
         P.xf = xf; P.ldo = I; P.nrm_in = nin; P.xf_out = xf2; P.out_q4 = 1;
         CK(dg_launch_swiglu(P, st));
     }, (double)gate.qbytes * 2 * 18 / 16, 2.0 * 2 * I * D * N);
-    stamps("gate|up", 1024);
+    stamps("gate|up", (int)dg_grid(gate.ntiles, 4, N));
     timeit("down+norm", [&](int i) {
         QGemmParams P = base(down, i);
         P.xf = xf2; P.out = x; P.ldo = D; P.resid = x;
         P.nrm_out = QGemmParams::NormOut{nw, xf, ssq, sc1};
         CK(dg_launch_plain(P, st));
     }, (double)down.qbytes * 18 / 16, 2.0 * D * I * N);
-    stamps("down", 1024);
+    stamps("down", (int)dg_grid(down.ntiles, 2, N));
 
     return 0;
 }
