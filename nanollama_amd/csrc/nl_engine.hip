@@ -317,6 +317,8 @@ struct nl_engine {
         bool retired = false;        // a poll gave up once (or the census was not 8 x 32): the handle keeps the launch plans
         uint8_t *raw[PD_MAXL][7] = {};
         uint8_t *lm_raw = nullptr;
+        unsigned char rtype[PD_MAXL][7] = {}, lm_type = 0;     // block type of every kept tensor (Q8_0 / Q4_0 / Q5_0)
+        uint8_t *embd_q8 = nullptr;  // token_embd of a Q4_0 / Q5_0 file re-blocked as Q8_0 for the in-launch lookup
         uint4 *wimg = nullptr, *lmimg = nullptr;
         unsigned short *simg = nullptr, *lmsimg = nullptr;
         pd_u64 *gx = nullptr, *gqkv = nullptr, *go = nullptr, *gxp = nullptr, *gh = nullptr;
@@ -1341,7 +1343,7 @@ void pd_free_raw(nl_engine *e) {
 void pd_free(nl_engine *e) {
     pd_free_raw(e);
     nl_engine::Persist &d = e->pd;
-    void *bufs[] = {d.wimg, d.lmimg, d.simg, d.lmsimg, d.gx, d.gqkv, d.go, d.gxp, d.gh, d.gam, d.census, d.status, d.dbg, d.norms, d.gtok, d.gpart};
+    void *bufs[] = {d.wimg, d.lmimg, d.simg, d.lmsimg, d.gx, d.gqkv, d.go, d.gxp, d.gh, d.gam, d.census, d.status, d.dbg, d.norms, d.gtok, d.gpart, d.embd_q8};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (d.h_status) (void)hipHostFree(d.h_status);
     if (d.h_mail) (void)hipHostFree(d.h_mail);
@@ -1353,7 +1355,7 @@ void pd_free(nl_engine *e) {
 int pd_build(nl_engine *e) {
     nl_engine::Persist &d = e->pd;
     const nl_config &c = e->cfg;
-    bool ok = d.candidate && e->embd_type == WT_Q8_0 && e->G == 1 && !e->force_tp_plan && e->num_cus == PD_GRID;
+    bool ok = d.candidate && (e->embd_type == WT_Q8_0 || e->embd_type == WT_Q4_0 || e->embd_type == WT_Q5_0) && e->G == 1 && !e->force_tp_plan && e->num_cus == PD_GRID;
     for (int l = 0; ok && l < c.n_layers; l++) {
         for (int i = 0; i < 7; i++) ok = ok && d.raw[l][i];
         const nl_engine::Layer &L = e->layers[l];
@@ -1368,8 +1370,16 @@ int pd_build(nl_engine *e) {
     e->bytes_weights += nw * 34 + nlm * 34;
     PdPackParams K{};
     for (int l = 0; l < c.n_layers; l++)
-        for (int i = 0; i < 7; i++) K.raw[l][i] = d.raw[l][i];
+        for (int i = 0; i < 7; i++) { K.raw[l][i] = d.raw[l][i]; K.rtype[l][i] = d.rtype[l][i]; }
     K.lm_raw = d.lm_raw ? d.lm_raw : e->embd_raw;        // tied head: output.weight missing -> token_embd (go/model.go:195-201)
+    K.lm_type = d.lm_raw ? d.lm_type : (unsigned char)e->embd_type;
+    if (e->embd_type != WT_Q8_0) {
+        const long long nblk = (long long)c.vocab * (c.dim / 32);
+        HIPCK(e, hipMalloc((void **)&d.embd_q8, (size_t)nblk * 34));
+        e->bytes_weights += (size_t)nblk * 34;
+        hipLaunchKernelGGL(pd_embd_q8_kernel, dim3(2048), dim3(256), 0, e->stream, e->embd_raw, e->embd_type, nblk, d.embd_q8);
+        HIPCK(e, hipGetLastError());
+    }
     K.D = c.dim; K.I = c.interm; K.H = c.n_heads; K.V = c.vocab; K.L = c.n_layers;
     K.wimg = d.wimg; K.simg = d.simg; K.lmimg = d.lmimg; K.lmsimg = d.lmsimg;
     hipLaunchKernelGGL(pd_pack_kernel, dim3(PD_GRID, PD_SLOTS * PD_UNITS + PD_ULM), dim3(PD_THREADS), 0, e->stream, K);
@@ -1452,7 +1462,7 @@ int pd_launch(nl_engine *e, int stream, int token, int pos, int n, float *host_l
     d.tag_base += (unsigned)n + 2u;
     P.wimg = d.wimg; P.simg = d.simg; P.lmimg = d.lmimg; P.lmsimg = d.lmsimg;
     P.norms = d.norms;
-    P.embd_raw = e->embd_raw;
+    P.embd_raw = e->pd.embd_q8 ? e->pd.embd_q8 : e->embd_raw;
     P.rope_cos = e->rope_cos; P.rope_sin = e->rope_sin;
     P.kcache = e->kcache + (long long)stream * e->kv_stream_stride; P.vcache = e->vcache + (long long)stream * e->kv_stream_stride;
     P.kv_layer_stride = e->kv_layer_stride;
@@ -2474,17 +2484,19 @@ int nl_upload_tensor(nl_handle e, const char *name, uint32_t type, const void *d
     };
 
     if (e->pd.candidate) {
-        // the persistent decode (nl_persist.h) packs its own lane images from the raw Q8_0 tensors at nl_finalize: keep them
+        // the persistent decode (nl_persist.h) packs its own lane images from the raw Q8_0 / Q4_0 / Q5_0 tensors at nl_finalize: keep them
         static const char *const kMat[7] = {"attn_q.weight", "attn_k.weight", "attn_v.weight", "attn_output.weight", "ffn_gate.weight",
                                             "ffn_up.weight", "ffn_down.weight"};
         int slot = -1;
         for (int i = 0; i < 7; i++) if (sl.layer >= 0 && f == kMat[i]) slot = i;
         const bool is_lm = sl.layer < 0 && f == "output.weight";
         const bool is_bias = f.size() > 5 && f.compare(f.size() - 5, 5, ".bias") == 0;
-        if (((slot >= 0 || is_lm) && type != WT_Q8_0) || is_bias) {
+        const bool int8_blocks = type == WT_Q8_0 || type == WT_Q4_0 || type == WT_Q5_0;     // 32 int8-valued quants x an fp16 d
+        if (((slot >= 0 || is_lm) && !int8_blocks) || is_bias) {
             e->pd.candidate = false;
         } else if (slot >= 0 || is_lm) {
             uint8_t **dst = is_lm ? &e->pd.lm_raw : &e->pd.raw[sl.layer][slot];
+            (is_lm ? e->pd.lm_type : e->pd.rtype[sl.layer][slot]) = (unsigned char)type;
             if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
             HIPCK(e, hipMalloc((void **)dst, nbytes));
             HIPCK(e, hipMemcpy(*dst, data, nbytes, hipMemcpyHostToDevice));

@@ -105,7 +105,7 @@ struct PdParams {
     const uint4 *lmimg;              // [256][5][2][512]
     const unsigned short *lmsimg;    // [256][5][512]
     const float *norms;              // [L][2][D] attn_norm | ffn_norm of every layer, then [D] output_norm (packed by pd_build)
-    const uint8_t *embd_raw;         // Q8_0 rows of token_embd
+    const uint8_t *embd_raw;         // Q8_0 rows of token_embd (a Q4_0 / Q5_0 file: its values re-blocked as Q8_0 by pd_embd_q8_kernel)
     const float *rope_cos, *rope_sin;
     float *kcache, *vcache;          // layer 0 of the stream: [kv head][seq][64]
     long long kv_layer_stride;
@@ -133,8 +133,9 @@ struct PdParams {
 };
 
 struct PdPackParams {
-    const uint8_t *raw[PD_MAXL][7];  // q, k, v, o, gate, up, down: raw GGUF Q8_0 tensors on the device
+    const uint8_t *raw[PD_MAXL][7];  // q, k, v, o, gate, up, down: raw GGUF tensors on the device, Q8_0 / Q4_0 / Q5_0 blocks (rtype)
     const uint8_t *lm_raw;           // output.weight (or token_embd for tied heads)
+    unsigned char rtype[PD_MAXL][7], lm_type;      // WT_Q8_0 / WT_Q4_0 / WT_Q5_0: every one is int8 quants x an fp16 d (n - 8, q - 16)
     int D, I, H, V, L;
     uint4 *wimg; unsigned short *simg; uint4 *lmimg; unsigned short *lmsimg;
 };
@@ -144,7 +145,9 @@ struct PdPackParams {
 __global__ void __launch_bounds__(PD_THREADS) pd_pack_kernel(PdPackParams P) {
     const int cu = blockIdx.x, xcd = cu / PD_CUS, idx = cu % PD_CUS, unit = blockIdx.y, tid = threadIdx.x;
     const int NB = P.D / 32, NBI = P.I / 32;
-    const uint8_t *src = nullptr;     // the 34-byte block, or null = zeros
+    const uint8_t *src = nullptr;     // the (row, block)'s first byte, or null = zeros
+    int bt = WT_Q8_0;                 // its block type
+    auto bsz = [](int t) { return t == WT_Q8_0 ? 34 : t == WT_Q4_0 ? 18 : 22; };
     if (unit < PD_SLOTS * PD_UNITS) {
         const int s = unit / PD_UNITS, k = unit % PD_UNITS;
         if (s < pd_nslots(P.L, xcd)) {
@@ -156,24 +159,25 @@ __global__ void __launch_bounds__(PD_THREADS) pd_pack_kernel(PdPackParams P) {
                 pd_unit_rc(u, NB, row, blk);
                 if (u < pd_pad4(qr) * NB && row < qr) {
                     const int R = idx * qr + row, sect = R / P.D;          // row R of [q; k; v]
-                    src = P.raw[layer][sect] + ((size_t)(R - sect * P.D) * NB + blk) * 34;
+                    bt = P.rtype[layer][sect];
+                    src = P.raw[layer][sect] + ((size_t)(R - sect * P.D) * NB + blk) * bsz(bt);
                 }
             } else if (k < PD_UQ + PD_UW) {
                 const int u = (k - PD_UQ) * PD_THREADS + tid;
                 pd_unit_rc(u, NB, row, blk);
-                if (u < pd_pad4(wr) * NB && row < wr) src = P.raw[layer][3] + ((size_t)(idx * wr + row) * NB + blk) * 34;
+                if (u < pd_pad4(wr) * NB && row < wr) { bt = P.rtype[layer][3]; src = P.raw[layer][3] + ((size_t)(idx * wr + row) * NB + blk) * bsz(bt); }
             } else if (k < PD_UQ + PD_UW + PD_UG) {
                 const int u = (k - PD_UQ - PD_UW) * PD_THREADS + tid, grp = pd_pad4(gr);
                 pd_unit_rc(u, NB, row, blk);
                 if (u < 2 * grp * NB) {            // rows [0, grp): gate, [grp, 2 grp): up -- padding rows stay zero
                     const bool up = row >= grp;
                     const int rr = up ? row - grp : row;
-                    if (rr < gr) src = P.raw[layer][up ? 5 : 4] + ((size_t)(idx * gr + rr) * NB + blk) * 34;
+                    if (rr < gr) { bt = P.rtype[layer][up ? 5 : 4]; src = P.raw[layer][up ? 5 : 4] + ((size_t)(idx * gr + rr) * NB + blk) * bsz(bt); }
                 }
             } else {
                 const int u = (k - PD_UQ - PD_UW - PD_UG) * PD_THREADS + tid;
                 pd_unit_rc(u, NBI, row, blk);
-                if (u < pd_pad4(wr) * NBI && row < wr) src = P.raw[layer][6] + ((size_t)(idx * wr + row) * NBI + blk) * 34;
+                if (u < pd_pad4(wr) * NBI && row < wr) { bt = P.rtype[layer][6]; src = P.raw[layer][6] + ((size_t)(idx * wr + row) * NBI + blk) * bsz(bt); }
             }
         }
     } else {
@@ -181,17 +185,30 @@ __global__ void __launch_bounds__(PD_THREADS) pd_pack_kernel(PdPackParams P) {
         const int r0 = cu * lr, nrows = max(0, min(lr, P.V - r0));
         int row, blk;
         pd_unit_rc(u, NB, row, blk);
-        if (u < pd_pad4(lr) * NB && row < nrows) src = P.lm_raw + ((size_t)(r0 + row) * NB + blk) * 34;
+        if (u < pd_pad4(lr) * NB && row < nrows) { bt = P.lm_type; src = P.lm_raw + ((size_t)(r0 + row) * NB + blk) * bsz(bt); }
     }
     uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
     unsigned short d16 = 0;
     if (src) {
+        // the block as 32 int8 and its fp16 d: Q8_0 as stored (go/quant.go:120-165); Q4_0 nibble - 8 (low nibbles = elements 0-15, high
+        // = 16-31: go/quant.go:45-94); Q5_0 (nibble | high bit << 4) - 16 (go/quant.go:405-420) -- every value an int8, the same d
         uint8_t b[34];
-        for (int i = 0; i < 34; i++) b[i] = src[i];
+        const int nbytes = bsz(bt);
+        for (int i = 0; i < 34; i++) b[i] = i < nbytes ? src[i] : 0;
         d16 = (unsigned short)(b[0] | (b[1] << 8));
-        auto w32 = [&](int o) { return (unsigned)b[o] | ((unsigned)b[o + 1] << 8) | ((unsigned)b[o + 2] << 16) | ((unsigned)b[o + 3] << 24); };
-        lo = make_uint4(w32(2), w32(6), w32(10), w32(14));
-        hi = make_uint4(w32(18), w32(22), w32(26), w32(30));
+        int8_t q[32];
+        if (bt == WT_Q8_0) { for (int i = 0; i < 32; i++) q[i] = (int8_t)b[2 + i]; }
+        else if (bt == WT_Q4_0) { for (int i = 0; i < 16; i++) { q[i] = (int8_t)((b[2 + i] & 0x0F) - 8); q[16 + i] = (int8_t)((b[2 + i] >> 4) - 8); } }
+        else {
+            const uint32_t qh = (uint32_t)b[2] | ((uint32_t)b[3] << 8) | ((uint32_t)b[4] << 16) | ((uint32_t)b[5] << 24);
+            for (int i = 0; i < 32; i++) {
+                const int nib = i < 16 ? (b[6 + i] & 0x0F) : (b[6 + i - 16] >> 4);
+                q[i] = (int8_t)((nib | (int)(((qh >> i) & 1u) << 4)) - 16);
+            }
+        }
+        auto w32 = [&](int o) { return (unsigned)(uint8_t)q[o] | ((unsigned)(uint8_t)q[o + 1] << 8) | ((unsigned)(uint8_t)q[o + 2] << 16) | ((unsigned)(uint8_t)q[o + 3] << 24); };
+        lo = make_uint4(w32(0), w32(4), w32(8), w32(12));
+        hi = make_uint4(w32(16), w32(20), w32(24), w32(28));
     }
     if (unit < PD_SLOTS * PD_UNITS) {
         const size_t base = ((size_t)cu * PD_SLOTS * PD_UNITS + unit);
@@ -203,6 +220,25 @@ __global__ void __launch_bounds__(PD_THREADS) pd_pack_kernel(PdPackParams P) {
         P.lmimg[(base * 2 + 0) * PD_THREADS + tid] = lo;
         P.lmimg[(base * 2 + 1) * PD_THREADS + tid] = hi;
         P.lmsimg[base * PD_THREADS + tid] = d16;
+    }
+}
+
+// token_embd of a Q4_0 / Q5_0 file as Q8_0 blocks (int8 of the same values, the same d): the decode kernel's in-launch embedding
+// lookup (embed_value, go/model.go:389-446) then has one format.  One thread per block.
+__global__ void pd_embd_q8_kernel(const uint8_t *src, int src_type, long long nblocks, uint8_t *dst) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nblocks; i += (long long)gridDim.x * blockDim.x) {
+        const uint8_t *b = src + i * (src_type == WT_Q4_0 ? 18 : 22);
+        uint8_t *o = dst + i * 34;
+        o[0] = b[0]; o[1] = b[1];
+        if (src_type == WT_Q4_0) {
+            for (int j = 0; j < 16; j++) { o[2 + j] = (uint8_t)(int8_t)((b[2 + j] & 0x0F) - 8); o[18 + j] = (uint8_t)(int8_t)((b[2 + j] >> 4) - 8); }
+        } else {
+            const uint32_t qh = (uint32_t)b[2] | ((uint32_t)b[3] << 8) | ((uint32_t)b[4] << 16) | ((uint32_t)b[5] << 24);
+            for (int j = 0; j < 32; j++) {
+                const int nib = j < 16 ? (b[6 + j] & 0x0F) : (b[6 + j - 16] >> 4);
+                o[2 + j] = (uint8_t)(int8_t)((nib | (int)(((qh >> j) & 1u) << 4)) - 16);
+            }
+        }
     }
 }
 

@@ -437,10 +437,49 @@ def test_two_handles_on_one_device_do_not_wait_out_each_others_sessions(hip, orc
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("wtype", ["q4_0", "q5_0"])
+def test_persistent_decode_takes_q4_0_and_q5_0_files(hip, orc, tmp_path, monkeypatch, wtype):
+    # a Q4_0 block is 32 values (nibble - 8) x d, a Q5_0 block (5-bit value - 16) x d (go/quant.go:45-94, :405-420): int8-valued
+    # quants with an fp16 scale, i.e. exactly what the register images hold -- the packer expands them, the kernel is the Q8_0 one;
+    # the embedding table is re-blocked as Q8_0 for the in-launch lookup.  Ids and logits against the oracle, the resident
+    # session too, the launch plans of the same file as second witness.
+    shape = synth.ModelShape(f"pd_{wtype}", 13, 256, 4, 4, 1024, seq_len=256, interm=512)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, wtype, 181)
+    g = gguf.load_gguf(str(p))
+    prompt = synth.prompt_ids(7, shape.vocab, seed=5)
+    first, want, want_logits = _oracle_run(orc, g, prompt, 140)       # (positions 7 .. 146: a second attention pass from 128 on)
+    dev = hip.load_llama_model(g)
+    assert dev.persist_info()["ready"], dev.persist_info()
+    dev.prefill(prompt)
+    assert int(np.argmax(dev.state.logits)) == first
+    got = dev.decode_greedy(first, len(prompt), 140)
+    assert dev.last_error() == "" and dev.persist_info()["tokens"] == 140
+    assert got == want, (got[:10], want[:10])
+    d = _rel(dev.debug_read("logits", shape.vocab), want_logits[-1])
+    # per-call Forward on the resident session: teacher-forced with the oracle's ids
+    dev.reset()
+    dev.prefill(prompt)
+    worst, tok = 0.0, first
+    for i in range(30):
+        dev.forward(tok, len(prompt) + i)
+        worst = max(worst, _rel(dev.state.logits, want_logits[i]))
+        tok = want[i]
+    print(f"\npersistent decode, {wtype}: 140 ids equal; last-step max|gpu-oracle| = {d:.2e}, session {worst:.2e}")
+    assert d <= LOGIT_TOL and worst <= LOGIT_TOL
+    monkeypatch.setenv("NL_PERSIST", "0")
+    plain = hip.load_llama_model(g)
+    assert not plain.persist_info()["ready"]
+    plain.prefill(prompt)
+    assert plain.decode_greedy(first, len(prompt), 140) == want
+    dev.close(); plain.close()
+
+
 def test_shapes_outside_the_instantiations_keep_the_launch_plans(hip, tmp_path):
-    # GQA, other widths, other weight types: not candidates (the launch plans serve them as before)
+    # GQA, other widths, weight types that are not 32 int8-valued quants x an fp16 scale: not candidates (the launch plans serve them)
     for shape, wt in ((synth.ModelShape("pd_gqa", 2, 256, 4, 2, 512, seq_len=64, interm=512), "q8_0"),
-                      (synth.ModelShape("pd_q4", 2, 256, 4, 4, 512, seq_len=64, interm=512), "q4_0"),
+                      (synth.ModelShape("pd_f16", 2, 256, 4, 4, 512, seq_len=64, interm=512), "f16"),
+                      (synth.ModelShape("pd_q4k", 2, 256, 4, 4, 512, seq_len=64, interm=512), "q4_k"),
                       (synth.ModelShape("pd_wide", 2, 512, 8, 8, 512, seq_len=64, interm=1024), "q8_0")):
         p = tmp_path / f"{shape.name}.gguf"
         synth.generate_gguf(str(p), shape, wt, 141)
