@@ -1380,7 +1380,7 @@ int pd_build(nl_engine *e) {
         hipLaunchKernelGGL(pd_embd_q8_kernel, dim3(2048), dim3(256), 0, e->stream, e->embd_raw, e->embd_type, nblk, d.embd_q8);
         HIPCK(e, hipGetLastError());
     }
-    K.D = c.dim; K.I = c.interm; K.H = c.n_heads; K.V = c.vocab; K.L = c.n_layers;
+    K.D = c.dim; K.I = c.interm; K.H = c.n_heads; K.V = c.vocab; K.L = c.n_layers; K.KV = c.n_kv_heads;
     K.wimg = d.wimg; K.simg = d.simg; K.lmimg = d.lmimg; K.lmsimg = d.lmsimg;
     hipLaunchKernelGGL(pd_pack_kernel, dim3(PD_GRID, PD_SLOTS * PD_UNITS + PD_ULM), dim3(PD_THREADS), 0, e->stream, K);
     HIPCK(e, hipGetLastError());
@@ -1417,7 +1417,9 @@ int pd_build(nl_engine *e) {
     HIPCK(e, hipMemset(d.dbg, 0, 64 * sizeof(long long)));
     HIPCK(e, hipHostMalloc((void **)&d.h_status, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
     *d.h_status = 0;
-    const void *kfn = c.dim == 576 ? reinterpret_cast<const void *>(pd_decode_kernel<18, 48>) : reinterpret_cast<const void *>(pd_decode_kernel<8, 16>);
+    // (the instantiations pd_shape_ok admits)
+    const void *kfn = c.dim == 576 ? (c.n_kv_heads == 9 ? reinterpret_cast<const void *>(pd_decode_kernel<18, 48, 9>) : reinterpret_cast<const void *>(pd_decode_kernel<18, 48, 3>))
+                                   : (c.n_kv_heads == 4 ? reinterpret_cast<const void *>(pd_decode_kernel<8, 16, 4>) : reinterpret_cast<const void *>(pd_decode_kernel<8, 16, 2>));
     if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd_lds_bytes()) != hipSuccess) {
         (void)hipGetLastError();
         d.candidate = false;
@@ -1469,8 +1471,10 @@ int pd_launch(nl_engine *e, int stream, int token, int pos, int n, float *host_l
     P.gx = d.gx; P.gqkv = d.gqkv; P.go = d.go; P.gxp = d.gxp; P.gh = d.gh; P.gam = d.gam; P.gpart = d.gpart;
     P.ids_out = e->ids; P.logits = e->logits; P.host_logits = host_logits;
     P.status = d.status; P.host_status = d.h_status; P.dbg = d.dbg;
-    if (c.dim == 576) hipLaunchKernelGGL((pd_decode_kernel<18, 48>), dim3(PD_GRID), dim3(PD_THREADS), pd_lds_bytes(), e->stream, P);
-    else hipLaunchKernelGGL((pd_decode_kernel<8, 16>), dim3(PD_GRID), dim3(PD_THREADS), pd_lds_bytes(), e->stream, P);
+    if (c.dim == 576 && c.n_kv_heads == 9) hipLaunchKernelGGL((pd_decode_kernel<18, 48, 9>), dim3(PD_GRID), dim3(PD_THREADS), pd_lds_bytes(), e->stream, P);
+    else if (c.dim == 576) hipLaunchKernelGGL((pd_decode_kernel<18, 48, 3>), dim3(PD_GRID), dim3(PD_THREADS), pd_lds_bytes(), e->stream, P);
+    else if (c.n_kv_heads == 4) hipLaunchKernelGGL((pd_decode_kernel<8, 16, 4>), dim3(PD_GRID), dim3(PD_THREADS), pd_lds_bytes(), e->stream, P);
+    else hipLaunchKernelGGL((pd_decode_kernel<8, 16, 2>), dim3(PD_GRID), dim3(PD_THREADS), pd_lds_bytes(), e->stream, P);
     HIPCK(e, hipGetLastError());
     d.launches++; d.tokens += n;
     return NL_OK;

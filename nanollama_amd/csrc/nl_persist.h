@@ -78,10 +78,12 @@ __host__ __device__ inline int pd_pad4(int n) { return (n + 3) & ~3; }
 __host__ __device__ inline void pd_unit_rc(int u, int NB, int &row, int &blk) { const int G = u >> 2; row = (G / NB) * 4 + (u & 3); blk = G % NB; }
 
 inline bool pd_shape_ok(int D, int I, int H, int KV, int hd, int V, int L) {
-    if (hd != 64 || KV != H || D != H * 64 || D % 32 || I % 32 || H < 1 || H > 16 || L < 1 || L > PD_MAXL) return false;
-    if (!((D == 576 && I == 1536) || (D == 256 && I == 512))) return false;     // the instantiations of pd_decode_kernel (nano's shape; a small test shape)
-    if ((3 * D) % PD_CUS || D % PD_CUS || I % PD_CUS) return false;              // equal row shares
-    const int NB = D / 32, NBI = I / 32, qr = pd_pad4(3 * D / PD_CUS), wr = pd_pad4(D / PD_CUS), gr = pd_pad4(I / PD_CUS);
+    if (hd != 64 || KV < 1 || H % KV || D != H * 64 || D % 32 || I % 32 || H < 1 || H > 16 || L < 1 || L > PD_MAXL) return false;
+    // the instantiations of pd_decode_kernel: nano's shape with 9 (MHA) or 3 kv heads; a small test shape with 4 or 2
+    if (!((D == 576 && I == 1536 && (KV == 9 || KV == 3)) || (D == 256 && I == 512 && (KV == 4 || KV == 2)))) return false;
+    const int RQ = D + 2 * KV * 64;                                              // rows of [Q; K; V]
+    if (RQ % PD_CUS || D % PD_CUS || I % PD_CUS) return false;                   // equal row shares
+    const int NB = D / 32, NBI = I / 32, qr = pd_pad4(RQ / PD_CUS), wr = pd_pad4(D / PD_CUS), gr = pd_pad4(I / PD_CUS);
     if (qr * NB > PD_UQ * PD_THREADS || wr * NB > PD_UW * PD_THREADS || 2 * gr * NB > PD_UG * PD_THREADS || wr * NBI > PD_UD * PD_THREADS) return false;
     if (4 * qr > PD_THREADS || 4 * gr > PD_THREADS || 4 * wr > PD_THREADS || 2 * gr * (NB + 1) > PD_PART || wr * (NBI + 1) > PD_PART || qr * (NB + 1) > PD_PART) return false;
     const int lr = pd_pad4(pd_lm_rows(V));
@@ -136,7 +138,7 @@ struct PdPackParams {
     const uint8_t *raw[PD_MAXL][7];  // q, k, v, o, gate, up, down: raw GGUF tensors on the device, Q8_0 / Q4_0 / Q5_0 blocks (rtype)
     const uint8_t *lm_raw;           // output.weight (or token_embd for tied heads)
     unsigned char rtype[PD_MAXL][7], lm_type;      // WT_Q8_0 / WT_Q4_0 / WT_Q5_0: every one is int8 quants x an fp16 d (n - 8, q - 16)
-    int D, I, H, V, L;
+    int D, I, H, V, L, KV;
     uint4 *wimg; unsigned short *simg; uint4 *lmimg; unsigned short *lmsimg;
 };
 
@@ -152,15 +154,17 @@ __global__ void __launch_bounds__(PD_THREADS) pd_pack_kernel(PdPackParams P) {
         const int s = unit / PD_UNITS, k = unit % PD_UNITS;
         if (s < pd_nslots(P.L, xcd)) {
             const int layer = pd_first(P.L, xcd) + s;
-            const int qr = 3 * P.D / PD_CUS, wr = P.D / PD_CUS, gr = P.I / PD_CUS;       // this unit's rows of Q | K | V, of WO / down, of gate / up
+            const int kvd = P.KV * 64;
+            const int qr = (P.D + 2 * kvd) / PD_CUS, wr = P.D / PD_CUS, gr = P.I / PD_CUS;       // this unit's rows of Q | K | V, of WO / down, of gate / up
             int row, blk;
             if (k < PD_UQ) {
                 const int u = k * PD_THREADS + tid;
                 pd_unit_rc(u, NB, row, blk);
                 if (u < pd_pad4(qr) * NB && row < qr) {
-                    const int R = idx * qr + row, sect = R / P.D;          // row R of [q; k; v]
+                    const int R = idx * qr + row, sect = R < P.D ? 0 : R < P.D + kvd ? 1 : 2;          // row R of [q; k; v] (k, v: KV heads)
+                    const int rr = sect == 0 ? R : sect == 1 ? R - P.D : R - P.D - kvd;
                     bt = P.rtype[layer][sect];
-                    src = P.raw[layer][sect] + ((size_t)(R - sect * P.D) * NB + blk) * bsz(bt);
+                    src = P.raw[layer][sect] + ((size_t)rr * NB + blk) * bsz(bt);
                 }
             } else if (k < PD_UQ + PD_UW) {
                 const int u = (k - PD_UQ) * PD_THREADS + tid;
@@ -510,7 +514,7 @@ __device__ __forceinline__ float pd_rowsum(const float *p, int q) {
     return a;
 }
 
-template <int NB, int NBI>   // D / 32, I / 32: one instantiation per shape class
+template <int NB, int NBI, int KVH>   // D / 32, I / 32, kv heads: one instantiation per shape class
 __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4 *lmw = reinterpret_cast<uint4 *>(smem);                                          // [5][2][512]
@@ -535,7 +539,9 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
 
     const int tid0 = threadIdx.x;
     constexpr int D = NB * 32, I = NBI * 32, H = D / 64, NBP = NB | 1, NBIP = NBI | 1;
-    constexpr int QR = 3 * D / PD_CUS, QRP = (QR + 3) & ~3, WR = D / PD_CUS, WRP = (WR + 3) & ~3, GR = I / PD_CUS, GRP = (GR + 3) & ~3;   // this unit's rows per matrix
+    constexpr int KVD = KVH * 64, GQ = H / KVH;          // GQA (go/model.go:557-587): query head h reads kv head h / GQ
+    static_assert(H % KVH == 0, "query heads per kv head");
+    constexpr int QR = (D + 2 * KVD) / PD_CUS, QRP = (QR + 3) & ~3, WR = D / PD_CUS, WRP = (WR + 3) & ~3, GR = I / PD_CUS, GRP = (GR + 3) & ~3;   // this unit's rows per matrix
     const int L = P0.L;
     unsigned xcd;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcd));
@@ -761,8 +767,8 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
             }
             const bool arole = head || apart < nparts;          // (a helper beyond the passes there are has nothing to do)
             const int chf = nch - 1 - apart;                    // this unit's first (= highest) pass
-            float *const kc = P.kcache + (long long)layer * P.kv_layer_stride + (long long)(arole ? hidx : 0) * P.seq_len * 64;
-            float *const vc = P.vcache + (long long)layer * P.kv_layer_stride + (long long)(arole ? hidx : 0) * P.seq_len * 64;
+            float *const kc = P.kcache + (long long)layer * P.kv_layer_stride + (long long)(arole ? hidx / GQ : 0) * P.seq_len * 64;
+            float *const vc = P.vcache + (long long)layer * P.kv_layer_stride + (long long)(arole ? hidx / GQ : 0) * P.seq_len * 64;
             const __amdgpu_buffer_rsrc_t kr_ = pd_rsrc(kc, (unsigned)P.seq_len * 256u), vr_ = pd_rsrc(vc, (unsigned)P.seq_len * 256u);
             const int kr = lane >> 2, kq = lane & 3, vg = lane >> 4, vcl = lane & 15;
             float4 kreg[4], vreg[4];
@@ -810,7 +816,7 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                     if (tid < (head ? 192 : 64)) {
                         const int sect = tid >> 6, e = tid & 63;
                         const __amdgpu_buffer_rsrc_t r = pd_rsrc(P.gqkv + (size_t)layer * 3 * D, 3u * D * 8u);
-                        const unsigned off = (unsigned)(sect * D + hidx * 64 + e) * 8u;
+                        const unsigned off = (unsigned)((sect == 0 ? hidx * 64 : sect == 1 ? D + (hidx / GQ) * 64 : D + KVD + (hidx / GQ) * 64) + e) * 8u;
                         pd_u64 g;
                         for (int spins = 0;; spins++) {
                             g = pd_ld8(r, off);
@@ -831,8 +837,9 @@ __global__ void __launch_bounds__(PD_THREADS, 2) pd_decode_kernel(PdParams P0) {
                             else o = up ? (-x0 * es + x1 * ec) : (x0 * ec + x1 * es);
                         }
                         qs[tid] = o;
-                        if (sect == 1) kc[(long long)pos * 64 + e] = o;
-                        if (sect == 2) vc[(long long)pos * 64 + e] = o;
+                        // (the first query head of a kv group stores the group's K / V row: every head of the group computed the same one)
+                        if (sect == 1 && head && hidx % GQ == 0) kc[(long long)pos * 64 + e] = o;
+                        if (sect == 2 && head && hidx % GQ == 0) vc[(long long)pos * 64 + e] = o;
                     }
                     __syncthreads();
                     PD_RELANE();

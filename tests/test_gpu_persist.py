@@ -475,9 +475,54 @@ def test_persistent_decode_takes_q4_0_and_q5_0_files(hip, orc, tmp_path, monkeyp
     dev.close(); plain.close()
 
 
+@pytest.mark.parametrize("which", ["small_kv2", "nano_kv3"])
+def test_persistent_decode_with_grouped_query_heads(hip, orc, tmp_path, monkeypatch, which):
+    # GQA (go/model.go:557-587: query head h attends over kv head h / (H / KV)): [Q; K; V] has D + 2 KV 64 rows, every head
+    # unit gathers its group's k | v rows, the group's first head stores them.  The small shape with 2 kv heads and nano's
+    # width with 3 (D 576, 9 heads): ids and logits against the oracle across a second attention pass (helpers included), the
+    # resident session, the launch plans as second witness.
+    shape = (synth.ModelShape("pd_gqa2", 13, 256, 4, 2, 1024, seq_len=256, interm=512) if which == "small_kv2"
+             else synth.ModelShape("pd_nano_gqa3", 13, 576, 9, 3, 4096, seq_len=256))
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0" if which == "small_kv2" else "q4_0", 191)
+    g = gguf.load_gguf(str(p))
+    prompt = synth.prompt_ids(6, shape.vocab, seed=7)
+    first, want, want_logits = _oracle_run(orc, g, prompt, 150)       # positions 6 .. 155
+    dev = hip.load_llama_model(g)
+    assert dev.persist_info()["ready"], dev.persist_info()
+    dev.prefill(prompt)
+    assert int(np.argmax(dev.state.logits)) == first
+    got = dev.decode_greedy(first, len(prompt), 150)
+    assert dev.last_error() == "" and dev.persist_info()["tokens"] == 150
+    assert got == want, (got[:10], want[:10])
+    d = _rel(dev.debug_read("logits", shape.vocab), want_logits[-1])
+    dev.reset()
+    dev.prefill(prompt)
+    worst, tok = 0.0, first
+    for i in range(150):
+        dev.forward(tok, len(prompt) + i)
+        if i % 7 == 0 or i > 118:
+            worst = max(worst, _rel(dev.state.logits, want_logits[i]))
+        tok = want[i]
+    print(f"\npersistent decode, GQA {which}: 150 ids equal; last-step max|gpu-oracle| = {d:.2e}, session {worst:.2e}")
+    assert d <= LOGIT_TOL and worst <= LOGIT_TOL
+    monkeypatch.setenv("NL_PERSIST", "0")
+    plain = hip.load_llama_model(g)
+    plain.prefill(prompt)
+    assert plain.decode_greedy(first, len(prompt), 150) == want
+    # the K / V rows it wrote are the launch plans'
+    for which_c in ("k_cache", "v_cache"):
+        n = shape.n_layer * shape.n_kv_head * shape.seq_len * 64
+        a = dev.debug_read(which_c, n).reshape(-1, shape.seq_len, 64)[:, :150]
+        b = plain.debug_read(which_c, n).reshape(-1, shape.seq_len, 64)[:, :150]
+        assert np.abs(a - b).max() <= 2e-5, which_c
+    dev.close(); plain.close()
+
+
 def test_shapes_outside_the_instantiations_keep_the_launch_plans(hip, tmp_path):
-    # GQA, other widths, weight types that are not 32 int8-valued quants x an fp16 scale: not candidates (the launch plans serve them)
-    for shape, wt in ((synth.ModelShape("pd_gqa", 2, 256, 4, 2, 512, seq_len=64, interm=512), "q8_0"),
+    # kv-head counts without an instantiation, other widths, weight types that are not 32 int8-valued quants x an fp16 scale: not
+    # candidates (the launch plans serve them)
+    for shape, wt in ((synth.ModelShape("pd_gqa1", 2, 256, 4, 1, 512, seq_len=64, interm=512), "q8_0"),
                       (synth.ModelShape("pd_f16", 2, 256, 4, 4, 512, seq_len=64, interm=512), "f16"),
                       (synth.ModelShape("pd_q4k", 2, 256, 4, 4, 512, seq_len=64, interm=512), "q4_k"),
                       (synth.ModelShape("pd_wide", 2, 512, 8, 8, 512, seq_len=64, interm=1024), "q8_0")):

@@ -78,6 +78,10 @@ int run(int N, int iters) {
 #ifdef QG2_STAMPS
         variant("4/2/8", qgemm2_kernel<WT, 4, 2, 8>, 4, 2, 8);
 #else
+        variant("8/1/4", qgemm2_kernel<WT, 8, 1, 4>, 8, 1, 4);
+        variant("16/1/4", qgemm2_kernel<WT, 16, 1, 4>, 16, 1, 4);
+        variant("16/1/2", qgemm2_kernel<WT, 16, 1, 2>, 16, 1, 2);
+        variant("8/2/2", qgemm2_kernel<WT, 8, 2, 2>, 8, 2, 2);
         variant("8/1/8", qgemm2_kernel<WT, 8, 1, 8>, 8, 1, 8);
         variant("4/1/4", qgemm2_kernel<WT, 4, 1, 4>, 4, 1, 4);
         variant("2/2/8", qgemm2_kernel<WT, 2, 2, 8>, 2, 2, 8);
