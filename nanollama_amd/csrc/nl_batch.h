@@ -173,11 +173,26 @@ struct BEmbedParams {
     float *x;  // [N][dim]
     const int *gamma_row;
     const float *gamma_val;
+    // optional (decode batches / short prompts on dgemm_kernel): the token's RoPE rows and cache row offset, QGemmParams::Rope::tcos ...
+    const int *pos, *stream;
+    const float *rope_cos, *rope_sin;
+    float *tcos, *tsin;
+    long long *tkv;
+    int half, hd;
+    long long kv_stream_stride;
 };
 
 __global__ void bembed_kernel(BEmbedParams P) {
     const int token = sload_i32(P.tokens + blockIdx.x);   // (per-workgroup words of the step's metadata: scalar cache, no vector wait)
     float *x = P.x + (long long)blockIdx.x * P.dim;
+    if (P.tcos) {
+        const int pos = sload_i32(P.pos + blockIdx.x), strm = sload_i32(P.stream + blockIdx.x);
+        if ((int)threadIdx.x < P.half) {
+            P.tcos[(long long)blockIdx.x * P.half + threadIdx.x] = P.rope_cos[pos * P.half + threadIdx.x];
+            P.tsin[(long long)blockIdx.x * P.half + threadIdx.x] = P.rope_sin[pos * P.half + threadIdx.x];
+        }
+        if (threadIdx.x == 0) P.tkv[blockIdx.x] = (long long)strm * P.kv_stream_stride + (long long)pos * P.hd;
+    }
     const int gr = P.gamma_row ? P.gamma_row[token] : -1;
     for (int i = threadIdx.x; i < P.dim; i += blockDim.x) {
         float v = embed_value(P.table, P.wtype, P.dim, token, i);

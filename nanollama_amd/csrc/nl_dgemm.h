@@ -54,8 +54,9 @@ template <int T, int NWV, int NS, bool SSQ> struct DgLds {
 #ifdef DG_STAMPS
 __device__ long long g_dg_stamps[64];
 __device__ long long g_dg_census[2 * 2048];      // wall clock (100 MHz) at entry / exit of wavefront 0 of every workgroup
-#define DG_STAMP(i) do { if (blockIdx.x == 9 && threadIdx.x == 0 && (i) < 64) g_dg_stamps[(i)] = clock64(); \
-    if (((i) == 0 || (i) == 40) && threadIdx.x == 0 && blockIdx.x < 2048) g_dg_census[2 * blockIdx.x + ((i) ? 1 : 0)] = wall_clock64(); } while (0)
+#define DG_LIN (blockIdx.y * gridDim.x + blockIdx.x)
+#define DG_STAMP(i) do { if (DG_LIN == 9 && threadIdx.x == 0 && (i) < 64) g_dg_stamps[(i)] = clock64(); \
+    if (((i) == 0 || (i) == 40) && threadIdx.x == 0 && DG_LIN < 2048) g_dg_census[2 * DG_LIN + ((i) ? 1 : 0)] = wall_clock64(); } while (0)
 #else
 #define DG_STAMP(i) do { } while (0)
 #endif
@@ -92,14 +93,23 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
     static_assert(T % EG == 0 && NEG <= NWV, "epilogue groups");
     __shared__ __attribute__((aligned(16))) uint4 lds_all[L::TOTAL_U4];
     DG_STAMP(0);
+    // every kernel argument the launch reads, requested as ONE batch of s_load (hipcc otherwise fetches each field before its first
+    // use with a wait behind it: the prologue was fourteen dependent scalar round trips, 2 of the launch's 4.5 us)
+    NL_KARGS8(P.q, P.s, P.xf, P.q1, P.s1, P.out, P.resid, P.bias);
+    NL_KARGS8(P.rows, P.cols, P.npairs, P.ntiles, P.nt16, P.n_tokens, P.ldo, P.xf_out);
+    if constexpr (EPI != QG_EPI_PLAIN) NL_KARGS8(P.nrm_in.ssq, P.nrm_in.scale, P.nrm_in.scale_next, P.nrm_in.nrb, P.nrm_in.dim, P.nrm_in.eps, P.q, P.s);
+    if constexpr (EPI == QG_EPI_PLAIN) NL_KARGS8(P.nrm_out.w, P.nrm_out.xf, P.nrm_out.ssq, P.nrm_out.scale, P.q, P.s, P.xf, P.out);
+    if constexpr (EPI == QG_EPI_ROPE) {
+        NL_KARGS8(P.rope.tcos, P.rope.tsin, P.rope.tkv, P.rope.q, P.rope.kcache, P.rope.vcache, P.rope.bias_q, P.rope.bias_k);
+        NL_KARGS8(P.rope.bias_v, P.rope.head_dim, P.rope.n_q_heads, P.rope.n_kv_heads, P.rope.seq_len, P.rope.conj, P.q, P.s);
+    }
 
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 15, lq = lane >> 4;
     uint4 *const ring = lds_all + SSQ_U4 + wv * WAVE_U4;      // this wavefront's area
-    // block -> (row group, token tile): the token tiles of one row group sit on the same XCD (b % 8), next to each other in
-    // dispatch order
-    const int ntt = (P.n_tokens + 15) >> 4;
-    const int b = blockIdx.x, rg = (b & 7) + 8 * (b / (8 * ntt)), tt = (b >> 3) % ntt;
+    // block -> (row group, token tile): gridDim.x = 8 x token tiles, blockIdx.y = row group / 8 -- the linear dispatch order puts the
+    // token tiles of one row group on the same XCD (block b runs on XCD b % 8), next to each other; no division
+    const int rg = ((int)blockIdx.x & 7) + 8 * (int)blockIdx.y, tt = (int)blockIdx.x >> 3;
     if (rg * TPG >= P.ntiles) return;                            // (padding of the row groups to a multiple of 8: the whole workgroup)
     const int tile_base = rg * TPG;                              // first row tile of the workgroup (FUSED: of gate and of up)
     const int nblocks = P.cols >> 5;
@@ -155,24 +165,18 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
     const bool live = n < P.n_tokens;
     const int etile0 = tile_base + (wv < NEG ? (FUSED ? wv * 2 : wv * EG) : 0);  // first row tile of this wavefront's epilogue group (wv < NEG)
     [[maybe_unused]] float nsc = 1.0f, psc = 1.0f;
-    [[maybe_unused]] int pos = 0, strm = 0;
+    [[maybe_unused]] long long kvoff = 0;       // ROPE: stream * kv_stream_stride + pos * hd of the lane's token
     [[maybe_unused]] float4 rv[EG], bv[EG], gw[EG], rc4, rs4;
     const float *const dummy = reinterpret_cast<const float *>(P.q);     // (an absent operand reads the first bytes of the weights -- value
                                                                          //  unused -- so that no load sits behind a branch)
     {   // (every wavefront: a load inside a branch would be waited for at the end of the branch)
         if constexpr (EPI != QG_EPI_PLAIN) nsc = *(P.nrm_in.ssq && P.nrm_in.scale ? P.nrm_in.scale + nn : dummy);
         if constexpr (EPI == QG_EPI_ROPE) {
-            const int nlast = P.n_tokens - 1 - tt * 16;        // (>= 0: the grid has no empty token tile)
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int pk = sload_i32(P.rope.pos + tt * 16 + min(k, nlast)), sk = sload_i32(P.rope.stream + tt * 16 + min(k, nlast));
-                pos = li == k ? pk : pos;
-                strm = li == k ? sk : strm;
-            }
-            const int hd = P.rope.head_dim, half = hd >> 1, tph = hd / 16;
-            const int tile = min(etile0, P.ntiles - 1), i0 = (tile % tph) * 8 + 4 * (lq & 1);
-            rc4 = *reinterpret_cast<const float4 *>(P.rope.cos + pos * half + i0);
-            rs4 = *reinterpret_cast<const float4 *>(P.rope.sin + pos * half + i0);
+            const int hd = P.rope.head_dim, half = hd >> 1, tsh = hd == 64 ? 2 : 1;      // (head_dim is 32 or 64: tiles per head 2 or 4)
+            const int tile = min(etile0, P.ntiles - 1), i0 = (tile & ((1 << tsh) - 1)) * 8 + 4 * (lq & 1);
+            rc4 = *reinterpret_cast<const float4 *>(P.rope.tcos + (size_t)nn * half + i0);
+            rs4 = *reinterpret_cast<const float4 *>(P.rope.tsin + (size_t)nn * half + i0);
+            kvoff = P.rope.tkv[nn];
         }
         if constexpr (EPI == QG_EPI_PLAIN) {
             const int row0 = min(etile0, P.ntiles - EG) * TR;
@@ -307,9 +311,9 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
         // RoPE (go/model.go:449-477) + attention biases (:525-527) + KV store (:552-554), as qgemm2_kernel's epilogue: the
         // rotation partner of rows 4*lq + j is rows 4*(lq ^ 2) + j of the same tile and token: lane ^ 32
         const QGemmParams::Rope &R = P.rope;
-        const int hd = R.head_dim, half = hd >> 1, tph = hd / 16, nq = R.n_q_heads * hd;
+        const int hd = R.head_dim, half = hd >> 1, tsh = hd == 64 ? 2 : 1, nq = R.n_q_heads * hd;
         const int tile = min(etile0, P.ntiles - 1);
-        const int head = tile / tph, i0 = (tile % tph) * 8 + 4 * (lq & 1), e0 = i0 + (lq >> 1) * half;
+        const int head = tile >> tsh, i0 = (tile & ((1 << tsh) - 1)) * 8 + 4 * (lq & 1), e0 = i0 + (lq >> 1) * half;
         const bool is_q = head < R.n_q_heads, is_k = !is_q && head < R.n_q_heads + R.n_kv_heads;
         const int kvh = head - R.n_q_heads - (is_k ? 0 : R.n_kv_heads);
         float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -333,8 +337,9 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
             o[j] = outv;
         }
         if (!live || etile0 >= P.ntiles) return;
+        asm volatile("" : "+v"(kvoff));
         float *dstp = is_q ? R.q + ((long long)n * nq + head * hd + e0)
-                           : (is_k ? R.kcache : R.vcache) + ((long long)strm * R.kv_stream_stride + ((long long)kvh * R.seq_len + pos) * hd + e0);
+                           : (is_k ? R.kcache : R.vcache) + (kvoff + (long long)kvh * R.seq_len * hd + e0);
         *reinterpret_cast<float4 *>(dstp) = make_float4(o[0], o[1], o[2], o[3]);
         return;
     }
@@ -389,23 +394,23 @@ __global__ void dg_permute_kernel(const uint4 *q, const uint32_t *s, uint4 *q3, 
     }
 }
 
-// grid.x of a dgemm launch: row groups padded to a multiple of 8 (the block -> XCD map), times the token tiles
-inline unsigned dg_grid(int ntiles, int tiles_per_wg, int n_tokens) {
+// grid of a dgemm launch: x = 8 x token tiles, y = row groups / 8 (row groups padded to a multiple of 8: the block -> XCD map)
+inline dim3 dg_grid(int ntiles, int tiles_per_wg, int n_tokens) {
     const int nrg = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
-    return (unsigned)(((nrg + 7) / 8) * 8 * ((n_tokens + 15) / 16));
+    return dim3((unsigned)(8 * ((n_tokens + 15) / 16)), (unsigned)((nrg + 7) / 8), 1);
 }
 
 // the three launches of a layer: T = 3 (Q|K|V), 8 (gate || up), 2 (WO, down); the wavefront count and the blocks per wavefront
-// follow from K.  false: no instantiation for this K (the caller keeps the split-K launches)
+// follow from K.  An instantiation that does not fit the LDS is not made (the caller keeps the split-K launches)
 template <int T, int NWV, int NS, int EPI>
 inline hipError_t dg_launch(QGemmParams P, hipStream_t st) {
     P.nt16 = ((P.n_tokens + 63) / 64) * 4;
     P.ksplit = 1;
     constexpr int TILES_PER_WG = EPI == QG_EPI_SWIGLU ? T / 2 : T;
     if constexpr (DgLds<T, NWV, NS, EPI != QG_EPI_PLAIN>::TOTAL_U4 * 16 <= DG_LDS_BYTES - 512) {
-        hipLaunchKernelGGL((dgemm_kernel<T, NWV, NS, EPI>), dim3(dg_grid(P.ntiles, TILES_PER_WG, P.n_tokens)), dim3(NWV * 64), 0, st, P);
+        hipLaunchKernelGGL((dgemm_kernel<T, NWV, NS, EPI>), dg_grid(P.ntiles, TILES_PER_WG, P.n_tokens), dim3(NWV * 64), 0, st, P);
         return hipGetLastError();
-    } else return hipErrorInvalidValue;      // (the weights of NS steps do not fit the LDS: not instantiated)
+    } else return hipErrorInvalidValue;
 }
 // wavefronts for a K of nb quant blocks: eight while that leaves a wavefront <= 8 blocks (measured faster than sixteen on every
 // K = 1536 launch: 7.85 / 5.7 / 11.75 us against 8.4 / 6.6 / 12.8, tools/dgemm_bench.hip), else sixteen; blocks per wavefront

@@ -212,6 +212,8 @@ struct nl_engine {
         float *x = nullptr, *qkv = nullptr, *q = nullptr, *g = nullptr, *u = nullptr, *logits = nullptr,
               *part_o = nullptr, *part_ml = nullptr;
         int *tok = nullptr, *pos = nullptr, *stream = nullptr, *ids = nullptr;
+        float *tcos = nullptr, *tsin = nullptr;      // [cap][hd / 2]: the RoPE rows of every token's position (bembed_kernel; QGemmParams::Rope::tcos)
+        long long *tkv = nullptr;                    // [cap]: stream * kv_stream_stride + pos * hd
         int *h_meta = nullptr;  // pinned [5][cap]: token | position | stream | attention workgroup list | partials per token
         uint4 *kv16 = nullptr;  // one layer's K / V^T of a prompt's stream as fp16 hi / lo LDS images (nl_batch.h Kv16Image)
     } bt;
@@ -1840,6 +1842,9 @@ int batch_alloc(nl_engine *e, nl_engine::Batch &b, int cap_limit = 2048) {
     b.pos = b.tok + n;
     b.stream = b.tok + 2 * n;
     HIPCK(e, dalloc(&b.ids, n, &e->bytes_state));
+    HIPCK(e, dalloc(&b.tcos, n * (size_t)(e->hd / 2), &e->bytes_state));
+    HIPCK(e, dalloc(&b.tsin, n * (size_t)(e->hd / 2), &e->bytes_state));
+    HIPCK(e, dalloc(&b.tkv, n, &e->bytes_state));
     {   // one layer's K / V^T as fp16 hi / lo LDS images (Kv16Image), rebuilt per layer of a prompt step
         const size_t img = e->hd == 64 ? Kv16Image<64>::BYTES : Kv16Image<32>::BYTES;
         HIPCK(e, dalloc(&b.kv16, (size_t)e->KVs * e->nsplit_max * img / 16, &e->bytes_state));
@@ -1971,7 +1976,8 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
     }
     LCK(hipMemcpyAsync(b.tok, b.h_meta, (size_t)5 * b.cap * 4, hipMemcpyHostToDevice, st));
     {
-        BEmbedParams P{e->embd_raw, e->embd_type, D, b.tok, b.x, e->gamma_row, e->gamma_val};
+        BEmbedParams P{e->embd_raw, e->embd_type, D, b.tok, b.x, e->gamma_row, e->gamma_val,
+                       b.pos, b.stream, e->rope_cos, e->rope_sin, b.tcos, b.tsin, b.tkv, hd / 2, hd, e->kv_stream_stride};
         hipLaunchKernelGGL(bembed_kernel, dim3(n), dim3(256), 0, st, P);
         LCK(hipGetLastError());
     }
@@ -2044,7 +2050,7 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
             P.xf = folded_in ? b.xfrag2 : b.xfrag; P.nrm_in = folded_in ? nin_attn : nin_off;
             P.n_tokens = n; P.ldo = (int)R; P.x1 = x1_gemm;
             P.rope = QGemmParams::Rope{b.pos, b.stream, e->rope_cos, e->rope_sin, b.q, kc, vc, e->kv_stream_stride,
-                                       L.bq, L.bk, L.bv, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate};
+                                       L.bq, L.bk, L.bv, hd, e->Hs, e->KVs, c.seq_len, c.rope_conjugate, b.tcos, b.tsin, b.tkv};
             LCK(dg ? launch_dgemm_rope(P, st) : launch_qgemm_rope(m.wtype, P, st));
         } else {
             LCK(qg(e, b, L.qkv, n, b.qkv, R, nullptr, st, &qkv_out, b.kpart, nullptr, nullptr, nullptr, x1_gemm));
@@ -3067,7 +3073,7 @@ int nl_destroy(nl_handle e) {
     if (e->stage) hipFree(e->stage);
     auto batch_free = [](nl_engine::Batch &b) {
         void *bb[] = {b.x, b.qkv, b.q, b.g, b.u, b.logits, b.part_o, b.part_ml, b.tok /* | pos | stream */, b.ids, b.kpart, b.kpart2,
-                      b.xfrag, b.xfrag2, b.ssq, b.nscale, b.kv16};
+                      b.xfrag, b.xfrag2, b.ssq, b.nscale, b.kv16, b.tcos, b.tsin, b.tkv};
         for (void *p : bb) if (p) hipFree(p);
         if (b.h_meta) hipHostFree(b.h_meta);
     };

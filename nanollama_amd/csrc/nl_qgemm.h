@@ -72,6 +72,10 @@ struct QGemmParams {
         long long kv_stream_stride;
         const float *bias_q, *bias_k, *bias_v;
         int head_dim, n_q_heads, n_kv_heads, seq_len, conj;
+        // dgemm_kernel (nl_dgemm.h): the step's positions resolved once per token by the embedding launch (bembed_kernel) -- the RoPE
+        // rows cos / sin[pos[n]][hd / 2] and stream[n] * kv_stream_stride + pos[n] * hd -- so that no launch of a layer chases pos -> table
+        const float *tcos, *tsin;            // [N][hd/2]
+        const long long *tkv;                // [N]
     } rope;
     // RMSNorm (go/quant.go:597-607) folded around the GEMMs of a prompt (nl_qgemm2.h).  A producer -- WO or down with
     // the plain epilogue, unsplit, so its lanes hold finished rows of the new residual stream -- also emits those rows

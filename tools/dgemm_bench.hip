@@ -25,6 +25,7 @@ __global__ void fill_f32(float *p, size_t n, float v) {
 __global__ void fill_f64(double *p, size_t n, double v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
+__global__ void fill_tkv(long long *p, int n, long long stream_stride, long long pos_mul) { for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = i * stream_stride + i * pos_mul; }
 __global__ void fill_iota(int *p, int n, int mul) { for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = i * mul; }
 
 int main(int argc, char **argv) {
@@ -48,7 +49,7 @@ int main(int argc, char **argv) {
     uint4 *xf, *xf2; CK(hipMalloc(&xf, nxf * 16)); CK(hipMalloc(&xf2, nxf * 16));
     fill_u32<<<2048, 256, 0, st>>>((uint32_t *)xf, nxf * 4, 3, 0x03ff03ffu, 0x30003000u); // fp16 values ~0.1
     fill_u32<<<2048, 256, 0, st>>>((uint32_t *)xf2, nxf * 4, 4, 0x03ff03ffu, 0x30003000u);
-    float *x, *qout, *kc, *vc, *cs, *sn, *nw, *sc1, *sc2; double *ssq; int *pos, *strm;
+    float *x, *qout, *kc, *vc, *cs, *sn, *nw, *sc1, *sc2, *tcs, *tsn; double *ssq; int *pos, *strm; long long *tkv;
     CK(hipMalloc(&x, (size_t)64 * D * 4)); CK(hipMalloc(&qout, (size_t)64 * H * hd * 4));
     const size_t kvs = (size_t)KV * seq * hd;
     CK(hipMalloc(&kc, kvs * 64 * 4)); CK(hipMalloc(&vc, kvs * 64 * 4));
@@ -60,6 +61,9 @@ int main(int argc, char **argv) {
     fill_f32<<<1, 64, 0, st>>>(sc1, 64, 1.0f); fill_f32<<<1, 64, 0, st>>>(sc2, 64, 1.0f);
     fill_f64<<<16, 256, 0, st>>>(ssq, (size_t)64 * (D / 32), 8.0);
     fill_iota<<<1, 64, 0, st>>>(pos, 64, 3); fill_iota<<<1, 64, 0, st>>>(strm, 64, 1);
+    CK(hipMalloc(&tcs, (size_t)64 * hd / 2 * 4)); CK(hipMalloc(&tsn, (size_t)64 * hd / 2 * 4)); CK(hipMalloc(&tkv, 64 * 8));
+    fill_f32<<<8, 256, 0, st>>>(tcs, (size_t)64 * hd / 2, 0.8f); fill_f32<<<8, 256, 0, st>>>(tsn, (size_t)64 * hd / 2, 0.6f);
+    fill_tkv<<<1, 64, 0, st>>>(tkv, 64, (long long)kvs, 3LL * hd);
     CK(hipStreamSynchronize(st));
 
     auto timeit = [&](const char *name, auto launch, double bytes, double flop) {
@@ -100,31 +104,31 @@ int main(int argc, char **argv) {
     timeit("qkv+rope", [&](int i) {
         QGemmParams P = base(qkv, i);
         P.xf = xf; P.ldo = R; P.nrm_in = nin;
-        P.rope = QGemmParams::Rope{pos, strm, cs, sn, qout, kc, vc, (long long)kvs, nullptr, nullptr, nullptr, hd, H, KV, seq, 0};
+        P.rope = QGemmParams::Rope{pos, strm, cs, sn, qout, kc, vc, (long long)kvs, nullptr, nullptr, nullptr, hd, H, KV, seq, 0, tcs, tsn, tkv};
         CK(dg_launch_rope(P, st));
     }, (double)qkv.qbytes * 18 / 16, 2.0 * R * D * N);
-    stamps("qkv", (int)dg_grid(qkv.ntiles, 3, N));
+    stamps("qkv", (int)(dg_grid(qkv.ntiles, 3, N).x * dg_grid(qkv.ntiles, 3, N).y));
     timeit("wo+norm", [&](int i) {
         QGemmParams P = base(wo, i);
         P.xf = xf; P.out = x; P.ldo = D; P.resid = x;
         P.nrm_out = QGemmParams::NormOut{nw, xf2, ssq, sc1};
         CK(dg_launch_plain(P, st));
     }, (double)wo.qbytes * 18 / 16, 2.0 * D * D * N);
-    stamps("wo", (int)dg_grid(wo.ntiles, 2, N));
+    stamps("wo", (int)(dg_grid(wo.ntiles, 2, N).x * dg_grid(wo.ntiles, 2, N).y));
     timeit("gate|up", [&](int i) {
         QGemmParams P = base(gate, i);
         P.q1 = up.q + (size_t)(i % up.copies) * up.qbytes; P.s1 = up.s + (size_t)(i % up.copies) * up.swords;
         P.xf = xf; P.ldo = I; P.nrm_in = nin; P.xf_out = xf2; P.out_q4 = 1;
         CK(dg_launch_swiglu(P, st));
     }, (double)gate.qbytes * 2 * 18 / 16, 2.0 * 2 * I * D * N);
-    stamps("gate|up", (int)dg_grid(gate.ntiles, 4, N));
+    stamps("gate|up", (int)(dg_grid(gate.ntiles, 4, N).x * dg_grid(gate.ntiles, 4, N).y));
     timeit("down+norm", [&](int i) {
         QGemmParams P = base(down, i);
         P.xf = xf2; P.out = x; P.ldo = D; P.resid = x;
         P.nrm_out = QGemmParams::NormOut{nw, xf, ssq, sc1};
         CK(dg_launch_plain(P, st));
     }, (double)down.qbytes * 18 / 16, 2.0 * D * I * N);
-    stamps("down", (int)dg_grid(down.ntiles, 2, N));
+    stamps("down", (int)(dg_grid(down.ntiles, 2, N).x * dg_grid(down.ntiles, 2, N).y));
 
     return 0;
 }
