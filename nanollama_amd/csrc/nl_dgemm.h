@@ -446,5 +446,300 @@ inline hipError_t dg_launch_k(const QGemmParams &P, hipStream_t st) {
 inline hipError_t dg_launch_rope(const QGemmParams &P, hipStream_t st) { return dg_launch_k<3, QG_EPI_ROPE>(P, st); }
 inline hipError_t dg_launch_swiglu(const QGemmParams &P, hipStream_t st) { return dg_launch_k<8, QG_EPI_SWIGLU>(P, st); }
 inline hipError_t dg_launch_plain(const QGemmParams &P, hipStream_t st) { return dg_launch_k<2, QG_EPI_PLAIN>(P, st); }
+// ---- the LM head of a decode batch (go/model.go:616-619) ------------------------------------------------------------------------
+// 2000 row tiles (vocabulary 32000) against 4 token tiles would be 1000-2000 workgroups of dgemm_kernel: four to eight rounds on 256
+// compute units, every round re-reading its token tile's fragments (98 KB for K = 1536) and paying ~3 us between a workgroup's exit
+// and its successor's entry (tools/dgemm_bench.hip: 41 us; the split-K launches it would replace: 45).  Here a workgroup STAYS: one
+// per compute unit, its 16 tokens' fragments in registers for the whole launch (NS pairs per wavefront, loaded once), and it walks
+// the row groups rg, rg + stride, ... of four row tiles each; the weights of the NEXT row group are requested (LDS-DMA into the other
+// of two buffers) before the products of this one start, so HBM latency and streaming sit under the matrix work.  Same per-wavefront
+// block ownership, operand layout and arithmetic as dgemm_kernel; the partial tiles overlay the buffer just consumed, one wavefront
+// per row tile reduces them in wavefront order, scales by the folded final RMSNorm (QGemmParams::NormIn), stores the logits rows and
+// one (max, index) candidate per token and row tile for the argmax launch behind (P.part1: [token][rows / 16] {value, index};
+// go/main.go:400-408: strict '>', the earlier index wins; row 0 is taken whatever it holds, as the reference's loop starts from it).
+// a workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every vector-memory operation of the wavefront
+// (vmcnt(0)) -- here that would drain the next row group's LDS-DMA pieces at every barrier (measured: 36 us instead of 18)
+__device__ __forceinline__ void dg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ... and LDS reads hipcc does not see: in front of a ds_read it emits, it waits for every LDS-DMA piece in flight (they might write
+// what is read) -- the partial tiles and the sums of squares are read while the next row group streams in.  The caller waits
+// (dg_lds_wait) before the first use.
+__device__ __forceinline__ unsigned dg_lds_addr(const void *p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p; }
+__device__ __forceinline__ void dg_lds_read16(f32x4_t &v, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory"); }
+__device__ __forceinline__ void dg_lds_read8(double &v, unsigned addr) { asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory"); }
+// (the values are operands of the wait: nothing that uses them may be scheduled in front of it)
+__device__ __forceinline__ void dg_lds_wait(double &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) :: "memory"); }
+template <int N>
+__device__ __forceinline__ void dg_lds_wait(f32x4_t (&v)[N]) {
+    static_assert(N == 8 || N == 16, "partial tiles of 8 or 16 wavefronts");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+    if constexpr (N == 16)
+        asm volatile("" : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) :: "memory");
+}
+#ifdef DG_DEBUG_INV
+__device__ float g_dg_dbg[192];
+#endif
+constexpr int DGH_T = 4;
+template <int NWV, int NS> struct DgHeadLds {
+    static constexpr int REG_U4 = 20 * DGH_T;
+    static constexpr int WAVE_U4 = NS * REG_U4 > DGH_T * 64 ? NS * REG_U4 : DGH_T * 64;
+    static constexpr int BUF_U4 = NWV * WAVE_U4;
+    static constexpr int SSQ_U4 = DG_SSQ_BYTES / 16 + 16;          // + 256 bytes: the producer's pre-scale of the tile's 16 tokens
+    static constexpr int TOTAL_U4 = SSQ_U4 + 2 * BUF_U4;
+};
+template <int NWV, int NS>
+__global__ void __launch_bounds__(NWV * 64, NWV / 4) dghead_kernel(QGemmParams P) {
+    typedef DgHeadLds<NWV, NS> L;
+    constexpr int T = DGH_T, REG_U4 = L::REG_U4, WAVE_U4 = L::WAVE_U4, BUF_U4 = L::BUF_U4, SSQ_U4 = L::SSQ_U4;
+    constexpr int OPS = 2;                                       // memory operations per step: one nibble piece (64 lanes = 4 tiles x 16 rows), one scale piece
+    static_assert((2 * NS - 1) * OPS <= 63, "vmcnt is six bits");
+    static_assert(NWV >= T, "one epilogue wavefront per row tile");
+    __shared__ __attribute__((aligned(16))) uint4 lds_all[L::TOTAL_U4];
+    NL_KARGS8(P.q, P.s, P.xf, P.out, P.part1, P.nrm_in.ssq, P.nrm_in.scale, P.nrm_in.scale_next);
+    NL_KARGS8(P.rows, P.cols, P.npairs, P.ntiles, P.nt16, P.n_tokens, P.ldo, P.nrm_in.nrb);
+    NL_KARGS2(P.nrm_in.dim, P.nrm_in.eps);
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 15, lq = lane >> 4;
+    // block -> (first row group, token tile) as dgemm_kernel: the token tiles of a row group on one XCD
+    const int rg0 = ((int)blockIdx.x & 7) + 8 * (int)blockIdx.y, tt = (int)blockIdx.x >> 3, stride = 8 * (int)gridDim.y;
+    DG_STAMP(0);
+    const int nrg = (P.ntiles + T - 1) / T;
+    if (rg0 >= nrg) return;
+    const int niter = (nrg - rg0 + stride - 1) / stride;
+    const int blk0 = wv, k0 = (blk0 >> 1) & 3, cc = blk0 & 1;
+    const int n = tt * 16 + li, nn = min(n, P.n_tokens - 1);
+    const bool live = n < P.n_tokens;
+    if (P.nrm_in.ssq) {      // the producer's partial sums of squares of this tile's 16 tokens -> LDS (older than every weight piece)
+        const unsigned bytes = 16u * (unsigned)P.nrm_in.nrb * 8u;
+        const char *const src = reinterpret_cast<const char *>(P.nrm_in.ssq + (size_t)tt * 16 * P.nrm_in.nrb);
+        for (unsigned p0 = (unsigned)wv * 1024u; p0 < bytes; p0 += NWV * 1024u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + min(p0 + lane * 16u, bytes - 16u)),
+                                             (__attribute__((address_space(3))) void *)(lds_all + p0 / 16), 16, 0, DG_AUX);
+        // ... and their power-of-two pre-scales (lane -> token lane & 15; a register load would have to be waited for by hand at
+        // a point the compiler may already have copied the register)
+        if (wv == 0 && P.nrm_in.scale)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(P.nrm_in.scale + nn),
+                                             (__attribute__((address_space(3))) void *)(lds_all + DG_SSQ_BYTES / 16), 4, 0, DG_AUX);
+    }
+    // this wavefront's NS fragment pairs of the token tile: registers, for the whole launch
+    dg_u32x4 xh[NS], xl[NS];
+    {
+        const unsigned xblock = (unsigned)P.nt16 * (2 * QG_FRAG * 16);
+        const char *xsrc = reinterpret_cast<const char *>(P.xf) + ((size_t)blk0 * xblock + ((size_t)(tt * 2) * QG_FRAG + lane) * 16);
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(xh[s]) : "v"(xsrc) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:1024 sc1" : "=&v"(xl[s]) : "v"(xsrc) : "memory");
+            xsrc += (size_t)NWV * xblock;
+        }
+    }
+    // the NS steps of row group rg into buffer b: lane -> (tile lane >> 4, row lane & 15) of the group
+    auto issue = [&](int rg, int b) {
+        const int tile = min(rg * T + (lane >> 4), P.ntiles - 1), r = lane & 15;
+        const size_t grp = (size_t)tile * P.npairs + (size_t)(blk0 >> 3) * KL;
+        const char *wsrc = reinterpret_cast<const char *>(P.q) + (grp * (2 * TR) + (size_t)((k0 * 2 + cc) * TR + r)) * 16;
+        const char *ssrc = reinterpret_cast<const char *>(P.s) + (grp * TR + (size_t)(k0 * TR + r)) * 4;
+        uint4 *const ring = lds_all + SSQ_U4 + b * BUF_U4 + wv * WAVE_U4;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)wsrc,
+                                             (__attribute__((address_space(3))) void *)(ring + s * REG_U4), 16, 0, DG_AUX);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)ssrc,
+                                             (__attribute__((address_space(3))) void *)(ring + s * REG_U4 + 16 * T), 4, 0, DG_AUX);
+            wsrc += KL * 2 * TR * 16 * (NWV / 8);
+            ssrc += KL * TR * 4 * (NWV / 8);
+        }
+    };
+    issue(rg0, 0);
+    if (niter > 1) issue(rg0 + stride, 1);
+    asm volatile("" ::: "memory");
+    // the fragments have landed when only the weight pieces issued behind them are outstanding.  They are pinned HERE, once, in
+    // straight-line code: a "+v" inside the loop's two product variants made hipcc copy the registers at the branch -- in front
+    // of the wait (wrong products for whatever had not landed; seen with one row group per workgroup)
+    if (niter > 1) DG_WAIT_VM(2 * NS * OPS); else DG_WAIT_VM(NS * OPS);
+#pragma unroll
+    for (int s = 0; s < NS; s++) asm volatile("" : "+v"(xh[s]), "+v"(xl[s]) :: "memory");
+    float inv = 1.0f;
+    for (int it = 0; it < niter; it++) {
+        const int rg = rg0 + it * stride, b = it & 1;
+        const bool has_next = it + 1 < niter;
+        if (it > 0 && has_next) issue(rg + stride, b ^ 1);
+        asm volatile("" ::: "memory");
+        DG_STAMP(1 + 4 * it);
+        uint4 *const ring = lds_all + SSQ_U4 + b * BUF_U4 + wv * WAVE_U4;
+        f32x4_t acc[T];
+#pragma unroll
+        for (int ti = 0; ti < T; ti++) acc[ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        auto products = [&](auto next_) {
+            constexpr int AHEAD = decltype(next_)::value ? NS * OPS : 0;      // the next row group's pieces, issued behind this one's
+            dg_static_for<0, NS>([&](auto s_) {
+                constexpr int s = decltype(s_)::value;
+                DG_WAIT_VM((NS - 1 - s) * OPS + AHEAD);
+                asm volatile("" ::: "memory");
+                const uint32_t *const sb32 = reinterpret_cast<const uint32_t *>(ring + s * REG_U4);
+                const half8_t xhv = __builtin_bit_cast(half8_t, xh[s]), xlv = __builtin_bit_cast(half8_t, xl[s]);
+                half8_t a[T];
+                uint32_t sw[T];
+                f32x4_t z[T];
+#pragma unroll
+                for (int g = 0; g < T; g++) {
+                    a[g] = WFrag<WT_Q4_0>::expand(sb32[(g * 16 + li) * 4 + lq]);
+                    sw[g] = sb32[(16 * T) * 4 + g * 16 + li];
+                }
+#pragma unroll
+                for (int g = 0; g < T; g++) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xlv, a[g], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < T; g++) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xhv, a[g], z[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < T; g++) {
+                    const float d = scale_of(sw[g], cc);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[g][r] = fmaf(z[g][r], d, acc[g][r]);
+                }
+            });
+        };
+#ifdef DG_STAMPS
+        if (DG_LIN == 9 && lane == 0 && it == 2) g_dg_stamps[41 + wv] = clock64();
+#endif
+        if (has_next) products(std::true_type{}); else products(std::false_type{});
+#ifdef DG_STAMPS
+        if (DG_LIN == 9 && lane == 0 && it == 2) g_dg_stamps[49 + wv] = clock64();
+#endif
+        DG_STAMP(2 + 4 * it);
+        // partial tiles over the buffer just consumed: D[token 4 lq + r][row li] out as [tile][token][row]
+        {
+            float *const mine = reinterpret_cast<float *>(ring);
+#pragma unroll
+            for (int ti = 0; ti < T; ti++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) mine[ti * 256 + (4 * lq + r) * 16 + li] = acc[ti][r];
+        }
+        dg_lds_barrier();
+        DG_STAMP(3 + 4 * it);
+        if (it == 0 && P.nrm_in.ssq) {       // inv of this lane's token, as dgemm_kernel's consumer side (every wavefront: the epilogue rotates)
+            const unsigned sq = dg_lds_addr(lds_all) + (unsigned)(li * P.nrm_in.nrb) * 8u;
+            double tot = 0.0;
+            for (int r = lq; r < P.nrm_in.nrb; r += 4) {
+                double v;
+                dg_lds_read8(v, sq + (unsigned)r * 8u);
+                dg_lds_wait(v);
+                tot += v;
+            }
+#ifdef DG_DEBUG_INV
+            if (rg0 == 0 && tt == 0 && wv == 1) g_dg_dbg[lane] = (float)tot;
+#endif
+            const double t1 = __shfl_xor(tot, 16);
+            const double lo2 = (lq & 1) ? t1 + tot : tot + t1;
+            const double t2 = __shfl_xor(lo2, 32);
+            tot = (lq & 2) ? t2 + lo2 : lo2 + t2;
+            inv = (float)(1.0 / sqrt(tot / (double)P.nrm_in.dim + (double)P.nrm_in.eps));
+#ifdef DG_DEBUG_INV
+            if (rg0 == 0 && tt == 0 && wv == 1) g_dg_dbg[64 + lane] = inv;
+#endif
+            if (P.nrm_in.scale) {
+                float nsc;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nsc) : "v"(dg_lds_addr(lds_all + DG_SSQ_BYTES / 16) + (unsigned)li * 4u) : "memory");
+                if (rg0 == 0 && wv == 0 && lq == 0 && live) P.nrm_in.scale_next[n] = norm_prescale(inv);
+                inv *= 1.0f / nsc;
+#ifdef DG_DEBUG_INV
+                if (rg0 == 0 && tt == 0 && wv == 1) g_dg_dbg[128 + lane] = nsc;
+#endif
+            }
+        }
+        // row tile ti of the group: wavefront (ti + it) % NWV (the duty moves so that no wavefront falls behind for the whole launch)
+        const int ti = (wv - it) & (NWV - 1);
+        const int etile = rg * T + ti;
+        if (ti < T && etile < P.ntiles) {
+            f32x4_t e = f32x4_t{0.f, 0.f, 0.f, 0.f}, pt[NWV];
+            const unsigned pa = dg_lds_addr(lds_all + SSQ_U4 + b * BUF_U4) + (unsigned)(ti * 256 + li * 16 + lq * 4) * 4u;
+#pragma unroll
+            for (int w = 0; w < NWV; w++) dg_lds_read16(pt[w], pa + (unsigned)(w * WAVE_U4) * 16u);
+            dg_lds_wait(pt);
+#pragma unroll
+            for (int w = 0; w < NWV; w++) e += pt[w];
+            e = e * inv;
+            if (live) {
+                const int row0 = etile * TR + lq * 4;
+                *reinterpret_cast<float4 *>(P.out + (size_t)n * P.ldo + row0) = make_float4(e[0], e[1], e[2], e[3]);
+                float best = -INFINITY;
+                int bidx = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (e[j] > best || row0 + j == 0) { best = e[j]; bidx = row0 + j; }
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {       // (the four lanes of a token are live together)
+                    const float ov = __shfl_xor(best, o);
+                    const int oi = __shfl_xor(bidx, o);
+                    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+                }
+                if (lq == 0) reinterpret_cast<uint2 *>(P.part1)[(size_t)n * P.ntiles + etile] = make_uint2(__float_as_uint(best), (unsigned)bidx);
+            }
+        }
+#ifdef DG_STAMPS
+        if (DG_LIN == 9 && lane == 0 && it == 2 && ti < T) g_dg_stamps[57 + ti] = clock64();
+#endif
+        DG_STAMP(4 + 4 * it);
+        if (has_next) dg_lds_barrier();      // (the row group after next lands in this buffer: requested behind this barrier)
+    }
+    DG_STAMP(40);
+}
+inline bool dg_head_ok(int rows, int cols) {
+    if (cols <= 0 || cols % 256 || rows % 16) return false;
+    const int nb = cols / 32, nwv = dg_waves(nb), ns = nb / nwv;
+    if (nb % nwv || !(ns == 1 || ns == 2 || ns == 3 || ns == 4 || ns == 6)) return false;
+    return (DG_SSQ_BYTES / 16 + 2 * nwv * std::max(ns * 20 * DGH_T, 64 * DGH_T)) * 16 <= DG_LDS_BYTES - 512;
+}
+template <int NWV, int NS>
+inline hipError_t dg_launch_head_k(QGemmParams P, hipStream_t st, int num_cus) {
+    P.nt16 = ((P.n_tokens + 63) / 64) * 4;
+    P.ksplit = 1;
+    if constexpr (DgHeadLds<NWV, NS>::TOTAL_U4 * 16 <= DG_LDS_BYTES - 512) {
+        const int ntt = (P.n_tokens + 15) / 16, nrg = (P.ntiles + DGH_T - 1) / DGH_T;
+        const int gy = std::max(1, std::min((nrg + 7) / 8, num_cus / (8 * ntt)));      // one workgroup per compute unit
+        hipLaunchKernelGGL((dghead_kernel<NWV, NS>), dim3((unsigned)(8 * ntt), (unsigned)gy), dim3(NWV * 64), 0, st, P);
+        return hipGetLastError();
+    } else return hipErrorInvalidValue;
+}
+inline hipError_t dg_launch_head(const QGemmParams &P, hipStream_t st, int num_cus = 256) {
+    const int nb = P.cols / 32, nwv = dg_waves(nb), ns = nb / nwv;
+    if (nwv == 8) {
+        switch (ns) {
+        case 1: return dg_launch_head_k<8, 1>(P, st, num_cus);
+        case 2: return dg_launch_head_k<8, 2>(P, st, num_cus);
+        case 3: return dg_launch_head_k<8, 3>(P, st, num_cus);
+        case 4: return dg_launch_head_k<8, 4>(P, st, num_cus);
+        case 6: return dg_launch_head_k<8, 6>(P, st, num_cus);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+// argmax of a decode batch behind the LM-head launch: its candidates [token][nc] {value, index} -> ids; one workgroup per token,
+// the merge of bargmax_kernel (nl_batch.h)
+__global__ void __launch_bounds__(1024) dg_argmax_kernel(const uint2 *cand, int nc, int *ids) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const uint2 *c = cand + (size_t)blockIdx.x * nc;
+    const int tid = threadIdx.x;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = tid; i < nc; i += (int)blockDim.x) {
+        const uint2 v = c[i];
+        const float f = __uint_as_float(v.x);
+        if (f > best || idx == 0x7fffffff) { best = f; idx = (int)v.y; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(idx, o);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        ids[blockIdx.x] = idx == 0x7fffffff ? 0 : idx;
+    }
+}
 
 }  // namespace nl

@@ -230,6 +230,7 @@ struct nl_engine {
         std::vector<G> graphs;
     } sub[4];
     int dg_state = 0;             // dgemm_kernel's weight copies: 0 not looked at yet, 1 built, -1 the model does not qualify
+    bool dg_head = false;         // ... and the LM head has one too (decode batches: dgemm_kernel with the argmax candidates in its epilogue)
     std::vector<SubBatch::G> bt_graphs;   // step graphs of the whole-batch decode step (bt), same key
     hipEvent_t sub_fork = nullptr;
     int sub_batches = 1;          // NL_SUB_BATCHES: groups a decode batch is cut into (1 = the whole batch as one step: measured fastest, profiles/r04_subbatch_groups.log)
@@ -1783,6 +1784,7 @@ bool dgemm_mat_ok(const PackedMat &m, bool rows32, int T, bool ssq) {
 hipError_t launch_dgemm_rope(const QGemmParams &P, hipStream_t st) { return dg_launch_rope(P, st); }
 hipError_t launch_dgemm_swiglu(const QGemmParams &P, hipStream_t st) { return dg_launch_swiglu(P, st); }
 hipError_t launch_dgemm_plain(const QGemmParams &P, hipStream_t st) { return dg_launch_plain(P, st); }
+hipError_t launch_dgemm_head(const QGemmParams &P, hipStream_t st, int num_cus) { return dg_launch_head(P, st, num_cus); }
 }  // namespace
 
 namespace {
@@ -1883,6 +1885,20 @@ int dgemm_prepare(nl_engine *e) {
                                reinterpret_cast<const uint4 *>(m->q), m->s, reinterpret_cast<uint4 *>(m->q3), m->s3, groups);
             HIPCK(e, hipGetLastError());
         }
+    // the LM head of a decode batch: dghead_kernel (resident workgroups, the final RMSNorm folded into the last down launch)
+    e->dg_head = false;
+    if (e->lm_head.wtype == WT_Q4_0 && dg_head_ok(e->lm_head.rows, e->lm_head.cols) && e->lm_head.ntiles * TR == e->lm_head.rows &&
+        e->lm_head.rows == e->cfg.vocab && e->lm_head.cols == e->cfg.dim) {
+        PackedMat *m = &e->lm_head;
+        HIPCK(e, arena_alloc(e, (void **)&m->q3, m->q_bytes));
+        HIPCK(e, arena_alloc(e, (void **)&m->s3, m->s_bytes));
+        e->bytes_weights += m->q_bytes + m->s_bytes;
+        const long long groups = (long long)m->ntiles * (m->npairs / KL);
+        hipLaunchKernelGGL(dg_permute_kernel, dim3((unsigned)std::min<long long>((groups * 128 + 255) / 256, 65535)), dim3(256), 0, e->stream,
+                           reinterpret_cast<const uint4 *>(m->q), m->s, reinterpret_cast<uint4 *>(m->q3), m->s3, groups);
+        HIPCK(e, hipGetLastError());
+        e->dg_head = true;
+    }
     HIPCK(e, hipStreamSynchronize(e->stream));
     e->dg_state = 1;
     return NL_OK;
@@ -2003,6 +2019,9 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
     const char *fk = getenv("NL_FOLD_NORM");   // knob (tests, tools; read per step so a test can flip it): 0 keeps the bnorm launches
     const bool fold_knob = !(fk && atoi(fk) == 0);
     const bool dg = dgemm_step_ok(e, n);      // short token runs (decode batches): nl_dgemm.h, always folded
+    // ... and the LM head of a step that wants every token's logits (knob NL_DGEMM_HEAD=0, read per step: the split-K launches)
+    const bool dg_head = dg && lm_mode == 1 && e->dg_head && n <= b.lm_cap && (size_t)n * e->lm_head.ntiles * 2 <= b.kpart_cap &&
+                         !(getenv("NL_DGEMM_HEAD") && atoi(getenv("NL_DGEMM_HEAD")) == 0);
     bool fold = fold_knob && !c.qk_norm && D % 64 == 0 && c.n_layers > 0;
     for (int l = 0; l < c.n_layers && fold; l++) {
         const nl_engine::Layer &L = e->layers[l];
@@ -2173,8 +2192,10 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
             LCK(hipGetLastError());
         }
         if (dg) {
-            const QGemmParams::NormOut nout{l + 1 < c.n_layers ? e->layers[l + 1].attn_norm : nullptr, b.xfrag2, b.ssq, sA};
-            LCK(dg_plain(L.down, down_in, nullptr, l + 1 < c.n_layers ? &nout : nullptr));
+            // (the last layer: the LM head's input when that runs on dgemm_kernel too -- the final norm's weights)
+            const float *const nw = l + 1 < c.n_layers ? e->layers[l + 1].attn_norm : dg_head ? e->output_norm : nullptr;
+            const QGemmParams::NormOut nout{nw, b.xfrag2, b.ssq, sA};
+            LCK(dg_plain(L.down, down_in, nullptr, nw ? &nout : nullptr));
         } else if (fold && l + 1 < c.n_layers) {
             const nl_engine::Layer &Ln = e->layers[l + 1];
             const QGemmParams::NormOut nout{Ln.attn_norm, b.xfrag2, b.ssq, sA};
@@ -2187,9 +2208,20 @@ int batched_step(nl_engine *e, nl_engine::Batch &b, hipStream_t st, int n, int l
         // logits rows [0, cnt) of bt.logits / ids [0, cnt): all tokens (mode 1, n <= lm_cap) or just the last (mode 2)
         const int first = lm_mode == 2 ? n - 1 : 0, cnt = lm_mode == 2 ? 1 : n;
         if (cnt > b.lm_cap) return e->fail(NL_ERR_INVALID, "LM head batch %d exceeds %d", cnt, b.lm_cap);
-        LCK(norm(e->output_norm, e->lm_head, first, cnt));
-        LCK(launch_qgemm_plain(e, b, e->lm_head, cnt, b.logits, c.vocab, st));
-        hipLaunchKernelGGL(bargmax_kernel, dim3(cnt), dim3(1024), 0, st, b.logits, c.vocab, b.ids);
+        if (dg_head) {
+            // final RMSNorm folded (the last down launch wrote the fragments and sums of squares), logits + one argmax candidate
+            // per (token, 16 rows) from the GEMM's epilogue, the candidates merged by a launch that reads 1 / 8 of the logits' bytes
+            const PackedMat &m = e->lm_head;
+            QGemmParams P{};
+            P.q = m.q3; P.s = m.s3; P.rows = m.rows; P.cols = m.cols; P.npairs = m.npairs; P.ntiles = m.ntiles;
+            P.xf = b.xfrag2; P.nrm_in = nin_attn; P.n_tokens = n; P.out = b.logits; P.ldo = c.vocab; P.part1 = b.kpart;
+            LCK(launch_dgemm_head(P, st, e->num_cus));
+            hipLaunchKernelGGL(dg_argmax_kernel, dim3(n), dim3(1024), 0, st, reinterpret_cast<const uint2 *>(b.kpart), m.ntiles, b.ids);
+        } else {
+            LCK(norm(e->output_norm, e->lm_head, first, cnt));
+            LCK(launch_qgemm_plain(e, b, e->lm_head, cnt, b.logits, c.vocab, st));
+            hipLaunchKernelGGL(bargmax_kernel, dim3(cnt), dim3(1024), 0, st, b.logits, c.vocab, b.ids);
+        }
         LCK(hipGetLastError());
     }
 #undef LCK
@@ -3573,8 +3605,8 @@ int nl_forward_batch(nl_handle e, const int *streams, const int *tokens, const i
         //  part of the key of a cached step graph)
         auto batch_knob_sig = [] {
             const char *rk = getenv("NL_ROPE_IN_ATTN"), *fk = getenv("NL_FOLD_NORM"), *pk = getenv("NL_PREFILL_PRECISION"), *kk = getenv("NL_KV16_MIN_TOKENS"),
-                       *dk = getenv("NL_DGEMM"), *dm = getenv("NL_DGEMM_MAX_TOKENS");
-            return (rk ? atoi(rk) + 1 : 0) + 3 * (fk ? atoi(fk) + 1 : 0) + 9 * (pk && !strcmp(pk, "fp16x1") ? 1 : 0) +
+                       *dk = getenv("NL_DGEMM"), *dm = getenv("NL_DGEMM_MAX_TOKENS"), *hk = getenv("NL_DGEMM_HEAD");
+            return 40503 * (hk ? atoi(hk) + 1 : 0) + (rk ? atoi(rk) + 1 : 0) + 3 * (fk ? atoi(fk) + 1 : 0) + 9 * (pk && !strcmp(pk, "fp16x1") ? 1 : 0) +
                    18 * (dk ? atoi(dk) + 1 : 0) + 54 * (dm ? (atoi(dm) & 0xff) + 1 : 0) + 13878 * (kk ? (atoi(kk) & 0xfff) + 1 : 0);
         };
         if (groups > 1 && groups <= 4) {

@@ -148,6 +148,44 @@ def test_short_prompt_and_split_attention_on_dgemm(hip, orc, tmp_path):
     dev.close()
 
 
+def test_lm_head_of_a_decode_batch_on_dgemm(hip, orc, tmp_path, monkeypatch):
+    # a Q4_0 LM head of whole 16-row tiles: final norm folded into the last down launch, logits + argmax candidates from the GEMM's
+    # epilogue (go/model.go:616-619, go/main.go:400-408); NL_DGEMM_HEAD=0 and a vocabulary that does not qualify (520 rows) keep the
+    # bnorm + split-K + argmax launches.  Logits against the oracle, ids = the argmax of the returned logits (ties: lowest index)
+    for vocab in (640, 520):
+        shape = synth.ModelShape(f"dg_h{vocab}", 2, 256, 4, 2, vocab, seq_len=64, interm=512)
+        p = tmp_path / f"h{vocab}.gguf"
+        synth.generate_gguf(str(p), shape, "q4_0", 229)
+        g = gguf.load_gguf(str(p))
+        ns = 21
+        rng = np.random.Generator(np.random.PCG64(13))
+        toks = [[int(t) for t in rng.integers(3, vocab, size=3)] for _ in range(ns)]
+        orc.set_threads(min(16, os.cpu_count() or 1))
+        refs = []
+        for s in (0, 15, 16, 20):
+            ref = orc.OracleModel(g)
+            refs.append((s, [ref.forward(t, pos).copy() for pos, t in enumerate(toks[s])]))
+            ref.close()
+        orc.set_threads(1)
+        outs = {}
+        for knob in ("1", "0"):
+            monkeypatch.setenv("NL_DGEMM_HEAD", knob)
+            dev = hip.load_llama_model(g, max_streams=ns)
+            got = []
+            for k in range(3):
+                ids, lg = dev.forward_batch(list(range(ns)), [toks[s][k] for s in range(ns)], [k] * ns, want_logits=True)
+                assert [int(i) for i in ids] == [int(np.argmax(lg[s])) for s in range(ns)], (vocab, knob, k)
+                for s, ref in refs:
+                    assert _rel(lg[s], ref[k]) <= LOGIT_TOL, (vocab, knob, k, s)
+                got.append(lg.copy())
+            outs[knob] = np.stack(got)
+            dev.close()
+        same = outs["1"].tobytes() == outs["0"].tobytes()
+        assert same == (vocab == 520), vocab            # (the qualifying head sums its blocks in another order: close, not identical)
+        assert float(np.abs(outs["1"] - outs["0"]).max()) <= 2e-5 * max(1.0, float(outs["0"].std()))
+    monkeypatch.delenv("NL_DGEMM_HEAD")
+
+
 def test_models_outside_dgemm_keep_the_split_k_launches(hip, tmp_path):
     # K not a whole number of 256-column groups, Q8_0 weights, QK-norm: the multi-token step keeps its split-K launches and
     # no second weight copy is built

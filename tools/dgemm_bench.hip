@@ -89,13 +89,25 @@ int main(int argc, char **argv) {
         CK(hipMemcpyFromSymbol(s_.data(), HIP_SYMBOL(g_dg_stamps), 64 * 8));
         printf("   %s: workgroup 9, wavefront 0, cycles since entry: issued", name);
         for (int i = 1; i < 40 && s_[i]; i++) printf(" %lld", s_[i] - s_[0]);
+        if (s_[41]) { printf("\n   iteration 2, per wavefront: products start"); for (int w = 0; w < 8; w++) printf(" %lld", s_[41 + w] - s_[0]); printf(" | end"); for (int w = 0; w < 8; w++) printf(" %lld", s_[49 + w] - s_[0]);
+                      printf(" | epilogue end (tile 0..3)"); for (int w = 0; w < 4; w++) printf(" %lld", s_[57 + w] - s_[0]); }
+        if (!s_[40]) { printf("\n"); goto census; }
         printf(" | partials out + barrier %lld\n", s_[40] - s_[0]);
+    census:
         std::vector<long long> c_(2 * 2048);
         CK(hipMemcpyFromSymbol(c_.data(), HIP_SYMBOL(g_dg_census), 2 * 2048 * 8));
         long long e0 = 1LL << 62, e1 = 0, x0 = 1LL << 62, x1 = 0; int nwg = 0;
         for (int i = 0; i < grid; i++) if (c_[2 * i] && c_[2 * i + 1]) { nwg++; e0 = std::min(e0, c_[2 * i]); e1 = std::max(e1, c_[2 * i]); x0 = std::min(x0, c_[2 * i + 1]); x1 = std::max(x1, c_[2 * i + 1]); }
         printf("   census: %d workgroups; entries spread %.2f us; first exit +%.2f us, last exit +%.2f us after the first entry; wg 9: entry +%.2f exit +%.2f\n",
                nwg, (e1 - e0) * 0.01, (x0 - e0) * 0.01, (x1 - e0) * 0.01, (c_[18] - e0) * 0.01, (c_[19] - e0) * 0.01);
+        if (nwg > 256) {      // several rounds of workgroups: when they enter, how long one stays
+            std::vector<double> ent, dur;
+            for (int i = 0; i < grid; i++) if (c_[2 * i] && c_[2 * i + 1]) { ent.push_back((c_[2 * i] - e0) * 0.01); dur.push_back((c_[2 * i + 1] - c_[2 * i]) * 0.01); }
+            std::sort(ent.begin(), ent.end()); std::sort(dur.begin(), dur.end());
+            printf("   entries at (us):");
+            for (int q = 0; q <= 8; q++) printf(" %.1f", ent[std::min(ent.size() - 1, ent.size() * q / 8)]);
+            printf("; time in the kernel per workgroup: min %.2f median %.2f max %.2f us\n", dur.front(), dur[dur.size() / 2], dur.back());
+        }
         std::vector<long long> z_(64, 0);
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_dg_stamps), z_.data(), 64 * 8));
 #endif
@@ -129,6 +141,43 @@ int main(int argc, char **argv) {
         CK(dg_launch_plain(P, st));
     }, (double)down.qbytes * 18 / 16, 2.0 * D * I * N);
     stamps("down", (int)(dg_grid(down.ntiles, 2, N).x * dg_grid(down.ntiles, 2, N).y));
-
+    {   // the LM head of the batch: 32000 rows, dghead_kernel (one resident workgroup per compute unit walks its row groups)
+        const int V = 32000;
+        Mat head = mk(V, D);
+        float *logits; uint2 *cand;
+        CK(hipMalloc(&logits, (size_t)64 * V * 4)); CK(hipMalloc(&cand, (size_t)64 * (V / 16) * 8));
+        CK(hipStreamSynchronize(st));
+        timeit("lm head", [&](int i) {
+            QGemmParams P = base(head, i);
+            P.xf = xf; P.out = logits; P.ldo = V; P.nrm_in = nin; P.part1 = reinterpret_cast<float *>(cand);
+            CK(dg_launch_head(P, st));
+        }, (double)head.qbytes * 18 / 16, 2.0 * V * D * N);
+        stamps("lm head", 256);
+        {   // same products as the plain launch (no norm on either side)
+            float *ref; CK(hipMalloc(&ref, (size_t)64 * V * 4));
+            CK(hipMemsetAsync(ref, 0, (size_t)64 * V * 4, st)); CK(hipMemsetAsync(logits, 0, (size_t)64 * V * 4, st));
+            QGemmParams P = base(head, 0);
+            P.xf = xf; P.out = ref; P.ldo = V;
+            CK(dg_launch_plain(P, st));
+            P.out = logits; P.part1 = reinterpret_cast<float *>(cand);
+            fill_f64<<<16, 256, 0, st>>>(ssq, (size_t)64 * (D / 32), 8.0);      // (the producer launches above left their own sums)
+            if (getenv("DG_HEAD_NORM")) P.nrm_in = nin;       // ssq 8.0 x 48 partials, dim 1536: inv = 1 / sqrt(0.25 + 1e-5)
+            CK(dg_launch_head(P, st));
+            CK(hipStreamSynchronize(st));
+#ifdef DG_DEBUG_INV
+            { std::vector<float> d_(192); CK(hipMemcpyFromSymbol(d_.data(), HIP_SYMBOL(g_dg_dbg), 192 * 4));
+              printf("   tot:"); for (int i = 0; i < 64; i += 5) printf(" %g", d_[i]); printf("\n   inv:"); for (int i = 0; i < 64; i += 5) printf(" %g", d_[64 + i]);
+              printf("\n   nsc:"); for (int i = 0; i < 64; i += 5) printf(" %g", d_[128 + i]); printf("\n"); }
+#endif
+            std::vector<float> a_((size_t)N * V), b_((size_t)N * V);
+            CK(hipMemcpy(a_.data(), ref, a_.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b_.data(), logits, b_.size() * 4, hipMemcpyDeviceToHost));
+            double worst = 0; size_t nbad = 0, first = (size_t)-1;
+            if (getenv("DG_HEAD_NORM")) for (auto &v : a_) v *= (float)(1.0 / sqrt(384.0 / 1536.0 + (double)1e-5f));
+            for (size_t i = 0; i < a_.size(); i++) { const double d = fabs((double)a_[i] - b_[i]); if (!(d <= 1e-3 * (1 + fabs(a_[i])))) { nbad++; if (first == (size_t)-1) first = i; } if (d > worst) worst = d; }
+            printf("   lm head against the plain launch: max |diff| %.3g, %zu of %zu off", worst, nbad, a_.size());
+            if (nbad) printf(" (first: token %zu row %zu: %g vs %g)", first / V, first % V, b_[first], a_[first]);
+            printf("\n");
+        }
+    }
     return 0;
 }
