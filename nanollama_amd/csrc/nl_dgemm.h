@@ -475,9 +475,6 @@ __device__ __forceinline__ void dg_lds_wait(f32x4_t (&v)[N]) {
     if constexpr (N == 16)
         asm volatile("" : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) :: "memory");
 }
-#ifdef DG_DEBUG_INV
-__device__ float g_dg_dbg[192];
-#endif
 constexpr int DGH_T = 4;
 template <int NWV, int NS> struct DgHeadLds {
     static constexpr int REG_U4 = 20 * DGH_T;
@@ -490,7 +487,7 @@ template <int NWV, int NS>
 __global__ void __launch_bounds__(NWV * 64, NWV / 4) dghead_kernel(QGemmParams P) {
     typedef DgHeadLds<NWV, NS> L;
     constexpr int T = DGH_T, REG_U4 = L::REG_U4, WAVE_U4 = L::WAVE_U4, BUF_U4 = L::BUF_U4, SSQ_U4 = L::SSQ_U4;
-    constexpr int OPS = 2;                                       // memory operations per step: one nibble piece (64 lanes = 4 tiles x 16 rows), one scale piece
+    constexpr int OPS = 2;                         // memory operations per step: one nibble piece (64 lanes = 4 tiles x 16 rows), one scale piece
     static_assert((2 * NS - 1) * OPS <= 63, "vmcnt is six bits");
     static_assert(NWV >= T, "one epilogue wavefront per row tile");
     __shared__ __attribute__((aligned(16))) uint4 lds_all[L::TOTAL_U4];
@@ -585,11 +582,11 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dghead_kernel(QGemmParams P
                     a[g] = WFrag<WT_Q4_0>::expand(sb32[(g * 16 + li) * 4 + lq]);
                     sw[g] = sb32[(16 * T) * 4 + g * 16 + li];
                 }
-#pragma unroll
+    #pragma unroll
                 for (int g = 0; g < T; g++) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xlv, a[g], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
+    #pragma unroll
                 for (int g = 0; g < T; g++) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xhv, a[g], z[g], 0, 0, 0);
-#pragma unroll
+    #pragma unroll
                 for (int g = 0; g < T; g++) {
                     const float d = scale_of(sw[g], cc);
 #pragma unroll
@@ -597,13 +594,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dghead_kernel(QGemmParams P
                 }
             });
         };
-#ifdef DG_STAMPS
-        if (DG_LIN == 9 && lane == 0 && it == 2) g_dg_stamps[41 + wv] = clock64();
-#endif
         if (has_next) products(std::true_type{}); else products(std::false_type{});
-#ifdef DG_STAMPS
-        if (DG_LIN == 9 && lane == 0 && it == 2) g_dg_stamps[49 + wv] = clock64();
-#endif
         DG_STAMP(2 + 4 * it);
         // partial tiles over the buffer just consumed: D[token 4 lq + r][row li] out as [tile][token][row]
         {
@@ -624,25 +615,16 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dghead_kernel(QGemmParams P
                 dg_lds_wait(v);
                 tot += v;
             }
-#ifdef DG_DEBUG_INV
-            if (rg0 == 0 && tt == 0 && wv == 1) g_dg_dbg[lane] = (float)tot;
-#endif
             const double t1 = __shfl_xor(tot, 16);
             const double lo2 = (lq & 1) ? t1 + tot : tot + t1;
             const double t2 = __shfl_xor(lo2, 32);
             tot = (lq & 2) ? t2 + lo2 : lo2 + t2;
             inv = (float)(1.0 / sqrt(tot / (double)P.nrm_in.dim + (double)P.nrm_in.eps));
-#ifdef DG_DEBUG_INV
-            if (rg0 == 0 && tt == 0 && wv == 1) g_dg_dbg[64 + lane] = inv;
-#endif
             if (P.nrm_in.scale) {
                 float nsc;
                 asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nsc) : "v"(dg_lds_addr(lds_all + DG_SSQ_BYTES / 16) + (unsigned)li * 4u) : "memory");
                 if (rg0 == 0 && wv == 0 && lq == 0 && live) P.nrm_in.scale_next[n] = norm_prescale(inv);
                 inv *= 1.0f / nsc;
-#ifdef DG_DEBUG_INV
-                if (rg0 == 0 && tt == 0 && wv == 1) g_dg_dbg[128 + lane] = nsc;
-#endif
             }
         }
         // row tile ti of the group: wavefront (ti + it) % NWV (the duty moves so that no wavefront falls behind for the whole launch)
@@ -674,9 +656,6 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dghead_kernel(QGemmParams P
                 if (lq == 0) reinterpret_cast<uint2 *>(P.part1)[(size_t)n * P.ntiles + etile] = make_uint2(__float_as_uint(best), (unsigned)bidx);
             }
         }
-#ifdef DG_STAMPS
-        if (DG_LIN == 9 && lane == 0 && it == 2 && ti < T) g_dg_stamps[57 + ti] = clock64();
-#endif
         DG_STAMP(4 + 4 * it);
         if (has_next) dg_lds_barrier();      // (the row group after next lands in this buffer: requested behind this barrier)
     }

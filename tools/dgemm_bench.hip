@@ -89,8 +89,6 @@ int main(int argc, char **argv) {
         CK(hipMemcpyFromSymbol(s_.data(), HIP_SYMBOL(g_dg_stamps), 64 * 8));
         printf("   %s: workgroup 9, wavefront 0, cycles since entry: issued", name);
         for (int i = 1; i < 40 && s_[i]; i++) printf(" %lld", s_[i] - s_[0]);
-        if (s_[41]) { printf("\n   iteration 2, per wavefront: products start"); for (int w = 0; w < 8; w++) printf(" %lld", s_[41 + w] - s_[0]); printf(" | end"); for (int w = 0; w < 8; w++) printf(" %lld", s_[49 + w] - s_[0]);
-                      printf(" | epilogue end (tile 0..3)"); for (int w = 0; w < 4; w++) printf(" %lld", s_[57 + w] - s_[0]); }
         if (!s_[40]) { printf("\n"); goto census; }
         printf(" | partials out + barrier %lld\n", s_[40] - s_[0]);
     census:
@@ -153,6 +151,15 @@ int main(int argc, char **argv) {
             CK(dg_launch_head(P, st));
         }, (double)head.qbytes * 18 / 16, 2.0 * V * D * N);
         stamps("lm head", 256);
+        timeit("down+head", [&](int i) {      // as in a step: the head behind the producer of its fragments (subtract down+norm above)
+            QGemmParams Q = base(down, i);
+            Q.xf = xf2; Q.out = x; Q.ldo = D; Q.resid = x;
+            Q.nrm_out = QGemmParams::NormOut{nw, xf, ssq, sc1};
+            CK(dg_launch_plain(Q, st));
+            QGemmParams P = base(head, i);
+            P.xf = xf; P.out = logits; P.ldo = V; P.nrm_in = nin; P.part1 = reinterpret_cast<float *>(cand);
+            CK(dg_launch_head(P, st));
+        }, (double)head.qbytes * 18 / 16, 2.0 * V * D * N);
         {   // same products as the plain launch (no norm on either side)
             float *ref; CK(hipMalloc(&ref, (size_t)64 * V * 4));
             CK(hipMemsetAsync(ref, 0, (size_t)64 * V * 4, st)); CK(hipMemsetAsync(logits, 0, (size_t)64 * V * 4, st));
@@ -164,11 +171,6 @@ int main(int argc, char **argv) {
             if (getenv("DG_HEAD_NORM")) P.nrm_in = nin;       // ssq 8.0 x 48 partials, dim 1536: inv = 1 / sqrt(0.25 + 1e-5)
             CK(dg_launch_head(P, st));
             CK(hipStreamSynchronize(st));
-#ifdef DG_DEBUG_INV
-            { std::vector<float> d_(192); CK(hipMemcpyFromSymbol(d_.data(), HIP_SYMBOL(g_dg_dbg), 192 * 4));
-              printf("   tot:"); for (int i = 0; i < 64; i += 5) printf(" %g", d_[i]); printf("\n   inv:"); for (int i = 0; i < 64; i += 5) printf(" %g", d_[64 + i]);
-              printf("\n   nsc:"); for (int i = 0; i < 64; i += 5) printf(" %g", d_[128 + i]); printf("\n"); }
-#endif
             std::vector<float> a_((size_t)N * V), b_((size_t)N * V);
             CK(hipMemcpy(a_.data(), ref, a_.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b_.data(), logits, b_.size() * 4, hipMemcpyDeviceToHost));
             double worst = 0; size_t nbad = 0, first = (size_t)-1;
