@@ -152,17 +152,18 @@ def test_lm_head_of_a_decode_batch_on_dgemm(hip, orc, tmp_path, monkeypatch):
     # a Q4_0 LM head of whole 16-row tiles: final norm folded into the last down launch, logits + argmax candidates from the GEMM's
     # epilogue (go/model.go:616-619, go/main.go:400-408); NL_DGEMM_HEAD=0 and a vocabulary that does not qualify (520 rows) keep the
     # bnorm + split-K + argmax launches.  Logits against the oracle, ids = the argmax of the returned logits (ties: lowest index)
-    for vocab in (640, 520):
+    # (9280 rows x 64 streams: 145 row groups over 64 resident workgroups per token tile -- two or three iterations each, the
+    #  double-buffered path; 640 rows x 21 streams: one iteration, a ragged token tile)
+    for vocab, ns in ((640, 21), (520, 21), (9280, 64)):
         shape = synth.ModelShape(f"dg_h{vocab}", 2, 256, 4, 2, vocab, seq_len=64, interm=512)
         p = tmp_path / f"h{vocab}.gguf"
         synth.generate_gguf(str(p), shape, "q4_0", 229)
         g = gguf.load_gguf(str(p))
-        ns = 21
         rng = np.random.Generator(np.random.PCG64(13))
         toks = [[int(t) for t in rng.integers(3, vocab, size=3)] for _ in range(ns)]
         orc.set_threads(min(16, os.cpu_count() or 1))
         refs = []
-        for s in (0, 15, 16, 20):
+        for s in (0, 15, 16, ns - 1):
             ref = orc.OracleModel(g)
             refs.append((s, [ref.forward(t, pos).copy() for pos, t in enumerate(toks[s])]))
             ref.close()
