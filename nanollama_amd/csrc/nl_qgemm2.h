@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(WAVES * 64, (RT * NTW <= 8 ? 4 : 2)) qgemm2_ke
 #pragma unroll
         for (int t = 0; t < NTW; t++) acc[rt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int RG = NTW == 1 ? 4 : 2;   // row tiles per MFMA group: RG * NTW = 4 independent accumulator chains
+    constexpr int RG = NTW == 1 ? (RT % 4 == 0 ? 4 : RT % 3 == 0 ? 3 : RT % 2 == 0 ? 2 : 1) : (RT % 2 == 0 ? 2 : 1);   // row tiles per MFMA group: RG * NTW <= 4 independent accumulator chains
     constexpr int NG = RT / RG;            // groups per block
     static_assert((QG_KC * NG) % 2 == 0, "weight fragment ping-pong");
     int chunk = blockIdx.z;

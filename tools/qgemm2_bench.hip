@@ -76,8 +76,17 @@ int run(int N, int iters) {
             printf(" %s %7.2f us x%.2f%s |", tag, ms2 * 1e3 / iters, ms1 / ms2, worst == 0 ? "" : " DIFF");
         };
 #ifdef QG2_STAMPS
-        variant("4/2/8", qgemm2_kernel<WT, 4, 2, 8>, 4, 2, 8);
+#ifdef QG2_STAMP_414
+        variant("4/1/4", qgemm2_kernel<WT, 4, 1, 4>, 4, 1, 4);
 #else
+        variant("4/2/8", qgemm2_kernel<WT, 4, 2, 8>, 4, 2, 8);
+#endif
+#else
+        variant("3/1/4", qgemm2_kernel<WT, 3, 1, 4>, 3, 1, 4);
+        variant("3/2/4", qgemm2_kernel<WT, 3, 2, 4>, 3, 2, 4);
+        variant("6/1/4", qgemm2_kernel<WT, 6, 1, 4>, 6, 1, 4);
+        variant("2/1/4", qgemm2_kernel<WT, 2, 1, 4>, 2, 1, 4);
+        variant("4/1/2", qgemm2_kernel<WT, 4, 1, 2>, 4, 1, 2);
         variant("8/1/4", qgemm2_kernel<WT, 8, 1, 4>, 8, 1, 4);
         variant("16/1/4", qgemm2_kernel<WT, 16, 1, 4>, 16, 1, 4);
         variant("16/1/2", qgemm2_kernel<WT, 16, 1, 2>, 16, 1, 2);
