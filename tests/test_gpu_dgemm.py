@@ -187,6 +187,30 @@ def test_lm_head_of_a_decode_batch_on_dgemm(hip, orc, tmp_path, monkeypatch):
     monkeypatch.delenv("NL_DGEMM_HEAD")
 
 
+def test_lm_head_on_dgemm_at_every_token_tile_count(hip, tmp_path, monkeypatch):
+    # 3 .. 64 streams (one to four token tiles, full and ragged; the grid's row-group stride and the iterations per workgroup
+    # change with the tile count): logits of the resident-workgroup LM head against the split-K launches of the same handle
+    # state, ids = argmax of the returned logits
+    shape = synth.ModelShape("dg_hn", 1, 256, 4, 2, 5136, seq_len=32, interm=512)       # 321 row tiles: ragged last row group
+    p = tmp_path / "hn.gguf"
+    synth.generate_gguf(str(p), shape, "q4_0", 233)
+    g = gguf.load_gguf(str(p))
+    rng = np.random.Generator(np.random.PCG64(17))
+    for ns in (3, 15, 16, 17, 32, 33, 47, 48, 49, 64):
+        toks = [int(t) for t in rng.integers(3, shape.vocab, size=ns)]
+        outs = {}
+        for knob in ("1", "0"):
+            monkeypatch.setenv("NL_DGEMM_HEAD", knob)
+            dev = hip.load_llama_model(g, max_streams=ns)
+            ids, lg = dev.forward_batch(list(range(ns)), toks, [0] * ns, want_logits=True)
+            assert [int(i) for i in ids] == [int(np.argmax(lg[s])) for s in range(ns)], (ns, knob)
+            outs[knob] = lg.copy()
+            dev.close()
+        assert np.isfinite(outs["1"]).all(), ns
+        assert float(np.abs(outs["1"] - outs["0"]).max()) <= 2e-5 * max(1.0, float(outs["0"].std())), ns
+    monkeypatch.delenv("NL_DGEMM_HEAD")
+
+
 def test_models_outside_dgemm_keep_the_split_k_launches(hip, tmp_path):
     # K not a whole number of 256-column groups, Q8_0 weights, QK-norm: the multi-token step keeps its split-K launches and
     # no second weight copy is built
