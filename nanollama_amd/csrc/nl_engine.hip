@@ -317,7 +317,9 @@ struct nl_engine {
     struct Persist {
         bool candidate = false;      // shape / type admit the path; raw Q8_0 tensors are kept on the device until nl_finalize
         bool ready = false;          // images built: nl_decode_greedy takes it for chunks that end below max_pos
-        bool retired = false;        // a poll gave up once (or the census was not 8 x 32): the handle keeps the launch plans
+        bool retired = false;        // a poll gave up once (or the census was not 8 x 32 three times): the handle keeps the launch plans
+        int fake_misses = 0;         // (NL_PERSIST_FAKE_CENSUS_MISS: misses reported so far)
+        int census_misses = 0;       // launches that found their workgroups placed otherwise (a transient: another launch held compute units)
         uint8_t *raw[PD_MAXL][7] = {};
         uint8_t *lm_raw = nullptr;
         unsigned char rtype[PD_MAXL][7] = {}, lm_type = 0;     // block type of every kept tensor (Q8_0 / Q4_0 / Q5_0)
@@ -1488,14 +1490,31 @@ int pd_launch(nl_engine *e, int stream, int token, int pos, int n, float *host_l
 // and this handle keeps them from now on.
 bool pd_take_timeout(nl_engine *e) {
     nl_engine::Persist &d = e->pd;
-    if (!d.h_status || !*d.h_status) return false;
+    if (!d.h_status) return false;
+    // (test knob, read per call: the first n launches of the handle are treated as census misses although they placed well --
+    //  the host side of the policy below is exercised without a crowded device)
+    const char *fk = getenv("NL_PERSIST_FAKE_CENSUS_MISS");
+    if (!*d.h_status && fk && d.launches > 0 && d.fake_misses < atoi(fk)) { d.fake_misses++; *d.h_status = 64u; }
+    if (!*d.h_status) return false;
     const unsigned st = *d.h_status;
     *d.h_status = 0;
     (void)hipMemsetAsync(d.status, 0, sizeof(unsigned), e->stream);
     (void)hipStreamSynchronize(e->stream);
-    d.retired = true;
-    e->fail(NL_OK, "warning: the persistent decode launch gave up (status %u: %s); the chunk was redone on the launch plans, which this "
-                   "handle keeps from now on", st, (st & 64u) ? "its workgroups were not placed 32 per XCD" : "a hand-off poll timed out");
+    // A hand-off poll that ran out retires the path at once.  A census that was not 8 x 32 is about WHERE the launch landed, not
+    // about the exchange protocol: the chunk is redone on the launch plans as well, but the handle tries the persistent launch
+    // again -- up to three misses (a server that lost its fast path to one crowded moment would keep the slow one for good).
+    d.retired = !(st == 64u && ++d.census_misses < 3);
+    // (what the census saw: workgroups per XCD and arrivals of the launch that gave up -- its words are still there, the next
+    //  launch would have zeroed them)
+    unsigned cen[16] = {0};
+    char seen[160] = "";
+    if ((st & 64u) && d.census && d.launch_no > 0 &&
+        hipMemcpy(cen, d.census + ((d.launch_no - 1u) & 1u) * 16, sizeof(cen), hipMemcpyDeviceToHost) == hipSuccess)
+        snprintf(seen, sizeof(seen), " [per XCD %u %u %u %u %u %u %u %u, %u of %d arrived, %d compute units]", cen[0], cen[1], cen[2], cen[3], cen[4],
+                 cen[5], cen[6], cen[7], cen[8], PD_GRID, e->num_cus);
+    e->fail(NL_OK, "warning: the persistent decode launch gave up (status %u: %s%s); the chunk was redone on the launch plans%s", st,
+            (st & 64u) ? "its workgroups were not placed 32 per XCD" : "a hand-off poll timed out", seen,
+            d.retired ? ", which this handle keeps from now on" : " (the next call tries the persistent launch again)");
     if (!getenv("NL_QUIET")) fprintf(stderr, "[nanollama_hip] %s\n", e->err.c_str());
     return true;
 }

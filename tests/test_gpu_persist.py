@@ -2,6 +2,7 @@
 tokens with every layer resident on one XCD.  Reference lines: go/main.go:173-219 (the greedy loop), go/model.go:490-620
 (Forward), go/main.go:400-408 (argmax).  The oracle's ids must be reproduced one for one and its logits within the engine's
 stated tolerance; the launch plans of the same handle (NL_PERSIST=0) are the second witness."""
+import functools
 import os
 import sys
 
@@ -13,6 +14,31 @@ from nanollama_amd import gguf, synth
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
+
+class _PlacementMiss(Exception):
+    """the persistent launch found its workgroups placed otherwise than 32 per XCD (observed, never assumed: nl_persist.h) -- the
+    chunk was redone on the launch plans and the results are right, but the run did not test the persistent path"""
+
+
+def _no_warning(dev):
+    err = dev.last_error()
+    if "not placed 32 per XCD" in err:
+        raise _PlacementMiss(err)
+    return err == ""
+
+
+def _retry_placement(fn):
+    """A placement miss is a property of the moment on the device, not of the code under test: one retry with fresh handles (the
+    note is printed); a second miss in a row fails the test."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        try:
+            return fn(*args, **kwargs)
+        except _PlacementMiss as exc:
+            print(f"\n[retry] {fn.__name__}: {exc}")
+        return fn(*args, **kwargs)
+    return wrapper
+
 
 LOGIT_TOL = 1e-4
 
@@ -52,6 +78,7 @@ def _oracle_run(orc, g, prompt, n):
 
 
 @pytest.mark.parametrize("layers", [5, 13, 16, 1])
+@_retry_placement
 def test_persistent_decode_matches_oracle_small_shape(hip, orc, tmp_path, monkeypatch, layers):
     # D 256 / 4 heads / I 512: the small instantiation.  5 layers: XCDs 0-4 hold one layer, 5-7 only LM-head rows; 13: nano's
     # split (two layers on XCDs 0-4); 16: two everywhere; 1: a single layer.  The handle's launch plans are the second witness.
@@ -67,7 +94,7 @@ def test_persistent_decode_matches_oracle_small_shape(hip, orc, tmp_path, monkey
     dev.prefill(prompt)
     assert int(np.argmax(dev.state.logits)) == first
     got = dev.decode_greedy(first, len(prompt), 60)
-    assert dev.last_error() == "", dev.last_error()
+    assert _no_warning(dev), dev.last_error()
     info = dev.persist_info()
     assert info["ready"] and info["launches"] == 1 and info["tokens"] == 60, info
     assert got == want, (got[:12], want[:12])
@@ -94,6 +121,7 @@ def test_persistent_decode_matches_oracle_small_shape(hip, orc, tmp_path, monkey
     dev.close(); plain.close()
 
 
+@_retry_placement
 def test_persistent_decode_per_step_logits_and_chunking(hip, orc, tmp_path):
     # one-token chunks (every step's logits against the oracle's), then ragged chunks: the same ids whatever the chunking
     shape = synth.ModelShape("pd_steps", 13, 256, 4, 4, 1024, seq_len=192, interm=512)
@@ -120,10 +148,11 @@ def test_persistent_decode_per_step_logits_and_chunking(hip, orc, tmp_path):
         ids = dev.decode_greedy(tok, pos, n)
         got += ids; tok = ids[-1]; pos += n
     assert got == want
-    assert dev.last_error() == "" and dev.persist_info()["launches"] == 157
+    assert _no_warning(dev) and dev.persist_info()["launches"] == 157
     dev.close()
 
 
+@_retry_placement
 def test_persistent_decode_hands_over_to_the_launch_plans_at_its_position_limit(hip, orc, tmp_path, monkeypatch):
     # a chunk that crosses the limit: the tokens below it in one persistent launch, the rest on the launch plans, one call
     shape = synth.ModelShape("pd_limit", 13, 256, 4, 4, 1024, seq_len=160, interm=512)
@@ -139,10 +168,11 @@ def test_persistent_decode_hands_over_to_the_launch_plans_at_its_position_limit(
     assert dev.decode_greedy(first, len(prompt), 100) == want
     info = dev.persist_info()
     assert info["launches"] == 1 and info["tokens"] == 40, info
-    assert dev.last_error() == ""
+    assert _no_warning(dev)
     dev.close()
 
 
+@_retry_placement
 def test_persistent_decode_give_up_falls_back_to_the_launch_plans(hip, orc, tmp_path, monkeypatch):
     # every hand-off poll gives up at once (spin limit 0): the call still returns the oracle's ids -- redone on the launch plans --
     # with a note in nl_last_error, and the handle keeps the plans from then on
@@ -178,6 +208,7 @@ def _rel(a, b):
     return float(np.abs(a - b).max()) / max(1.0, float(b.std()))
 
 
+@_retry_placement
 def test_resident_session_serves_per_call_forward(hip, orc, tmp_path, monkeypatch):
     # go/main.go:173-219 calls Forward once per token with a token the HOST chose: here arbitrary (not the argmax) tokens.  One
     # resident launch serves the whole run of nl_forward calls; every step's logits against the oracle's.
@@ -195,7 +226,7 @@ def test_resident_session_serves_per_call_forward(hip, orc, tmp_path, monkeypatc
         worst = max(worst, _rel(dev.state.logits, want[pos]))
     info = dev.persist_info()
     print(f"\nresident session, 150 forced tokens: max|gpu-oracle| = {worst:.2e}; launches {info['launches']}")
-    assert worst <= LOGIT_TOL and dev.last_error() == ""
+    assert worst <= LOGIT_TOL and _no_warning(dev)
     assert info["launches"] == 1 and info["tokens"] == 150, info
     keep = dev.state.logits.copy()
     # the launch has left when another entry point needs the stream; what it wrote is what the launch plans read
@@ -224,10 +255,11 @@ def test_resident_session_serves_per_call_forward(hip, orc, tmp_path, monkeypatc
     for pos in (0, 1, 2, 9, 10):
         dev.forward(tokens[pos], pos); plain.forward(tokens[pos], pos)
         assert _rel(dev.state.logits, plain.state.logits) <= 2e-5, pos
-    assert dev.last_error() == ""
+    assert _no_warning(dev)
     dev.close(); plain.close()
 
 
+@_retry_placement
 def test_resident_session_idles_out_and_is_restarted(hip, orc, tmp_path, monkeypatch):
     # a caller slower than the idle limit: the launch has left by the time the next token arrives; the call starts another
     import time
@@ -245,10 +277,11 @@ def test_resident_session_idles_out_and_is_restarted(hip, orc, tmp_path, monkeyp
         time.sleep(0.02)
     info = dev.persist_info()
     assert info["launches"] == 12 and info["tokens"] == 12 and info["ready"], info
-    assert dev.last_error() == ""
+    assert _no_warning(dev)
     dev.close()
 
 
+@_retry_placement
 def test_resident_session_position_limit_and_give_up(hip, orc, tmp_path, monkeypatch):
     shape = synth.ModelShape("pd_slimit", 13, 256, 4, 4, 1024, seq_len=96, interm=512)
     p = tmp_path / "m.gguf"
@@ -263,7 +296,7 @@ def test_resident_session_position_limit_and_give_up(hip, orc, tmp_path, monkeyp
         dev.forward(t, pos)
         assert _rel(dev.state.logits, want[pos]) <= LOGIT_TOL, pos
     info = dev.persist_info()
-    assert info["launches"] == 1 and info["tokens"] == 32 and dev.last_error() == "", info
+    assert info["launches"] == 1 and info["tokens"] == 32 and _no_warning(dev), info
     dev.close()
     # every poll gives up at once: the call is redone on the launch plans, which the handle keeps
     monkeypatch.delenv("NL_PERSIST_MAX_POS")
@@ -287,6 +320,7 @@ def test_resident_session_position_limit_and_give_up(hip, orc, tmp_path, monkeyp
     dev.close()
 
 
+@_retry_placement
 def test_persistent_decode_long_context_shares_the_attention_passes(hip, orc, tmp_path):
     # from position 128 on a head's 128-position passes are shared by up to three units of its XCD (the owner + two helpers that
     # are not heads in that layer slot; go/model.go:557-587); the owner merges their records.  Teacher-forced against the oracle
@@ -313,7 +347,7 @@ def test_persistent_decode_long_context_shares_the_attention_passes(hip, orc, tm
             worst = max(worst, _rel(dev.state.logits, want[pos]))
     info = dev.persist_info()
     print(f"\npersistent decode, positions 0 .. 1039 teacher-forced: max|gpu-oracle| = {worst:.2e} at {len(check)} positions; {info}")
-    assert worst <= LOGIT_TOL and dev.last_error() == ""
+    assert worst <= LOGIT_TOL and _no_warning(dev)
     assert info["tokens"] == 1024 and info["launches"] <= 3, info      # (one resident launch unless the host paused longer than the idle limit)
     # chained: from position 900 over the limit, the oracle's greedy ids
     first = int(orc.argmax(ref.forward(tokens[900], 900)))       # (the oracle's cache holds positions 0 .. 1039: position 900 again)
@@ -332,10 +366,11 @@ def test_persistent_decode_long_context_shares_the_attention_passes(hip, orc, tm
     f0 = int(np.argmax(dev.state.logits))
     assert f0 == first
     assert dev.decode_greedy(f0, 901, 150) == ids
-    assert dev.last_error() == ""
+    assert _no_warning(dev)
     dev.close()
 
 
+@_retry_placement
 def test_nano_true_shape_resident_session_and_chained_decode_across_every_pass_count(hip, orc, tmp_path, monkeypatch):
     # BASELINE configs[1] at its OWN geometry (D 576 / 9 heads / I 1536, 13 layers, Q8_0): the helper assignment of the shared
     # attention passes depends on the head count (nl_persist.h: `apart = 1 + j / H`), so the D 256 / 4-head test above does not
@@ -373,7 +408,7 @@ def test_nano_true_shape_resident_session_and_chained_decode_across_every_pass_c
     info = dev.persist_info()
     print(f"\nnano true shape, resident session, positions 0 .. 1039 teacher-forced: max|gpu-oracle| = {worst:.2e} (position "
           f"{worst_pos}) over {len(check)} positions; {info}")
-    assert worst <= LOGIT_TOL and dev.last_error() == ""
+    assert worst <= LOGIT_TOL and _no_warning(dev)
     assert info["tokens"] == 1024 and info["launches"] <= 4, info      # (one resident launch unless the host paused past the idle limit)
     # (b) chained from position 900 over the limit
     ref = orc.OracleModel(g)
@@ -396,7 +431,7 @@ def test_nano_true_shape_resident_session_and_chained_decode_across_every_pass_c
     assert f0 == first
     base = dev.persist_info()["tokens"]
     got = dev.decode_greedy(f0, 901, 150)
-    assert dev.last_error() == ""
+    assert _no_warning(dev)
     assert dev.persist_info()["tokens"] - base == 1024 - 901, dev.persist_info()      # positions 901 .. 1023 in the persistent launch
     if got != ids:
         k = next(i for i in range(150) if got[i] != ids[i])
@@ -410,6 +445,7 @@ def test_nano_true_shape_resident_session_and_chained_decode_across_every_pass_c
     dev.close(); plain.close()
 
 
+@_retry_placement
 def test_two_handles_on_one_device_do_not_wait_out_each_others_sessions(hip, orc, tmp_path):
     # a resident launch fills every compute unit; a second handle on the device (two models in one server) posts a quit into the
     # first one's mailbox before it queues work instead of waiting for the 2 ms idle limit: alternating calls stay correct and
@@ -433,11 +469,12 @@ def test_two_handles_on_one_device_do_not_wait_out_each_others_sessions(hip, orc
     dt = (time.perf_counter() - t0) / 46
     print(f"\ntwo handles alternating on one device: {dt * 1e3:.3f} ms per call")
     assert dt < 1.2e-3, dt          # (an idle-out per call would be >= 2 ms)
-    assert a.last_error() == "" and b.last_error() == ""
+    assert _no_warning(a) and _no_warning(b)
     a.close(); b.close()
 
 
 @pytest.mark.parametrize("wtype", ["q4_0", "q5_0"])
+@_retry_placement
 def test_persistent_decode_takes_q4_0_and_q5_0_files(hip, orc, tmp_path, monkeypatch, wtype):
     # a Q4_0 block is 32 values (nibble - 8) x d, a Q5_0 block (5-bit value - 16) x d (go/quant.go:45-94, :405-420): int8-valued
     # quants with an fp16 scale, i.e. exactly what the register images hold -- the packer expands them, the kernel is the Q8_0 one;
@@ -454,7 +491,7 @@ def test_persistent_decode_takes_q4_0_and_q5_0_files(hip, orc, tmp_path, monkeyp
     dev.prefill(prompt)
     assert int(np.argmax(dev.state.logits)) == first
     got = dev.decode_greedy(first, len(prompt), 140)
-    assert dev.last_error() == "" and dev.persist_info()["tokens"] == 140
+    assert _no_warning(dev) and dev.persist_info()["tokens"] == 140
     assert got == want, (got[:10], want[:10])
     d = _rel(dev.debug_read("logits", shape.vocab), want_logits[-1])
     # per-call Forward on the resident session: teacher-forced with the oracle's ids
@@ -476,6 +513,7 @@ def test_persistent_decode_takes_q4_0_and_q5_0_files(hip, orc, tmp_path, monkeyp
 
 
 @pytest.mark.parametrize("which", ["small_kv2", "nano_kv3"])
+@_retry_placement
 def test_persistent_decode_with_grouped_query_heads(hip, orc, tmp_path, monkeypatch, which):
     # GQA (go/model.go:557-587: query head h attends over kv head h / (H / KV)): [Q; K; V] has D + 2 KV 64 rows, every head
     # unit gathers its group's k | v rows, the group's first head stores them.  The small shape with 2 kv heads and nano's
@@ -493,7 +531,7 @@ def test_persistent_decode_with_grouped_query_heads(hip, orc, tmp_path, monkeypa
     dev.prefill(prompt)
     assert int(np.argmax(dev.state.logits)) == first
     got = dev.decode_greedy(first, len(prompt), 150)
-    assert dev.last_error() == "" and dev.persist_info()["tokens"] == 150
+    assert _no_warning(dev) and dev.persist_info()["tokens"] == 150
     assert got == want, (got[:10], want[:10])
     d = _rel(dev.debug_read("logits", shape.vocab), want_logits[-1])
     dev.reset()
@@ -519,6 +557,7 @@ def test_persistent_decode_with_grouped_query_heads(hip, orc, tmp_path, monkeypa
     dev.close(); plain.close()
 
 
+@_retry_placement
 def test_shapes_outside_the_instantiations_keep_the_launch_plans(hip, tmp_path):
     # kv-head counts without an instantiation, other widths, weight types that are not 32 int8-valued quants x an fp16 scale: not
     # candidates (the launch plans serve them)
@@ -531,4 +570,33 @@ def test_shapes_outside_the_instantiations_keep_the_launch_plans(hip, tmp_path):
         dev = hip.load_llama_model(gguf.load_gguf(str(p)))
         assert not dev.persist_info()["ready"], shape.name
         assert len(dev.decode_greedy(3, 0, 8)) == 8
+        dev.close()
+
+
+def test_a_census_miss_is_forgiven_twice(hip, orc, tmp_path, monkeypatch):
+    # where a launch landed is not how it exchanged: a launch whose census was not 8 x 32 has its chunk redone on the launch plans
+    # (the oracle's ids either way) and the handle tries the persistent launch again; the third miss retires the path.  The misses
+    # are simulated on the host side (NL_PERSIST_FAKE_CENSUS_MISS): the launches themselves place well
+    shape = synth.ModelShape("pd_census", 13, 256, 4, 4, 1024, seq_len=96, interm=512)
+    p = tmp_path / "m.gguf"
+    synth.generate_gguf(str(p), shape, "q8_0", 163)
+    g = gguf.load_gguf(str(p))
+    prompt = synth.prompt_ids(6, shape.vocab, seed=15)
+    first, want, _ = _oracle_run(orc, g, prompt, 50)
+    monkeypatch.setenv("NL_QUIET", "1")
+    for misses, ready_after in ((2, True), (3, False)):
+        monkeypatch.setenv("NL_PERSIST_FAKE_CENSUS_MISS", str(misses))
+        dev = hip.load_llama_model(g)
+        dev.prefill(prompt)
+        got, tok = [], first
+        for k in range(5):
+            ids = dev.decode_greedy(tok, len(prompt) + 10 * k, 10)
+            got += ids
+            tok = ids[-1]
+            note = dev.last_error()
+            if k < misses:
+                assert "not placed 32 per XCD" in note and ("tries the persistent launch again" in note) == (k < 2), (misses, k, note)
+        assert got == want[:50], misses
+        info = dev.persist_info()
+        assert info["ready"] == ready_after and info["launches"] == (5 if ready_after else 3), (misses, info)
         dev.close()
