@@ -55,10 +55,24 @@ template <int T, int NWV, int NS, bool SSQ> struct DgLds {
 __device__ long long g_dg_stamps[64];
 __device__ long long g_dg_census[2 * 2048];      // wall clock (100 MHz) at entry / exit of wavefront 0 of every workgroup
 #define DG_LIN (blockIdx.y * gridDim.x + blockIdx.x)
-#define DG_STAMP(i) do { if (DG_LIN == 9 && threadIdx.x == 0 && (i) < 64) g_dg_stamps[(i)] = clock64(); \
-    if (((i) == 0 || (i) == 40) && threadIdx.x == 0 && DG_LIN < 2048) g_dg_census[2 * DG_LIN + ((i) ? 1 : 0)] = wall_clock64(); } while (0)
+// (inside the engine -- tools/dg_stamps.sh builds a copy of the library with -DDG_STAMPS -DDG_STAMP_EPI=<epilogue> -- only the launches
+//  of that epilogue stamp, so that the numbers read back after a step are the last layer's launch of that kind)
+#ifndef DG_STAMP_EPI
+#define DG_STAMP_EPI -1
+#endif
+#define DG_STAMP(i) do { if (DG_STAMP_EPI < 0 || DG_STAMP_EPI == DG_THIS_EPI) { \
+    if (DG_LIN == 9 && threadIdx.x == 0 && (i) < 64) g_dg_stamps[(i)] = clock64(); \
+    if (((i) == 0 || (i) == 40) && threadIdx.x == 0 && DG_LIN < 2048) g_dg_census[2 * DG_LIN + ((i) ? 1 : 0)] = wall_clock64(); } } while (0)
+// ... and a log of every launch: entry and exit (wall clock, 10 ns) of workgroup 0's first wavefront, in launch order
+__device__ long long g_dg_log[2 * 4096];
+__device__ unsigned g_dg_log_n;
+#define DG_LOG_ENTRY() [[maybe_unused]] unsigned dg_log_i_ = 0xffffffffu; \
+    do { if (DG_LIN == 0 && threadIdx.x == 0) { dg_log_i_ = atomicAdd(&g_dg_log_n, 1u) & 4095u; g_dg_log[2 * dg_log_i_] = wall_clock64(); } } while (0)
+#define DG_LOG_EXIT() do { if (dg_log_i_ != 0xffffffffu) g_dg_log[2 * dg_log_i_ + 1] = wall_clock64(); } while (0)
 #else
 #define DG_STAMP(i) do { } while (0)
+#define DG_LOG_ENTRY() do { } while (0)
+#define DG_LOG_EXIT() do { } while (0)
 #endif
 
 // cache policy of the LDS-DMA pieces (CPol bits of global_load_lds: 1 = sc0, 2 = nt, 16 = sc1).  The vector L1's fill path gives
@@ -85,14 +99,16 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
     constexpr int REG_U4 = L::REG_U4, SSQ_U4 = L::SSQ_U4, WAVE_U4 = L::WAVE_U4;
     constexpr int NP = L::NP, PPS = 2 + 2 * NP;                  // memory operations per step: 2 fragment loads, NP nibble pieces (16 B per lane), NP scale pieces (4 B per lane)
     constexpr bool FUSED = EPI == QG_EPI_SWIGLU;
-    constexpr int EG = EPI == QG_EPI_ROPE ? 1 : FUSED ? 4 : 2;   // tiles per epilogue group (one wavefront each)
+    constexpr int EG = EPI == QG_EPI_ROPE ? 1 : 2;               // tiles per epilogue group (one wavefront each; FUSED: a gate tile and its up tile)
     constexpr int NEG = T / EG;
     constexpr int TPG = FUSED ? T / 2 : T;                       // distinct row tiles of the workgroup per matrix
     static_assert(NWV == 8 || NWV == 16, "a wavefront owns block w % 8 of the groups it visits");
     static_assert((NS - 1) * PPS <= 63, "vmcnt is six bits");
     static_assert(T % EG == 0 && NEG <= NWV, "epilogue groups");
     __shared__ __attribute__((aligned(16))) uint4 lds_all[L::TOTAL_U4];
+    [[maybe_unused]] constexpr int DG_THIS_EPI = EPI + (EPI == QG_EPI_PLAIN && NWV == 16 ? 10 : 0);      // (stamps: 0 WO, 10 down, 1 gate || up, 2 Q|K|V)
     DG_STAMP(0);
+    DG_LOG_ENTRY();
     // every kernel argument the launch reads, requested as ONE batch of s_load (hipcc otherwise fetches each field before its first
     // use with a wait behind it: the prologue was fourteen dependent scalar round trips, 2 of the launch's 4.5 us)
     NL_KARGS8(P.q, P.s, P.xf, P.q1, P.s1, P.out, P.resid, P.bias);
@@ -163,7 +179,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
     //      behind the K loop; the RoPE position of the lane's token comes through the scalar cache (lgkmcnt) ----
     const int n = tt * 16 + li, nn = min(n, P.n_tokens - 1);   // epilogue: this lane's token; its rows are 4 * lq .. + 3 of every tile
     const bool live = n < P.n_tokens;
-    const int etile0 = tile_base + (wv < NEG ? (FUSED ? wv * 2 : wv * EG) : 0);  // first row tile of this wavefront's epilogue group (wv < NEG)
+    const int etile0 = tile_base + (wv < NEG ? (FUSED ? wv : wv * EG) : 0);      // first row tile of this wavefront's epilogue group (wv < NEG; FUSED: the h tile)
     [[maybe_unused]] float nsc = 1.0f, psc = 1.0f;
     [[maybe_unused]] long long kvoff = 0;       // ROPE: stream * kv_stream_stride + pos * hd of the lane's token
     [[maybe_unused]] float4 rv[EG], bv[EG], gw[EG], rc4, rs4;
@@ -255,12 +271,14 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
     }
     __syncthreads();
     DG_STAMP(40);
+    DG_LOG_EXIT();
     if (wv >= NEG) return;
     f32x4_t e[EG];
 #pragma unroll
     for (int g = 0; g < EG; g++) {
-        // epilogue group wv: PLAIN / ROPE tiles wv * EG + g; FUSED: gate tiles 2 wv, 2 wv + 1, then the same tiles of up
-        const int ti = FUSED ? (g >> 1) * (T / 2) + wv * 2 + (g & 1) : wv * EG + g;
+        // epilogue group wv: PLAIN / ROPE tiles wv * EG + g; FUSED: gate tile wv, then up tile wv (four wavefronts share the
+        // SiLUs of a workgroup -- float64 exponentials: two wavefronts with eight each were 3.5 us behind the last product)
+        const int ti = FUSED ? g * (T / 2) + wv : wv * EG + g;
         e[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
         for (int w = 0; w < NWV; w++)      // (four reads in flight: fully unrolled, hipcc hoists all NWV x EG reads -- 256 registers)
@@ -289,22 +307,17 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
         for (int g = 0; g < EG; g++) e[g] = e[g] * inv;
     }
     if constexpr (EPI == QG_EPI_SWIGLU) {
-        // h = SiLU(gate) * up (go/quant.go:629-631, go/model.go:604-606): rows 4*lq..+3 of both 16-row tiles of one token are
-        // the two float4 groups of k-slot group lq of the group's 32-row block of h (Q4_0 consumer: slot_offsets)
-        const int hblk = etile0 >> 1;
-        if (hblk * 32 >= P.rows || !live) return;
-        float hv[2][4];
+        // h = SiLU(gate) * up (go/quant.go:629-631, go/model.go:604-606): rows 4*lq..+3 of this wavefront's 16-row tile of one token are
+        // one float4 group of k-slot group lq of the tile's 32-row block of h -- half a fragment entry (store_frag_half)
+        if (etile0 * TR >= P.rows || !live) return;
+        float hv[4];
 #pragma unroll
-        for (int r = 0; r < 2; r++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float gv = e[r][j], uv = e[r + 2][j];
-                const float ex = exp_f64_as_f32(-gv);
-                hv[r][j] = (gv / (1.0f + ex)) * uv;
-            }
-        float v[8];
-        slots_from(1, make_float4(hv[0][0], hv[0][1], hv[0][2], hv[0][3]), make_float4(hv[1][0], hv[1][1], hv[1][2], hv[1][3]), v);
-        store_frag(P.xf_out, P.nt16, n, hblk, lq, v);
+        for (int j = 0; j < 4; j++) {
+            const float gv = e[0][j], uv = e[1][j];
+            const float ex = exp_f64_as_f32(-gv);
+            hv[j] = (gv / (1.0f + ex)) * uv;
+        }
+        store_frag_half(P.xf_out, P.nt16, n, etile0 >> 1, lq, etile0 & 1, make_float4(hv[0], hv[1], hv[2], hv[3]));
         return;
     }
     if constexpr (EPI == QG_EPI_ROPE) {
@@ -500,7 +513,9 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dghead_kernel(QGemmParams P
     const int li = lane & 15, lq = lane >> 4;
     // block -> (first row group, token tile) as dgemm_kernel: the token tiles of a row group on one XCD
     const int rg0 = ((int)blockIdx.x & 7) + 8 * (int)blockIdx.y, tt = (int)blockIdx.x >> 3, stride = 8 * (int)gridDim.y;
+    [[maybe_unused]] constexpr int DG_THIS_EPI = 3;      // (stamps: the LM head)
     DG_STAMP(0);
+    DG_LOG_ENTRY();
     const int nrg = (P.ntiles + T - 1) / T;
     if (rg0 >= nrg) return;
     const int niter = (nrg - rg0 + stride - 1) / stride;
@@ -662,6 +677,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dghead_kernel(QGemmParams P
         if (has_next) dg_lds_barrier();      // (the row group after next lands in this buffer: requested behind this barrier)
     }
     DG_STAMP(40);
+    DG_LOG_EXIT();
 }
 inline bool dg_head_ok(int rows, int cols) {
     if (cols <= 0 || cols % 256 || rows % 16) return false;

@@ -2358,6 +2358,17 @@ __attribute__((visibility("default"))) int nl_debug_att_census(long long *out) {
 }
 #endif
 
+#ifdef DG_STAMPS
+__attribute__((visibility("default"))) int nl_debug_dg_stamps(long long *stamps64, long long *census4096) {
+    if (hipMemcpyFromSymbol(stamps64, HIP_SYMBOL(nl::g_dg_stamps), 64 * sizeof(long long)) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(census4096, HIP_SYMBOL(nl::g_dg_census), 2 * 2048 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+__attribute__((visibility("default"))) int nl_debug_dg_log(long long *log8192, unsigned *n) {
+    if (hipMemcpyFromSymbol(n, HIP_SYMBOL(nl::g_dg_log_n), sizeof(unsigned)) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(log8192, HIP_SYMBOL(nl::g_dg_log), 2 * 4096 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int nl_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

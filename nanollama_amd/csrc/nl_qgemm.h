@@ -272,6 +272,24 @@ __device__ __forceinline__ void store_frag(uint4 *xf, int nt16, int n, int blk, 
     xf[(bt * 2 + 1) * QG_FRAG + fl] = __builtin_bit_cast(uint4, lo);
 }
 
+// ... one 16-row half of it: the four k-slots j = 4 half .. 4 half + 3 of group w are 8 bytes of the hi and 8 bytes of the lo entry
+// (Q4_0 slot order: rows 4w, 4w + 2, 4w + 1, 4w + 3 of the half -- slots_from)
+__device__ __forceinline__ void store_frag_half(uint4 *xf, int nt16, int n, int blk, int w, int half, const float4 &r) {
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+    const float v[4] = {r.x, r.z, r.y, r.w};
+    half4_t hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        _Float16 h, l;
+        split_hi_lo(v[j], h, l);
+        hi[j] = h; lo[j] = l;
+    }
+    const long long bt = (long long)blk * nt16 + (n >> 4);
+    const int fl = w * 16 + (n & 15);
+    reinterpret_cast<uint2 *>(xf + (bt * 2 + 0) * QG_FRAG + fl)[half] = __builtin_bit_cast(uint2, hi);
+    reinterpret_cast<uint2 *>(xf + (bt * 2 + 1) * QG_FRAG + fl)[half] = __builtin_bit_cast(uint2, lo);
+}
+
 // Workgroup = QG_WAVES wavefronts x QG_RT row tiles (8 x 1: 128 weight rows) x 64 tokens; K walked in 128-column
 // chunks.  Eight light wavefronts (one row tile, ~100 VGPRs) at four per SIMD measured 5-15 % faster than four
 // heavy ones at two per SIMD for 64-512 tokens and equal at 2047 (tools/qgemm_variants.sh).
