@@ -86,6 +86,17 @@ __device__ unsigned g_dg_log_n;
 #define DG_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0f70 | ((n) & 15) | (((n) >> 4) << 14))
 
 typedef unsigned dg_u32x4 __attribute__((ext_vector_type(4)));
+// 1 / sqrt(ss / dim + eps) as float32 (go/quant.go:597-607 computes it in float64): v_rsq_f64 + two Newton steps -- relative error
+// < 1e-30 before the rounding to float32, the same float32 as the IEEE divide and square root give except at rounding boundaries of
+// measure zero -- instead of sixty dependent float64 instructions behind the last product of the launch (nl_persist.h pd_inv_rms)
+__device__ __forceinline__ float dg_inv_rms(double ss, int dim, float eps) {
+    const double rdim = 1.0 / (double)dim;                 // (independent of ss: off the critical path)
+    const double m = fma(ss, rdim, (double)eps);
+    double y = __builtin_amdgcn_rsq(m);
+    y = y * fma(-0.5 * m * y, y, 1.5);
+    y = y * fma(-0.5 * m * y, y, 1.5);
+    return (float)y;
+}
 template <int I, int N, class F>
 __device__ __forceinline__ void dg_static_for(F &&f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); dg_static_for<I + 1, N>(f); }
@@ -292,12 +303,18 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
             asm volatile("" : "+v"(nsc));          // (first use HERE, behind the loop)
             const double *const sq = reinterpret_cast<const double *>(lds_all) + li * P.nrm_in.nrb;
             double tot = 0.0;
-            for (int r = lq; r < P.nrm_in.nrb; r += 4) tot += sq[r];
+            for (int r0 = lq; r0 < P.nrm_in.nrb; r0 += 16) {      // (four reads in flight; added in ascending order)
+                double v4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v4[u] = sq[min(r0 + 4 * u, P.nrm_in.nrb - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) tot += r0 + 4 * u < P.nrm_in.nrb ? v4[u] : 0.0;
+            }
             const double t1 = __shfl_xor(tot, 16);
             const double lo2 = (lq & 1) ? t1 + tot : tot + t1;          // (lq 0 + lq 1) resp. (lq 2 + lq 3), same order in both lanes
             const double t2 = __shfl_xor(lo2, 32);
             tot = (lq & 2) ? t2 + lo2 : lo2 + t2;
-            inv = (float)(1.0 / sqrt(tot / (double)P.nrm_in.dim + (double)P.nrm_in.eps));
+            inv = dg_inv_rms(tot, P.nrm_in.dim, P.nrm_in.eps);
             if (P.nrm_in.scale) {     // the producer's power-of-two pre-scale (norm_prescale, nl_qgemm.h): undone exactly
                 if (rg == 0 && wv == 0 && lq == 0 && live) P.nrm_in.scale_next[n] = norm_prescale(inv);
                 inv *= 1.0f / nsc;
@@ -636,7 +653,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dghead_kernel(QGemmParams P
             const double lo2 = (lq & 1) ? t1 + tot : tot + t1;
             const double t2 = __shfl_xor(lo2, 32);
             tot = (lq & 2) ? t2 + lo2 : lo2 + t2;
-            inv = (float)(1.0 / sqrt(tot / (double)P.nrm_in.dim + (double)P.nrm_in.eps));
+            inv = dg_inv_rms(tot, P.nrm_in.dim, P.nrm_in.eps);
             if (P.nrm_in.scale) {
                 float nsc;
                 asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nsc) : "v"(dg_lds_addr(lds_all + DG_SSQ_BYTES / 16) + (unsigned)li * 4u) : "memory");
