@@ -64,15 +64,17 @@ __device__ long long g_dg_census[2 * 2048];      // wall clock (100 MHz) at entr
     if (DG_LIN == 9 && threadIdx.x == 0 && (i) < 64) g_dg_stamps[(i)] = clock64(); \
     if (((i) == 0 || (i) == 40) && threadIdx.x == 0 && DG_LIN < 2048) g_dg_census[2 * DG_LIN + ((i) ? 1 : 0)] = wall_clock64(); } } while (0)
 // ... and a log of every launch: entry and exit (wall clock, 10 ns) of workgroup 0's first wavefront, in launch order
-__device__ long long g_dg_log[2 * 4096];
+__device__ long long g_dg_log[4 * 4096];          // [launch][entry, barrier, end of wavefront 0's epilogue, -]
 __device__ unsigned g_dg_log_n;
 #define DG_LOG_ENTRY() [[maybe_unused]] unsigned dg_log_i_ = 0xffffffffu; \
-    do { if (DG_LIN == 0 && threadIdx.x == 0) { dg_log_i_ = atomicAdd(&g_dg_log_n, 1u) & 4095u; g_dg_log[2 * dg_log_i_] = wall_clock64(); } } while (0)
-#define DG_LOG_EXIT() do { if (dg_log_i_ != 0xffffffffu) g_dg_log[2 * dg_log_i_ + 1] = wall_clock64(); } while (0)
+    do { if (DG_LIN == 0 && threadIdx.x == 0) { dg_log_i_ = atomicAdd(&g_dg_log_n, 1u) & 4095u; g_dg_log[4 * dg_log_i_] = wall_clock64(); } } while (0)
+#define DG_LOG_EXIT() do { if (dg_log_i_ != 0xffffffffu) g_dg_log[4 * dg_log_i_ + 1] = wall_clock64(); } while (0)
+#define DG_LOG_END() do { if (dg_log_i_ != 0xffffffffu) g_dg_log[4 * dg_log_i_ + 2] = wall_clock64(); } while (0)
 #else
 #define DG_STAMP(i) do { } while (0)
 #define DG_LOG_ENTRY() do { } while (0)
 #define DG_LOG_EXIT() do { } while (0)
+#define DG_LOG_END() do { } while (0)
 #endif
 
 // cache policy of the LDS-DMA pieces (CPol bits of global_load_lds: 1 = sc0, 2 = nt, 16 = sc1).  The vector L1's fill path gives
@@ -335,6 +337,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
             hv[j] = (gv / (1.0f + ex)) * uv;
         }
         store_frag_half(P.xf_out, P.nt16, n, etile0 >> 1, lq, etile0 & 1, make_float4(hv[0], hv[1], hv[2], hv[3]));
+        DG_LOG_END();
         return;
     }
     if constexpr (EPI == QG_EPI_ROPE) {
@@ -371,6 +374,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
         float *dstp = is_q ? R.q + ((long long)n * nq + head * hd + e0)
                            : (is_k ? R.kcache : R.vcache) + (kvoff + (long long)kvh * R.seq_len * hd + e0);
         *reinterpret_cast<float4 *>(dstp) = make_float4(o[0], o[1], o[2], o[3]);
+        DG_LOG_END();
         return;
     }
     if constexpr (EPI == QG_EPI_PLAIN) {
@@ -410,6 +414,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV / 4) dgemm_kernel(QGemmParams P)
             slots_from(1, make_float4(y[0][0], y[0][1], y[0][2], y[0][3]), make_float4(y[1][0], y[1][1], y[1][2], y[1][3]), v);
             if (live) store_frag(P.nrm_out.xf, P.nt16, n, etile0 >> 1, lq, v);
         }
+        DG_LOG_END();
     }
 }
 

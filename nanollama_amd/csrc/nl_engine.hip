@@ -2363,9 +2363,9 @@ __attribute__((visibility("default"))) int nl_debug_dg_stamps(long long *stamps6
     if (hipMemcpyFromSymbol(stamps64, HIP_SYMBOL(nl::g_dg_stamps), 64 * sizeof(long long)) != hipSuccess) return -1;
     return hipMemcpyFromSymbol(census4096, HIP_SYMBOL(nl::g_dg_census), 2 * 2048 * sizeof(long long)) == hipSuccess ? 0 : -1;
 }
-__attribute__((visibility("default"))) int nl_debug_dg_log(long long *log8192, unsigned *n) {
+__attribute__((visibility("default"))) int nl_debug_dg_log(long long *log16384, unsigned *n) {
     if (hipMemcpyFromSymbol(n, HIP_SYMBOL(nl::g_dg_log_n), sizeof(unsigned)) != hipSuccess) return -1;
-    return hipMemcpyFromSymbol(log8192, HIP_SYMBOL(nl::g_dg_log), 2 * 4096 * sizeof(long long)) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(log16384, HIP_SYMBOL(nl::g_dg_log), 4 * 4096 * sizeof(long long)) == hipSuccess ? 0 : -1;
 }
 #endif
 

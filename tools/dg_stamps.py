@@ -31,18 +31,20 @@ for k in range(12):
     print(f"   census: {int(recent.sum())} workgroups; entries spread {(ent.max() - ent.min()) / 100:.2f} us; exits first +{(ext.min() - ent.min()) / 100:.2f} / last +{(ext.max() - ent.min()) / 100:.2f} us; "
           f"time in kernel per workgroup: median {np.median(ext - ent) / 100:.2f} us")
 # the launch log of the last step: entry / exit of workgroup 0 of every dgemm / dghead launch, in launch order
-lg, n = (C.c_longlong * 8192)(), C.c_uint(0)
+lg, n = (C.c_longlong * 16384)(), C.c_uint(0)
 L.nl_debug_dg_log.argtypes = [C.POINTER(C.c_longlong), C.POINTER(C.c_uint)]
 if L.nl_debug_dg_log(lg, C.byref(n)) == 0:
-    a = np.array(lg[:], dtype=np.int64).reshape(4096, 2)
+    a = np.array(lg[:], dtype=np.int64).reshape(4096, 4)
     per = 4 * 28 + 1                                     # launches with a log entry per step
     last = [(n.value - 1 - i) & 4095 for i in range(per)][::-1]
-    ent, ext = a[last, 0], a[last, 1]
+    ent, ext, end = a[last, 0], a[last, 1], a[last, 2]
     names = ["Q|K|V", "WO", "gate|up", "down"]
     print("last step, workgroup 0 of each launch (us): in-kernel, then the gap to the next launch's entry")
     for k in range(4):
         ins = (ext[k:per - 1:4] - ent[k:per - 1:4]) / 100.0
         gap = (ent[k + 1:per:4] - ext[k:per - 1:4]) / 100.0
-        print(f"   {names[k]:8s} in-kernel median {np.median(ins):.2f} (min {ins.min():.2f} max {ins.max():.2f});  exit -> next entry median {np.median(gap):.2f} (min {gap.min():.2f} max {gap.max():.2f})")
+        epi = (end[k:per - 1:4] - ext[k:per - 1:4]) / 100.0
+        print(f"   {names[k]:8s} entry -> barrier median {np.median(ins):.2f} (min {ins.min():.2f} max {ins.max():.2f});  wavefront 0's epilogue {np.median(epi):.2f};  "
+              f"barrier -> next launch's entry median {np.median(gap):.2f} (min {gap.min():.2f} max {gap.max():.2f})")
     print(f"   LM head  in-kernel {(ext[-1] - ent[-1]) / 100.0:.2f};  first Q|K|V entry -> head exit {(ext[-1] - ent[0]) / 100.0:.1f} us")
 dev.close()
